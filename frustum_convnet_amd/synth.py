@@ -1,0 +1,167 @@
+"""Deterministic synthetic frustum batches and counter-hash weights.
+
+Everything here is a pure function of integer seeds: a splitmix64 counter hash
+turned into uniforms with exact float64 arithmetic (no libm calls), so the GPU
+box, the CPU oracle and the fixture generator all see bit-identical inputs
+without depending on torch's RNG.
+
+Shapes follow the reference's data provider (datasets/provider_sample.py:248-262
+for the dict keys, :291-299 for the sliding-frustum centres).
+"""
+import zlib
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+CAR_MEAN_SIZE = (3.88311640418, 1.62856739989, 1.52563191462)
+
+
+def _splitmix(x):
+    x = x.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x ^= x >> np.uint64(30)
+        x = x * np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27)
+        x = x * np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    return x
+
+
+def stream_id(name):
+    """Stable 32-bit id of a tensor / stream name."""
+    return zlib.crc32(name.encode("utf-8")) & 0xFFFFFFFF
+
+
+def uniform01(seed, stream, shape, lane=0):
+    """float64 uniforms in [0,1) of `shape`; element i of stream (seed, stream, lane)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    ctr = np.arange(n, dtype=np.uint64)
+    key = _splitmix(np.array([(int(seed) << 32) ^ int(stream)], dtype=np.uint64))
+    key = _splitmix(key ^ np.uint64(int(lane) * 0x51ED27 + 1))
+    with np.errstate(over="ignore"):
+        h = _splitmix(ctr * np.uint64(0xD1342543DE82EF95) + key)
+    u = (h >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    return u.reshape(shape)
+
+
+def normalish(seed, stream, shape):
+    """Zero-mean unit-variance samples (Irwin-Hall of 12 uniforms): exact arithmetic only."""
+    acc = np.zeros(shape, dtype=np.float64)
+    for lane in range(12):
+        acc += uniform01(seed, stream, shape, lane=lane + 1)
+    return acc - 6.0
+
+
+def frustum_centres(stride, max_depth=70.0):
+    """z of the sliding-frustum centres for one scale (provider_sample.py:293-299)."""
+    return np.arange(0, max_depth, stride) + stride / 2.0
+
+
+def make_batch(batch, npoint, strides=(0.25, 0.5, 1.0, 2.0), max_depth=70.0, seed=1234,
+               variant="car", tilt=(0.0, 0.0), with_labels=True, z_range=None):
+    """Synthetic KITTI-car-shaped batch as a dict of numpy arrays (reference dict keys).
+
+    variant: "car"     60 % foreground z ~ N(z_obj, 0.8^2), 40 % background U(0, max_depth)
+             "uniform" z ~ U(0, max_depth)
+    tilt:    (kx, ky) centre x,y = k * z (the reference projects the 2-D box centre along depth)
+    z_range: optional (lo, hi) to confine everything (refine-stage style short frustums)
+    """
+    B, N = batch, npoint
+    lo, hi = (0.0, float(max_depth)) if z_range is None else z_range
+    u = lambda name, shape, lane=0: uniform01(seed, stream_id(name), shape, lane)
+    z_obj = lo + (hi - lo) * (5.0 / 70.0 + u("z_obj", (B,)) * (55.0 / 70.0))
+    z_bg = lo + (hi - lo) * u("z_bg", (B, N))
+    if variant == "car":
+        is_fg = u("fg_mask", (B, N)) < 0.6
+        z_fg = z_obj[:, None] + 0.8 * normalish(seed, stream_id("z_fg"), (B, N))
+        z = np.where(is_fg, z_fg, z_bg)
+    elif variant == "uniform":
+        z = z_bg
+    else:
+        raise ValueError(variant)
+    eps = 0.05 * (hi - lo) / 70.0
+    z = np.clip(z, lo + eps, hi - eps)
+    x = (u("x", (B, N)) * 4.0 - 2.0) * (np.abs(z) / 20.0 + 0.2)
+    y = u("y", (B, N)) * 2.5 - 1.5
+    pc = np.stack([x, y, z], axis=1).astype(np.float32)  # (B,3,N)
+
+    out = {"point_cloud": pc}
+    one_hot = np.zeros((B, 3), dtype=np.float32)
+    one_hot[:, 0] = 1.0
+    out["one_hot"] = one_hot
+    for s, stride in enumerate(strides):
+        if z_range is None:
+            zc = frustum_centres(stride, max_depth)
+        else:
+            zc = np.arange(lo, hi, stride) + stride / 2.0
+        ref = np.zeros((B, 3, len(zc)), dtype=np.float64)
+        ref[:, 0, :] = tilt[0] * zc
+        ref[:, 1, :] = tilt[1] * zc
+        ref[:, 2, :] = zc
+        out["center_ref%d" % (s + 1)] = ref.astype(np.float32)
+    if with_labels:
+        zc2 = out["center_ref2"][0, 2].astype(np.float64)
+        L2 = len(zc2)
+        nearest = np.argmin(np.abs(zc2[None, :] - z_obj[:, None]), axis=1)
+        cls = np.zeros((B, L2), dtype=np.int64)
+        for b in range(B):
+            c = int(nearest[b])
+            if c - 1 >= 0:
+                cls[b, c - 1] = -1
+            if c + 1 < L2:
+                cls[b, c + 1] = -1
+            cls[b, c] = 1
+        out["cls_label"] = cls
+        out["size_class"] = np.zeros((B, 1), dtype=np.int64)
+        ctr = np.zeros((B, 3), dtype=np.float64)
+        ctr[:, 0] = tilt[0] * z_obj
+        ctr[:, 1] = tilt[1] * z_obj
+        ctr[:, 2] = z_obj
+        out["box3d_center"] = ctr.astype(np.float32)
+        out["box3d_heading"] = ((u("heading", (B, 1)) * 2.0 - 1.0) * np.pi).astype(np.float32)
+        size = np.array(CAR_MEAN_SIZE)[None, :] * (0.9 + 0.2 * u("size", (B, 3)))
+        out["box3d_size"] = size.astype(np.float32)
+    return out
+
+
+def fill_state_dict(state_dict, seed=7):
+    """Overwrite every entry of a torch state_dict in place from the counter hash.
+
+    conv / head weights: zero-mean, std = sqrt(2 / fan_in) (kaiming fan_in scale,
+    reference models/det_base.py:59,190); BN weight U(0.5,1.5), bias U(-0.2,0.2),
+    running_mean 0, running_var 1, num_batches_tracked 0; head bias U(-0.1,0.1).
+    Keys and shapes come from the module, so the same call fills the reference model
+    and this package's model identically.
+    """
+    import torch
+
+    for name, t in state_dict.items():
+        sid = stream_id(name)
+        shape = tuple(t.shape)
+        if name.endswith("num_batches_tracked"):
+            t.zero_()
+            continue
+        if name.endswith("running_mean"):
+            t.zero_()
+            continue
+        if name.endswith("running_var"):
+            t.fill_(1.0)
+            continue
+        if t.dim() >= 2:  # conv weights (Cout, Cin, k[, 1]) or ConvTranspose1d (Cin, Cout, k)
+            fan_in = int(np.prod(shape[1:]))
+            v = normalish(seed, sid, shape) * np.sqrt(2.0 / fan_in)
+        elif name.endswith(".1.weight"):
+            v = 0.5 + uniform01(seed, sid, shape)
+        elif name.endswith(".1.bias"):
+            v = -0.2 + 0.4 * uniform01(seed, sid, shape)
+        else:  # head biases
+            v = -0.1 + 0.2 * uniform01(seed, sid, shape)
+        t.copy_(torch.from_numpy(np.ascontiguousarray(v)).to(t.dtype))
+    return state_dict
+
+
+def to_torch(batch, device="cpu"):
+    import torch
+
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k, v in batch.items()}
