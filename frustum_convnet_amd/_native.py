@@ -1,0 +1,88 @@
+"""ctypes binding of libfcn_hip.so (see include/fcn_hip.h for the C-ABI).
+
+There is deliberately no fallback: if the shared library is missing, or a call returns non-zero,
+this raises -- a PyTorch/CPU substitute would silently void every parity and performance claim.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfcn_hip.so")
+
+c_fp = ctypes.c_void_p
+
+
+class PnDesc(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("L", ctypes.c_int32), ("K", ctypes.c_int32),
+                ("C1", ctypes.c_int32), ("C2", ctypes.c_int32), ("C3", ctypes.c_int32),
+                ("nvec", ctypes.c_int32), ("training", ctypes.c_int32),
+                ("eps", ctypes.c_float), ("momentum", ctypes.c_float)]
+
+
+class PnParams(ctypes.Structure):
+    _fields_ = [("W", c_fp * 3), ("gamma", c_fp * 3), ("beta", c_fp * 3),
+                ("running_mean", c_fp * 3), ("running_var", c_fp * 3), ("num_batches_tracked", c_fp * 3)]
+
+
+class PnWs(ctypes.Structure):
+    _fields_ = [("woff", c_fp), ("ent", c_fp), ("ewin", c_fp), ("y2", c_fp), ("y3", c_fp), ("amax", c_fp),
+                ("stat", c_fp), ("bn", c_fp), ("gmax", c_fp), ("dy3", c_fp), ("dz2", c_fp), ("bstat", c_fp),
+                ("coef", c_fp), ("partial", c_fp), ("nsplit", ctypes.c_int32)]
+
+
+EXPORTS = ("fcn_arch", "fcn_query_depth_point_f32", "fcn_pn_wgrad_rows", "fcn_pn_compact",
+           "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_conv_fwd")
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads the library once.  Raises ImportError (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "frustum_convnet_amd: %s not found -- build it with `python -m frustum_convnet_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the hot path." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    L.fcn_arch.restype = ctypes.c_int
+    L.fcn_arch.argtypes = []
+    L.fcn_pn_wgrad_rows.restype = ctypes.c_int
+    L.fcn_pn_wgrad_rows.argtypes = []
+    L.fcn_query_depth_point_f32.restype = ctypes.c_int
+    L.fcn_query_depth_point_f32.argtypes = [
+        c_fp, ctypes.c_int64, ctypes.c_int64, c_fp, ctypes.c_int64, ctypes.c_int64,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp]
+    L.fcn_pn_compact.restype = ctypes.c_int
+    L.fcn_pn_compact.argtypes = [ctypes.POINTER(PnDesc), c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(PnWs), c_fp]
+    L.fcn_pn_forward.restype = ctypes.c_int
+    L.fcn_pn_forward.argtypes = [ctypes.POINTER(PnDesc), ctypes.POINTER(PnParams), c_fp, c_fp,
+                                 ctypes.POINTER(PnWs), c_fp, c_fp]
+    L.fcn_pn_backward.restype = ctypes.c_int
+    L.fcn_pn_backward.argtypes = [ctypes.POINTER(PnDesc), ctypes.POINTER(PnParams), c_fp,
+                                  ctypes.POINTER(PnWs), c_fp * 3, c_fp * 3, c_fp * 3, c_fp]
+    L.fcn_pn_conv_fwd.restype = ctypes.c_int
+    L.fcn_pn_conv_fwd.argtypes = [ctypes.POINTER(PnDesc), ctypes.POINTER(PnParams), ctypes.POINTER(PnWs),
+                                  ctypes.c_int, ctypes.c_int, c_fp]
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise NativeError("%s failed with code %d (hipError_t or FCN_E_*; see include/fcn_hip.h)" % (what, rc))
+
+
+def ptr(t):
+    """data pointer of a tensor (or None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream(device=None):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

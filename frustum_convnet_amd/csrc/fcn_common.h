@@ -1,0 +1,53 @@
+// Shared device helpers for libfcn_hip.so (gfx950 only: wave64, 32x32x2 f32 MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fcn_hip.h"
+
+#define FCN_WAVE 64
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define FCN_CHECK_LAUNCH()                         \
+    do {                                           \
+        hipError_t e__ = hipGetLastError();        \
+        if (e__ != hipSuccess) return (int)e__;    \
+    } while (0)
+
+#define FCN_TRY(expr)                              \
+    do {                                           \
+        int rc__ = (int)(expr);                    \
+        if (rc__ != 0) return rc__;                \
+    } while (0)
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void atomic_add_f64(double *p, double v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Layout of fcn_pn_ws.stat (doubles)
+//   [0]      sum w          (= B*L*K)
+//   [1..3]   sum w*u
+//   [4..9]   sum w*u*u^T    (xx,xy,xz,yy,yz,zz)
+//   [16 .. 16+2*C2)            layer-2 sum, sumsq
+//   [16+2*C2 .. 16+2*C2+2*C3)  layer-3 sum, sumsq
+#define FCN_STAT_MOM 0
+#define FCN_STAT_L2 16
+
+// Layout of fcn_pn_ws.bn (floats): layer j block at offset 4*(sum of previous widths):
+//   scale[C], shift[C], mean[C], rstd[C]
+__host__ __device__ inline int fcn_bn_off(int layer, int C1, int C2) {
+    return layer == 0 ? 0 : (layer == 1 ? 4 * C1 : 4 * (C1 + C2));
+}

@@ -1,0 +1,55 @@
+// 32x32x2 f32 MFMA tile machinery shared by the forward / dgrad / wgrad kernels.
+//
+// Workgroup = 256 threads = 4 waves arranged 2 (M) x 2 (N); each wave owns MT x NT MFMA tiles of
+// 32x32, i.e. the workgroup tile is (64*MT) x (64*NT).  Operands are staged k-major in LDS
+// ([k][m] and [k][n], leading dimension padded to an odd number of dwords) so that the MFMA operand
+// reads -- lane l needs A[m0 + (l&31)][k + (l>>5)] and B[k + (l>>5)][n0 + (l&31)] -- are 32 consecutive
+// dwords per half-wave: conflict-free ds_read_b32.  v_mfma_f32_32x32x2_f32 is exact fp32 (bitwise an
+// fmaf chain, cdna guide section 3), which is what keeps the logits within 1e-4 of the fp32 reference.
+#pragma once
+#include "fcn_common.h"
+
+#define GT 256          // threads per workgroup
+#define KC 32           // reduction chunk staged per iteration
+
+template <int MT, int NT>
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[MT][NT]) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
+
+// One KC-deep chunk: As is [KC][LDA] (m fastest), Bs is [KC][LDB] (n fastest).
+template <int MT, int NT, int LDA, int LDB>
+__device__ __forceinline__ void mma_chunk(const float *As, const float *Bs, int arow0, int bcol0,
+                                          f32x16 (&acc)[MT][NT]) {
+    const int lane = threadIdx.x & 63;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const float *ap = As + lh * LDA + arow0 + l31;
+    const float *bp = Bs + lh * LDB + bcol0 + l31;
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 2) {
+        float a[MT], b[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[i] = ap[kk * LDA + i * 32];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[j] = bp[kk * LDB + j * 32];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+// Row (M index inside the 32x32 tile) held by accumulator register `reg` of this lane.
+__device__ __forceinline__ int acc_row(int reg, int lh) { return (reg & 3) + 8 * (reg >> 2) + 4 * lh; }
+
+// conv1 + BN1 + ReLU of one entry, folded: alpha = scale * W1 row, t = shift.  The SAME expression is
+// used by the forward, the dgrad ReLU mask and the wgrad operand so the three agree bit-for-bit.
+__device__ __forceinline__ float l1_pre(const float *al3, float t, float ux, float uy, float uz) {
+    return fmaf(al3[0], ux, fmaf(al3[1], uy, fmaf(al3[2], uz, t)));
+}

@@ -1,0 +1,582 @@
+// Backward of one PointNet scale in entry space (autograd of models/det_base.py:75-101,134-157).
+//
+// Entry-space BatchNorm backward (derivation + CPU proof: tests/entry_ref.py, tests/test_entry_space_math.py):
+//   dz[e] = G[e] * [z[e] > 0]                      G = gradient summed over the duplicates of entry e
+//   dbeta = sum_e dz,  dgamma = sum_e dz * xhat
+//   dy[e] = gamma*rstd * (dz[e] - w_e*dbeta/M - w_e*xhat[e]*dgamma/M)      (w_e = multiplicity, M = B*L*K)
+//   dW    = sum_e dy[e] (x) a_prev[e],   G_prev[e] = W^T dy[e]
+//
+//   poolbwd        : routes dfeat to the max rows (gmax), dbeta3/dgamma3
+//   dgrad<3>       : builds dy3 while staging (writes it once), G2 = dy3 . W3 on MFMA, ReLU mask from y2,
+//                    writes dz2, dbeta2/dgamma2 in the epilogue
+//   wgrad<3>       : dW3 = dy3^T . relu(bn2(y2)) (split over rows, partials + deterministic reduce)
+//   dgrad<2>       : dy2 built while staging, G1 = dy2 . W2, ReLU mask recomputed from u, epilogue
+//                    accumulates Q = sum dz1 * (1,u) -- enough for dW1/dgamma1/dbeta1 (conv1 is linear in u)
+//   wgrad<2>       : dW2 = dy2^T . relu(bn1(conv1(u)))
+//   l1_finalize    : dW1, dgamma1, dbeta1 from Q and the forward's input moments
+#include "gemm_tile.h"
+
+#define LDT 129                 // transposed (k-major) staging of a 128-row tile
+#define MAXC 512
+#define WG_ROWS 1024            // rows of one wgrad split
+#define PWB 32                  // windows per poolbwd workgroup
+
+extern "C" int fcn_pn_wgrad_rows(void) { return WG_ROWS; }
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GT) void poolbwd_kernel(
+    const float *__restrict__ dfeat, const int32_t *__restrict__ amax, const float *__restrict__ y3,
+    const float *__restrict__ bn3, float *__restrict__ gmax, double *__restrict__ bstat,
+    int L, int cap, int C3, int CT, int cpb)
+{
+    __shared__ float dS[256 * (PWB + 1)];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z, l0 = blockIdx.x * PWB, c0 = blockIdx.y * cpb;
+    for (int f = tid; f < cpb * PWB; f += GT) {
+        const int cc = f / PWB, wl = f % PWB, l = l0 + wl;
+        dS[cc * (PWB + 1) + wl] = (l < L) ? dfeat[((int64_t)b * CT + c0 + cc) * L + l] : 0.f;
+    }
+    __syncthreads();
+    const int cl = tid % cpb, wlane = tid / cpb, nwl = GT / cpb;
+    const int c = c0 + cl;
+    const float mean = bn3[2 * C3 + c], rstd = bn3[3 * C3 + c];
+    float sB = 0.f, sG = 0.f;
+    for (int wl = wlane; wl < PWB; wl += nwl) {
+        const int l = l0 + wl;
+        if (l >= L) break;
+        const int64_t o = ((int64_t)b * L + l) * C3 + c;
+        const int am = amax[o];
+        float g = 0.f;
+        if (am >= 0) {
+            g = dS[cl * (PWB + 1) + wl];
+            const float xh = (y3[((int64_t)b * cap + am) * C3 + c] - mean) * rstd;
+            sB += g;
+            sG = fmaf(g, xh, sG);
+        }
+        gmax[o] = g;
+    }
+    // combine the window lanes of one channel through LDS, then one fp64 atomic pair per channel
+    __syncthreads();
+    float *red = dS;
+    red[tid * 2] = sB;
+    red[tid * 2 + 1] = sG;
+    __syncthreads();
+    if (tid < cpb) {
+        double a = 0.0, g = 0.0;
+        for (int w = 0; w < nwl; ++w) {
+            a += (double)red[(w * cpb + tid) * 2];
+            g += (double)red[(w * cpb + tid) * 2 + 1];
+        }
+        atomic_add_f64(&bstat[c0 + tid], a);
+        atomic_add_f64(&bstat[C3 + c0 + tid], g);
+    }
+}
+
+// coef[0..5) x C : gamma*rstd, mean, rstd, dbeta/M, dgamma/M ; also exports dgamma/dbeta (fp32)
+__global__ void bnbwd_finalize_kernel(const double *__restrict__ bstat, const float *__restrict__ gamma,
+                                      const float *__restrict__ bn, int C, double M,
+                                      float *__restrict__ coef, float *__restrict__ dgamma,
+                                      float *__restrict__ dbeta)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double db = bstat[c], dg = bstat[C + c];
+    const float rstd = bn[3 * C + c];
+    coef[c] = gamma[c] * rstd;
+    coef[C + c] = bn[2 * C + c];
+    coef[2 * C + c] = rstd;
+    coef[3 * C + c] = (float)(db / M);
+    coef[4 * C + c] = (float)(dg / M);
+    dgamma[c] = (float)dg;
+    dbeta[c] = (float)db;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct DgradArgs {
+    const float4 *ent;      // (B,cap)
+    const int32_t *woff;    // (B,L+1)
+    const int32_t *ewin;    // (B,cap)            LAYER 3
+    const float *ycur;      // y3 (LAYER 3) / y2 (LAYER 2): pre-BN output of the layer being differentiated
+    const int32_t *amax;    // (B,L,C3)           LAYER 3
+    const float *gmax;      // (B,L,C3)           LAYER 3
+    const float *dzcur;     // dz2 (B,cap,C2)     LAYER 2
+    const float *coef;      // 5 x CRED
+    const float *W;         // (CRED, CPREV) row-major = the conv weight (Cout,Cin)
+    float *dybuf;           // LAYER 3: dy3 (B,cap,C3) written by the blockIdx.y == 0 column block
+    const float *yprev;     // LAYER 3: y2 (B,cap,C2)
+    const float *bn_prev;   // scale, shift, mean, rstd of the previous layer's BN (width CPREV)
+    const float *W1;        // LAYER 2: (C1,3)
+    float *dzprev;          // LAYER 3: dz2 out (B,cap,C2)
+    double *bstat_prev;     // LAYER 3: dbeta2[C2], dgamma2[C2]; LAYER 2: Q[4][C1]
+    int L, cap, CRED, CPREV, tps;
+};
+
+template <int LAYER, int NT>
+__global__ __launch_bounds__(GT) void dgrad_kernel(DgradArgs a)
+{
+    constexpr int LDB = 64 * NT + 4;
+    __shared__ __attribute__((aligned(16))) float As[KC * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[KC * LDB];
+    __shared__ float coefS[5 * MAXC];
+    __shared__ __attribute__((aligned(16))) float4 uS[128];     // (ux,uy,uz,w) of the tile rows
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int b = blockIdx.x / a.tps, t = blockIdx.x % a.tps;
+    const int nent = a.woff[(int64_t)b * (a.L + 1) + a.L];
+    const int row0 = t * 128;
+    if (row0 >= nent) return;
+    const int nvalid = min(128, nent - row0);
+    const int64_t grow0 = (int64_t)b * a.cap + row0;
+    const int k0 = blockIdx.y * 64 * NT;          // first output column (channel of the previous layer)
+    const int CRED = a.CRED, CPREV = a.CPREV;
+
+    for (int i = tid; i < 5 * CRED; i += GT) coefS[i] = a.coef[i];
+    if (tid < 128) uS[tid] = (tid < nvalid) ? a.ent[grow0 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int kq = tid & 7, rb = tid >> 3;
+    int wrow[4];          // LAYER 3: window base offset into amax/gmax of this thread's 4 rows
+    if constexpr (LAYER == 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = rb + 32 * i;
+            wrow[i] = (r < nvalid) ? a.ewin[grow0 + r] : 0;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[2][NT];
+    acc_zero<2, NT>(acc);
+    float4 ry[4], rz[4];
+    int4 rm[4];
+    float4 rw[2 * NT];
+    const int nchunk = CRED / KC;
+
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = rb + 32 * i;
+            const int nq = c * KC + 4 * kq;
+            if (r < nvalid) {
+                ry[i] = *(const float4 *)(a.ycur + (grow0 + r) * CRED + nq);
+                if constexpr (LAYER == 3) {
+                    const int64_t o = ((int64_t)b * a.L + wrow[i]) * CRED + nq;
+                    rm[i] = *(const int4 *)(a.amax + o);
+                    rz[i] = *(const float4 *)(a.gmax + o);
+                } else {
+                    rz[i] = *(const float4 *)(a.dzcur + (grow0 + r) * CRED + nq);
+                }
+            } else {
+                ry[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                rz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (LAYER == 3) rm[i] = make_int4(-1, -1, -1, -1);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * NT; ++i) {
+            const int f = tid + GT * i;
+            const int nn = f / (16 * NT), cq = f % (16 * NT);
+            rw[i] = *(const float4 *)(a.W + (int64_t)(c * KC + nn) * CPREV + k0 + 4 * cq);
+        }
+    };
+
+    load_chunk(0);
+    for (int c = 0; c < nchunk; ++c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = rb + 32 * i;
+            const bool ok = r < nvalid;
+            const float w = uS[r].w;
+            const int rloc = row0 + r;
+            const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
+            const float zv[4] = {rz[i].x, rz[i].y, rz[i].z, rz[i].w};
+            int mv[4] = {0, 0, 0, 0};
+            if constexpr (LAYER == 3) { mv[0] = rm[i].x; mv[1] = rm[i].y; mv[2] = rm[i].z; mv[3] = rm[i].w; }
+            float dv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = c * KC + 4 * kq + j;
+                float dz = zv[j];
+                if constexpr (LAYER == 3) dz = (mv[j] == rloc) ? zv[j] : 0.f;
+                const float xh = (yv[j] - coefS[CRED + n]) * coefS[2 * CRED + n];
+                const float dy = coefS[n] * (dz - w * fmaf(xh, coefS[4 * CRED + n], coefS[3 * CRED + n]));
+                dv[j] = ok ? dy : 0.f;
+                As[(4 * kq + j) * LDT + r] = dv[j];
+            }
+            if constexpr (LAYER == 3) {
+                if (ok && blockIdx.y == 0)
+                    *(float4 *)(a.dybuf + (grow0 + r) * CRED + c * KC + 4 * kq) =
+                        make_float4(dv[0], dv[1], dv[2], dv[3]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * NT; ++i) {
+            const int f = tid + GT * i;
+            const int nn = f / (16 * NT), cq = f % (16 * NT);
+            *(float4 *)(Bs + nn * LDB + 4 * cq) = rw[i];
+        }
+        __syncthreads();
+        if (c + 1 < nchunk) load_chunk(c + 1);
+        mma_chunk<2, NT, LDT, LDB>(As, Bs, wm * 64, wn * 32 * NT, acc);
+        __syncthreads();
+    }
+
+    // ---- epilogue: ReLU mask of the previous layer, its BN-backward statistics
+    constexpr int NS = (LAYER == 3) ? 2 : 4;
+    float st[NT][NS];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = k0 + wn * 32 * NT + nt * 32 + l31;
+        const float ps = a.bn_prev[col], pt = a.bn_prev[CPREV + col];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) st[nt][q] = 0.f;
+        if constexpr (LAYER == 3) {
+            const float pm = a.bn_prev[2 * CPREV + col], pr = a.bn_prev[3 * CPREV + col];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = wm * 64 + mt * 32 + acc_row(reg, lh);
+                    if (row < nvalid) {
+                        const int64_t o = (grow0 + row) * CPREV + col;
+                        const float yv = a.yprev[o];
+                        const float dz = (fmaf(ps, yv, pt) > 0.f) ? acc[mt][nt][reg] : 0.f;
+                        a.dzprev[o] = dz;
+                        st[nt][0] += dz;
+                        st[nt][1] = fmaf(dz, (yv - pm) * pr, st[nt][1]);
+                    }
+                }
+        } else {
+            const float al[3] = {ps * a.W1[3 * col], ps * a.W1[3 * col + 1], ps * a.W1[3 * col + 2]};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = wm * 64 + mt * 32 + acc_row(reg, lh);
+                    if (row < nvalid) {
+                        const float4 u = uS[row];
+                        const float dz = (l1_pre(al, pt, u.x, u.y, u.z) > 0.f) ? acc[mt][nt][reg] : 0.f;
+                        st[nt][0] += dz;
+                        st[nt][1] = fmaf(dz, u.x, st[nt][1]);
+                        st[nt][2] = fmaf(dz, u.y, st[nt][2]);
+                        st[nt][3] = fmaf(dz, u.z, st[nt][3]);
+                    }
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < NS; ++q) st[nt][q] += __shfl_xor(st[nt][q], 32, 64);
+    }
+    float *red = As;      // [wn][nt][l31][NS], written by wm == 1
+    if (wm == 1 && lh == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q = 0; q < NS; ++q) red[(((wn * NT + nt) * 32 + l31) * NS) + q] = st[nt][q];
+    }
+    __syncthreads();
+    if (wm == 0 && lh == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = k0 + wn * 32 * NT + nt * 32 + l31;
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                const double v = (double)st[nt][q] + (double)red[(((wn * NT + nt) * 32 + l31) * NS) + q];
+                atomic_add_f64(&a.bstat_prev[q * CPREV + col], v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float4 *ent;
+    const int32_t *woff;
+    const float *dy;        // LAYER 3: dy3 (B,cap,C3)
+    const float *dz;        // LAYER 2: dz2 (B,cap,C2)
+    const float *ycur;      // LAYER 2: y2 (for xhat2)
+    const float *coef;      // LAYER 2: 5 x C2
+    const float *yprev;     // LAYER 3: y2 -> a2
+    const float *bn_prev;   // scale, shift of the previous layer's BN
+    const float *W1;        // LAYER 2
+    float *partial;         // (nsplit, COUT, CIN)
+    int L, cap, COUT, CIN, spb;
+};
+
+// dW[n][k] = sum_rows dy[row][n] * a_prev[row][k]; workgroup tile (64*MT) x (64*NT), rows split by WG_ROWS.
+template <int LAYER, int MT, int NT>
+__global__ __launch_bounds__(GT) void wgrad_kernel(WgradArgs a)
+{
+    constexpr int LDA = 64 * MT + 4, LDB = 64 * NT + 4;
+    __shared__ __attribute__((aligned(16))) float As[KC * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[KC * LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int b = blockIdx.x / a.spb, sp = blockIdx.x % a.spb;
+    const int nent = a.woff[(int64_t)b * (a.L + 1) + a.L];
+    const int rbeg = sp * WG_ROWS;
+    if (rbeg >= nent) return;
+    const int rend = min(nent, rbeg + WG_ROWS);
+    const int n0 = blockIdx.y * 64 * MT, k0 = blockIdx.z * 64 * NT;
+    const int COUT = a.COUT, CIN = a.CIN;
+    const int64_t gbase = (int64_t)b * a.cap;
+
+    // per-thread constant columns of the two staged operands
+    const int acq = tid % (16 * MT), arr = tid / (16 * MT);     // A: column quad, first row; rows step 16/MT
+    const int bcq = tid % (16 * NT), brr = tid / (16 * NT);
+    constexpr int ARS = 16 / MT, BRS = 16 / NT;                  // row stride between a thread's float4s
+    float cf[5][4];
+    float bs[4], bt[4], bal[4][3];
+    if constexpr (LAYER == 2) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cf[q][j] = a.coef[q * COUT + n0 + 4 * acq + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + 4 * bcq + j;
+        bs[j] = a.bn_prev[k];
+        bt[j] = a.bn_prev[CIN + k];
+        if constexpr (LAYER == 2) {
+            bal[j][0] = bs[j] * a.W1[3 * k];
+            bal[j][1] = bs[j] * a.W1[3 * k + 1];
+            bal[j][2] = bs[j] * a.W1[3 * k + 2];
+        }
+    }
+
+    f32x16 acc[MT][NT];
+    acc_zero<MT, NT>(acc);
+    float4 ra[2 * MT], ra2[2 * MT], rb4[2 * NT];
+    float rwt[2 * MT];
+
+    auto load_chunk = [&](int r0) {
+#pragma unroll
+        for (int i = 0; i < 2 * MT; ++i) {
+            const int row = r0 + arr + ARS * i;
+            if (row < rend) {
+                const int64_t o = (gbase + row) * COUT + n0 + 4 * acq;
+                if constexpr (LAYER == 3) {
+                    ra[i] = *(const float4 *)(a.dy + o);
+                } else {
+                    ra[i] = *(const float4 *)(a.dz + o);
+                    ra2[i] = *(const float4 *)(a.ycur + o);
+                    rwt[i] = a.ent[gbase + row].w;
+                }
+            } else {
+                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (LAYER == 2) { ra2[i] = make_float4(0.f, 0.f, 0.f, 0.f); rwt[i] = 0.f; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * NT; ++i) {
+            const int row = r0 + brr + BRS * i;
+            if (row < rend) {
+                if constexpr (LAYER == 3) rb4[i] = *(const float4 *)(a.yprev + (gbase + row) * CIN + k0 + 4 * bcq);
+                else rb4[i] = a.ent[gbase + row];
+            } else {
+                rb4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+
+    load_chunk(rbeg);
+    for (int r0 = rbeg; r0 < rend; r0 += KC) {
+#pragma unroll
+        for (int i = 0; i < 2 * MT; ++i) {
+            const int rr = arr + ARS * i;
+            const bool ok = (r0 + rr) < rend;
+            float4 v = ra[i];
+            if constexpr (LAYER == 2) {
+                const float dzv[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+                const float yv[4] = {ra2[i].x, ra2[i].y, ra2[i].z, ra2[i].w};
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (yv[j] - cf[1][j]) * cf[2][j];
+                    o[j] = cf[0][j] * (dzv[j] - rwt[i] * fmaf(xh, cf[4][j], cf[3][j]));
+                }
+                v = ok ? make_float4(o[0], o[1], o[2], o[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            *(float4 *)(As + rr * LDA + 4 * acq) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * NT; ++i) {
+            const int rr = brr + BRS * i;
+            const bool ok = (r0 + rr) < rend;
+            float o[4];
+            if constexpr (LAYER == 3) {
+                const float yv[4] = {rb4[i].x, rb4[i].y, rb4[i].z, rb4[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = fmaxf(fmaf(bs[j], yv[j], bt[j]), 0.f);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    o[j] = fmaxf(l1_pre(bal[j], bt[j], rb4[i].x, rb4[i].y, rb4[i].z), 0.f);
+            }
+            *(float4 *)(Bs + rr * LDB + 4 * bcq) =
+                ok ? make_float4(o[0], o[1], o[2], o[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        if (r0 + KC < rend) load_chunk(r0 + KC);
+        mma_chunk<MT, NT, LDA, LDB>(As, Bs, wm * 32 * MT, wn * 32 * NT, acc);
+        __syncthreads();
+    }
+
+    float *out = a.partial + (int64_t)blockIdx.x * COUT * CIN;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int n = n0 + wm * 32 * MT + mt * 32 + acc_row(reg, lh);
+                const int k = k0 + wn * 32 * NT + nt * 32 + l31;
+                out[(int64_t)n * CIN + k] = acc[mt][nt][reg];
+            }
+}
+
+__global__ void wgrad_reduce_kernel(const float *__restrict__ partial, const int32_t *__restrict__ woff,
+                                    int L, int spb, int nsplit, int64_t nelem, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nelem) return;
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) {
+        const int b = sp / spb, q = sp % spb;
+        if (q * WG_ROWS < woff[(int64_t)b * (L + 1) + L]) s += partial[(int64_t)sp * nelem + i];
+    }
+    out[i] = s;
+}
+
+// dW1, dgamma1, dbeta1 from Q = sum_e dz1 (1, u) and the forward's weighted moments of u.
+__global__ void l1_finalize_kernel(const double *__restrict__ Q, const double *__restrict__ mom,
+                                   const float *__restrict__ W1, const float *__restrict__ gamma,
+                                   const float *__restrict__ bn1, int C, double M,
+                                   float *__restrict__ dW1, float *__restrict__ dgamma, float *__restrict__ dbeta)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double q0 = Q[c], qu[3] = {Q[C + c], Q[2 * C + c], Q[3 * C + c]};
+    const double w[3] = {W1[3 * c], W1[3 * c + 1], W1[3 * c + 2]};
+    const double mean = bn1[2 * C + c], rstd = bn1[3 * C + c];
+    const double db = q0;
+    const double dg = rstd * (w[0] * qu[0] + w[1] * qu[1] + w[2] * qu[2] - mean * q0);
+    const double mu[3] = {mom[1] / M, mom[2] / M, mom[3] / M};
+    const double m2[3][3] = {{mom[4] / M, mom[5] / M, mom[6] / M},
+                             {mom[5] / M, mom[7] / M, mom[8] / M},
+                             {mom[6] / M, mom[8] / M, mom[9] / M}};
+    const double kk = (double)gamma[c] * rstd;
+    for (int j = 0; j < 3; ++j) {
+        const double wm2 = w[0] * m2[0][j] + w[1] * m2[1][j] + w[2] * m2[2][j];
+        // sum_e w x^ u_j = rstd * M * (W1_c . m2[:,j] - mean * mu_j);  sum_e w u_j = M mu_j
+        const double v = kk * (qu[j] - db * mu[j] - dg * rstd * (wm2 - mean * mu[j]));
+        dW1[3 * c + j] = (float)v;
+    }
+    dgamma[c] = (float)dg;
+    dbeta[c] = (float)db;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int LAYER>
+static int launch_dgrad(const DgradArgs &a, int B, hipStream_t st)
+{
+    if (a.CRED % 64 || a.CPREV % 64 || a.CRED > MAXC) return FCN_E_BADARG;
+    if (a.CPREV % 128 == 0) {
+        hipLaunchKernelGGL((dgrad_kernel<LAYER, 2>), dim3(B * a.tps, a.CPREV / 128), dim3(GT), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((dgrad_kernel<LAYER, 1>), dim3(B * a.tps, a.CPREV / 64), dim3(GT), 0, st, a);
+    }
+    FCN_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int LAYER>
+static int launch_wgrad(const WgradArgs &a, int B, hipStream_t st)
+{
+    const bool m2 = (a.COUT % 128 == 0), n2 = (a.CIN % 128 == 0);
+    dim3 grid(B * a.spb, a.COUT / (m2 ? 128 : 64), a.CIN / (n2 ? 128 : 64));
+    if (m2 && n2) hipLaunchKernelGGL((wgrad_kernel<LAYER, 2, 2>), grid, dim3(GT), 0, st, a);
+    else if (m2) hipLaunchKernelGGL((wgrad_kernel<LAYER, 2, 1>), grid, dim3(GT), 0, st, a);
+    else if (n2) hipLaunchKernelGGL((wgrad_kernel<LAYER, 1, 2>), grid, dim3(GT), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<LAYER, 1, 1>), grid, dim3(GT), 0, st, a);
+    FCN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fcn_pn_backward(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dfeat,
+                               const fcn_pn_ws *ws, float *dW[3], float *dgamma[3], float *dbeta[3],
+                               void *stream)
+{
+    if (!d || !p || !ws || !dfeat || !dW || !dgamma || !dbeta) return FCN_E_BADARG;
+    if (!d->training) return FCN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = d->B, L = d->L, K = d->K, C1 = d->C1, C2 = d->C2, C3 = d->C3;
+    if (C1 % 64 || C2 % 64 || C3 % 64 || C1 > MAXC || C2 > MAXC || C3 > MAXC) return FCN_E_BADARG;
+    const int cap = L * K;
+    const double M = (double)B * (double)L * (double)K;
+    const int tps = (cap + 127) / 128;
+    const int spb = (cap + WG_ROWS - 1) / WG_ROWS;
+    if (ws->nsplit < B * spb) return FCN_E_BADARG;
+    const float *bn1 = ws->bn + fcn_bn_off(0, C1, C2);
+    const float *bn2 = ws->bn + fcn_bn_off(1, C1, C2);
+    const float *bn3 = ws->bn + fcn_bn_off(2, C1, C2);
+    double *bs3 = ws->bstat, *bs2 = bs3 + 2 * C3, *bsQ = bs2 + 2 * C2;
+    float *coef3 = ws->coef, *coef2 = coef3 + 5 * C3;
+
+    hipError_t e = hipMemsetAsync(ws->bstat, 0, sizeof(double) * (size_t)(2 * C3 + 2 * C2 + 4 * C1), st);
+    if (e != hipSuccess) return (int)e;
+
+    const int cpb = C3 >= 256 ? 256 : C3;
+    if (GT % cpb || C3 % cpb) return FCN_E_BADARG;
+    hipLaunchKernelGGL(poolbwd_kernel, dim3((L + PWB - 1) / PWB, C3 / cpb, B), dim3(GT), 0, st, dfeat, ws->amax,
+                       ws->y3, bn3, ws->gmax, bs3, L, cap, C3, C3 + d->nvec, cpb);
+    FCN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bnbwd_finalize_kernel, dim3((C3 + 63) / 64), dim3(64), 0, st, bs3, p->gamma[2], bn3, C3, M,
+                       coef3, dgamma[2], dbeta[2]);
+    FCN_CHECK_LAUNCH();
+
+    DgradArgs g;
+    g.ent = (const float4 *)ws->ent; g.woff = ws->woff; g.ewin = ws->ewin; g.L = L; g.cap = cap; g.tps = tps;
+    g.ycur = ws->y3; g.amax = ws->amax; g.gmax = ws->gmax; g.dzcur = nullptr; g.coef = coef3; g.W = p->W[2];
+    g.dybuf = ws->dy3; g.yprev = ws->y2; g.bn_prev = bn2; g.W1 = nullptr; g.dzprev = ws->dz2; g.bstat_prev = bs2;
+    g.CRED = C3; g.CPREV = C2;
+    FCN_TRY(launch_dgrad<3>(g, B, st));
+
+    WgradArgs w;
+    w.ent = (const float4 *)ws->ent; w.woff = ws->woff; w.L = L; w.cap = cap; w.spb = spb; w.partial = ws->partial;
+    w.dy = ws->dy3; w.dz = nullptr; w.ycur = nullptr; w.coef = nullptr; w.yprev = ws->y2; w.bn_prev = bn2;
+    w.W1 = nullptr; w.COUT = C3; w.CIN = C2;
+    FCN_TRY(launch_wgrad<3>(w, B, st));
+    {
+        const int64_t ne = (int64_t)C3 * C2;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, ws->partial,
+                           ws->woff, L, spb, B * spb, ne, dW[2]);
+        FCN_CHECK_LAUNCH();
+    }
+
+    hipLaunchKernelGGL(bnbwd_finalize_kernel, dim3((C2 + 63) / 64), dim3(64), 0, st, bs2, p->gamma[1], bn2, C2, M,
+                       coef2, dgamma[1], dbeta[1]);
+    FCN_CHECK_LAUNCH();
+
+    g.ycur = ws->y2; g.amax = nullptr; g.gmax = nullptr; g.dzcur = ws->dz2; g.coef = coef2; g.W = p->W[1];
+    g.dybuf = nullptr; g.yprev = nullptr; g.bn_prev = bn1; g.W1 = p->W[0]; g.dzprev = nullptr; g.bstat_prev = bsQ;
+    g.CRED = C2; g.CPREV = C1;
+    FCN_TRY(launch_dgrad<2>(g, B, st));
+
+    w.dy = nullptr; w.dz = ws->dz2; w.ycur = ws->y2; w.coef = coef2; w.yprev = nullptr; w.bn_prev = bn1;
+    w.W1 = p->W[0]; w.COUT = C2; w.CIN = C1;
+    FCN_TRY(launch_wgrad<2>(w, B, st));
+    {
+        const int64_t ne = (int64_t)C2 * C1;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, ws->partial,
+                           ws->woff, L, spb, B * spb, ne, dW[1]);
+        FCN_CHECK_LAUNCH();
+    }
+
+    hipLaunchKernelGGL(l1_finalize_kernel, dim3((C1 + 63) / 64), dim3(64), 0, st, bsQ, ws->stat + FCN_STAT_MOM,
+                       p->W[0], p->gamma[0], bn1, C1, M, dW[0], dgamma[0], dbeta[0]);
+    FCN_CHECK_LAUNCH();
+    return 0;
+}

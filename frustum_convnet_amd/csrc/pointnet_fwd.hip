@@ -1,0 +1,380 @@
+// Forward of one PointNet scale in entry space (replaces models/det_base.py:75-101 + :134-157).
+//
+//   bn1_finalize : BN1 scale/shift from the weighted input moments (conv1 is linear in u)
+//   fwd_gemm<0>  : a1 = relu(bn1(conv1(u))) computed on the fly (Cin = 3 -> VALU), y2 = a1 . W2^T on MFMA,
+//                  per-channel weighted sum / sum-of-squares of y2 in the epilogue
+//   bn_finalize  : BN scale/shift (+ running stats) from those sums
+//   fwd_gemm<1>  : a2 = relu(bn2(y2)) applied while staging, y3 = a2 . W3^T, statistics epilogue
+//   pool         : relu(bn3(y3)), (cnt>0) mask, max over each window's rows (+argmax), one-hot rows
+//
+// Training-mode BatchNorm needs whole-batch statistics between layers, hence one launch per layer;
+// everything elementwise (gather, centre, BN apply, ReLU, mask, max, concat) is fused into the
+// neighbouring GEMM's prologue/epilogue, so only the pre-BN conv outputs y2, y3 ever reach HBM.
+#include "gemm_tile.h"
+
+#define LDT 129            // LDS leading dimension of a 128-wide k-major tile
+#define MAXC 512           // largest supported reduction width (C1, C2)
+
+// ------------------------------------------------------------------------------------------------
+__global__ void bn1_finalize_kernel(const double *__restrict__ mom, const float *__restrict__ W1,
+                                    const float *__restrict__ gamma, const float *__restrict__ beta,
+                                    float *rmean, float *rvar, int64_t *nbt, int C, int training,
+                                    float eps, float momentum, double M, float *__restrict__ bn)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double mean, var;
+    if (training) {
+        const double mx = mom[1] / M, my = mom[2] / M, mz = mom[3] / M;
+        const double cxx = mom[4] / M - mx * mx, cxy = mom[5] / M - mx * my, cxz = mom[6] / M - mx * mz;
+        const double cyy = mom[7] / M - my * my, cyz = mom[8] / M - my * mz, czz = mom[9] / M - mz * mz;
+        const double w0 = W1[3 * c], w1 = W1[3 * c + 1], w2 = W1[3 * c + 2];
+        mean = w0 * mx + w1 * my + w2 * mz;
+        var = w0 * (cxx * w0 + cxy * w1 + cxz * w2) + w1 * (cxy * w0 + cyy * w1 + cyz * w2) +
+              w2 * (cxz * w0 + cyz * w1 + czz * w2);
+        if (var < 0.0) var = 0.0;
+        if (rmean) {
+            rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mean);
+            rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * var * (M / (M - 1.0)));
+            if (c == 0 && nbt) nbt[0] += 1;
+        }
+    } else {
+        mean = rmean[c];
+        var = rvar[c];
+    }
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double s = (double)gamma[c] * rstd;
+    bn[c] = (float)s;
+    bn[C + c] = (float)((double)beta[c] - mean * s);
+    bn[2 * C + c] = (float)mean;
+    bn[3 * C + c] = (float)rstd;
+}
+
+__global__ void bn_finalize_kernel(const double *__restrict__ stat, const float *__restrict__ gamma,
+                                   const float *__restrict__ beta, float *rmean, float *rvar, int64_t *nbt,
+                                   int C, int training, float eps, float momentum, double M,
+                                   float *__restrict__ bn)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double mean, var;
+    if (training) {
+        mean = stat[c] / M;
+        var = stat[C + c] / M - mean * mean;
+        if (var < 0.0) var = 0.0;
+        if (rmean) {
+            rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mean);
+            rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * var * (M / (M - 1.0)));
+            if (c == 0 && nbt) nbt[0] += 1;
+        }
+    } else {
+        mean = rmean[c];
+        var = rvar[c];
+    }
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double s = (double)gamma[c] * rstd;
+    bn[c] = (float)s;
+    bn[C + c] = (float)((double)beta[c] - mean * s);
+    bn[2 * C + c] = (float)mean;
+    bn[3 * C + c] = (float)rstd;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct FwdArgs {
+    const float4 *ent;     // (B,cap) rows (ux,uy,uz,w)
+    const int32_t *woff;   // (B,L+1)
+    const float *aprev;    // MODE 1: (B,cap,CIN) pre-BN output of the previous conv
+    const float *bn_in;    // scale[CIN], shift[CIN] of the BN in front of this conv
+    const float *W1;       // MODE 0: (CIN,3)
+    const float *W;        // (COUT,CIN)
+    float *y;              // (B,cap,COUT)
+    double *stat;          // sum[COUT], sumsq[COUT] or nullptr (eval)
+    int L, cap, CIN, COUT, tps;
+};
+
+// MODE 0: operand rows are conv1+BN1+ReLU of the entries (computed here); MODE 1: BN+ReLU of aprev.
+template <int MODE, int NT>
+__global__ __launch_bounds__(GT) void fwd_gemm_kernel(FwdArgs a)
+{
+    constexpr int LDB = 64 * NT + 1;
+    __shared__ float As[KC * LDT];
+    __shared__ float Bs[KC * LDB];
+    __shared__ float tS[MAXC];
+    __shared__ float sS[MODE == 0 ? 3 * MAXC : MAXC];   // MODE 0: alpha[CIN][3]
+    __shared__ float wS[128];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int b = blockIdx.x / a.tps, t = blockIdx.x % a.tps;
+    const int nent = a.woff[(int64_t)b * (a.L + 1) + a.L];
+    const int row0 = t * 128;
+    if (row0 >= nent) return;
+    const int nvalid = min(128, nent - row0);
+    const int64_t grow0 = (int64_t)b * a.cap + row0;
+    const int n0 = blockIdx.y * 64 * NT;
+    const int CIN = a.CIN, COUT = a.COUT;
+
+    for (int i = tid; i < CIN; i += GT) {
+        const float s = a.bn_in[i];
+        tS[i] = a.bn_in[CIN + i];
+        if constexpr (MODE == 0) {
+            sS[3 * i] = s * a.W1[3 * i];
+            sS[3 * i + 1] = s * a.W1[3 * i + 1];
+            sS[3 * i + 2] = s * a.W1[3 * i + 2];
+        } else {
+            sS[i] = s;
+        }
+    }
+    if (tid < 128) wS[tid] = (tid < nvalid) ? a.ent[grow0 + tid].w : 0.f;
+    float ux = 0.f, uy = 0.f, uz = 0.f;
+    const int r0 = tid & 127;
+    const bool r0valid = r0 < nvalid;
+    if (MODE == 0 && r0valid) {
+        const float4 e = a.ent[grow0 + r0];
+        ux = e.x; uy = e.y; uz = e.z;
+    }
+    __syncthreads();
+
+    f32x16 acc[2][NT];
+    acc_zero<2, NT>(acc);
+    const int kq = tid & 7, rb = tid >> 3;
+    float4 ra[4], rw[2 * NT];
+    const int nchunk = CIN / KC;
+
+    auto load_chunk = [&](int c) {
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = rb + 32 * i;
+                ra[i] = (r < nvalid) ? *(const float4 *)(a.aprev + (grow0 + r) * CIN + c * KC + 4 * kq)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * NT; ++i) {
+            const int n = rb + 32 * i;
+            rw[i] = *(const float4 *)(a.W + (int64_t)(n0 + n) * CIN + c * KC + 4 * kq);
+        }
+    };
+
+    load_chunk(0);
+    for (int c = 0; c < nchunk; ++c) {
+        // ---- registers -> LDS (k-major), applying the input BN + ReLU
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = rb + 32 * i;
+                const bool ok = r < nvalid;
+                const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 4 * kq + j;
+                    const float z = fmaf(sS[c * KC + k], v[j], tS[c * KC + k]);
+                    As[k * LDT + r] = ok ? fmaxf(z, 0.f) : 0.f;
+                }
+            }
+        } else {
+            const int half = tid >> 7;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int k = half * 16 + j;
+                const int kk = c * KC + k;
+                const float z = l1_pre(&sS[3 * kk], tS[kk], ux, uy, uz);
+                As[k * LDT + r0] = r0valid ? fmaxf(z, 0.f) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * NT; ++i) {
+            const int n = rb + 32 * i;
+            const float v[4] = {rw[i].x, rw[i].y, rw[i].z, rw[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Bs[(4 * kq + j) * LDB + n] = v[j];
+        }
+        __syncthreads();
+        if (c + 1 < nchunk) load_chunk(c + 1);
+        mma_chunk<2, NT, LDT, LDB>(As, Bs, wm * 64, wn * 32 * NT, acc);
+        __syncthreads();
+    }
+
+    // ---- epilogue: store y (valid rows), per-channel weighted statistics
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = wm * 64 + mt * 32 + acc_row(reg, lh);
+                const int col = n0 + wn * 32 * NT + nt * 32 + l31;
+                if (row < nvalid) a.y[(grow0 + row) * COUT + col] = acc[mt][nt][reg];
+            }
+    if (a.stat) {
+        float *red = As;   // free after the last barrier: [wn][nt*32+l31][2] written by the wm==1 waves
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const float w = wS[wm * 64 + mt * 32 + acc_row(reg, lh)];
+                    const float v = acc[mt][nt][reg];
+                    s1 = fmaf(w, v, s1);
+                    s2 = fmaf(w * v, v, s2);
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (wm == 1 && lh == 0) {
+                red[((wn * NT + nt) * 32 + l31) * 2] = s1;
+                red[((wn * NT + nt) * 32 + l31) * 2 + 1] = s2;
+            }
+            acc[0][nt][0] = s1;   // keep for the wm == 0 waves
+            acc[0][nt][1] = s2;
+        }
+        __syncthreads();
+        if (wm == 0 && lh == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = n0 + wn * 32 * NT + nt * 32 + l31;
+                const double s1 = (double)acc[0][nt][0] + (double)red[((wn * NT + nt) * 32 + l31) * 2];
+                const double s2 = (double)acc[0][nt][1] + (double)red[((wn * NT + nt) * 32 + l31) * 2 + 1];
+                atomic_add_f64(&a.stat[col], s1);
+                atomic_add_f64(&a.stat[COUT + col], s2);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+#define PW 8     // windows per pool workgroup
+
+__global__ __launch_bounds__(GT) void pool_kernel(
+    const float *__restrict__ y3, const float *__restrict__ bn3, const int32_t *__restrict__ woff,
+    const int32_t *__restrict__ cnt, const float *__restrict__ one_hot, float *__restrict__ feat,
+    int32_t *__restrict__ amax, int L, int cap, int C3, int nvec, int cpb)
+{
+    __shared__ float outS[256 * (PW + 1)];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z, l0 = blockIdx.x * PW, c0 = blockIdx.y * cpb;
+    const int cl = tid % cpb, wlane = tid / cpb, nwl = GT / cpb;
+    const int c = c0 + cl;
+    const float s = bn3[c], t = bn3[C3 + c];
+    const int32_t *wo = woff + (int64_t)b * (L + 1);
+    for (int wl = wlane; wl < PW; wl += nwl) {
+        const int l = l0 + wl;
+        float best = 0.f;
+        int arg = -1;
+        if (l < L && cnt[(int64_t)b * L + l] > 0) {
+            const int o0 = wo[l], o1 = wo[l + 1];
+            const float *yp = y3 + ((int64_t)b * cap + o0) * C3 + c;
+            for (int r = o0; r < o1; ++r, yp += C3) {
+                const float v = fmaf(s, *yp, t);
+                if (v > best) { best = v; arg = r; }
+            }
+        }
+        outS[cl * (PW + 1) + wl] = best;
+        if (l < L && amax) amax[((int64_t)b * L + l) * C3 + c] = arg;
+    }
+    __syncthreads();
+    const int CT = C3 + nvec;
+    for (int f = tid; f < cpb * PW; f += GT) {
+        const int cc = f / PW, wl = f % PW, l = l0 + wl;
+        if (l < L) feat[((int64_t)b * CT + c0 + cc) * L + l] = outS[cc * (PW + 1) + wl];
+    }
+    if (blockIdx.y == 0 && tid < nvec * PW) {
+        const int v = tid / PW, wl = tid % PW, l = l0 + wl;
+        if (l < L) feat[((int64_t)b * CT + C3 + v) * L + l] = one_hot[(int64_t)b * nvec + v];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+static int launch_fwd_gemm(const FwdArgs &a, int B, hipStream_t st)
+{
+    if (a.CIN % 64 || a.COUT % 64 || a.CIN > MAXC) return FCN_E_BADARG;
+    if (a.COUT % 128 == 0) {
+        dim3 grid(B * a.tps, a.COUT / 128);
+        hipLaunchKernelGGL((fwd_gemm_kernel<MODE, 2>), grid, dim3(GT), 0, st, a);
+    } else {
+        dim3 grid(B * a.tps, a.COUT / 64);
+        hipLaunchKernelGGL((fwd_gemm_kernel<MODE, 1>), grid, dim3(GT), 0, st, a);
+    }
+    FCN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, const int32_t *cnt,
+                              const float *one_hot, const fcn_pn_ws *ws, float *feat, void *stream)
+{
+    if (!d || !p || !ws || !cnt || !feat) return FCN_E_BADARG;
+    if (d->C1 % 64 || d->C2 % 64 || d->C3 % 64 || d->C1 > MAXC || d->C2 > MAXC) return FCN_E_BADARG;
+    if (d->nvec > 0 && !one_hot) return FCN_E_BADARG;
+    if (d->nvec * PW > GT) return FCN_E_LIMIT;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = d->B, L = d->L, K = d->K, C1 = d->C1, C2 = d->C2, C3 = d->C3;
+    const int cap = L * K;
+    const double M = (double)B * (double)L * (double)K;
+    const int tr = d->training ? 1 : 0;
+    float *bn1 = ws->bn + fcn_bn_off(0, C1, C2);
+    float *bn2 = ws->bn + fcn_bn_off(1, C1, C2);
+    float *bn3 = ws->bn + fcn_bn_off(2, C1, C2);
+    double *st2 = ws->stat + FCN_STAT_L2, *st3 = st2 + 2 * C2;
+
+    hipLaunchKernelGGL(bn1_finalize_kernel, dim3((C1 + 63) / 64), dim3(64), 0, st, ws->stat + FCN_STAT_MOM,
+                       p->W[0], p->gamma[0], p->beta[0], p->running_mean[0], p->running_var[0],
+                       p->num_batches_tracked[0], C1, tr, d->eps, d->momentum, M, bn1);
+    FCN_CHECK_LAUNCH();
+
+    FwdArgs a;
+    a.ent = (const float4 *)ws->ent; a.woff = ws->woff; a.L = L; a.cap = cap; a.tps = (cap + 127) / 128;
+    a.aprev = nullptr; a.bn_in = bn1; a.W1 = p->W[0]; a.W = p->W[1]; a.y = ws->y2;
+    a.stat = tr ? st2 : nullptr; a.CIN = C1; a.COUT = C2;
+    FCN_TRY(launch_fwd_gemm<0>(a, B, st));
+
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C2 + 63) / 64), dim3(64), 0, st, st2, p->gamma[1], p->beta[1],
+                       p->running_mean[1], p->running_var[1], p->num_batches_tracked[1], C2, tr, d->eps,
+                       d->momentum, M, bn2);
+    FCN_CHECK_LAUNCH();
+
+    a.aprev = ws->y2; a.bn_in = bn2; a.W1 = nullptr; a.W = p->W[2]; a.y = ws->y3;
+    a.stat = tr ? st3 : nullptr; a.CIN = C2; a.COUT = C3;
+    FCN_TRY(launch_fwd_gemm<1>(a, B, st));
+
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C3 + 63) / 64), dim3(64), 0, st, st3, p->gamma[2], p->beta[2],
+                       p->running_mean[2], p->running_var[2], p->num_batches_tracked[2], C3, tr, d->eps,
+                       d->momentum, M, bn3);
+    FCN_CHECK_LAUNCH();
+
+    const int cpb = C3 >= 256 ? 256 : C3;   // C3 is a multiple of 64: 64, 128, 192 -> must divide 256
+    if (GT % cpb) return FCN_E_BADARG;
+    dim3 pgrid((L + PW - 1) / PW, C3 / cpb, B);
+    if (C3 % cpb) return FCN_E_BADARG;
+    hipLaunchKernelGGL(pool_kernel, pgrid, dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, one_hot, feat,
+                       tr ? ws->amax : nullptr, L, cap, C3, d->nvec, cpb);
+    FCN_CHECK_LAUNCH();
+    return 0;
+}
+
+// Single-kernel entry (micro-benchmarks, roofline accounting, unit tests): launches only the conv GEMM of
+// `layer` (2: conv1+BN1+ReLU fused into conv2; 3: BN2+ReLU fused into conv3) on workspace state left by
+// fcn_pn_compact / fcn_pn_forward.  with_stats != 0 also runs the statistics epilogue (accumulates into
+// ws->stat, which the caller must not reuse for a backward afterwards).
+extern "C" int fcn_pn_conv_fwd(const fcn_pn_desc *d, const fcn_pn_params *p, const fcn_pn_ws *ws, int layer,
+                               int with_stats, void *stream)
+{
+    if (!d || !p || !ws || (layer != 2 && layer != 3)) return FCN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = d->B, L = d->L, K = d->K, C1 = d->C1, C2 = d->C2, C3 = d->C3;
+    const int cap = L * K;
+    double *st2 = ws->stat + FCN_STAT_L2, *st3 = st2 + 2 * C2;
+    FwdArgs a;
+    a.ent = (const float4 *)ws->ent; a.woff = ws->woff; a.L = L; a.cap = cap; a.tps = (cap + 127) / 128;
+    if (layer == 2) {
+        a.aprev = nullptr; a.bn_in = ws->bn + fcn_bn_off(0, C1, C2); a.W1 = p->W[0]; a.W = p->W[1]; a.y = ws->y2;
+        a.stat = with_stats ? st2 : nullptr; a.CIN = C1; a.COUT = C2;
+        return launch_fwd_gemm<0>(a, B, st);
+    }
+    a.aprev = ws->y2; a.bn_in = ws->bn + fcn_bn_off(1, C1, C2); a.W1 = nullptr; a.W = p->W[2]; a.y = ws->y3;
+    a.stat = with_stats ? st3 : nullptr; a.CIN = C2; a.COUT = C3;
+    return launch_fwd_gemm<1>(a, B, st);
+}

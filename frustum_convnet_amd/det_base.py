@@ -1,0 +1,294 @@
+"""Drop-in for the reference's models/det_base.py: PointNetModule, PointNetFeat, ConvFeatNet, PointNetDet.
+
+Same constructors, forward signatures, return structures and state_dict keys (154 entries:
+feat_net.pointnet{1-4}.conv{1-3}.{0.weight,1.*}, conv_net.block*.{0.weight,1.*}, cls_out.*, reg_out.*), so
+checkpoints written by the reference's train/train_net_det.py:384-398 load unchanged.
+
+What runs where:
+  * grouping + shared MLP + max-pool + one-hot concat of every scale: hand-written HIP (csrc/), reached
+    through PointNetModule.forward_pooled.  The nn.Conv2d/BatchNorm2d children only HOLD the parameters.
+  * Conv1d FCN + heads (11 % of the dense FLOPs): MIOpen/rocBLAS through torch for now.
+  * loss tail: torch ops on device, written mask-weighted so the step has no host synchronisation
+    (the reference syncs at det_base.py:70, :414 and :495 every step).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .config import cfg
+from .dataset_info import DATASET_INFO
+from .common import Conv1d, Conv2d, DeConv1d, init_params, softmax_focal_loss_ignore, get_accuracy, masked_mean
+from .query_depth_point import QueryDepthPoint
+from .pointnet_fused import WorkspacePool, pointnet_pooled
+from . import box_ops
+
+
+class PointNetModule(nn.Module):
+    """Single-scale PointNet (reference: models/det_base.py:35-103)."""
+
+    def __init__(self, Infea, mlp, dist, nsample, use_xyz=True, use_feature=True):
+        super(PointNetModule, self).__init__()
+        self.dist = dist
+        self.nsample = nsample
+        self.use_xyz = use_xyz
+        self.use_feature = Infea > 0
+        if self.use_feature or not use_xyz:
+            raise NotImplementedError(
+                "only the xyz-only path (Infea == 0) is implemented: every shipped cfg has "
+                "WITH_EXTRA_FEAT False and train_net_det.py:296 makes Infea <= 0 otherwise")
+        self.query_depth_point = QueryDepthPoint(dist, nsample)
+        self.conv1 = Conv2d(Infea + 3, mlp[0], 1)
+        self.conv2 = Conv2d(mlp[0], mlp[1], 1)
+        self.conv3 = Conv2d(mlp[1], mlp[2], 1)
+        init_params([self.conv1[0], self.conv2[0], self.conv3[0]], 'kaiming_normal')
+        init_params([self.conv1[1], self.conv2[1], self.conv3[1]], 1)
+        self._pool = WorkspacePool()
+
+    def _param_pack(self):
+        convs = (self.conv1, self.conv2, self.conv3)
+        params = []
+        for c in convs:
+            params += [c[0].weight, c[1].weight, c[1].bias]
+        bufs = ([c[1].running_mean for c in convs], [c[1].running_var for c in convs],
+                [c[1].num_batches_tracked for c in convs])
+        return params, bufs
+
+    def forward_pooled(self, pc, new_pc, one_hot_vec=None):
+        """Fused fast path: max over K of the masked features, one-hot appended -> (B, C3+nvec, L).
+        Equals torch.max(self.forward(pc, None, new_pc), -1)[0] (+ the concat of PointNetFeat.forward)."""
+        params, bufs = self._param_pack()
+        bn = self.conv1[1]
+        feat, _, _ = pointnet_pooled(self._pool, self.dist, self.nsample, self.training, bn.eps,
+                                     0.1 if bn.momentum is None else bn.momentum,
+                                     pc.contiguous(), new_pc.contiguous(), one_hot_vec, bufs, params)
+        return feat
+
+    def forward(self, pc, feat, new_pc=None):
+        """Reference-shaped output (B, C3, L, nsample), masked.  Inspection / parity API: it expands the
+        fused path's per-entry activations back to the dense slots with device-side indexing and carries
+        no autograd graph -- training goes through forward_pooled (PointNetFeat does that)."""
+        from .pointnet_fused import dense_from_entries
+        params, bufs = self._param_pack()
+        bn = self.conv1[1]
+        with torch.no_grad():
+            return dense_from_entries(self._pool, self.dist, self.nsample, self.training, bn.eps,
+                                      0.1 if bn.momentum is None else bn.momentum,
+                                      pc.contiguous(), new_pc.contiguous(), bufs, params)
+
+
+class PointNetFeat(nn.Module):
+    """Four scales (reference: models/det_base.py:107-159)."""
+
+    def __init__(self, input_channel=3, num_vec=0):
+        super(PointNetFeat, self).__init__()
+        self.num_vec = num_vec
+        u = cfg.DATA.HEIGHT_HALF
+        assert len(u) == 4
+        self.pointnet1 = PointNetModule(input_channel - 3, [64, 64, 128], u[0], 32, use_xyz=True, use_feature=True)
+        self.pointnet2 = PointNetModule(input_channel - 3, [64, 64, 128], u[1], 64, use_xyz=True, use_feature=True)
+        self.pointnet3 = PointNetModule(input_channel - 3, [128, 128, 256], u[2], 64, use_xyz=True, use_feature=True)
+        self.pointnet4 = PointNetModule(input_channel - 3, [256, 256, 512], u[3], 128, use_xyz=True, use_feature=True)
+
+    def forward(self, point_cloud, sample_pc, feat=None, one_hot_vec=None):
+        if one_hot_vec is not None:
+            assert self.num_vec == one_hot_vec.shape[1]
+        nets = (self.pointnet1, self.pointnet2, self.pointnet3, self.pointnet4)
+        return tuple(net.forward_pooled(point_cloud, ref, one_hot_vec) for net, ref in zip(nets, sample_pc))
+
+
+class ConvFeatNet(nn.Module):
+    """Conv1d FCN over the stacked frustum feature maps (reference: models/det_base.py:163-224)."""
+
+    def __init__(self, i_c=128, num_vec=3):
+        super(ConvFeatNet, self).__init__()
+        self.block1_conv1 = Conv1d(i_c + num_vec, 128, 3, 1, 1)
+        self.block2_conv1 = Conv1d(128, 128, 3, 2, 1)
+        self.block2_conv2 = Conv1d(128, 128, 3, 1, 1)
+        self.block2_merge = Conv1d(128 + 128 + num_vec, 128, 1, 1)
+        self.block3_conv1 = Conv1d(128, 256, 3, 2, 1)
+        self.block3_conv2 = Conv1d(256, 256, 3, 1, 1)
+        self.block3_merge = Conv1d(256 + 256 + num_vec, 256, 1, 1)
+        self.block4_conv1 = Conv1d(256, 512, 3, 2, 1)
+        self.block4_conv2 = Conv1d(512, 512, 3, 1, 1)
+        self.block4_merge = Conv1d(512 + 512 + num_vec, 512, 1, 1)
+        self.block2_deconv = DeConv1d(128, 256, 1, 1, 0)
+        self.block3_deconv = DeConv1d(256, 256, 2, 2, 0)
+        self.block4_deconv = DeConv1d(512, 256, 4, 4, 0)
+        for m in self.modules():
+            if isinstance(m, (nn.Conv1d, nn.ConvTranspose1d)):
+                nn.init.kaiming_normal_(m.weight.data, mode='fan_in')
+                if m.bias is not None:
+                    m.bias.data.zero_()
+            if isinstance(m, nn.BatchNorm1d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def forward(self, x1, x2, x3, x4):
+        x = self.block1_conv1(x1)
+        x = self.block2_conv2(self.block2_conv1(x))
+        xx1 = x = self.block2_merge(torch.cat([x, x2], 1))
+        x = self.block3_conv2(self.block3_conv1(x))
+        xx2 = x = self.block3_merge(torch.cat([x, x3], 1))
+        x = self.block4_conv2(self.block4_conv1(x))
+        xx3 = self.block4_merge(torch.cat([x, x4], 1))
+        xx1 = self.block2_deconv(xx1)
+        xx2 = self.block3_deconv(xx2)
+        xx3 = self.block4_deconv(xx3)
+        n = xx1.shape[-1]
+        return torch.cat([xx1, xx2[:, :, :n], xx3[:, :, :n]], 1)
+
+
+class PointNetDet(nn.Module):
+    """Whole pipeline (reference: models/det_base.py:228-525)."""
+
+    def __init__(self, input_channel=3, num_vec=0, num_classes=2):
+        super(PointNetDet, self).__init__()
+        dataset_name = cfg.DATA.DATASET_NAME
+        assert dataset_name in DATASET_INFO
+        self.category_info = DATASET_INFO[dataset_name]
+        self.num_size_cluster = len(self.category_info.CLASSES)
+        self.mean_size_array = self.category_info.MEAN_SIZE_ARRAY
+        self.feat_net = PointNetFeat(input_channel, num_vec)
+        self.conv_net = ConvFeatNet(128, num_vec)
+        self.num_classes = num_classes
+        self.num_bins = cfg.DATA.NUM_HEADING_BIN
+        output_size = 3 + self.num_bins * 2 + self.num_size_cluster * 4
+        self.reg_out = nn.Conv1d(768, output_size, 1)
+        self.cls_out = nn.Conv1d(768, 2, 1)
+        self.relu = nn.ReLU(True)
+        nn.init.kaiming_uniform_(self.cls_out.weight, mode='fan_in')
+        nn.init.kaiming_uniform_(self.reg_out.weight, mode='fan_in')
+        self.cls_out.bias.data.zero_()
+        self.reg_out.bias.data.zero_()
+        # strict=True reproduces the reference's per-step host checks (fg assert) and IoU metrics
+        # through `iou_fn(corners_pred, corners_gt) -> (n,2)` when one is supplied.
+        # constant table kept on the module's device (not in the state_dict: the reference rebuilds it from
+        # numpy every forward, det_base.py:357 -- an H2D copy that cannot be captured in a hipGraph)
+        self.register_buffer("_mean_size", torch.tensor(self.mean_size_array, dtype=torch.float32),
+                             persistent=False)
+        self.strict = False
+        self.iou_fn = None
+        self.last_logits = None
+
+    def _slice_output(self, output):
+        nb, ns = self.num_bins, self.num_size_cluster
+        center = output[:, 0:3]
+        heading_scores = output[:, 3:3 + nb]
+        heading_res_norm = output[:, 3 + nb:3 + 2 * nb]
+        size_scores = output[:, 3 + 2 * nb:3 + 2 * nb + ns]
+        size_res_norm = output[:, 3 + 2 * nb + ns:].reshape(output.shape[0], ns, 3)
+        return center, heading_scores, heading_res_norm, size_scores, size_res_norm
+
+    def forward(self, data_dicts):
+        point_cloud = data_dicts.get('point_cloud')
+        one_hot_vec = data_dicts.get('one_hot')
+        cls_label = data_dicts.get('cls_label')
+        size_class_label = data_dicts.get('size_class')
+        center_label = data_dicts.get('box3d_center')
+        heading_label = data_dicts.get('box3d_heading')
+        size_label = data_dicts.get('box3d_size')
+        refs = [data_dicts.get('center_ref%d' % i) for i in (1, 2, 3, 4)]
+
+        batch_size = point_cloud.shape[0]
+        xyz = point_cloud[:, :3, :].contiguous()
+        mean_size_array = self._mean_size.to(device=point_cloud.device, dtype=point_cloud.dtype)
+
+        feat1, feat2, feat3, feat4 = self.feat_net(xyz, refs, None, one_hot_vec)
+        x = self.conv_net(feat1, feat2, feat3, feat4)
+        cls_raw = self.cls_out(x)
+        reg_raw = self.reg_out(x)
+        self.last_logits = (cls_raw, reg_raw)
+
+        num_out = reg_raw.shape[2]
+        cls_scores = cls_raw.permute(0, 2, 1).reshape(-1, 2)
+        outputs = reg_raw.permute(0, 2, 1).reshape(-1, reg_raw.shape[1])
+        center_ref2 = refs[1].permute(0, 2, 1).reshape(-1, 3)
+        cls_probs = F.softmax(cls_scores, -1)
+
+        if center_label is None:
+            assert not self.training, 'Please provide labels for training.'
+            center_boxnet, heading_scores, heading_res_norm, size_scores, size_res_norm = self._slice_output(outputs)
+            heading_probs = F.softmax(heading_scores, -1)
+            size_probs = F.softmax(size_scores, -1)
+            heading_pred_label = torch.argmax(heading_probs, -1)
+            size_pred_label = torch.argmax(size_probs, -1)
+            center_preds = center_boxnet + center_ref2
+            heading_preds = box_ops.angle_decode(heading_res_norm, heading_pred_label, num_bins=self.num_bins)
+            size_preds = box_ops.size_decode(size_res_norm, mean_size_array, size_pred_label)
+            return (cls_probs.view(batch_size, -1, 2), center_preds.view(batch_size, -1, 3),
+                    heading_preds.view(batch_size, -1), size_preds.view(batch_size, -1, 3),
+                    heading_probs.view(batch_size, -1, self.num_bins),
+                    size_probs.view(batch_size, -1, self.num_size_cluster))
+
+        # ---- training / validation branch: every loss is a mean over the foreground rows
+        # (cls_label == 1); written as mask-weighted sums over all B*L2 rows -> no nonzero(), no sync.
+        lab = cls_label.view(-1)
+        fg = (lab == 1).to(outputs.dtype)
+        nfg = fg.sum()
+        if self.strict:
+            assert int(nfg.item()) != 0
+        center_boxnet, heading_scores, heading_res_norm, size_scores, size_res_norm = self._slice_output(outputs)
+        heading_probs = F.softmax(heading_scores, -1)
+        size_probs = F.softmax(size_scores, -1)
+        cls_loss = softmax_focal_loss_ignore(cls_probs, lab, ignore_idx=-1)
+
+        center_lab = center_label.unsqueeze(1).expand(-1, num_out, -1).reshape(-1, 3)
+        heading_lab = heading_label.expand(-1, num_out).reshape(-1)
+        size_lab = size_label.unsqueeze(1).expand(-1, num_out, -1).reshape(-1, 3)
+        size_cls_lab = size_class_label.expand(-1, num_out).reshape(-1)
+
+        center_gt_offsets = box_ops.center_encode(center_lab, center_ref2)
+        heading_cls_lab, heading_res_lab = box_ops.angle_encode(heading_lab, num_bins=self.num_bins)
+        size_res_lab = box_ops.size_encode(size_lab, mean_size_array, size_cls_lab)
+
+        mm = lambda v: masked_mean(v, fg, nfg)
+        center_dist = torch.norm(center_gt_offsets - center_boxnet, 2, dim=-1)
+        center_loss = mm(box_ops.huber_elem(center_dist, 3.0))
+        heading_class_loss = mm(F.cross_entropy(heading_scores, heading_cls_lab, reduction='none'))
+        hres_sel = torch.gather(heading_res_norm, 1, heading_cls_lab.view(-1, 1)).squeeze(1)
+        heading_res_norm_loss = mm(box_ops.huber_elem(hres_sel - heading_res_lab, 1.0))
+        size_class_loss = mm(F.cross_entropy(size_scores, size_cls_lab, reduction='none'))
+        sres_sel = torch.gather(size_res_norm, 1, size_cls_lab.view(-1, 1, 1).expand(-1, 1, 3)).squeeze(1)
+        size_res_norm_loss = mm(box_ops.huber_elem(torch.norm(size_res_lab - sres_sel, 2, dim=-1), 1.0))
+
+        center_preds = box_ops.center_decode(center_ref2, center_boxnet)
+        heading = box_ops.angle_decode(heading_res_norm, heading_cls_lab, num_bins=self.num_bins)
+        size = box_ops.size_decode(size_res_norm, mean_size_array, size_cls_lab)
+        corners_gt = box_ops.get_box3d_corners_helper(center_lab, heading_lab, size_lab)
+        corners_gt_flip = box_ops.get_box3d_corners_helper(center_lab, heading_lab + np.pi, size_lab)
+        corners_pred = box_ops.get_box3d_corners_helper(center_preds, heading, size)
+        corners_dist = torch.min(torch.norm(corners_pred - corners_gt, 2, dim=-1).mean(-1),
+                                 torch.norm(corners_pred - corners_gt_flip, 2, dim=-1).mean(-1))
+        corners_loss = mm(box_ops.huber_elem(corners_dist, 1.0))
+
+        L = cfg.LOSS
+        loss = cls_loss + L.BOX_LOSS_WEIGHT * (
+            center_loss + heading_class_loss + size_class_loss + L.HEAD_REG_WEIGHT * heading_res_norm_loss +
+            L.SIZE_REG_WEIGHT * size_res_norm_loss + L.CORNER_LOSS_WEIGHT * corners_loss)
+
+        with torch.no_grad():
+            cls_prec = get_accuracy(cls_probs, lab, ignore=-1)
+            heading_prec = get_accuracy(heading_probs, heading_cls_lab, mask=fg)
+            size_prec = get_accuracy(size_probs, size_cls_lab, mask=fg)
+            zero = torch.zeros((), dtype=cls_prec.dtype, device=cls_prec.device)
+            iou2d_mean = iou3d_mean = iou3d_gt_mean = zero
+            if self.iou_fn is not None:
+                keep = fg.bool()
+                hp = box_ops.angle_decode(heading_res_norm, torch.argmax(heading_probs, -1), num_bins=self.num_bins)
+                sp = box_ops.size_decode(size_res_norm, mean_size_array, torch.argmax(size_probs, -1))
+                cp = box_ops.get_box3d_corners_helper(center_preds, hp, sp)
+                ov = self.iou_fn(cp[keep].detach().cpu().numpy(), corners_gt[keep].detach().cpu().numpy())
+                iou2d_mean = torch.tensor(ov[:, 0].mean()).type_as(cls_prec)
+                iou3d_mean = torch.tensor(ov[:, 1].mean()).type_as(cls_prec)
+                iou3d_gt_mean = torch.tensor((ov[:, 1] >= cfg.IOU_THRESH).mean()).type_as(cls_prec)
+
+        losses = {'total_loss': loss, 'cls_loss': cls_loss, 'center_loss': center_loss,
+                  'head_cls_loss': heading_class_loss, 'head_res_loss': heading_res_norm_loss,
+                  'size_cls_loss': size_class_loss, 'size_res_loss': size_res_norm_loss,
+                  'corners_loss': corners_loss}
+        metrics = {'cls_acc': cls_prec, 'head_acc': heading_prec, 'size_acc': size_prec,
+                   'IoU_2D': iou2d_mean, 'IoU_3D': iou3d_mean, 'IoU_' + str(cfg.IOU_THRESH): iou3d_gt_mean}
+        return losses, metrics

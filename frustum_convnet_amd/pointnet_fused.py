@@ -1,0 +1,176 @@
+"""Host side of the fused PointNet scale: workspaces + autograd binding over the C-ABI.
+
+One call = one scale of models/det_base.py's PointNetFeat: grouping -> (gather, centre, 3 x [1x1 conv, BN,
+ReLU], mask, max over K, one-hot concat) -> pooled (B, C3+nvec, L), forward and backward, all in HIP
+(frustum_convnet_amd/csrc).  Nothing here computes on the host or falls back to torch ops.
+"""
+import ctypes
+
+import torch
+
+from . import _native
+from ._native import PnDesc, PnParams, PnWs
+from .query_depth_point import query_depth_point
+
+
+class Workspace:
+    """Caller-owned scratch of one scale (fcn_pn_ws).  Persistent across steps, recycled through the
+    owning module's free list so that two forwards in flight (before their backwards) never share one."""
+
+    def __init__(self, B, N, L, K, C1, C2, C3, device, need_grad):
+        cap = L * K
+        f32, i32, f64 = torch.float32, torch.int32, torch.float64
+        dev = device
+        self.key = (B, N, L, K, C1, C2, C3, bool(need_grad))
+        self.woff = torch.empty((B, L + 1), dtype=i32, device=dev)
+        self.ent = torch.empty((B, cap, 4), dtype=f32, device=dev)
+        self.ewin = torch.empty((B, cap), dtype=i32, device=dev)
+        self.y2 = torch.empty((B, cap, C2), dtype=f32, device=dev)
+        self.y3 = torch.empty((B, cap, C3), dtype=f32, device=dev)
+        self.stat = torch.zeros((16 + 2 * C2 + 2 * C3,), dtype=f64, device=dev)
+        self.bn = torch.empty((4 * (C1 + C2 + C3),), dtype=f32, device=dev)
+        self.amax = self.gmax = self.dy3 = self.dz2 = self.bstat = self.coef = self.partial = None
+        self.nsplit = 0
+        if need_grad:
+            rows = _native.lib().fcn_pn_wgrad_rows()
+            self.nsplit = B * ((cap + rows - 1) // rows)
+            self.amax = torch.empty((B, L, C3), dtype=i32, device=dev)
+            self.gmax = torch.empty((B, L, C3), dtype=f32, device=dev)
+            self.dy3 = torch.empty((B, cap, C3), dtype=f32, device=dev)
+            self.dz2 = torch.empty((B, cap, C2), dtype=f32, device=dev)
+            self.bstat = torch.zeros((2 * C3 + 2 * C2 + 4 * C1,), dtype=f64, device=dev)
+            self.coef = torch.empty((5 * (C3 + C2),), dtype=f32, device=dev)
+            self.partial = torch.empty((self.nsplit * max(C3 * C2, C2 * C1),), dtype=f32, device=dev)
+        p = lambda t: None if t is None else t.data_ptr()
+        self.c = PnWs(p(self.woff), p(self.ent), p(self.ewin), p(self.y2), p(self.y3), p(self.amax),
+                      p(self.stat), p(self.bn), p(self.gmax), p(self.dy3), p(self.dz2), p(self.bstat),
+                      p(self.coef), p(self.partial), self.nsplit)
+
+
+class WorkspacePool:
+    def __init__(self):
+        self.free = {}
+
+    def acquire(self, *key, device, need_grad):
+        k = tuple(key) + (bool(need_grad), str(device))
+        lst = self.free.setdefault(k, [])
+        if lst:
+            return lst.pop()
+        ws = Workspace(*key, device=device, need_grad=need_grad)
+        ws.pool_key = k
+        return ws
+
+    def release(self, ws):
+        self.free.setdefault(ws.pool_key, []).append(ws)
+
+
+def _params_struct(Ws, gammas, betas, rmeans, rvars, nbts):
+    arr = lambda ts: (ctypes.c_void_p * 3)(*[None if t is None else t.data_ptr() for t in ts])
+    return PnParams(arr(Ws), arr(gammas), arr(betas), arr(rmeans), arr(rvars), arr(nbts))
+
+
+def _forward_impl(pool, cfgt, pc, ref, one_hot, bufs, plist, need_grad):
+    """grouping -> compaction -> fused forward of one scale; returns the workspace still held."""
+    dist, K, training, eps, momentum = cfgt
+    W1, g1, b1, W2, g2, b2, W3, g3, b3 = plist
+    L = _native.lib()
+    B, _, N = pc.shape
+    Lw = ref.shape[2]
+    C1, C2, C3 = W1.shape[0], W2.shape[0], W3.shape[0]
+    nvec = 0 if one_hot is None else one_hot.shape[1]
+    dev = pc.device
+    idx, cnt = query_depth_point(dist, K, pc, ref)
+    ws = pool.acquire(B, N, Lw, K, C1, C2, C3, device=dev, need_grad=need_grad)
+    desc = PnDesc(B, N, Lw, K, C1, C2, C3, nvec, 1 if training else 0, eps, momentum)
+    rmeans, rvars, nbts = bufs
+    Wc = [W1.detach().reshape(C1, 3).contiguous(), W2.detach().reshape(C2, C1).contiguous(),
+          W3.detach().reshape(C3, C2).contiguous()]
+    gs = [g1.detach().contiguous(), g2.detach().contiguous(), g3.detach().contiguous()]
+    bs = [b1.detach().contiguous(), b2.detach().contiguous(), b3.detach().contiguous()]
+    params = _params_struct(Wc, gs, bs, rmeans, rvars, nbts)
+    feat = torch.empty((B, C3 + nvec, Lw), dtype=torch.float32, device=dev)
+    oh = None if one_hot is None else one_hot.detach().contiguous().float()
+    with torch.cuda.device(dev):
+        st = _native.current_stream(dev)
+        _native.check(L.fcn_pn_compact(ctypes.byref(desc), pc.data_ptr(), ref.data_ptr(), idx.data_ptr(),
+                                       cnt.data_ptr(), ctypes.byref(ws.c), st), "fcn_pn_compact")
+        _native.check(L.fcn_pn_forward(ctypes.byref(desc), ctypes.byref(params), cnt.data_ptr(),
+                                       None if oh is None else oh.data_ptr(), ctypes.byref(ws.c),
+                                       feat.data_ptr(), st), "fcn_pn_forward")
+    return feat, idx, cnt, ws, desc, (Wc, gs, bs, cnt, idx, oh)
+
+
+class _PointNetPooled(torch.autograd.Function):
+    """feat = pooled PointNet features.  Differentiable w.r.t. the 9 parameter tensors only (the reference
+    never needs gradients w.r.t. the point cloud either: inputs do not require grad)."""
+
+    @staticmethod
+    def forward(ctx, pool, cfgt, pc, ref, one_hot, bufs, W1, g1, b1, W2, g2, b2, W3, g3, b3):
+        plist = (W1, g1, b1, W2, g2, b2, W3, g3, b3)
+        need_grad = bool(cfgt[2]) and torch.is_grad_enabled() and any(t.requires_grad for t in plist)
+        feat, idx, cnt, ws, desc, keep = _forward_impl(pool, cfgt, pc, ref, one_hot, bufs, plist, need_grad)
+        ctx.pool = pool
+        ctx.live = need_grad
+        if need_grad:
+            ctx.ws, ctx.desc, ctx.keep = ws, desc, keep
+            ctx.shapes = (W1.shape, W2.shape, W3.shape)
+        else:
+            pool.release(ws)
+        ctx.mark_non_differentiable(idx, cnt)
+        return feat, idx, cnt
+
+    @staticmethod
+    def backward(ctx, dfeat, _didx, _dcnt):
+        if not ctx.live:
+            raise RuntimeError("fused PointNet forward ran without saved state (eval mode or no_grad)")
+        L = _native.lib()
+        ws, desc = ctx.ws, ctx.desc
+        Wc, gs, bs, cnt, idx, oh = ctx.keep
+        dev = dfeat.device
+        C1, C2, C3 = desc.C1, desc.C2, desc.C3
+        dfeat = dfeat.contiguous().float()
+        dW = [torch.empty_like(w) for w in Wc]
+        dg = [torch.empty_like(g) for g in gs]
+        db = [torch.empty_like(b) for b in bs]
+        params = _params_struct(Wc, gs, bs, [None] * 3, [None] * 3, [None] * 3)
+        arr = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
+        with torch.cuda.device(dev):
+            _native.check(L.fcn_pn_backward(ctypes.byref(desc), ctypes.byref(params), dfeat.data_ptr(),
+                                            ctypes.byref(ws.c), arr(dW), arr(dg), arr(db),
+                                            _native.current_stream(dev)), "fcn_pn_backward")
+        ctx.pool.release(ws)
+        ctx.ws = None
+        ctx.live = False
+        s1, s2, s3 = ctx.shapes
+        return (None, None, None, None, None, None,
+                dW[0].view(s1), dg[0], db[0], dW[1].view(s2), dg[1], db[1], dW[2].view(s3), dg[2], db[2])
+
+
+def pointnet_pooled(pool, dist, nsample, training, eps, momentum, pc, ref, one_hot, bufs, params):
+    """params = (W1,g1,b1,W2,g2,b2,W3,g3,b3); bufs = ([rm1,rm2,rm3],[rv1,rv2,rv3],[nbt1,nbt2,nbt3])."""
+    if not pc.is_cuda:
+        raise RuntimeError("frustum_convnet_amd: the PointNet hot path runs on an MI355X only "
+                           "(got a %s tensor); there is no CPU fallback" % pc.device)
+    cfgt = (float(dist), int(nsample), bool(training), float(eps), float(momentum))
+    return _PointNetPooled.apply(pool, cfgt, pc, ref, one_hot, bufs, *params)
+
+
+def dense_from_entries(pool, dist, nsample, training, eps, momentum, pc, ref, bufs, params):
+    """Reference-shaped (B, C3, L, K) masked activations of one scale (PointNetModule.forward's return,
+    models/det_base.py:103), expanded from the per-entry conv3 output of the HIP forward: slot k of window
+    l maps to row woff[l] + (k < ne ? k : 0).  Device-side indexing only; no autograd graph."""
+    if not pc.is_cuda:
+        raise RuntimeError("frustum_convnet_amd: MI355X only; no CPU fallback")
+    cfgt = (float(dist), int(nsample), bool(training), float(eps), float(momentum))
+    feat, idx, cnt, ws, desc, _ = _forward_impl(pool, cfgt, pc, ref, None, bufs, params, False)
+    B, L, K, C1, C2, C3 = desc.B, desc.L, desc.K, desc.C1, desc.C2, desc.C3
+    off3 = 4 * (C1 + C2)
+    s3, t3 = ws.bn[off3:off3 + C3], ws.bn[off3 + C3:off3 + 2 * C3]
+    ne = cnt.clamp(min=1).long()
+    k = torch.arange(K, device=pc.device).view(1, 1, K)
+    rows = ws.woff[:, :L].long().unsqueeze(2) + torch.where(k < ne.unsqueeze(2), k, torch.zeros_like(k))
+    y = torch.gather(ws.y3, 1, rows.view(B, L * K, 1).expand(-1, -1, C3)).view(B, L, K, C3)
+    a = torch.relu(y * s3 + t3) * (cnt > 0).view(B, L, 1, 1).float()
+    out = a.permute(0, 3, 1, 2).contiguous()
+    pool.release(ws)
+    return out

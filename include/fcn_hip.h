@@ -1,0 +1,115 @@
+/*
+ * fcn_hip.h -- C-ABI of libfcn_hip.so: the MI355X (gfx950) implementation of Frustum ConvNet's
+ * per-frustum hot path.  Plain pointers + sizes + a HIP stream; no torch types, no hidden
+ * allocation, no implicit synchronisation, no global state.  Every function enqueues work on
+ * `stream` (a hipStream_t passed as void*) and returns 0 or a non-zero code (hipError_t value, or
+ * FCN_E_* below); it is safe to call while the stream is being captured into a hipGraph.
+ *
+ * What each entry point replaces in the reference (paths relative to the reference repo):
+ *
+ *   fcn_query_depth_point_f32   query_depth_point_forward(), PYBIND11 "forward"
+ *                               ops/query_depth_point/query_depth_point_cuda.cpp:25-50 and the launcher +
+ *                               kernel ops/query_depth_point/query_depth_point_cuda_kernel.cu:16-86
+ *   fcn_pn_compact / fcn_pn_forward / fcn_pn_backward
+ *                               the torch ops behind PointNetModule.forward + the max over K in
+ *                               PointNetFeat.forward: gather, centre subtract, 3 x [Conv2d 1x1, BatchNorm2d,
+ *                               ReLU], (cnt>0) mask, torch.max(.,-1), one-hot concat
+ *                               models/det_base.py:75-101,134-157 (+ autograd of the same)
+ *
+ * Buffers are caller-owned.  "ws" buffers are scratch the caller provides (sizes documented per call).
+ */
+#ifndef FCN_HIP_H
+#define FCN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FCN_E_BADARG 10001   /* unsupported shape / null pointer */
+#define FCN_E_LIMIT  10002   /* size beyond a documented limit   */
+
+/* Version / build probe: returns 950 (the only arch this library is built for). */
+int fcn_arch(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sliding-frustum grouping.  Bit-exact restatement of query_depth_point_cuda_kernel.cu:16-65.
+ *   pts_z : z of point 0 of sample 0; element stride pt_stride floats, sample stride pt_bstride floats
+ *           ((B,3,N) layout: xyz+2*N, 1, 3*N;  (B,N,3) layout: xyz+2, 3, 3*N) -- never transposed on device
+ *   ctr_z : same for the m window centres
+ *   idx   : (b,m,nsample) int64, fully written (padding with first hit; zeros for empty windows)
+ *   cnt   : (b,m) int32
+ * ------------------------------------------------------------------------------------------- */
+int fcn_query_depth_point_f32(const float *pts_z, int64_t pt_stride, int64_t pt_bstride,
+                              const float *ctr_z, int64_t ct_stride, int64_t ct_bstride,
+                              int b, int n, int m, float dis_z, int nsample,
+                              int64_t *idx, int32_t *cnt, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * One PointNet scale (PointNetModule + max over K), "entry space" dataflow: every distinct
+ * (window, point) pair is evaluated once and carries its multiplicity as a weight.
+ * Channel widths C1,C2,C3 must be multiples of 64; L <= 8192; K <= 1024.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct fcn_pn_desc {
+    int32_t B, N, L, K;          /* frustums, points per frustum, windows, nsample        */
+    int32_t C1, C2, C3;          /* MLP widths                                              */
+    int32_t nvec;                /* one-hot width appended after pooling (0..)              */
+    int32_t training;            /* 1: batch statistics (+ running-stat update), 0: running */
+    float   eps, momentum;       /* BatchNorm eps (1e-5) and momentum (0.1)                 */
+} fcn_pn_desc;
+
+/* Parameters of the three conv+BN pairs (reference state_dict order: conv{1,2,3}.0.weight,
+ * conv{1,2,3}.1.{weight,bias,running_mean,running_var,num_batches_tracked}). */
+typedef struct fcn_pn_params {
+    const float *W[3];           /* (C1,3) (C2,C1) (C3,C2) row-major                        */
+    const float *gamma[3], *beta[3];
+    float *running_mean[3], *running_var[3];
+    int64_t *num_batches_tracked[3];
+} fcn_pn_params;
+
+/* Scratch + saved-for-backward buffers of one scale.  cap = L*K rows per frustum.
+ * All must stay alive from fcn_pn_forward until fcn_pn_backward has been enqueued. */
+typedef struct fcn_pn_ws {
+    int32_t *woff;               /* (B, L+1)   window row offsets, woff[b][L] = live rows    */
+    float   *ent;                /* (B, cap, 4) (ux,uy,uz,w)                                 */
+    int32_t *ewin;               /* (B, cap)    window of each row                           */
+    float   *y2;                 /* (B, cap, C2) conv2 output (pre-BN)                       */
+    float   *y3;                 /* (B, cap, C3) conv3 output (pre-BN)                       */
+    int32_t *amax;               /* (B, L, C3)  row of the pooled max, -1 = no gradient      */
+    double  *stat;               /* 16 + 2*C2 + 2*C3 doubles: input moments, sum/sumsq       */
+    float   *bn;                 /* 4*(C1+C2+C3) floats: per layer scale, shift, mean, rstd  */
+    /* backward only */
+    float   *gmax;               /* (B, L, C3)  dfeat routed to the max rows                 */
+    float   *dy3;                /* (B, cap, C3)                                             */
+    float   *dz2;                /* (B, cap, C2)                                             */
+    double  *bstat;              /* 2*C3 + 2*C2 + 4*C1 doubles                               */
+    float   *coef;               /* 5*(C3+C2) floats                                         */
+    float   *partial;            /* wgrad partials: nsplit * max(C3*C2, C2*C1) floats        */
+    int32_t  nsplit;             /* capacity of `partial` in splits (>= B * ceil(cap/rows_per_split)) */
+} fcn_pn_ws;
+
+/* rows of one wgrad split (constant of the library; caller sizes ws.partial with it) */
+int fcn_pn_wgrad_rows(void);
+
+/* idx/cnt -> entry list + weighted input moments (ws.woff, ws.ent, ws.ewin, ws.stat[0..9]) */
+int fcn_pn_compact(const fcn_pn_desc *d, const float *pc /*(B,3,N)*/, const float *ref /*(B,3,L)*/,
+                   const int64_t *idx, const int32_t *cnt, const fcn_pn_ws *ws, void *stream);
+
+/* Whole forward of one scale after fcn_pn_compact: feat (B, C3+nvec, L), one_hot (B,nvec) or NULL. */
+int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, const int32_t *cnt,
+                   const float *one_hot, const fcn_pn_ws *ws, float *feat, void *stream);
+
+/* Backward: dfeat (B, C3+nvec, L) -> dW[3], dgamma[3], dbeta[3] (overwritten, not accumulated). */
+int fcn_pn_backward(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dfeat,
+                    const fcn_pn_ws *ws, float *dW[3], float *dgamma[3], float *dbeta[3], void *stream);
+
+/* Launches ONLY the conv GEMM of `layer` (2 or 3) on the state a previous fcn_pn_compact/fcn_pn_forward left in
+ * ws: the unit the roofline figure in bench.py is measured on.  with_stats != 0 keeps the BN-statistics epilogue. */
+int fcn_pn_conv_fwd(const fcn_pn_desc *d, const fcn_pn_params *p, const fcn_pn_ws *ws, int layer,
+                    int with_stats, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FCN_HIP_H */

@@ -1,0 +1,80 @@
+"""-m gpu: HIP sliding-frustum grouping (C-ABI fcn_query_depth_point_f32) vs the oracle: bit-exact."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import grouping
+from helpers import load_golden, golden_inputs, NSAMPLE
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu(dis, ns, xyz1, xyz2):
+    from frustum_convnet_amd.query_depth_point import QueryDepthPoint
+    op = QueryDepthPoint(dis, ns)
+    idx, cnt = op(torch.from_numpy(np.ascontiguousarray(xyz1)).cuda(), torch.from_numpy(np.ascontiguousarray(xyz2)).cuda())
+    assert idx.dtype == torch.int64 and cnt.dtype == torch.int32
+    return idx.cpu().numpy(), cnt.cpu().numpy()
+
+
+def test_testpy_scenario():
+    g = load_golden("qdp_testpy")
+    idx, cnt = _gpu(0.2, 4, g["xyz1"], g["xyz2"])
+    assert np.array_equal(idx, g["idx"]) and np.array_equal(cnt, g["cnt"])
+
+
+@pytest.mark.parametrize("case", ["car_b4_n512", "car_b4_n512_uniform", "refine_b4_n512"])
+def test_golden_full(case):
+    g = load_golden(case)
+    d = golden_inputs(g)
+    for s in range(4):
+        idx, cnt = _gpu(float(g["meta_strides"][s]), NSAMPLE[s], d["point_cloud"], d["center_ref%d" % (s + 1)])
+        assert np.array_equal(cnt, g["cnt%d" % (s + 1)])
+        assert np.array_equal(idx, g["idx%d" % (s + 1)].astype(np.int64))
+
+
+@pytest.mark.parametrize("case", ["car_b32_n1024", "people_b2_n512"])
+def test_golden_sha(case):
+    g = load_golden(case)
+    d = golden_inputs(g)
+    for s in range(4):
+        idx, cnt = _gpu(float(g["meta_strides"][s]), NSAMPLE[s], d["point_cloud"], d["center_ref%d" % (s + 1)])
+        assert np.array_equal(cnt, g["cnt%d" % (s + 1)])
+        assert hashlib.sha256(np.ascontiguousarray(idx).tobytes()).hexdigest() == str(g["idx%d_sha" % (s + 1)])
+
+
+@pytest.mark.parametrize("B,N,M,ns,dis", [(1, 1, 1, 1, 0.5), (2, 63, 5, 7, 0.3), (2, 65, 17, 64, 0.3),
+                                          (3, 1000, 33, 200, 0.05), (1, 20000, 9, 16, 0.01), (2, 300, 70, 1, 1.0)])
+def test_ragged_shapes(B, N, M, ns, dis):
+    rng = np.random.RandomState(N + M)
+    xyz1 = rng.rand(B, 3, N).astype(np.float32)
+    xyz2 = rng.rand(B, 3, M).astype(np.float32)
+    xyz2[:, 2, 0] = 5.0                        # an empty window
+    e_idx, e_cnt = grouping.query_depth_point_c(dis, ns, xyz1, xyz2)
+    idx, cnt = _gpu(dis, ns, xyz1, xyz2)
+    assert np.array_equal(cnt, e_cnt) and np.array_equal(idx, e_idx)
+    assert cnt[:, 0].max() == 0 and not idx[:, 0].any()
+
+
+def test_boundary_is_strict_and_fp32():
+    xyz1 = np.zeros((1, 3, 8), dtype=np.float32)
+    xyz1[0, 2] = [5.0, 1.0, 1.25, 0.75, 1.0, 1.1, 0.9, 1.0]
+    xyz2 = np.zeros((1, 3, 3), dtype=np.float32)
+    xyz2[0, 2] = [1.0, 3.0, 5.25]
+    idx, cnt = _gpu(0.25, 3, xyz1, xyz2)
+    assert cnt.tolist() == [[3, 0, 0]] and idx[0, 0].tolist() == [1, 4, 5]
+    idx, cnt = _gpu(0.2500001, 8, xyz1, xyz2)
+    assert cnt.tolist() == [[7, 0, 1]] and idx[0, 0].tolist() == [1, 2, 3, 4, 5, 6, 7, 1]
+
+
+def test_kernel_native_layout_matches():
+    from frustum_convnet_amd.query_depth_point import query_depth_point, query_depth_point_bn3
+    g = load_golden("car_b4_n512")
+    d = golden_inputs(g)
+    pc = torch.from_numpy(d["point_cloud"]).cuda()
+    ref = torch.from_numpy(d["center_ref2"]).cuda()
+    a = query_depth_point(0.5, 64, pc, ref)
+    b = query_depth_point_bn3(0.5, 64, pc.permute(0, 2, 1).contiguous(), ref.permute(0, 2, 1).contiguous())
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
