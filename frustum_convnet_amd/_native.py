@@ -49,6 +49,9 @@ def lib():
         raise ImportError(
             "frustum_convnet_amd: %s not found -- build it with `python -m frustum_convnet_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the hot path." % LIB_PATH)
+    # torch bundles its own libamdhip64; load it FIRST so this library binds to the same HIP runtime (streams and
+    # device pointers are only meaningful inside one runtime instance).
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     L.fcn_arch.restype = ctypes.c_int
     L.fcn_arch.argtypes = []

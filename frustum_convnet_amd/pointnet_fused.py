@@ -71,7 +71,7 @@ def _params_struct(Ws, gammas, betas, rmeans, rvars, nbts):
 
 def _forward_impl(pool, cfgt, pc, ref, one_hot, bufs, plist, need_grad):
     """grouping -> compaction -> fused forward of one scale; returns the workspace still held."""
-    dist, K, training, eps, momentum = cfgt
+    dist, K, training, eps, momentum = cfgt[:5]
     W1, g1, b1, W2, g2, b2, W3, g3, b3 = plist
     L = _native.lib()
     B, _, N = pc.shape
@@ -107,7 +107,7 @@ class _PointNetPooled(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pool, cfgt, pc, ref, one_hot, bufs, W1, g1, b1, W2, g2, b2, W3, g3, b3):
         plist = (W1, g1, b1, W2, g2, b2, W3, g3, b3)
-        need_grad = bool(cfgt[2]) and torch.is_grad_enabled() and any(t.requires_grad for t in plist)
+        need_grad = bool(cfgt[5])     # decided by the caller: grad mode is always off inside Function.forward
         feat, idx, cnt, ws, desc, keep = _forward_impl(pool, cfgt, pc, ref, one_hot, bufs, plist, need_grad)
         ctx.pool = pool
         ctx.live = need_grad
@@ -151,7 +151,8 @@ def pointnet_pooled(pool, dist, nsample, training, eps, momentum, pc, ref, one_h
     if not pc.is_cuda:
         raise RuntimeError("frustum_convnet_amd: the PointNet hot path runs on an MI355X only "
                            "(got a %s tensor); there is no CPU fallback" % pc.device)
-    cfgt = (float(dist), int(nsample), bool(training), float(eps), float(momentum))
+    need_grad = bool(training) and torch.is_grad_enabled() and any(t.requires_grad for t in params)
+    cfgt = (float(dist), int(nsample), bool(training), float(eps), float(momentum), need_grad)
     return _PointNetPooled.apply(pool, cfgt, pc, ref, one_hot, bufs, *params)
 
 

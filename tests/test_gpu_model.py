@@ -128,4 +128,5 @@ def test_two_forwards_before_backward_do_not_share_workspace():
     m.zero_grad()
     l2["total_loss"].backward()
     # second graph saw updated running stats but identical batch statistics -> same gradients
-    assert torch.allclose(g1, m.feat_net.pointnet4.conv3[0].weight.grad, rtol=1e-4, atol=1e-6)
+    g2 = m.feat_net.pointnet4.conv3[0].weight.grad
+    assert float((g1 - g2).abs().max()) <= 1e-4 * float(g1.abs().max())
