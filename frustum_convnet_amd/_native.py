@@ -25,7 +25,7 @@ class PnParams(ctypes.Structure):
 
 
 class PnWs(ctypes.Structure):
-    _fields_ = [("woff", c_fp), ("ent", c_fp), ("ewin", c_fp), ("y2", c_fp), ("y3", c_fp), ("amax", c_fp),
+    _fields_ = [("woff", c_fp), ("ent", c_fp), ("ewin", c_fp), ("tiles", c_fp), ("y2", c_fp), ("y3", c_fp), ("amax", c_fp),
                 ("stat", c_fp), ("bn", c_fp), ("gmax", c_fp), ("dy3", c_fp), ("dz2", c_fp), ("bstat", c_fp),
                 ("coef", c_fp), ("partial", c_fp), ("nsplit", ctypes.c_int32)]
 

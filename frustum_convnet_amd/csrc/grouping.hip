@@ -158,6 +158,39 @@ __global__ __launch_bounds__(CP_THREADS) void compact_kernel(
     if (tid < 10) atomic_add_f64(&mom[tid], red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
 }
 
+// Live-tile list: tiles[0] = number of 128-row tiles that hold at least one live row, tiles[4+i] = b*tps + t.
+// Every GEMM kernel indexes its row tile through this list, so grids are dense in live work and the wgrad
+// splits are balanced no matter how the rows distribute over frustums.
+__global__ __launch_bounds__(256) void tile_list_kernel(const int32_t *__restrict__ woff, int B, int L, int tps,
+                                                        int32_t *__restrict__ tiles)
+{
+    __shared__ int wsum[4];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < B; b0 += 256) {
+        const int b = b0 + tid;
+        const int nt = (b < B) ? (woff[(int64_t)b * (L + 1) + L] + 127) / 128 : 0;
+        int incl = nt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int base = carry_s;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        const int off = base + incl - nt;
+        for (int t = 0; t < nt; ++t) tiles[4 + off + t] = b * tps + t;
+        __syncthreads();
+        if (tid == 255) carry_s = base + incl;
+        __syncthreads();
+    }
+    if (tid == 0) tiles[0] = carry_s;
+}
+
 extern "C" int fcn_pn_compact(const fcn_pn_desc *d, const float *pc, const float *ref,
                               const int64_t *idx, const int32_t *cnt, const fcn_pn_ws *ws, void *stream)
 {
@@ -171,6 +204,9 @@ extern "C" int fcn_pn_compact(const fcn_pn_desc *d, const float *pc, const float
     hipLaunchKernelGGL(compact_kernel, grid, dim3(CP_THREADS), sizeof(int) * (size_t)(d->L + 1), st,
                        pc, ref, idx, cnt, d->N, d->L, d->K, ws->woff, (float4 *)ws->ent, ws->ewin,
                        ws->stat + FCN_STAT_MOM);
+    FCN_CHECK_LAUNCH();
+    const int tps = (d->L * d->K + 127) / 128;
+    hipLaunchKernelGGL(tile_list_kernel, dim3(1), dim3(256), 0, st, ws->woff, d->B, d->L, tps, ws->tiles);
     FCN_CHECK_LAUNCH();
     return 0;
 }

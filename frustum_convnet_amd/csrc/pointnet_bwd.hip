@@ -18,54 +18,55 @@
 
 #define LDT 129                 // transposed (k-major) staging of a 128-row tile
 #define MAXC 512
-#define WG_ROWS 1024            // rows of one wgrad split
-#define PWB 32                  // windows per poolbwd workgroup
+#define WG_ROWS 128             // rows of one row tile (wgrad splits are multiples of it)
+#define PWB 64                  // windows per poolbwd workgroup
 
 extern "C" int fcn_pn_wgrad_rows(void) { return WG_ROWS; }
 
 // ------------------------------------------------------------------------------------------------
+// One wave = one window x 64 channels (lane = channel); a workgroup covers PWB consecutive windows, stages
+// its dfeat tile through LDS (dfeat is (B,C,L): 64-B runs along L), routes the gradient to the max rows and
+// reduces dbeta3 / dgamma3 over its windows before one fp64 atomic pair per channel.
 __global__ __launch_bounds__(GT) void poolbwd_kernel(
     const float *__restrict__ dfeat, const int32_t *__restrict__ amax, const float *__restrict__ y3,
     const float *__restrict__ bn3, float *__restrict__ gmax, double *__restrict__ bstat,
-    int L, int cap, int C3, int CT, int cpb)
+    int L, int cap, int C3, int CT)
 {
-    __shared__ float dS[256 * (PWB + 1)];
-    const int tid = threadIdx.x;
-    const int b = blockIdx.z, l0 = blockIdx.x * PWB, c0 = blockIdx.y * cpb;
-    for (int f = tid; f < cpb * PWB; f += GT) {
+    __shared__ float dS[64 * (PWB + 1)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, l0 = blockIdx.x * PWB, c0 = blockIdx.y * 64;
+    for (int f = tid; f < 64 * PWB; f += GT) {
         const int cc = f / PWB, wl = f % PWB, l = l0 + wl;
         dS[cc * (PWB + 1) + wl] = (l < L) ? dfeat[((int64_t)b * CT + c0 + cc) * L + l] : 0.f;
     }
     __syncthreads();
-    const int cl = tid % cpb, wlane = tid / cpb, nwl = GT / cpb;
-    const int c = c0 + cl;
+    const int c = c0 + lane;
     const float mean = bn3[2 * C3 + c], rstd = bn3[3 * C3 + c];
     float sB = 0.f, sG = 0.f;
-    for (int wl = wlane; wl < PWB; wl += nwl) {
+    for (int wl = wave; wl < PWB; wl += 4) {
         const int l = l0 + wl;
         if (l >= L) break;
         const int64_t o = ((int64_t)b * L + l) * C3 + c;
         const int am = amax[o];
         float g = 0.f;
         if (am >= 0) {
-            g = dS[cl * (PWB + 1) + wl];
+            g = dS[lane * (PWB + 1) + wl];
             const float xh = (y3[((int64_t)b * cap + am) * C3 + c] - mean) * rstd;
             sB += g;
             sG = fmaf(g, xh, sG);
         }
         gmax[o] = g;
     }
-    // combine the window lanes of one channel through LDS, then one fp64 atomic pair per channel
     __syncthreads();
     float *red = dS;
     red[tid * 2] = sB;
     red[tid * 2 + 1] = sG;
     __syncthreads();
-    if (tid < cpb) {
+    if (tid < 64) {
         double a = 0.0, g = 0.0;
-        for (int w = 0; w < nwl; ++w) {
-            a += (double)red[(w * cpb + tid) * 2];
-            g += (double)red[(w * cpb + tid) * 2 + 1];
+        for (int w = 0; w < 4; ++w) {
+            a += (double)red[(w * 64 + tid) * 2];
+            g += (double)red[(w * 64 + tid) * 2 + 1];
         }
         atomic_add_f64(&bstat[c0 + tid], a);
         atomic_add_f64(&bstat[C3 + c0 + tid], g);
@@ -95,6 +96,7 @@ __global__ void bnbwd_finalize_kernel(const double *__restrict__ bstat, const fl
 struct DgradArgs {
     const float4 *ent;      // (B,cap)
     const int32_t *woff;    // (B,L+1)
+    const int32_t *tiles;   // live-tile list
     const int32_t *ewin;    // (B,cap)            LAYER 3
     const float *ycur;      // y3 (LAYER 3) / y2 (LAYER 2): pre-BN output of the layer being differentiated
     const int32_t *amax;    // (B,L,C3)           LAYER 3
@@ -111,10 +113,14 @@ struct DgradArgs {
     int L, cap, CRED, CPREV, tps;
 };
 
-template <int LAYER, int NT>
-__global__ __launch_bounds__(GT) void dgrad_kernel(DgradArgs a)
+template <int LAYER, int NT, int WN>
+__global__ __launch_bounds__(128 * WN) void dgrad_kernel(DgradArgs a)
 {
-    constexpr int LDB = 64 * NT + 4;
+    constexpr int NTHR = 128 * WN;
+    constexpr int TN = 32 * NT * WN;
+    constexpr int LDB = TN + 4;
+    constexpr int NA4 = 1024 / NTHR;          // row-quads of the A tile per thread per chunk
+    constexpr int NB4 = TN * 8 / NTHR;        // float4 of W per thread per chunk
     __shared__ __attribute__((aligned(16))) float As[KC * LDT];
     __shared__ __attribute__((aligned(16))) float Bs[KC * LDB];
     __shared__ float coefS[5 * MAXC];
@@ -122,24 +128,26 @@ __global__ __launch_bounds__(GT) void dgrad_kernel(DgradArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int b = blockIdx.x / a.tps, t = blockIdx.x % a.tps;
+    const int wm = wave / WN, wn = wave % WN;
+    if ((int)blockIdx.x >= a.tiles[0]) return;
+    const int code = a.tiles[4 + blockIdx.x];
+    const int b = code / a.tps, t = code % a.tps;
     const int nent = a.woff[(int64_t)b * (a.L + 1) + a.L];
     const int row0 = t * 128;
-    if (row0 >= nent) return;
     const int nvalid = min(128, nent - row0);
     const int64_t grow0 = (int64_t)b * a.cap + row0;
-    const int k0 = blockIdx.y * 64 * NT;          // first output column (channel of the previous layer)
+    const int k0 = blockIdx.y * TN;               // first output column (channel of the previous layer)
     const int CRED = a.CRED, CPREV = a.CPREV;
 
-    for (int i = tid; i < 5 * CRED; i += GT) coefS[i] = a.coef[i];
+    for (int i = tid; i < 5 * CRED; i += NTHR) coefS[i] = a.coef[i];
     if (tid < 128) uS[tid] = (tid < nvalid) ? a.ent[grow0 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int kq = tid & 7, rb = tid >> 3;
-    int wrow[4];          // LAYER 3: window base offset into amax/gmax of this thread's 4 rows
+    constexpr int RSTEP = NTHR / 8;               // rows between a thread's consecutive A quads
+    int wrow[NA4];        // LAYER 3: window of this thread's rows
     if constexpr (LAYER == 3) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = rb + 32 * i;
+        for (int i = 0; i < NA4; ++i) {
+            const int r = rb + RSTEP * i;
             wrow[i] = (r < nvalid) ? a.ewin[grow0 + r] : 0;
         }
     }
@@ -147,15 +155,15 @@ __global__ __launch_bounds__(GT) void dgrad_kernel(DgradArgs a)
 
     f32x16 acc[2][NT];
     acc_zero<2, NT>(acc);
-    float4 ry[4], rz[4];
-    int4 rm[4];
-    float4 rw[2 * NT];
+    float4 ry[NA4], rz[NA4];
+    int4 rm[NA4];
+    float4 rw[NB4];
     const int nchunk = CRED / KC;
 
     auto load_chunk = [&](int c) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = rb + 32 * i;
+        for (int i = 0; i < NA4; ++i) {
+            const int r = rb + RSTEP * i;
             const int nq = c * KC + 4 * kq;
             if (r < nvalid) {
                 ry[i] = *(const float4 *)(a.ycur + (grow0 + r) * CRED + nq);
@@ -173,9 +181,9 @@ __global__ __launch_bounds__(GT) void dgrad_kernel(DgradArgs a)
             }
         }
 #pragma unroll
-        for (int i = 0; i < 2 * NT; ++i) {
-            const int f = tid + GT * i;
-            const int nn = f / (16 * NT), cq = f % (16 * NT);
+        for (int i = 0; i < NB4; ++i) {
+            const int f = tid + NTHR * i;
+            const int nn = f / (TN / 4), cq = f % (TN / 4);
             rw[i] = *(const float4 *)(a.W + (int64_t)(c * KC + nn) * CPREV + k0 + 4 * cq);
         }
     };
@@ -183,8 +191,8 @@ __global__ __launch_bounds__(GT) void dgrad_kernel(DgradArgs a)
     load_chunk(0);
     for (int c = 0; c < nchunk; ++c) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = rb + 32 * i;
+        for (int i = 0; i < NA4; ++i) {
+            const int r = rb + RSTEP * i;
             const bool ok = r < nvalid;
             const float w = uS[r].w;
             const int rloc = row0 + r;
@@ -210,9 +218,9 @@ __global__ __launch_bounds__(GT) void dgrad_kernel(DgradArgs a)
             }
         }
 #pragma unroll
-        for (int i = 0; i < 2 * NT; ++i) {
-            const int f = tid + GT * i;
-            const int nn = f / (16 * NT), cq = f % (16 * NT);
+        for (int i = 0; i < NB4; ++i) {
+            const int f = tid + NTHR * i;
+            const int nn = f / (TN / 4), cq = f % (TN / 4);
             *(float4 *)(Bs + nn * LDB + 4 * cq) = rw[i];
         }
         __syncthreads();
@@ -291,6 +299,7 @@ __global__ __launch_bounds__(GT) void dgrad_kernel(DgradArgs a)
 struct WgradArgs {
     const float4 *ent;
     const int32_t *woff;
+    const int32_t *tiles;   // live-tile list
     const float *dy;        // LAYER 3: dy3 (B,cap,C3)
     const float *dz;        // LAYER 2: dz2 (B,cap,C2)
     const float *ycur;      // LAYER 2: y2 (for xhat2)
@@ -299,10 +308,12 @@ struct WgradArgs {
     const float *bn_prev;   // scale, shift of the previous layer's BN
     const float *W1;        // LAYER 2
     float *partial;         // (nsplit, COUT, CIN)
-    int L, cap, COUT, CIN, spb;
+    int L, cap, COUT, CIN, tps, tpb;   // tpb = live row tiles per split
 };
 
-// dW[n][k] = sum_rows dy[row][n] * a_prev[row][k]; workgroup tile (64*MT) x (64*NT), rows split by WG_ROWS.
+// dW[n][k] = sum_rows dy[row][n] * a_prev[row][k]; workgroup tile (64*MT) x (64*NT).  Split s reduces the
+// rows of live tiles [s*tpb, (s+1)*tpb) and writes one partial; wgrad_reduce sums the live partials in a fixed
+// order (deterministic, no float atomics).
 template <int LAYER, int MT, int NT>
 __global__ __launch_bounds__(GT) void wgrad_kernel(WgradArgs a)
 {
@@ -313,17 +324,16 @@ __global__ __launch_bounds__(GT) void wgrad_kernel(WgradArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int b = blockIdx.x / a.spb, sp = blockIdx.x % a.spb;
-    const int nent = a.woff[(int64_t)b * (a.L + 1) + a.L];
-    const int rbeg = sp * WG_ROWS;
-    if (rbeg >= nent) return;
-    const int rend = min(nent, rbeg + WG_ROWS);
+    const int ntile = a.tiles[0];
+    const int t_beg = blockIdx.x * a.tpb;
+    if (t_beg >= ntile) return;
+    const int t_end = min(ntile, t_beg + a.tpb);
+    const int nq = (t_end - t_beg) * 4;                 // 32-row chunks to reduce
     const int n0 = blockIdx.y * 64 * MT, k0 = blockIdx.z * 64 * NT;
     const int COUT = a.COUT, CIN = a.CIN;
-    const int64_t gbase = (int64_t)b * a.cap;
 
     // per-thread constant columns of the two staged operands
-    const int acq = tid % (16 * MT), arr = tid / (16 * MT);     // A: column quad, first row; rows step 16/MT
+    const int acq = tid % (16 * MT), arr = tid / (16 * MT);
     const int bcq = tid % (16 * NT), brr = tid / (16 * NT);
     constexpr int ARS = 16 / MT, BRS = 16 / NT;                  // row stride between a thread's float4s
     float cf[5][4];
@@ -351,18 +361,31 @@ __global__ __launch_bounds__(GT) void wgrad_kernel(WgradArgs a)
     float4 ra[2 * MT], ra2[2 * MT], rb4[2 * NT];
     float rwt[2 * MT];
 
-    auto load_chunk = [&](int r0) {
+    // chunk q -> (global row of its first row, number of valid rows left in its tile from there)
+    auto chunk_rows = [&](int q, int64_t &g0, int &left) {
+        const int code = a.tiles[4 + t_beg + (q >> 2)];
+        const int b = code / a.tps, t = code % a.tps;
+        const int nent = a.woff[(int64_t)b * (a.L + 1) + a.L];
+        const int r0 = t * 128 + (q & 3) * KC;
+        g0 = (int64_t)b * a.cap + r0;
+        left = nent - r0;                                      // may be <= 0 for the tail chunks of a tile
+    };
+
+    auto load_chunk = [&](int q) {
+        int64_t g0;
+        int left;
+        chunk_rows(q, g0, left);
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
-            const int row = r0 + arr + ARS * i;
-            if (row < rend) {
-                const int64_t o = (gbase + row) * COUT + n0 + 4 * acq;
+            const int rr = arr + ARS * i;
+            if (rr < left) {
+                const int64_t o = (g0 + rr) * COUT + n0 + 4 * acq;
                 if constexpr (LAYER == 3) {
                     ra[i] = *(const float4 *)(a.dy + o);
                 } else {
                     ra[i] = *(const float4 *)(a.dz + o);
                     ra2[i] = *(const float4 *)(a.ycur + o);
-                    rwt[i] = a.ent[gbase + row].w;
+                    rwt[i] = a.ent[g0 + rr].w;
                 }
             } else {
                 ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -371,22 +394,25 @@ __global__ __launch_bounds__(GT) void wgrad_kernel(WgradArgs a)
         }
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {
-            const int row = r0 + brr + BRS * i;
-            if (row < rend) {
-                if constexpr (LAYER == 3) rb4[i] = *(const float4 *)(a.yprev + (gbase + row) * CIN + k0 + 4 * bcq);
-                else rb4[i] = a.ent[gbase + row];
+            const int rr = brr + BRS * i;
+            if (rr < left) {
+                if constexpr (LAYER == 3) rb4[i] = *(const float4 *)(a.yprev + (g0 + rr) * CIN + k0 + 4 * bcq);
+                else rb4[i] = a.ent[g0 + rr];
             } else {
                 rb4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
 
-    load_chunk(rbeg);
-    for (int r0 = rbeg; r0 < rend; r0 += KC) {
+    load_chunk(0);
+    for (int q = 0; q < nq; ++q) {
+        int64_t g0_;
+        int left;
+        chunk_rows(q, g0_, left);
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
             const int rr = arr + ARS * i;
-            const bool ok = (r0 + rr) < rend;
+            const bool ok = rr < left;
             float4 v = ra[i];
             if constexpr (LAYER == 2) {
                 const float dzv[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
@@ -404,7 +430,7 @@ __global__ __launch_bounds__(GT) void wgrad_kernel(WgradArgs a)
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {
             const int rr = brr + BRS * i;
-            const bool ok = (r0 + rr) < rend;
+            const bool ok = rr < left;
             float o[4];
             if constexpr (LAYER == 3) {
                 const float yv[4] = {rb4[i].x, rb4[i].y, rb4[i].z, rb4[i].w};
@@ -419,7 +445,7 @@ __global__ __launch_bounds__(GT) void wgrad_kernel(WgradArgs a)
                 ok ? make_float4(o[0], o[1], o[2], o[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
-        if (r0 + KC < rend) load_chunk(r0 + KC);
+        if (q + 1 < nq) load_chunk(q + 1);
         mma_chunk<MT, NT, LDA, LDB>(As, Bs, wm * 32 * MT, wn * 32 * NT, acc);
         __syncthreads();
     }
@@ -437,17 +463,24 @@ __global__ __launch_bounds__(GT) void wgrad_kernel(WgradArgs a)
             }
 }
 
-__global__ void wgrad_reduce_kernel(const float *__restrict__ partial, const int32_t *__restrict__ woff,
-                                    int L, int spb, int nsplit, int64_t nelem, float *__restrict__ out)
+// out[i] = sum over the live splits (fixed order -> deterministic); 4 independent loads in flight per thread.
+__global__ void wgrad_reduce_kernel(const float *__restrict__ partial, const int32_t *__restrict__ tiles, int tpb,
+                                    int64_t nelem, float *__restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nelem) return;
-    float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) {
-        const int b = sp / spb, q = sp % spb;
-        if (q * WG_ROWS < woff[(int64_t)b * (L + 1) + L]) s += partial[(int64_t)sp * nelem + i];
+    const int nsp = (tiles[0] + tpb - 1) / tpb;
+    const float *p = partial + i;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int sp = 0;
+    for (; sp + 4 <= nsp; sp += 4) {
+        s0 += p[(int64_t)sp * nelem];
+        s1 += p[(int64_t)(sp + 1) * nelem];
+        s2 += p[(int64_t)(sp + 2) * nelem];
+        s3 += p[(int64_t)(sp + 3) * nelem];
     }
-    out[i] = s;
+    for (; sp < nsp; ++sp) s0 += p[(int64_t)sp * nelem];
+    out[i] = (s0 + s1) + (s2 + s3);
 }
 
 // dW1, dgamma1, dbeta1 from Q = sum_e dz1 (1, u) and the forward's weighted moments of u.
@@ -483,24 +516,49 @@ template <int LAYER>
 static int launch_dgrad(const DgradArgs &a, int B, hipStream_t st)
 {
     if (a.CRED % 64 || a.CPREV % 64 || a.CRED > MAXC) return FCN_E_BADARG;
-    if (a.CPREV % 128 == 0) {
-        hipLaunchKernelGGL((dgrad_kernel<LAYER, 2>), dim3(B * a.tps, a.CPREV / 128), dim3(GT), 0, st, a);
+    const unsigned nt = (unsigned)(B * a.tps);
+    if (a.CPREV % 256 == 0) {
+        hipLaunchKernelGGL((dgrad_kernel<LAYER, 2, 4>), dim3(nt, a.CPREV / 256), dim3(512), 0, st, a);
+    } else if (a.CPREV % 128 == 0) {
+        hipLaunchKernelGGL((dgrad_kernel<LAYER, 2, 2>), dim3(nt, a.CPREV / 128), dim3(256), 0, st, a);
     } else {
-        hipLaunchKernelGGL((dgrad_kernel<LAYER, 1>), dim3(B * a.tps, a.CPREV / 64), dim3(GT), 0, st, a);
+        hipLaunchKernelGGL((dgrad_kernel<LAYER, 1, 2>), dim3(nt, a.CPREV / 64), dim3(256), 0, st, a);
     }
     FCN_CHECK_LAUNCH();
     return 0;
 }
 
+// Row tiles per split: keep >= ~512 workgroups in flight.  The live-tile count is only known on the device, so
+// the estimate uses the typical occupancy of the sliding frustums (each point falls into ~2 windows per scale:
+// ~2*N rows per frustum), clamped to the worst case.
+static int pick_tpb(int B, int N, int tps, int out_tiles)
+{
+    long est = ((long)2 * N * B + 127) / 128;
+    const long worst = (long)B * tps;
+    if (est > worst) est = worst;
+    long tpb = est * out_tiles / 512;
+    if (tpb < 1) tpb = 1;
+    if (tpb > 16) tpb = 16;
+    return (int)tpb;
+}
+
 template <int LAYER>
-static int launch_wgrad(const WgradArgs &a, int B, hipStream_t st)
+static int launch_wgrad(WgradArgs &a, int B, int N, int nsplit_cap, hipStream_t st, float *out)
 {
     const bool m2 = (a.COUT % 128 == 0), n2 = (a.CIN % 128 == 0);
-    dim3 grid(B * a.spb, a.COUT / (m2 ? 128 : 64), a.CIN / (n2 ? 128 : 64));
+    const int oy = a.COUT / (m2 ? 128 : 64), oz = a.CIN / (n2 ? 128 : 64);
+    a.tpb = pick_tpb(B, N, a.tps, oy * oz);
+    const int nsplit = (B * a.tps + a.tpb - 1) / a.tpb;
+    if (nsplit > nsplit_cap) return FCN_E_BADARG;
+    dim3 grid(nsplit, oy, oz);
     if (m2 && n2) hipLaunchKernelGGL((wgrad_kernel<LAYER, 2, 2>), grid, dim3(GT), 0, st, a);
     else if (m2) hipLaunchKernelGGL((wgrad_kernel<LAYER, 2, 1>), grid, dim3(GT), 0, st, a);
     else if (n2) hipLaunchKernelGGL((wgrad_kernel<LAYER, 1, 2>), grid, dim3(GT), 0, st, a);
     else hipLaunchKernelGGL((wgrad_kernel<LAYER, 1, 1>), grid, dim3(GT), 0, st, a);
+    FCN_CHECK_LAUNCH();
+    const int64_t ne = (int64_t)a.COUT * a.CIN;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, a.partial, a.tiles,
+                       a.tpb, ne, out);
     FCN_CHECK_LAUNCH();
     return 0;
 }
@@ -517,8 +575,7 @@ extern "C" int fcn_pn_backward(const fcn_pn_desc *d, const fcn_pn_params *p, con
     const int cap = L * K;
     const double M = (double)B * (double)L * (double)K;
     const int tps = (cap + 127) / 128;
-    const int spb = (cap + WG_ROWS - 1) / WG_ROWS;
-    if (ws->nsplit < B * spb) return FCN_E_BADARG;
+    if (ws->nsplit < B * tps) return FCN_E_BADARG;
     const float *bn1 = ws->bn + fcn_bn_off(0, C1, C2);
     const float *bn2 = ws->bn + fcn_bn_off(1, C1, C2);
     const float *bn3 = ws->bn + fcn_bn_off(2, C1, C2);
@@ -528,33 +585,26 @@ extern "C" int fcn_pn_backward(const fcn_pn_desc *d, const fcn_pn_params *p, con
     hipError_t e = hipMemsetAsync(ws->bstat, 0, sizeof(double) * (size_t)(2 * C3 + 2 * C2 + 4 * C1), st);
     if (e != hipSuccess) return (int)e;
 
-    const int cpb = C3 >= 256 ? 256 : C3;
-    if (GT % cpb || C3 % cpb) return FCN_E_BADARG;
-    hipLaunchKernelGGL(poolbwd_kernel, dim3((L + PWB - 1) / PWB, C3 / cpb, B), dim3(GT), 0, st, dfeat, ws->amax,
-                       ws->y3, bn3, ws->gmax, bs3, L, cap, C3, C3 + d->nvec, cpb);
+    hipLaunchKernelGGL(poolbwd_kernel, dim3((L + PWB - 1) / PWB, C3 / 64, B), dim3(GT), 0, st, dfeat, ws->amax,
+                       ws->y3, bn3, ws->gmax, bs3, L, cap, C3, C3 + d->nvec);
     FCN_CHECK_LAUNCH();
     hipLaunchKernelGGL(bnbwd_finalize_kernel, dim3((C3 + 63) / 64), dim3(64), 0, st, bs3, p->gamma[2], bn3, C3, M,
                        coef3, dgamma[2], dbeta[2]);
     FCN_CHECK_LAUNCH();
 
     DgradArgs g;
-    g.ent = (const float4 *)ws->ent; g.woff = ws->woff; g.ewin = ws->ewin; g.L = L; g.cap = cap; g.tps = tps;
+    g.ent = (const float4 *)ws->ent; g.woff = ws->woff; g.tiles = ws->tiles; g.ewin = ws->ewin; g.L = L; g.cap = cap; g.tps = tps;
     g.ycur = ws->y3; g.amax = ws->amax; g.gmax = ws->gmax; g.dzcur = nullptr; g.coef = coef3; g.W = p->W[2];
     g.dybuf = ws->dy3; g.yprev = ws->y2; g.bn_prev = bn2; g.W1 = nullptr; g.dzprev = ws->dz2; g.bstat_prev = bs2;
     g.CRED = C3; g.CPREV = C2;
     FCN_TRY(launch_dgrad<3>(g, B, st));
 
     WgradArgs w;
-    w.ent = (const float4 *)ws->ent; w.woff = ws->woff; w.L = L; w.cap = cap; w.spb = spb; w.partial = ws->partial;
+    w.ent = (const float4 *)ws->ent; w.woff = ws->woff; w.tiles = ws->tiles; w.L = L; w.cap = cap; w.tps = tps; w.tpb = 1;
+    w.partial = ws->partial;
     w.dy = ws->dy3; w.dz = nullptr; w.ycur = nullptr; w.coef = nullptr; w.yprev = ws->y2; w.bn_prev = bn2;
     w.W1 = nullptr; w.COUT = C3; w.CIN = C2;
-    FCN_TRY(launch_wgrad<3>(w, B, st));
-    {
-        const int64_t ne = (int64_t)C3 * C2;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, ws->partial,
-                           ws->woff, L, spb, B * spb, ne, dW[2]);
-        FCN_CHECK_LAUNCH();
-    }
+    FCN_TRY(launch_wgrad<3>(w, B, d->N, ws->nsplit, st, dW[2]));
 
     hipLaunchKernelGGL(bnbwd_finalize_kernel, dim3((C2 + 63) / 64), dim3(64), 0, st, bs2, p->gamma[1], bn2, C2, M,
                        coef2, dgamma[1], dbeta[1]);
@@ -567,13 +617,7 @@ extern "C" int fcn_pn_backward(const fcn_pn_desc *d, const fcn_pn_params *p, con
 
     w.dy = nullptr; w.dz = ws->dz2; w.ycur = ws->y2; w.coef = coef2; w.yprev = nullptr; w.bn_prev = bn1;
     w.W1 = p->W[0]; w.COUT = C2; w.CIN = C1;
-    FCN_TRY(launch_wgrad<2>(w, B, st));
-    {
-        const int64_t ne = (int64_t)C2 * C1;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, ws->partial,
-                           ws->woff, L, spb, B * spb, ne, dW[1]);
-        FCN_CHECK_LAUNCH();
-    }
+    FCN_TRY(launch_wgrad<2>(w, B, d->N, ws->nsplit, st, dW[1]));
 
     hipLaunchKernelGGL(l1_finalize_kernel, dim3((C1 + 63) / 64), dim3(64), 0, st, bsQ, ws->stat + FCN_STAT_MOM,
                        p->W[0], p->gamma[0], bn1, C1, M, dW[0], dgamma[0], dbeta[0]);

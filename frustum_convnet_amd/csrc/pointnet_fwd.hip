@@ -83,6 +83,7 @@ __global__ void bn_finalize_kernel(const double *__restrict__ stat, const float 
 struct FwdArgs {
     const float4 *ent;     // (B,cap) rows (ux,uy,uz,w)
     const int32_t *woff;   // (B,L+1)
+    const int32_t *tiles;  // live-tile list
     const float *aprev;    // MODE 1: (B,cap,CIN) pre-BN output of the previous conv
     const float *bn_in;    // scale[CIN], shift[CIN] of the BN in front of this conv
     const float *W1;       // MODE 0: (CIN,3)
@@ -93,10 +94,17 @@ struct FwdArgs {
 };
 
 // MODE 0: operand rows are conv1+BN1+ReLU of the entries (computed here); MODE 1: BN+ReLU of aprev.
-template <int MODE, int NT>
-__global__ __launch_bounds__(GT) void fwd_gemm_kernel(FwdArgs a)
+// Workgroup = 2 x WN waves; tile = 128 rows x (32*NT*WN) output channels.  WN = 4 (512 threads) shares one
+// staged A tile between 256 output columns, halving the BN+ReLU staging work per output element.
+template <int MODE, int NT, int WN>
+__global__ __launch_bounds__(128 * WN) void fwd_gemm_kernel(FwdArgs a)
 {
-    constexpr int LDB = 64 * NT + 1;
+    constexpr int NTHR = 128 * WN;
+    constexpr int TN = 32 * NT * WN;
+    constexpr int LDB = TN + 1;
+    constexpr int NA4 = 1024 / NTHR;          // float4 of A per thread per chunk (MODE 1)
+    constexpr int NB4 = TN * 8 / NTHR;        // float4 of W per thread per chunk
+    constexpr int KPT = 4096 / NTHR;          // MODE 0: k values per thread per chunk
     __shared__ float As[KC * LDT];
     __shared__ float Bs[KC * LDB];
     __shared__ float tS[MAXC];
@@ -105,17 +113,18 @@ __global__ __launch_bounds__(GT) void fwd_gemm_kernel(FwdArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int b = blockIdx.x / a.tps, t = blockIdx.x % a.tps;
+    const int wm = wave / WN, wn = wave % WN;
+    if ((int)blockIdx.x >= a.tiles[0]) return;
+    const int code = a.tiles[4 + blockIdx.x];
+    const int b = code / a.tps, t = code % a.tps;
     const int nent = a.woff[(int64_t)b * (a.L + 1) + a.L];
     const int row0 = t * 128;
-    if (row0 >= nent) return;
     const int nvalid = min(128, nent - row0);
     const int64_t grow0 = (int64_t)b * a.cap + row0;
-    const int n0 = blockIdx.y * 64 * NT;
+    const int n0 = blockIdx.y * TN;
     const int CIN = a.CIN, COUT = a.COUT;
 
-    for (int i = tid; i < CIN; i += GT) {
+    for (int i = tid; i < CIN; i += NTHR) {
         const float s = a.bn_in[i];
         tS[i] = a.bn_in[CIN + i];
         if constexpr (MODE == 0) {
@@ -138,22 +147,23 @@ __global__ __launch_bounds__(GT) void fwd_gemm_kernel(FwdArgs a)
 
     f32x16 acc[2][NT];
     acc_zero<2, NT>(acc);
-    const int kq = tid & 7, rb = tid >> 3;
-    float4 ra[4], rw[2 * NT];
+    float4 ra[NA4], rw[NB4];
     const int nchunk = CIN / KC;
 
     auto load_chunk = [&](int c) {
         if constexpr (MODE == 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = rb + 32 * i;
+            for (int i = 0; i < NA4; ++i) {
+                const int f = tid + NTHR * i;
+                const int r = f >> 3, kq = f & 7;
                 ra[i] = (r < nvalid) ? *(const float4 *)(a.aprev + (grow0 + r) * CIN + c * KC + 4 * kq)
                                      : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
 #pragma unroll
-        for (int i = 0; i < 2 * NT; ++i) {
-            const int n = rb + 32 * i;
+        for (int i = 0; i < NB4; ++i) {
+            const int f = tid + NTHR * i;
+            const int n = f >> 3, kq = f & 7;
             rw[i] = *(const float4 *)(a.W + (int64_t)(n0 + n) * CIN + c * KC + 4 * kq);
         }
     };
@@ -163,8 +173,9 @@ __global__ __launch_bounds__(GT) void fwd_gemm_kernel(FwdArgs a)
         // ---- registers -> LDS (k-major), applying the input BN + ReLU
         if constexpr (MODE == 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = rb + 32 * i;
+            for (int i = 0; i < NA4; ++i) {
+                const int f = tid + NTHR * i;
+                const int r = f >> 3, kq = f & 7;
                 const bool ok = r < nvalid;
                 const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
 #pragma unroll
@@ -175,18 +186,19 @@ __global__ __launch_bounds__(GT) void fwd_gemm_kernel(FwdArgs a)
                 }
             }
         } else {
-            const int half = tid >> 7;
+            const int part = tid >> 7;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int k = half * 16 + j;
+            for (int j = 0; j < KPT; ++j) {
+                const int k = part * KPT + j;
                 const int kk = c * KC + k;
                 const float z = l1_pre(&sS[3 * kk], tS[kk], ux, uy, uz);
                 As[k * LDT + r0] = r0valid ? fmaxf(z, 0.f) : 0.f;
             }
         }
 #pragma unroll
-        for (int i = 0; i < 2 * NT; ++i) {
-            const int n = rb + 32 * i;
+        for (int i = 0; i < NB4; ++i) {
+            const int f = tid + NTHR * i;
+            const int n = f >> 3, kq = f & 7;
             const float v[4] = {rw[i].x, rw[i].y, rw[i].z, rw[i].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) Bs[(4 * kq + j) * LDB + n] = v[j];
@@ -246,38 +258,50 @@ __global__ __launch_bounds__(GT) void fwd_gemm_kernel(FwdArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-#define PW 8     // windows per pool workgroup
+// Pool: one wave = one window x 64 channels (lane = channel: every row read is a coalesced 256-B run);
+// a workgroup covers 16 consecutive windows so the (B, C, L) output goes out as 64-B runs through LDS.
+#define PW 16
 
 __global__ __launch_bounds__(GT) void pool_kernel(
     const float *__restrict__ y3, const float *__restrict__ bn3, const int32_t *__restrict__ woff,
     const int32_t *__restrict__ cnt, const float *__restrict__ one_hot, float *__restrict__ feat,
-    int32_t *__restrict__ amax, int L, int cap, int C3, int nvec, int cpb)
+    int32_t *__restrict__ amax, int L, int cap, int C3, int nvec)
 {
-    __shared__ float outS[256 * (PW + 1)];
-    const int tid = threadIdx.x;
-    const int b = blockIdx.z, l0 = blockIdx.x * PW, c0 = blockIdx.y * cpb;
-    const int cl = tid % cpb, wlane = tid / cpb, nwl = GT / cpb;
-    const int c = c0 + cl;
+    __shared__ float outS[64 * (PW + 1)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, l0 = blockIdx.x * PW, c0 = blockIdx.y * 64;
+    const int c = c0 + lane;
     const float s = bn3[c], t = bn3[C3 + c];
     const int32_t *wo = woff + (int64_t)b * (L + 1);
-    for (int wl = wlane; wl < PW; wl += nwl) {
+#pragma unroll 1
+    for (int q = 0; q < PW / 4; ++q) {
+        const int wl = wave * (PW / 4) + q;
         const int l = l0 + wl;
         float best = 0.f;
         int arg = -1;
         if (l < L && cnt[(int64_t)b * L + l] > 0) {
             const int o0 = wo[l], o1 = wo[l + 1];
             const float *yp = y3 + ((int64_t)b * cap + o0) * C3 + c;
-            for (int r = o0; r < o1; ++r, yp += C3) {
+            int r = o0;
+            for (; r + 4 <= o1; r += 4, yp += 4 * (int64_t)C3) {
+                const float v0 = fmaf(s, yp[0], t), v1 = fmaf(s, yp[C3], t);
+                const float v2 = fmaf(s, yp[2 * (int64_t)C3], t), v3 = fmaf(s, yp[3 * (int64_t)C3], t);
+                if (v0 > best) { best = v0; arg = r; }
+                if (v1 > best) { best = v1; arg = r + 1; }
+                if (v2 > best) { best = v2; arg = r + 2; }
+                if (v3 > best) { best = v3; arg = r + 3; }
+            }
+            for (; r < o1; ++r, yp += C3) {
                 const float v = fmaf(s, *yp, t);
                 if (v > best) { best = v; arg = r; }
             }
         }
-        outS[cl * (PW + 1) + wl] = best;
+        outS[lane * (PW + 1) + wl] = best;
         if (l < L && amax) amax[((int64_t)b * L + l) * C3 + c] = arg;
     }
     __syncthreads();
     const int CT = C3 + nvec;
-    for (int f = tid; f < cpb * PW; f += GT) {
+    for (int f = tid; f < 64 * PW; f += GT) {
         const int cc = f / PW, wl = f % PW, l = l0 + wl;
         if (l < L) feat[((int64_t)b * CT + c0 + cc) * L + l] = outS[cc * (PW + 1) + wl];
     }
@@ -292,12 +316,13 @@ template <int MODE>
 static int launch_fwd_gemm(const FwdArgs &a, int B, hipStream_t st)
 {
     if (a.CIN % 64 || a.COUT % 64 || a.CIN > MAXC) return FCN_E_BADARG;
-    if (a.COUT % 128 == 0) {
-        dim3 grid(B * a.tps, a.COUT / 128);
-        hipLaunchKernelGGL((fwd_gemm_kernel<MODE, 2>), grid, dim3(GT), 0, st, a);
+    const unsigned nt = (unsigned)(B * a.tps);
+    if (a.COUT % 256 == 0) {
+        hipLaunchKernelGGL((fwd_gemm_kernel<MODE, 2, 4>), dim3(nt, a.COUT / 256), dim3(512), 0, st, a);
+    } else if (a.COUT % 128 == 0) {
+        hipLaunchKernelGGL((fwd_gemm_kernel<MODE, 2, 2>), dim3(nt, a.COUT / 128), dim3(256), 0, st, a);
     } else {
-        dim3 grid(B * a.tps, a.COUT / 64);
-        hipLaunchKernelGGL((fwd_gemm_kernel<MODE, 1>), grid, dim3(GT), 0, st, a);
+        hipLaunchKernelGGL((fwd_gemm_kernel<MODE, 1, 2>), dim3(nt, a.COUT / 64), dim3(256), 0, st, a);
     }
     FCN_CHECK_LAUNCH();
     return 0;
@@ -326,7 +351,7 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
     FCN_CHECK_LAUNCH();
 
     FwdArgs a;
-    a.ent = (const float4 *)ws->ent; a.woff = ws->woff; a.L = L; a.cap = cap; a.tps = (cap + 127) / 128;
+    a.ent = (const float4 *)ws->ent; a.woff = ws->woff; a.tiles = ws->tiles; a.L = L; a.cap = cap; a.tps = (cap + 127) / 128;
     a.aprev = nullptr; a.bn_in = bn1; a.W1 = p->W[0]; a.W = p->W[1]; a.y = ws->y2;
     a.stat = tr ? st2 : nullptr; a.CIN = C1; a.COUT = C2;
     FCN_TRY(launch_fwd_gemm<0>(a, B, st));
@@ -345,12 +370,9 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
                        d->momentum, M, bn3);
     FCN_CHECK_LAUNCH();
 
-    const int cpb = C3 >= 256 ? 256 : C3;   // C3 is a multiple of 64: 64, 128, 192 -> must divide 256
-    if (GT % cpb) return FCN_E_BADARG;
-    dim3 pgrid((L + PW - 1) / PW, C3 / cpb, B);
-    if (C3 % cpb) return FCN_E_BADARG;
+    dim3 pgrid((L + PW - 1) / PW, C3 / 64, B);
     hipLaunchKernelGGL(pool_kernel, pgrid, dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, one_hot, feat,
-                       tr ? ws->amax : nullptr, L, cap, C3, d->nvec, cpb);
+                       tr ? ws->amax : nullptr, L, cap, C3, d->nvec);
     FCN_CHECK_LAUNCH();
     return 0;
 }
@@ -368,7 +390,7 @@ extern "C" int fcn_pn_conv_fwd(const fcn_pn_desc *d, const fcn_pn_params *p, con
     const int cap = L * K;
     double *st2 = ws->stat + FCN_STAT_L2, *st3 = st2 + 2 * C2;
     FwdArgs a;
-    a.ent = (const float4 *)ws->ent; a.woff = ws->woff; a.L = L; a.cap = cap; a.tps = (cap + 127) / 128;
+    a.ent = (const float4 *)ws->ent; a.woff = ws->woff; a.tiles = ws->tiles; a.L = L; a.cap = cap; a.tps = (cap + 127) / 128;
     if (layer == 2) {
         a.aprev = nullptr; a.bn_in = ws->bn + fcn_bn_off(0, C1, C2); a.W1 = p->W[0]; a.W = p->W[1]; a.y = ws->y2;
         a.stat = with_stats ? st2 : nullptr; a.CIN = C1; a.COUT = C2;

@@ -76,6 +76,30 @@ class GradAllReducer:
         self.flat.grad.div_(self.world)
 
 
+class CoalescedGradAllReducer:
+    """Gradient mean over ranks for per-tensor gradients: one flatten (single cat kernel), ONE RCCL all-reduce of the
+    13.3 MB buffer, one scatter back.  world_size 1 is a no-op."""
+
+    def __init__(self, params, world, group=None):
+        self.params, self.world, self.group = list(params), world, group
+        self.buf = None
+
+    def allreduce(self):
+        if self.world == 1:
+            return
+        grads = [p.grad for p in self.params if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.div_(self.world)
+        off = 0
+        views = []
+        for g in grads:
+            n = g.numel()
+            views.append(flat[off:off + n].view_as(g))
+            off += n
+        torch._foreach_copy_(grads, views)
+
+
 def broadcast_state(model, src=0):
     """Rank `src`'s parameters and buffers to everyone (start of training, or DataParallel-like buffer sync)."""
     if not dist.is_initialized():

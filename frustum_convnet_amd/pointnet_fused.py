@@ -25,6 +25,9 @@ class Workspace:
         self.woff = torch.empty((B, L + 1), dtype=i32, device=dev)
         self.ent = torch.empty((B, cap, 4), dtype=f32, device=dev)
         self.ewin = torch.empty((B, cap), dtype=i32, device=dev)
+        rows = _native.lib().fcn_pn_wgrad_rows()
+        ntile_max = B * ((cap + rows - 1) // rows)
+        self.tiles = torch.zeros((4 + ntile_max,), dtype=i32, device=dev)
         self.y2 = torch.empty((B, cap, C2), dtype=f32, device=dev)
         self.y3 = torch.empty((B, cap, C3), dtype=f32, device=dev)
         self.stat = torch.zeros((16 + 2 * C2 + 2 * C3,), dtype=f64, device=dev)
@@ -32,8 +35,7 @@ class Workspace:
         self.amax = self.gmax = self.dy3 = self.dz2 = self.bstat = self.coef = self.partial = None
         self.nsplit = 0
         if need_grad:
-            rows = _native.lib().fcn_pn_wgrad_rows()
-            self.nsplit = B * ((cap + rows - 1) // rows)
+            self.nsplit = ntile_max
             self.amax = torch.empty((B, L, C3), dtype=i32, device=dev)
             self.gmax = torch.empty((B, L, C3), dtype=f32, device=dev)
             self.dy3 = torch.empty((B, cap, C3), dtype=f32, device=dev)
@@ -42,7 +44,7 @@ class Workspace:
             self.coef = torch.empty((5 * (C3 + C2),), dtype=f32, device=dev)
             self.partial = torch.empty((self.nsplit * max(C3 * C2, C2 * C1),), dtype=f32, device=dev)
         p = lambda t: None if t is None else t.data_ptr()
-        self.c = PnWs(p(self.woff), p(self.ent), p(self.ewin), p(self.y2), p(self.y3), p(self.amax),
+        self.c = PnWs(p(self.woff), p(self.ent), p(self.ewin), p(self.tiles), p(self.y2), p(self.y3), p(self.amax),
                       p(self.stat), p(self.bn), p(self.gmax), p(self.dy3), p(self.dz2), p(self.bstat),
                       p(self.coef), p(self.partial), self.nsplit)
 

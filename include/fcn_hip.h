@@ -74,6 +74,7 @@ typedef struct fcn_pn_ws {
     int32_t *woff;               /* (B, L+1)   window row offsets, woff[b][L] = live rows    */
     float   *ent;                /* (B, cap, 4) (ux,uy,uz,w)                                 */
     int32_t *ewin;               /* (B, cap)    window of each row                           */
+    int32_t *tiles;              /* 4 + B*ceil(cap/128): [0] = live 128-row tiles, [4+i] = b*tps + t */
     float   *y2;                 /* (B, cap, C2) conv2 output (pre-BN)                       */
     float   *y3;                 /* (B, cap, C3) conv3 output (pre-BN)                       */
     int32_t *amax;               /* (B, L, C3)  row of the pooled max, -1 = no gradient      */
@@ -86,13 +87,13 @@ typedef struct fcn_pn_ws {
     double  *bstat;              /* 2*C3 + 2*C2 + 4*C1 doubles                               */
     float   *coef;               /* 5*(C3+C2) floats                                         */
     float   *partial;            /* wgrad partials: nsplit * max(C3*C2, C2*C1) floats        */
-    int32_t  nsplit;             /* capacity of `partial` in splits (>= B * ceil(cap/rows_per_split)) */
+    int32_t  nsplit;             /* capacity of `partial` in splits: >= B*ceil(cap/128) (one per row tile) */
 } fcn_pn_ws;
 
-/* rows of one wgrad split (constant of the library; caller sizes ws.partial with it) */
+/* rows of one row tile (128): the caller sizes ws.tiles / ws.partial with it */
 int fcn_pn_wgrad_rows(void);
 
-/* idx/cnt -> entry list + weighted input moments (ws.woff, ws.ent, ws.ewin, ws.stat[0..9]) */
+/* idx/cnt -> entry list + live-tile list + weighted input moments (ws.woff, ws.ent, ws.ewin, ws.tiles, ws.stat[0..9]) */
 int fcn_pn_compact(const fcn_pn_desc *d, const float *pc /*(B,3,N)*/, const float *ref /*(B,3,L)*/,
                    const int64_t *idx, const int32_t *cnt, const fcn_pn_ws *ws, void *stream);
 

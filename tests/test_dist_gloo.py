@@ -50,6 +50,19 @@ def _worker(rank, world, port, q):
         mean = sum(allg) / world
         ok = torch.allclose(flat.grad, mean, rtol=1e-6, atol=1e-7)
         q.put((rank, nb, bool(ok), bool(same_init), bool(views_ok)))
+    # per-tensor gradients through the coalesced reducer (what bench.py uses)
+    model2 = torch.nn.Sequential(torch.nn.Conv1d(4, 8, 3), torch.nn.Conv1d(8, 2, 1))
+    torch.manual_seed(5)
+    for p_ in model2.parameters():
+        p_.grad = torch.randn_like(p_) * (rank + 1)
+    loc = [p_.grad.clone() for p_ in model2.parameters()]
+    fdist.CoalescedGradAllReducer(list(model2.parameters()), world).allreduce()
+    okc = True
+    for p_, l_ in zip(model2.parameters(), loc):
+        allg = [torch.zeros_like(l_) for _ in range(world)]
+        dist.all_gather(allg, l_)
+        okc = okc and torch.allclose(p_.grad, sum(allg) / world, rtol=1e-6, atol=1e-7)
+    q.put((rank, "coalesced", bool(okc), True, True))
     # optimizer over the flat parameter moves every view
     fp = flat.as_parameter()
     before = model[0].weight.detach().clone()
@@ -70,8 +83,8 @@ def test_world2_gloo():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    got = [q.get(timeout=5) for _ in range(world * 3)]
-    assert len(got) == 6 and all(g[2] and g[3] and g[4] for g in got), got
+    got = [q.get(timeout=5) for _ in range(world * 4)]
+    assert len(got) == 8 and all(g[2] and g[3] and g[4] for g in got), got
 
 
 def test_shard_batch_matches_dataparallel_scatter():
