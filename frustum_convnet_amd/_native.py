@@ -31,7 +31,7 @@ class PnWs(ctypes.Structure):
 
 
 EXPORTS = ("fcn_arch", "fcn_query_depth_point_f32", "fcn_pn_wgrad_rows", "fcn_pn_compact",
-           "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_conv_fwd")
+           "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_conv_fwd", "fcn_det_loss_tail")
 
 _lib = None
 
@@ -72,6 +72,8 @@ def lib():
     L.fcn_pn_conv_fwd.restype = ctypes.c_int
     L.fcn_pn_conv_fwd.argtypes = [ctypes.POINTER(PnDesc), ctypes.POINTER(PnParams), ctypes.POINTER(PnWs),
                                   ctypes.c_int, ctypes.c_int, c_fp]
+    L.fcn_det_loss_tail.restype = ctypes.c_int
+    L.fcn_det_loss_tail.argtypes = [c_fp] * 9 + [ctypes.c_int] * 4 + [ctypes.c_float] * 4 + [c_fp] * 4
     _lib = L
     return L
 

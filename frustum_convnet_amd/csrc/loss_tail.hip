@@ -1,0 +1,279 @@
+// Fused train-loss tail of PointNetDet.forward (models/det_base.py:373-476 with models/common.py:217-232,
+// models/model_util.py:9-19,48-72, models/box_transform.py:5-65): softmax focal loss over the non-ignored
+// rows, and on the foreground rows (cls_label == 1) centre / heading / size / corner losses -- forward values
+// AND d(total_loss)/d(logits) in one launch.  The reference runs ~150 tiny elementwise kernels and three host
+// synchronisations here; on an MI355X that tail cost more than the whole fused PointNet forward.
+//
+// One workgroup (the batch has B*L2 ~ 4.5 k rows, of which ~B are foreground): pass 1 counts the foreground
+// rows (every mean is 1/nfg), pass 2 evaluates one row per thread, reading the (B,C,L2) logits with lanes along
+// L2 (coalesced), and block-reduces the 8 loss sums and 3 accuracy counters.
+#include "fcn_common.h"
+
+#define LT_THREADS 1024
+#define LT_NB 12          // heading bins (cfg.DATA.NUM_HEADING_BIN default, det_base.py:245)
+#define LT_NS 3           // size clusters (KITTI)
+
+struct LossArgs {
+    const float *cls_raw;      // (B,2,L2)
+    const float *reg_raw;      // (B,3+2*NB+4*NS,L2)
+    const int64_t *cls_label;  // (B,L2)  in {-1,0,1}
+    const float *ref2;         // (B,3,L2)
+    const float *box_center;   // (B,3)
+    const float *box_heading;  // (B,1)
+    const float *box_size;     // (B,3)
+    const int64_t *size_class; // (B,1)
+    const float *mean_size;    // (NS,3)
+    float *out;                // 16: total, cls, center, head_cls, head_res, size_cls, size_res, corners, cls_acc, head_acc, size_acc, nfg
+    float *dcls;               // (B,2,L2)  d total / d cls_raw
+    float *dreg;               // (B,39,L2) d total / d reg_raw
+    int B, L2;
+    float w_box, w_corner, w_headreg, w_sizereg;
+};
+
+__device__ __forceinline__ float block_sum(float v, float *sh)
+{
+    v = wave_sum_f32(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < LT_THREADS / 64; ++w) t += sh[w];
+    return t;
+}
+
+__device__ __forceinline__ float pymod(float a, float b) { return a - b * floorf(a / b); }
+
+__device__ __forceinline__ void corners8(float cx, float cy, float cz, float ang, float l, float w, float h,
+                                         float (&px)[8], float (&py)[8], float (&pz)[8])
+{
+    const float c = cosf(ang), s = sinf(ang);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float sx = (k & 2) ? -0.5f : 0.5f;                         // + + - - + + - -
+        const float sy = (k & 4) ? -0.5f : 0.5f;                         // + + + + - - - -
+        const float sz = ((k & 3) == 1 || (k & 3) == 2) ? -0.5f : 0.5f;  // + - - + + - - +
+        const float x = sx * l, y = sy * h, z = sz * w;
+        px[k] = c * x + s * z + cx;
+        py[k] = y + cy;
+        pz[k] = -s * x + c * z + cz;
+    }
+}
+
+__global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
+{
+    __shared__ float sh[LT_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int B = a.B, L2 = a.L2, R = B * L2;
+    constexpr int NB = LT_NB, NS = LT_NS, NC = 3 + 2 * NB + 4 * NS;
+    const float TWO_PI = 6.283185307179586f, PI = 3.141592653589793f;
+    const float per = (float)(6.283185307179586 / NB), half = (float)(6.283185307179586 / NB / 2.0);
+
+    float cfg_ = 0.f, ckeep = 0.f;
+    for (int r = tid; r < R; r += LT_THREADS) {
+        const int64_t lab = a.cls_label[r];
+        cfg_ += (lab == 1) ? 1.f : 0.f;
+        ckeep += (lab != -1) ? 1.f : 0.f;
+    }
+    const float nfg = block_sum(cfg_, sh);
+    const float nkeep = block_sum(ckeep, sh);
+    const float inv_cls = 1.f / (nfg + 1e-14f);
+    const float inv_fg = 1.f / nfg;
+
+    float acc[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) acc[i] = 0.f;
+
+    for (int r = tid; r < R; r += LT_THREADS) {
+        const int b = r / L2, l = r % L2;
+        const int64_t lab = a.cls_label[r];
+        // ---------------- focal classification loss (common.py:217-232)
+        const float c0 = a.cls_raw[((int64_t)b * 2 + 0) * L2 + l], c1 = a.cls_raw[((int64_t)b * 2 + 1) * L2 + l];
+        const float m = fmaxf(c0, c1);
+        const float e0 = expf(c0 - m), e1 = expf(c1 - m);
+        const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+        float g0 = 0.f, g1 = 0.f;
+        if (lab != -1) {
+            const int t = lab >= 1 ? 1 : 0;
+            const float pt = t ? p1 : p0;
+            const float alpha = t ? 0.25f : 0.75f;
+            const float om = 1.f - pt, lg = logf(pt + 1e-14f);
+            acc[1] += -alpha * om * om * lg;
+            const float dpt = -alpha * (-2.f * om * lg + om * om / (pt + 1e-14f));
+            const float gt_ = dpt * pt * om * inv_cls;
+            g0 = t ? -gt_ : gt_;
+            g1 = t ? gt_ : -gt_;
+            acc[8] += ((p1 > p0 ? 1 : 0) == t) ? 1.f : 0.f;
+        }
+        if (a.dcls) {
+            a.dcls[((int64_t)b * 2 + 0) * L2 + l] = g0;
+            a.dcls[((int64_t)b * 2 + 1) * L2 + l] = g1;
+        }
+        float go[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) go[j] = 0.f;
+        if (lab == 1) {
+            float o[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) o[j] = a.reg_raw[((int64_t)b * NC + j) * L2 + l];
+            const float rx = a.ref2[((int64_t)b * 3 + 0) * L2 + l], ry = a.ref2[((int64_t)b * 3 + 1) * L2 + l],
+                        rz = a.ref2[((int64_t)b * 3 + 2) * L2 + l];
+            const float clx = a.box_center[b * 3], cly = a.box_center[b * 3 + 1], clz = a.box_center[b * 3 + 2];
+            const float hlab = a.box_heading[b];
+            const float sl0 = a.box_size[b * 3], sl1 = a.box_size[b * 3 + 1], sl2 = a.box_size[b * 3 + 2];
+            const int sc = (int)a.size_class[b];
+            const float ex0 = a.mean_size[sc * 3], ex1 = a.mean_size[sc * 3 + 1], ex2 = a.mean_size[sc * 3 + 2];
+            const float wB = a.w_box * inv_fg;
+
+            // ---- centre (huber on the distance, delta 3)
+            {
+                const float dx = clx - rx - o[0], dy = cly - ry - o[1], dz = clz - rz - o[2];
+                const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+                const float q = fminf(dist, 3.f);
+                acc[2] += 0.5f * q * q + 3.f * (dist - q);
+                if (dist > 0.f) {
+                    const float k = -wB * q / dist;
+                    go[0] += k * dx; go[1] += k * dy; go[2] += k * dz;
+                }
+            }
+            // ---- heading: class CE + residual huber (box_transform.py:55-65)
+            const float ga = pymod(hlab, TWO_PI);
+            const float shifted = pymod(ga + half, TWO_PI);
+            int hc = (int)floorf(shifted / per);
+            hc = hc < 0 ? 0 : (hc > NB - 1 ? NB - 1 : hc);
+            const float hres = (shifted - ((float)hc * per + half)) / half;
+            {
+                float mx = o[3];
+                int am = 0;
+#pragma unroll
+                for (int j = 1; j < NB; ++j)
+                    if (o[3 + j] > mx) { mx = o[3 + j]; am = j; }
+                float se = 0.f, ej[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) { ej[j] = expf(o[3 + j] - mx); se += ej[j]; }
+                acc[3] += logf(se) + mx - o[3 + hc];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) go[3 + j] += wB * (ej[j] / se - (j == hc ? 1.f : 0.f));
+                acc[9] += (am == hc) ? 1.f : 0.f;
+                const float e = o[3 + NB + hc] - hres;
+                const float ab = fabsf(e), q = fminf(ab, 1.f);
+                acc[4] += 0.5f * q * q + (ab - q);
+                go[3 + NB + hc] += wB * a.w_headreg * (e > 0.f ? q : (e < 0.f ? -q : 0.f));
+            }
+            // ---- size: class CE + residual huber on the norm (box_transform.py:5-19)
+            {
+                const float *ss = &o[3 + 2 * NB];
+                float mx = ss[0];
+                int am = 0;
+#pragma unroll
+                for (int j = 1; j < NS; ++j)
+                    if (ss[j] > mx) { mx = ss[j]; am = j; }
+                float se = 0.f, ej[NS];
+#pragma unroll
+                for (int j = 0; j < NS; ++j) { ej[j] = expf(ss[j] - mx); se += ej[j]; }
+                acc[5] += logf(se) + mx - ss[sc];
+#pragma unroll
+                for (int j = 0; j < NS; ++j) go[3 + 2 * NB + j] += wB * (ej[j] / se - (j == sc ? 1.f : 0.f));
+                acc[10] += (am == sc) ? 1.f : 0.f;
+            }
+            const int so = 3 + 2 * NB + NS + sc * 3;      // the selected size-residual triple
+            {
+                const float v0 = (sl0 - ex0) / ex0 - o[so], v1 = (sl1 - ex1) / ex1 - o[so + 1],
+                            v2 = (sl2 - ex2) / ex2 - o[so + 2];
+                const float n = sqrtf(v0 * v0 + v1 * v1 + v2 * v2);
+                const float q = fminf(n, 1.f);
+                acc[6] += 0.5f * q * q + (n - q);
+                if (n > 0.f) {
+                    const float k = -wB * a.w_sizereg * q / n;
+                    go[so] += k * v0; go[so + 1] += k * v1; go[so + 2] += k * v2;
+                }
+            }
+            // ---- corner loss (model_util.py:48-72, det_base.py:314-332)
+            {
+                float ang = (float)hc * per + o[3 + NB + hc] * half;
+                if (ang > PI) ang -= TWO_PI;
+                const float pl = o[so] * ex0 + ex0, pw = o[so + 1] * ex1 + ex1, ph = o[so + 2] * ex2 + ex2;
+                const float pcx = rx + o[0], pcy = ry + o[1], pcz = rz + o[2];
+                float px[8], py[8], pz[8], gx[8], gy[8], gz[8], fx[8], fy[8], fz[8];
+                corners8(pcx, pcy, pcz, ang, pl, pw, ph, px, py, pz);
+                corners8(clx, cly, clz, hlab, sl0, sl1, sl2, gx, gy, gz);
+                corners8(clx, cly, clz, hlab + PI, sl0, sl1, sl2, fx, fy, fz);
+                float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    d1 += sqrtf((px[k] - gx[k]) * (px[k] - gx[k]) + (py[k] - gy[k]) * (py[k] - gy[k]) +
+                                (pz[k] - gz[k]) * (pz[k] - gz[k]));
+                    d2 += sqrtf((px[k] - fx[k]) * (px[k] - fx[k]) + (py[k] - fy[k]) * (py[k] - fy[k]) +
+                                (pz[k] - fz[k]) * (pz[k] - fz[k]));
+                }
+                d1 *= 0.125f; d2 *= 0.125f;
+                const bool first = d1 <= d2;
+                const float cd = first ? d1 : d2;
+                const float q = fminf(cd, 1.f);
+                acc[7] += 0.5f * q * q + (cd - q);
+                const float wk = wB * a.w_corner * q * 0.125f;
+                const float c = cosf(ang), s = sinf(ang);
+                float dcx = 0.f, dcy = 0.f, dcz = 0.f, dl = 0.f, dw = 0.f, dh = 0.f, dang = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float tx = first ? gx[k] : fx[k], ty = first ? gy[k] : fy[k], tz = first ? gz[k] : fz[k];
+                    const float ex_ = px[k] - tx, ey_ = py[k] - ty, ez_ = pz[k] - tz;
+                    const float nn = sqrtf(ex_ * ex_ + ey_ * ey_ + ez_ * ez_);
+                    if (nn > 0.f) {
+                        const float kx = wk * ex_ / nn, ky = wk * ey_ / nn, kz = wk * ez_ / nn;
+                        const float sx = (k & 2) ? -0.5f : 0.5f, sy = (k & 4) ? -0.5f : 0.5f;
+                        const float sz = ((k & 3) == 1 || (k & 3) == 2) ? -0.5f : 0.5f;
+                        const float x = sx * pl, z = sz * pw;
+                        dcx += kx; dcy += ky; dcz += kz;
+                        dl += kx * c * sx - kz * s * sx;
+                        dw += kx * s * sz + kz * c * sz;
+                        dh += ky * sy;
+                        dang += kx * (-s * x + c * z) + kz * (-c * x - s * z);
+                    }
+                }
+                go[0] += dcx; go[1] += dcy; go[2] += dcz;
+                go[so] += dl * ex0; go[so + 1] += dw * ex1; go[so + 2] += dh * ex2;
+                go[3 + NB + hc] += dang * half;
+            }
+        }
+        if (a.dreg) {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) a.dreg[((int64_t)b * NC + j) * L2 + l] = go[j];
+        }
+    }
+    float tot[11];
+#pragma unroll
+    for (int i = 1; i < 11; ++i) tot[i] = block_sum(acc[i], sh);
+    if (tid == 0) {
+        const float cls = tot[1] * inv_cls;
+        const float center = tot[2] * inv_fg, hcls = tot[3] * inv_fg, hres = tot[4] * inv_fg;
+        const float scls = tot[5] * inv_fg, sres = tot[6] * inv_fg, corner = tot[7] * inv_fg;
+        a.out[0] = cls + a.w_box * (center + hcls + scls + a.w_headreg * hres + a.w_sizereg * sres + a.w_corner * corner);
+        a.out[1] = cls; a.out[2] = center; a.out[3] = hcls; a.out[4] = hres;
+        a.out[5] = scls; a.out[6] = sres; a.out[7] = corner;
+        a.out[8] = tot[8] / nkeep; a.out[9] = tot[9] * inv_fg; a.out[10] = tot[10] * inv_fg;
+        a.out[11] = nfg;
+    }
+}
+
+extern "C" int fcn_det_loss_tail(const float *cls_raw, const float *reg_raw, const int64_t *cls_label,
+                                 const float *center_ref2, const float *box3d_center, const float *box3d_heading,
+                                 const float *box3d_size, const int64_t *size_class, const float *mean_size,
+                                 int B, int L2, int num_heading_bin, int num_size_cluster,
+                                 float w_box, float w_corner, float w_headreg, float w_sizereg,
+                                 float *out16, float *dcls, float *dreg, void *stream)
+{
+    if (!cls_raw || !reg_raw || !cls_label || !center_ref2 || !box3d_center || !box3d_heading || !box3d_size ||
+        !size_class || !mean_size || !out16)
+        return FCN_E_BADARG;
+    if (num_heading_bin != LT_NB || num_size_cluster != LT_NS) return FCN_E_LIMIT;
+    if (B <= 0 || L2 <= 0) return FCN_E_BADARG;
+    LossArgs a;
+    a.cls_raw = cls_raw; a.reg_raw = reg_raw; a.cls_label = cls_label; a.ref2 = center_ref2;
+    a.box_center = box3d_center; a.box_heading = box3d_heading; a.box_size = box3d_size; a.size_class = size_class;
+    a.mean_size = mean_size; a.out = out16; a.dcls = dcls; a.dreg = dreg; a.B = B; a.L2 = L2;
+    a.w_box = w_box; a.w_corner = w_corner; a.w_headreg = w_headreg; a.w_sizereg = w_sizereg;
+    hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(LT_THREADS), 0, (hipStream_t)stream, a);
+    FCN_CHECK_LAUNCH();
+    return 0;
+}

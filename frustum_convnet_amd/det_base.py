@@ -171,6 +171,9 @@ class PointNetDet(nn.Module):
                              persistent=False)
         self.strict = False
         self.iou_fn = None
+        # fused_loss: the whole train-loss tail (values + d total/d logits) in one HIP launch (csrc/loss_tail.hip);
+        # False keeps the mask-weighted torch formulation below (needed for the optional IoU metrics).
+        self.fused_loss = True
         self.last_logits = None
 
     def _slice_output(self, output):
@@ -222,6 +225,19 @@ class PointNetDet(nn.Module):
                     heading_preds.view(batch_size, -1), size_preds.view(batch_size, -1, 3),
                     heading_probs.view(batch_size, -1, self.num_bins),
                     size_probs.view(batch_size, -1, self.num_size_cluster))
+
+        if self.fused_loss and cls_raw.is_cuda and self.iou_fn is None and not self.strict \
+                and self.num_bins == 12 and self.num_size_cluster == 3:
+            from .loss_fused import det_loss_tail
+            Lw = cfg.LOSS
+            losses, (a_cls, a_head, a_size) = det_loss_tail(
+                cls_raw, reg_raw, cls_label, refs[1], center_label, heading_label, size_label, size_class_label,
+                mean_size_array, self.num_bins, self.num_size_cluster,
+                (Lw.BOX_LOSS_WEIGHT, Lw.CORNER_LOSS_WEIGHT, Lw.HEAD_REG_WEIGHT, Lw.SIZE_REG_WEIGHT))
+            zero = torch.zeros((), dtype=a_cls.dtype, device=a_cls.device)
+            metrics = {'cls_acc': a_cls, 'head_acc': a_head, 'size_acc': a_size, 'IoU_2D': zero, 'IoU_3D': zero,
+                       'IoU_' + str(cfg.IOU_THRESH): zero}
+            return losses, metrics
 
         # ---- training / validation branch: every loss is a mean over the foreground rows
         # (cls_label == 1); written as mask-weighted sums over all B*L2 rows -> no nonzero(), no sync.

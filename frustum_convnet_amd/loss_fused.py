@@ -1,0 +1,58 @@
+"""Autograd binding of the fused train-loss tail (C-ABI fcn_det_loss_tail, csrc/loss_tail.hip).
+
+Replaces the ~150 elementwise torch ops of models/det_base.py:373-476 by one launch that returns the 8 loss
+scalars, 3 accuracies and d(total_loss)/d(logits).  Only `total_loss` is differentiable (the reference never
+back-propagates the other entries either: train/train_net_det.py:124-127)."""
+import torch
+
+from . import _native
+
+LOSS_NAMES = ("total_loss", "cls_loss", "center_loss", "head_cls_loss", "head_res_loss", "size_cls_loss",
+              "size_res_loss", "corners_loss")
+
+
+class _LossTail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cls_raw, reg_raw, cls_label, ref2, center, heading, size, size_class, mean_size, nb, ns, w):
+        L = _native.lib()
+        B, _, L2 = cls_raw.shape
+        cls_c, reg_c = cls_raw.detach().contiguous(), reg_raw.detach().contiguous()
+        need = cls_raw.requires_grad or reg_raw.requires_grad
+        out = torch.empty(16, dtype=torch.float32, device=cls_raw.device)
+        dcls = torch.empty_like(cls_c) if need else None
+        dreg = torch.empty_like(reg_c) if need else None
+        args = [cls_label.contiguous(), ref2.contiguous().float(), center.contiguous().float(),
+                heading.contiguous().float(), size.contiguous().float(), size_class.contiguous(),
+                mean_size.contiguous().float()]
+        with torch.cuda.device(cls_raw.device):
+            rc = L.fcn_det_loss_tail(cls_c.data_ptr(), reg_c.data_ptr(), *[t.data_ptr() for t in args],
+                                     B, L2, int(nb), int(ns), float(w[0]), float(w[1]), float(w[2]), float(w[3]),
+                                     out.data_ptr(), None if dcls is None else dcls.data_ptr(),
+                                     None if dreg is None else dreg.data_ptr(), _native.current_stream(cls_raw.device))
+        _native.check(rc, "fcn_det_loss_tail")
+        ctx.save_for_backward(*(t for t in (dcls, dreg) if t is not None))
+        ctx.need = need
+        total = out[0].clone()
+        rest = out.detach()
+        ctx.mark_non_differentiable(rest)
+        return total, rest
+
+    @staticmethod
+    def backward(ctx, gtotal, _grest):
+        if not ctx.need:
+            return (None,) * 12
+        dcls, dreg = ctx.saved_tensors
+        return (dcls * gtotal, dreg * gtotal) + (None,) * 10
+
+
+def det_loss_tail(cls_raw, reg_raw, cls_label, center_ref2, box3d_center, box3d_heading, box3d_size, size_class,
+                  mean_size, num_bins, num_sizes, weights):
+    """-> (losses dict with the reference's 8 keys, accuracies (cls, head, size))."""
+    if not cls_raw.is_cuda:
+        raise RuntimeError("frustum_convnet_amd: fused loss tail runs on the GPU only")
+    total, rest = _LossTail.apply(cls_raw, reg_raw, cls_label, center_ref2, box3d_center, box3d_heading, box3d_size,
+                                  size_class, mean_size, num_bins, num_sizes, weights)
+    losses = {"total_loss": total}
+    for i, k in enumerate(LOSS_NAMES[1:], start=1):
+        losses[k] = rest[i]
+    return losses, (rest[8], rest[9], rest[10])

@@ -15,6 +15,7 @@
  *                               PointNetFeat.forward: gather, centre subtract, 3 x [Conv2d 1x1, BatchNorm2d,
  *                               ReLU], (cnt>0) mask, torch.max(.,-1), one-hot concat
  *                               models/det_base.py:75-101,134-157 (+ autograd of the same)
+ *   fcn_det_loss_tail           the ~150 torch ops of the train-loss tail, models/det_base.py:373-476
  *
  * Buffers are caller-owned.  "ws" buffers are scratch the caller provides (sizes documented per call).
  */
@@ -109,6 +110,22 @@ int fcn_pn_backward(const fcn_pn_desc *d, const fcn_pn_params *p, const float *d
  * ws: the unit the roofline figure in bench.py is measured on.  with_stats != 0 keeps the BN-statistics epilogue. */
 int fcn_pn_conv_fwd(const fcn_pn_desc *d, const fcn_pn_params *p, const fcn_pn_ws *ws, int layer,
                     int with_stats, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused train-loss tail of PointNetDet.forward (models/det_base.py:373-476; focal loss models/common.py:217-232,
+ * huber + box corners models/model_util.py:9-19,48-72, encode/decode models/box_transform.py:5-65).
+ *   cls_raw (B,2,L2), reg_raw (B,3+2*NB+4*NS,L2): raw head outputs;  cls_label (B,L2) int64 in {-1,0,1};
+ *   center_ref2 (B,3,L2); box3d_center (B,3); box3d_heading (B,1); box3d_size (B,3); size_class (B,1) int64;
+ *   mean_size (NS,3).  NB must be 12 and NS 3 (the KITTI configuration), else FCN_E_LIMIT.
+ *   out16: total, cls, center, head_cls, head_res, size_cls, size_res, corners, cls_acc, head_acc, size_acc, nfg
+ *   dcls / dreg: d(total)/d(cls_raw), d(total)/d(reg_raw), same layouts (NULL to skip).
+ * ------------------------------------------------------------------------------------------- */
+int fcn_det_loss_tail(const float *cls_raw, const float *reg_raw, const int64_t *cls_label,
+                      const float *center_ref2, const float *box3d_center, const float *box3d_heading,
+                      const float *box3d_size, const int64_t *size_class, const float *mean_size,
+                      int B, int L2, int num_heading_bin, int num_size_cluster,
+                      float w_box, float w_corner, float w_headreg, float w_sizereg,
+                      float *out16, float *dcls, float *dreg, void *stream);
 
 #ifdef __cplusplus
 }

@@ -130,3 +130,34 @@ def test_two_forwards_before_backward_do_not_share_workspace():
     # second graph saw updated running stats but identical batch statistics -> same gradients
     g2 = m.feat_net.pointnet4.conv3[0].weight.grad
     assert float((g1 - g2).abs().max()) <= 1e-4 * float(g1.abs().max())
+
+
+def test_fused_loss_tail_matches_torch_tail():
+    """C-ABI fcn_det_loss_tail (one launch) vs the mask-weighted torch tail and the oracle's tail: values and
+    d(total)/d(logits)."""
+    from oracle import det_ref
+    g = load_golden("car_b4_n512")
+    data = synth.to_torch(golden_inputs(g), "cuda")
+    m = _model(g)
+    m.train()
+    outs = {}
+    for fused in (True, False):
+        m.fused_loss = fused
+        m.zero_grad()
+        losses, metrics = m(data)
+        cls, reg = m.last_logits
+        cls.retain_grad(); reg.retain_grad()
+        losses["total_loss"].backward()
+        outs[fused] = ({k: float(v) for k, v in losses.items()}, {k: float(v) for k, v in metrics.items()},
+                       cls.grad.clone(), reg.grad.clone())
+    for k, v in outs[False][0].items():
+        assert abs(outs[True][0][k] - v) <= 2e-5 * max(1.0, abs(v)), k
+    for k in ("cls_acc", "head_acc", "size_acc"):
+        assert abs(outs[True][1][k] - outs[False][1][k]) < 1e-6, k
+    for i in (2, 3):
+        a, b = outs[True][i], outs[False][i]
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-7
+    cpu = synth.to_torch(golden_inputs(g))
+    ref = det_ref.loss_tail(torch.from_numpy(g["cls_train"]), torch.from_numpy(g["reg_train"]), cpu)
+    for k, v in ref.items():
+        assert abs(outs[True][0][k] - float(v)) <= 1e-4 * max(1.0, abs(float(v))), k

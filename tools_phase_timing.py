@@ -64,11 +64,6 @@ report("FCN+heads fwd", fcn_f)
 x0 = model.conv_net(*feats).detach()
 cls0 = model.cls_out(x0).detach().requires_grad_(True)
 reg0 = model.reg_out(x0).detach().requires_grad_(True)
-import types
-class Tail(torch.nn.Module):
-    pass
-tail = type(model).__new__(type(model)); tail.__dict__ = dict(model.__dict__)
-tail.feat_net = types.SimpleNamespace(); tail.feat_net = lambda *a, **k: (None,) * 4
 def tail_fb():
     m = model
     of, oc, ocl, orr = m.feat_net.forward, m.conv_net.forward, m.cls_out.forward, m.reg_out.forward
