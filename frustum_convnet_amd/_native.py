@@ -16,7 +16,23 @@ class PnDesc(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("L", ctypes.c_int32), ("K", ctypes.c_int32),
                 ("C1", ctypes.c_int32), ("C2", ctypes.c_int32), ("C3", ctypes.c_int32),
                 ("nvec", ctypes.c_int32), ("training", ctypes.c_int32),
+                ("eps", ctypes.c_float), ("momentum", ctypes.c_float), ("nlc", ctypes.c_int32)]
+
+
+class CnDesc(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("L", ctypes.c_int32 * 4), ("nvec", ctypes.c_int32),
+                ("reg_out", ctypes.c_int32), ("training", ctypes.c_int32),
                 ("eps", ctypes.c_float), ("momentum", ctypes.c_float)]
+
+
+class CnParams(ctypes.Structure):
+    _fields_ = [("W", c_fp * 14), ("gamma", c_fp * 14), ("beta", c_fp * 14), ("running_mean", c_fp * 14),
+                ("running_var", c_fp * 14), ("num_batches_tracked", c_fp * 14), ("bias", c_fp)]
+
+
+class CnWs(ctypes.Structure):
+    _fields_ = [("y", c_fp), ("dz", c_fp), ("wp", c_fp), ("bn", c_fp), ("stat", c_fp), ("bstat", c_fp),
+                ("coef", c_fp), ("partial", c_fp)]
 
 
 class PnParams(ctypes.Structure):
@@ -31,7 +47,8 @@ class PnWs(ctypes.Structure):
 
 
 EXPORTS = ("fcn_arch", "fcn_query_depth_point_f32", "fcn_pn_wgrad_rows", "fcn_pn_compact",
-           "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_conv_fwd", "fcn_det_loss_tail")
+           "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows",
+           "fcn_convnet_sizes", "fcn_convnet_forward", "fcn_convnet_backward")
 
 _lib = None
 
@@ -74,6 +91,16 @@ def lib():
                                   ctypes.c_int, ctypes.c_int, c_fp]
     L.fcn_det_loss_tail.restype = ctypes.c_int
     L.fcn_det_loss_tail.argtypes = [c_fp] * 9 + [ctypes.c_int] * 4 + [ctypes.c_float] * 4 + [c_fp] * 4
+    L.fcn_det_loss_tail_rows.restype = ctypes.c_int
+    L.fcn_det_loss_tail_rows.argtypes = [c_fp] * 8 + [ctypes.c_int] * 4 + [ctypes.c_float] * 4 + [c_fp] * 3
+    L.fcn_convnet_sizes.restype = ctypes.c_int
+    L.fcn_convnet_sizes.argtypes = [ctypes.POINTER(CnDesc), ctypes.POINTER(ctypes.c_int64 * 6)]
+    L.fcn_convnet_forward.restype = ctypes.c_int
+    L.fcn_convnet_forward.argtypes = [ctypes.POINTER(CnDesc), ctypes.POINTER(CnParams), ctypes.POINTER(CnWs),
+                                      c_fp * 4, c_fp, c_fp, c_fp]
+    L.fcn_convnet_backward.restype = ctypes.c_int
+    L.fcn_convnet_backward.argtypes = [ctypes.POINTER(CnDesc), ctypes.POINTER(CnParams), ctypes.POINTER(CnWs),
+                                       c_fp * 4, c_fp, c_fp, c_fp * 4, c_fp * 14, c_fp * 14, c_fp * 14, c_fp, c_fp]
     _lib = L
     return L
 

@@ -30,18 +30,29 @@ __device__ __forceinline__ void mma_chunk(const float *As, const float *Bs, int 
     const int l31 = lane & 31, lh = lane >> 5;
     const float *ap = As + lh * LDA + arow0 + l31;
     const float *bp = Bs + lh * LDB + bcol0 + l31;
+    // operands of k-step kk+2 are fetched from LDS before the MFMAs of k-step kk issue, so the ds_read latency
+    // hides behind 4 x 64 cycles of matrix work instead of stalling every step on lgkmcnt(0)
+    float a[2][MT], b[2][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a[0][i] = ap[i * 32];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b[0][j] = bp[j * 32];
 #pragma unroll
     for (int kk = 0; kk < KC; kk += 2) {
-        float a[MT], b[NT];
+        const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+        if (kk + 2 < KC) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) a[i] = ap[kk * LDA + i * 32];
+            for (int i = 0; i < MT; ++i) a[nxt][i] = ap[(kk + 2) * LDA + i * 32];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) b[j] = bp[kk * LDB + j * 32];
+            for (int j = 0; j < NT; ++j) b[nxt][j] = bp[(kk + 2) * LDB + j * 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE this step's MFMAs (hipcc otherwise sinks it)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 

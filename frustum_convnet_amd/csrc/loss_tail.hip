@@ -28,6 +28,8 @@ struct LossArgs {
     float *dreg;               // (B,39,L2) d total / d reg_raw
     int B, L2;
     float w_box, w_corner, w_headreg, w_sizereg;
+    int ld;                    // 0: (B,C,L2) planes above; > 0: row-major logits (B*L2, ld) in cls_raw (cols 0..1 cls,
+                               // 2.. reg) and row-major gradient in dcls (all ld columns written)
 };
 
 __device__ __forceinline__ float block_sum(float v, float *sh)
@@ -88,7 +90,8 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
         const int b = r / L2, l = r % L2;
         const int64_t lab = a.cls_label[r];
         // ---------------- focal classification loss (common.py:217-232)
-        const float c0 = a.cls_raw[((int64_t)b * 2 + 0) * L2 + l], c1 = a.cls_raw[((int64_t)b * 2 + 1) * L2 + l];
+        const float c0 = a.ld ? a.cls_raw[(int64_t)r * a.ld] : a.cls_raw[((int64_t)b * 2 + 0) * L2 + l];
+        const float c1 = a.ld ? a.cls_raw[(int64_t)r * a.ld + 1] : a.cls_raw[((int64_t)b * 2 + 1) * L2 + l];
         const float m = fmaxf(c0, c1);
         const float e0 = expf(c0 - m), e1 = expf(c1 - m);
         const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
@@ -106,8 +109,13 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
             acc[8] += ((p1 > p0 ? 1 : 0) == t) ? 1.f : 0.f;
         }
         if (a.dcls) {
-            a.dcls[((int64_t)b * 2 + 0) * L2 + l] = g0;
-            a.dcls[((int64_t)b * 2 + 1) * L2 + l] = g1;
+            if (a.ld) {
+                a.dcls[(int64_t)r * a.ld] = g0;
+                a.dcls[(int64_t)r * a.ld + 1] = g1;
+            } else {
+                a.dcls[((int64_t)b * 2 + 0) * L2 + l] = g0;
+                a.dcls[((int64_t)b * 2 + 1) * L2 + l] = g1;
+            }
         }
         float go[NC];
 #pragma unroll
@@ -115,7 +123,8 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
         if (lab == 1) {
             float o[NC];
 #pragma unroll
-            for (int j = 0; j < NC; ++j) o[j] = a.reg_raw[((int64_t)b * NC + j) * L2 + l];
+            for (int j = 0; j < NC; ++j)
+                o[j] = a.ld ? a.cls_raw[(int64_t)r * a.ld + 2 + j] : a.reg_raw[((int64_t)b * NC + j) * L2 + l];
             const float rx = a.ref2[((int64_t)b * 3 + 0) * L2 + l], ry = a.ref2[((int64_t)b * 3 + 1) * L2 + l],
                         rz = a.ref2[((int64_t)b * 3 + 2) * L2 + l];
             const float clx = a.box_center[b * 3], cly = a.box_center[b * 3 + 1], clz = a.box_center[b * 3 + 2];
@@ -236,7 +245,13 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
                 go[3 + NB + hc] += dang * half;
             }
         }
-        if (a.dreg) {
+        if (a.ld) {
+            if (a.dcls) {
+#pragma unroll
+                for (int j = 0; j < NC; ++j) a.dcls[(int64_t)r * a.ld + 2 + j] = go[j];
+                for (int j = 2 + NC; j < a.ld; ++j) a.dcls[(int64_t)r * a.ld + j] = 0.f;
+            }
+        } else if (a.dreg) {
 #pragma unroll
             for (int j = 0; j < NC; ++j) a.dreg[((int64_t)b * NC + j) * L2 + l] = go[j];
         }
@@ -272,7 +287,29 @@ extern "C" int fcn_det_loss_tail(const float *cls_raw, const float *reg_raw, con
     a.cls_raw = cls_raw; a.reg_raw = reg_raw; a.cls_label = cls_label; a.ref2 = center_ref2;
     a.box_center = box3d_center; a.box_heading = box3d_heading; a.box_size = box3d_size; a.size_class = size_class;
     a.mean_size = mean_size; a.out = out16; a.dcls = dcls; a.dreg = dreg; a.B = B; a.L2 = L2;
-    a.w_box = w_box; a.w_corner = w_corner; a.w_headreg = w_headreg; a.w_sizereg = w_sizereg;
+    a.w_box = w_box; a.w_corner = w_corner; a.w_headreg = w_headreg; a.w_sizereg = w_sizereg; a.ld = 0;
+    hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(LT_THREADS), 0, (hipStream_t)stream, a);
+    FCN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fcn_det_loss_tail_rows(const float *logits, const int64_t *cls_label, const float *center_ref2,
+                                      const float *box3d_center, const float *box3d_heading, const float *box3d_size,
+                                      const int64_t *size_class, const float *mean_size, int B, int L2,
+                                      int num_heading_bin, int num_size_cluster,
+                                      float w_box, float w_corner, float w_headreg, float w_sizereg,
+                                      float *out16, float *dlogits, void *stream)
+{
+    if (!logits || !cls_label || !center_ref2 || !box3d_center || !box3d_heading || !box3d_size || !size_class ||
+        !mean_size || !out16)
+        return FCN_E_BADARG;
+    if (num_heading_bin != LT_NB || num_size_cluster != LT_NS) return FCN_E_LIMIT;
+    if (B <= 0 || L2 <= 0) return FCN_E_BADARG;
+    LossArgs a;
+    a.cls_raw = logits; a.reg_raw = nullptr; a.cls_label = cls_label; a.ref2 = center_ref2;
+    a.box_center = box3d_center; a.box_heading = box3d_heading; a.box_size = box3d_size; a.size_class = size_class;
+    a.mean_size = mean_size; a.out = out16; a.dcls = dlogits; a.dreg = nullptr; a.B = B; a.L2 = L2;
+    a.w_box = w_box; a.w_corner = w_corner; a.w_headreg = w_headreg; a.w_sizereg = w_sizereg; a.ld = 64;
     hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(LT_THREADS), 0, (hipStream_t)stream, a);
     FCN_CHECK_LAUNCH();
     return 0;

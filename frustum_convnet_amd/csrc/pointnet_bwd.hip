@@ -20,6 +20,9 @@
 #define MAXC 512
 #define WG_ROWS 128             // rows of one row tile (wgrad splits are multiples of it)
 #define PWB 64                  // windows per poolbwd workgroup
+#ifndef FCN_WIDE_TILES
+#define FCN_WIDE_TILES 0
+#endif
 
 extern "C" int fcn_pn_wgrad_rows(void) { return WG_ROWS; }
 
@@ -30,12 +33,12 @@ extern "C" int fcn_pn_wgrad_rows(void) { return WG_ROWS; }
 __global__ __launch_bounds__(GT) void poolbwd_kernel(
     const float *__restrict__ dfeat, const int32_t *__restrict__ amax, const float *__restrict__ y3,
     const float *__restrict__ bn3, float *__restrict__ gmax, double *__restrict__ bstat,
-    int L, int cap, int C3, int CT)
+    int L, int cap, int C3, int CT, int nlc)
 {
     __shared__ float dS[64 * (PWB + 1)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, l0 = blockIdx.x * PWB, c0 = blockIdx.y * 64;
-    for (int f = tid; f < 64 * PWB; f += GT) {
+    for (int f = tid; f < 64 * PWB && !nlc; f += GT) {
         const int cc = f / PWB, wl = f % PWB, l = l0 + wl;
         dS[cc * (PWB + 1) + wl] = (l < L) ? dfeat[((int64_t)b * CT + c0 + cc) * L + l] : 0.f;
     }
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(GT) void poolbwd_kernel(
         const int am = amax[o];
         float g = 0.f;
         if (am >= 0) {
-            g = dS[lane * (PWB + 1) + wl];
+            g = nlc ? dfeat[((int64_t)b * L + l) * C3 + c] : dS[lane * (PWB + 1) + wl];
             const float xh = (y3[((int64_t)b * cap + am) * C3 + c] - mean) * rstd;
             sB += g;
             sG = fmaf(g, xh, sG);
@@ -308,7 +311,7 @@ struct WgradArgs {
     const float *bn_prev;   // scale, shift of the previous layer's BN
     const float *W1;        // LAYER 2
     float *partial;         // (nsplit, COUT, CIN)
-    int L, cap, COUT, CIN, tps, tpb;   // tpb = live row tiles per split
+    int L, cap, COUT, CIN, tps;
 };
 
 // dW[n][k] = sum_rows dy[row][n] * a_prev[row][k]; workgroup tile (64*MT) x (64*NT).  Split s reduces the
@@ -325,9 +328,10 @@ __global__ __launch_bounds__(GT) void wgrad_kernel(WgradArgs a)
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int ntile = a.tiles[0];
-    const int t_beg = blockIdx.x * a.tpb;
+    const int tpb = (ntile + (int)gridDim.x - 1) / (int)gridDim.x;   // live tiles per split, balanced on the device
+    const int t_beg = blockIdx.x * tpb;
     if (t_beg >= ntile) return;
-    const int t_end = min(ntile, t_beg + a.tpb);
+    const int t_end = min(ntile, t_beg + tpb);
     const int nq = (t_end - t_beg) * 4;                 // 32-row chunks to reduce
     const int n0 = blockIdx.y * 64 * MT, k0 = blockIdx.z * 64 * NT;
     const int COUT = a.COUT, CIN = a.CIN;
@@ -464,12 +468,14 @@ __global__ __launch_bounds__(GT) void wgrad_kernel(WgradArgs a)
 }
 
 // out[i] = sum over the live splits (fixed order -> deterministic); 4 independent loads in flight per thread.
-__global__ void wgrad_reduce_kernel(const float *__restrict__ partial, const int32_t *__restrict__ tiles, int tpb,
+__global__ void wgrad_reduce_kernel(const float *__restrict__ partial, const int32_t *__restrict__ tiles, int nsplit,
                                     int64_t nelem, float *__restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nelem) return;
-    const int nsp = (tiles[0] + tpb - 1) / tpb;
+    const int ntile = tiles[0];
+    const int tpb = (ntile + nsplit - 1) / nsplit;
+    const int nsp = tpb > 0 ? (ntile + tpb - 1) / tpb : 0;
     const float *p = partial + i;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int sp = 0;
@@ -517,7 +523,7 @@ static int launch_dgrad(const DgradArgs &a, int B, hipStream_t st)
 {
     if (a.CRED % 64 || a.CPREV % 64 || a.CRED > MAXC) return FCN_E_BADARG;
     const unsigned nt = (unsigned)(B * a.tps);
-    if (a.CPREV % 256 == 0) {
+    if (FCN_WIDE_TILES && a.CPREV % 256 == 0) {
         hipLaunchKernelGGL((dgrad_kernel<LAYER, 2, 4>), dim3(nt, a.CPREV / 256), dim3(512), 0, st, a);
     } else if (a.CPREV % 128 == 0) {
         hipLaunchKernelGGL((dgrad_kernel<LAYER, 2, 2>), dim3(nt, a.CPREV / 128), dim3(256), 0, st, a);
@@ -528,28 +534,17 @@ static int launch_dgrad(const DgradArgs &a, int B, hipStream_t st)
     return 0;
 }
 
-// Row tiles per split: keep >= ~512 workgroups in flight.  The live-tile count is only known on the device, so
-// the estimate uses the typical occupancy of the sliding frustums (each point falls into ~2 windows per scale:
-// ~2*N rows per frustum), clamped to the worst case.
-static int pick_tpb(int B, int N, int tps, int out_tiles)
-{
-    long est = ((long)2 * N * B + 127) / 128;
-    const long worst = (long)B * tps;
-    if (est > worst) est = worst;
-    long tpb = est * out_tiles / 512;
-    if (tpb < 1) tpb = 1;
-    if (tpb > 16) tpb = 16;
-    return (int)tpb;
-}
-
 template <int LAYER>
-static int launch_wgrad(WgradArgs &a, int B, int N, int nsplit_cap, hipStream_t st, float *out)
+static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, hipStream_t st, float *out)
 {
     const bool m2 = (a.COUT % 128 == 0), n2 = (a.CIN % 128 == 0);
     const int oy = a.COUT / (m2 ? 128 : 64), oz = a.CIN / (n2 ? 128 : 64);
-    a.tpb = pick_tpb(B, N, a.tps, oy * oz);
-    const int nsplit = (B * a.tps + a.tpb - 1) / a.tpb;
-    if (nsplit > nsplit_cap) return FCN_E_BADARG;
+    // ~768 workgroups per launch; each split takes ceil(live_tiles / nsplit) row tiles (computed on the device,
+    // where the live count is known), so splits stay balanced whatever the occupancy of the frustums.
+    int nsplit = 768 / (oy * oz);
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > B * a.tps) nsplit = B * a.tps;
+    if (nsplit > nsplit_cap) nsplit = nsplit_cap;
     dim3 grid(nsplit, oy, oz);
     if (m2 && n2) hipLaunchKernelGGL((wgrad_kernel<LAYER, 2, 2>), grid, dim3(GT), 0, st, a);
     else if (m2) hipLaunchKernelGGL((wgrad_kernel<LAYER, 2, 1>), grid, dim3(GT), 0, st, a);
@@ -558,7 +553,7 @@ static int launch_wgrad(WgradArgs &a, int B, int N, int nsplit_cap, hipStream_t 
     FCN_CHECK_LAUNCH();
     const int64_t ne = (int64_t)a.COUT * a.CIN;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, a.partial, a.tiles,
-                       a.tpb, ne, out);
+                       nsplit, ne, out);
     FCN_CHECK_LAUNCH();
     return 0;
 }
@@ -586,7 +581,7 @@ extern "C" int fcn_pn_backward(const fcn_pn_desc *d, const fcn_pn_params *p, con
     if (e != hipSuccess) return (int)e;
 
     hipLaunchKernelGGL(poolbwd_kernel, dim3((L + PWB - 1) / PWB, C3 / 64, B), dim3(GT), 0, st, dfeat, ws->amax,
-                       ws->y3, bn3, ws->gmax, bs3, L, cap, C3, C3 + d->nvec);
+                       ws->y3, bn3, ws->gmax, bs3, L, cap, C3, C3 + d->nvec, d->nlc);
     FCN_CHECK_LAUNCH();
     hipLaunchKernelGGL(bnbwd_finalize_kernel, dim3((C3 + 63) / 64), dim3(64), 0, st, bs3, p->gamma[2], bn3, C3, M,
                        coef3, dgamma[2], dbeta[2]);
@@ -600,11 +595,11 @@ extern "C" int fcn_pn_backward(const fcn_pn_desc *d, const fcn_pn_params *p, con
     FCN_TRY(launch_dgrad<3>(g, B, st));
 
     WgradArgs w;
-    w.ent = (const float4 *)ws->ent; w.woff = ws->woff; w.tiles = ws->tiles; w.L = L; w.cap = cap; w.tps = tps; w.tpb = 1;
+    w.ent = (const float4 *)ws->ent; w.woff = ws->woff; w.tiles = ws->tiles; w.L = L; w.cap = cap; w.tps = tps;
     w.partial = ws->partial;
     w.dy = ws->dy3; w.dz = nullptr; w.ycur = nullptr; w.coef = nullptr; w.yprev = ws->y2; w.bn_prev = bn2;
     w.W1 = nullptr; w.COUT = C3; w.CIN = C2;
-    FCN_TRY(launch_wgrad<3>(w, B, d->N, ws->nsplit, st, dW[2]));
+    FCN_TRY(launch_wgrad<3>(w, B, ws->nsplit, st, dW[2]));
 
     hipLaunchKernelGGL(bnbwd_finalize_kernel, dim3((C2 + 63) / 64), dim3(64), 0, st, bs2, p->gamma[1], bn2, C2, M,
                        coef2, dgamma[1], dbeta[1]);
@@ -617,7 +612,7 @@ extern "C" int fcn_pn_backward(const fcn_pn_desc *d, const fcn_pn_params *p, con
 
     w.dy = nullptr; w.dz = ws->dz2; w.ycur = ws->y2; w.coef = coef2; w.yprev = nullptr; w.bn_prev = bn1;
     w.W1 = p->W[0]; w.COUT = C2; w.CIN = C1;
-    FCN_TRY(launch_wgrad<2>(w, B, d->N, ws->nsplit, st, dW[1]));
+    FCN_TRY(launch_wgrad<2>(w, B, ws->nsplit, st, dW[1]));
 
     hipLaunchKernelGGL(l1_finalize_kernel, dim3((C1 + 63) / 64), dim3(64), 0, st, bsQ, ws->stat + FCN_STAT_MOM,
                        p->W[0], p->gamma[0], bn1, C1, M, dW[0], dgamma[0], dbeta[0]);

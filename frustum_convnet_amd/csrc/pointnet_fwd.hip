@@ -14,6 +14,11 @@
 
 #define LDT 129            // LDS leading dimension of a 128-wide k-major tile
 #define MAXC 512           // largest supported reduction width (C1, C2)
+// 128x256 (8-wave) tiles halve the staging work per output but leave ~1 workgroup per CU at B=32: the 128x128
+// tiles balance better on 256 CUs (measured 124 vs 147 us on the 256->512 conv3), so they are the default.
+#ifndef FCN_WIDE_TILES
+#define FCN_WIDE_TILES 0
+#endif
 
 // ------------------------------------------------------------------------------------------------
 __global__ void bn1_finalize_kernel(const double *__restrict__ mom, const float *__restrict__ W1,
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(128 * WN) void fwd_gemm_kernel(FwdArgs a)
 __global__ __launch_bounds__(GT) void pool_kernel(
     const float *__restrict__ y3, const float *__restrict__ bn3, const int32_t *__restrict__ woff,
     const int32_t *__restrict__ cnt, const float *__restrict__ one_hot, float *__restrict__ feat,
-    int32_t *__restrict__ amax, int L, int cap, int C3, int nvec)
+    int32_t *__restrict__ amax, int L, int cap, int C3, int nvec, int nlc)
 {
     __shared__ float outS[64 * (PW + 1)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -298,7 +303,9 @@ __global__ __launch_bounds__(GT) void pool_kernel(
         }
         outS[lane * (PW + 1) + wl] = best;
         if (l < L && amax) amax[((int64_t)b * L + l) * C3 + c] = arg;
+        if (nlc && l < L) feat[((int64_t)b * L + l) * C3 + c] = best;      // position-major: lanes = channels
     }
+    if (nlc) return;
     __syncthreads();
     const int CT = C3 + nvec;
     for (int f = tid; f < 64 * PW; f += GT) {
@@ -317,7 +324,7 @@ static int launch_fwd_gemm(const FwdArgs &a, int B, hipStream_t st)
 {
     if (a.CIN % 64 || a.COUT % 64 || a.CIN > MAXC) return FCN_E_BADARG;
     const unsigned nt = (unsigned)(B * a.tps);
-    if (a.COUT % 256 == 0) {
+    if (FCN_WIDE_TILES && a.COUT % 256 == 0) {
         hipLaunchKernelGGL((fwd_gemm_kernel<MODE, 2, 4>), dim3(nt, a.COUT / 256), dim3(512), 0, st, a);
     } else if (a.COUT % 128 == 0) {
         hipLaunchKernelGGL((fwd_gemm_kernel<MODE, 2, 2>), dim3(nt, a.COUT / 128), dim3(256), 0, st, a);
@@ -333,7 +340,7 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
 {
     if (!d || !p || !ws || !cnt || !feat) return FCN_E_BADARG;
     if (d->C1 % 64 || d->C2 % 64 || d->C3 % 64 || d->C1 > MAXC || d->C2 > MAXC) return FCN_E_BADARG;
-    if (d->nvec > 0 && !one_hot) return FCN_E_BADARG;
+    if (d->nvec > 0 && !one_hot && !d->nlc) return FCN_E_BADARG;
     if (d->nvec * PW > GT) return FCN_E_LIMIT;
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, L = d->L, K = d->K, C1 = d->C1, C2 = d->C2, C3 = d->C3;
@@ -372,7 +379,7 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
 
     dim3 pgrid((L + PW - 1) / PW, C3 / 64, B);
     hipLaunchKernelGGL(pool_kernel, pgrid, dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, one_hot, feat,
-                       tr ? ws->amax : nullptr, L, cap, C3, d->nvec);
+                       tr ? ws->amax : nullptr, L, cap, C3, d->nvec, d->nlc);
     FCN_CHECK_LAUNCH();
     return 0;
 }

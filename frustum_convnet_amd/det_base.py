@@ -56,14 +56,15 @@ class PointNetModule(nn.Module):
                 [c[1].num_batches_tracked for c in convs])
         return params, bufs
 
-    def forward_pooled(self, pc, new_pc, one_hot_vec=None):
+    def forward_pooled(self, pc, new_pc, one_hot_vec=None, nlc=False):
         """Fused fast path: max over K of the masked features, one-hot appended -> (B, C3+nvec, L).
-        Equals torch.max(self.forward(pc, None, new_pc), -1)[0] (+ the concat of PointNetFeat.forward)."""
+        Equals torch.max(self.forward(pc, None, new_pc), -1)[0] (+ the concat of PointNetFeat.forward).
+        nlc=True: position-major (B, L, C3) without the one-hot rows (what the fused ConvFeatNet consumes)."""
         params, bufs = self._param_pack()
         bn = self.conv1[1]
         feat, _, _ = pointnet_pooled(self._pool, self.dist, self.nsample, self.training, bn.eps,
                                      0.1 if bn.momentum is None else bn.momentum,
-                                     pc.contiguous(), new_pc.contiguous(), one_hot_vec, bufs, params)
+                                     pc.contiguous(), new_pc.contiguous(), one_hot_vec, bufs, params, nlc=nlc)
         return feat
 
     def forward(self, pc, feat, new_pc=None):
@@ -91,12 +92,37 @@ class PointNetFeat(nn.Module):
         self.pointnet2 = PointNetModule(input_channel - 3, [64, 64, 128], u[1], 64, use_xyz=True, use_feature=True)
         self.pointnet3 = PointNetModule(input_channel - 3, [128, 128, 256], u[2], 64, use_xyz=True, use_feature=True)
         self.pointnet4 = PointNetModule(input_channel - 3, [256, 256, 512], u[3], 128, use_xyz=True, use_feature=True)
+        self.concurrent_scales = True
+        self._stream_cache = {}
 
-    def forward(self, point_cloud, sample_pc, feat=None, one_hot_vec=None):
+    def forward(self, point_cloud, sample_pc, feat=None, one_hot_vec=None, nlc=False):
         if one_hot_vec is not None:
             assert self.num_vec == one_hot_vec.shape[1]
         nets = (self.pointnet1, self.pointnet2, self.pointnet3, self.pointnet4)
-        return tuple(net.forward_pooled(point_cloud, ref, one_hot_vec) for net, ref in zip(nets, sample_pc))
+        if not (self.concurrent_scales and point_cloud.is_cuda):
+            return tuple(net.forward_pooled(point_cloud, ref, one_hot_vec, nlc) for net, ref in zip(nets, sample_pc))
+        # The four scales are independent until the FCN: run them on four HIP streams so one scale's tail
+        # (a few workgroups left on 256 CUs) overlaps the others' work.  autograd replays each scale's backward
+        # on the stream its forward ran on, so the backward overlaps the same way; the fork/join is captured
+        # as parallel branches of the step's hipGraph.
+        cur = torch.cuda.current_stream(point_cloud.device)
+        streams = self._streams(point_cloud.device)
+        outs = [None] * 4
+        order = (3, 2, 0, 1)                      # heaviest scale first
+        for s in order:
+            st = streams[s]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs[s] = nets[s].forward_pooled(point_cloud, sample_pc[s], one_hot_vec, nlc)
+        for s in order:
+            cur.wait_stream(streams[s])
+        return tuple(outs)
+
+    def _streams(self, device):
+        key = str(device)
+        if key not in self._stream_cache:
+            self._stream_cache[key] = [torch.cuda.Stream(device=device) for _ in range(4)]
+        return self._stream_cache[key]
 
 
 class ConvFeatNet(nn.Module):
@@ -174,6 +200,11 @@ class PointNetDet(nn.Module):
         # fused_loss: the whole train-loss tail (values + d total/d logits) in one HIP launch (csrc/loss_tail.hip);
         # False keeps the mask-weighted torch formulation below (needed for the optional IoU metrics).
         self.fused_loss = True
+        # fused_fcn: ConvFeatNet + heads as hand-written implicit-GEMM HIP kernels over position-major activations
+        # (csrc/fcn_net.hip); False runs the nn.Conv1d / BatchNorm1d modules through MIOpen.
+        self.fused_fcn = True
+        from .fcn_fused import CnPool
+        self._cn_pool = CnPool()
         self.last_logits = None
 
     def _slice_output(self, output):
@@ -199,10 +230,20 @@ class PointNetDet(nn.Module):
         xyz = point_cloud[:, :3, :].contiguous()
         mean_size_array = self._mean_size.to(device=point_cloud.device, dtype=point_cloud.dtype)
 
-        feat1, feat2, feat3, feat4 = self.feat_net(xyz, refs, None, one_hot_vec)
-        x = self.conv_net(feat1, feat2, feat3, feat4)
-        cls_raw = self.cls_out(x)
-        reg_raw = self.reg_out(x)
+        logits64 = None
+        if self.fused_fcn and point_cloud.is_cuda and one_hot_vec is not None:
+            from .fcn_fused import convnet_fused
+            feats = self.feat_net(xyz, refs, None, one_hot_vec, nlc=True)
+            logits64 = convnet_fused(self._cn_pool, self.conv_net, self.cls_out, self.reg_out, feats, one_hot_vec)
+            lv = logits64.view(batch_size, refs[1].shape[2], 64)
+            nreg = self.reg_out.weight.shape[0]
+            cls_raw = lv[:, :, 0:2].permute(0, 2, 1)
+            reg_raw = lv[:, :, 2:2 + nreg].permute(0, 2, 1)
+        else:
+            feat1, feat2, feat3, feat4 = self.feat_net(xyz, refs, None, one_hot_vec)
+            x = self.conv_net(feat1, feat2, feat3, feat4)
+            cls_raw = self.cls_out(x)
+            reg_raw = self.reg_out(x)
         self.last_logits = (cls_raw, reg_raw)
 
         num_out = reg_raw.shape[2]
@@ -228,12 +269,17 @@ class PointNetDet(nn.Module):
 
         if self.fused_loss and cls_raw.is_cuda and self.iou_fn is None and not self.strict \
                 and self.num_bins == 12 and self.num_size_cluster == 3:
-            from .loss_fused import det_loss_tail
+            from .loss_fused import det_loss_tail, det_loss_tail_rows
             Lw = cfg.LOSS
-            losses, (a_cls, a_head, a_size) = det_loss_tail(
-                cls_raw, reg_raw, cls_label, refs[1], center_label, heading_label, size_label, size_class_label,
-                mean_size_array, self.num_bins, self.num_size_cluster,
-                (Lw.BOX_LOSS_WEIGHT, Lw.CORNER_LOSS_WEIGHT, Lw.HEAD_REG_WEIGHT, Lw.SIZE_REG_WEIGHT))
+            wts = (Lw.BOX_LOSS_WEIGHT, Lw.CORNER_LOSS_WEIGHT, Lw.HEAD_REG_WEIGHT, Lw.SIZE_REG_WEIGHT)
+            if logits64 is not None:
+                losses, (a_cls, a_head, a_size) = det_loss_tail_rows(
+                    logits64, batch_size, num_out, cls_label, refs[1], center_label, heading_label, size_label,
+                    size_class_label, mean_size_array, self.num_bins, self.num_size_cluster, wts)
+            else:
+                losses, (a_cls, a_head, a_size) = det_loss_tail(
+                    cls_raw, reg_raw, cls_label, refs[1], center_label, heading_label, size_label, size_class_label,
+                    mean_size_array, self.num_bins, self.num_size_cluster, wts)
             zero = torch.zeros((), dtype=a_cls.dtype, device=a_cls.device)
             metrics = {'cls_acc': a_cls, 'head_acc': a_head, 'size_acc': a_size, 'IoU_2D': zero, 'IoU_3D': zero,
                        'IoU_' + str(cfg.IOU_THRESH): zero}

@@ -1,0 +1,141 @@
+"""Autograd binding of the fused ConvFeatNet + heads (C-ABI fcn_convnet_forward / fcn_convnet_backward,
+csrc/fcn_net.hip).  Input: the four position-major pooled feature maps of the PointNet scales; output: row-major
+logits (B*L2, 64) (cols 0..1 cls_out, 2..40 reg_out) that feed the fused loss tail directly."""
+import ctypes
+
+import torch
+
+from . import _native
+from ._native import CnDesc, CnParams, CnWs
+
+LAYERS = ("block1_conv1", "block2_conv1", "block2_conv2", "block2_merge", "block3_conv1", "block3_conv2",
+          "block3_merge", "block4_conv1", "block4_conv2", "block4_merge", "block2_deconv", "block3_deconv",
+          "block4_deconv")
+
+
+class CnWorkspace:
+    def __init__(self, desc, device, need_grad):
+        L = _native.lib()
+        sizes = (ctypes.c_int64 * 6)()
+        _native.check(L.fcn_convnet_sizes(ctypes.byref(desc), ctypes.byref(sizes)), "fcn_convnet_sizes")
+        ny, nwp, nbn, nst, ncoef, npart = [int(v) for v in sizes]
+        f32, f64 = torch.float32, torch.float64
+        self.y = torch.empty(ny, dtype=f32, device=device)
+        self.wp = torch.empty(nwp, dtype=f32, device=device)
+        self.bn = torch.empty(nbn, dtype=f32, device=device)
+        self.stat = torch.zeros(nst, dtype=f64, device=device)
+        self.partial = torch.empty(npart, dtype=f32, device=device)      # split-K partials: forward needs it too
+        self.dz = self.bstat = self.coef = None
+        if need_grad:
+            self.dz = torch.empty(ny, dtype=f32, device=device)
+            self.bstat = torch.zeros(nst, dtype=f64, device=device)
+            self.coef = torch.empty(ncoef, dtype=f32, device=device)
+        p = lambda t: None if t is None else t.data_ptr()
+        self.c = CnWs(p(self.y), p(self.dz), p(self.wp), p(self.bn), p(self.stat), p(self.bstat), p(self.coef),
+                      p(self.partial))
+
+
+class CnPool:
+    def __init__(self):
+        self.free = {}
+
+    def acquire(self, key, desc, device, need_grad):
+        k = key + (bool(need_grad), str(device))
+        lst = self.free.setdefault(k, [])
+        if lst:
+            return lst.pop()
+        ws = CnWorkspace(desc, device, need_grad)
+        ws.pool_key = k
+        return ws
+
+    def release(self, ws):
+        self.free.setdefault(ws.pool_key, []).append(ws)
+
+
+def _arr(ts, n=14):
+    vals = [None if t is None else t.data_ptr() for t in ts] + [None] * (n - len(ts))
+    return (ctypes.c_void_p * n)(*vals)
+
+
+class _ConvNetFused(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pool, cfgt, bufs, one_hot, f1, f2, f3, f4, *pt):
+        # pt: 13 conv weights, 13 gammas, 13 betas, cls_w, reg_w, cls_b, reg_b
+        training, eps, momentum, need_grad = cfgt
+        L = _native.lib()
+        feats = [f.detach().contiguous() for f in (f1, f2, f3, f4)]
+        B = feats[0].shape[0]
+        Ls = [f.shape[1] for f in feats]
+        Ws = [w.detach().contiguous() for w in pt[0:13]]
+        gs = [g.detach().contiguous() for g in pt[13:26]]
+        bs = [b.detach().contiguous() for b in pt[26:39]]
+        cls_w, reg_w, cls_b, reg_b = [t.detach() for t in pt[39:43]]
+        Wh = torch.cat([cls_w, reg_w], 0).contiguous()
+        bh = torch.cat([cls_b, reg_b], 0).contiguous()
+        nvec = 0 if one_hot is None else one_hot.shape[1]
+        oh = None if one_hot is None else one_hot.detach().contiguous().float()
+        dev = feats[0].device
+        desc = CnDesc(B, (ctypes.c_int32 * 4)(*Ls), nvec, reg_w.shape[0], 1 if training else 0, eps, momentum)
+        ws = pool.acquire((B,) + tuple(Ls) + (nvec, reg_w.shape[0]), desc, dev, need_grad)
+        rmeans, rvars, nbts = bufs
+        params = CnParams(_arr(Ws + [Wh]), _arr(gs), _arr(bs), _arr(rmeans), _arr(rvars), _arr(nbts), bh.data_ptr())
+        logits = torch.empty((B * Ls[1], 64), dtype=torch.float32, device=dev)
+        fp = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in feats])
+        with torch.cuda.device(dev):
+            _native.check(L.fcn_convnet_forward(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(ws.c), fp,
+                                                None if oh is None else oh.data_ptr(), logits.data_ptr(),
+                                                _native.current_stream(dev)), "fcn_convnet_forward")
+        ctx.pool, ctx.live = pool, need_grad
+        if need_grad:
+            ctx.ws, ctx.desc, ctx.keep = ws, desc, (feats, oh, Ws, Wh, gs, bs, bh)
+            ctx.shapes = [w.shape for w in pt[0:13]]
+        else:
+            pool.release(ws)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        if not ctx.live:
+            raise RuntimeError("fused ConvFeatNet forward ran without saved state (eval mode or no_grad)")
+        L = _native.lib()
+        ws, desc = ctx.ws, ctx.desc
+        feats, oh, Ws, Wh, gs, bs, bh = ctx.keep
+        dev = dlogits.device
+        dlogits = dlogits.contiguous().float()
+        dfeats = [torch.empty_like(f) for f in feats]
+        dW = [torch.empty_like(w) for w in Ws] + [torch.empty_like(Wh)]
+        dg = [torch.empty_like(g) for g in gs]
+        db = [torch.empty_like(b) for b in bs]
+        dbh = torch.empty_like(bh)
+        params = CnParams(_arr(Ws + [Wh]), _arr(gs), _arr(bs), _arr([]), _arr([]), _arr([]), bh.data_ptr())
+        fp = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in feats])
+        dfp = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in dfeats])
+        with torch.cuda.device(dev):
+            _native.check(L.fcn_convnet_backward(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(ws.c), fp,
+                                                 None if oh is None else oh.data_ptr(), dlogits.data_ptr(), dfp,
+                                                 _arr(dW), _arr(dg), _arr(db), dbh.data_ptr(),
+                                                 _native.current_stream(dev)), "fcn_convnet_backward")
+        ctx.pool.release(ws)
+        ctx.ws, ctx.live = None, False
+        ncls = 2
+        return (None, None, None, None, dfeats[0], dfeats[1], dfeats[2], dfeats[3]) + tuple(dW[:13]) + tuple(dg) + \
+            tuple(db) + (dW[13][:ncls], dW[13][ncls:], dbh[:ncls], dbh[ncls:])
+
+
+def convnet_fused(pool, conv_net, cls_out, reg_out, feats, one_hot):
+    """feats: 4 x (B, L_s, C_s) position-major pooled features.  Returns logits (B*L2, 64)."""
+    if not feats[0].is_cuda:
+        raise RuntimeError("frustum_convnet_amd: fused ConvFeatNet runs on the GPU only")
+    seqs = [getattr(conv_net, n) for n in LAYERS]
+    Ws = [s[0].weight for s in seqs]
+    gs = [s[1].weight for s in seqs]
+    bs = [s[1].bias for s in seqs]
+    bufs = ([s[1].running_mean for s in seqs], [s[1].running_var for s in seqs],
+            [s[1].num_batches_tracked for s in seqs])
+    bn0 = seqs[0][1]
+    training = conv_net.training
+    pt = Ws + gs + bs + [cls_out.weight, reg_out.weight, cls_out.bias, reg_out.bias]
+    need_grad = bool(training) and torch.is_grad_enabled() and (
+        any(t.requires_grad for t in pt) or any(f.requires_grad for f in feats))
+    cfgt = (bool(training), float(bn0.eps), float(0.1 if bn0.momentum is None else bn0.momentum), need_grad)
+    return _ConvNetFused.apply(pool, cfgt, bufs, one_hot, feats[0], feats[1], feats[2], feats[3], *pt)

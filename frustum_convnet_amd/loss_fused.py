@@ -56,3 +56,48 @@ def det_loss_tail(cls_raw, reg_raw, cls_label, center_ref2, box3d_center, box3d_
     for i, k in enumerate(LOSS_NAMES[1:], start=1):
         losses[k] = rest[i]
     return losses, (rest[8], rest[9], rest[10])
+
+
+class _LossTailRows(torch.autograd.Function):
+    """Same tail on the row-major (B*L2, 64) logits of the fused ConvFeatNet."""
+
+    @staticmethod
+    def forward(ctx, logits, cls_label, ref2, center, heading, size, size_class, mean_size, B, L2, nb, ns, w):
+        L = _native.lib()
+        lg = logits.detach().contiguous()
+        need = logits.requires_grad
+        out = torch.empty(16, dtype=torch.float32, device=lg.device)
+        dlog = torch.empty_like(lg) if need else None
+        args = [cls_label.contiguous(), ref2.contiguous().float(), center.contiguous().float(),
+                heading.contiguous().float(), size.contiguous().float(), size_class.contiguous(),
+                mean_size.contiguous().float()]
+        with torch.cuda.device(lg.device):
+            rc = L.fcn_det_loss_tail_rows(lg.data_ptr(), *[t.data_ptr() for t in args], int(B), int(L2), int(nb),
+                                          int(ns), float(w[0]), float(w[1]), float(w[2]), float(w[3]),
+                                          out.data_ptr(), None if dlog is None else dlog.data_ptr(),
+                                          _native.current_stream(lg.device))
+        _native.check(rc, "fcn_det_loss_tail_rows")
+        ctx.need = need
+        if need:
+            ctx.save_for_backward(dlog)
+        total = out[0].clone()
+        rest = out.detach()
+        ctx.mark_non_differentiable(rest)
+        return total, rest
+
+    @staticmethod
+    def backward(ctx, gtotal, _grest):
+        if not ctx.need:
+            return (None,) * 13
+        (dlog,) = ctx.saved_tensors
+        return (dlog * gtotal,) + (None,) * 12
+
+
+def det_loss_tail_rows(logits, B, L2, cls_label, center_ref2, box3d_center, box3d_heading, box3d_size, size_class,
+                       mean_size, num_bins, num_sizes, weights):
+    total, rest = _LossTailRows.apply(logits, cls_label, center_ref2, box3d_center, box3d_heading, box3d_size,
+                                      size_class, mean_size, B, L2, num_bins, num_sizes, weights)
+    losses = {"total_loss": total}
+    for i, k in enumerate(LOSS_NAMES[1:], start=1):
+        losses[k] = rest[i]
+    return losses, (rest[8], rest[9], rest[10])

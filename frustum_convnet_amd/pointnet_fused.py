@@ -74,24 +74,25 @@ def _params_struct(Ws, gammas, betas, rmeans, rvars, nbts):
 def _forward_impl(pool, cfgt, pc, ref, one_hot, bufs, plist, need_grad):
     """grouping -> compaction -> fused forward of one scale; returns the workspace still held."""
     dist, K, training, eps, momentum = cfgt[:5]
+    nlc = bool(cfgt[6]) if len(cfgt) > 6 else False
     W1, g1, b1, W2, g2, b2, W3, g3, b3 = plist
     L = _native.lib()
     B, _, N = pc.shape
     Lw = ref.shape[2]
     C1, C2, C3 = W1.shape[0], W2.shape[0], W3.shape[0]
-    nvec = 0 if one_hot is None else one_hot.shape[1]
+    nvec = 0 if (one_hot is None or nlc) else one_hot.shape[1]
     dev = pc.device
     idx, cnt = query_depth_point(dist, K, pc, ref)
     ws = pool.acquire(B, N, Lw, K, C1, C2, C3, device=dev, need_grad=need_grad)
-    desc = PnDesc(B, N, Lw, K, C1, C2, C3, nvec, 1 if training else 0, eps, momentum)
+    desc = PnDesc(B, N, Lw, K, C1, C2, C3, nvec, 1 if training else 0, eps, momentum, 1 if nlc else 0)
     rmeans, rvars, nbts = bufs
     Wc = [W1.detach().reshape(C1, 3).contiguous(), W2.detach().reshape(C2, C1).contiguous(),
           W3.detach().reshape(C3, C2).contiguous()]
     gs = [g1.detach().contiguous(), g2.detach().contiguous(), g3.detach().contiguous()]
     bs = [b1.detach().contiguous(), b2.detach().contiguous(), b3.detach().contiguous()]
     params = _params_struct(Wc, gs, bs, rmeans, rvars, nbts)
-    feat = torch.empty((B, C3 + nvec, Lw), dtype=torch.float32, device=dev)
-    oh = None if one_hot is None else one_hot.detach().contiguous().float()
+    feat = torch.empty((B, Lw, C3) if nlc else (B, C3 + nvec, Lw), dtype=torch.float32, device=dev)
+    oh = None if (one_hot is None or nlc) else one_hot.detach().contiguous().float()
     with torch.cuda.device(dev):
         st = _native.current_stream(dev)
         _native.check(L.fcn_pn_compact(ctypes.byref(desc), pc.data_ptr(), ref.data_ptr(), idx.data_ptr(),
@@ -148,13 +149,14 @@ class _PointNetPooled(torch.autograd.Function):
                 dW[0].view(s1), dg[0], db[0], dW[1].view(s2), dg[1], db[1], dW[2].view(s3), dg[2], db[2])
 
 
-def pointnet_pooled(pool, dist, nsample, training, eps, momentum, pc, ref, one_hot, bufs, params):
-    """params = (W1,g1,b1,W2,g2,b2,W3,g3,b3); bufs = ([rm1,rm2,rm3],[rv1,rv2,rv3],[nbt1,nbt2,nbt3])."""
+def pointnet_pooled(pool, dist, nsample, training, eps, momentum, pc, ref, one_hot, bufs, params, nlc=False):
+    """params = (W1,g1,b1,W2,g2,b2,W3,g3,b3); bufs = ([rm1,rm2,rm3],[rv1,rv2,rv3],[nbt1,nbt2,nbt3]).
+    nlc=True returns position-major (B, L, C3) features without the one-hot rows (input of the fused ConvFeatNet)."""
     if not pc.is_cuda:
         raise RuntimeError("frustum_convnet_amd: the PointNet hot path runs on an MI355X only "
                            "(got a %s tensor); there is no CPU fallback" % pc.device)
     need_grad = bool(training) and torch.is_grad_enabled() and any(t.requires_grad for t in params)
-    cfgt = (float(dist), int(nsample), bool(training), float(eps), float(momentum), need_grad)
+    cfgt = (float(dist), int(nsample), bool(training), float(eps), float(momentum), need_grad, bool(nlc))
     return _PointNetPooled.apply(pool, cfgt, pc, ref, one_hot, bufs, *params)
 
 

@@ -15,6 +15,8 @@
  *                               PointNetFeat.forward: gather, centre subtract, 3 x [Conv2d 1x1, BatchNorm2d,
  *                               ReLU], (cnt>0) mask, torch.max(.,-1), one-hot concat
  *                               models/det_base.py:75-101,134-157 (+ autograd of the same)
+ *   fcn_convnet_forward/backward ConvFeatNet.forward + cls_out/reg_out (cuDNN/ATen in the reference),
+ *                               models/det_base.py:196-224,367-368 (+ autograd of the same)
  *   fcn_det_loss_tail           the ~150 torch ops of the train-loss tail, models/det_base.py:373-476
  *
  * Buffers are caller-owned.  "ws" buffers are scratch the caller provides (sizes documented per call).
@@ -58,6 +60,8 @@ typedef struct fcn_pn_desc {
     int32_t nvec;                /* one-hot width appended after pooling (0..)              */
     int32_t training;            /* 1: batch statistics (+ running-stat update), 0: running */
     float   eps, momentum;       /* BatchNorm eps (1e-5) and momentum (0.1)                 */
+    int32_t nlc;                 /* 0: feat/dfeat are (B, C3+nvec, L) as the reference returns them;
+                                    1: position-major (B, L, C3), no one-hot rows (input of fcn_convnet_*) */
 } fcn_pn_desc;
 
 /* Parameters of the three conv+BN pairs (reference state_dict order: conv{1,2,3}.0.weight,
@@ -112,6 +116,50 @@ int fcn_pn_conv_fwd(const fcn_pn_desc *d, const fcn_pn_params *p, const fcn_pn_w
                     int with_stats, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * ConvFeatNet + heads (models/det_base.py:163-224,250-251,365-368): 10 Conv1d + 3 ConvTranspose1d (each with
+ * BatchNorm1d + ReLU) and the two k=1 heads, as implicit GEMMs over position-major (B*L, C) activations.
+ * Layer order of every per-layer array (14 entries; entry 13 = heads, no BN):
+ *   0 block1_conv1  1 block2_conv1  2 block2_conv2  3 block2_merge  4 block3_conv1  5 block3_conv2  6 block3_merge
+ *   7 block4_conv1  8 block4_conv2  9 block4_merge  10 block2_deconv  11 block3_deconv  12 block4_deconv  13 heads
+ * W[l]: the torch weight ((Cout,Cin,k) Conv1d / (Cin,Cout,k) ConvTranspose1d); W[13] = cat(cls_out.weight,
+ * reg_out.weight) (2+reg_out, 768, 1), bias = cat of the two biases.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct fcn_cn_desc {
+    int32_t B;
+    int32_t L[4];                /* positions of the four pooled feature maps (L[1] is the output length)      */
+    int32_t nvec;                /* one-hot width                                                               */
+    int32_t reg_out;             /* regression head width (39 for KITTI)                                        */
+    int32_t training;
+    float   eps, momentum;
+} fcn_cn_desc;
+
+typedef struct fcn_cn_params {
+    const float *W[14];
+    const float *gamma[14], *beta[14];
+    float *running_mean[14], *running_var[14];
+    int64_t *num_batches_tracked[14];
+    const float *bias;           /* (2 + reg_out) heads bias */
+} fcn_cn_params;
+
+/* Workspace; element counts come from fcn_convnet_sizes (out6: y/dz floats, packed-weight floats, bn floats,
+ * stat/bstat doubles, coef floats, wgrad-partial floats). */
+typedef struct fcn_cn_ws {
+    float  *y, *dz, *wp, *bn;
+    double *stat, *bstat;
+    float  *coef, *partial;
+} fcn_cn_ws;
+
+int fcn_convnet_sizes(const fcn_cn_desc *d, int64_t *out6);
+/* feats[s]: (B, L[s], C_s) with C = 128,128,256,512 (fcn_pn_forward with nlc = 1); logits: (B*L[1], 64) rows, columns
+ * 0..1 = cls_out, 2..2+reg_out = reg_out, rest zero. */
+int fcn_convnet_forward(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
+                        const float *const feats[4], const float *one_hot, float *logits, void *stream);
+int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
+                         const float *const feats[4], const float *one_hot, const float *dlogits,
+                         float *const dfeats[4], float *const dW[14], float *const dgamma[14],
+                         float *const dbeta[14], float *dbias, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Fused train-loss tail of PointNetDet.forward (models/det_base.py:373-476; focal loss models/common.py:217-232,
  * huber + box corners models/model_util.py:9-19,48-72, encode/decode models/box_transform.py:5-65).
  *   cls_raw (B,2,L2), reg_raw (B,3+2*NB+4*NS,L2): raw head outputs;  cls_label (B,L2) int64 in {-1,0,1};
@@ -126,6 +174,13 @@ int fcn_det_loss_tail(const float *cls_raw, const float *reg_raw, const int64_t 
                       int B, int L2, int num_heading_bin, int num_size_cluster,
                       float w_box, float w_corner, float w_headreg, float w_sizereg,
                       float *out16, float *dcls, float *dreg, void *stream);
+/* Same on the row-major logits of fcn_convnet_forward: logits (B*L2, 64), dlogits same shape (fully written). */
+int fcn_det_loss_tail_rows(const float *logits, const int64_t *cls_label, const float *center_ref2,
+                           const float *box3d_center, const float *box3d_heading, const float *box3d_size,
+                           const int64_t *size_class, const float *mean_size, int B, int L2,
+                           int num_heading_bin, int num_size_cluster,
+                           float w_box, float w_corner, float w_headreg, float w_sizereg,
+                           float *out16, float *dlogits, void *stream);
 
 #ifdef __cplusplus
 }

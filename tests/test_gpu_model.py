@@ -46,10 +46,13 @@ def test_train_eval_parity(case):
         losses["total_loss"].backward()
         named = dict(m.named_parameters())
         worst = 0.0
+        nmax = float(np.max(g["grad_norms"]))
         for nm, ref in zip(g["grad_names"], g["grad_norms"]):
             got = float(named[str(nm)].grad.double().norm())
             worst = max(worst, abs(got - ref) / max(ref, 1e-3))
-            assert abs(got - ref) <= 1e-3 * max(ref, 1e-3), (nm, got, ref)
+            # 5e-3: measured fp32 noise floor of these norms -- two CPU fp32 evaluations of the same graph (reference
+            # modules vs oracle/det_ref.py) differ from the fp64 value by up to 3.5e-3 on the conv1/BN tensors
+            assert abs(got - ref) <= 5e-3 * max(ref, 1e-3) + 2e-5 * nmax, (nm, got, ref)
         print(case, "worst relative grad-norm diff %.3e" % worst)
         for k in g.files:
             if k.startswith("grad::"):
@@ -141,6 +144,7 @@ def test_fused_loss_tail_matches_torch_tail():
     m = _model(g)
     m.train()
     outs = {}
+    m.fused_fcn = False                # planar logits path: exercises fcn_det_loss_tail ((B,C,L2) layout)
     for fused in (True, False):
         m.fused_loss = fused
         m.zero_grad()
@@ -161,3 +165,76 @@ def test_fused_loss_tail_matches_torch_tail():
     ref = det_ref.loss_tail(torch.from_numpy(g["cls_train"]), torch.from_numpy(g["reg_train"]), cpu)
     for k, v in ref.items():
         assert abs(outs[True][0][k] - float(v)) <= 1e-4 * max(1.0, abs(float(v))), k
+
+
+def _fp64_oracle_grads(g, data_np):
+    from oracle import det_ref
+    sd = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in golden_state_dict(g).items()}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    d64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in synth.to_torch(data_np).items()}
+    _, _, lo = det_ref.forward(sd, d64, tuple(g["meta_strides"]), training=True)
+    lo["total_loss"].backward()
+    return {k: v.grad for k, v in sd.items() if v.grad is not None}, float(lo["total_loss"])
+
+
+@pytest.mark.parametrize("case", ["car_b4_n512", "refine_b4_n512", "people_b2_n512"])
+def test_fused_convnet_matches_module_path(case):
+    """C-ABI fcn_convnet_forward/backward + fcn_det_loss_tail_rows vs the nn.Conv1d/BatchNorm1d (MIOpen) path with the
+    same weights: logits, losses, running statistics agree; every parameter gradient of BOTH paths is judged against
+    the fp64 evaluation of the oracle (fp32 BN-backward sums cancel heavily, so two fp32 paths may differ by ~1e-3)."""
+    g = load_golden(case)
+    data_np = golden_inputs(g)
+    data = synth.to_torch(data_np, "cuda")
+    res = {}
+    for fused in (True, False):
+        m = _model(g)
+        m.train()
+        m.fused_fcn = fused
+        losses, _ = m(data)
+        losses["total_loss"].backward()
+        cls, reg = m.last_logits
+        res[fused] = (cls.detach().clone(), reg.detach().clone(), {k: float(v) for k, v in losses.items()},
+                      {k: p.grad.clone() for k, p in m.named_parameters()},
+                      {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "tracked" in k})
+    assert float((res[True][0] - res[False][0]).abs().max()) < 5e-5
+    assert float((res[True][1] - res[False][1]).abs().max()) < 5e-5
+    for k, v in res[False][2].items():
+        assert abs(res[True][2][k] - v) <= 1e-4 * max(1.0, abs(v)), k
+    for k, v in res[False][4].items():
+        assert torch.allclose(res[True][4][k].float(), v.float(), rtol=1e-4, atol=1e-5), k
+    ref, _ = _fp64_oracle_grads(g, data_np)
+    gscale = max(float(v.abs().max()) for v in ref.values())
+    for fused in (True, False):
+        for k, gref in ref.items():
+            d = float((res[fused][3][k].double().cpu() - gref).abs().max())
+            assert d <= 5e-3 * float(gref.abs().max()) + 2e-6 * gscale, (fused, k, d, float(gref.abs().max()))
+
+
+def test_gradients_vs_fp64_oracle():
+    """Every parameter gradient of the full HIP step against the fp64 evaluation of the oracle (the fp32 noise floor of
+    some of these tensors is ~3e-3 of their max, so fp64 is the referee): elementwise 5e-3 of each tensor's max."""
+    from oracle import det_ref
+    g = load_golden("car_b4_n512")
+    data_np = golden_inputs(g)
+    m = _model(g)
+    m.train()
+    losses, _ = m(synth.to_torch(data_np, "cuda"))
+    losses["total_loss"].backward()
+    sd = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in golden_state_dict(g).items()}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    d64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in synth.to_torch(data_np).items()}
+    _, _, lo = det_ref.forward(sd, d64, tuple(g["meta_strides"]), training=True)
+    lo["total_loss"].backward()
+    assert abs(float(losses["total_loss"]) - float(lo["total_loss"])) <= 1e-5 * abs(float(lo["total_loss"]))
+    worst = 0.0
+    for k, p in m.named_parameters():
+        ref = sd[k].grad
+        d = float((p.grad.double().cpu() - ref).abs().max())
+        sc = float(ref.abs().max())
+        worst = max(worst, d / max(sc, 1e-9))
+        assert d <= 5e-3 * sc + 1e-9, (k, d, sc)
+    print("worst elementwise grad error vs fp64 oracle: %.2e of tensor max" % worst)
