@@ -32,7 +32,7 @@ class CnParams(ctypes.Structure):
 
 class CnWs(ctypes.Structure):
     _fields_ = [("y", c_fp), ("dz", c_fp), ("wp", c_fp), ("bn", c_fp), ("stat", c_fp), ("bstat", c_fp),
-                ("coef", c_fp), ("partial", c_fp)]
+                ("coef", c_fp), ("partial", c_fp), ("oh64", c_fp)]
 
 
 class PnParams(ctypes.Structure):

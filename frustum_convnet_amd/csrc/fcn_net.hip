@@ -16,6 +16,7 @@
 //     mask + BN-backward sums in the epilogue), wgrad kernels reduce over rows in splits + a deterministic reduce
 //     that scatters straight into the torch weight layout.
 #include "gemm_tile.h"
+#include <cstdlib>
 
 #define CG_T 256
 #define LDC 65                 // k-major LDS leading dim of a 64-wide tile (transposed staging)
@@ -25,10 +26,10 @@
 #define CN_NLAYER 14           // 13 conv/deconv+BN layers + heads
 
 struct CgSeg {
-    const float *x;            // type 0: (B*Lsrc, C) rows; type 1: one_hot (B, nvec)
+    const float *x;            // type 0: (B*Lsrc, C) rows; type 1: one-hot zero-padded to (B, OH_PAD)
     const float *bn;           // scale[C], shift[C], mean[C], rstd[C] of the producer's BN, or nullptr (already activated)
     int C;                     // channels seen by the GEMM (type 1: OH_PAD)
-    int Lsrc;                  // rows per frustum in the source buffer
+    int Lsrc;                  // rows per frustum in the source buffer (type 1: 1 row per frustum, every position reads it)
     int type, nvec;
 };
 
@@ -43,8 +44,23 @@ struct CgLayer {
     int nbias;
     float *y;                  // (B*Lout, Cout) pre-BN output
     double *stat;              // sum[Cs], sumsq[Cs] or nullptr
+    int dbg;                   // ablation switches (env FCN_DBG): 1 skip MFMA, 2 skip global loads, 4 skip LDS staging
 };
 
+#define SEL3(i, a0, a1, a2) ((i) == 0 ? (a0) : ((i) == 1 ? (a1) : (a2)))
+
+// Pins a wave-uniform value in an SGPR.  Without it LLVM rewrites "select between fields of the by-value kernel
+// struct" into "load from a dynamically selected field address", which needs the struct in memory: the whole kernarg
+// struct gets memcpy'd to scratch and every later field access becomes a scratch load.
+template <class T>
+__device__ __forceinline__ T opaque_s(T v)
+{
+    asm volatile("" : "+s"(v));
+    return v;
+}
+
+// (segment, tap, channel) of packed column kk.  Only STATIC indices into L.seg: a dynamically indexed by-value
+// kernel struct is copied to scratch and every access becomes a scratch/vector load in the middle of the prefetch.
 __device__ __forceinline__ void cg_locate(const CgLayer &L, int kk, int &sg, int &tap, int &k0, int &segoff)
 {
     sg = 0; segoff = 0;
@@ -55,158 +71,192 @@ __device__ __forceinline__ void cg_locate(const CgLayer &L, int kk, int &sg, int
             if (sg == s && kk >= span) { kk -= span; segoff += span; sg = s + 1; }
         }
     }
-    tap = kk / L.seg[sg].C;
-    k0 = kk % L.seg[sg].C;
+    const int C = SEL3(sg, opaque_s(L.seg[0].C), opaque_s(L.seg[1].C), opaque_s(L.seg[2].C));
+    tap = kk / C;
+    k0 = kk % C;
 }
 
-// A[r][k0..k0+3] of the virtual im2col matrix for output row (b,l) and (segment, tap), activation applied.
-__device__ __forceinline__ float4 cg_load_a(const CgLayer &L, int sg, int tap, int kc, int b, int l, bool rvalid)
+// RAW, UNCONDITIONAL load of A[r][kc..kc+3] of the virtual im2col matrix: the position is clamped to a valid row and
+// `ok` says whether the value counts.  No branch and no arithmetic on the loaded value here -- the producer's BN +
+// ReLU and the ok-mask are applied when the registers go to LDS one iteration later -- so the load stays in flight
+// across the MFMA phase (a "load or zero" select makes hipcc wait for the load right away).
+// A one-hot segment is a (B, OH_PAD) buffer: one row per frustum (Lsrc = 1), every position reads it (linmul = 0).
+__device__ __forceinline__ v4f cg_load_raw(const CgLayer &L, const float *x, int C, int Lsrc, int linmul, int tap,
+                                           int kc, int b, int l, bool rvalid, bool &ok)
 {
-    const CgSeg &S = L.seg[sg];
     const int lin = l * L.stride + tap - L.pad;
-    const bool ok = rvalid && lin >= 0 && lin < L.Lin;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!ok) return v;
-    if (S.type == 0) {
-        v = *(const float4 *)(S.x + ((int64_t)b * S.Lsrc + lin) * S.C + kc);
-        if (S.bn) {
-            const float4 s = *(const float4 *)(S.bn + kc), t = *(const float4 *)(S.bn + S.C + kc);
-            v.x = fmaxf(fmaf(s.x, v.x, t.x), 0.f); v.y = fmaxf(fmaf(s.y, v.y, t.y), 0.f);
-            v.z = fmaxf(fmaf(s.z, v.z, t.z), 0.f); v.w = fmaxf(fmaf(s.w, v.w, t.w), 0.f);
-        }
-    } else {
-        const float *oh = S.x + (int64_t)b * S.nvec;
-        v.x = (kc + 0 < S.nvec) ? oh[kc + 0] : 0.f; v.y = (kc + 1 < S.nvec) ? oh[kc + 1] : 0.f;
-        v.z = (kc + 2 < S.nvec) ? oh[kc + 2] : 0.f; v.w = (kc + 3 < S.nvec) ? oh[kc + 3] : 0.f;
-    }
-    return v;
+    ok = rvalid && lin >= 0 && lin < L.Lin;
+    const int lc = min(max(lin, 0), L.Lin - 1) * linmul;
+    return ldg4(x + ((int64_t)b * Lsrc + lc) * C + kc);
 }
+
+#define CG_KMAX 1792           // largest Ktot staged as per-column BN scale/shift (block4_conv2: 3*512 = 1536)
+
+// per-column (kk) scale/shift of the virtual A matrix: BN of the producer, or (1,0) for inputs that are already
+// activations (pooled features, one-hot: both >= 0, so the ReLU applied uniformly is the identity on them)
+__device__ __forceinline__ void cg_fill_bn(const CgLayer &L, float *sS, float *tS, int tid, int nthr)
+{
+    int off = 0;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        if (s < L.nseg) {
+            const float *bn = L.seg[s].bn;
+            const int C = L.seg[s].C, span = L.KT * C;
+            for (int i = tid; i < span; i += nthr) {
+                const int k = i % C;
+                sS[off + i] = bn ? bn[k] : 1.f;
+                tS[off + i] = bn ? bn[C + k] : 0.f;
+            }
+            off += span;
+        }
+    }
+}
+
+__device__ __forceinline__ float cg_act(float s, float x, float t, bool ok) { return ok ? fmaxf(fmaf(s, x, t), 0.f) : 0.f; }
 
 // ------------------------------------------------------------------------------------------------
-// Forward: y[r][n] = sum_kk A[r][kk] * Wp[n][kk] (+bias); 64 x 64 tile, 4 waves of one 32x32 MFMA tile each.
-// gridDim.z > 1: split-K -- split z reduces chunks [z*cps, (z+1)*cps) and stores its raw tile into `partial`
-// (S, R, Cout); cg_fwd_finish_kernel sums the splits and runs the epilogue.  These GEMMs are small (B*L rows): without
-// the split a layer is ~140 workgroups of up to 48 dependent chunk iterations on 256 CUs (latency-bound, 37 us/layer).
-__global__ __launch_bounds__(CG_T) void cg_fwd_kernel(CgLayer L, float *__restrict__ partial, int cps)
+// K-group kernels: one workgroup of G groups of MW x 2 waves owns one (32*MW) x 64 output tile; group g reduces the
+// K chunks g, g+G, ... through its own LDS buffers, the group accumulators are summed through LDS and ONE pass runs
+// the whole epilogue (bias, store, BN statistics).  These GEMMs are small (B*L rows): 8-16 resident waves per
+// workgroup hide the gather / staging latency, and nothing but the result goes back to HBM.
+// <2,4>: 64 x 64 tile, 1024 threads;  <1,4>: 32 x 64 tile, 512 threads (layers with few rows: more tiles for 256 CUs).
+template <int MW, int G>
+__global__ __launch_bounds__(G * 128 * MW) void cgk_fwd_kernel(CgLayer L)
 {
-    __shared__ float As[KC * LDC];
-    __shared__ float Bs[KC * LDC];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    constexpr int TG = 128 * MW, TMB = 32 * MW, LDA = TMB + 1, NTHR = G * TG;
+    constexpr int NA = TMB * 8 / TG;          // 4-vectors of A per thread per chunk (2)
+    constexpr int NB = 512 / TG;              // 4-vectors of W per thread per chunk (2 or 4)
+    __shared__ __attribute__((aligned(16))) float lds[G * KC * (LDA + LDC)];
+    __shared__ float sS[CG_KMAX], tS[CG_KMAX];
+    __shared__ int cSeg[CG_KMAX / KC], cTap[CG_KMAX / KC], cK0[CG_KMAX / KC];   // chunk -> (segment, tap, channel)
+    const int tid = threadIdx.x, g = tid / TG, gt = tid % TG;
+    const int lane = tid & 63, gw = gt >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int wm = (MW == 2) ? (gw >> 1) : 0, wn = gw & 1;
+    float *As = lds + g * KC * (LDA + LDC), *Bs = As + KC * LDA;
     const int R = L.B * L.Lout;
-    const int row0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
-    const int kq = tid & 7, rb = tid >> 3;
-    int bb[2], ll[2];
-    bool rv[2];
+    const int row0 = blockIdx.x * TMB, n0 = blockIdx.y * 64;
+    const int kq = gt & 7, rb = gt >> 3;      // rb: 0..31 (MW=2) or 0..15 (MW=1)
+    constexpr int RSTEP = TG / 8;
+    const int nchunk = L.Ktot / KC, nit = (nchunk + G - 1) / G;
+    if (tid < nchunk) {
+        int sg, tap, k0, so;
+        cg_locate(L, tid * KC, sg, tap, k0, so);
+        cSeg[tid] = sg; cTap[tid] = tap; cK0[tid] = k0;
+    }
+    cg_fill_bn(L, sS, tS, tid, NTHR);
+    // segment fields as scalars (static indices)
+    const float *x0 = opaque_s(L.seg[0].x), *x1 = opaque_s(L.seg[1].x), *x2 = opaque_s(L.seg[2].x);
+    const int C0 = opaque_s(L.seg[0].C), C1 = opaque_s(L.seg[1].C), C2 = opaque_s(L.seg[2].C);
+    const int T0 = opaque_s(L.seg[0].type), T1 = opaque_s(L.seg[1].type), T2 = opaque_s(L.seg[2].type);
+    const int Q0 = opaque_s(L.seg[0].Lsrc), Q1 = opaque_s(L.seg[1].Lsrc), Q2 = opaque_s(L.seg[2].Lsrc);
+    int bb[NA], ll[NA];
+    bool rv[NA], ok[NA];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int g = row0 + rb + 32 * i;
-        rv[i] = g < R;
-        bb[i] = rv[i] ? g / L.Lout : 0;
-        ll[i] = rv[i] ? g % L.Lout : 0;
+    for (int i = 0; i < NA; ++i) {
+        const int gr = row0 + rb + RSTEP * i;
+        rv[i] = gr < R;
+        bb[i] = rv[i] ? gr / L.Lout : 0;
+        ll[i] = rv[i] ? gr % L.Lout : 0;
+        ok[i] = false;
     }
     f32x16 acc[1][1];
     acc_zero<1, 1>(acc);
-    float4 ra[2], rw[2];
-    const int nchunk_all = L.Ktot / KC;
-    const int cbeg = blockIdx.z * cps, nchunk = min(nchunk_all, cbeg + cps);
-    auto load_chunk = [&](int c) {
-        int sg, tap, k0, so;
-        cg_locate(L, c * KC, sg, tap, k0, so);
+    v4f ra[NA], rw[NB];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            ra[i] = cg_load_a(L, sg, tap, k0 + 4 * kq, bb[i], ll[i], rv[i]);
-            rw[i] = *(const float4 *)(L.Wp + (int64_t)(n0 + rb + 32 * i) * L.Ktot + c * KC + 4 * kq);
-        }
-    };
-    load_chunk(cbeg);
-    for (int c = cbeg; c < nchunk; ++c) {
+    for (int i = 0; i < NA; ++i) ra[i] = zero4();
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = rb + 32 * i;
-            As[(4 * kq + 0) * LDC + r] = ra[i].x; As[(4 * kq + 1) * LDC + r] = ra[i].y;
-            As[(4 * kq + 2) * LDC + r] = ra[i].z; As[(4 * kq + 3) * LDC + r] = ra[i].w;
-            Bs[(4 * kq + 0) * LDC + r] = rw[i].x; Bs[(4 * kq + 1) * LDC + r] = rw[i].y;
-            Bs[(4 * kq + 2) * LDC + r] = rw[i].z; Bs[(4 * kq + 3) * LDC + r] = rw[i].w;
+    for (int i = 0; i < NB; ++i) rw[i] = zero4();
+    // (a macro, not a lambda: the by-reference closure of a lambda called from two places is not always scalarised by
+    // hipcc and drags every captured variable into scratch)
+    // the chunk (hence the segment) is uniform within a K-group, i.e. within every wave: scalar selects
+#define CGK_FWD_LOAD(cc)                                                                                              \
+    {                                                                                                                 \
+        const int c_ = (cc);                                                                                          \
+        const int sgi = __builtin_amdgcn_readfirstlane(cSeg[c_]);                                                     \
+        const int tap = __builtin_amdgcn_readfirstlane(cTap[c_]), k0 = __builtin_amdgcn_readfirstlane(cK0[c_]);       \
+        const float *x = SEL3(sgi, x0, x1, x2);                                                                       \
+        const int C = SEL3(sgi, C0, C1, C2), ty = SEL3(sgi, T0, T1, T2), Ls = SEL3(sgi, Q0, Q1, Q2);                  \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                                \
+            ra[i] = cg_load_raw(L, x, C, Ls, ty ? 0 : 1, tap, k0 + 4 * kq, bb[i], ll[i], rv[i], ok[i]);               \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                                \
+            rw[i] = ldg4(L.Wp + (int64_t)(n0 + rb + RSTEP * i) * L.Ktot + c_ * KC + 4 * kq);                          \
+    }
+    const bool dload = !(L.dbg & 2), dlds = !(L.dbg & 4), dmma = !(L.dbg & 1);
+    __syncthreads();                            // sS / tS and the chunk table ready
+    if (dload) CGK_FWD_LOAD(min(g, nchunk - 1));
+    for (int it = 0; it < nit; ++it) {
+        const int c = it * G + g;
+        const bool act = c < nchunk;
+        if (act && dlds) {
+            const float *sp = sS + c * KC + 4 * kq, *tp = tS + c * KC + 4 * kq;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int r = rb + RSTEP * i;
+                As[(4 * kq + 0) * LDA + r] = cg_act(sp[0], ra[i].x, tp[0], ok[i]);
+                As[(4 * kq + 1) * LDA + r] = cg_act(sp[1], ra[i].y, tp[1], ok[i]);
+                As[(4 * kq + 2) * LDA + r] = cg_act(sp[2], ra[i].z, tp[2], ok[i]);
+                As[(4 * kq + 3) * LDA + r] = cg_act(sp[3], ra[i].w, tp[3], ok[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int n = rb + RSTEP * i;
+                Bs[(4 * kq + 0) * LDC + n] = rw[i].x; Bs[(4 * kq + 1) * LDC + n] = rw[i].y;
+                Bs[(4 * kq + 2) * LDC + n] = rw[i].z; Bs[(4 * kq + 3) * LDC + n] = rw[i].w;
+            }
         }
         __syncthreads();
-        if (c + 1 < nchunk) load_chunk(c + 1);
-        mma_chunk<1, 1, LDC, LDC>(As, Bs, wm * 32, wn * 32, acc);
+        if (c + G < nchunk && dload) CGK_FWD_LOAD(c + G);
+        if (act && dmma) mma_chunk<1, 1, LDA, LDC>(As, Bs, wm * 32, wn * 32, acc);
         __syncthreads();
     }
-    const int col = n0 + wn * 32 + l31;
-    if (partial) {
-        float *pp = partial + (int64_t)blockIdx.z * R * L.Cout;
+    // ---- sum the G group accumulators through LDS, then one epilogue pass over the tile
+    float *red = lds;                                   // [G][TMB][64]
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row = row0 + wm * 32 + acc_row(reg, lh);
-            if (row < R) pp[(int64_t)row * L.Cout + col] = acc[0][0][reg];
+    for (int reg = 0; reg < 16; ++reg)
+        red[(g * TMB + wm * 32 + acc_row(reg, lh)) * 64 + wn * 32 + l31] = acc[0][0][reg];
+    __syncthreads();
+    const int ecq = tid & 15;
+    const int col = n0 + 4 * ecq;
+    v4f cs1 = zero4(), cs2 = zero4();                   // per-thread column sums (over its rows)
+    for (int er = tid >> 4; er < TMB; er += NTHR / 16) {
+        v4f v = zero4();
+#pragma unroll
+        for (int q = 0; q < G; ++q) v += *(const v4f *)(red + (q * TMB + er) * 64 + 4 * ecq);
+        if (L.bias) {
+            v.x += col + 0 < L.nbias ? L.bias[col + 0] : 0.f; v.y += col + 1 < L.nbias ? L.bias[col + 1] : 0.f;
+            v.z += col + 2 < L.nbias ? L.bias[col + 2] : 0.f; v.w += col + 3 < L.nbias ? L.bias[col + 3] : 0.f;
         }
-        return;
-    }
-    const float bias = (L.bias && col < L.nbias) ? L.bias[col] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int row = row0 + wm * 32 + acc_row(reg, lh);
+        const int row = row0 + er;
         if (row < R) {
-            const float v = acc[0][0][reg] + bias;
-            L.y[(int64_t)row * L.Cout + col] = v;
-            s1 += v;
-            s2 = fmaf(v, v, s2);
+            sts4(L.y + (int64_t)row * L.Cout + col, v);
+            cs1 += v;
+            cs2 += v * v;
         }
-    }
-    if (L.stat) {
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        float *red = As;
-        if (wm == 1 && lh == 0) { red[(wn * 32 + l31) * 2] = s1; red[(wn * 32 + l31) * 2 + 1] = s2; }
-        __syncthreads();
-        if (wm == 0 && lh == 0) {
-            const int ch = col % L.Cs;
-            atomic_add_f64(&L.stat[ch], (double)s1 + (double)red[(wn * 32 + l31) * 2]);
-            atomic_add_f64(&L.stat[L.Cs + ch], (double)s2 + (double)red[(wn * 32 + l31) * 2 + 1]);
-        }
-    }
-}
-
-// y = sum of the split partials (+bias), BN statistics.  Workgroup: 128 rows x 64 columns, thread = 4 columns x 16 row lanes.
-__global__ __launch_bounds__(CG_T) void cg_fwd_finish_kernel(CgLayer L, const float *__restrict__ partial, int S)
-{
-    __shared__ float red[16][64][2];
-    const int tid = threadIdx.x, cq = tid & 15, rl = tid >> 4;
-    const int R = L.B * L.Lout;
-    const int col = blockIdx.y * 64 + 4 * cq;
-    const int rbeg = blockIdx.x * 128, rend = min(R, rbeg + 128);
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (L.bias) {
-        bias.x = col + 0 < L.nbias ? L.bias[col + 0] : 0.f; bias.y = col + 1 < L.nbias ? L.bias[col + 1] : 0.f;
-        bias.z = col + 2 < L.nbias ? L.bias[col + 2] : 0.f; bias.w = col + 3 < L.nbias ? L.bias[col + 3] : 0.f;
-    }
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    const int64_t plane = (int64_t)R * L.Cout;
-    for (int row = rbeg + rl; row < rend; row += 16) {
-        const int64_t o = (int64_t)row * L.Cout + col;
-        float4 v = bias;
-        for (int sp = 0; sp < S; ++sp) {
-            const float4 q = *(const float4 *)(partial + sp * plane + o);
-            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-        }
-        *(float4 *)(L.y + o) = v;
-        s1[0] += v.x; s1[1] += v.y; s1[2] += v.z; s1[3] += v.w;
-        s2[0] = fmaf(v.x, v.x, s2[0]); s2[1] = fmaf(v.y, v.y, s2[1]);
-        s2[2] = fmaf(v.z, v.z, s2[2]); s2[3] = fmaf(v.w, v.w, s2[3]);
     }
     if (!L.stat) return;
+    // rows of one wave: lanes 16 apart share a column quad -> xor-shuffle over 16 and 32, then across waves via LDS
+    float pv[8] = {cs1.x, cs1.y, cs1.z, cs1.w, cs2.x, cs2.y, cs2.z, cs2.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { red[rl][4 * cq + j][0] = s1[j]; red[rl][4 * cq + j][1] = s2[j]; }
+    for (int q = 0; q < 8; ++q) {
+        pv[q] += __shfl_xor(pv[q], 16, 64);
+        pv[q] += __shfl_xor(pv[q], 32, 64);
+    }
+    __syncthreads();
+    float *st = lds;                                    // [NTHR/64 waves][64 cols][2]
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            st[((tid >> 6) * 64 + 4 * ecq + j) * 2] = pv[j];
+            st[((tid >> 6) * 64 + 4 * ecq + j) * 2 + 1] = pv[4 + j];
+        }
+    }
     __syncthreads();
     if (tid < 128) {
         const int c = tid & 63, w = tid >> 6;
         double a = 0.0;
-        for (int r = 0; r < 16; ++r) a += (double)red[r][c][w];
-        const int ch = (blockIdx.y * 64 + c) % L.Cs;
-        atomic_add_f64(&L.stat[w * L.Cs + ch], a);
+#pragma unroll
+        for (int r = 0; r < NTHR / 64; ++r) a += (double)st[(r * 64 + c) * 2 + w];
+        atomic_add_f64(&L.stat[w * L.Cs + (n0 + c) % L.Cs], a);
     }
 }
 
@@ -255,21 +305,13 @@ __global__ void cn_bnbwd_finalize_kernel(const double *__restrict__ bstat, const
     dbeta[c] = (float)db;
 }
 
-// dy of a BN layer for 4 consecutive columns: kk*(dz - dbeta/M - xhat*dgamma/M); coef == nullptr: dy = dz (heads)
-__device__ __forceinline__ float4 cg_dy4(const float *dz, const float *y, const float *coef, int Cs, int64_t off, int col)
+#define CG_CMAX 512            // largest BN width (Cs) whose backward coefficients are staged in LDS
+
+// dy of a BN layer from raw (dz, y) and the LDS-staged coefficients: kk*(dz - dbeta/M - xhat*dgamma/M)
+__device__ __forceinline__ float cg_dy(const float *coefS, int Cs, int ch, float dz, float y)
 {
-    float4 d = *(const float4 *)(dz + off);
-    if (!coef) return d;
-    const float4 yv = *(const float4 *)(y + off);
-    const int ch = col % Cs;                 // 4 consecutive columns never straddle a Cs boundary (Cs % 64 == 0)
-    const float4 kk = *(const float4 *)(coef + ch), mu = *(const float4 *)(coef + Cs + ch);
-    const float4 rs = *(const float4 *)(coef + 2 * Cs + ch), cb = *(const float4 *)(coef + 3 * Cs + ch);
-    const float4 cg = *(const float4 *)(coef + 4 * Cs + ch);
-    d.x = kk.x * (d.x - fmaf((yv.x - mu.x) * rs.x, cg.x, cb.x));
-    d.y = kk.y * (d.y - fmaf((yv.y - mu.y) * rs.y, cg.y, cb.y));
-    d.z = kk.z * (d.z - fmaf((yv.z - mu.z) * rs.z, cg.z, cb.z));
-    d.w = kk.w * (d.w - fmaf((yv.w - mu.w) * rs.w, cg.w, cb.w));
-    return d;
+    const float xh = (y - coefS[Cs + ch]) * coefS[2 * Cs + ch];
+    return coefS[ch] * (dz - fmaf(xh, coefS[4 * Cs + ch], coefS[3 * Cs + ch]));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -283,162 +325,150 @@ struct CgDgrad {
     double *bstat_src;         // non-null on the LAST consumer: sum dz, sum dz*xhat of the producer
 };
 
-// G[rs][k] = sum_tap sum_n dy[r_out(rs,tap)][n] * Wp[n][segoff + tap*C + k]; 64 source rows x 64 source channels.
-__global__ __launch_bounds__(CG_T) void cg_dgrad_kernel(CgDgrad a, float *__restrict__ partial, int cps)
+// G[rs][k] = sum_tap sum_n dy[r_out(rs,tap)][n] * Wp[n][segoff + tap*C + k]; (32*MW) source rows x 64 source channels,
+// then the producer-side epilogue: ReLU mask from its pre-BN output, accumulate (second consumer), BN-backward sums.
+template <int MW, int G>
+__global__ __launch_bounds__(G * 128 * MW) void cgk_dgrad_kernel(CgDgrad a)
 {
-    __shared__ __attribute__((aligned(16))) float As[KC * LDC];
-    __shared__ __attribute__((aligned(16))) float Bs[KC * LDN];
+    constexpr int TG = 128 * MW, TMB = 32 * MW, LDA = TMB + 1, NTHR = G * TG;
+    constexpr int NA = TMB * 8 / TG, NB = 512 / TG;
+    constexpr int ASZ = KC * (LDA + 3);                 // As padded so that Bs stays 16-B aligned
+    __shared__ __attribute__((aligned(16))) float lds[G * (ASZ + KC * LDN)];
+    __shared__ float coefS[5 * CG_CMAX];
     const CgLayer &L = a.lay;
-    const CgSeg &S = L.seg[a.sg];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5, wm = wave >> 1, wn = wave & 1;
-    const int C = S.C, Rs = L.B * S.Lsrc;
-    const int row0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    const int kq = tid & 7, rb = tid >> 3;
-    int bb[2], li[2];
-    bool rv[2];
+    // a.sg is a kernel argument (scalar): static-index selects, no dynamic struct indexing
+    const int SC = SEL3(a.sg, opaque_s(L.seg[0].C), opaque_s(L.seg[1].C), opaque_s(L.seg[2].C));
+    const int SLsrc = SEL3(a.sg, opaque_s(L.seg[0].Lsrc), opaque_s(L.seg[1].Lsrc), opaque_s(L.seg[2].Lsrc));
+    const int tid = threadIdx.x, g = tid / TG, gt = tid % TG;
+    const int lane = tid & 63, gw = gt >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int wm = (MW == 2) ? (gw >> 1) : 0, wn = gw & 1;
+    float *As = lds + g * (ASZ + KC * LDN), *Bs = As + ASZ;
+    const int C = SC, Rs = L.B * SLsrc, Cs = L.Cs;
+    const int row0 = blockIdx.x * TMB, c0 = blockIdx.y * 64;
+    const int kq = gt & 7, rb = gt >> 3;
+    constexpr int RSTEP = TG / 8;
+    const bool hasbn = a.coefc != nullptr;
+    if (hasbn)
+        for (int i = tid; i < 5 * Cs; i += NTHR) coefS[i] = a.coefc[i];
+    int bb[NA], li[NA];
+    bool rv[NA], ok[NA];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int g = row0 + rb + 32 * i;
-        rv[i] = g < Rs;
-        bb[i] = rv[i] ? g / S.Lsrc : 0;
-        li[i] = rv[i] ? g % S.Lsrc : 0;
-        rv[i] = rv[i] && li[i] < L.Lin;          // cropped positions receive no gradient
+    for (int i = 0; i < NA; ++i) {
+        const int gr = row0 + rb + RSTEP * i;
+        rv[i] = gr < Rs;
+        bb[i] = rv[i] ? gr / SLsrc : 0;
+        li[i] = rv[i] ? gr % SLsrc : 0;
+        rv[i] = rv[i] && li[i] < L.Lin;
+        ok[i] = false;
     }
     f32x16 acc[1][1];
     acc_zero<1, 1>(acc);
-    float4 ra[2], rw[2];
-    const int ncn = L.Cout / KC;                  // n-chunks per tap
-    const int cbeg = blockIdx.z * cps, nchunk = min(L.KT * ncn, cbeg + cps);
-    auto load_chunk = [&](int c) {
+    v4f rz[NA], ry[NA], rw[NB];
+    const int ncn = L.Cout / KC, nchunk = L.KT * ncn, nit = (nchunk + G - 1) / G;
+    auto load_chunk = [&](int c) __attribute__((always_inline)) {
         const int tap = c / ncn, nq = (c % ncn) * KC + 4 * kq;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NA; ++i) {
             const int t = li[i] + L.pad - tap;
             const int lo = t / L.stride;
-            const bool ok = rv[i] && t >= 0 && (t % L.stride) == 0 && lo < L.Lout;
-            ra[i] = ok ? cg_dy4(a.dzc, a.yc, a.coefc, L.Cs, ((int64_t)bb[i] * L.Lout + lo) * L.Cout + nq, nq)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            ok[i] = rv[i] && t >= 0 && (t % L.stride) == 0 && lo < L.Lout;
+            const int64_t o = ((int64_t)bb[i] * L.Lout + min(max(lo, 0), L.Lout - 1)) * L.Cout + nq;
+            rz[i] = ldg4(a.dzc + o);                       // unconditional (clamped row), masked at store time
+            ry[i] = ldg4((hasbn ? a.yc : a.dzc) + o);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int f = tid + CG_T * i;
+        for (int i = 0; i < NB; ++i) {
+            const int f = gt + TG * i;
             const int nn = f >> 4, cq = f & 15;
-            rw[i] = *(const float4 *)(L.Wp + (int64_t)((c % ncn) * KC + nn) * L.Ktot + a.segoff + tap * C + c0 + 4 * cq);
+            rw[i] = ldg4(L.Wp + (int64_t)((c % ncn) * KC + nn) * L.Ktot + a.segoff + tap * C + c0 + 4 * cq);
         }
     };
-    load_chunk(cbeg);
-    for (int c = cbeg; c < nchunk; ++c) {
+    load_chunk(min(g, nchunk - 1));
+    __syncthreads();                            // coefS ready
+    for (int it = 0; it < nit; ++it) {
+        const int c = it * G + g;
+        const bool act = c < nchunk;
+        if (act) {
+            const int nq = (c % ncn) * KC + 4 * kq;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = rb + 32 * i;
-            As[(4 * kq + 0) * LDC + r] = ra[i].x; As[(4 * kq + 1) * LDC + r] = ra[i].y;
-            As[(4 * kq + 2) * LDC + r] = ra[i].z; As[(4 * kq + 3) * LDC + r] = ra[i].w;
-            const int f = tid + CG_T * i;
-            *(float4 *)(Bs + (f >> 4) * LDN + 4 * (f & 15)) = rw[i];
-        }
-        __syncthreads();
-        if (c + 1 < nchunk) load_chunk(c + 1);
-        mma_chunk<1, 1, LDC, LDN>(As, Bs, wm * 32, wn * 32, acc);
-        __syncthreads();
-    }
-    const int col = c0 + wn * 32 + l31;
-    if (partial) {
-        float *pp = partial + (int64_t)blockIdx.z * Rs * C;
+            for (int i = 0; i < NA; ++i) {
+                const int r = rb + RSTEP * i;
+                float d[4] = {rz[i].x, rz[i].y, rz[i].z, rz[i].w};
+                const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row = row0 + wm * 32 + acc_row(reg, lh);
-            if (row < Rs) pp[(int64_t)row * C + col] = acc[0][0][reg];
-        }
-        return;
-    }
-    float ps = 0.f, pt = 0.f, pm = 0.f, pr = 0.f;
-    if (a.bnsrc) { ps = a.bnsrc[col]; pt = a.bnsrc[C + col]; pm = a.bnsrc[2 * C + col]; pr = a.bnsrc[3 * C + col]; }
-    float s1 = 0.f, s2 = 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    if (hasbn) d[j] = cg_dy(coefS, Cs, (nq + j) % Cs, d[j], yv[j]);
+                    d[j] = ok[i] ? d[j] : 0.f;
+                }
+                As[(4 * kq + 0) * LDA + r] = d[0]; As[(4 * kq + 1) * LDA + r] = d[1];
+                As[(4 * kq + 2) * LDA + r] = d[2]; As[(4 * kq + 3) * LDA + r] = d[3];
+            }
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int row = row0 + wm * 32 + acc_row(reg, lh);
-        if (row < Rs) {
-            const int64_t o = (int64_t)row * C + col;
-            float g = acc[0][0][reg];
-            if (a.bnsrc) {
-                const float yv = a.ysrc[o];
-                g = (fmaf(ps, yv, pt) > 0.f) ? g : 0.f;
-                if (a.accumulate) g += a.out[o];
-                a.out[o] = g;
-                s1 += g;
-                s2 = fmaf(g, (yv - pm) * pr, s2);
-            } else {
-                if (a.accumulate) g += a.out[o];
-                a.out[o] = g;
+            for (int i = 0; i < NB; ++i) {
+                const int f = gt + TG * i;
+                sts4(Bs + (f >> 4) * LDN + 4 * (f & 15), rw[i]);
             }
         }
-    }
-    if (a.bstat_src) {
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        float *red = As;
-        if (wm == 1 && lh == 0) { red[(wn * 32 + l31) * 2] = s1; red[(wn * 32 + l31) * 2 + 1] = s2; }
         __syncthreads();
-        if (wm == 0 && lh == 0) {
-            atomic_add_f64(&a.bstat_src[col], (double)s1 + (double)red[(wn * 32 + l31) * 2]);
-            atomic_add_f64(&a.bstat_src[C + col], (double)s2 + (double)red[(wn * 32 + l31) * 2 + 1]);
-        }
+        if (c + G < nchunk) load_chunk(c + G);
+        if (act) mma_chunk<1, 1, LDA, LDN>(As, Bs, wm * 32, wn * 32, acc);
+        __syncthreads();
     }
-}
-
-// Sum of the dgrad split partials + the producer-side epilogue (ReLU mask, accumulate, BN-backward sums).
-__global__ __launch_bounds__(CG_T) void cg_dgrad_finish_kernel(CgDgrad a, const float *__restrict__ partial, int S)
-{
-    __shared__ float red[16][64][2];
-    const CgSeg &Sg = a.lay.seg[a.sg];
-    const int tid = threadIdx.x, cq = tid & 15, rl = tid >> 4;
-    const int C = Sg.C, Rs = a.lay.B * Sg.Lsrc;
-    const int col = blockIdx.y * 64 + 4 * cq;
-    const int rbeg = blockIdx.x * 128, rend = min(Rs, rbeg + 128);
-    float4 ps = make_float4(0.f, 0.f, 0.f, 0.f), pt = ps, pm = ps, pr = ps;
+    float *red = lds;                                   // [G][TMB][64]
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg)
+        red[(g * TMB + wm * 32 + acc_row(reg, lh)) * 64 + wn * 32 + l31] = acc[0][0][reg];
+    __syncthreads();
+    const int ecq = tid & 15;
+    const int col = c0 + 4 * ecq;
+    v4f ps = zero4(), pt = zero4(), pm = zero4(), pr = zero4();
     if (a.bnsrc) {
-        ps = *(const float4 *)(a.bnsrc + col); pt = *(const float4 *)(a.bnsrc + C + col);
-        pm = *(const float4 *)(a.bnsrc + 2 * C + col); pr = *(const float4 *)(a.bnsrc + 3 * C + col);
+        ps = ldg4(a.bnsrc + col); pt = ldg4(a.bnsrc + C + col);
+        pm = ldg4(a.bnsrc + 2 * C + col); pr = ldg4(a.bnsrc + 3 * C + col);
     }
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    const int64_t plane = (int64_t)Rs * C;
-    for (int row = rbeg + rl; row < rend; row += 16) {
+    v4f cs1 = zero4(), cs2 = zero4();
+    for (int er = tid >> 4; er < TMB; er += NTHR / 16) {
+        const int row = row0 + er;
+        if (row >= Rs) continue;
+        v4f gsum = zero4();
+#pragma unroll
+        for (int q = 0; q < G; ++q) gsum += *(const v4f *)(red + (q * TMB + er) * 64 + 4 * ecq);
         const int64_t o = (int64_t)row * C + col;
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int sp = 0; sp < S; ++sp) {
-            const float4 q = *(const float4 *)(partial + sp * plane + o);
-            g.x += q.x; g.y += q.y; g.z += q.z; g.w += q.w;
-        }
+        v4f xh = zero4();
         if (a.bnsrc) {
-            const float4 yv = *(const float4 *)(a.ysrc + o);
-            g.x = fmaf(ps.x, yv.x, pt.x) > 0.f ? g.x : 0.f; g.y = fmaf(ps.y, yv.y, pt.y) > 0.f ? g.y : 0.f;
-            g.z = fmaf(ps.z, yv.z, pt.z) > 0.f ? g.z : 0.f; g.w = fmaf(ps.w, yv.w, pt.w) > 0.f ? g.w : 0.f;
-            if (a.accumulate) {
-                const float4 p0 = *(const float4 *)(a.out + o);
-                g.x += p0.x; g.y += p0.y; g.z += p0.z; g.w += p0.w;
-            }
-            *(float4 *)(a.out + o) = g;
-            s1[0] += g.x; s1[1] += g.y; s1[2] += g.z; s1[3] += g.w;
-            s2[0] = fmaf(g.x, (yv.x - pm.x) * pr.x, s2[0]); s2[1] = fmaf(g.y, (yv.y - pm.y) * pr.y, s2[1]);
-            s2[2] = fmaf(g.z, (yv.z - pm.z) * pr.z, s2[2]); s2[3] = fmaf(g.w, (yv.w - pm.w) * pr.w, s2[3]);
-        } else {
-            if (a.accumulate) {
-                const float4 p0 = *(const float4 *)(a.out + o);
-                g.x += p0.x; g.y += p0.y; g.z += p0.z; g.w += p0.w;
-            }
-            *(float4 *)(a.out + o) = g;
+            const v4f yv = ldg4(a.ysrc + o);
+            gsum.x = fmaf(ps.x, yv.x, pt.x) > 0.f ? gsum.x : 0.f; gsum.y = fmaf(ps.y, yv.y, pt.y) > 0.f ? gsum.y : 0.f;
+            gsum.z = fmaf(ps.z, yv.z, pt.z) > 0.f ? gsum.z : 0.f; gsum.w = fmaf(ps.w, yv.w, pt.w) > 0.f ? gsum.w : 0.f;
+            xh = (yv - pm) * pr;
         }
+        if (a.accumulate) gsum += ldg4(a.out + o);
+        sts4(a.out + o, gsum);
+        cs1 += gsum;
+        cs2 += gsum * xh;
     }
     if (!a.bstat_src) return;
+    float pv[8] = {cs1.x, cs1.y, cs1.z, cs1.w, cs2.x, cs2.y, cs2.z, cs2.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { red[rl][4 * cq + j][0] = s1[j]; red[rl][4 * cq + j][1] = s2[j]; }
+    for (int q = 0; q < 8; ++q) {
+        pv[q] += __shfl_xor(pv[q], 16, 64);
+        pv[q] += __shfl_xor(pv[q], 32, 64);
+    }
+    __syncthreads();
+    float *st = lds;                                    // [NTHR/64 waves][64 cols][2]
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            st[((tid >> 6) * 64 + 4 * ecq + j) * 2] = pv[j];
+            st[((tid >> 6) * 64 + 4 * ecq + j) * 2 + 1] = pv[4 + j];
+        }
+    }
     __syncthreads();
     if (tid < 128) {
         const int c = tid & 63, w = tid >> 6;
         double v = 0.0;
-        for (int r = 0; r < 16; ++r) v += (double)red[r][c][w];
-        atomic_add_f64(&a.bstat_src[w * C + blockIdx.y * 64 + c], v);
+#pragma unroll
+        for (int r = 0; r < NTHR / 64; ++r) v += (double)st[(r * 64 + c) * 2 + w];
+        atomic_add_f64(&a.bstat_src[w * C + c0 + c], v);
     }
 }
 
@@ -450,7 +480,7 @@ struct CgWgrad {
     int rows;                  // rows per split (multiple of 32)
 };
 
-// dWp[n][kk] = sum_r dy[r][n] * A[r][kk]; tile 64 (n) x 64 (kk), rows split in CG_SPLIT_ROWS.
+// dWp[n][kk] = sum_r dy[r][n] * A[r][kk]; tile 64 (n) x 64 (kk), rows split over blockIdx.x.
 __global__ __launch_bounds__(CG_T) void cg_wgrad_kernel(CgWgrad a)
 {
     __shared__ __attribute__((aligned(16))) float As[KC * LDN];
@@ -458,37 +488,68 @@ __global__ __launch_bounds__(CG_T) void cg_wgrad_kernel(CgWgrad a)
     const CgLayer &L = a.lay;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5, wm = wave >> 1, wn = wave & 1;
-    const int R = L.B * L.Lout;
+    const int R = L.B * L.Lout, Cs = L.Cs;
     const int rbeg = blockIdx.x * a.rows, rend = min(R, rbeg + a.rows);
     const int n0 = blockIdx.y * 64, kk0 = blockIdx.z * 64;
     int sg, tap, k0, so;
-    cg_locate(L, kk0, sg, tap, k0, so);
+    cg_locate(L, kk0, sg, tap, k0, so);                   // kk0 is workgroup-uniform
+    sg = __builtin_amdgcn_readfirstlane(sg);
+    const float *Sx = SEL3(sg, opaque_s(L.seg[0].x), opaque_s(L.seg[1].x), opaque_s(L.seg[2].x));
+    const float *Sbn = SEL3(sg, opaque_s(L.seg[0].bn), opaque_s(L.seg[1].bn), opaque_s(L.seg[2].bn));
+    const int SC = SEL3(sg, opaque_s(L.seg[0].C), opaque_s(L.seg[1].C), opaque_s(L.seg[2].C));
+    const int Sty = SEL3(sg, opaque_s(L.seg[0].type), opaque_s(L.seg[1].type), opaque_s(L.seg[2].type));
+    const int SLs = SEL3(sg, opaque_s(L.seg[0].Lsrc), opaque_s(L.seg[1].Lsrc), opaque_s(L.seg[2].Lsrc));
     const int cq = tid & 15, rr0 = tid >> 4;              // column quad, first row (rows rr0, rr0+16)
+    // per-thread constants of its 4 columns: BN-backward coefficients of dy, BN scale/shift of the A operand
+    const bool hasbn = a.coef != nullptr;
+    float cf[5][4], as[4], at[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ch = (n0 + 4 * cq + j) % Cs;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) cf[q][j] = hasbn ? a.coef[q * Cs + ch] : 0.f;
+        as[j] = Sbn ? Sbn[k0 + 4 * cq + j] : 1.f;
+        at[j] = Sbn ? Sbn[SC + k0 + 4 * cq + j] : 0.f;
+    }
     f32x16 acc[1][1];
     acc_zero<1, 1>(acc);
-    float4 ra[2], rb4[2];
-    auto load_chunk = [&](int r0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = r0 + rr0 + 16 * i;
-            if (row < rend) {
-                ra[i] = cg_dy4(a.dz, L.y, a.coef, L.Cs, (int64_t)row * L.Cout + n0 + 4 * cq, n0 + 4 * cq);
-                rb4[i] = cg_load_a(L, sg, tap, k0 + 4 * cq, row / L.Lout, row % L.Lout, true);
-            } else {
-                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                rb4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    };
-    load_chunk(rbeg);
+    v4f rz[2], ry[2], rx[2];
+    bool ok[2];
+    const int xC = SC, xLs = SLs, xlm = Sty ? 0 : 1;
+#define CG_WGRAD_LOAD(rr)                                                                                             \
+    {                                                                                                                 \
+        const int r0_ = (rr);                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                               \
+            const int row = min(r0_ + rr0 + 16 * i, rend - 1); /* clamped: unconditional loads, masked at store */    \
+            const int64_t o = (int64_t)row * L.Cout + n0 + 4 * cq;                                                    \
+            rz[i] = ldg4(a.dz + o);                                                                                   \
+            ry[i] = ldg4((hasbn ? L.y : a.dz) + o);                                                                   \
+            rx[i] = cg_load_raw(L, Sx, xC, xLs, xlm, tap, k0 + 4 * cq, row / L.Lout, row % L.Lout, true, ok[i]);      \
+        }                                                                                                             \
+    }
+    CG_WGRAD_LOAD(rbeg);
     for (int r0 = rbeg; r0 < rend; r0 += KC) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            *(float4 *)(As + (rr0 + 16 * i) * LDN + 4 * cq) = ra[i];
-            *(float4 *)(Bs + (rr0 + 16 * i) * LDN + 4 * cq) = rb4[i];
+            float d[4] = {rz[i].x, rz[i].y, rz[i].z, rz[i].w};
+            const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
+            const bool live = (r0 + rr0 + 16 * i) < rend;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (hasbn) {
+                    const float xh = (yv[j] - cf[1][j]) * cf[2][j];
+                    d[j] = cf[0][j] * (d[j] - fmaf(xh, cf[4][j], cf[3][j]));
+                }
+                d[j] = live ? d[j] : 0.f;
+            }
+            v4f dv = {d[0], d[1], d[2], d[3]};
+            sts4(As + (rr0 + 16 * i) * LDN + 4 * cq, dv);
+            v4f av = {cg_act(as[0], rx[i].x, at[0], ok[i] && live), cg_act(as[1], rx[i].y, at[1], ok[i] && live),
+                      cg_act(as[2], rx[i].z, at[2], ok[i] && live), cg_act(as[3], rx[i].w, at[3], ok[i] && live)};
+            sts4(Bs + (rr0 + 16 * i) * LDN + 4 * cq, av);
         }
         __syncthreads();
-        if (r0 + KC < rend) load_chunk(r0 + KC);
+        if (r0 + KC < rend) CG_WGRAD_LOAD(r0 + KC);
         mma_chunk<1, 1, LDN, LDN>(As, Bs, wm * 32, wn * 32, acc);
         __syncthreads();
     }
@@ -529,12 +590,22 @@ struct CgPackAll {
     float *dst[CN_NLAYER];
     int64_t pre[CN_NLAYER + 1];
     int nrow_real[CN_NLAYER];           // rows of the packed matrix that exist in the torch weight (heads: 41 of 64)
+    const float *oh;                    // one-hot (B, nvec) -> oh64 (B, OH_PAD), zero padded
+    float *oh64;
+    int B, nvec;
 };
 
 __global__ void cg_pack_kernel(CgPackAll t)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= t.pre[CN_NLAYER]) return;
+    if (i >= t.pre[CN_NLAYER]) {
+        const int64_t j = i - t.pre[CN_NLAYER];
+        if (j < (int64_t)t.B * OH_PAD) {
+            const int b = (int)(j / OH_PAD), v = (int)(j % OH_PAD);
+            t.oh64[j] = (v < t.nvec) ? t.oh[(int64_t)b * t.nvec + v] : 0.f;
+        }
+        return;
+    }
     int l = 0;
 #pragma unroll
     for (int q = 1; q < CN_NLAYER; ++q)
@@ -595,16 +666,6 @@ struct CnPlan {
 };
 
 static int conv_len(int L, int k, int s, int p) { return (L + 2 * p - k) / s + 1; }
-
-// chunks per split so that tiles*splits ~ 1024 workgroups and every split keeps >= 2 chunks
-static int pick_cps(int tiles, int nchunk)
-{
-    int S = 1024 / (tiles > 0 ? tiles : 1);
-    if (S > nchunk / 2) S = nchunk / 2;
-    if (S > 16) S = 16;
-    if (S < 1) S = 1;
-    return (nchunk + S - 1) / S;
-}
 
 // rows per wgrad split (multiple of 32): ~1024 workgroups, >= 64 rows each
 static int pick_wrows(int R, int out_tiles)
@@ -693,25 +754,9 @@ extern "C" int fcn_convnet_sizes(const fcn_cn_desc *d, int64_t *out6)
     int64_t pmax = 0;
     for (int l = 0; l < CN_NLAYER; ++l) {
         const int64_t R = (int64_t)d->B * P.Lout[l];
-        {   // forward split-K partials
-            const int tiles = (int)((R + 63) / 64) * (P.N[l] / 64), nch = P.Ktot[l] / KC;
-            const int cps = pick_cps(tiles, nch), S = (nch + cps - 1) / cps;
-            const int64_t v = (int64_t)S * R * P.N[l];
-            if (v > pmax) pmax = v;
-        }
         {   // wgrad row splits
             const int rows = pick_wrows((int)R, (P.N[l] / 64) * (P.Ktot[l] / 64));
             const int64_t v = ((R + rows - 1) / rows) * P.N[l] * P.Ktot[l];
-            if (v > pmax) pmax = v;
-        }
-        for (int sg = 0; sg < P.nseg[l]; ++sg) {   // dgrad split partials
-            if (P.src[l][sg] == -9) continue;
-            const int src = P.src[l][sg];
-            const int Lsrc = src < 0 ? d->L[-src - 1] : P.Lout[src] * (P.dk[src] > 0 ? P.dk[src] : 1);
-            const int64_t Rs = (int64_t)d->B * Lsrc;
-            const int tiles = (int)((Rs + 63) / 64) * (P.C[l][sg] / 64), nch = P.KT[l] * P.N[l] / KC;
-            const int cps = pick_cps(tiles, nch), S = (nch + cps - 1) / cps;
-            const int64_t v = (int64_t)S * Rs * P.C[l][sg];
             if (v > pmax) pmax = v;
         }
     }
@@ -730,12 +775,13 @@ static void cn_fill_layer(const fcn_cn_desc *d, const CnPlan &P, const CnOffsets
     L.nseg = P.nseg[l]; L.KT = P.KT[l]; L.stride = P.stride[l]; L.pad = P.pad[l];
     L.Lin = P.Lin[l]; L.Lout = P.Lout[l]; L.B = d->B; L.Cout = P.N[l]; L.Ktot = P.Ktot[l]; L.Cs = P.Cs[l];
     L.Wp = ws->wp + O.wp[l]; L.bias = nullptr; L.nbias = 0; L.y = ws->y + O.y[l]; L.stat = nullptr;
+    { const char *e = getenv("FCN_DBG"); L.dbg = e ? atoi(e) : 0; }
     for (int s = 0; s < 3; ++s) {
         CgSeg &S = L.seg[s];
         S.x = nullptr; S.bn = nullptr; S.C = P.C[l][s]; S.Lsrc = P.Lin[l]; S.type = 0; S.nvec = 0;
         if (s >= P.nseg[l]) continue;
         const int src = P.src[l][s];
-        if (src == -9) { S.type = 1; S.x = one_hot; S.nvec = d->nvec; }
+        if (src == -9) { S.type = 1; S.x = ws->oh64; S.nvec = d->nvec; S.Lsrc = 1; }
         else if (src < 0) { S.x = feats[-src - 1]; S.Lsrc = d->L[-src - 1]; }
         else {
             S.x = ws->y + O.y[src]; S.bn = ws->bn + O.bn[src];
@@ -755,7 +801,7 @@ extern "C" int fcn_convnet_forward(const fcn_cn_desc *d, const fcn_cn_params *p,
                                    const float *const feats[4], const float *one_hot, float *logits, void *stream)
 {
     if (!d || !p || !ws || !feats || !logits) return FCN_E_BADARG;
-    if (!ws->y || !ws->wp || !ws->bn || !ws->stat || !ws->partial) return FCN_E_BADARG;
+    if (!ws->y || !ws->wp || !ws->bn || !ws->stat || !ws->partial || !ws->oh64) return FCN_E_BADARG;
     if (d->nvec > 0 && !one_hot) return FCN_E_BADARG;
     if (d->nvec > OH_PAD) return FCN_E_LIMIT;
     hipStream_t st = (hipStream_t)stream;
@@ -777,7 +823,9 @@ extern "C" int fcn_convnet_forward(const fcn_cn_desc *d, const fcn_cn_params *p,
         t.pre[l + 1] = t.pre[l] + (int64_t)P.N[l] * P.Ktot[l];
         t.nrow_real[l] = P.nrow_real[l];
     }
-    hipLaunchKernelGGL(cg_pack_kernel, dim3((unsigned)((t.pre[CN_NLAYER] + 255) / 256)), dim3(256), 0, st, t);
+    t.oh = one_hot; t.oh64 = ws->oh64; t.B = d->B; t.nvec = d->nvec;
+    hipLaunchKernelGGL(cg_pack_kernel, dim3((unsigned)((t.pre[CN_NLAYER] + (int64_t)d->B * OH_PAD + 255) / 256)), dim3(256),
+                       0, st, t);
     FCN_CHECK_LAUNCH();
     const int order[CN_NLAYER] = {0, 1, 2, 3, 10, 4, 5, 6, 11, 7, 8, 9, 12, 13};
     for (int q = 0; q < CN_NLAYER; ++q) {
@@ -788,18 +836,13 @@ extern "C" int fcn_convnet_forward(const fcn_cn_desc *d, const fcn_cn_params *p,
         else if (tr) L.stat = ws->stat + O.st[l];
         const int R = d->B * P.Lout[l];
         {
-            const int mt = (R + 63) / 64, ntl = P.N[l] / 64, nch = P.Ktot[l] / KC;
-            const int cps = pick_cps(mt * ntl, nch), S = (nch + cps - 1) / cps;
-            if (S == 1) {
-                hipLaunchKernelGGL(cg_fwd_kernel, dim3(mt, ntl, 1), dim3(CG_T), 0, st, L, (float *)nullptr, nch);
-                FCN_CHECK_LAUNCH();
-            } else {
-                hipLaunchKernelGGL(cg_fwd_kernel, dim3(mt, ntl, S), dim3(CG_T), 0, st, L, ws->partial, cps);
-                FCN_CHECK_LAUNCH();
-                hipLaunchKernelGGL(cg_fwd_finish_kernel, dim3((R + 127) / 128, ntl), dim3(CG_T), 0, st, L,
-                                   (const float *)ws->partial, S);
-                FCN_CHECK_LAUNCH();
-            }
+            // 64-row tiles when they already give >= ~200 workgroups, else 32-row tiles (R = B*L is small here)
+            const int ntl = P.N[l] / 64;
+            if (((R + 63) / 64) * ntl >= 200)
+                hipLaunchKernelGGL((cgk_fwd_kernel<2, 4>), dim3((R + 63) / 64, ntl), dim3(1024), 0, st, L);
+            else
+                hipLaunchKernelGGL((cgk_fwd_kernel<1, 4>), dim3((R + 31) / 32, ntl), dim3(512), 0, st, L);
+            FCN_CHECK_LAUNCH();
         }
         if (l != 13) {
             const double M = (double)R * (P.dk[l] > 0 ? P.dk[l] : 1);
@@ -887,18 +930,12 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
                     g.ysrc = nullptr; g.bnsrc = nullptr; g.out = dfeats[-src - 1]; g.accumulate = 0; g.bstat_src = nullptr;
                 }
                 const int Rs = d->B * L.seg[s].Lsrc;
-                const int mt = (Rs + 63) / 64, ntl = P.C[l][s] / 64, nch = P.KT[l] * P.N[l] / KC;
-                const int cps = pick_cps(mt * ntl, nch), S = (nch + cps - 1) / cps;
-                if (S == 1) {
-                    hipLaunchKernelGGL(cg_dgrad_kernel, dim3(mt, ntl, 1), dim3(CG_T), 0, st, g, (float *)nullptr, nch);
-                    FCN_CHECK_LAUNCH();
-                } else {
-                    hipLaunchKernelGGL(cg_dgrad_kernel, dim3(mt, ntl, S), dim3(CG_T), 0, st, g, ws->partial, cps);
-                    FCN_CHECK_LAUNCH();
-                    hipLaunchKernelGGL(cg_dgrad_finish_kernel, dim3((Rs + 127) / 128, ntl), dim3(CG_T), 0, st, g,
-                                       (const float *)ws->partial, S);
-                    FCN_CHECK_LAUNCH();
-                }
+                const int ntl = P.C[l][s] / 64;
+                if (((Rs + 63) / 64) * ntl >= 200)
+                    hipLaunchKernelGGL((cgk_dgrad_kernel<2, 4>), dim3((Rs + 63) / 64, ntl), dim3(1024), 0, st, g);
+                else
+                    hipLaunchKernelGGL((cgk_dgrad_kernel<1, 4>), dim3((Rs + 31) / 32, ntl), dim3(512), 0, st, g);
+                FCN_CHECK_LAUNCH();
             }
             segoff += P.KT[l] * P.C[l][s];
         }

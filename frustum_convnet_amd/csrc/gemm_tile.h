@@ -9,6 +9,21 @@
 #pragma once
 #include "fcn_common.h"
 
+// Native 4-wide vectors for register staging.  HIP's float4 is a struct: copying an array element of it between
+// address spaces (global -> register array -> LDS) is lowered to memcpy through a PRIVATE (scratch) array that SROA
+// does not always remove -- v4f / v4i are plain LLVM vectors and stay in VGPRs.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+// loads through an explicit GLOBAL address space: a pointer whose provenance the compiler lost (select between
+// kernel-struct fields, inline-asm pin) would otherwise be generic and load with flat_load, which counts on lgkmcnt
+// as well -- the next s_waitcnt lgkmcnt(0) in front of an MFMA would then also wait for the prefetch.
+typedef const v4f __attribute__((address_space(1))) *gv4fp;
+typedef const v4i __attribute__((address_space(1))) *gv4ip;
+__device__ __forceinline__ v4f ldg4(const float *p) { return *(gv4fp)p; }
+__device__ __forceinline__ v4i ldg4i(const int *p) { return *(gv4ip)p; }
+__device__ __forceinline__ void sts4(float *p, v4f v) { *(v4f *)p = v; }
+__device__ __forceinline__ v4f zero4() { v4f z = {0.f, 0.f, 0.f, 0.f}; return z; }
+
 #define GT 256          // threads per workgroup
 #define KC 32           // reduction chunk staged per iteration
 

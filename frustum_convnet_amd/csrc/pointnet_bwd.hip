@@ -158,36 +158,36 @@ __global__ __launch_bounds__(128 * WN) void dgrad_kernel(DgradArgs a)
 
     f32x16 acc[2][NT];
     acc_zero<2, NT>(acc);
-    float4 ry[NA4], rz[NA4];
-    int4 rm[NA4];
-    float4 rw[NB4];
+    v4f ry[NA4], rz[NA4];
+    v4i rm[NA4];
+    v4f rw[NB4];
     const int nchunk = CRED / KC;
 
-    auto load_chunk = [&](int c) {
+    auto load_chunk = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NA4; ++i) {
             const int r = rb + RSTEP * i;
             const int nq = c * KC + 4 * kq;
             if (r < nvalid) {
-                ry[i] = *(const float4 *)(a.ycur + (grow0 + r) * CRED + nq);
+                ry[i] = ldg4(a.ycur + (grow0 + r) * CRED + nq);
                 if constexpr (LAYER == 3) {
                     const int64_t o = ((int64_t)b * a.L + wrow[i]) * CRED + nq;
-                    rm[i] = *(const int4 *)(a.amax + o);
-                    rz[i] = *(const float4 *)(a.gmax + o);
+                    rm[i] = ldg4i(a.amax + o);
+                    rz[i] = ldg4(a.gmax + o);
                 } else {
-                    rz[i] = *(const float4 *)(a.dzcur + (grow0 + r) * CRED + nq);
+                    rz[i] = ldg4(a.dzcur + (grow0 + r) * CRED + nq);
                 }
             } else {
-                ry[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                rz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (LAYER == 3) rm[i] = make_int4(-1, -1, -1, -1);
+                ry[i] = zero4();
+                rz[i] = zero4();
+                if constexpr (LAYER == 3) { v4i m1 = {-1, -1, -1, -1}; rm[i] = m1; }
             }
         }
 #pragma unroll
         for (int i = 0; i < NB4; ++i) {
             const int f = tid + NTHR * i;
             const int nn = f / (TN / 4), cq = f % (TN / 4);
-            rw[i] = *(const float4 *)(a.W + (int64_t)(c * KC + nn) * CPREV + k0 + 4 * cq);
+            rw[i] = ldg4(a.W + (int64_t)(c * KC + nn) * CPREV + k0 + 4 * cq);
         }
     };
 
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(128 * WN) void dgrad_kernel(DgradArgs a)
         for (int i = 0; i < NB4; ++i) {
             const int f = tid + NTHR * i;
             const int nn = f / (TN / 4), cq = f % (TN / 4);
-            *(float4 *)(Bs + nn * LDB + 4 * cq) = rw[i];
+            sts4(Bs + nn * LDB + 4 * cq, rw[i]);
         }
         __syncthreads();
         if (c + 1 < nchunk) load_chunk(c + 1);
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(GT) void wgrad_kernel(WgradArgs a)
     float rwt[2 * MT];
 
     // chunk q -> (global row of its first row, number of valid rows left in its tile from there)
-    auto chunk_rows = [&](int q, int64_t &g0, int &left) {
+    auto chunk_rows = [&](int q, int64_t &g0, int &left) __attribute__((always_inline)) {
         const int code = a.tiles[4 + t_beg + (q >> 2)];
         const int b = code / a.tps, t = code % a.tps;
         const int nent = a.woff[(int64_t)b * (a.L + 1) + a.L];
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(GT) void wgrad_kernel(WgradArgs a)
         left = nent - r0;                                      // may be <= 0 for the tail chunks of a tile
     };
 
-    auto load_chunk = [&](int q) {
+    auto load_chunk = [&](int q) __attribute__((always_inline)) {
         int64_t g0;
         int left;
         chunk_rows(q, g0, left);

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(128 * WN) void fwd_gemm_kernel(FwdArgs a)
     float4 ra[NA4], rw[NB4];
     const int nchunk = CIN / KC;
 
-    auto load_chunk = [&](int c) {
+    auto load_chunk = [&](int c) __attribute__((always_inline)) {
         if constexpr (MODE == 1) {
 #pragma unroll
             for (int i = 0; i < NA4; ++i) {

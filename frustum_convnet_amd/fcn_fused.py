@@ -24,7 +24,8 @@ class CnWorkspace:
         self.wp = torch.empty(nwp, dtype=f32, device=device)
         self.bn = torch.empty(nbn, dtype=f32, device=device)
         self.stat = torch.zeros(nst, dtype=f64, device=device)
-        self.partial = torch.empty(npart, dtype=f32, device=device)      # split-K partials: forward needs it too
+        self.partial = torch.empty(npart, dtype=f32, device=device)
+        self.oh64 = torch.zeros(desc.B * 64, dtype=f32, device=device)
         self.dz = self.bstat = self.coef = None
         if need_grad:
             self.dz = torch.empty(ny, dtype=f32, device=device)
@@ -32,7 +33,7 @@ class CnWorkspace:
             self.coef = torch.empty(ncoef, dtype=f32, device=device)
         p = lambda t: None if t is None else t.data_ptr()
         self.c = CnWs(p(self.y), p(self.dz), p(self.wp), p(self.bn), p(self.stat), p(self.bstat), p(self.coef),
-                      p(self.partial))
+                      p(self.partial), p(self.oh64))
 
 
 class CnPool:

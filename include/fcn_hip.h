@@ -147,6 +147,7 @@ typedef struct fcn_cn_ws {
     float  *y, *dz, *wp, *bn;
     double *stat, *bstat;
     float  *coef, *partial;
+    float  *oh64;                /* B * 64 floats: the one-hot vector zero-padded to 64 channels */
 } fcn_cn_ws;
 
 int fcn_convnet_sizes(const fcn_cn_desc *d, int64_t *out6);

@@ -9,7 +9,7 @@ echo "== smoke"; timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.
 echo "== bench"; timeout 900 python bench.py --steps $STEPS --warmup 5 $BENCH_ARGS > gpurun_out/bench.txt 2> gpurun_out/bench.err; echo "rc=$?"; tail -2 gpurun_out/bench.txt; tail -5 gpurun_out/bench.err
 if [ -n "$PROF" ]; then
   echo "== rocprof"; cd /tmp; rm -rf /tmp/prof; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline $BENCH_ARGS > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.txt 2> $GRAFT_REPO_ROOT/gpurun_out/prof.err; echo "rc=$?"
-  cd $GRAFT_REPO_ROOT; find /tmp/prof -type f | head -20; for f in $(find /tmp/prof -name "*kernel_stats*.csv"); do cp $f gpurun_out/kernel_stats.csv; done
+  cd $GRAFT_REPO_ROOT; find /tmp/prof -type f | head -20; for f in $(find /tmp/prof -name "*kernel_stats*.csv"); do cp $f gpurun_out/kernel_stats.csv; done; for f in $(find /tmp/prof -name "*kernel_trace*.csv"); do cp $f gpurun_out/kernel_trace.csv; done
   head -30 gpurun_out/kernel_stats.csv; tail -1 gpurun_out/prof_bench.txt
 fi
 if [ -n "$PHASE" ]; then echo "== phase timing"; timeout 600 python tools_phase_timing.py > gpurun_out/phase.txt 2>&1; echo "rc=$?"; cat gpurun_out/phase.txt | grep -v Warning | tail -20; fi
