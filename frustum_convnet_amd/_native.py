@@ -100,7 +100,8 @@ def lib():
                                       c_fp * 4, c_fp, c_fp, c_fp]
     L.fcn_convnet_backward.restype = ctypes.c_int
     L.fcn_convnet_backward.argtypes = [ctypes.POINTER(CnDesc), ctypes.POINTER(CnParams), ctypes.POINTER(CnWs),
-                                       c_fp * 4, c_fp, c_fp, c_fp * 4, c_fp * 14, c_fp * 14, c_fp * 14, c_fp, c_fp]
+                                       c_fp * 4, c_fp, c_fp, c_fp * 4, c_fp * 14, c_fp * 14, c_fp * 14, c_fp, c_fp, c_fp,
+                                       ctypes.POINTER(c_fp)]
     _lib = L
     return L
 

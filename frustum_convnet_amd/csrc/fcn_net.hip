@@ -858,12 +858,19 @@ extern "C" int fcn_convnet_forward(const fcn_cn_desc *d, const fcn_cn_params *p,
 extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
                                     const float *const feats[4], const float *one_hot, const float *dlogits,
                                     float *const dfeats[4], float *const dW[CN_NLAYER], float *const dgamma[CN_NLAYER],
-                                    float *const dbeta[CN_NLAYER], float *dbias, void *stream)
+                                    float *const dbeta[CN_NLAYER], float *dbias, void *stream, void *stream2,
+                                    void *const *events)
 {
     if (!d || !p || !ws || !feats || !dlogits || !dfeats || !dW || !dgamma || !dbeta || !dbias) return FCN_E_BADARG;
     if (!d->training) return FCN_E_BADARG;
     if (!ws->y || !ws->dz || !ws->wp || !ws->bn || !ws->bstat || !ws->coef || !ws->partial) return FCN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
+    // The data-gradient chain (finalize -> dgrad -> next layer) is a latency-bound sequence of small launches; the
+    // weight gradients only hang off it.  With a second stream + CN_NLAYER+1 caller-owned events they run beside the
+    // chain instead of inside it: main records events[l] once layer l's dz and BN coefficients are final, the side
+    // stream waits for it, runs wgrad(l) + reduce(l), and main joins on events[CN_NLAYER] at the end.
+    const bool two = stream2 != nullptr && events != nullptr;
+    hipStream_t sw = two ? (hipStream_t)stream2 : st;
     CnPlan P;
     FCN_TRY(cn_make_plan(d, P));
     CnOffsets O;
@@ -899,18 +906,24 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
             FCN_CHECK_LAUNCH();
             coef = ws->coef + O.coef[l];
         }
-        // ---- weight gradient
+        // ---- weight gradient (side stream when available)
+        if (two) {
+            e = hipEventRecord((hipEvent_t)events[l], st);
+            if (e != hipSuccess) return (int)e;
+            e = hipStreamWaitEvent(sw, (hipEvent_t)events[l], 0);
+            if (e != hipSuccess) return (int)e;
+        }
         {
             CgWgrad w;
             w.lay = L; w.dz = dz; w.coef = coef; w.partial = ws->partial;
             w.rows = pick_wrows(R, (P.N[l] / 64) * (P.Ktot[l] / 64));
             const int nsplit = (R + w.rows - 1) / w.rows;
-            hipLaunchKernelGGL(cg_wgrad_kernel, dim3(nsplit, P.N[l] / 64, P.Ktot[l] / 64), dim3(CG_T), 0, st, w);
+            hipLaunchKernelGGL(cg_wgrad_kernel, dim3(nsplit, P.N[l] / 64, P.Ktot[l] / 64), dim3(CG_T), 0, sw, w);
             FCN_CHECK_LAUNCH();
             CgPack pk;
             cn_fill_pack(d, P, l, pk);
             const int64_t ne = (int64_t)P.N[l] * P.Ktot[l];
-            hipLaunchKernelGGL(cg_wgrad_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, ws->partial,
+            hipLaunchKernelGGL(cg_wgrad_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, sw, ws->partial,
                                nsplit, pk, P.nrow_real[l], dW[l]);
             FCN_CHECK_LAUNCH();
         }
@@ -939,6 +952,12 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
             }
             segoff += P.KT[l] * P.C[l][s];
         }
+    }
+    if (two) {
+        e = hipEventRecord((hipEvent_t)events[CN_NLAYER], sw);
+        if (e != hipSuccess) return (int)e;
+        e = hipStreamWaitEvent(st, (hipEvent_t)events[CN_NLAYER], 0);
+        if (e != hipSuccess) return (int)e;
     }
     return 0;
 }

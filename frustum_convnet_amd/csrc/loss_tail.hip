@@ -4,12 +4,13 @@
 // AND d(total_loss)/d(logits) in one launch.  The reference runs ~150 tiny elementwise kernels and three host
 // synchronisations here; on an MI355X that tail cost more than the whole fused PointNet forward.
 //
-// One workgroup (the batch has B*L2 ~ 4.5 k rows, of which ~B are foreground): pass 1 counts the foreground
-// rows (every mean is 1/nfg), pass 2 evaluates one row per thread, reading the (B,C,L2) logits with lanes along
-// L2 (coalesced), and block-reduces the 8 loss sums and 3 accuracy counters.
+// One row per thread, 128-thread workgroups (B*L2 ~ 4.5 k rows, of which ~B are foreground).  Every workgroup first
+// counts the foreground rows itself (each mean is 1/nfg; 36 KB of labels from L2, cheaper than a second launch),
+// then evaluates its rows, block-reduces the 8 loss sums + 3 accuracy counters and adds them to an accumulator with
+// device-scope atomics; the last workgroup to arrive (ticket) turns the sums into the final scalars.
 #include "fcn_common.h"
 
-#define LT_THREADS 1024
+#define LT_THREADS 128
 #define LT_NB 12          // heading bins (cfg.DATA.NUM_HEADING_BIN default, det_base.py:245)
 #define LT_NS 3           // size clusters (KITTI)
 
@@ -65,6 +66,7 @@ __device__ __forceinline__ void corners8(float cx, float cy, float cz, float ang
 __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
 {
     __shared__ float sh[LT_THREADS / 64];
+    __shared__ int last_s;
     const int tid = threadIdx.x;
     const int B = a.B, L2 = a.L2, R = B * L2;
     constexpr int NB = LT_NB, NS = LT_NS, NC = 3 + 2 * NB + 4 * NS;
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
 #pragma unroll
     for (int i = 0; i < 11; ++i) acc[i] = 0.f;
 
-    for (int r = tid; r < R; r += LT_THREADS) {
+    for (int r = blockIdx.x * LT_THREADS + tid; r < R; r += gridDim.x * LT_THREADS) {
         const int b = r / L2, l = r % L2;
         const int64_t lab = a.cls_label[r];
         // ---------------- focal classification loss (common.py:217-232)
@@ -256,19 +258,43 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
             for (int j = 0; j < NC; ++j) a.dreg[((int64_t)b * NC + j) * L2 + l] = go[j];
         }
     }
+    // ---- combine the workgroups: out[1..10] accumulate, out[15] (as int) is the arrival ticket; both were zeroed by the
+    // hipMemsetAsync in front of the launch.  Accumulators are written and read with device-scope atomics only.
     float tot[11];
 #pragma unroll
     for (int i = 1; i < 11; ++i) tot[i] = block_sum(acc[i], sh);
     if (tid == 0) {
-        const float cls = tot[1] * inv_cls;
-        const float center = tot[2] * inv_fg, hcls = tot[3] * inv_fg, hres = tot[4] * inv_fg;
-        const float scls = tot[5] * inv_fg, sres = tot[6] * inv_fg, corner = tot[7] * inv_fg;
+#pragma unroll
+        for (int i = 1; i < 11; ++i) atomicAdd(&a.out[i], tot[i]);
+        __threadfence();
+        const int ticket = atomicAdd((int *)&a.out[15], 1);
+        last_s = (ticket == (int)gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (last_s && tid == 0) {
+        __threadfence();
+        float t[11];
+#pragma unroll
+        for (int i = 1; i < 11; ++i) t[i] = __hip_atomic_load(&a.out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float cls = t[1] * inv_cls;
+        const float center = t[2] * inv_fg, hcls = t[3] * inv_fg, hres = t[4] * inv_fg;
+        const float scls = t[5] * inv_fg, sres = t[6] * inv_fg, corner = t[7] * inv_fg;
         a.out[0] = cls + a.w_box * (center + hcls + scls + a.w_headreg * hres + a.w_sizereg * sres + a.w_corner * corner);
         a.out[1] = cls; a.out[2] = center; a.out[3] = hcls; a.out[4] = hres;
         a.out[5] = scls; a.out[6] = sres; a.out[7] = corner;
-        a.out[8] = tot[8] / nkeep; a.out[9] = tot[9] * inv_fg; a.out[10] = tot[10] * inv_fg;
+        a.out[8] = t[8] / nkeep; a.out[9] = t[9] * inv_fg; a.out[10] = t[10] * inv_fg;
         a.out[11] = nfg;
     }
+}
+
+static int launch_loss(const LossArgs &a, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(a.out, 0, 16 * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    const int R = a.B * a.L2;
+    hipLaunchKernelGGL(loss_tail_kernel, dim3((R + LT_THREADS - 1) / LT_THREADS), dim3(LT_THREADS), 0, st, a);
+    FCN_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int fcn_det_loss_tail(const float *cls_raw, const float *reg_raw, const int64_t *cls_label,
@@ -288,9 +314,7 @@ extern "C" int fcn_det_loss_tail(const float *cls_raw, const float *reg_raw, con
     a.box_center = box3d_center; a.box_heading = box3d_heading; a.box_size = box3d_size; a.size_class = size_class;
     a.mean_size = mean_size; a.out = out16; a.dcls = dcls; a.dreg = dreg; a.B = B; a.L2 = L2;
     a.w_box = w_box; a.w_corner = w_corner; a.w_headreg = w_headreg; a.w_sizereg = w_sizereg; a.ld = 0;
-    hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(LT_THREADS), 0, (hipStream_t)stream, a);
-    FCN_CHECK_LAUNCH();
-    return 0;
+    return launch_loss(a, (hipStream_t)stream);
 }
 
 extern "C" int fcn_det_loss_tail_rows(const float *logits, const int64_t *cls_label, const float *center_ref2,
@@ -310,7 +334,5 @@ extern "C" int fcn_det_loss_tail_rows(const float *logits, const int64_t *cls_la
     a.box_center = box3d_center; a.box_heading = box3d_heading; a.box_size = box3d_size; a.size_class = size_class;
     a.mean_size = mean_size; a.out = out16; a.dcls = dlogits; a.dreg = nullptr; a.B = B; a.L2 = L2;
     a.w_box = w_box; a.w_corner = w_corner; a.w_headreg = w_headreg; a.w_sizereg = w_sizereg; a.ld = 64;
-    hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(LT_THREADS), 0, (hipStream_t)stream, a);
-    FCN_CHECK_LAUNCH();
-    return 0;
+    return launch_loss(a, (hipStream_t)stream);
 }

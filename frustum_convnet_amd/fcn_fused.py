@@ -39,6 +39,20 @@ class CnWorkspace:
 class CnPool:
     def __init__(self):
         self.free = {}
+        self.side = {}
+
+    def side_stream(self, device):
+        """Second HIP stream + 15 events (caller-owned, handed to fcn_convnet_backward) per device."""
+        key = str(device)
+        if key not in self.side:
+            with torch.cuda.device(device):
+                st = torch.cuda.Stream(device=device)
+                evs = [torch.cuda.Event(enable_timing=False) for _ in range(15)]
+                for ev in evs:
+                    ev.record()                     # materialise the hipEvent_t handles
+                arr = (ctypes.c_void_p * 15)(*[ev.cuda_event for ev in evs])
+            self.side[key] = (st, evs, arr)
+        return self.side[key]
 
     def acquire(self, key, desc, device, need_grad):
         k = key + (bool(need_grad), str(device))
@@ -111,11 +125,13 @@ class _ConvNetFused(torch.autograd.Function):
         params = CnParams(_arr(Ws + [Wh]), _arr(gs), _arr(bs), _arr([]), _arr([]), _arr([]), bh.data_ptr())
         fp = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in feats])
         dfp = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in dfeats])
+        side, _evs, evarr = ctx.pool.side_stream(dev)
         with torch.cuda.device(dev):
             _native.check(L.fcn_convnet_backward(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(ws.c), fp,
                                                  None if oh is None else oh.data_ptr(), dlogits.data_ptr(), dfp,
                                                  _arr(dW), _arr(dg), _arr(db), dbh.data_ptr(),
-                                                 _native.current_stream(dev)), "fcn_convnet_backward")
+                                                 _native.current_stream(dev), ctypes.c_void_p(side.cuda_stream),
+                                                 evarr), "fcn_convnet_backward")
         ctx.pool.release(ws)
         ctx.ws, ctx.live = None, False
         ncls = 2

@@ -158,7 +158,9 @@ int fcn_convnet_forward(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_
 int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
                          const float *const feats[4], const float *one_hot, const float *dlogits,
                          float *const dfeats[4], float *const dW[14], float *const dgamma[14],
-                         float *const dbeta[14], float *dbias, void *stream);
+                         float *const dbeta[14], float *dbias, void *stream, void *stream2, void *const *events);
+/* stream2 / events may be NULL (single stream).  Otherwise: a second hipStream_t and 15 caller-owned hipEvent_t; the
+ * weight-gradient launches run on stream2 beside the data-gradient chain and `stream` joins before returning work. */
 
 /* ---------------------------------------------------------------------------------------------
  * Fused train-loss tail of PointNetDet.forward (models/det_base.py:373-476; focal loss models/common.py:217-232,
