@@ -47,7 +47,7 @@ class PnWs(ctypes.Structure):
 
 
 EXPORTS = ("fcn_arch", "fcn_query_depth_point_f32", "fcn_pn_wgrad_rows", "fcn_pn_compact",
-           "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows",
+           "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows",
            "fcn_convnet_sizes", "fcn_convnet_forward", "fcn_convnet_backward")
 
 _lib = None
@@ -86,6 +86,9 @@ def lib():
     L.fcn_pn_backward.restype = ctypes.c_int
     L.fcn_pn_backward.argtypes = [ctypes.POINTER(PnDesc), ctypes.POINTER(PnParams), c_fp,
                                   ctypes.POINTER(PnWs), c_fp * 3, c_fp * 3, c_fp * 3, c_fp]
+    L.fcn_pn_backward2.restype = ctypes.c_int
+    L.fcn_pn_backward2.argtypes = [ctypes.POINTER(PnDesc), ctypes.POINTER(PnParams), c_fp,
+                                   ctypes.POINTER(PnWs), c_fp * 3, c_fp * 3, c_fp * 3, c_fp, c_fp, ctypes.POINTER(c_fp)]
     L.fcn_pn_conv_fwd.restype = ctypes.c_int
     L.fcn_pn_conv_fwd.argtypes = [ctypes.POINTER(PnDesc), ctypes.POINTER(PnParams), ctypes.POINTER(PnWs),
                                   ctypes.c_int, ctypes.c_int, c_fp]

@@ -27,10 +27,20 @@
 
 struct CgSeg {
     const float *x;            // type 0: (B*Lsrc, C) rows; type 1: one-hot zero-padded to (B, OH_PAD)
-    const float *bn;           // scale[C], shift[C], mean[C], rstd[C] of the producer's BN, or nullptr (already activated)
+    float *bn;                 // scale[C], shift[C], mean[C], rstd[C] of the producer's BN, or nullptr (already activated)
     int C;                     // channels seen by the GEMM (type 1: OH_PAD)
     int Lsrc;                  // rows per frustum in the source buffer (type 1: 1 row per frustum, every position reads it)
     int type, nvec;
+    // The producer's BN is FINALISED BY ITS CONSUMERS: every forward workgroup derives scale/shift from the batch sums
+    // in its prologue (a few hundred fp64 operations) instead of waiting for a separate one-workgroup launch between
+    // every two layers of a latency-bound chain.  Workgroup (0,0) of the consumer flagged `writer` also publishes
+    // bn[] (the backward reads it) and updates the running statistics.
+    const double *stat;        // training: sum[C], sumsq[C] over M positions (final); eval: nullptr -> running stats
+    const float *gamma, *beta;
+    float *rmean, *rvar;
+    int64_t *nbt;
+    double M;
+    int writer;
 };
 
 struct CgLayer {
@@ -44,6 +54,7 @@ struct CgLayer {
     int nbias;
     float *y;                  // (B*Lout, Cout) pre-BN output
     double *stat;              // sum[Cs], sumsq[Cs] or nullptr
+    float eps, momentum;
     int dbg;                   // ablation switches (env FCN_DBG): 1 skip MFMA, 2 skip global loads, 4 skip LDS staging
 };
 
@@ -94,18 +105,42 @@ __device__ __forceinline__ v4f cg_load_raw(const CgLayer &L, const float *x, int
 
 // per-column (kk) scale/shift of the virtual A matrix: BN of the producer, or (1,0) for inputs that are already
 // activations (pooled features, one-hot: both >= 0, so the ReLU applied uniformly is the identity on them)
-__device__ __forceinline__ void cg_fill_bn(const CgLayer &L, float *sS, float *tS, int tid, int nthr)
+__device__ __forceinline__ void cg_fill_bn(const CgLayer &L, float *sS, float *tS, int tid, int nthr, bool pub)
 {
     int off = 0;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         if (s < L.nseg) {
-            const float *bn = L.seg[s].bn;
-            const int C = L.seg[s].C, span = L.KT * C;
-            for (int i = tid; i < span; i += nthr) {
-                const int k = i % C;
-                sS[off + i] = bn ? bn[k] : 1.f;
-                tS[off + i] = bn ? bn[C + k] : 0.f;
+            const CgSeg &S = L.seg[s];
+            const int C = S.C, span = L.KT * C;
+            if (S.gamma) {
+                const bool batch = S.stat != nullptr;
+                const bool wr = pub && S.writer;
+                for (int k = tid; k < C; k += nthr) {
+                    double mean, var;
+                    if (batch) {
+                        mean = S.stat[k] / S.M;
+                        var = S.stat[C + k] / S.M - mean * mean;
+                        if (var < 0.0) var = 0.0;
+                    } else {
+                        mean = S.rmean[k];
+                        var = S.rvar[k];
+                    }
+                    const double rstd = 1.0 / sqrt(var + (double)L.eps);
+                    const double sc = (double)S.gamma[k] * rstd;
+                    const float fs = (float)sc, ft = (float)((double)S.beta[k] - mean * sc);
+                    for (int t = 0; t < L.KT; ++t) { sS[off + t * C + k] = fs; tS[off + t * C + k] = ft; }
+                    if (wr) {
+                        S.bn[k] = fs; S.bn[C + k] = ft; S.bn[2 * C + k] = (float)mean; S.bn[3 * C + k] = (float)rstd;
+                        if (batch) {
+                            S.rmean[k] = (float)((1.0 - L.momentum) * S.rmean[k] + L.momentum * mean);
+                            S.rvar[k] = (float)((1.0 - L.momentum) * S.rvar[k] + L.momentum * var * (S.M / (S.M - 1.0)));
+                            if (k == 0) S.nbt[0] += 1;
+                        }
+                    }
+                }
+            } else {
+                for (int i = tid; i < span; i += nthr) { sS[off + i] = 1.f; tS[off + i] = 0.f; }
             }
             off += span;
         }
@@ -143,7 +178,7 @@ __global__ __launch_bounds__(G * 128 * MW) void cgk_fwd_kernel(CgLayer L)
         cg_locate(L, tid * KC, sg, tap, k0, so);
         cSeg[tid] = sg; cTap[tid] = tap; cK0[tid] = k0;
     }
-    cg_fill_bn(L, sS, tS, tid, NTHR);
+    cg_fill_bn(L, sS, tS, tid, NTHR, blockIdx.x == 0 && blockIdx.y == 0);
     // segment fields as scalars (static indices)
     const float *x0 = opaque_s(L.seg[0].x), *x1 = opaque_s(L.seg[1].x), *x2 = opaque_s(L.seg[2].x);
     const int C0 = opaque_s(L.seg[0].C), C1 = opaque_s(L.seg[1].C), C2 = opaque_s(L.seg[2].C);
@@ -260,49 +295,26 @@ __global__ __launch_bounds__(G * 128 * MW) void cgk_fwd_kernel(CgLayer L)
     }
 }
 
-// BN scale/shift/mean/rstd (+ running stats) from sum / sumsq over M rows; eval mode reads the running stats.
-__global__ void cn_bn_finalize_kernel(const double *__restrict__ stat, const float *__restrict__ gamma,
-                                      const float *__restrict__ beta, float *rmean, float *rvar, int64_t *nbt,
-                                      int C, int training, float eps, float momentum, double M, float *__restrict__ bn)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double mean, var;
-    if (training) {
-        mean = stat[c] / M;
-        var = stat[C + c] / M - mean * mean;
-        if (var < 0.0) var = 0.0;
-        rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mean);
-        rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * var * (M / (M - 1.0)));
-        if (c == 0) nbt[0] += 1;
-    } else {
-        mean = rmean[c];
-        var = rvar[c];
-    }
-    const double rstd = 1.0 / sqrt(var + (double)eps);
-    const double s = (double)gamma[c] * rstd;
-    bn[c] = (float)s;
-    bn[C + c] = (float)((double)beta[c] - mean * s);
-    bn[2 * C + c] = (float)mean;
-    bn[3 * C + c] = (float)rstd;
-}
+// BN-backward coefficients of one channel from the batch sums (sum dz, sum dz*xhat): gamma*rstd, mean, rstd, dbeta/M,
+// dgamma/M.  Like the forward's scale/shift they are derived by every consumer workgroup in its prologue; the
+// designated workgroup also exports dgamma / dbeta.
+struct CgBnBwd {
+    const double *bstat;       // sum dz [Cs], sum dz*xhat [Cs] (final); nullptr: the layer has no BN (heads)
+    const float *gamma, *bn;   // bn: (scale, shift, mean, rstd) published by the forward
+    double M;
+    float *dgamma, *dbeta;     // non-null on the launch that exports them
+};
 
-// coef: gamma*rstd, mean, rstd, dbeta/M, dgamma/M ; exports dgamma, dbeta
-__global__ void cn_bnbwd_finalize_kernel(const double *__restrict__ bstat, const float *__restrict__ gamma,
-                                         const float *__restrict__ bn, int C, double M, float *__restrict__ coef,
-                                         float *__restrict__ dgamma, float *__restrict__ dbeta)
+__device__ __forceinline__ void cg_bnbwd_coef(const CgBnBwd &q, int Cs, int c, float (&cf)[5], bool pub)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double db = bstat[c], dg = bstat[C + c];
-    const float rstd = bn[3 * C + c];
-    coef[c] = gamma[c] * rstd;
-    coef[C + c] = bn[2 * C + c];
-    coef[2 * C + c] = rstd;
-    coef[3 * C + c] = (float)(db / M);
-    coef[4 * C + c] = (float)(dg / M);
-    dgamma[c] = (float)dg;
-    dbeta[c] = (float)db;
+    const double db = q.bstat[c], dg = q.bstat[Cs + c];
+    const float rstd = q.bn[3 * Cs + c];
+    cf[0] = q.gamma[c] * rstd;
+    cf[1] = q.bn[2 * Cs + c];
+    cf[2] = rstd;
+    cf[3] = (float)(db / q.M);
+    cf[4] = (float)(dg / q.M);
+    if (pub && q.dgamma) { q.dgamma[c] = (float)dg; q.dbeta[c] = (float)db; }
 }
 
 #define CG_CMAX 512            // largest BN width (Cs) whose backward coefficients are staged in LDS
@@ -318,7 +330,8 @@ __device__ __forceinline__ float cg_dy(const float *coefS, int Cs, int ch, float
 struct CgDgrad {
     CgLayer lay;               // the consumer layer
     int sg, segoff;            // which of its segments is differentiated; its column offset in Wp
-    const float *dzc, *yc, *coefc;   // consumer's incoming dz, pre-BN output, BN-backward coefficients (null: no BN)
+    const float *dzc, *yc;     // consumer's incoming dz, pre-BN output
+    CgBnBwd cb;                // consumer's BN backward (bstat null: no BN)
     const float *ysrc, *bnsrc; // producer's pre-BN output and BN (scale,shift,mean,rstd); null: source is a plain input
     float *out;                // producer's dz (Rsrc x C) or the input gradient
     int accumulate;            // add to what `out` already holds (a second consumer)
@@ -347,9 +360,16 @@ __global__ __launch_bounds__(G * 128 * MW) void cgk_dgrad_kernel(CgDgrad a)
     const int row0 = blockIdx.x * TMB, c0 = blockIdx.y * 64;
     const int kq = gt & 7, rb = gt >> 3;
     constexpr int RSTEP = TG / 8;
-    const bool hasbn = a.coefc != nullptr;
-    if (hasbn)
-        for (int i = tid; i < 5 * Cs; i += NTHR) coefS[i] = a.coefc[i];
+    const bool hasbn = a.cb.bstat != nullptr;
+    if (hasbn) {
+        const bool pub = blockIdx.x == 0 && blockIdx.y == 0;
+        for (int c = tid; c < Cs; c += NTHR) {
+            float cf[5];
+            cg_bnbwd_coef(a.cb, Cs, c, cf, pub);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) coefS[q * Cs + c] = cf[q];
+        }
+    }
     int bb[NA], li[NA];
     bool rv[NA], ok[NA];
 #pragma unroll
@@ -475,7 +495,8 @@ __global__ __launch_bounds__(G * 128 * MW) void cgk_dgrad_kernel(CgDgrad a)
 // ------------------------------------------------------------------------------------------------
 struct CgWgrad {
     CgLayer lay;
-    const float *dz, *coef;    // incoming dz of this layer (R x Cout), BN-backward coefficients (null: no BN)
+    const float *dz;           // incoming dz of this layer (R x Cout)
+    CgBnBwd cb;                // its BN backward (bstat null: no BN); dgamma/dbeta are exported by the dgrad launch
     float *partial;            // (nsplit, Cout, Ktot)
     int rows;                  // rows per split (multiple of 32)
 };
@@ -501,13 +522,15 @@ __global__ __launch_bounds__(CG_T) void cg_wgrad_kernel(CgWgrad a)
     const int SLs = SEL3(sg, opaque_s(L.seg[0].Lsrc), opaque_s(L.seg[1].Lsrc), opaque_s(L.seg[2].Lsrc));
     const int cq = tid & 15, rr0 = tid >> 4;              // column quad, first row (rows rr0, rr0+16)
     // per-thread constants of its 4 columns: BN-backward coefficients of dy, BN scale/shift of the A operand
-    const bool hasbn = a.coef != nullptr;
+    const bool hasbn = a.cb.bstat != nullptr;
     float cf[5][4], as[4], at[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int ch = (n0 + 4 * cq + j) % Cs;
+        float c5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (hasbn) cg_bnbwd_coef(a.cb, Cs, ch, c5, false);
 #pragma unroll
-        for (int q = 0; q < 5; ++q) cf[q][j] = hasbn ? a.coef[q * Cs + ch] : 0.f;
+        for (int q = 0; q < 5; ++q) cf[q][j] = c5[q];
         as[j] = Sbn ? Sbn[k0 + 4 * cq + j] : 1.f;
         at[j] = Sbn ? Sbn[SC + k0 + 4 * cq + j] : 0.f;
     }
@@ -620,22 +643,34 @@ __global__ void cg_pack_kernel(CgPackAll t)
     t.dst[l][e] = v;
 }
 
-// dW (torch layout) = sum of the split partials; padding columns/rows are dropped.
-__global__ void cg_wgrad_reduce_kernel(const float *__restrict__ partial, int nsplit, CgPack p, int nrow_real,
-                                       float *__restrict__ dW)
+// dW (torch layout) = sum of the split partials (fixed order); padding columns/rows are dropped.  64 consecutive
+// packed elements x CG_RG split groups per workgroup: a few independent loads per thread, then a group sum through LDS.
+#define CG_RG 8
+__global__ __launch_bounds__(64 * CG_RG) void cg_wgrad_reduce_kernel(const float *__restrict__ partial, int nsplit, CgPack p,
+                                                                   int nrow_real, float *__restrict__ dW)
 {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float sh[CG_RG][64];
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + x;             // N * Ktot is a multiple of 64
     const int64_t nelem = (int64_t)p.N * p.Ktot;
-    if (e >= nelem) return;
+    float s0 = 0.f, s1 = 0.f;
+    int sp = y;
+    for (; sp + CG_RG < nsplit; sp += 2 * CG_RG) {
+        s0 += partial[(int64_t)sp * nelem + e];
+        s1 += partial[(int64_t)(sp + CG_RG) * nelem + e];
+    }
+    if (sp < nsplit) s0 += partial[(int64_t)sp * nelem + e];
+    sh[y][x] = s0 + s1;
+    __syncthreads();
+    if (y != 0) return;
     const int n = (int)(e / p.Ktot), kk = (int)(e % p.Ktot);
     if (n >= nrow_real) return;
     const int64_t o = cg_torch_index(p, n, kk);
     if (o < 0) return;
-    float s0 = 0.f, s1 = 0.f;
-    int sp = 0;
-    for (; sp + 2 <= nsplit; sp += 2) { s0 += partial[(int64_t)sp * nelem + e]; s1 += partial[(int64_t)(sp + 1) * nelem + e]; }
-    if (sp < nsplit) s0 += partial[(int64_t)sp * nelem + e];
-    dW[o] = s0 + s1;
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < CG_RG; ++q) t += sh[q][x];
+    dW[o] = t;
 }
 
 // dbias[n] = sum_r dlogits[r][n] (heads)
@@ -769,16 +804,18 @@ extern "C" int fcn_convnet_sizes(const fcn_cn_desc *d, int64_t *out6)
     return 0;
 }
 
-static void cn_fill_layer(const fcn_cn_desc *d, const CnPlan &P, const CnOffsets &O, const fcn_cn_ws *ws,
-                          const float *const feats[4], const float *one_hot, int l, CgLayer &L)
+static void cn_fill_layer(const fcn_cn_desc *d, const fcn_cn_params *p, const CnPlan &P, const CnOffsets &O,
+                          const fcn_cn_ws *ws, const float *const feats[4], const float *one_hot, int l, CgLayer &L)
 {
     L.nseg = P.nseg[l]; L.KT = P.KT[l]; L.stride = P.stride[l]; L.pad = P.pad[l];
     L.Lin = P.Lin[l]; L.Lout = P.Lout[l]; L.B = d->B; L.Cout = P.N[l]; L.Ktot = P.Ktot[l]; L.Cs = P.Cs[l];
     L.Wp = ws->wp + O.wp[l]; L.bias = nullptr; L.nbias = 0; L.y = ws->y + O.y[l]; L.stat = nullptr;
     { const char *e = getenv("FCN_DBG"); L.dbg = e ? atoi(e) : 0; }
+    L.eps = d->eps; L.momentum = d->momentum;
     for (int s = 0; s < 3; ++s) {
         CgSeg &S = L.seg[s];
         S.x = nullptr; S.bn = nullptr; S.C = P.C[l][s]; S.Lsrc = P.Lin[l]; S.type = 0; S.nvec = 0;
+        S.stat = nullptr; S.gamma = S.beta = nullptr; S.rmean = S.rvar = nullptr; S.nbt = nullptr; S.M = 1.0; S.writer = 0;
         if (s >= P.nseg[l]) continue;
         const int src = P.src[l][s];
         if (src == -9) { S.type = 1; S.x = ws->oh64; S.nvec = d->nvec; S.Lsrc = 1; }
@@ -786,6 +823,10 @@ static void cn_fill_layer(const fcn_cn_desc *d, const CnPlan &P, const CnOffsets
         else {
             S.x = ws->y + O.y[src]; S.bn = ws->bn + O.bn[src];
             S.Lsrc = P.Lout[src] * (P.dk[src] > 0 ? P.dk[src] : 1);     // a deconv's buffer is (B, L*k, 256)
+            S.stat = d->training ? ws->stat + O.st[src] : nullptr;
+            S.gamma = p->gamma[src]; S.beta = p->beta[src]; S.rmean = p->running_mean[src]; S.rvar = p->running_var[src];
+            S.nbt = p->num_batches_tracked[src];
+            S.M = (double)d->B * P.Lout[src] * (P.dk[src] > 0 ? P.dk[src] : 1);
         }
     }
 }
@@ -828,10 +869,16 @@ extern "C" int fcn_convnet_forward(const fcn_cn_desc *d, const fcn_cn_params *p,
                        0, st, t);
     FCN_CHECK_LAUNCH();
     const int order[CN_NLAYER] = {0, 1, 2, 3, 10, 4, 5, 6, 11, 7, 8, 9, 12, 13};
+    bool published[CN_NLAYER];
+    for (int l = 0; l < CN_NLAYER; ++l) published[l] = false;
     for (int q = 0; q < CN_NLAYER; ++q) {
         const int l = order[q];
         CgLayer L;
-        cn_fill_layer(d, P, O, ws, feats, one_hot, l, L);
+        cn_fill_layer(d, p, P, O, ws, feats, one_hot, l, L);
+        for (int s = 0; s < P.nseg[l]; ++s) {       // the first consumer of a BN layer publishes its statistics
+            const int src = P.src[l][s];
+            if (src >= 0 && !published[src]) { L.seg[s].writer = 1; published[src] = true; }
+        }
         if (l == 13) { L.y = logits; L.bias = p->bias; L.nbias = P.nrow_real[13]; }
         else if (tr) L.stat = ws->stat + O.st[l];
         const int R = d->B * P.Lout[l];
@@ -842,13 +889,6 @@ extern "C" int fcn_convnet_forward(const fcn_cn_desc *d, const fcn_cn_params *p,
                 hipLaunchKernelGGL((cgk_fwd_kernel<2, 4>), dim3((R + 63) / 64, ntl), dim3(1024), 0, st, L);
             else
                 hipLaunchKernelGGL((cgk_fwd_kernel<1, 4>), dim3((R + 31) / 32, ntl), dim3(512), 0, st, L);
-            FCN_CHECK_LAUNCH();
-        }
-        if (l != 13) {
-            const double M = (double)R * (P.dk[l] > 0 ? P.dk[l] : 1);
-            hipLaunchKernelGGL(cn_bn_finalize_kernel, dim3((P.Cs[l] + 63) / 64), dim3(64), 0, st, ws->stat + O.st[l],
-                               p->gamma[l], p->beta[l], p->running_mean[l], p->running_var[l],
-                               p->num_batches_tracked[l], P.Cs[l], tr, d->eps, d->momentum, M, ws->bn + O.bn[l]);
             FCN_CHECK_LAUNCH();
         }
     }
@@ -891,20 +931,18 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
     for (int q = 0; q < CN_NLAYER; ++q) {
         const int l = order[q];
         CgLayer L;
-        cn_fill_layer(d, P, O, ws, feats, one_hot, l, L);
+        cn_fill_layer(d, p, P, O, ws, feats, one_hot, l, L);
         const int R = d->B * P.Lout[l];
         const float *dz = (l == 13) ? dlogits : ws->dz + O.y[l];
-        const float *coef = nullptr;
+        CgBnBwd cb;
+        cb.bstat = nullptr; cb.gamma = nullptr; cb.bn = nullptr; cb.M = 1.0; cb.dgamma = nullptr; cb.dbeta = nullptr;
         if (l == 13) {
             L.y = nullptr;
             hipLaunchKernelGGL(cg_colsum_kernel, dim3(64), dim3(256), 0, st, dlogits, R, 64, P.nrow_real[13], dbias);
             FCN_CHECK_LAUNCH();
         } else {
-            const double M = (double)R * (P.dk[l] > 0 ? P.dk[l] : 1);
-            hipLaunchKernelGGL(cn_bnbwd_finalize_kernel, dim3((P.Cs[l] + 63) / 64), dim3(64), 0, st, ws->bstat + O.st[l],
-                               p->gamma[l], ws->bn + O.bn[l], P.Cs[l], M, ws->coef + O.coef[l], dgamma[l], dbeta[l]);
-            FCN_CHECK_LAUNCH();
-            coef = ws->coef + O.coef[l];
+            cb.bstat = ws->bstat + O.st[l]; cb.gamma = p->gamma[l]; cb.bn = ws->bn + O.bn[l];
+            cb.M = (double)R * (P.dk[l] > 0 ? P.dk[l] : 1);
         }
         // ---- weight gradient (side stream when available)
         if (two) {
@@ -915,7 +953,7 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
         }
         {
             CgWgrad w;
-            w.lay = L; w.dz = dz; w.coef = coef; w.partial = ws->partial;
+            w.lay = L; w.dz = dz; w.cb = cb; w.partial = ws->partial;
             w.rows = pick_wrows(R, (P.N[l] / 64) * (P.Ktot[l] / 64));
             const int nsplit = (R + w.rows - 1) / w.rows;
             hipLaunchKernelGGL(cg_wgrad_kernel, dim3(nsplit, P.N[l] / 64, P.Ktot[l] / 64), dim3(CG_T), 0, sw, w);
@@ -923,17 +961,19 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
             CgPack pk;
             cn_fill_pack(d, P, l, pk);
             const int64_t ne = (int64_t)P.N[l] * P.Ktot[l];
-            hipLaunchKernelGGL(cg_wgrad_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, sw, ws->partial,
+            hipLaunchKernelGGL(cg_wgrad_reduce_kernel, dim3((unsigned)(ne / 64)), dim3(64 * CG_RG), 0, sw, ws->partial,
                                nsplit, pk, P.nrow_real[l], dW[l]);
             FCN_CHECK_LAUNCH();
         }
         // ---- data gradients into every non-constant source
         int segoff = 0;
+        bool exported = (l == 13);
         for (int s = 0; s < P.nseg[l]; ++s) {
             const int src = P.src[l][s];
             if (src != -9) {
                 CgDgrad g;
-                g.lay = L; g.sg = s; g.segoff = segoff; g.dzc = dz; g.yc = L.y; g.coefc = coef;
+                g.lay = L; g.sg = s; g.segoff = segoff; g.dzc = dz; g.yc = L.y; g.cb = cb;
+                if (!exported) { g.cb.dgamma = dgamma[l]; g.cb.dbeta = dbeta[l]; exported = true; }
                 if (src >= 0) {
                     g.ysrc = ws->y + O.y[src]; g.bnsrc = ws->bn + O.bn[src]; g.out = ws->dz + O.y[src];
                     g.accumulate = seen[src] > 0 ? 1 : 0;

@@ -467,26 +467,38 @@ __global__ __launch_bounds__(GT) void wgrad_kernel(WgradArgs a)
             }
 }
 
-// out[i] = sum over the live splits (fixed order -> deterministic); 4 independent loads in flight per thread.
-__global__ void wgrad_reduce_kernel(const float *__restrict__ partial, const int32_t *__restrict__ tiles, int nsplit,
-                                    int64_t nelem, float *__restrict__ out)
+// out[i] = sum over the live splits in a fixed order (deterministic).  A small layer has few elements but hundreds of
+// splits: 64 consecutive elements x 16 split groups per workgroup, so every thread has a handful of independent loads
+// in flight instead of one thread walking all the splits of its element.
+#define WR_G 16
+__global__ __launch_bounds__(64 * WR_G) void wgrad_reduce_kernel(const float *__restrict__ partial,
+                                                                const int32_t *__restrict__ tiles, int nsplit,
+                                                                int64_t nelem, float *__restrict__ out)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nelem) return;
+    __shared__ float sh[WR_G][64];
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + x;             // nelem is a multiple of 64
     const int ntile = tiles[0];
     const int tpb = (ntile + nsplit - 1) / nsplit;
     const int nsp = tpb > 0 ? (ntile + tpb - 1) / tpb : 0;
     const float *p = partial + i;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int sp = 0;
-    for (; sp + 4 <= nsp; sp += 4) {
+    int sp = y;
+    for (; sp + 3 * WR_G < nsp; sp += 4 * WR_G) {
         s0 += p[(int64_t)sp * nelem];
-        s1 += p[(int64_t)(sp + 1) * nelem];
-        s2 += p[(int64_t)(sp + 2) * nelem];
-        s3 += p[(int64_t)(sp + 3) * nelem];
+        s1 += p[(int64_t)(sp + WR_G) * nelem];
+        s2 += p[(int64_t)(sp + 2 * WR_G) * nelem];
+        s3 += p[(int64_t)(sp + 3 * WR_G) * nelem];
     }
-    for (; sp < nsp; ++sp) s0 += p[(int64_t)sp * nelem];
-    out[i] = (s0 + s1) + (s2 + s3);
+    for (; sp < nsp; sp += WR_G) s0 += p[(int64_t)sp * nelem];
+    sh[y][x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (y == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < WR_G; ++q) t += sh[q][x];
+        out[i] = t;
+    }
 }
 
 // dW1, dgamma1, dbeta1 from Q = sum_e dz1 (1, u) and the forward's weighted moments of u.
@@ -552,19 +564,34 @@ static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, hipStream_t st, flo
     else hipLaunchKernelGGL((wgrad_kernel<LAYER, 1, 1>), grid, dim3(GT), 0, st, a);
     FCN_CHECK_LAUNCH();
     const int64_t ne = (int64_t)a.COUT * a.CIN;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, a.partial, a.tiles,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(ne / 64)), dim3(64 * WR_G), 0, st, a.partial, a.tiles,
                        nsplit, ne, out);
     FCN_CHECK_LAUNCH();
     return 0;
 }
 
+extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dfeat,
+                                const fcn_pn_ws *ws, float *dW[3], float *dgamma[3], float *dbeta[3],
+                                void *stream, void *stream2, void *const *events);
+
 extern "C" int fcn_pn_backward(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dfeat,
                                const fcn_pn_ws *ws, float *dW[3], float *dgamma[3], float *dbeta[3],
                                void *stream)
 {
+    return fcn_pn_backward2(d, p, dfeat, ws, dW, dgamma, dbeta, stream, nullptr, nullptr);
+}
+
+// Same with the weight gradients (wgrad + reduce of conv3 and conv2) on a second stream beside the data-gradient
+// chain poolbwd -> dgrad3 -> dgrad2 -> l1_finalize.  events: 3 caller-owned hipEvent_t (fork, fork, join).
+extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dfeat,
+                                const fcn_pn_ws *ws, float *dW[3], float *dgamma[3], float *dbeta[3],
+                                void *stream, void *stream2, void *const *events)
+{
     if (!d || !p || !ws || !dfeat || !dW || !dgamma || !dbeta) return FCN_E_BADARG;
     if (!d->training) return FCN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
+    const bool two = stream2 != nullptr && events != nullptr;
+    hipStream_t sw = two ? (hipStream_t)stream2 : st;
     const int B = d->B, L = d->L, K = d->K, C1 = d->C1, C2 = d->C2, C3 = d->C3;
     if (C1 % 64 || C2 % 64 || C3 % 64 || C1 > MAXC || C2 > MAXC || C3 > MAXC) return FCN_E_BADARG;
     const int cap = L * K;
@@ -599,23 +626,46 @@ extern "C" int fcn_pn_backward(const fcn_pn_desc *d, const fcn_pn_params *p, con
     w.partial = ws->partial;
     w.dy = ws->dy3; w.dz = nullptr; w.ycur = nullptr; w.coef = nullptr; w.yprev = ws->y2; w.bn_prev = bn2;
     w.W1 = nullptr; w.COUT = C3; w.CIN = C2;
-    FCN_TRY(launch_wgrad<3>(w, B, ws->nsplit, st, dW[2]));
+    if (two) {     // dy3 is final: conv3's weight gradient can run beside the rest of the chain
+        e = hipEventRecord((hipEvent_t)events[0], st);
+        if (e != hipSuccess) return (int)e;
+        e = hipStreamWaitEvent(sw, (hipEvent_t)events[0], 0);
+        if (e != hipSuccess) return (int)e;
+    }
+    FCN_TRY(launch_wgrad<3>(w, B, ws->nsplit, sw, dW[2]));
 
     hipLaunchKernelGGL(bnbwd_finalize_kernel, dim3((C2 + 63) / 64), dim3(64), 0, st, bs2, p->gamma[1], bn2, C2, M,
                        coef2, dgamma[1], dbeta[1]);
     FCN_CHECK_LAUNCH();
 
+    if (two) {     // coef2 is final (dz2 was by events[0]): conv2's weight gradient follows conv3's on the side stream
+        e = hipEventRecord((hipEvent_t)events[1], st);
+        if (e != hipSuccess) return (int)e;
+        e = hipStreamWaitEvent(sw, (hipEvent_t)events[1], 0);
+        if (e != hipSuccess) return (int)e;
+        w.dy = nullptr; w.dz = ws->dz2; w.ycur = ws->y2; w.coef = coef2; w.yprev = nullptr; w.bn_prev = bn1;
+        w.W1 = p->W[0]; w.COUT = C2; w.CIN = C1;
+        FCN_TRY(launch_wgrad<2>(w, B, ws->nsplit, sw, dW[1]));
+        e = hipEventRecord((hipEvent_t)events[2], sw);
+        if (e != hipSuccess) return (int)e;
+    }
     g.ycur = ws->y2; g.amax = nullptr; g.gmax = nullptr; g.dzcur = ws->dz2; g.coef = coef2; g.W = p->W[1];
     g.dybuf = nullptr; g.yprev = nullptr; g.bn_prev = bn1; g.W1 = p->W[0]; g.dzprev = nullptr; g.bstat_prev = bsQ;
     g.CRED = C2; g.CPREV = C1;
     FCN_TRY(launch_dgrad<2>(g, B, st));
 
-    w.dy = nullptr; w.dz = ws->dz2; w.ycur = ws->y2; w.coef = coef2; w.yprev = nullptr; w.bn_prev = bn1;
-    w.W1 = p->W[0]; w.COUT = C2; w.CIN = C1;
-    FCN_TRY(launch_wgrad<2>(w, B, ws->nsplit, st, dW[1]));
+    if (!two) {
+        w.dy = nullptr; w.dz = ws->dz2; w.ycur = ws->y2; w.coef = coef2; w.yprev = nullptr; w.bn_prev = bn1;
+        w.W1 = p->W[0]; w.COUT = C2; w.CIN = C1;
+        FCN_TRY(launch_wgrad<2>(w, B, ws->nsplit, st, dW[1]));
+    }
 
     hipLaunchKernelGGL(l1_finalize_kernel, dim3((C1 + 63) / 64), dim3(64), 0, st, bsQ, ws->stat + FCN_STAT_MOM,
                        p->W[0], p->gamma[0], bn1, C1, M, dW[0], dgamma[0], dbeta[0]);
     FCN_CHECK_LAUNCH();
+    if (two) {
+        e = hipStreamWaitEvent(st, (hipEvent_t)events[2], 0);
+        if (e != hipSuccess) return (int)e;
+    }
     return 0;
 }

@@ -14,6 +14,8 @@ What runs where:
 import math
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -94,34 +96,42 @@ class PointNetFeat(nn.Module):
         self.pointnet4 = PointNetModule(input_channel - 3, [256, 256, 512], u[3], 128, use_xyz=True, use_feature=True)
         self.concurrent_scales = True
         self._stream_cache = {}
+        # the widest scale is the long pole of the backward: its weight-gradient GEMMs run on a second stream beside
+        # its data-gradient chain (bit k of FCN_PN_SIDE = scale k+1; default scale 4 only)
+        mask = int(os.environ.get("FCN_PN_SIDE", "8"))
+        for k, net in enumerate((self.pointnet1, self.pointnet2, self.pointnet3, self.pointnet4)):
+            net._pool.side_wgrad = bool(mask >> k & 1)
 
     def forward(self, point_cloud, sample_pc, feat=None, one_hot_vec=None, nlc=False):
         if one_hot_vec is not None:
             assert self.num_vec == one_hot_vec.shape[1]
         nets = (self.pointnet1, self.pointnet2, self.pointnet3, self.pointnet4)
-        if not (self.concurrent_scales and point_cloud.is_cuda):
+        if not (self.concurrent_scales and point_cloud.is_cuda) or os.environ.get("FCN_SERIAL", "0") == "1":
             return tuple(net.forward_pooled(point_cloud, ref, one_hot_vec, nlc) for net, ref in zip(nets, sample_pc))
-        # The four scales are independent until the FCN: run them on four HIP streams so one scale's tail
-        # (a few workgroups left on 256 CUs) overlaps the others' work.  autograd replays each scale's backward
-        # on the stream its forward ran on, so the backward overlaps the same way; the fork/join is captured
-        # as parallel branches of the step's hipGraph.
+        # The four scales are independent until the FCN: scales 1-3 run on three forked HIP streams and the widest
+        # (scale 4, the long pole) on the current stream, so one scale's tail (a few workgroups left on 256 CUs)
+        # overlaps the others' work.  autograd replays each scale's backward on the stream its forward ran on, so the
+        # backward overlaps the same way; the fork/join is captured as parallel branches of the step's hipGraph.
+        # Scale 4 stays on the current stream because its backward forks a second stream for the weight gradients
+        # and ROCm 7.2 stream capture crashes on a fork from an already-forked stream (flat forks only).
         cur = torch.cuda.current_stream(point_cloud.device)
         streams = self._streams(point_cloud.device)
         outs = [None] * 4
-        order = (3, 2, 0, 1)                      # heaviest scale first
-        for s in order:
+        forked = (2, 0, 1)
+        for s in forked:
             st = streams[s]
             st.wait_stream(cur)
             with torch.cuda.stream(st):
                 outs[s] = nets[s].forward_pooled(point_cloud, sample_pc[s], one_hot_vec, nlc)
-        for s in order:
+        outs[3] = nets[3].forward_pooled(point_cloud, sample_pc[3], one_hot_vec, nlc)
+        for s in forked:
             cur.wait_stream(streams[s])
         return tuple(outs)
 
     def _streams(self, device):
         key = str(device)
         if key not in self._stream_cache:
-            self._stream_cache[key] = [torch.cuda.Stream(device=device) for _ in range(4)]
+            self._stream_cache[key] = [torch.cuda.Stream(device=device) for _ in range(3)]
         return self._stream_cache[key]
 
 

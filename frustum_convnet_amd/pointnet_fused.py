@@ -5,6 +5,7 @@ ReLU], mask, max over K, one-hot concat) -> pooled (B, C3+nvec, L), forward and 
 (frustum_convnet_amd/csrc).  Nothing here computes on the host or falls back to torch ops.
 """
 import ctypes
+import os
 
 import torch
 
@@ -52,6 +53,21 @@ class Workspace:
 class WorkspacePool:
     def __init__(self):
         self.free = {}
+        self.side = {}
+        self.side_wgrad = False     # weight-gradient GEMMs of the backward on a second stream (fcn_pn_backward2)
+
+    def side_stream(self, device):
+        """Second HIP stream + 3 events (caller-owned, handed to fcn_pn_backward2) per device."""
+        key = str(device)
+        if key not in self.side:
+            with torch.cuda.device(device):
+                st = torch.cuda.Stream(device=device)
+                evs = [torch.cuda.Event(enable_timing=False) for _ in range(3)]
+                for ev in evs:
+                    ev.record()
+                arr = (ctypes.c_void_p * 3)(*[ev.cuda_event for ev in evs])
+            self.side[key] = (st, evs, arr)
+        return self.side[key]
 
     def acquire(self, *key, device, need_grad):
         k = tuple(key) + (bool(need_grad), str(device))
@@ -137,10 +153,16 @@ class _PointNetPooled(torch.autograd.Function):
         db = [torch.empty_like(b) for b in bs]
         params = _params_struct(Wc, gs, bs, [None] * 3, [None] * 3, [None] * 3)
         arr = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
+        if ctx.pool.side_wgrad:
+            side, _evs, evarr = ctx.pool.side_stream(dev)
+            s2 = ctypes.c_void_p(side.cuda_stream)
+        else:
+            s2, evarr = None, None
         with torch.cuda.device(dev):
-            _native.check(L.fcn_pn_backward(ctypes.byref(desc), ctypes.byref(params), dfeat.data_ptr(),
-                                            ctypes.byref(ws.c), arr(dW), arr(dg), arr(db),
-                                            _native.current_stream(dev)), "fcn_pn_backward")
+            _native.check(L.fcn_pn_backward2(ctypes.byref(desc), ctypes.byref(params), dfeat.data_ptr(),
+                                             ctypes.byref(ws.c), arr(dW), arr(dg), arr(db),
+                                             _native.current_stream(dev), s2, evarr),
+                          "fcn_pn_backward2")
         ctx.pool.release(ws)
         ctx.ws = None
         ctx.live = False

@@ -110,6 +110,12 @@ int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, const int32_t *
 int fcn_pn_backward(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dfeat,
                     const fcn_pn_ws *ws, float *dW[3], float *dgamma[3], float *dbeta[3], void *stream);
 
+/* Same as fcn_pn_backward with the two weight-gradient GEMMs (+ their reduces) enqueued on a second stream beside the
+ * data-gradient chain; events = 3 caller-owned hipEvent_t.  stream joins on the side stream before returning work. */
+int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dfeat,
+                     const fcn_pn_ws *ws, float *dW[3], float *dgamma[3], float *dbeta[3],
+                     void *stream, void *stream2, void *const *events);
+
 /* Launches ONLY the conv GEMM of `layer` (2 or 3) on the state a previous fcn_pn_compact/fcn_pn_forward left in
  * ws: the unit the roofline figure in bench.py is measured on.  with_stats != 0 keeps the BN-statistics epilogue. */
 int fcn_pn_conv_fwd(const fcn_pn_desc *d, const fcn_pn_params *p, const fcn_pn_ws *ws, int layer,
