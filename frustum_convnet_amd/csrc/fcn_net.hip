@@ -385,31 +385,50 @@ __global__ __launch_bounds__(G * 128 * MW) void cgk_dgrad_kernel(CgDgrad a)
     acc_zero<1, 1>(acc);
     v4f rz[NA], ry[NA], rw[NB];
     const int ncn = L.Cout / KC, nchunk = L.KT * ncn, nit = (nchunk + G - 1) / G;
-    auto load_chunk = [&](int c) __attribute__((always_inline)) {
-        const int tap = c / ncn, nq = (c % ncn) * KC + 4 * kq;
+    // No integer division inside the reduction loop (each one is ~40 VALU instructions and the loop body is otherwise
+    // ~100): the (tap, column base, BN channel base) of every chunk comes from a small LDS table, and the output
+    // position a source row meets through tap t -- (li + pad - t) / stride, valid when it divides -- is precomputed
+    // per tap into registers that are picked with wave-uniform selects.
+    __shared__ int cTap[CG_KMAX / KC], cNb[CG_KMAX / KC], cCh[CG_KMAX / KC];
+    if (tid < nchunk) {
+        const int tp = tid / ncn, nb = (tid % ncn) * KC;
+        cTap[tid] = tp; cNb[tid] = nb; cCh[tid] = nb % Cs;
+    }
+    int lo_t[NA][3];
+    bool ok_t[NA][3];
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int t = li[i] + L.pad - tap;
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3) {
+            const int t = li[i] + L.pad - t3;
             const int lo = t / L.stride;
-            ok[i] = rv[i] && t >= 0 && (t % L.stride) == 0 && lo < L.Lout;
-            const int64_t o = ((int64_t)bb[i] * L.Lout + min(max(lo, 0), L.Lout - 1)) * L.Cout + nq;
-            rz[i] = ldg4(a.dzc + o);                       // unconditional (clamped row), masked at store time
-            ry[i] = ldg4((hasbn ? a.yc : a.dzc) + o);
+            ok_t[i][t3] = rv[i] && t3 < L.KT && t >= 0 && (t % L.stride) == 0 && lo < L.Lout;
+            lo_t[i][t3] = min(max(lo, 0), L.Lout - 1);
         }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int f = gt + TG * i;
-            const int nn = f >> 4, cq = f & 15;
-            rw[i] = ldg4(L.Wp + (int64_t)((c % ncn) * KC + nn) * L.Ktot + a.segoff + tap * C + c0 + 4 * cq);
-        }
-    };
-    load_chunk(min(g, nchunk - 1));
-    __syncthreads();                            // coefS ready
+    __syncthreads();                            // chunk table (and coefS) ready
+#define CGK_DGRAD_LOAD(cc)                                                                                            \
+    {                                                                                                                 \
+        const int c_ = (cc);                                                                                          \
+        const int tap = __builtin_amdgcn_readfirstlane(cTap[c_]), nb = __builtin_amdgcn_readfirstlane(cNb[c_]);       \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                              \
+            ok[i] = SEL3(tap, ok_t[i][0], ok_t[i][1], ok_t[i][2]);                                                    \
+            const int lo = SEL3(tap, lo_t[i][0], lo_t[i][1], lo_t[i][2]);                                             \
+            const int64_t o = ((int64_t)bb[i] * L.Lout + lo) * L.Cout + nb + 4 * kq;                                  \
+            rz[i] = ldg4(a.dzc + o);                       /* unconditional (clamped row), masked at store time */    \
+            ry[i] = ldg4((hasbn ? a.yc : a.dzc) + o);                                                                 \
+        }                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                              \
+            const int f = gt + TG * i;                                                                                \
+            const int nn = f >> 4, cq = f & 15;                                                                       \
+            rw[i] = ldg4(L.Wp + (int64_t)(nb + nn) * L.Ktot + a.segoff + tap * C + c0 + 4 * cq);                      \
+        }                                                                                                             \
+    }
+    CGK_DGRAD_LOAD(min(g, nchunk - 1));
     for (int it = 0; it < nit; ++it) {
         const int c = it * G + g;
         const bool act = c < nchunk;
         if (act) {
-            const int nq = (c % ncn) * KC + 4 * kq;
+            const int chb = __builtin_amdgcn_readfirstlane(cCh[c]) + 4 * kq;     // BN channel of this thread's first column
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int r = rb + RSTEP * i;
@@ -417,7 +436,7 @@ __global__ __launch_bounds__(G * 128 * MW) void cgk_dgrad_kernel(CgDgrad a)
                 const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (hasbn) d[j] = cg_dy(coefS, Cs, (nq + j) % Cs, d[j], yv[j]);
+                    if (hasbn) d[j] = cg_dy(coefS, Cs, chb + j, d[j], yv[j]);
                     d[j] = ok[i] ? d[j] : 0.f;
                 }
                 As[(4 * kq + 0) * LDA + r] = d[0]; As[(4 * kq + 1) * LDA + r] = d[1];
@@ -430,7 +449,7 @@ __global__ __launch_bounds__(G * 128 * MW) void cgk_dgrad_kernel(CgDgrad a)
             }
         }
         __syncthreads();
-        if (c + G < nchunk) load_chunk(c + G);
+        if (c + G < nchunk) CGK_DGRAD_LOAD(c + G);
         if (act) mma_chunk<1, 1, LDA, LDN>(As, Bs, wm * 32, wn * 32, acc);
         __syncthreads();
     }
@@ -539,15 +558,24 @@ __global__ __launch_bounds__(CG_T) void cg_wgrad_kernel(CgWgrad a)
     v4f rz[2], ry[2], rx[2];
     bool ok[2];
     const int xC = SC, xLs = SLs, xlm = Sty ? 0 : 1;
+    // (frustum, position) of this thread's two rows, advanced by KC per chunk instead of divided out of the row index
+    int wb[2], wl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int r = rbeg + rr0 + 16 * i; wb[i] = r / L.Lout; wl[i] = r % L.Lout; }
+    const int bend = (rend - 1) / L.Lout, lend = (rend - 1) % L.Lout;
 #define CG_WGRAD_LOAD(rr)                                                                                             \
     {                                                                                                                 \
         const int r0_ = (rr);                                                                                         \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                               \
-            const int row = min(r0_ + rr0 + 16 * i, rend - 1); /* clamped: unconditional loads, masked at store */    \
+            const bool in = r0_ + rr0 + 16 * i < rend;      /* clamped: unconditional loads, masked at store */       \
+            const int row = in ? r0_ + rr0 + 16 * i : rend - 1;                                                       \
             const int64_t o = (int64_t)row * L.Cout + n0 + 4 * cq;                                                    \
             rz[i] = ldg4(a.dz + o);                                                                                   \
             ry[i] = ldg4((hasbn ? L.y : a.dz) + o);                                                                   \
-            rx[i] = cg_load_raw(L, Sx, xC, xLs, xlm, tap, k0 + 4 * cq, row / L.Lout, row % L.Lout, true, ok[i]);      \
+            rx[i] = cg_load_raw(L, Sx, xC, xLs, xlm, tap, k0 + 4 * cq, in ? wb[i] : bend, in ? wl[i] : lend, true,    \
+                                ok[i]);                                                                               \
+            wl[i] += KC;                                                                                              \
+            while (wl[i] >= L.Lout) { wl[i] -= L.Lout; wb[i] += 1; }                                                  \
         }                                                                                                             \
     }
     CG_WGRAD_LOAD(rbeg);
@@ -757,6 +785,8 @@ static int cn_make_plan(const fcn_cn_desc *d, CnPlan &P)
         for (int s = 0; s < P.nseg[l]; ++s) { cs += P.C[l][s]; ct += (P.src[l][s] == -9) ? d->nvec : P.C[l][s]; }
         P.Ktot[l] = P.KT[l] * cs;
         P.cin_tot[l] = ct;
+        // LDS tables of the kernels: per-column BN scale/shift, per-chunk descriptors, BN-backward coefficients
+        if (P.Ktot[l] > CG_KMAX || P.KT[l] * P.N[l] > CG_KMAX || P.Cs[l] > 512 || P.KT[l] > 3 || P.stride[l] > 2) return FCN_E_LIMIT;
     }
     return 0;
 }
@@ -904,6 +934,7 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
     if (!d || !p || !ws || !feats || !dlogits || !dfeats || !dW || !dgamma || !dbeta || !dbias) return FCN_E_BADARG;
     if (!d->training) return FCN_E_BADARG;
     if (!ws->y || !ws->dz || !ws->wp || !ws->bn || !ws->bstat || !ws->coef || !ws->partial) return FCN_E_BADARG;
+
     hipStream_t st = (hipStream_t)stream;
     // The data-gradient chain (finalize -> dgrad -> next layer) is a latency-bound sequence of small launches; the
     // weight gradients only hang off it.  With a second stream + CN_NLAYER+1 caller-owned events they run beside the
