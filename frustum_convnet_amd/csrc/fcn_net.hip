@@ -326,293 +326,6 @@ __device__ __forceinline__ float cg_dy(const float *coefS, int Cs, int ch, float
     return coefS[ch] * (dz - fmaf(xh, coefS[4 * Cs + ch], coefS[3 * Cs + ch]));
 }
 
-// ------------------------------------------------------------------------------------------------
-struct CgDgrad {
-    CgLayer lay;               // the consumer layer
-    int sg, segoff;            // which of its segments is differentiated; its column offset in Wp
-    const float *dzc, *yc;     // consumer's incoming dz, pre-BN output
-    CgBnBwd cb;                // consumer's BN backward (bstat null: no BN)
-    const float *ysrc, *bnsrc; // producer's pre-BN output and BN (scale,shift,mean,rstd); null: source is a plain input
-    float *out;                // producer's dz (Rsrc x C) or the input gradient
-    int accumulate;            // add to what `out` already holds (a second consumer)
-    double *bstat_src;         // non-null on the LAST consumer: sum dz, sum dz*xhat of the producer
-};
-
-// G[rs][k] = sum_tap sum_n dy[r_out(rs,tap)][n] * Wp[n][segoff + tap*C + k]; (32*MW) source rows x 64 source channels,
-// then the producer-side epilogue: ReLU mask from its pre-BN output, accumulate (second consumer), BN-backward sums.
-template <int MW, int G>
-__global__ __launch_bounds__(G * 128 * MW) void cgk_dgrad_kernel(CgDgrad a)
-{
-    constexpr int TG = 128 * MW, TMB = 32 * MW, LDA = TMB + 1, NTHR = G * TG;
-    constexpr int NA = TMB * 8 / TG, NB = 512 / TG;
-    constexpr int ASZ = KC * (LDA + 3);                 // As padded so that Bs stays 16-B aligned
-    __shared__ __attribute__((aligned(16))) float lds[G * (ASZ + KC * LDN)];
-    __shared__ float coefS[5 * CG_CMAX];
-    const CgLayer &L = a.lay;
-    // a.sg is a kernel argument (scalar): static-index selects, no dynamic struct indexing
-    const int SC = SEL3(a.sg, opaque_s(L.seg[0].C), opaque_s(L.seg[1].C), opaque_s(L.seg[2].C));
-    const int SLsrc = SEL3(a.sg, opaque_s(L.seg[0].Lsrc), opaque_s(L.seg[1].Lsrc), opaque_s(L.seg[2].Lsrc));
-    const int tid = threadIdx.x, g = tid / TG, gt = tid % TG;
-    const int lane = tid & 63, gw = gt >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int wm = (MW == 2) ? (gw >> 1) : 0, wn = gw & 1;
-    float *As = lds + g * (ASZ + KC * LDN), *Bs = As + ASZ;
-    const int C = SC, Rs = L.B * SLsrc, Cs = L.Cs;
-    const int row0 = blockIdx.x * TMB, c0 = blockIdx.y * 64;
-    const int kq = gt & 7, rb = gt >> 3;
-    constexpr int RSTEP = TG / 8;
-    const bool hasbn = a.cb.bstat != nullptr;
-    if (hasbn) {
-        const bool pub = blockIdx.x == 0 && blockIdx.y == 0;
-        for (int c = tid; c < Cs; c += NTHR) {
-            float cf[5];
-            cg_bnbwd_coef(a.cb, Cs, c, cf, pub);
-#pragma unroll
-            for (int q = 0; q < 5; ++q) coefS[q * Cs + c] = cf[q];
-        }
-    }
-    int bb[NA], li[NA];
-    bool rv[NA], ok[NA];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int gr = row0 + rb + RSTEP * i;
-        rv[i] = gr < Rs;
-        bb[i] = rv[i] ? gr / SLsrc : 0;
-        li[i] = rv[i] ? gr % SLsrc : 0;
-        rv[i] = rv[i] && li[i] < L.Lin;
-        ok[i] = false;
-    }
-    f32x16 acc[1][1];
-    acc_zero<1, 1>(acc);
-    v4f rz[NA], ry[NA], rw[NB];
-    const int ncn = L.Cout / KC, nchunk = L.KT * ncn, nit = (nchunk + G - 1) / G;
-    // No integer division inside the reduction loop (each one is ~40 VALU instructions and the loop body is otherwise
-    // ~100): the (tap, column base, BN channel base) of every chunk comes from a small LDS table, and the output
-    // position a source row meets through tap t -- (li + pad - t) / stride, valid when it divides -- is precomputed
-    // per tap into registers that are picked with wave-uniform selects.
-    __shared__ int cTap[CG_KMAX / KC], cNb[CG_KMAX / KC], cCh[CG_KMAX / KC];
-    if (tid < nchunk) {
-        const int tp = tid / ncn, nb = (tid % ncn) * KC;
-        cTap[tid] = tp; cNb[tid] = nb; cCh[tid] = nb % Cs;
-    }
-    int lo_t[NA][3];
-    bool ok_t[NA][3];
-#pragma unroll
-    for (int i = 0; i < NA; ++i)
-#pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3) {
-            const int t = li[i] + L.pad - t3;
-            const int lo = t / L.stride;
-            ok_t[i][t3] = rv[i] && t3 < L.KT && t >= 0 && (t % L.stride) == 0 && lo < L.Lout;
-            lo_t[i][t3] = min(max(lo, 0), L.Lout - 1);
-        }
-    __syncthreads();                            // chunk table (and coefS) ready
-#define CGK_DGRAD_LOAD(cc)                                                                                            \
-    {                                                                                                                 \
-        const int c_ = (cc);                                                                                          \
-        const int tap = __builtin_amdgcn_readfirstlane(cTap[c_]), nb = __builtin_amdgcn_readfirstlane(cNb[c_]);       \
-        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                              \
-            ok[i] = SEL3(tap, ok_t[i][0], ok_t[i][1], ok_t[i][2]);                                                    \
-            const int lo = SEL3(tap, lo_t[i][0], lo_t[i][1], lo_t[i][2]);                                             \
-            const int64_t o = ((int64_t)bb[i] * L.Lout + lo) * L.Cout + nb + 4 * kq;                                  \
-            rz[i] = ldg4(a.dzc + o);                       /* unconditional (clamped row), masked at store time */    \
-            ry[i] = ldg4((hasbn ? a.yc : a.dzc) + o);                                                                 \
-        }                                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                              \
-            const int f = gt + TG * i;                                                                                \
-            const int nn = f >> 4, cq = f & 15;                                                                       \
-            rw[i] = ldg4(L.Wp + (int64_t)(nb + nn) * L.Ktot + a.segoff + tap * C + c0 + 4 * cq);                      \
-        }                                                                                                             \
-    }
-    CGK_DGRAD_LOAD(min(g, nchunk - 1));
-    for (int it = 0; it < nit; ++it) {
-        const int c = it * G + g;
-        const bool act = c < nchunk;
-        if (act) {
-            const int chb = __builtin_amdgcn_readfirstlane(cCh[c]) + 4 * kq;     // BN channel of this thread's first column
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int r = rb + RSTEP * i;
-                float d[4] = {rz[i].x, rz[i].y, rz[i].z, rz[i].w};
-                const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (hasbn) d[j] = cg_dy(coefS, Cs, chb + j, d[j], yv[j]);
-                    d[j] = ok[i] ? d[j] : 0.f;
-                }
-                As[(4 * kq + 0) * LDA + r] = d[0]; As[(4 * kq + 1) * LDA + r] = d[1];
-                As[(4 * kq + 2) * LDA + r] = d[2]; As[(4 * kq + 3) * LDA + r] = d[3];
-            }
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int f = gt + TG * i;
-                sts4(Bs + (f >> 4) * LDN + 4 * (f & 15), rw[i]);
-            }
-        }
-        __syncthreads();
-        if (c + G < nchunk) CGK_DGRAD_LOAD(c + G);
-        if (act) mma_chunk<1, 1, LDA, LDN>(As, Bs, wm * 32, wn * 32, acc);
-        __syncthreads();
-    }
-    float *red = lds;                                   // [G][TMB][64]
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg)
-        red[(g * TMB + wm * 32 + acc_row(reg, lh)) * 64 + wn * 32 + l31] = acc[0][0][reg];
-    __syncthreads();
-    const int ecq = tid & 15;
-    const int col = c0 + 4 * ecq;
-    v4f ps = zero4(), pt = zero4(), pm = zero4(), pr = zero4();
-    if (a.bnsrc) {
-        ps = ldg4(a.bnsrc + col); pt = ldg4(a.bnsrc + C + col);
-        pm = ldg4(a.bnsrc + 2 * C + col); pr = ldg4(a.bnsrc + 3 * C + col);
-    }
-    v4f cs1 = zero4(), cs2 = zero4();
-    for (int er = tid >> 4; er < TMB; er += NTHR / 16) {
-        const int row = row0 + er;
-        if (row >= Rs) continue;
-        v4f gsum = zero4();
-#pragma unroll
-        for (int q = 0; q < G; ++q) gsum += *(const v4f *)(red + (q * TMB + er) * 64 + 4 * ecq);
-        const int64_t o = (int64_t)row * C + col;
-        v4f xh = zero4();
-        if (a.bnsrc) {
-            const v4f yv = ldg4(a.ysrc + o);
-            gsum.x = fmaf(ps.x, yv.x, pt.x) > 0.f ? gsum.x : 0.f; gsum.y = fmaf(ps.y, yv.y, pt.y) > 0.f ? gsum.y : 0.f;
-            gsum.z = fmaf(ps.z, yv.z, pt.z) > 0.f ? gsum.z : 0.f; gsum.w = fmaf(ps.w, yv.w, pt.w) > 0.f ? gsum.w : 0.f;
-            xh = (yv - pm) * pr;
-        }
-        if (a.accumulate) gsum += ldg4(a.out + o);
-        sts4(a.out + o, gsum);
-        cs1 += gsum;
-        cs2 += gsum * xh;
-    }
-    if (!a.bstat_src) return;
-    float pv[8] = {cs1.x, cs1.y, cs1.z, cs1.w, cs2.x, cs2.y, cs2.z, cs2.w};
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        pv[q] += __shfl_xor(pv[q], 16, 64);
-        pv[q] += __shfl_xor(pv[q], 32, 64);
-    }
-    __syncthreads();
-    float *st = lds;                                    // [NTHR/64 waves][64 cols][2]
-    if (lane < 16) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            st[((tid >> 6) * 64 + 4 * ecq + j) * 2] = pv[j];
-            st[((tid >> 6) * 64 + 4 * ecq + j) * 2 + 1] = pv[4 + j];
-        }
-    }
-    __syncthreads();
-    if (tid < 128) {
-        const int c = tid & 63, w = tid >> 6;
-        double v = 0.0;
-#pragma unroll
-        for (int r = 0; r < NTHR / 64; ++r) v += (double)st[(r * 64 + c) * 2 + w];
-        atomic_add_f64(&a.bstat_src[w * C + c0 + c], v);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-struct CgWgrad {
-    CgLayer lay;
-    const float *dz;           // incoming dz of this layer (R x Cout)
-    CgBnBwd cb;                // its BN backward (bstat null: no BN); dgamma/dbeta are exported by the dgrad launch
-    float *partial;            // (nsplit, Cout, Ktot)
-    int rows;                  // rows per split (multiple of 32)
-};
-
-// dWp[n][kk] = sum_r dy[r][n] * A[r][kk]; tile 64 (n) x 64 (kk), rows split over blockIdx.x.
-__global__ __launch_bounds__(CG_T) void cg_wgrad_kernel(CgWgrad a)
-{
-    __shared__ __attribute__((aligned(16))) float As[KC * LDN];
-    __shared__ __attribute__((aligned(16))) float Bs[KC * LDN];
-    const CgLayer &L = a.lay;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5, wm = wave >> 1, wn = wave & 1;
-    const int R = L.B * L.Lout, Cs = L.Cs;
-    const int rbeg = blockIdx.x * a.rows, rend = min(R, rbeg + a.rows);
-    const int n0 = blockIdx.y * 64, kk0 = blockIdx.z * 64;
-    int sg, tap, k0, so;
-    cg_locate(L, kk0, sg, tap, k0, so);                   // kk0 is workgroup-uniform
-    sg = __builtin_amdgcn_readfirstlane(sg);
-    const float *Sx = SEL3(sg, opaque_s(L.seg[0].x), opaque_s(L.seg[1].x), opaque_s(L.seg[2].x));
-    const float *Sbn = SEL3(sg, opaque_s(L.seg[0].bn), opaque_s(L.seg[1].bn), opaque_s(L.seg[2].bn));
-    const int SC = SEL3(sg, opaque_s(L.seg[0].C), opaque_s(L.seg[1].C), opaque_s(L.seg[2].C));
-    const int Sty = SEL3(sg, opaque_s(L.seg[0].type), opaque_s(L.seg[1].type), opaque_s(L.seg[2].type));
-    const int SLs = SEL3(sg, opaque_s(L.seg[0].Lsrc), opaque_s(L.seg[1].Lsrc), opaque_s(L.seg[2].Lsrc));
-    const int cq = tid & 15, rr0 = tid >> 4;              // column quad, first row (rows rr0, rr0+16)
-    // per-thread constants of its 4 columns: BN-backward coefficients of dy, BN scale/shift of the A operand
-    const bool hasbn = a.cb.bstat != nullptr;
-    float cf[5][4], as[4], at[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int ch = (n0 + 4 * cq + j) % Cs;
-        float c5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-        if (hasbn) cg_bnbwd_coef(a.cb, Cs, ch, c5, false);
-#pragma unroll
-        for (int q = 0; q < 5; ++q) cf[q][j] = c5[q];
-        as[j] = Sbn ? Sbn[k0 + 4 * cq + j] : 1.f;
-        at[j] = Sbn ? Sbn[SC + k0 + 4 * cq + j] : 0.f;
-    }
-    f32x16 acc[1][1];
-    acc_zero<1, 1>(acc);
-    v4f rz[2], ry[2], rx[2];
-    bool ok[2];
-    const int xC = SC, xLs = SLs, xlm = Sty ? 0 : 1;
-    // (frustum, position) of this thread's two rows, advanced by KC per chunk instead of divided out of the row index
-    int wb[2], wl[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { const int r = rbeg + rr0 + 16 * i; wb[i] = r / L.Lout; wl[i] = r % L.Lout; }
-    const int bend = (rend - 1) / L.Lout, lend = (rend - 1) % L.Lout;
-#define CG_WGRAD_LOAD(rr)                                                                                             \
-    {                                                                                                                 \
-        const int r0_ = (rr);                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                               \
-            const bool in = r0_ + rr0 + 16 * i < rend;      /* clamped: unconditional loads, masked at store */       \
-            const int row = in ? r0_ + rr0 + 16 * i : rend - 1;                                                       \
-            const int64_t o = (int64_t)row * L.Cout + n0 + 4 * cq;                                                    \
-            rz[i] = ldg4(a.dz + o);                                                                                   \
-            ry[i] = ldg4((hasbn ? L.y : a.dz) + o);                                                                   \
-            rx[i] = cg_load_raw(L, Sx, xC, xLs, xlm, tap, k0 + 4 * cq, in ? wb[i] : bend, in ? wl[i] : lend, true,    \
-                                ok[i]);                                                                               \
-            wl[i] += KC;                                                                                              \
-            while (wl[i] >= L.Lout) { wl[i] -= L.Lout; wb[i] += 1; }                                                  \
-        }                                                                                                             \
-    }
-    CG_WGRAD_LOAD(rbeg);
-    for (int r0 = rbeg; r0 < rend; r0 += KC) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float d[4] = {rz[i].x, rz[i].y, rz[i].z, rz[i].w};
-            const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
-            const bool live = (r0 + rr0 + 16 * i) < rend;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (hasbn) {
-                    const float xh = (yv[j] - cf[1][j]) * cf[2][j];
-                    d[j] = cf[0][j] * (d[j] - fmaf(xh, cf[4][j], cf[3][j]));
-                }
-                d[j] = live ? d[j] : 0.f;
-            }
-            v4f dv = {d[0], d[1], d[2], d[3]};
-            sts4(As + (rr0 + 16 * i) * LDN + 4 * cq, dv);
-            v4f av = {cg_act(as[0], rx[i].x, at[0], ok[i] && live), cg_act(as[1], rx[i].y, at[1], ok[i] && live),
-                      cg_act(as[2], rx[i].z, at[2], ok[i] && live), cg_act(as[3], rx[i].w, at[3], ok[i] && live)};
-            sts4(Bs + (rr0 + 16 * i) * LDN + 4 * cq, av);
-        }
-        __syncthreads();
-        if (r0 + KC < rend) CG_WGRAD_LOAD(r0 + KC);
-        mma_chunk<1, 1, LDN, LDN>(As, Bs, wm * 32, wn * 32, acc);
-        __syncthreads();
-    }
-    float *out = a.partial + (int64_t)blockIdx.x * L.Cout * L.Ktot;
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int n = n0 + wm * 32 + acc_row(reg, lh);
-        const int kk = kk0 + wn * 32 + l31;
-        out[(int64_t)n * L.Ktot + kk] = acc[0][0][reg];
-    }
-}
-
 // Weight packing descriptor of one layer: conv (Cout, Cin, KT) or deconv (Cin, Cout, k) <-> packed (N, Ktot).
 struct CgPack {
     int N, Ktot, KT, nseg;
@@ -671,34 +384,375 @@ __global__ void cg_pack_kernel(CgPackAll t)
     t.dst[l][e] = v;
 }
 
-// dW (torch layout) = sum of the split partials (fixed order); padding columns/rows are dropped.  64 consecutive
-// packed elements x CG_RG split groups per workgroup: a few independent loads per thread, then a group sum through LDS.
-#define CG_RG 8
-__global__ __launch_bounds__(64 * CG_RG) void cg_wgrad_reduce_kernel(const float *__restrict__ partial, int nsplit, CgPack p,
-                                                                   int nrow_real, float *__restrict__ dW)
+// ------------------------------------------------------------------------------------------------
+// Backward: ONE launch per layer.  The data-gradient chain is a latency-bound sequence of small GEMMs (B*L rows) and
+// the weight gradients only hang off it; run as separate launches -- even on a second captured stream -- ROCm's graph
+// executor serialises them.  So each step's launch carries three kinds of workgroups, picked by block index:
+//   [0, w_blk0)       data-gradient tiles of every differentiated input segment of layer l   (the critical chain)
+//   [w_blk0, r_blk0)  weight-gradient tiles of layer l, rows split over workgroups -> partials
+//   [r_blk0, end)     the fixed-order sum of the PREVIOUS step's partials into the torch weight layout
+// The weight-gradient and reduce workgroups fill the CUs the few data-gradient tiles leave idle.
+struct CgDgSeg {               // one differentiated input segment of the layer
+    int sg, segoff;            // which segment; its column offset in Wp
+    const float *ysrc, *bnsrc; // producer's pre-BN output and published BN (scale,shift,mean,rstd); null: plain input
+    float *out;                // producer's dz (Rsrc x C) or the input gradient
+    int accumulate;            // add to what `out` already holds (a second consumer)
+    double *bstat_src;         // non-null on the LAST consumer: sum dz, sum dz*xhat of the producer
+    int tx;                    // row tiles (32 rows each); workgroup t of the segment -> (t % tx, t / tx)
+    int blk0;                  // first workgroup of this segment
+};
+
+struct CgReduce {
+    const float *partial;      // (nsplit, N, Ktot)
+    int nsplit;
+    CgPack pk;
+    int nrow_real;
+    float *dW;
+};
+
+struct CgBwdStep {
+    CgLayer lay;               // the layer being differentiated
+    const float *dz;           // its incoming dz (R x Cout)
+    CgBnBwd cb;                // its BN backward (bstat null: no BN)
+    int ndg;
+    CgDgSeg dg0, dg1, dg2;
+    float *partial;            // wgrad partials of this layer
+    int rows, w_ns, w_ny;      // rows per split (multiple of KC), splits, 64-row tiles of Wp
+    int w_blk0, r_blk0;
+    CgReduce red;
+};
+
+#define CGB_T 512
+#define CGB_G 4
+// dgrad: G groups x (A [KC][36] + W [KC][LDN]) + BN-backward coefficients + chunk tables
+#define CGB_ASZ (KC * 36)
+#define CGB_LDS (CGB_G * (CGB_ASZ + KC * LDN))
+#define CGB_SMEM (CGB_LDS + 5 * CG_CMAX + 3 * (CG_KMAX / KC))
+
+// G[rs][k] = sum_tap sum_n dy[r_out(rs,tap)][n] * Wp[n][segoff + tap*C + k]; 32 source rows x 64 source channels by 4
+// K-groups, then the producer-side epilogue: ReLU mask from its pre-BN output, accumulate (second consumer),
+// BN-backward sums.
+__device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &cb, const float *dzc, const float *yc,
+                                              int sgi, int segoff, const float *ysrc, const float *bnsrc, float *outp,
+                                              int accumulate, double *bstat_src, int bx, int by, bool pub, float *smem)
 {
-    __shared__ float sh[CG_RG][64];
+    constexpr int G = CGB_G, TG = 128, TMB = 32, LDA = TMB + 1, NTHR = G * TG;
+    constexpr int NA = TMB * 8 / TG, NB = 512 / TG;
+    constexpr int ASZ = CGB_ASZ;                        // As padded so that Bs stays 16-B aligned
+    float *lds = smem;
+    float *coefS = smem + CGB_LDS;
+    int *cTap = (int *)(coefS + 5 * CG_CMAX), *cNb = cTap + CG_KMAX / KC, *cCh = cNb + CG_KMAX / KC;
+    // sgi is workgroup-uniform: static-index selects, no dynamic struct indexing
+    const int SC = SEL3(sgi, opaque_s(L.seg[0].C), opaque_s(L.seg[1].C), opaque_s(L.seg[2].C));
+    const int SLsrc = SEL3(sgi, opaque_s(L.seg[0].Lsrc), opaque_s(L.seg[1].Lsrc), opaque_s(L.seg[2].Lsrc));
+    const int tid = threadIdx.x, g = tid / TG, gt = tid % TG;
+    const int lane = tid & 63, gw = gt >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int wm = 0, wn = gw & 1;
+    float *As = lds + g * (ASZ + KC * LDN), *Bs = As + ASZ;
+    const int C = SC, Rs = L.B * SLsrc, Cs = L.Cs;
+    const int row0 = bx * TMB, c0 = by * 64;
+    const int kq = gt & 7, rb = gt >> 3;
+    constexpr int RSTEP = TG / 8;
+    const bool hasbn = cb.bstat != nullptr;
+    if (hasbn) {
+        for (int c = tid; c < Cs; c += NTHR) {
+            float cf[5];
+            cg_bnbwd_coef(cb, Cs, c, cf, pub);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) coefS[q * Cs + c] = cf[q];
+        }
+    }
+    int bb[NA], li[NA];
+    bool rv[NA], ok[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int gr = row0 + rb + RSTEP * i;
+        rv[i] = gr < Rs;
+        bb[i] = rv[i] ? gr / SLsrc : 0;
+        li[i] = rv[i] ? gr % SLsrc : 0;
+        rv[i] = rv[i] && li[i] < L.Lin;
+        ok[i] = false;
+    }
+    f32x16 acc[1][1];
+    acc_zero<1, 1>(acc);
+    v4f rz[NA], ry[NA], rw[NB];
+    const int ncn = L.Cout / KC, nchunk = L.KT * ncn, nit = (nchunk + G - 1) / G;
+    // No integer division inside the reduction loop (each one is ~40 VALU instructions and the loop body is otherwise
+    // ~100): the (tap, column base, BN channel base) of every chunk comes from a small LDS table, and the output
+    // position a source row meets through tap t -- (li + pad - t) / stride, valid when it divides -- is precomputed
+    // per tap into registers that are picked with wave-uniform selects.
+    if (tid < nchunk) {
+        const int tp = tid / ncn, nb = (tid % ncn) * KC;
+        cTap[tid] = tp; cNb[tid] = nb; cCh[tid] = nb % Cs;
+    }
+    int lo_t[NA][3];
+    bool ok_t[NA][3];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3) {
+            const int t = li[i] + L.pad - t3;
+            const int lo = t / L.stride;
+            ok_t[i][t3] = rv[i] && t3 < L.KT && t >= 0 && (t % L.stride) == 0 && lo < L.Lout;
+            lo_t[i][t3] = min(max(lo, 0), L.Lout - 1);
+        }
+    __syncthreads();                            // chunk table (and coefS) ready
+#define CGK_DGRAD_LOAD(cc)                                                                                            \
+    {                                                                                                                 \
+        const int c_ = (cc);                                                                                          \
+        const int tap = __builtin_amdgcn_readfirstlane(cTap[c_]), nb = __builtin_amdgcn_readfirstlane(cNb[c_]);       \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                              \
+            ok[i] = SEL3(tap, ok_t[i][0], ok_t[i][1], ok_t[i][2]);                                                    \
+            const int lo = SEL3(tap, lo_t[i][0], lo_t[i][1], lo_t[i][2]);                                             \
+            const int64_t o = ((int64_t)bb[i] * L.Lout + lo) * L.Cout + nb + 4 * kq;                                  \
+            rz[i] = ldg4(dzc + o);                         /* unconditional (clamped row), masked at store time */    \
+            ry[i] = ldg4((hasbn ? yc : dzc) + o);                                                                     \
+        }                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                              \
+            const int f = gt + TG * i;                                                                                \
+            const int nn = f >> 4, cq = f & 15;                                                                       \
+            rw[i] = ldg4(L.Wp + (int64_t)(nb + nn) * L.Ktot + segoff + tap * C + c0 + 4 * cq);                        \
+        }                                                                                                             \
+    }
+    CGK_DGRAD_LOAD(min(g, nchunk - 1));
+    for (int it = 0; it < nit; ++it) {
+        const int c = it * G + g;
+        const bool act = c < nchunk;
+        if (act) {
+            const int chb = __builtin_amdgcn_readfirstlane(cCh[c]) + 4 * kq;     // BN channel of this thread's first column
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int r = rb + RSTEP * i;
+                float d[4] = {rz[i].x, rz[i].y, rz[i].z, rz[i].w};
+                const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (hasbn) d[j] = cg_dy(coefS, Cs, chb + j, d[j], yv[j]);
+                    d[j] = ok[i] ? d[j] : 0.f;
+                }
+                As[(4 * kq + 0) * LDA + r] = d[0]; As[(4 * kq + 1) * LDA + r] = d[1];
+                As[(4 * kq + 2) * LDA + r] = d[2]; As[(4 * kq + 3) * LDA + r] = d[3];
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int f = gt + TG * i;
+                sts4(Bs + (f >> 4) * LDN + 4 * (f & 15), rw[i]);
+            }
+        }
+        __syncthreads();
+        if (c + G < nchunk) CGK_DGRAD_LOAD(c + G);
+        if (act) mma_chunk<1, 1, LDA, LDN>(As, Bs, wm * 32, wn * 32, acc);
+        __syncthreads();
+    }
+    float *red = lds;                                   // [G][TMB][64]
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg)
+        red[(g * TMB + wm * 32 + acc_row(reg, lh)) * 64 + wn * 32 + l31] = acc[0][0][reg];
+    __syncthreads();
+    const int ecq = tid & 15;
+    const int col = c0 + 4 * ecq;
+    v4f ps = zero4(), pt = zero4(), pm = zero4(), pr = zero4();
+    if (bnsrc) {
+        ps = ldg4(bnsrc + col); pt = ldg4(bnsrc + C + col);
+        pm = ldg4(bnsrc + 2 * C + col); pr = ldg4(bnsrc + 3 * C + col);
+    }
+    v4f cs1 = zero4(), cs2 = zero4();
+    for (int er = tid >> 4; er < TMB; er += NTHR / 16) {
+        const int row = row0 + er;
+        if (row >= Rs) continue;
+        v4f gsum = zero4();
+#pragma unroll
+        for (int q = 0; q < G; ++q) gsum += *(const v4f *)(red + (q * TMB + er) * 64 + 4 * ecq);
+        const int64_t o = (int64_t)row * C + col;
+        v4f xh = zero4();
+        if (bnsrc) {
+            const v4f yv = ldg4(ysrc + o);
+            gsum.x = fmaf(ps.x, yv.x, pt.x) > 0.f ? gsum.x : 0.f; gsum.y = fmaf(ps.y, yv.y, pt.y) > 0.f ? gsum.y : 0.f;
+            gsum.z = fmaf(ps.z, yv.z, pt.z) > 0.f ? gsum.z : 0.f; gsum.w = fmaf(ps.w, yv.w, pt.w) > 0.f ? gsum.w : 0.f;
+            xh = (yv - pm) * pr;
+        }
+        if (accumulate) gsum += ldg4(outp + o);
+        sts4(outp + o, gsum);
+        cs1 += gsum;
+        cs2 += gsum * xh;
+    }
+    if (!bstat_src) return;
+    float pv[8] = {cs1.x, cs1.y, cs1.z, cs1.w, cs2.x, cs2.y, cs2.z, cs2.w};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        pv[q] += __shfl_xor(pv[q], 16, 64);
+        pv[q] += __shfl_xor(pv[q], 32, 64);
+    }
+    __syncthreads();
+    float *st = lds;                                    // [NTHR/64 waves][64 cols][2]
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            st[((tid >> 6) * 64 + 4 * ecq + j) * 2] = pv[j];
+            st[((tid >> 6) * 64 + 4 * ecq + j) * 2 + 1] = pv[4 + j];
+        }
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int c = tid & 63, w = tid >> 6;
+        double v = 0.0;
+#pragma unroll
+        for (int r = 0; r < NTHR / 64; ++r) v += (double)st[(r * 64 + c) * 2 + w];
+        atomic_add_f64(&bstat_src[w * C + c0 + c], v);
+    }
+}
+
+// dWp[n][kk] = sum_r dy[r][n] * A[r][kk]; tile 64 (n) x 64 (kk); the workgroup owns rows [rbeg, rend) of one split and
+// its two 256-thread halves take alternate KC-row chunks (summed through LDS at the end).
+__device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float *smem)
+{
+    const CgLayer &L = a.lay;
+    const int tid = threadIdx.x, h = tid >> 8, gt = tid & 255;
+    const int lane = tid & 63, wave = gt >> 6;
+    const int l31 = lane & 31, lh = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    float *As = smem + h * (2 * KC * LDN), *Bs = As + KC * LDN;
+    const int bx = wid % a.w_ns, byz = wid / a.w_ns, by = byz % a.w_ny, bz = byz / a.w_ny;
+    const int R = L.B * L.Lout, Cs = L.Cs;
+    const int rbeg = bx * a.rows, rend = min(R, rbeg + a.rows);
+    const int n0 = by * 64, kk0 = bz * 64;
+    int sg, tap, k0, so;
+    cg_locate(L, kk0, sg, tap, k0, so);                   // kk0 is workgroup-uniform
+    sg = __builtin_amdgcn_readfirstlane(sg);
+    const float *Sx = SEL3(sg, opaque_s(L.seg[0].x), opaque_s(L.seg[1].x), opaque_s(L.seg[2].x));
+    const float *Sbn = SEL3(sg, opaque_s((const float *)L.seg[0].bn), opaque_s((const float *)L.seg[1].bn),
+                            opaque_s((const float *)L.seg[2].bn));
+    const int SC = SEL3(sg, opaque_s(L.seg[0].C), opaque_s(L.seg[1].C), opaque_s(L.seg[2].C));
+    const int Sty = SEL3(sg, opaque_s(L.seg[0].type), opaque_s(L.seg[1].type), opaque_s(L.seg[2].type));
+    const int SLs = SEL3(sg, opaque_s(L.seg[0].Lsrc), opaque_s(L.seg[1].Lsrc), opaque_s(L.seg[2].Lsrc));
+    const int cq = gt & 15, rr0 = gt >> 4;                // column quad, first row (rows rr0, rr0+16)
+    // per-thread constants of its 4 columns: BN-backward coefficients of dy, BN scale/shift of the A operand
+    const bool hasbn = a.cb.bstat != nullptr;
+    float cf[5][4], as[4], at[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ch = (n0 + 4 * cq + j) % Cs;
+        float c5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (hasbn) cg_bnbwd_coef(a.cb, Cs, ch, c5, false);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) cf[q][j] = c5[q];
+        as[j] = Sbn ? Sbn[k0 + 4 * cq + j] : 1.f;
+        at[j] = Sbn ? Sbn[SC + k0 + 4 * cq + j] : 0.f;
+    }
+    f32x16 acc[1][1];
+    acc_zero<1, 1>(acc);
+    v4f rz[2], ry[2], rx[2];
+    bool ok[2];
+    const int xC = SC, xLs = SLs, xlm = Sty ? 0 : 1;
+    const int nch = (rend - rbeg + KC - 1) / KC, nit = (nch + 1) / 2;
+    // (frustum, position) of this thread's two rows, advanced by 2*KC per chunk instead of divided out of the row index
+    int wb[2], wl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int r = rbeg + h * KC + rr0 + 16 * i; wb[i] = r / L.Lout; wl[i] = r % L.Lout; }
+    const int bend = (rend - 1) / L.Lout, lend = (rend - 1) % L.Lout;
+#define CG_WGRAD_LOAD(rr)                                                                                             \
+    {                                                                                                                 \
+        const int r0_ = (rr);                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                               \
+            const bool in = r0_ + rr0 + 16 * i < rend;      /* clamped: unconditional loads, masked at store */       \
+            const int row = in ? r0_ + rr0 + 16 * i : rend - 1;                                                       \
+            const int64_t o = (int64_t)row * L.Cout + n0 + 4 * cq;                                                    \
+            rz[i] = ldg4(a.dz + o);                                                                                   \
+            ry[i] = ldg4((hasbn ? L.y : a.dz) + o);                                                                   \
+            rx[i] = cg_load_raw(L, Sx, xC, xLs, xlm, tap, k0 + 4 * cq, in ? wb[i] : bend, in ? wl[i] : lend, true,    \
+                                ok[i]);                                                                               \
+            wl[i] += 2 * KC;                                                                                          \
+            while (wl[i] >= L.Lout) { wl[i] -= L.Lout; wb[i] += 1; }                                                  \
+        }                                                                                                             \
+    }
+    if (h < nch) CG_WGRAD_LOAD(rbeg + h * KC);
+    for (int it = 0; it < nit; ++it) {
+        const int c = 2 * it + h;
+        const bool act = c < nch;
+        const int r0 = rbeg + c * KC;
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float d[4] = {rz[i].x, rz[i].y, rz[i].z, rz[i].w};
+                const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
+                const bool live = (r0 + rr0 + 16 * i) < rend;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (hasbn) {
+                        const float xh = (yv[j] - cf[1][j]) * cf[2][j];
+                        d[j] = cf[0][j] * (d[j] - fmaf(xh, cf[4][j], cf[3][j]));
+                    }
+                    d[j] = live ? d[j] : 0.f;
+                }
+                v4f dv = {d[0], d[1], d[2], d[3]};
+                sts4(As + (rr0 + 16 * i) * LDN + 4 * cq, dv);
+                v4f av = {cg_act(as[0], rx[i].x, at[0], ok[i] && live), cg_act(as[1], rx[i].y, at[1], ok[i] && live),
+                          cg_act(as[2], rx[i].z, at[2], ok[i] && live), cg_act(as[3], rx[i].w, at[3], ok[i] && live)};
+                sts4(Bs + (rr0 + 16 * i) * LDN + 4 * cq, av);
+            }
+        }
+        __syncthreads();
+        if (c + 2 < nch) CG_WGRAD_LOAD(r0 + 2 * KC);
+        if (act) mma_chunk<1, 1, LDN, LDN>(As, Bs, wm * 32, wn * 32, acc);
+        __syncthreads();
+    }
+    float *red = smem;                                  // [64][64]: the second half's accumulators
+    if (h == 1) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) red[(wm * 32 + acc_row(reg, lh)) * 64 + wn * 32 + l31] = acc[0][0][reg];
+    }
+    __syncthreads();
+    if (h == 0) {
+        float *out = a.partial + (int64_t)bx * L.Cout * L.Ktot;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int rr = wm * 32 + acc_row(reg, lh), cc = wn * 32 + l31;
+            out[(int64_t)(n0 + rr) * L.Ktot + kk0 + cc] = acc[0][0][reg] + red[rr * 64 + cc];
+        }
+    }
+}
+
+// dW (torch layout) = sum of the split partials (fixed order); padding columns/rows are dropped.  64 consecutive
+// packed elements x 8 split groups per workgroup: a few independent loads per thread, then a group sum through LDS.
+#define CG_RG (CGB_T / 64)
+__device__ __forceinline__ void cg_reduce_body(const CgReduce &q, int rid, float *smem)
+{
+    float (*sh)[64] = (float (*)[64])smem;              // [CG_RG][64]
+    const CgPack &p = q.pk;
     const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
-    const int64_t e = (int64_t)blockIdx.x * 64 + x;             // N * Ktot is a multiple of 64
+    const int64_t e = (int64_t)rid * 64 + x;                    // N * Ktot is a multiple of 64
     const int64_t nelem = (int64_t)p.N * p.Ktot;
     float s0 = 0.f, s1 = 0.f;
     int sp = y;
-    for (; sp + CG_RG < nsplit; sp += 2 * CG_RG) {
-        s0 += partial[(int64_t)sp * nelem + e];
-        s1 += partial[(int64_t)(sp + CG_RG) * nelem + e];
+    for (; sp + CG_RG < q.nsplit; sp += 2 * CG_RG) {
+        s0 += q.partial[(int64_t)sp * nelem + e];
+        s1 += q.partial[(int64_t)(sp + CG_RG) * nelem + e];
     }
-    if (sp < nsplit) s0 += partial[(int64_t)sp * nelem + e];
+    if (sp < q.nsplit) s0 += q.partial[(int64_t)sp * nelem + e];
     sh[y][x] = s0 + s1;
     __syncthreads();
     if (y != 0) return;
     const int n = (int)(e / p.Ktot), kk = (int)(e % p.Ktot);
-    if (n >= nrow_real) return;
+    if (n >= q.nrow_real) return;
     const int64_t o = cg_torch_index(p, n, kk);
     if (o < 0) return;
     float t = 0.f;
 #pragma unroll
-    for (int q = 0; q < CG_RG; ++q) t += sh[q][x];
-    dW[o] = t;
+    for (int g = 0; g < CG_RG; ++g) t += sh[g][x];
+    q.dW[o] = t;
+}
+
+__global__ __launch_bounds__(CGB_T) void cg_bwd_step_kernel(CgBwdStep a)
+{
+    __shared__ __attribute__((aligned(16))) float smem[CGB_SMEM];
+    const int bid = blockIdx.x;
+    if (bid >= a.r_blk0) { cg_reduce_body(a.red, bid - a.r_blk0, smem); return; }
+    if (bid >= a.w_blk0) { cg_wgrad_body(a, bid - a.w_blk0, smem); return; }
+    const int role = (a.ndg > 2 && bid >= a.dg2.blk0) ? 2 : ((a.ndg > 1 && bid >= a.dg1.blk0) ? 1 : 0);
+#define DGF(f) SEL3(role, opaque_s(a.dg0.f), opaque_s(a.dg1.f), opaque_s(a.dg2.f))
+    const int t = bid - DGF(blk0), tx = DGF(tx);
+    cg_dgrad_body(a.lay, a.cb, a.dz, a.lay.y, DGF(sg), DGF(segoff), DGF(ysrc), DGF(bnsrc), DGF(out), DGF(accumulate),
+                  DGF(bstat_src), t % tx, t / tx, bid == 0, smem);
+#undef DGF
 }
 
 // dbias[n] = sum_r dlogits[r][n] (heads)
@@ -730,10 +784,10 @@ struct CnPlan {
 
 static int conv_len(int L, int k, int s, int p) { return (L + 2 * p - k) / s + 1; }
 
-// rows per wgrad split (multiple of 32): ~1024 workgroups, >= 64 rows each
+// rows per wgrad split (multiple of 32): ~768 workgroups, >= 64 rows each
 static int pick_wrows(int R, int out_tiles)
 {
-    int ns = 1024 / (out_tiles > 0 ? out_tiles : 1);
+    int ns = 768 / (out_tiles > 0 ? out_tiles : 1);
     if (ns > (R + 63) / 64) ns = (R + 63) / 64;
     if (ns < 1) ns = 1;
     int rows = (R + ns - 1) / ns;
@@ -809,6 +863,8 @@ static void cn_offsets(const fcn_cn_desc *d, const CnPlan &P, CnOffsets &O)
     }
 }
 
+static int64_t cn_partial_elems(const fcn_cn_desc *d, const CnPlan &P);
+
 extern "C" int fcn_convnet_sizes(const fcn_cn_desc *d, int64_t *out6)
 {
     if (!d || !out6) return FCN_E_BADARG;
@@ -816,15 +872,7 @@ extern "C" int fcn_convnet_sizes(const fcn_cn_desc *d, int64_t *out6)
     FCN_TRY(cn_make_plan(d, P));
     CnOffsets O;
     cn_offsets(d, P, O);
-    int64_t pmax = 0;
-    for (int l = 0; l < CN_NLAYER; ++l) {
-        const int64_t R = (int64_t)d->B * P.Lout[l];
-        {   // wgrad row splits
-            const int rows = pick_wrows((int)R, (P.N[l] / 64) * (P.Ktot[l] / 64));
-            const int64_t v = ((R + rows - 1) / rows) * P.N[l] * P.Ktot[l];
-            if (v > pmax) pmax = v;
-        }
-    }
+    const int64_t pmax = 2 * cn_partial_elems(d, P);   // two buffers: a step's reduce runs beside the next step's wgrad
     out6[0] = O.y[CN_NLAYER];      // floats: y (and dz) of all layers
     out6[1] = O.wp[CN_NLAYER];     // floats: packed weights
     out6[2] = O.bn[CN_NLAYER];     // floats: bn scale/shift/mean/rstd
@@ -925,6 +973,26 @@ extern "C" int fcn_convnet_forward(const fcn_cn_desc *d, const fcn_cn_params *p,
     return 0;
 }
 
+// rows per wgrad split for the fused step kernel and the resulting split count
+static void cn_wgrad_split(int R, int out_tiles, int &rows, int &ns)
+{
+    rows = pick_wrows(R, out_tiles);
+    if (rows < 2 * KC) rows = 2 * KC;                   // both halves of a workgroup get a chunk
+    ns = (R + rows - 1) / rows;
+}
+
+static int64_t cn_partial_elems(const fcn_cn_desc *d, const CnPlan &P)
+{
+    int64_t pmax = 0;
+    for (int l = 0; l < CN_NLAYER; ++l) {
+        int rows, ns;
+        cn_wgrad_split(d->B * P.Lout[l], (P.N[l] / 64) * (P.Ktot[l] / 64), rows, ns);
+        const int64_t v = (int64_t)ns * P.N[l] * P.Ktot[l];
+        if (v > pmax) pmax = v;
+    }
+    return pmax;
+}
+
 extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
                                     const float *const feats[4], const float *one_hot, const float *dlogits,
                                     float *const dfeats[4], float *const dW[CN_NLAYER], float *const dgamma[CN_NLAYER],
@@ -934,20 +1002,15 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
     if (!d || !p || !ws || !feats || !dlogits || !dfeats || !dW || !dgamma || !dbeta || !dbias) return FCN_E_BADARG;
     if (!d->training) return FCN_E_BADARG;
     if (!ws->y || !ws->dz || !ws->wp || !ws->bn || !ws->bstat || !ws->coef || !ws->partial) return FCN_E_BADARG;
-
+    (void)stream2; (void)events;        // kept in the ABI; the weight gradients now ride in the step launches
     hipStream_t st = (hipStream_t)stream;
-    // The data-gradient chain (finalize -> dgrad -> next layer) is a latency-bound sequence of small launches; the
-    // weight gradients only hang off it.  With a second stream + CN_NLAYER+1 caller-owned events they run beside the
-    // chain instead of inside it: main records events[l] once layer l's dz and BN coefficients are final, the side
-    // stream waits for it, runs wgrad(l) + reduce(l), and main joins on events[CN_NLAYER] at the end.
-    const bool two = stream2 != nullptr && events != nullptr;
-    hipStream_t sw = two ? (hipStream_t)stream2 : st;
     CnPlan P;
     FCN_TRY(cn_make_plan(d, P));
     CnOffsets O;
     cn_offsets(d, P, O);
     hipError_t e = hipMemsetAsync(ws->bstat, 0, sizeof(double) * (size_t)O.st[CN_NLAYER], st);
     if (e != hipSuccess) return (int)e;
+    const int64_t phalf = cn_partial_elems(d, P);       // ws->partial holds two of these (steps alternate)
 
     // consumers still to come for each producer layer (to know which dgrad is the last one)
     int pending[CN_NLAYER];
@@ -959,76 +1022,79 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
     for (int l = 0; l < CN_NLAYER; ++l) seen[l] = 0;
 
     const int order[CN_NLAYER] = {13, 12, 9, 8, 7, 11, 6, 5, 4, 10, 3, 2, 1, 0};
-    for (int q = 0; q < CN_NLAYER; ++q) {
-        const int l = order[q];
-        CgLayer L;
-        cn_fill_layer(d, p, P, O, ws, feats, one_hot, l, L);
-        const int R = d->B * P.Lout[l];
-        const float *dz = (l == 13) ? dlogits : ws->dz + O.y[l];
-        CgBnBwd cb;
-        cb.bstat = nullptr; cb.gamma = nullptr; cb.bn = nullptr; cb.M = 1.0; cb.dgamma = nullptr; cb.dbeta = nullptr;
-        if (l == 13) {
-            L.y = nullptr;
-            hipLaunchKernelGGL(cg_colsum_kernel, dim3(64), dim3(256), 0, st, dlogits, R, 64, P.nrow_real[13], dbias);
-            FCN_CHECK_LAUNCH();
-        } else {
-            cb.bstat = ws->bstat + O.st[l]; cb.gamma = p->gamma[l]; cb.bn = ws->bn + O.bn[l];
-            cb.M = (double)R * (P.dk[l] > 0 ? P.dk[l] : 1);
+    CgReduce prev;                      // the reduce that rides in the next launch
+    int prev_blocks = 0;
+    for (int q = 0; q <= CN_NLAYER; ++q) {
+        CgBwdStep a;
+        a.ndg = 0; a.w_ns = 0; a.w_ny = 1; a.rows = 2 * KC; a.partial = nullptr; a.dz = nullptr;
+        a.cb.bstat = nullptr; a.cb.gamma = nullptr; a.cb.bn = nullptr; a.cb.M = 1.0; a.cb.dgamma = nullptr; a.cb.dbeta = nullptr;
+        CgDgSeg *dgs[3] = {&a.dg0, &a.dg1, &a.dg2};
+        for (int s = 0; s < 3; ++s) {
+            dgs[s]->sg = 0; dgs[s]->segoff = 0; dgs[s]->ysrc = dgs[s]->bnsrc = nullptr; dgs[s]->out = nullptr;
+            dgs[s]->accumulate = 0; dgs[s]->bstat_src = nullptr; dgs[s]->tx = 1; dgs[s]->blk0 = 0;
         }
-        // ---- weight gradient (side stream when available)
-        if (two) {
-            e = hipEventRecord((hipEvent_t)events[l], st);
-            if (e != hipSuccess) return (int)e;
-            e = hipStreamWaitEvent(sw, (hipEvent_t)events[l], 0);
-            if (e != hipSuccess) return (int)e;
-        }
-        {
-            CgWgrad w;
-            w.lay = L; w.dz = dz; w.cb = cb; w.partial = ws->partial;
-            w.rows = pick_wrows(R, (P.N[l] / 64) * (P.Ktot[l] / 64));
-            const int nsplit = (R + w.rows - 1) / w.rows;
-            hipLaunchKernelGGL(cg_wgrad_kernel, dim3(nsplit, P.N[l] / 64, P.Ktot[l] / 64), dim3(CG_T), 0, sw, w);
-            FCN_CHECK_LAUNCH();
-            CgPack pk;
-            cn_fill_pack(d, P, l, pk);
-            const int64_t ne = (int64_t)P.N[l] * P.Ktot[l];
-            hipLaunchKernelGGL(cg_wgrad_reduce_kernel, dim3((unsigned)(ne / 64)), dim3(64 * CG_RG), 0, sw, ws->partial,
-                               nsplit, pk, P.nrow_real[l], dW[l]);
-            FCN_CHECK_LAUNCH();
-        }
-        // ---- data gradients into every non-constant source
-        int segoff = 0;
-        bool exported = (l == 13);
-        for (int s = 0; s < P.nseg[l]; ++s) {
-            const int src = P.src[l][s];
-            if (src != -9) {
-                CgDgrad g;
-                g.lay = L; g.sg = s; g.segoff = segoff; g.dzc = dz; g.yc = L.y; g.cb = cb;
-                if (!exported) { g.cb.dgamma = dgamma[l]; g.cb.dbeta = dbeta[l]; exported = true; }
-                if (src >= 0) {
-                    g.ysrc = ws->y + O.y[src]; g.bnsrc = ws->bn + O.bn[src]; g.out = ws->dz + O.y[src];
-                    g.accumulate = seen[src] > 0 ? 1 : 0;
-                    seen[src] += 1;
-                    g.bstat_src = (seen[src] == pending[src]) ? ws->bstat + O.st[src] : nullptr;
-                } else {
-                    g.ysrc = nullptr; g.bnsrc = nullptr; g.out = dfeats[-src - 1]; g.accumulate = 0; g.bstat_src = nullptr;
-                }
-                const int Rs = d->B * L.seg[s].Lsrc;
-                const int ntl = P.C[l][s] / 64;
-                if (((Rs + 63) / 64) * ntl >= 200)
-                    hipLaunchKernelGGL((cgk_dgrad_kernel<2, 4>), dim3((Rs + 63) / 64, ntl), dim3(1024), 0, st, g);
-                else
-                    hipLaunchKernelGGL((cgk_dgrad_kernel<1, 4>), dim3((Rs + 31) / 32, ntl), dim3(512), 0, st, g);
+        int nblk = 0;
+        CgReduce cur;
+        int cur_blocks = 0;
+        if (q < CN_NLAYER) {
+            const int l = order[q];
+            cn_fill_layer(d, p, P, O, ws, feats, one_hot, l, a.lay);
+            const int R = d->B * P.Lout[l];
+            a.dz = (l == 13) ? dlogits : ws->dz + O.y[l];
+            if (l == 13) {
+                a.lay.y = nullptr;
+                hipLaunchKernelGGL(cg_colsum_kernel, dim3(64), dim3(256), 0, st, dlogits, R, 64, P.nrow_real[13], dbias);
                 FCN_CHECK_LAUNCH();
+            } else {
+                a.cb.bstat = ws->bstat + O.st[l]; a.cb.gamma = p->gamma[l]; a.cb.bn = ws->bn + O.bn[l];
+                a.cb.M = (double)R * (P.dk[l] > 0 ? P.dk[l] : 1);
+                a.cb.dgamma = dgamma[l]; a.cb.dbeta = dbeta[l];      // exported by workgroup 0 (a data-gradient tile)
             }
-            segoff += P.KT[l] * P.C[l][s];
+            // ---- data gradients into every non-constant source
+            int segoff = 0;
+            for (int s = 0; s < P.nseg[l]; ++s) {
+                const int src = P.src[l][s];
+                if (src != -9) {
+                    CgDgSeg &g = *dgs[a.ndg];
+                    g.sg = s; g.segoff = segoff;
+                    if (src >= 0) {
+                        g.ysrc = ws->y + O.y[src]; g.bnsrc = ws->bn + O.bn[src]; g.out = ws->dz + O.y[src];
+                        g.accumulate = seen[src] > 0 ? 1 : 0;
+                        seen[src] += 1;
+                        g.bstat_src = (seen[src] == pending[src]) ? ws->bstat + O.st[src] : nullptr;
+                    } else {
+                        g.out = dfeats[-src - 1];
+                    }
+                    const int Rs = d->B * a.lay.seg[s].Lsrc;
+                    g.tx = (Rs + 31) / 32;
+                    g.blk0 = nblk;
+                    nblk += g.tx * (P.C[l][s] / 64);
+                    a.ndg += 1;
+                }
+                segoff += P.KT[l] * P.C[l][s];
+            }
+            // ---- weight gradient partials of this layer
+            a.w_blk0 = nblk;
+            a.partial = ws->partial + (q & 1) * phalf;
+            a.w_ny = P.N[l] / 64;
+            cn_wgrad_split(R, a.w_ny * (P.Ktot[l] / 64), a.rows, a.w_ns);
+            nblk += a.w_ns * a.w_ny * (P.Ktot[l] / 64);
+            cur.partial = a.partial; cur.nsplit = a.w_ns; cn_fill_pack(d, P, l, cur.pk); cur.nrow_real = P.nrow_real[l];
+            cur.dW = dW[l];
+            cur_blocks = (int)(((int64_t)P.N[l] * P.Ktot[l]) / 64);
+        } else {
+            cn_fill_layer(d, p, P, O, ws, feats, one_hot, 0, a.lay);      // unused by the reduce-only launch
+            a.w_blk0 = 0;
         }
-    }
-    if (two) {
-        e = hipEventRecord((hipEvent_t)events[CN_NLAYER], sw);
-        if (e != hipSuccess) return (int)e;
-        e = hipStreamWaitEvent(st, (hipEvent_t)events[CN_NLAYER], 0);
-        if (e != hipSuccess) return (int)e;
+        // ---- the previous step's partials are complete: reduce them beside this step's work
+        a.r_blk0 = nblk;
+        if (prev_blocks > 0) { a.red = prev; nblk += prev_blocks; }
+        else { a.red.partial = nullptr; a.red.nsplit = 0; a.red.nrow_real = 0; a.red.dW = nullptr; cn_fill_pack(d, P, 0, a.red.pk); }
+        if (nblk > 0) {
+            hipLaunchKernelGGL(cg_bwd_step_kernel, dim3(nblk), dim3(CGB_T), 0, st, a);
+            FCN_CHECK_LAUNCH();
+        }
+        prev = cur; prev_blocks = cur_blocks;
     }
     return 0;
 }
