@@ -161,21 +161,18 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    from frustum_convnet_amd.train_state import FlatTrainState
     model = build_model(dev)
-    params = [p for p in model.parameters()]
     if world > 1:
         fdist.broadcast_state(model, 0)
-    reducer = fdist.CoalescedGradAllReducer(params, world)
-    opt = None
-    if not a.no_optim:
-        # reference optimiser: Adam(lr 1e-3, weight_decay 1e-4), train/train_net_det.py:321-339; one fused
-        # multi-tensor kernel over the 152 parameter tensors, capturable into the step's hipGraph
-        opt = torch.optim.Adam(params, lr=1e-3, weight_decay=1e-4, capturable=True, fused=True)
+    # reference optimiser: Adam(lr 1e-3, weight_decay 1e-4), train/train_net_det.py:321-339.  Parameters, gradients and
+    # moments are flat buffers: the backward kernels write the gradients in place, the exchange is one all-reduce and the
+    # step one streaming kernel (capturable: step counter and hyper-parameters live on the device).
+    state = FlatTrainState(model, lr=1e-3, weight_decay=1e-4, world=world)
+    optim = not a.no_optim
     data = synth.to_torch(synth.make_batch(a.batch, a.npoint, seed=1234 + rank, variant="car", tilt=(0.01, 0.05)), dev)
 
     def fwd_bwd():
-        for p in params:
-            p.grad = None                  # fresh gradients: autograd hands its buffers over, no accumulate kernels
         losses, _ = model(data)
         losses["total_loss"].backward()
         return losses["total_loss"]
@@ -187,9 +184,9 @@ def main():
     with torch.cuda.stream(side):
         for _ in range(3):                     # allocator / workspace / MIOpen find warm-up, outside capture
             loss = fwd_bwd()
-            reducer.allreduce()
-            if opt is not None:
-                opt.step()
+            state.allreduce()
+            if optim:
+                state.adam_step()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     if use_graph:
@@ -197,8 +194,8 @@ def main():
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 loss = fwd_bwd()
-                if world == 1 and opt is not None:
-                    opt.step()
+                if world == 1 and optim:
+                    state.adam_step()
         except Exception as e:  # noqa
             if rank == 0:
                 print("[bench] hipGraph capture failed (%s: %s); falling back to eager launches" %
@@ -210,14 +207,14 @@ def main():
         if graph is not None:
             graph.replay()
             if world > 1:
-                reducer.allreduce()
-                if opt is not None:
-                    opt.step()
+                state.allreduce()
+                if optim:
+                    state.adam_step()
         else:
             fwd_bwd()
-            reducer.allreduce()
-            if opt is not None:
-                opt.step()
+            state.allreduce()
+            if optim:
+                state.adam_step()
 
     for _ in range(a.warmup):
         step()

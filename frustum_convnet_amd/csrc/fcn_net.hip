@@ -408,6 +408,7 @@ struct CgReduce {
     CgPack pk;
     int nrow_real;
     float *dW;
+    int gr;                    // split groups per workgroup (1, 2, 4, 8)
 };
 
 struct CgBwdStep {
@@ -711,33 +712,36 @@ __device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float
     }
 }
 
-// dW (torch layout) = sum of the split partials (fixed order); padding columns/rows are dropped.  64 consecutive
-// packed elements x 8 split groups per workgroup: a few independent loads per thread, then a group sum through LDS.
-#define CG_RG (CGB_T / 64)
+// dW (torch layout) = sum of the split partials (fixed order); padding columns/rows are dropped.  The workgroup covers
+// CGB_T / gr consecutive packed elements with gr split groups (gr = 1, 2, 4 or 8, chosen on the host from the split
+// count): big layers have few splits and many elements (one thread per element), small layers the opposite (a few
+// independent loads per thread, then a group sum through LDS).
 __device__ __forceinline__ void cg_reduce_body(const CgReduce &q, int rid, float *smem)
 {
-    float (*sh)[64] = (float (*)[64])smem;              // [CG_RG][64]
     const CgPack &p = q.pk;
-    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
-    const int64_t e = (int64_t)rid * 64 + x;                    // N * Ktot is a multiple of 64
+    const int gr = q.gr, per = CGB_T / gr;
+    const int x = threadIdx.x % per, y = threadIdx.x / per;
+    const int64_t e = (int64_t)rid * per + x;                   // N * Ktot is a multiple of 64 * 8
     const int64_t nelem = (int64_t)p.N * p.Ktot;
     float s0 = 0.f, s1 = 0.f;
     int sp = y;
-    for (; sp + CG_RG < q.nsplit; sp += 2 * CG_RG) {
+    for (; sp + gr < q.nsplit; sp += 2 * gr) {
         s0 += q.partial[(int64_t)sp * nelem + e];
-        s1 += q.partial[(int64_t)(sp + CG_RG) * nelem + e];
+        s1 += q.partial[(int64_t)(sp + gr) * nelem + e];
     }
     if (sp < q.nsplit) s0 += q.partial[(int64_t)sp * nelem + e];
-    sh[y][x] = s0 + s1;
-    __syncthreads();
-    if (y != 0) return;
+    float t = s0 + s1;
+    if (gr > 1) {
+        smem[y * per + x] = t;
+        __syncthreads();
+        if (y != 0) return;
+        t = 0.f;
+        for (int g = 0; g < gr; ++g) t += smem[g * per + x];
+    }
     const int n = (int)(e / p.Ktot), kk = (int)(e % p.Ktot);
     if (n >= q.nrow_real) return;
     const int64_t o = cg_torch_index(p, n, kk);
     if (o < 0) return;
-    float t = 0.f;
-#pragma unroll
-    for (int g = 0; g < CG_RG; ++g) t += sh[g][x];
     q.dW[o] = t;
 }
 
@@ -1023,6 +1027,7 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
 
     const int order[CN_NLAYER] = {13, 12, 9, 8, 7, 11, 6, 5, 4, 10, 3, 2, 1, 0};
     CgReduce prev;                      // the reduce that rides in the next launch
+    prev.partial = nullptr; prev.nsplit = 0; prev.nrow_real = 0; prev.dW = nullptr; prev.gr = 1; cn_fill_pack(d, P, 0, prev.pk);
     int prev_blocks = 0;
     for (int q = 0; q <= CN_NLAYER; ++q) {
         CgBwdStep a;
@@ -1034,7 +1039,7 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
             dgs[s]->accumulate = 0; dgs[s]->bstat_src = nullptr; dgs[s]->tx = 1; dgs[s]->blk0 = 0;
         }
         int nblk = 0;
-        CgReduce cur;
+        CgReduce cur = prev;
         int cur_blocks = 0;
         if (q < CN_NLAYER) {
             const int l = order[q];
@@ -1081,7 +1086,8 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
             nblk += a.w_ns * a.w_ny * (P.Ktot[l] / 64);
             cur.partial = a.partial; cur.nsplit = a.w_ns; cn_fill_pack(d, P, l, cur.pk); cur.nrow_real = P.nrow_real[l];
             cur.dW = dW[l];
-            cur_blocks = (int)(((int64_t)P.N[l] * P.Ktot[l]) / 64);
+            cur.gr = a.w_ns >= 32 ? 8 : (a.w_ns >= 16 ? 4 : (a.w_ns >= 8 ? 2 : 1));
+            cur_blocks = (int)(((int64_t)P.N[l] * P.Ktot[l]) / (CGB_T / cur.gr));
         } else {
             cn_fill_layer(d, p, P, O, ws, feats, one_hot, 0, a.lay);      // unused by the reduce-only launch
             a.w_blk0 = 0;
@@ -1089,7 +1095,7 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
         // ---- the previous step's partials are complete: reduce them beside this step's work
         a.r_blk0 = nblk;
         if (prev_blocks > 0) { a.red = prev; nblk += prev_blocks; }
-        else { a.red.partial = nullptr; a.red.nsplit = 0; a.red.nrow_real = 0; a.red.dW = nullptr; cn_fill_pack(d, P, 0, a.red.pk); }
+        else { a.red.partial = nullptr; a.red.nsplit = 0; a.red.nrow_real = 0; a.red.dW = nullptr; a.red.gr = 1; cn_fill_pack(d, P, 0, a.red.pk); }
         if (nblk > 0) {
             hipLaunchKernelGGL(cg_bwd_step_kernel, dim3(nblk), dim3(CGB_T), 0, st, a);
             FCN_CHECK_LAUNCH();

@@ -1,0 +1,79 @@
+// Adam over ONE flat fp32 buffer: the optimiser step of the reference's loop (train/train_net_det.py:321-339 builds
+// optim.Adam(lr, weight_decay); :131-133 calls it every iteration).  The 79 parameter tensors, their gradients and
+// both moments live in four contiguous 13.3 MB buffers, so the step is a single streaming kernel (4 reads + 3 writes
+// per element, HBM-bound) instead of a multi-tensor launch chain, and the same flat gradient is what one RCCL
+// all-reduce exchanges.  Arithmetic follows torch.optim.Adam (L2 weight decay folded into the gradient, lerp form of
+// the first moment, eps added after the bias-corrected sqrt).
+#include "fcn_common.h"
+#include "gemm_tile.h"
+
+struct AdamArgs {
+    float *p;
+    const float *g;
+    float *m, *v;
+    int64_t n;
+    const float *hyper;        // device: lr, beta1, beta2, eps, weight_decay, grad_scale
+    int64_t *step;             // device step counter (incremented by the last workgroup)
+    unsigned *ticket;          // device, zero between launches
+};
+
+#define ADAM_T 256
+#define ADAM_V 4               // float4 per thread per iteration
+
+// moments of one element / one 4-vector (T = float or v4f); the parameter update needs a per-lane sqrt and follows
+template <class T>
+__device__ __forceinline__ void adam_moments(T p, T g, T &m, T &v, float b1, float b2, float wd, float gs)
+{
+    g = wd * p + g * gs;
+    m = m + (g - m) * (1.f - b1);
+    v = v * b2 + (1.f - b2) * g * g;
+}
+
+__global__ __launch_bounds__(ADAM_T) void adam_kernel(AdamArgs a)
+{
+    const float lr = a.hyper[0], b1 = a.hyper[1], b2 = a.hyper[2], eps = a.hyper[3], wd = a.hyper[4], gs = a.hyper[5];
+    const double t = (double)(a.step[0] + 1);
+    const float bc1 = (float)(1.0 - pow((double)b1, t)), bc2 = (float)(1.0 - pow((double)b2, t));
+    const float lr_c = lr / bc1, rsq_bc2 = 1.f / sqrtf(bc2);
+    const int64_t n4 = a.n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * ADAM_T;
+    for (int64_t i = (int64_t)blockIdx.x * ADAM_T + threadIdx.x; i < n4; i += stride) {
+        v4f p = ldg4(a.p + 4 * i), g = ldg4(a.g + 4 * i), m = ldg4(a.m + 4 * i), v = ldg4(a.v + 4 * i);
+        adam_moments(p, g, m, v, b1, b2, wd, gs);
+        const v4f rt = {sqrtf(v.x), sqrtf(v.y), sqrtf(v.z), sqrtf(v.w)};
+        p = p - lr_c * (m / (rt * rsq_bc2 + eps));
+        sts4(a.p + 4 * i, p); sts4(a.m + 4 * i, m); sts4(a.v + 4 * i, v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {           // tail (n not a multiple of 4)
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        float p = a.p[i], m = a.m[i], v = a.v[i];
+        adam_moments(p, a.g[i], m, v, b1, b2, wd, gs);
+        p = p - lr_c * (m / (sqrtf(v) * rsq_bc2 + eps));
+        a.p[i] = p; a.m[i] = m; a.v[i] = v;
+    }
+    // every workgroup has read step[0] by the time it takes a ticket: the last one advances the counter
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned k = atomicAdd(a.ticket, 1u);
+        if (k == gridDim.x - 1) {
+            a.step[0] += 1;
+            a.ticket[0] = 0u;
+        }
+    }
+}
+
+extern "C" int fcn_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                                 const float *hyper6, int64_t *step, uint32_t *ticket, void *stream)
+{
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper6 || !step || !ticket || n <= 0) return FCN_E_BADARG;
+    if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return FCN_E_BADARG;
+    AdamArgs a;
+    a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n; a.hyper = hyper6; a.step = step; a.ticket = ticket;
+    int64_t blocks = ((n >> 2) + ADAM_T - 1) / ADAM_T;
+    if (blocks > 2048) blocks = 2048;                   // 8 workgroups per CU, grid-stride beyond
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(ADAM_T), 0, (hipStream_t)stream, a);
+    FCN_CHECK_LAUNCH();
+    return 0;
+}

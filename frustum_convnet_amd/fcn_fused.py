@@ -39,20 +39,6 @@ class CnWorkspace:
 class CnPool:
     def __init__(self):
         self.free = {}
-        self.side = {}
-
-    def side_stream(self, device):
-        """Second HIP stream + 15 events (caller-owned, handed to fcn_convnet_backward) per device."""
-        key = str(device)
-        if key not in self.side:
-            with torch.cuda.device(device):
-                st = torch.cuda.Stream(device=device)
-                evs = [torch.cuda.Event(enable_timing=False) for _ in range(15)]
-                for ev in evs:
-                    ev.record()                     # materialise the hipEvent_t handles
-                arr = (ctypes.c_void_p * 15)(*[ev.cuda_event for ev in evs])
-            self.side[key] = (st, evs, arr)
-        return self.side[key]
 
     def acquire(self, key, desc, device, need_grad):
         k = key + (bool(need_grad), str(device))
@@ -74,9 +60,10 @@ def _arr(ts, n=14):
 
 class _ConvNetFused(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pool, cfgt, bufs, one_hot, f1, f2, f3, f4, *pt):
+    def forward(ctx, pool, cfgt, bufs, one_hot, gdst, f1, f2, f3, f4, *pt):
         # pt: 13 conv weights, 13 gammas, 13 betas, cls_w, reg_w, cls_b, reg_b
         training, eps, momentum, need_grad = cfgt
+        ctx.gdst = gdst
         L = _native.lib()
         feats = [f.detach().contiguous() for f in (f1, f2, f3, f4)]
         B = feats[0].shape[0]
@@ -85,8 +72,13 @@ class _ConvNetFused(torch.autograd.Function):
         gs = [g.detach().contiguous() for g in pt[13:26]]
         bs = [b.detach().contiguous() for b in pt[26:39]]
         cls_w, reg_w, cls_b, reg_b = [t.detach() for t in pt[39:43]]
-        Wh = torch.cat([cls_w, reg_w], 0).contiguous()
-        bh = torch.cat([cls_b, reg_b], 0).contiguous()
+        # heads as one (2 + reg_out, 768) matrix: adjacent in memory under FlatTrainState (no copy), else concatenated
+        Wh = _adjacent(cls_w, reg_w)
+        if Wh is None:
+            Wh = torch.cat([cls_w, reg_w], 0).contiguous()
+        bh = _adjacent(cls_b, reg_b)
+        if bh is None:
+            bh = torch.cat([cls_b, reg_b], 0).contiguous()
         nvec = 0 if one_hot is None else one_hot.shape[1]
         oh = None if one_hot is None else one_hot.detach().contiguous().float()
         dev = feats[0].device
@@ -118,25 +110,52 @@ class _ConvNetFused(torch.autograd.Function):
         dev = dlogits.device
         dlogits = dlogits.contiguous().float()
         dfeats = [torch.empty_like(f) for f in feats]
-        dW = [torch.empty_like(w) for w in Ws] + [torch.empty_like(Wh)]
-        dg = [torch.empty_like(g) for g in gs]
-        db = [torch.empty_like(b) for b in bs]
-        dbh = torch.empty_like(bh)
+        # gradient destinations: flat-buffer views under FlatTrainState (written in place, autograd gets None)
+        gd = ctx.gdst
+        pick = lambda j, like: gd[j] if gd[j] is not None else torch.empty_like(like)
+        dWh = None if gd[39] is None or gd[40] is None else _adjacent(gd[39], gd[40])
+        dbh = None if gd[41] is None or gd[42] is None else _adjacent(gd[41], gd[42])
+        heads_direct = dWh is not None and dbh is not None
+        if not heads_direct:
+            dWh, dbh = torch.empty_like(Wh), torch.empty_like(bh)
+        dW = [pick(i, Ws[i]) for i in range(13)] + [dWh]
+        dg = [pick(13 + i, gs[i]) for i in range(13)]
+        db = [pick(26 + i, bs[i]) for i in range(13)]
         params = CnParams(_arr(Ws + [Wh]), _arr(gs), _arr(bs), _arr([]), _arr([]), _arr([]), bh.data_ptr())
         fp = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in feats])
         dfp = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in dfeats])
-        side, _evs, evarr = ctx.pool.side_stream(dev)
         with torch.cuda.device(dev):
             _native.check(L.fcn_convnet_backward(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(ws.c), fp,
                                                  None if oh is None else oh.data_ptr(), dlogits.data_ptr(), dfp,
                                                  _arr(dW), _arr(dg), _arr(db), dbh.data_ptr(),
-                                                 _native.current_stream(dev), ctypes.c_void_p(side.cuda_stream),
-                                                 evarr), "fcn_convnet_backward")
+                                                 _native.current_stream(dev), None, None),
+                          "fcn_convnet_backward")
         ctx.pool.release(ws)
         ctx.ws, ctx.live = None, False
         ncls = 2
-        return (None, None, None, None, dfeats[0], dfeats[1], dfeats[2], dfeats[3]) + tuple(dW[:13]) + tuple(dg) + \
-            tuple(db) + (dW[13][:ncls], dW[13][ncls:], dbh[:ncls], dbh[ncls:])
+        outs = list(dW[:13]) + dg + db
+        outs = [None if gd[j] is not None else t for j, t in enumerate(outs)]
+        if heads_direct:
+            hz = [None] * 4
+        else:
+            hz = [dW[13][:ncls], dW[13][ncls:], dbh[:ncls], dbh[ncls:]]
+            for j in range(4):
+                if gd[39 + j] is not None:           # flat views that are not adjacent: copy in, hand autograd nothing
+                    gd[39 + j].copy_(hz[j])
+                    hz[j] = None
+        return (None, None, None, None, None, dfeats[0], dfeats[1], dfeats[2], dfeats[3]) + tuple(outs) + tuple(hz)
+
+
+def _adjacent(a, b):
+    """One tensor over a and b when b starts where a ends in memory (rows of the same width), else None."""
+    if not (a.is_contiguous() and b.is_contiguous()) or a.shape[1:] != b.shape[1:]:
+        return None
+    if b.data_ptr() != a.data_ptr() + a.numel() * a.element_size():
+        return None
+    try:
+        return torch.as_strided(a, (a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), a.stride())
+    except RuntimeError:
+        return None
 
 
 def convnet_fused(pool, conv_net, cls_out, reg_out, feats, one_hot):
@@ -155,4 +174,5 @@ def convnet_fused(pool, conv_net, cls_out, reg_out, feats, one_hot):
     need_grad = bool(training) and torch.is_grad_enabled() and (
         any(t.requires_grad for t in pt) or any(f.requires_grad for f in feats))
     cfgt = (bool(training), float(bn0.eps), float(0.1 if bn0.momentum is None else bn0.momentum), need_grad)
-    return _ConvNetFused.apply(pool, cfgt, bufs, one_hot, feats[0], feats[1], feats[2], feats[3], *pt)
+    gdst = tuple(getattr(t, "_fcn_grad", None) for t in pt)
+    return _ConvNetFused.apply(pool, cfgt, bufs, one_hot, gdst, feats[0], feats[1], feats[2], feats[3], *pt)

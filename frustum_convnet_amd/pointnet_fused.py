@@ -124,8 +124,9 @@ class _PointNetPooled(torch.autograd.Function):
     never needs gradients w.r.t. the point cloud either: inputs do not require grad)."""
 
     @staticmethod
-    def forward(ctx, pool, cfgt, pc, ref, one_hot, bufs, W1, g1, b1, W2, g2, b2, W3, g3, b3):
+    def forward(ctx, pool, cfgt, pc, ref, one_hot, bufs, gdst, W1, g1, b1, W2, g2, b2, W3, g3, b3):
         plist = (W1, g1, b1, W2, g2, b2, W3, g3, b3)
+        ctx.gdst = gdst
         need_grad = bool(cfgt[5])     # decided by the caller: grad mode is always off inside Function.forward
         feat, idx, cnt, ws, desc, keep = _forward_impl(pool, cfgt, pc, ref, one_hot, bufs, plist, need_grad)
         ctx.pool = pool
@@ -148,9 +149,13 @@ class _PointNetPooled(torch.autograd.Function):
         dev = dfeat.device
         C1, C2, C3 = desc.C1, desc.C2, desc.C3
         dfeat = dfeat.contiguous().float()
-        dW = [torch.empty_like(w) for w in Wc]
-        dg = [torch.empty_like(g) for g in gs]
-        db = [torch.empty_like(b) for b in bs]
+        # gradient destinations: the parameter's flat-buffer view when the caller trains through FlatTrainState
+        # (written in place, autograd gets None), else a fresh tensor handed back to autograd
+        gd = ctx.gdst
+        pick = lambda j, like: gd[j] if gd[j] is not None else torch.empty_like(like)
+        dW = [pick(3 * i, Wc[i]) for i in range(3)]
+        dg = [pick(3 * i + 1, gs[i]) for i in range(3)]
+        db = [pick(3 * i + 2, bs[i]) for i in range(3)]
         params = _params_struct(Wc, gs, bs, [None] * 3, [None] * 3, [None] * 3)
         arr = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
         if ctx.pool.side_wgrad:
@@ -167,8 +172,9 @@ class _PointNetPooled(torch.autograd.Function):
         ctx.ws = None
         ctx.live = False
         s1, s2, s3 = ctx.shapes
-        return (None, None, None, None, None, None,
-                dW[0].view(s1), dg[0], db[0], dW[1].view(s2), dg[1], db[1], dW[2].view(s3), dg[2], db[2])
+        outs = [dW[0].view(s1), dg[0], db[0], dW[1].view(s2), dg[1], db[1], dW[2].view(s3), dg[2], db[2]]
+        outs = [None if gd[j] is not None else t for j, t in enumerate(outs)]
+        return (None, None, None, None, None, None, None) + tuple(outs)
 
 
 def pointnet_pooled(pool, dist, nsample, training, eps, momentum, pc, ref, one_hot, bufs, params, nlc=False):
@@ -179,7 +185,8 @@ def pointnet_pooled(pool, dist, nsample, training, eps, momentum, pc, ref, one_h
                            "(got a %s tensor); there is no CPU fallback" % pc.device)
     need_grad = bool(training) and torch.is_grad_enabled() and any(t.requires_grad for t in params)
     cfgt = (float(dist), int(nsample), bool(training), float(eps), float(momentum), need_grad, bool(nlc))
-    return _PointNetPooled.apply(pool, cfgt, pc, ref, one_hot, bufs, *params)
+    gdst = tuple(getattr(t, "_fcn_grad", None) for t in params)
+    return _PointNetPooled.apply(pool, cfgt, pc, ref, one_hot, bufs, gdst, *params)
 
 
 def dense_from_entries(pool, dist, nsample, training, eps, momentum, pc, ref, bufs, params):

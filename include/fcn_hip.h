@@ -165,8 +165,8 @@ int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn
                          const float *const feats[4], const float *one_hot, const float *dlogits,
                          float *const dfeats[4], float *const dW[14], float *const dgamma[14],
                          float *const dbeta[14], float *dbias, void *stream, void *stream2, void *const *events);
-/* stream2 / events may be NULL (single stream).  Otherwise: a second hipStream_t and 15 caller-owned hipEvent_t; the
- * weight-gradient launches run on stream2 beside the data-gradient chain and `stream` joins before returning work. */
+/* One launch per layer: its data-gradient tiles, its weight-gradient row splits and the reduce of the previous layer's
+ * splits are workgroup roles of the same kernel.  stream2 / events are ignored (kept for ABI stability; pass NULL). */
 
 /* ---------------------------------------------------------------------------------------------
  * Fused train-loss tail of PointNetDet.forward (models/det_base.py:373-476; focal loss models/common.py:217-232,
@@ -190,6 +190,16 @@ int fcn_det_loss_tail_rows(const float *logits, const int64_t *cls_label, const 
                            int num_heading_bin, int num_size_cluster,
                            float w_box, float w_corner, float w_headreg, float w_sizereg,
                            float *out16, float *dlogits, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimiser step of the training loop (train/train_net_det.py:321-339 optim.Adam(lr, weight_decay); :131-133
+ * optimizer.step()).  One streaming kernel over flat fp32 buffers of n elements (16-byte aligned), torch.optim.Adam
+ * arithmetic (L2 weight decay, bias correction from the step counter).  Everything the host may change between steps
+ * lives in device memory so the launch can sit inside a captured hipGraph:
+ *   hyper6: lr, beta1, beta2, eps, weight_decay, grad_scale (grad is multiplied by grad_scale first: 1/world after a
+ *           summing all-reduce);  step: int64 counter, incremented by the launch;  ticket: uint32, zero. */
+int fcn_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                      const float *hyper6, int64_t *step, uint32_t *ticket, void *stream);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,19 @@ def _worker(rank, world, port, q):
         dist.all_gather(allg, l_)
         okc = okc and torch.allclose(p_.grad, sum(allg) / world, rtol=1e-6, atol=1e-7)
     q.put((rank, "coalesced", bool(okc), True, True))
+    # the step loop's flat training state: one summing all-reduce of the flat gradient, 1/world folded into hyper[5]
+    from frustum_convnet_amd.train_state import FlatTrainState
+    model3 = torch.nn.Sequential(torch.nn.Conv1d(4, 8, 3), torch.nn.BatchNorm1d(8), torch.nn.Conv1d(8, 2, 1))
+    st = FlatTrainState(model3, lr=1e-3, world=world)
+    torch.manual_seed(11 + rank)
+    st.grad.copy_(torch.randn(st.numel))
+    loc3 = st.grad.clone()
+    st.allreduce()
+    allg = [torch.zeros_like(loc3) for _ in range(world)]
+    dist.all_gather(allg, loc3)
+    ok3 = torch.allclose(st.grad * float(st.hyper[5]), sum(allg) / world, rtol=1e-6, atol=1e-7)
+    ok3 = ok3 and all(p.grad.data_ptr() == st.grad.data_ptr() + 4 * o for p, o in zip(st.params, st.offsets))
+    q.put((rank, "flat_state", bool(ok3), True, True))
     # optimizer over the flat parameter moves every view
     fp = flat.as_parameter()
     before = model[0].weight.detach().clone()
@@ -83,8 +96,8 @@ def test_world2_gloo():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    got = [q.get(timeout=5) for _ in range(world * 4)]
-    assert len(got) == 8 and all(g[2] and g[3] and g[4] for g in got), got
+    got = [q.get(timeout=5) for _ in range(world * 5)]
+    assert len(got) == 10 and all(g[2] and g[3] and g[4] for g in got), got
 
 
 def test_shard_batch_matches_dataparallel_scatter():

@@ -1,0 +1,131 @@
+"""-m gpu: the step loop's flat training state (train_state.FlatTrainState + C-ABI fcn_adam_step_f32) against
+torch.optim.Adam on the same gradients, and the 2-step loss trajectory against the CPU oracle stepped with
+torch.optim.Adam (reference loop: train/train_net_det.py:114-137, optimiser :321-339)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, golden_inputs, golden_state_dict
+from frustum_convnet_amd import synth
+from test_gpu_model import _model
+
+pytestmark = pytest.mark.gpu
+
+
+def test_flat_layout_and_direct_gradients():
+    from frustum_convnet_amd.train_state import FlatTrainState
+    g = load_golden("car_b4_n512")
+    data = synth.to_torch(golden_inputs(g), "cuda")
+    ref = _model(g)
+    ref.train()
+    lo, _ = ref(data)
+    lo["total_loss"].backward()
+    want = {k: p.grad.clone() for k, p in ref.named_parameters()}
+
+    m = _model(g)
+    m.train()
+    st = FlatTrainState(m, lr=1e-3, weight_decay=1e-4)
+    named = dict(m.named_parameters())
+    assert st.numel >= sum(p.numel() for p in named.values())
+    for k, p in named.items():
+        assert p.grad is p._fcn_grad and p.grad.data_ptr() % 4 == 0
+        assert st.flat.data_ptr() <= p.data_ptr() < st.flat.data_ptr() + 4 * st.numel
+    cw, rw = named["cls_out.weight"], named["reg_out.weight"]
+    assert rw.data_ptr() == cw.data_ptr() + 4 * cw.numel()          # heads adjacent: one GEMM operand, no cat
+    st.grad.fill_(float("nan"))                                      # every element must be overwritten
+    lo2, _ = m(data)
+    lo2["total_loss"].backward()
+    assert float(lo2["total_loss"]) == float(lo["total_loss"])
+    for k, p in named.items():
+        assert p.grad is p._fcn_grad                                 # autograd did not replace the view
+        assert torch.equal(p.grad, want[k]), k                       # same kernels, same bits, written in place
+    # a second backward overwrites (no accumulation)
+    lo3, _ = m(data)
+    lo3["total_loss"].backward()
+    k = "conv_net.block1_conv1.0.weight"
+    assert float((named[k].grad - want[k]).abs().max()) <= 1e-4 * float(want[k].abs().max())
+    used = torch.zeros(st.numel, dtype=torch.bool, device="cuda")
+    for p, o in zip(st.params, st.offsets):
+        used[o:o + p.numel()] = True
+    assert torch.isfinite(st.grad[used]).all()
+
+
+def test_flat_adam_matches_torch_adam():
+    from frustum_convnet_amd.train_state import FlatTrainState
+    g = load_golden("car_b4_n512")
+    data = synth.to_torch(golden_inputs(g), "cuda")
+    a = _model(g)
+    b = _model(g)
+    a.train()
+    b.train()
+    opt = torch.optim.Adam(a.parameters(), lr=1e-3, weight_decay=1e-4)
+    st = FlatTrainState(b, lr=1e-3, weight_decay=1e-4)
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    for it in range(3):
+        opt.zero_grad(set_to_none=True)
+        la, _ = a(data)
+        la["total_loss"].backward()
+        opt.step()
+        lb, _ = b(data)
+        lb["total_loss"].backward()
+        st.step()
+        assert abs(float(la["total_loss"]) - float(lb["total_loss"])) <= 2e-4 * abs(float(la["total_loss"])), it
+        worst = max(float((pa[k] - pb[k]).abs().max()) for k in pa)
+        print("flat Adam vs torch.optim.Adam after step %d: max |dparam| %.2e" % (it + 1, worst))
+        for k in pa:
+            d = float((pa[k] - pb[k]).abs().max())
+            if it == 0:
+                # identical gradients in, one update: only the fp32 rounding of the update arithmetic differs
+                assert d <= 1e-7 + 1e-6 * float(pa[k].abs().max()), (k, d)
+            else:
+                # later steps see slightly different gradients (lr 1e-3 on these weights is an unstable regime: the
+                # loss goes 106 -> 249 -> 67), so rounding differences are amplified; each step moves a parameter
+                # by at most ~lr
+                assert d <= 2e-4, (k, d, it)
+    assert int(st.step_count) == 3
+    # learning-rate change on the device
+    st.set_lr(0.0)
+    before = st.flat.clone()
+    st.adam_step()
+    assert torch.equal(before, st.flat) and int(st.step_count) == 4
+
+
+def test_two_step_trajectory_vs_cpu_oracle():
+    """Loss after 0, 1 and 2 Adam(lr 1e-3, wd 1e-4) steps from the same weights: HIP step loop vs oracle/det_ref.py
+    stepped by torch.optim.Adam on the CPU; rel 1e-3.  The referee is the oracle evaluated
+    in fp64: with these weights lr 1e-3 is an unstable regime (106.51 -> 248.93 -> 66.85) that amplifies rounding, and
+    the oracle's own fp32 evaluation lands 1.4 % away from its fp64 value at step 2 (67.76 vs 66.85, measured)."""
+    from oracle import det_ref
+    from frustum_convnet_amd.train_state import FlatTrainState
+    g = load_golden("car_b4_n512")
+    data_np = golden_inputs(g)
+    strides = tuple(g["meta_strides"])
+    f64 = lambda v: v.double() if v.dtype.is_floating_point else v
+    sd = {k: f64(v.clone()) for k, v in golden_state_dict(g).items()}
+    leaves = []
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+            leaves.append(v)
+    opt = torch.optim.Adam(leaves, lr=1e-3, weight_decay=1e-4)
+    dcpu = {k: f64(v) for k, v in synth.to_torch(data_np).items()}
+    ref_losses = []
+    for it in range(3):
+        opt.zero_grad(set_to_none=True)
+        _, _, lo = det_ref.forward(sd, dcpu, strides, training=True)    # train mode: batch statistics only
+        ref_losses.append(float(lo["total_loss"]))
+        lo["total_loss"].backward()
+        opt.step()
+    m = _model(g)
+    m.train()
+    st = FlatTrainState(m, lr=1e-3, weight_decay=1e-4)
+    data = synth.to_torch(data_np, "cuda")
+    got = []
+    for it in range(3):
+        lo, _ = m(data)
+        got.append(float(lo["total_loss"]))
+        lo["total_loss"].backward()
+        st.step()
+    print("trajectory fp64 oracle", ref_losses, "hip", got)
+    for r, h in zip(ref_losses, got):
+        assert abs(r - h) <= 1e-3 * abs(r), (ref_losses, got)

@@ -163,3 +163,34 @@ def test_loss_tail_matches_oracle_on_cpu():
     assert torch.allclose(cls_raw.grad, c2.grad, rtol=1e-4, atol=1e-6)
     assert torch.allclose(reg_raw.grad, r2.grad, rtol=1e-4, atol=1e-6)
     assert 0.0 <= float(metrics["cls_acc"]) <= 1.0
+
+
+def test_flat_train_state_layout_on_cpu():
+    """FlatTrainState re-homes parameters/gradients into flat buffers (heads adjacent, 16-byte aligned starts); the
+    optimiser step itself is a HIP kernel and refuses to run on the CPU."""
+    import pytest
+    from frustum_convnet_amd.config import reset_cfg
+    from frustum_convnet_amd import det_base
+    from frustum_convnet_amd.train_state import FlatTrainState
+    from frustum_convnet_amd.fcn_fused import _adjacent
+    reset_cfg()
+    m = det_base.PointNetDet(3, num_vec=3, num_classes=2)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    st = FlatTrainState(m, lr=1e-3, weight_decay=1e-4, world=4)
+    assert abs(float(st.hyper[5]) - 0.25) < 1e-7
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    named = dict(m.named_parameters())
+    assert len(st.params) == len(named) == 79 and sum(p.numel() for p in st.params) == 3316777
+    for p, o in zip(st.params, st.offsets):
+        assert p.data_ptr() == st.flat.data_ptr() + 4 * o and p.grad.data_ptr() == st.grad.data_ptr() + 4 * o
+    Wh = _adjacent(named["cls_out.weight"], named["reg_out.weight"])
+    assert Wh is not None and Wh.shape[0] == 41 and Wh.data_ptr() == named["cls_out.weight"].data_ptr()
+    assert torch.equal(Wh[2:], named["reg_out.weight"])
+    bh = _adjacent(named["cls_out.bias"], named["reg_out.bias"])
+    assert bh is not None and bh.shape == (41,)
+    assert _adjacent(named["reg_out.weight"], named["cls_out.weight"]) is None
+    with pytest.raises(RuntimeError):
+        st.adam_step()
+    st.release()
+    assert all(p.grad is None for p in st.params)
