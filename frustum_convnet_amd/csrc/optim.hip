@@ -18,7 +18,7 @@ struct AdamArgs {
 };
 
 #define ADAM_T 256
-#define ADAM_V 4               // float4 per thread per iteration
+#define ADAM_V 2               // 4-vectors per thread
 
 // moments of one element / one 4-vector (T = float or v4f); the parameter update needs a per-lane sqrt and follows
 template <class T>
@@ -31,25 +31,40 @@ __device__ __forceinline__ void adam_moments(T p, T g, T &m, T &v, float b1, flo
 
 __global__ __launch_bounds__(ADAM_T) void adam_kernel(AdamArgs a)
 {
+    __shared__ float bcs[2];
     const float lr = a.hyper[0], b1 = a.hyper[1], b2 = a.hyper[2], eps = a.hyper[3], wd = a.hyper[4], gs = a.hyper[5];
-    const double t = (double)(a.step[0] + 1);
-    const float bc1 = (float)(1.0 - pow((double)b1, t)), bc2 = (float)(1.0 - pow((double)b2, t));
-    const float lr_c = lr / bc1, rsq_bc2 = 1.f / sqrtf(bc2);
+    if (threadIdx.x == 0) {             // the two fp64 pow() are ~600 instructions: once per workgroup, not per thread
+        const double t = (double)(a.step[0] + 1);
+        bcs[0] = (float)(1.0 - pow((double)b1, t));
+        bcs[1] = (float)(1.0 - pow((double)b2, t));
+    }
     const int64_t n4 = a.n >> 2;
-    const int64_t stride = (int64_t)gridDim.x * ADAM_T;
-    for (int64_t i = (int64_t)blockIdx.x * ADAM_T + threadIdx.x; i < n4; i += stride) {
-        v4f p = ldg4(a.p + 4 * i), g = ldg4(a.g + 4 * i), m = ldg4(a.m + 4 * i), v = ldg4(a.v + 4 * i);
-        adam_moments(p, g, m, v, b1, b2, wd, gs);
-        const v4f rt = {sqrtf(v.x), sqrtf(v.y), sqrtf(v.z), sqrtf(v.w)};
-        p = p - lr_c * (m / (rt * rsq_bc2 + eps));
-        sts4(a.p + 4 * i, p); sts4(a.m + 4 * i, m); sts4(a.v + 4 * i, v);
+    // ADAM_V 4-vectors per thread, every load issued before the first use
+    const int64_t base = (int64_t)blockIdx.x * (ADAM_T * ADAM_V) + threadIdx.x;
+    v4f p[ADAM_V], g[ADAM_V], m[ADAM_V], v[ADAM_V];
+#pragma unroll
+    for (int q = 0; q < ADAM_V; ++q) {
+        const int64_t i = min(base + q * ADAM_T, n4 - 1);
+        p[q] = ldg4(a.p + 4 * i); g[q] = ldg4(a.g + 4 * i); m[q] = ldg4(a.m + 4 * i); v[q] = ldg4(a.v + 4 * i);
+    }
+    __syncthreads();
+    const float lr_c = lr / bcs[0], rsq_bc2 = 1.f / sqrtf(bcs[1]);
+#pragma unroll
+    for (int q = 0; q < ADAM_V; ++q) {
+        const int64_t i = base + q * ADAM_T;
+        if (i < n4) {
+            adam_moments(p[q], g[q], m[q], v[q], b1, b2, wd, gs);
+            const v4f rt = {sqrtf(v[q].x), sqrtf(v[q].y), sqrtf(v[q].z), sqrtf(v[q].w)};
+            p[q] = p[q] - lr_c * (m[q] / (rt * rsq_bc2 + eps));
+            sts4(a.p + 4 * i, p[q]); sts4(a.m + 4 * i, m[q]); sts4(a.v + 4 * i, v[q]);
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {           // tail (n not a multiple of 4)
         const int64_t i = (n4 << 2) + threadIdx.x;
-        float p = a.p[i], m = a.m[i], v = a.v[i];
-        adam_moments(p, a.g[i], m, v, b1, b2, wd, gs);
-        p = p - lr_c * (m / (sqrtf(v) * rsq_bc2 + eps));
-        a.p[i] = p; a.m[i] = m; a.v[i] = v;
+        float pp = a.p[i], mm = a.m[i], vv = a.v[i];
+        adam_moments(pp, a.g[i], mm, vv, b1, b2, wd, gs);
+        pp = pp - lr_c * (mm / (sqrtf(vv) * rsq_bc2 + eps));
+        a.p[i] = pp; a.m[i] = mm; a.v[i] = vv;
     }
     // every workgroup has read step[0] by the time it takes a ticket: the last one advances the counter
     __syncthreads();
@@ -70,9 +85,9 @@ extern "C" int fcn_adam_step_f32(float *param, const float *grad, float *exp_avg
     if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return FCN_E_BADARG;
     AdamArgs a;
     a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n; a.hyper = hyper6; a.step = step; a.ticket = ticket;
-    int64_t blocks = ((n >> 2) + ADAM_T - 1) / ADAM_T;
-    if (blocks > 2048) blocks = 2048;                   // 8 workgroups per CU, grid-stride beyond
-    if (blocks < 1) blocks = 1;
+    if (n < 4) return FCN_E_BADARG;
+    const int64_t per = (int64_t)ADAM_T * ADAM_V;
+    const int64_t blocks = ((n >> 2) + per - 1) / per;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(ADAM_T), 0, (hipStream_t)stream, a);
     FCN_CHECK_LAUNCH();
     return 0;

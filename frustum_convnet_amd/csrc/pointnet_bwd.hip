@@ -467,38 +467,41 @@ __global__ __launch_bounds__(GT) void wgrad_kernel(WgradArgs a)
             }
 }
 
-// out[i] = sum over the live splits in a fixed order (deterministic).  A small layer has few elements but hundreds of
-// splits: 64 consecutive elements x 16 split groups per workgroup, so every thread has a handful of independent loads
-// in flight instead of one thread walking all the splits of its element.
-#define WR_G 16
-__global__ __launch_bounds__(64 * WR_G) void wgrad_reduce_kernel(const float *__restrict__ partial,
-                                                                const int32_t *__restrict__ tiles, int nsplit,
-                                                                int64_t nelem, float *__restrict__ out)
+// out[i] = sum over the live splits in a fixed order (deterministic).  The 256-thread workgroup covers 256 / gr
+// consecutive elements with gr split groups (gr = 1, 2, 4, 8 or 16 picked on the host from the split count): a small
+// layer has few elements but hundreds of splits (a few independent loads per thread, group sum through LDS), a big one
+// the opposite (one thread per element).
+#define WR_T 256
+__global__ __launch_bounds__(WR_T) void wgrad_reduce_kernel(const float *__restrict__ partial,
+                                                            const int32_t *__restrict__ tiles, int nsplit, int gr,
+                                                            int64_t nelem, float *__restrict__ out)
 {
-    __shared__ float sh[WR_G][64];
-    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 64 + x;             // nelem is a multiple of 64
+    __shared__ float sh[WR_T];
+    const int per = WR_T / gr;
+    const int x = threadIdx.x % per, y = threadIdx.x / per;
+    const int64_t i = (int64_t)blockIdx.x * per + x;            // nelem is a multiple of 256
     const int ntile = tiles[0];
     const int tpb = (ntile + nsplit - 1) / nsplit;
     const int nsp = tpb > 0 ? (ntile + tpb - 1) / tpb : 0;
     const float *p = partial + i;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int sp = y;
-    for (; sp + 3 * WR_G < nsp; sp += 4 * WR_G) {
+    for (; sp + 3 * gr < nsp; sp += 4 * gr) {
         s0 += p[(int64_t)sp * nelem];
-        s1 += p[(int64_t)(sp + WR_G) * nelem];
-        s2 += p[(int64_t)(sp + 2 * WR_G) * nelem];
-        s3 += p[(int64_t)(sp + 3 * WR_G) * nelem];
+        s1 += p[(int64_t)(sp + gr) * nelem];
+        s2 += p[(int64_t)(sp + 2 * gr) * nelem];
+        s3 += p[(int64_t)(sp + 3 * gr) * nelem];
     }
-    for (; sp < nsp; sp += WR_G) s0 += p[(int64_t)sp * nelem];
-    sh[y][x] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (y == 0) {
-        float t = 0.f;
-#pragma unroll
-        for (int q = 0; q < WR_G; ++q) t += sh[q][x];
-        out[i] = t;
+    for (; sp < nsp; sp += gr) s0 += p[(int64_t)sp * nelem];
+    float t = (s0 + s1) + (s2 + s3);
+    if (gr > 1) {
+        sh[y * per + x] = t;
+        __syncthreads();
+        if (y != 0) return;
+        t = 0.f;
+        for (int q = 0; q < gr; ++q) t += sh[q * per + x];
     }
+    out[i] = t;
 }
 
 // dW1, dgamma1, dbeta1 from Q = sum_e dz1 (1, u) and the forward's weighted moments of u.
@@ -564,8 +567,9 @@ static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, hipStream_t st, flo
     else hipLaunchKernelGGL((wgrad_kernel<LAYER, 1, 1>), grid, dim3(GT), 0, st, a);
     FCN_CHECK_LAUNCH();
     const int64_t ne = (int64_t)a.COUT * a.CIN;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(ne / 64)), dim3(64 * WR_G), 0, st, a.partial, a.tiles,
-                       nsplit, ne, out);
+    const int gr = nsplit >= 128 ? 16 : (nsplit >= 64 ? 8 : (nsplit >= 32 ? 4 : (nsplit >= 16 ? 2 : 1)));
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(ne / (WR_T / gr))), dim3(WR_T), 0, st, a.partial, a.tiles,
+                       nsplit, gr, ne, out);
     FCN_CHECK_LAUNCH();
     return 0;
 }

@@ -213,6 +213,7 @@ class PointNetDet(nn.Module):
         # fused_fcn: ConvFeatNet + heads as hand-written implicit-GEMM HIP kernels over position-major activations
         # (csrc/fcn_net.hip); False runs the nn.Conv1d / BatchNorm1d modules through MIOpen.
         self.fused_fcn = True
+        self._zero_cache = {}
         from .fcn_fused import CnPool
         self._cn_pool = CnPool()
         self.last_logits = None
@@ -225,6 +226,15 @@ class PointNetDet(nn.Module):
         size_scores = output[:, 3 + 2 * nb:3 + 2 * nb + ns]
         size_res_norm = output[:, 3 + 2 * nb + ns:].reshape(output.shape[0], ns, 3)
         return center, heading_scores, heading_res_norm, size_scores, size_res_norm
+
+    def _zero_scalar(self, like):
+        """A cached constant 0 (the IoU metric placeholders): no fill kernel per step."""
+        key = (str(like.device), like.dtype)
+        z = self._zero_cache.get(key)
+        if z is None:
+            z = torch.zeros((), dtype=like.dtype, device=like.device)
+            self._zero_cache[key] = z
+        return z
 
     def forward(self, data_dicts):
         point_cloud = data_dicts.get('point_cloud')
@@ -257,10 +267,13 @@ class PointNetDet(nn.Module):
         self.last_logits = (cls_raw, reg_raw)
 
         num_out = reg_raw.shape[2]
-        cls_scores = cls_raw.permute(0, 2, 1).reshape(-1, 2)
-        outputs = reg_raw.permute(0, 2, 1).reshape(-1, reg_raw.shape[1])
-        center_ref2 = refs[1].permute(0, 2, 1).reshape(-1, 3)
-        cls_probs = F.softmax(cls_scores, -1)
+        fused_tail = (center_label is not None and self.fused_loss and cls_raw.is_cuda and self.iou_fn is None
+                      and not self.strict and self.num_bins == 12 and self.num_size_cluster == 3)
+        if not fused_tail:       # the fused loss tail reads the raw logits itself: none of these copies / softmax
+            cls_scores = cls_raw.permute(0, 2, 1).reshape(-1, 2)
+            outputs = reg_raw.permute(0, 2, 1).reshape(-1, reg_raw.shape[1])
+            center_ref2 = refs[1].permute(0, 2, 1).reshape(-1, 3)
+            cls_probs = F.softmax(cls_scores, -1)
 
         if center_label is None:
             assert not self.training, 'Please provide labels for training.'
@@ -277,8 +290,7 @@ class PointNetDet(nn.Module):
                     heading_probs.view(batch_size, -1, self.num_bins),
                     size_probs.view(batch_size, -1, self.num_size_cluster))
 
-        if self.fused_loss and cls_raw.is_cuda and self.iou_fn is None and not self.strict \
-                and self.num_bins == 12 and self.num_size_cluster == 3:
+        if fused_tail:
             from .loss_fused import det_loss_tail, det_loss_tail_rows
             Lw = cfg.LOSS
             wts = (Lw.BOX_LOSS_WEIGHT, Lw.CORNER_LOSS_WEIGHT, Lw.HEAD_REG_WEIGHT, Lw.SIZE_REG_WEIGHT)
@@ -290,7 +302,7 @@ class PointNetDet(nn.Module):
                 losses, (a_cls, a_head, a_size) = det_loss_tail(
                     cls_raw, reg_raw, cls_label, refs[1], center_label, heading_label, size_label, size_class_label,
                     mean_size_array, self.num_bins, self.num_size_cluster, wts)
-            zero = torch.zeros((), dtype=a_cls.dtype, device=a_cls.device)
+            zero = self._zero_scalar(a_cls)
             metrics = {'cls_acc': a_cls, 'head_acc': a_head, 'size_acc': a_size, 'IoU_2D': zero, 'IoU_3D': zero,
                        'IoU_' + str(cfg.IOU_THRESH): zero}
             return losses, metrics

@@ -83,11 +83,12 @@ class _LossTailRows(torch.autograd.Function):
         total = out[0].clone()
         rest = out.detach()
         ctx.mark_non_differentiable(rest)
+        ctx.set_materialize_grads(False)          # no zero-filled gradient for `rest`
         return total, rest
 
     @staticmethod
     def backward(ctx, gtotal, _grest):
-        if not ctx.need:
+        if not ctx.need or gtotal is None:
             return (None,) * 13
         (dlog,) = ctx.saved_tensors
         return (dlog * gtotal,) + (None,) * 12

@@ -137,10 +137,13 @@ class _PointNetPooled(torch.autograd.Function):
         else:
             pool.release(ws)
         ctx.mark_non_differentiable(idx, cnt)
+        ctx.set_materialize_grads(False)          # no zero-filled "gradients" for idx / cnt (two fill kernels per scale)
         return feat, idx, cnt
 
     @staticmethod
     def backward(ctx, dfeat, _didx, _dcnt):
+        if dfeat is None:
+            return (None,) * 16
         if not ctx.live:
             raise RuntimeError("fused PointNet forward ran without saved state (eval mode or no_grad)")
         L = _native.lib()
