@@ -47,7 +47,7 @@ class PnWs(ctypes.Structure):
 
 
 EXPORTS = ("fcn_arch", "fcn_query_depth_point_f32", "fcn_pn_wgrad_rows", "fcn_pn_compact",
-           "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_adam_step_f32",
+           "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_adam_step_f32", "fcn_adam_step_slots",
            "fcn_convnet_sizes", "fcn_convnet_forward", "fcn_convnet_backward")
 
 _lib = None
@@ -95,7 +95,9 @@ def lib():
     L.fcn_det_loss_tail.restype = ctypes.c_int
     L.fcn_det_loss_tail.argtypes = [c_fp] * 9 + [ctypes.c_int] * 4 + [ctypes.c_float] * 4 + [c_fp] * 4
     L.fcn_adam_step_f32.restype = ctypes.c_int
-    L.fcn_adam_step_f32.argtypes = [c_fp] * 4 + [ctypes.c_int64] + [c_fp] * 4
+    L.fcn_adam_step_f32.argtypes = [c_fp] * 4 + [ctypes.c_int64] + [c_fp] * 3
+    L.fcn_adam_step_slots.restype = ctypes.c_int64
+    L.fcn_adam_step_slots.argtypes = [ctypes.c_int64]
     L.fcn_det_loss_tail_rows.restype = ctypes.c_int
     L.fcn_det_loss_tail_rows.argtypes = [c_fp] * 8 + [ctypes.c_int] * 4 + [ctypes.c_float] * 4 + [c_fp] * 3
     L.fcn_convnet_sizes.restype = ctypes.c_int

@@ -13,8 +13,9 @@ struct AdamArgs {
     float *m, *v;
     int64_t n;
     const float *hyper;        // device: lr, beta1, beta2, eps, weight_decay, grad_scale
-    int64_t *step;             // device step counter (incremented by the last workgroup)
-    unsigned *ticket;          // device, zero between launches
+    int64_t *step;             // device step counters, ONE PER WORKGROUP (each reads and advances its own slot: no
+                               // cross-workgroup hazard and no same-address atomic -- a ticket counter taken by
+                               // 1600 workgroups serialises in L2 and cost 60 us of a 70 us launch)
 };
 
 #define ADAM_T 256
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(ADAM_T) void adam_kernel(AdamArgs a)
     __shared__ float bcs[2];
     const float lr = a.hyper[0], b1 = a.hyper[1], b2 = a.hyper[2], eps = a.hyper[3], wd = a.hyper[4], gs = a.hyper[5];
     if (threadIdx.x == 0) {             // the two fp64 pow() are ~600 instructions: once per workgroup, not per thread
-        const double t = (double)(a.step[0] + 1);
+        const double t = (double)(a.step[blockIdx.x] + 1);
         bcs[0] = (float)(1.0 - pow((double)b1, t));
         bcs[1] = (float)(1.0 - pow((double)b2, t));
     }
@@ -66,28 +67,22 @@ __global__ __launch_bounds__(ADAM_T) void adam_kernel(AdamArgs a)
         pp = pp - lr_c * (mm / (sqrtf(vv) * rsq_bc2 + eps));
         a.p[i] = pp; a.m[i] = mm; a.v[i] = vv;
     }
-    // every workgroup has read step[0] by the time it takes a ticket: the last one advances the counter
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned k = atomicAdd(a.ticket, 1u);
-        if (k == gridDim.x - 1) {
-            a.step[0] += 1;
-            a.ticket[0] = 0u;
-        }
-    }
+    if (threadIdx.x == 0) a.step[blockIdx.x] += 1;     // thread 0 read it above
 }
 
+static int64_t adam_blocks(int64_t n) { const int64_t per = (int64_t)ADAM_T * ADAM_V; return ((n >> 2) + per - 1) / per; }
+
+extern "C" int64_t fcn_adam_step_slots(int64_t n) { return n < 4 ? 0 : adam_blocks(n); }
+
 extern "C" int fcn_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
-                                 const float *hyper6, int64_t *step, uint32_t *ticket, void *stream)
+                                 const float *hyper6, int64_t *step_slots, void *stream)
 {
-    if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper6 || !step || !ticket || n <= 0) return FCN_E_BADARG;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper6 || !step_slots || n <= 0) return FCN_E_BADARG;
     if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return FCN_E_BADARG;
     AdamArgs a;
-    a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n; a.hyper = hyper6; a.step = step; a.ticket = ticket;
+    a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n; a.hyper = hyper6; a.step = step_slots;
     if (n < 4) return FCN_E_BADARG;
-    const int64_t per = (int64_t)ADAM_T * ADAM_V;
-    const int64_t blocks = ((n >> 2) + per - 1) / per;
+    const int64_t blocks = adam_blocks(n);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(ADAM_T), 0, (hipStream_t)stream, a);
     FCN_CHECK_LAUNCH();
     return 0;

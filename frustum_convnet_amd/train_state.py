@@ -65,8 +65,10 @@ class FlatTrainState:
         self.world, self.group = int(world), group
         self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, 1.0 / self.world], device=dev,
                                   dtype=torch.float32)
-        self.step_count = torch.zeros(1, device=dev, dtype=torch.int64)
-        self._ticket = torch.zeros(1, device=dev, dtype=torch.int32)
+        # one step counter per workgroup of the optimiser kernel (all equal); step_count is slot 0
+        nslot = int(_native.lib().fcn_adam_step_slots(ctypes.c_int64(total)))
+        self._step_slots = torch.zeros(max(nslot, 1), device=dev, dtype=torch.int64)
+        self.step_count = self._step_slots[0:1]
         self.device = dev
 
     def set_lr(self, lr):
@@ -89,8 +91,8 @@ class FlatTrainState:
         with torch.cuda.device(self.device):
             _native.check(L.fcn_adam_step_f32(self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
                                               self.exp_avg_sq.data_ptr(), ctypes.c_int64(self.numel),
-                                              self.hyper.data_ptr(), self.step_count.data_ptr(),
-                                              self._ticket.data_ptr(), _native.current_stream(self.device)),
+                                              self.hyper.data_ptr(), self._step_slots.data_ptr(),
+                                              _native.current_stream(self.device)),
                           "fcn_adam_step_f32")
 
     def step(self):

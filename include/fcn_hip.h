@@ -197,9 +197,11 @@ int fcn_det_loss_tail_rows(const float *logits, const int64_t *cls_label, const 
  * arithmetic (L2 weight decay, bias correction from the step counter).  Everything the host may change between steps
  * lives in device memory so the launch can sit inside a captured hipGraph:
  *   hyper6: lr, beta1, beta2, eps, weight_decay, grad_scale (grad is multiplied by grad_scale first: 1/world after a
- *           summing all-reduce);  step: int64 counter, incremented by the launch;  ticket: uint32, zero. */
+ *           summing all-reduce);  step_slots: fcn_adam_step_slots(n) int64 counters, all equal (0 at start), every
+ *           one advanced by the launch -- one per workgroup, so no workgroup waits on another. */
+int64_t fcn_adam_step_slots(int64_t n);
 int fcn_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
-                      const float *hyper6, int64_t *step, uint32_t *ticket, void *stream);
+                      const float *hyper6, int64_t *step_slots, void *stream);
 
 #ifdef __cplusplus
 }
