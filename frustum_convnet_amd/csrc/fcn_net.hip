@@ -185,26 +185,28 @@ __global__ __launch_bounds__(G * 128 * MW) void cgk_fwd_kernel(CgLayer L)
     const int T0 = opaque_s(L.seg[0].type), T1 = opaque_s(L.seg[1].type), T2 = opaque_s(L.seg[2].type);
     const int Q0 = opaque_s(L.seg[0].Lsrc), Q1 = opaque_s(L.seg[1].Lsrc), Q2 = opaque_s(L.seg[2].Lsrc);
     int bb[NA], ll[NA];
-    bool rv[NA], ok[NA];
+    bool rv[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int gr = row0 + rb + RSTEP * i;
         rv[i] = gr < R;
         bb[i] = rv[i] ? gr / L.Lout : 0;
         ll[i] = rv[i] ? gr % L.Lout : 0;
-        ok[i] = false;
     }
     f32x16 acc[1][1];
     acc_zero<1, 1>(acc);
-    v4f ra[NA], rw[NB];
+    // TWO register sets: the chunk staged in iteration `it` was requested two iterations earlier, so a load has two
+    // MFMA phases (not one) to come back from L2 / MALL / HBM before the LDS store needs it
+    v4f ra0[NA], rw0[NB], ra1[NA], rw1[NB];
+    bool ok0[NA], ok1[NA];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) ra[i] = zero4();
+    for (int i = 0; i < NA; ++i) { ra0[i] = zero4(); ra1[i] = zero4(); ok0[i] = false; ok1[i] = false; }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) rw[i] = zero4();
-    // (a macro, not a lambda: the by-reference closure of a lambda called from two places is not always scalarised by
-    // hipcc and drags every captured variable into scratch)
+    for (int i = 0; i < NB; ++i) { rw0[i] = zero4(); rw1[i] = zero4(); }
+    // (macros, not lambdas: the by-reference closure of a lambda called from several places is not always scalarised
+    // by hipcc and drags every captured variable into scratch)
     // the chunk (hence the segment) is uniform within a K-group, i.e. within every wave: scalar selects
-#define CGK_FWD_LOAD(cc)                                                                                              \
+#define CGK_FWD_LOAD(cc, RA, RW, OK)                                                                                  \
     {                                                                                                                 \
         const int c_ = (cc);                                                                                          \
         const int sgi = __builtin_amdgcn_readfirstlane(cSeg[c_]);                                                     \
@@ -212,37 +214,45 @@ __global__ __launch_bounds__(G * 128 * MW) void cgk_fwd_kernel(CgLayer L)
         const float *x = SEL3(sgi, x0, x1, x2);                                                                       \
         const int C = SEL3(sgi, C0, C1, C2), ty = SEL3(sgi, T0, T1, T2), Ls = SEL3(sgi, Q0, Q1, Q2);                  \
         _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                                \
-            ra[i] = cg_load_raw(L, x, C, Ls, ty ? 0 : 1, tap, k0 + 4 * kq, bb[i], ll[i], rv[i], ok[i]);               \
+            RA[i] = cg_load_raw(L, x, C, Ls, ty ? 0 : 1, tap, k0 + 4 * kq, bb[i], ll[i], rv[i], OK[i]);               \
         _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                                \
-            rw[i] = ldg4(L.Wp + (int64_t)(n0 + rb + RSTEP * i) * L.Ktot + c_ * KC + 4 * kq);                          \
+            RW[i] = ldg4(L.Wp + (int64_t)(n0 + rb + RSTEP * i) * L.Ktot + c_ * KC + 4 * kq);                          \
+    }
+#define CGK_FWD_STAGE(c_, RA, RW, OK)                                                                                 \
+    {                                                                                                                 \
+        const float *sp = sS + (c_) * KC + 4 * kq, *tp = tS + (c_) * KC + 4 * kq;                                     \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                              \
+            const int r = rb + RSTEP * i;                                                                             \
+            As[(4 * kq + 0) * LDA + r] = cg_act(sp[0], RA[i].x, tp[0], OK[i]);                                        \
+            As[(4 * kq + 1) * LDA + r] = cg_act(sp[1], RA[i].y, tp[1], OK[i]);                                        \
+            As[(4 * kq + 2) * LDA + r] = cg_act(sp[2], RA[i].z, tp[2], OK[i]);                                        \
+            As[(4 * kq + 3) * LDA + r] = cg_act(sp[3], RA[i].w, tp[3], OK[i]);                                        \
+        }                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                              \
+            const int n = rb + RSTEP * i;                                                                             \
+            Bs[(4 * kq + 0) * LDC + n] = RW[i].x; Bs[(4 * kq + 1) * LDC + n] = RW[i].y;                               \
+            Bs[(4 * kq + 2) * LDC + n] = RW[i].z; Bs[(4 * kq + 3) * LDC + n] = RW[i].w;                               \
+        }                                                                                                             \
+    }
+#define CGK_FWD_ITER(it_, RA, RW, OK)                                                                                 \
+    {                                                                                                                 \
+        const int c = (it_) * G + g;                                                                                  \
+        const bool act = c < nchunk;                                                                                  \
+        if (act && dlds) CGK_FWD_STAGE(c, RA, RW, OK);                                                                \
+        __syncthreads();                                                                                              \
+        if (c + 2 * G < nchunk && dload) CGK_FWD_LOAD(c + 2 * G, RA, RW, OK);                                         \
+        if (act && dmma) mma_chunk<1, 1, LDA, LDC>(As, Bs, wm * 32, wn * 32, acc);                                    \
+        __syncthreads();                                                                                              \
     }
     const bool dload = !(L.dbg & 2), dlds = !(L.dbg & 4), dmma = !(L.dbg & 1);
     __syncthreads();                            // sS / tS and the chunk table ready
-    if (dload) CGK_FWD_LOAD(min(g, nchunk - 1));
-    for (int it = 0; it < nit; ++it) {
-        const int c = it * G + g;
-        const bool act = c < nchunk;
-        if (act && dlds) {
-            const float *sp = sS + c * KC + 4 * kq, *tp = tS + c * KC + 4 * kq;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int r = rb + RSTEP * i;
-                As[(4 * kq + 0) * LDA + r] = cg_act(sp[0], ra[i].x, tp[0], ok[i]);
-                As[(4 * kq + 1) * LDA + r] = cg_act(sp[1], ra[i].y, tp[1], ok[i]);
-                As[(4 * kq + 2) * LDA + r] = cg_act(sp[2], ra[i].z, tp[2], ok[i]);
-                As[(4 * kq + 3) * LDA + r] = cg_act(sp[3], ra[i].w, tp[3], ok[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int n = rb + RSTEP * i;
-                Bs[(4 * kq + 0) * LDC + n] = rw[i].x; Bs[(4 * kq + 1) * LDC + n] = rw[i].y;
-                Bs[(4 * kq + 2) * LDC + n] = rw[i].z; Bs[(4 * kq + 3) * LDC + n] = rw[i].w;
-            }
-        }
-        __syncthreads();
-        if (c + G < nchunk && dload) CGK_FWD_LOAD(c + G);
-        if (act && dmma) mma_chunk<1, 1, LDA, LDC>(As, Bs, wm * 32, wn * 32, acc);
-        __syncthreads();
+    if (dload) {
+        CGK_FWD_LOAD(min(g, nchunk - 1), ra0, rw0, ok0);
+        CGK_FWD_LOAD(min(g + G, nchunk - 1), ra1, rw1, ok1);
+    }
+    for (int it = 0; it < nit; it += 2) {
+        CGK_FWD_ITER(it, ra0, rw0, ok0);
+        if (it + 1 < nit) CGK_FWD_ITER(it + 1, ra1, rw1, ok1);
     }
     // ---- sum the G group accumulators through LDS, then one epilogue pass over the tile
     float *red = lds;                                   // [G][TMB][64]

@@ -19,7 +19,7 @@
 #define LDT 129                 // transposed (k-major) staging of a 128-row tile
 #define MAXC 512
 #define WG_ROWS 128             // rows of one row tile (wgrad splits are multiples of it)
-#define PWB 64                  // windows per poolbwd workgroup
+#define PWB 16                  // windows per poolbwd workgroup (4 per wave, their loads issued together)
 #ifndef FCN_WIDE_TILES
 #define FCN_WIDE_TILES 0
 #endif
@@ -46,19 +46,30 @@ __global__ __launch_bounds__(GT) void poolbwd_kernel(
     const int c = c0 + lane;
     const float mean = bn3[2 * C3 + c], rstd = bn3[3 * C3 + c];
     float sB = 0.f, sG = 0.f;
-    for (int wl = wave; wl < PWB; wl += 4) {
-        const int l = l0 + wl;
-        if (l >= L) break;
-        const int64_t o = ((int64_t)b * L + l) * C3 + c;
-        const int am = amax[o];
+    // the wave's 4 windows: argmax rows first, then the gathers they address -- two dependent round trips in all
+    constexpr int NW = PWB / 4;
+    int am[NW];
+    float gg[NW], yy[NW];
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+        const int l = l0 + wave + 4 * q;
+        am[q] = (l < L) ? amax[((int64_t)b * L + l) * C3 + c] : -1;
+        gg[q] = (l < L && nlc) ? dfeat[((int64_t)b * L + l) * C3 + c] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < NW; ++q) yy[q] = (am[q] >= 0) ? y3[((int64_t)b * cap + am[q]) * C3 + c] : 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+        const int wl = wave + 4 * q, l = l0 + wl;
+        if (l >= L) continue;
         float g = 0.f;
-        if (am >= 0) {
-            g = nlc ? dfeat[((int64_t)b * L + l) * C3 + c] : dS[lane * (PWB + 1) + wl];
-            const float xh = (y3[((int64_t)b * cap + am) * C3 + c] - mean) * rstd;
+        if (am[q] >= 0) {
+            g = nlc ? gg[q] : dS[lane * (PWB + 1) + wl];
+            const float xh = (yy[q] - mean) * rstd;
             sB += g;
             sG = fmaf(g, xh, sG);
         }
-        gmax[o] = g;
+        gmax[((int64_t)b * L + l) * C3 + c] = g;
     }
     __syncthreads();
     float *red = dS;

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(128 * WN) void fwd_gemm_kernel(FwdArgs a)
 // ------------------------------------------------------------------------------------------------
 // Pool: one wave = one window x 64 channels (lane = channel: every row read is a coalesced 256-B run);
 // a workgroup covers 16 consecutive windows so the (B, C, L) output goes out as 64-B runs through LDS.
-#define PW 16
+#define PW 4            // windows per workgroup: ONE PER WAVE (the row walk of a window is a serial latency chain)
 
 __global__ __launch_bounds__(GT) void pool_kernel(
     const float *__restrict__ y3, const float *__restrict__ bn3, const int32_t *__restrict__ woff,
@@ -278,9 +278,8 @@ __global__ __launch_bounds__(GT) void pool_kernel(
     const int c = c0 + lane;
     const float s = bn3[c], t = bn3[C3 + c];
     const int32_t *wo = woff + (int64_t)b * (L + 1);
-#pragma unroll 1
-    for (int q = 0; q < PW / 4; ++q) {
-        const int wl = wave * (PW / 4) + q;
+    {
+        const int wl = wave;
         const int l = l0 + wl;
         float best = 0.f;
         int arg = -1;
@@ -288,13 +287,16 @@ __global__ __launch_bounds__(GT) void pool_kernel(
             const int o0 = wo[l], o1 = wo[l + 1];
             const float *yp = y3 + ((int64_t)b * cap + o0) * C3 + c;
             int r = o0;
-            for (; r + 4 <= o1; r += 4, yp += 4 * (int64_t)C3) {
-                const float v0 = fmaf(s, yp[0], t), v1 = fmaf(s, yp[C3], t);
-                const float v2 = fmaf(s, yp[2 * (int64_t)C3], t), v3 = fmaf(s, yp[3 * (int64_t)C3], t);
-                if (v0 > best) { best = v0; arg = r; }
-                if (v1 > best) { best = v1; arg = r + 1; }
-                if (v2 > best) { best = v2; arg = r + 2; }
-                if (v3 > best) { best = v3; arg = r + 3; }
+            // 8 independent row loads in flight; compared in row order (first maximum wins, like torch.max)
+            for (; r + 8 <= o1; r += 8, yp += 8 * (int64_t)C3) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = yp[j * (int64_t)C3];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float u = fmaf(s, v[j], t);
+                    if (u > best) { best = u; arg = r + j; }
+                }
             }
             for (; r < o1; ++r, yp += C3) {
                 const float v = fmaf(s, *yp, t);
