@@ -67,6 +67,7 @@ def roofline_probe(model, data, reps=20):
     tot_ms = 0.0
     tot_flops_exec = 0.0
     tot_flops_dense = 0.0
+    tot_bytes_alg = 0.0
     launches = 0
     per = []
     for s, net in enumerate(nets):
@@ -93,6 +94,9 @@ def roofline_probe(model, data, reps=20):
             ms = e0.elapsed_time(e1) / reps
             fl_exec = 2.0 * E * cin * cout
             fl_dense = 2.0 * B * Lw * K * cin * cout
+            # compulsory bytes of the launch: operand rows once (conv2 reads the 16-B entries, conv3 the previous
+            # pre-BN output), result rows once, the weight matrix once
+            tot_bytes_alg += E * (16.0 if layer == 2 else 4.0 * cin) + 4.0 * E * cout + 4.0 * cin * cout
             per.append({"scale": s + 1, "layer": layer, "ms": round(ms, 5), "rows": E,
                         "tflops_executed": round(fl_exec / ms / 1e9, 2)})
             tot_ms += ms
@@ -104,6 +108,7 @@ def roofline_probe(model, data, reps=20):
     return {"bound": "mfma", "kernel": "fwd_gemm_kernel (conv2/conv3 1x1 GEMMs, fp32 v_mfma_f32_32x32x2)",
             "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": _pmc_traffic(),
+            "bytes_per_launch_algorithmic": tot_bytes_alg / launches,
             "flops_per_launch_executed": tot_flops_exec / launches,
             "flops_per_launch_dense_equivalent": tot_flops_dense / launches,
             "avg_launch_ms": round(tot_ms / launches, 5), "launches_per_step": launches, "per_launch": per}
