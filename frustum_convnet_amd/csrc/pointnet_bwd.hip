@@ -127,82 +127,86 @@ struct DgradArgs {
     int L, cap, CRED, CPREV, tps;
 };
 
-template <int LAYER, int NT, int WN>
-__global__ __launch_bounds__(128 * WN) void dgrad_kernel(DgradArgs a)
+// Tile = (64*MT) rows x (32*NT*WN) columns of the previous layer; 2 x WN waves, each MT x NT MFMA tiles.
+// <L,1,2,2> (64 x 128) and <L,1,1,2> (64 x 64) stay under 168 VGPRs: 3 workgroups per CU instead of the 2 that the
+// 128 x 128 tile's 220 VGPRs allow -- scale 4's 570 big tiles were 1.1 waves of 512 slots (two rounds, the second
+// almost empty); 1140 half tiles on 768 slots are 1.5.
+template <int LAYER, int MT, int NT, int WN>
+__global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT * NT <= 2 ? 3 : 2, 4)))
+void dgrad_kernel(DgradArgs a)
 {
     constexpr int NTHR = 128 * WN;
+    constexpr int TM = 64 * MT;               // rows of the tile
     constexpr int TN = 32 * NT * WN;
+    constexpr int LDA = TM + 1;               // k-major staging of the TM-row tile
     constexpr int LDB = TN + 4;
-    constexpr int NA4 = 1024 / NTHR;          // row-quads of the A tile per thread per chunk
+    constexpr int NA4 = TM * 8 / NTHR;        // row-quads of the A tile per thread per chunk
     constexpr int NB4 = TN * 8 / NTHR;        // float4 of W per thread per chunk
-    __shared__ __attribute__((aligned(16))) float As[KC * LDT];
+    constexpr int SUB = 128 / TM;             // workgroups per 128-row tile of the live-tile list
+    __shared__ __attribute__((aligned(16))) float As[KC * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[KC * LDB];
     __shared__ float coefS[5 * MAXC];
-    __shared__ __attribute__((aligned(16))) float4 uS[128];     // (ux,uy,uz,w) of the tile rows
+    __shared__ __attribute__((aligned(16))) float4 uS[TM];      // (ux,uy,uz,w) of the tile rows
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    if ((int)blockIdx.x >= a.tiles[0]) return;
-    const int code = a.tiles[4 + blockIdx.x];
+    const int lt = blockIdx.x / SUB, sub = blockIdx.x % SUB;
+    if (lt >= a.tiles[0]) return;
+    const int code = a.tiles[4 + lt];
     const int b = code / a.tps, t = code % a.tps;
     const int nent = a.woff[(int64_t)b * (a.L + 1) + a.L];
-    const int row0 = t * 128;
-    const int nvalid = min(128, nent - row0);
+    const int row0 = t * 128 + sub * TM;
+    const int nvalid = min(TM, nent - row0);
+    if (nvalid <= 0) return;
     const int64_t grow0 = (int64_t)b * a.cap + row0;
     const int k0 = blockIdx.y * TN;               // first output column (channel of the previous layer)
     const int CRED = a.CRED, CPREV = a.CPREV;
 
     for (int i = tid; i < 5 * CRED; i += NTHR) coefS[i] = a.coef[i];
-    if (tid < 128) uS[tid] = (tid < nvalid) ? a.ent[grow0 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < TM) uS[tid] = (tid < nvalid) ? a.ent[grow0 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int kq = tid & 7, rb = tid >> 3;
     constexpr int RSTEP = NTHR / 8;               // rows between a thread's consecutive A quads
-    int wrow[NA4];        // LAYER 3: window of this thread's rows
-    if constexpr (LAYER == 3) {
+    // loads are UNCONDITIONAL on a clamped row (a "load or zero" branch makes hipcc wait for the load at once); rows
+    // past nvalid are zeroed when the registers go to LDS
+    int64_t arow[NA4];    // element offset of this thread's (clamped) rows in a (rows, CRED) buffer
+    int64_t wbase[NA4];   // LAYER 3: offset of the row's window in the (B, L, CRED) arg-max / routed-gradient maps
 #pragma unroll
-        for (int i = 0; i < NA4; ++i) {
-            const int r = rb + RSTEP * i;
-            wrow[i] = (r < nvalid) ? a.ewin[grow0 + r] : 0;
-        }
+    for (int i = 0; i < NA4; ++i) {
+        const int rc = min(rb + RSTEP * i, nvalid - 1);
+        arow[i] = (grow0 + rc) * CRED;
+        wbase[i] = 0;
+        if constexpr (LAYER == 3) wbase[i] = ((int64_t)b * a.L + a.ewin[grow0 + rc]) * CRED;
     }
     __syncthreads();
 
-    f32x16 acc[2][NT];
-    acc_zero<2, NT>(acc);
+    f32x16 acc[MT][NT];
+    acc_zero<MT, NT>(acc);
     v4f ry[NA4], rz[NA4];
     v4i rm[NA4];
     v4f rw[NB4];
     const int nchunk = CRED / KC;
 
-    auto load_chunk = [&](int c) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NA4; ++i) {
-            const int r = rb + RSTEP * i;
-            const int nq = c * KC + 4 * kq;
-            if (r < nvalid) {
-                ry[i] = ldg4(a.ycur + (grow0 + r) * CRED + nq);
-                if constexpr (LAYER == 3) {
-                    const int64_t o = ((int64_t)b * a.L + wrow[i]) * CRED + nq;
-                    rm[i] = ldg4i(a.amax + o);
-                    rz[i] = ldg4(a.gmax + o);
-                } else {
-                    rz[i] = ldg4(a.dzcur + (grow0 + r) * CRED + nq);
-                }
-            } else {
-                ry[i] = zero4();
-                rz[i] = zero4();
-                if constexpr (LAYER == 3) { v4i m1 = {-1, -1, -1, -1}; rm[i] = m1; }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NB4; ++i) {
-            const int f = tid + NTHR * i;
-            const int nn = f / (TN / 4), cq = f % (TN / 4);
-            rw[i] = ldg4(a.W + (int64_t)(c * KC + nn) * CPREV + k0 + 4 * cq);
-        }
-    };
+#define DGRAD_LOAD(cc)                                                                                                \
+    {                                                                                                                 \
+        const int nq_ = (cc) * KC + 4 * kq;                                                                           \
+        _Pragma("unroll") for (int i = 0; i < NA4; ++i) {                                                             \
+            ry[i] = ldg4(a.ycur + arow[i] + nq_);                                                                     \
+            if constexpr (LAYER == 3) {                                                                               \
+                rm[i] = ldg4i(a.amax + wbase[i] + nq_);                                                               \
+                rz[i] = ldg4(a.gmax + wbase[i] + nq_);                                                                \
+            } else {                                                                                                  \
+                rz[i] = ldg4(a.dzcur + arow[i] + nq_);                                                                \
+            }                                                                                                         \
+        }                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < NB4; ++i) {                                                             \
+            const int f = tid + NTHR * i;                                                                             \
+            const int nn = f / (TN / 4), cq = f % (TN / 4);                                                           \
+            rw[i] = ldg4(a.W + (int64_t)((cc) * KC + nn) * CPREV + k0 + 4 * cq);                                      \
+        }                                                                                                             \
+    }
 
-    load_chunk(0);
+    DGRAD_LOAD(0);
     for (int c = 0; c < nchunk; ++c) {
 #pragma unroll
         for (int i = 0; i < NA4; ++i) {
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(128 * WN) void dgrad_kernel(DgradArgs a)
                 const float xh = (yv[j] - coefS[CRED + n]) * coefS[2 * CRED + n];
                 const float dy = coefS[n] * (dz - w * fmaf(xh, coefS[4 * CRED + n], coefS[3 * CRED + n]));
                 dv[j] = ok ? dy : 0.f;
-                As[(4 * kq + j) * LDT + r] = dv[j];
+                As[(4 * kq + j) * LDA + r] = dv[j];
             }
             if constexpr (LAYER == 3) {
                 if (ok && blockIdx.y == 0)
@@ -238,10 +242,11 @@ __global__ __launch_bounds__(128 * WN) void dgrad_kernel(DgradArgs a)
             sts4(Bs + nn * LDB + 4 * cq, rw[i]);
         }
         __syncthreads();
-        if (c + 1 < nchunk) load_chunk(c + 1);
-        mma_chunk<2, NT, LDT, LDB>(As, Bs, wm * 64, wn * 32 * NT, acc);
+        if (c + 1 < nchunk) DGRAD_LOAD(c + 1);
+        mma_chunk<MT, NT, LDA, LDB>(As, Bs, wm * 32 * MT, wn * 32 * NT, acc);
         __syncthreads();
     }
+#undef DGRAD_LOAD
 
     // ---- epilogue: ReLU mask of the previous layer, its BN-backward statistics
     constexpr int NS = (LAYER == 3) ? 2 : 4;
@@ -255,10 +260,10 @@ __global__ __launch_bounds__(128 * WN) void dgrad_kernel(DgradArgs a)
         if constexpr (LAYER == 3) {
             const float pm = a.bn_prev[2 * CPREV + col], pr = a.bn_prev[3 * CPREV + col];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    const int row = wm * 64 + mt * 32 + acc_row(reg, lh);
+                    const int row = wm * 32 * MT + mt * 32 + acc_row(reg, lh);
                     if (row < nvalid) {
                         const int64_t o = (grow0 + row) * CPREV + col;
                         const float yv = a.yprev[o];
@@ -271,10 +276,10 @@ __global__ __launch_bounds__(128 * WN) void dgrad_kernel(DgradArgs a)
         } else {
             const float al[3] = {ps * a.W1[3 * col], ps * a.W1[3 * col + 1], ps * a.W1[3 * col + 2]};
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    const int row = wm * 64 + mt * 32 + acc_row(reg, lh);
+                    const int row = wm * 32 * MT + mt * 32 + acc_row(reg, lh);
                     if (row < nvalid) {
                         const float4 u = uS[row];
                         const float dz = (l1_pre(al, pt, u.x, u.y, u.z) > 0.f) ? acc[mt][nt][reg] : 0.f;
@@ -329,7 +334,7 @@ struct WgradArgs {
 // rows of live tiles [s*tpb, (s+1)*tpb) and writes one partial; wgrad_reduce sums the live partials in a fixed
 // order (deterministic, no float atomics).
 template <int LAYER, int MT, int NT>
-__global__ __launch_bounds__(GT) void wgrad_kernel(WgradArgs a)
+__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ? 3 : 2, 4))) void wgrad_kernel(WgradArgs a)
 {
     constexpr int LDA = 64 * MT + 4, LDB = 64 * NT + 4;
     __shared__ __attribute__((aligned(16))) float As[KC * LDA];
@@ -549,12 +554,10 @@ static int launch_dgrad(const DgradArgs &a, int B, hipStream_t st)
 {
     if (a.CRED % 64 || a.CPREV % 64 || a.CRED > MAXC) return FCN_E_BADARG;
     const unsigned nt = (unsigned)(B * a.tps);
-    if (FCN_WIDE_TILES && a.CPREV % 256 == 0) {
-        hipLaunchKernelGGL((dgrad_kernel<LAYER, 2, 4>), dim3(nt, a.CPREV / 256), dim3(512), 0, st, a);
-    } else if (a.CPREV % 128 == 0) {
-        hipLaunchKernelGGL((dgrad_kernel<LAYER, 2, 2>), dim3(nt, a.CPREV / 128), dim3(256), 0, st, a);
-    } else {
-        hipLaunchKernelGGL((dgrad_kernel<LAYER, 1, 2>), dim3(nt, a.CPREV / 64), dim3(256), 0, st, a);
+    if (a.CPREV % 128 == 0) {          // 64 x 128 tiles, two workgroups per listed 128-row tile
+        hipLaunchKernelGGL((dgrad_kernel<LAYER, 1, 2, 2>), dim3(2 * nt, a.CPREV / 128), dim3(256), 0, st, a);
+    } else {                            // 64 x 64 tiles (the 64-channel layers of scales 1 and 2: few column tiles)
+        hipLaunchKernelGGL((dgrad_kernel<LAYER, 1, 1, 2>), dim3(2 * nt, a.CPREV / 64), dim3(256), 0, st, a);
     }
     FCN_CHECK_LAUNCH();
     return 0;
@@ -565,9 +568,11 @@ static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, hipStream_t st, flo
 {
     const bool m2 = (a.COUT % 128 == 0), n2 = (a.CIN % 128 == 0);
     const int oy = a.COUT / (m2 ? 128 : 64), oz = a.CIN / (n2 ? 128 : 64);
-    // ~768 workgroups per launch; each split takes ceil(live_tiles / nsplit) row tiles (computed on the device,
-    // where the live count is known), so splits stay balanced whatever the occupancy of the frustums.
-    int nsplit = 768 / (oy * oz);
+    // one full wave of workgroups per launch (768 = 3 per CU; the 128 x 128 tile of layer 2 needs 182 VGPRs: 2 per CU);
+    // each split takes ceil(live_tiles / nsplit) row tiles (computed on the device, where the live count is known),
+    // so splits stay balanced whatever the occupancy of the frustums.
+    const int slots = (LAYER == 2 && m2 && n2) ? 512 : 768;
+    int nsplit = slots / (oy * oz);
     if (nsplit < 1) nsplit = 1;
     if (nsplit > B * a.tps) nsplit = B * a.tps;
     if (nsplit > nsplit_cap) nsplit = nsplit_cap;

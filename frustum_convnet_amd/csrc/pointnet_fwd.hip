@@ -102,7 +102,7 @@ struct FwdArgs {
 // Workgroup = 2 x WN waves; tile = 128 rows x (32*NT*WN) output channels.  WN = 4 (512 threads) shares one
 // staged A tile between 256 output columns, halving the BN+ReLU staging work per output element.
 template <int MODE, int NT, int WN>
-__global__ __launch_bounds__(128 * WN) void fwd_gemm_kernel(FwdArgs a)
+__global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(3, 4))) void fwd_gemm_kernel(FwdArgs a)
 {
     constexpr int NTHR = 128 * WN;
     constexpr int TN = 32 * NT * WN;
