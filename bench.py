@@ -197,7 +197,11 @@ def main():
     if use_graph:
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            if world > 1:
+                torch.distributed.barrier()          # no collective in flight while the step is being captured
+                torch.cuda.synchronize()
+            # thread_local: RCCL's watchdog thread may query events while this thread captures
+            with torch.cuda.graph(graph, capture_error_mode="thread_local" if world > 1 else "global"):
                 loss = fwd_bwd()
                 if world == 1 and optim:
                     state.adam_step()
@@ -266,6 +270,17 @@ def main():
             out["roofline"] = roofline_probe(model, data)
         except Exception as e:  # noqa
             out["roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if world == 1:
+        # whole-step HBM roofline (BASELINE.json's "HBM roofline %"): fabric bytes of one step from the committed
+        # rocprofv3 --pmc passes (profiles/pmc_traffic.json, tools_gpu_traffic.sh) over THIS command, divided by the
+        # step time measured now; peak 8 TB/s (MI355X_MICROARCH.md).  null when no PMC summary is committed.
+        try:
+            sb = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["step"]["bytes_per_step"]
+            tbps = sb / (ms_per_step * 1e-3) / 1e12
+            out["hbm_roofline"] = {"bound": "hbm", "bytes_per_step": sb, "bytes_per_frustum": round(sb / a.batch),
+                                   "achieved": round(tbps, 3), "peak": 8.0, "unit": "TB/s", "frac": round(tbps / 8.0, 4)}
+        except Exception:  # noqa
+            out["hbm_roofline"] = None
     if world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_batch, a.npoint)
