@@ -798,11 +798,12 @@ struct CnPlan {
 
 static int conv_len(int L, int k, int s, int p) { return (L + 2 * p - k) / s + 1; }
 
-// rows per wgrad split (multiple of 32): ~768 workgroups, >= 64 rows each
+// rows per wgrad split (multiple of 32): ~768 workgroups, >= 256 rows each
 static int pick_wrows(int R, int out_tiles)
 {
-    int ns = 768 / (out_tiles > 0 ? out_tiles : 1);
-    if (ns > (R + 63) / 64) ns = (R + 63) / 64;
+    const int target = 768, minrows = 256;      // swept on MI355X: fewer, fatter splits beat more partial traffic
+    int ns = target / (out_tiles > 0 ? out_tiles : 1);
+    if (ns > (R + minrows - 1) / minrows) ns = (R + minrows - 1) / minrows;
     if (ns < 1) ns = 1;
     int rows = (R + ns - 1) / ns;
     rows = (rows + 31) / 32 * 32;
