@@ -46,8 +46,14 @@ class PnWs(ctypes.Structure):
                 ("coef", c_fp), ("partial", c_fp), ("nsplit", ctypes.c_int32)]
 
 
+class InpDesc(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("pt_stride", ctypes.c_int32), ("L", ctypes.c_int32 * 4),
+                ("stride", ctypes.c_double * 4), ("max_depth", ctypes.c_double),
+                ("random_flip", ctypes.c_int32), ("random_shift", ctypes.c_int32)]
+
+
 EXPORTS = ("fcn_arch", "fcn_query_depth_point_f32", "fcn_pn_wgrad_rows", "fcn_pn_compact",
-           "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_adam_step_f32", "fcn_adam_step_slots",
+           "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_adam_step_f32", "fcn_adam_step_slots", "fcn_prepare_inputs",
            "fcn_convnet_sizes", "fcn_convnet_forward", "fcn_convnet_backward")
 
 _lib = None
@@ -96,6 +102,8 @@ def lib():
     L.fcn_det_loss_tail.argtypes = [c_fp] * 9 + [ctypes.c_int] * 4 + [ctypes.c_float] * 4 + [c_fp] * 4
     L.fcn_adam_step_f32.restype = ctypes.c_int
     L.fcn_adam_step_f32.argtypes = [c_fp] * 4 + [ctypes.c_int64] + [c_fp] * 3
+    L.fcn_prepare_inputs.restype = ctypes.c_int
+    L.fcn_prepare_inputs.argtypes = [ctypes.POINTER(InpDesc)] + [c_fp] * 13 + [c_fp * 4] + [c_fp] * 7
     L.fcn_adam_step_slots.restype = ctypes.c_int64
     L.fcn_adam_step_slots.argtypes = [ctypes.c_int64]
     L.fcn_det_loss_tail_rows.restype = ctypes.c_int

@@ -1,0 +1,154 @@
+// On-device construction of one training batch from raw frustum records: what the reference's data loader does per
+// sample on the host in numpy (datasets/provider_sample.py::ProviderDataset.__getitem__ :137-262 with generate_ref
+// :291-327, generate_labels :270-289, centre-view helpers :329-372; datasets/data_utils.py rotate_pc_along_y :7-21,
+// compute_box_3d :44-70, project_image_to_rect :73-93) and collates into the dict PointNetDet.forward consumes.
+// One workgroup per frustum; HBM/latency-bound gather + a few hundred fp64 operations -- no GEMM in sight.
+//   points:  resample (indices drawn on the host: the reference's np.random.choice), rotate to the frustum's centre
+//            view, optional x-flip and depth shift, written channel-major (B,3,N) with lanes along N
+//   centres: arange(0, max_depth, stride) + stride/2 on the ray through the 2-D box centre (calibration P), rotated
+//   labels:  +1 inside the half-size box, -1 inside the full box, nearest centre when none is inside the half box
+// fp64 where numpy computes in fp64, rounded to fp32 exactly where the reference stores fp32.
+#include "fcn_common.h"
+#include "../../include/fcn_hip.h"
+
+#define INP_T 256
+
+struct InpArgs {
+    fcn_inp_desc d;
+    const float *raw;
+    const int64_t *off, *raw_seg;
+    const int32_t *choice;
+    const double *fangle, *box2d, *P, *corners, *heading, *size, *coin, *normal;
+    float *pc, *ref[4];
+    int64_t *cls;
+    float *center, *head, *osize, *rot;
+    int64_t *seg;
+};
+
+__device__ __forceinline__ bool inp_in_box(double dx, double dy, double dz, double c, double s, double l, double w, double h)
+{
+    const double lx = c * dx - s * dz, lz = s * dx + c * dz;
+    return fabs(lx) <= l / 2.0 && fabs(dy) <= h / 2.0 && fabs(lz) <= w / 2.0;
+}
+
+__global__ __launch_bounds__(INP_T) void prepare_inputs_kernel(InpArgs a)
+{
+    __shared__ double sdist[INP_T];
+    __shared__ int sidx[INP_T];
+    __shared__ int sany;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int N = a.d.N;
+    // ---- per-frustum scalars (every thread computes the same values)
+    const double rot = M_PI / 2.0 + a.fangle[b];
+    const double c = cos(rot), s = sin(rot);
+    const double *cr = a.corners + (int64_t)b * 24;
+    const double c0x = (cr[0] + cr[18]) / 2.0, c0y = (cr[1] + cr[19]) / 2.0, c0z = (cr[2] + cr[20]) / 2.0;
+    double cx = c0x * c + c0z * (-s), cy = c0y, cz = c0x * s + c0z * c;
+    double ang = a.heading[b] - rot;
+    const bool flip = a.d.random_flip && a.coin[b] > 0.5;
+    if (flip) { cx = -cx; ang = M_PI - ang; }
+    const double sl = a.size[3 * b], sw = a.size[3 * b + 1], sh = a.size[3 * b + 2];
+    double shift = 0.0;
+    if (a.d.random_shift) {
+        const double dist = sqrt(sl * sl + sw * sw);
+        shift = fmin(fmax(a.normal[b] * dist * 0.2, -0.5 * dist), 0.5 * dist);
+        shift = fmin(fmax(shift + cz, 0.0), a.d.max_depth) - cz;
+        cz += shift;
+    }
+    if (tid == 0) {
+        a.center[3 * b] = (float)cx; a.center[3 * b + 1] = (float)cy; a.center[3 * b + 2] = (float)cz;
+        a.head[b] = (float)ang;
+        a.osize[3 * b] = (float)sl; a.osize[3 * b + 1] = (float)sw; a.osize[3 * b + 2] = (float)sh;
+        a.rot[b] = (float)rot;
+    }
+    // ---- points
+    const int64_t o0 = a.off[b];
+    const int ps = a.d.pt_stride;
+    for (int i = tid; i < N; i += INP_T) {
+        const int64_t j = o0 + a.choice[(int64_t)b * N + i];
+        const float *p = a.raw + j * ps;
+        const double x = p[0], z = p[2];
+        float xr = (float)(x * c + z * (-s));              // the reference stores the rotated record back as float32
+        float zr = (float)(x * s + z * c);
+        if (flip) xr = -xr;
+        if (a.d.random_shift) zr = (float)((double)zr + shift);
+        float *o = a.pc + (int64_t)b * 3 * N;
+        o[i] = xr; o[N + i] = p[1]; o[2 * N + i] = zr;
+        if (a.seg) a.seg[(int64_t)b * N + i] = a.raw_seg[j];
+    }
+    // ---- frustum centres of the four strides, labels on stride 2
+    const double *P = a.P + (int64_t)b * 12;
+    const double cu = P[2], cv = P[6], fu = P[0], fv = P[5];
+    const double bx = P[3] / (-fu), by = P[7] / (-fv);
+    const double u0 = (a.box2d[4 * b] + a.box2d[4 * b + 2]) / 2.0, v0 = (a.box2d[4 * b + 1] + a.box2d[4 * b + 3]) / 2.0;
+    const double ca = cos(ang), sa = sin(ang);
+    double best = 1e300;
+    int bidx = 0x7fffffff;
+    bool any1 = false;
+    if (tid == 0) sany = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (int sc = 0; sc < 4; ++sc) {
+        const int L = a.d.L[sc];
+        const double st = a.d.stride[sc];
+        for (int l = tid; l < L; l += INP_T) {
+            const double z = (double)l * st + st / 2.0;
+            const double x = ((u0 - cu) * z) / fu + bx, y = ((v0 - cv) * z) / fv + by;
+            double xr = x * c + z * (-s);
+            const double zr = x * s + z * c;
+            if (flip) xr = -xr;
+            float *o = a.ref[sc] + (int64_t)b * 3 * L;
+            o[l] = (float)xr; o[L + l] = (float)y; o[2 * L + l] = (float)zr;
+            if (sc == 1 && a.cls) {
+                const double dx = xr - cx, dy = y - cy, dz = zr - cz;
+                const bool in1 = inp_in_box(dx, dy, dz, ca, sa, sl * 0.5, sw * 0.5, sh * 0.5);
+                const bool in2 = inp_in_box(dx, dy, dz, ca, sa, sl, sw, sh);
+                a.cls[(int64_t)b * L + l] = in1 ? 1 : (in2 ? -1 : 0);
+                any1 = any1 || in1;
+                const double dd = sqrt(dx * dx + dy * dy + dz * dz);
+                if (dd < best) { best = dd; bidx = l; }       // l ascends per thread: first minimum kept
+            }
+        }
+    }
+    if (!a.cls) return;
+    if (any1) sany = 1;
+    sdist[tid] = best; sidx[tid] = bidx;
+    __syncthreads();
+    if (sany) return;
+    // nobody inside the half-size box: the nearest centre is the positive (np.argmin: first of equal minima)
+    for (int o = INP_T / 2; o > 0; o >>= 1) {
+        if (tid < o) {
+            const double d2 = sdist[tid + o];
+            const int i2 = sidx[tid + o];
+            if (d2 < sdist[tid] || (d2 == sdist[tid] && i2 < sidx[tid])) { sdist[tid] = d2; sidx[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && sidx[0] != 0x7fffffff) a.cls[(int64_t)b * a.d.L[1] + sidx[0]] = 1;
+}
+
+extern "C" int fcn_prepare_inputs(const fcn_inp_desc *d, const float *raw_pts, const int64_t *pt_off, const int64_t *raw_seg,
+                                  const int32_t *choice, const double *frustum_angle, const double *box2d, const double *P,
+                                  const double *box3d_corners, const double *heading, const double *size,
+                                  const double *coin, const double *normal, float *point_cloud, float *const center_ref[4],
+                                  int64_t *cls_label, float *box3d_center, float *box3d_heading, float *box3d_size,
+                                  float *rot_angle, int64_t *seg_label, void *stream)
+{
+    if (!d || !raw_pts || !pt_off || !choice || !frustum_angle || !box2d || !P || !point_cloud || !center_ref ||
+        !box3d_center || !box3d_heading || !box3d_size || !rot_angle)
+        return FCN_E_BADARG;
+    if (!box3d_corners || !heading || !size) return FCN_E_BADARG;
+    if (d->B <= 0 || d->N <= 0 || d->pt_stride < 3) return FCN_E_BADARG;
+    if ((d->random_flip && !coin) || (d->random_shift && !normal) || (seg_label && !raw_seg)) return FCN_E_BADARG;
+    for (int s = 0; s < 4; ++s)
+        if (d->L[s] <= 0 || !(d->stride[s] > 0.0) || !center_ref[s]) return FCN_E_BADARG;
+    InpArgs a;
+    a.d = *d; a.raw = raw_pts; a.off = pt_off; a.raw_seg = raw_seg; a.choice = choice; a.fangle = frustum_angle;
+    a.box2d = box2d; a.P = P; a.corners = box3d_corners; a.heading = heading; a.size = size; a.coin = coin; a.normal = normal;
+    a.pc = point_cloud;
+    for (int s = 0; s < 4; ++s) a.ref[s] = center_ref[s];
+    a.cls = cls_label; a.center = box3d_center; a.head = box3d_heading; a.osize = box3d_size; a.rot = rot_angle; a.seg = seg_label;
+    hipLaunchKernelGGL(prepare_inputs_kernel, dim3(d->B), dim3(INP_T), 0, (hipStream_t)stream, a);
+    FCN_CHECK_LAUNCH();
+    return 0;
+}

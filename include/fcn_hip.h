@@ -203,6 +203,29 @@ int64_t fcn_adam_step_slots(int64_t n);
 int fcn_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                       const float *hyper6, int64_t *step_slots, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * On-device construction of one training batch from raw frustum records: replaces the
+ * per-sample numpy work of datasets/provider_sample.py::ProviderDataset.__getitem__ (:137-262; generate_ref :291-327,
+ * generate_labels :270-289, centre-view helpers :329-372) and torch's default_collate (:396-397).
+ *   raw_pts (sum n_b, pt_stride) float32 records in rect camera coordinates, pt_off (B+1) int64 row offsets,
+ *   raw_seg (sum n_b) int64 or NULL, choice (B,N) int32 resample indices (the reference's np.random.choice),
+ *   frustum_angle (B), box2d (B,4), P (B,3,4), box3d_corners (B,8,3), heading (B), size (B,3) (l,w,h), coin (B)
+ *   (flip when > 0.5), normal (B) (depth-shift draw): all fp64 like the pickled records.
+ * Outputs (caller-owned): point_cloud (B,3,N), center_ref[s] (B,3,L[s]), cls_label (B,L[1]) int64 in {-1,0,1} (NULL to
+ * skip), box3d_center (B,3), box3d_heading (B,1), box3d_size (B,3), rot_angle (B,1), seg_label (B,N) int64 or NULL. */
+typedef struct fcn_inp_desc {
+    int32_t B, N, pt_stride;     /* frustums, points per frustum after resampling, floats per raw record (>= 3) */
+    int32_t L[4];                /* centres per stride: len(arange(0, max_depth, stride[s])) */
+    double  stride[4], max_depth;
+    int32_t random_flip, random_shift;
+} fcn_inp_desc;
+int fcn_prepare_inputs(const fcn_inp_desc *d, const float *raw_pts, const int64_t *pt_off, const int64_t *raw_seg,
+                       const int32_t *choice, const double *frustum_angle, const double *box2d, const double *P,
+                       const double *box3d_corners, const double *heading, const double *size,
+                       const double *coin, const double *normal, float *point_cloud, float *const center_ref[4],
+                       int64_t *cls_label, float *box3d_center, float *box3d_heading, float *box3d_size,
+                       float *rot_angle, int64_t *seg_label, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

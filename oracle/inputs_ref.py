@@ -1,0 +1,114 @@
+"""TEST INFRASTRUCTURE (oracle) -- CPU restatement of the reference's per-sample input construction, the row
+"next-1" of SURVEY.md section 8f: datasets/provider_sample.py::ProviderDataset.__getitem__ (:137-262) with
+generate_ref (:291-327), generate_labels (:270-289) and the centre-view helpers (:329-372), on top of
+datasets/data_utils.py (rotate_pc_along_y :7-21, compute_box_3d :44-70, project_image_to_rect :73-93).
+
+Pure numpy, fp64 where the reference computes in fp64, rounded to fp32 where it stores fp32.  Randomness is an INPUT:
+the three draws the reference takes per sample (np.random.choice resample, np.random.random flip coin,
+np.random.randn shift) are passed in, so the restatement is deterministic and comparable.
+
+Pinned by tests/golden/inputs_kitti_b6.npz: outputs of the reference's own ProviderDataset run on a synthetic pickle with
+its RNG calls recorded (tests/golden/make_golden_inputs.py; tests/test_oracle_inputs.py).  One deliberate difference:
+the reference decides "centre inside the (half) box" with scipy's Delaunay hull (data_utils.py:24-37); here it is the
+closed-form oriented-box test, identical except for points within qhull's ~1e-12 tolerance of a face.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import numpy as np
+
+
+def rotate_along_y(xz, rot_angle):
+    """(n,2) columns (x, z) -> rotated, fp64 (data_utils.py:16-20: pc[:, [0,2]] . rotmat^T)."""
+    c, s = np.cos(rot_angle), np.sin(rot_angle)
+    x, z = xz[:, 0].astype(np.float64), xz[:, 1].astype(np.float64)
+    return np.stack([x * c + z * (-s), x * s + z * c], 1)
+
+
+def generate_ref(box2d, P, strides, max_depth):
+    """provider_sample.py:291-327 + data_utils.py:73-93: frustum centres on the ray through the 2-D box centre."""
+    cu, cv, fu, fv = P[0, 2], P[1, 2], P[0, 0], P[1, 1]
+    bx, by = P[0, 3] / (-fu), P[1, 3] / (-fv)
+    cx, cy = (box2d[0] + box2d[2]) / 2.0, (box2d[1] + box2d[3]) / 2.0
+    refs = []
+    for s in strides:
+        z = np.arange(0, max_depth, s) + s / 2.0
+        x = ((cx - cu) * z) / fu + bx
+        y = ((cy - cv) * z) / fv + by
+        refs.append(np.stack([x, y, z], 1))
+    return refs
+
+
+def in_box(p, center, dims, angle):
+    """Closed-form stand-in for extract_pc_in_box3d(p, compute_box_3d(center, dims, angle)) (data_utils.py:31-70):
+    corners = roty(angle) . (+-l/2, +-h/2, +-w/2) + center  =>  local = roty(angle)^T (p - center)."""
+    c, s = np.cos(angle), np.sin(angle)
+    d = p - center[None, :]
+    lx = c * d[:, 0] - s * d[:, 2]
+    lz = s * d[:, 0] + c * d[:, 2]
+    l, w, h = dims
+    return (np.abs(lx) <= l / 2.0) & (np.abs(d[:, 1]) <= h / 2.0) & (np.abs(lz) <= w / 2.0)
+
+
+def generate_labels(center, size, angle, ref):
+    """provider_sample.py:270-289: 1 inside the half-size box, -1 inside the full box, else 0; nearest centre = 1
+    when no centre is inside the half-size box."""
+    labels = np.zeros(len(ref), dtype=np.int64)
+    inside1 = in_box(ref, center, size * 0.5, angle)
+    inside2 = in_box(ref, center, size, angle)
+    labels[inside2] = -1
+    labels[inside1] = 1
+    if inside1.sum() == 0:
+        dis = np.sqrt(((ref - center[None, :]) ** 2).sum(1))
+        labels[np.argmin(dis)] = 1
+    return labels
+
+
+def prepare_sample(raw_pts, raw_seg, box2d, P, box3d_corners, heading, size, frustum_angle, choice, coin, normal,
+                   strides, max_depth, random_flip=True, random_shift=True):
+    """One training sample with rotate-to-centre (cfg.DATA.RTC), provider_sample.py:137-262."""
+    rot = np.pi / 2.0 + frustum_angle                                           # :329-332
+    xz = rotate_along_y(raw_pts[:, [0, 2]], rot).astype(np.float32)             # stored back into the float32 record
+    pts = np.stack([xz[:, 0], raw_pts[:, 1].astype(np.float32), xz[:, 1]], 1)[choice]   # :155-170
+    seg = raw_seg[choice]
+    refs = generate_ref(box2d, P, strides, max_depth)
+    for r in refs:                                                              # :176-180
+        r[:, [0, 2]] = rotate_along_y(r[:, [0, 2]], rot)
+    c0 = (box3d_corners[0] + box3d_corners[6]) / 2.0                            # :339-346
+    cxz = rotate_along_y(c0[None, [0, 2]], rot)[0]
+    center = np.array([cxz[0], c0[1], cxz[1]], dtype=np.float64)
+    angle = heading - rot                                                       # :214-218
+    if random_flip and coin > 0.5:                                              # :222-233
+        pts[:, 0] *= -1
+        center[0] *= -1
+        angle = np.pi - angle
+        for r in refs:
+            r[:, 0] *= -1
+    if random_shift:                                                            # :235-242
+        l, w, h = size
+        dist = np.sqrt(np.sum(l ** 2 + w ** 2))
+        shift = np.clip(normal * dist * 0.2, -0.5 * dist, 0.5 * dist)
+        shift = np.clip(shift + center[2], 0, max_depth) - center[2]
+        pts[:, 2] = (pts[:, 2].astype(np.float64) + shift).astype(np.float32)   # float32 record += float64 scalar
+        center[2] += shift
+    labels = generate_labels(center, np.asarray(size, dtype=np.float64), angle, refs[1])
+    out = {"point_cloud": np.ascontiguousarray(pts.T), "rot_angle": np.array([rot], dtype=np.float32),
+           "cls_label": labels, "box3d_center": center.astype(np.float32),
+           "box3d_heading": np.array([angle], dtype=np.float32), "box3d_size": np.asarray(size).astype(np.float32),
+           "seg_label": seg.astype(np.int64)}
+    for i, r in enumerate(refs):
+        out["center_ref%d" % (i + 1)] = np.ascontiguousarray(r.astype(np.float32).T)
+    return out
+
+
+def prepare_batch(rec, strides, max_depth, random_flip=True, random_shift=True):
+    """rec: dict with raw_points (sum n, C) float32, raw_seg, raw_counts, box2d, P, box3d_corners, heading, size,
+    frustum_angle, draw_choice, draw_coin, draw_normal (the fixture's layout).  Returns the collated batch."""
+    offs = np.concatenate([[0], np.cumsum(rec["raw_counts"])])
+    items = []
+    for b in range(len(rec["raw_counts"])):
+        sl = slice(int(offs[b]), int(offs[b + 1]))
+        items.append(prepare_sample(rec["raw_points"][sl], rec["raw_seg"][sl], rec["box2d"][b], rec["P"][b],
+                                    rec["box3d_corners"][b], float(rec["heading"][b]), rec["size"][b],
+                                    float(rec["frustum_angle"][b]), rec["draw_choice"][b], float(rec["draw_coin"][b]),
+                                    float(rec["draw_normal"][b]), strides, max_depth, random_flip, random_shift))
+    return {k: np.stack([it[k] for it in items]) for k in items[0]}
