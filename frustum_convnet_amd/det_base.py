@@ -24,7 +24,7 @@ from .config import cfg
 from .dataset_info import DATASET_INFO
 from .common import Conv1d, Conv2d, DeConv1d, init_params, softmax_focal_loss_ignore, get_accuracy, masked_mean
 from .query_depth_point import QueryDepthPoint
-from .pointnet_fused import WorkspacePool, pointnet_pooled
+from .pointnet_fused import WorkspacePool, pointnet_pooled, launch_pooled, attach_pooled
 from . import box_ops
 
 
@@ -69,6 +69,18 @@ class PointNetModule(nn.Module):
                                      pc.contiguous(), new_pc.contiguous(), one_hot_vec, bufs, params, nlc=nlc)
         return feat
 
+    def launch_pooled(self, pc, new_pc, one_hot_vec=None, nlc=False):
+        """Enqueue this scale's forward kernels now, create the autograd node later with attach_pooled()."""
+        params, bufs = self._param_pack()
+        bn = self.conv1[1]
+        return launch_pooled(self._pool, self.dist, self.nsample, self.training, bn.eps,
+                             0.1 if bn.momentum is None else bn.momentum,
+                             pc.contiguous(), new_pc.contiguous(), one_hot_vec, bufs, params, nlc=nlc)
+
+    def attach_pooled(self, handle):
+        feat, _, _ = attach_pooled(self._pool, handle)
+        return feat
+
     def forward(self, pc, feat, new_pc=None):
         """Reference-shaped output (B, C3, L, nsample), masked.  Inspection / parity API: it expands the
         fused path's per-entry activations back to the dense slots with device-side indexing and carries
@@ -110,23 +122,41 @@ class PointNetFeat(nn.Module):
             return tuple(net.forward_pooled(point_cloud, ref, one_hot_vec, nlc) for net, ref in zip(nets, sample_pc))
         # The four scales are independent until the FCN: scales 1-3 run on three forked HIP streams and the widest
         # (scale 4, the long pole) on the current stream, so one scale's tail (a few workgroups left on 256 CUs)
-        # overlaps the others' work.  autograd replays each scale's backward on the stream its forward ran on, so the
-        # backward overlaps the same way; the fork/join is captured as parallel branches of the step's hipGraph.
-        # Scale 4 stays on the current stream because its backward forks a second stream for the weight gradients
-        # and ROCm 7.2 stream capture crashes on a fork from an already-forked stream (flat forks only).
-        cur = torch.cuda.current_stream(point_cloud.device)
-        streams = self._streams(point_cloud.device)
-        outs = [None] * 4
-        forked = (2, 0, 1)
-        for s in forked:
+        # overlaps the others' work; the fork/join is captured as parallel branches of the step's hipGraph.
+        #  * Launch order is heaviest first (4, 3, 1, 2): the graph executor starts branches in capture order, and the
+        #    long pole must not start after the small scales have come and gone.
+        #  * Node creation order is lightest first (1, 2, 3, 4): autograd replays each scale's backward on the stream
+        #    its node was created under, in REVERSE creation order -- heaviest first again.
+        #    launch_pooled() / attach_pooled() separate the two orders.
+        #  * Scale 4 stays on the current stream because its backward forks a second stream for the weight gradients
+        #    and ROCm 7.2 stream capture crashes on a fork from an already-forked stream (flat forks only); the forked
+        #    streams wait on an event recorded BEFORE scale 4's kernels, not on the stream itself.
+        dev = point_cloud.device
+        cur = torch.cuda.current_stream(dev)
+        streams = self._streams(dev)              # for scales 1, 2, 3
+        fork = self._fork_event(dev)
+        fork.record(cur)
+        handles = [None] * 4
+        handles[3] = nets[3].launch_pooled(point_cloud, sample_pc[3], one_hot_vec, nlc)
+        for s in (2, 0, 1):
             st = streams[s]
-            st.wait_stream(cur)
+            st.wait_event(fork)
             with torch.cuda.stream(st):
-                outs[s] = nets[s].forward_pooled(point_cloud, sample_pc[s], one_hot_vec, nlc)
-        outs[3] = nets[3].forward_pooled(point_cloud, sample_pc[3], one_hot_vec, nlc)
-        for s in forked:
+                handles[s] = nets[s].launch_pooled(point_cloud, sample_pc[s], one_hot_vec, nlc)
+        outs = [None] * 4
+        for s in (0, 1, 2):
+            with torch.cuda.stream(streams[s]):
+                outs[s] = nets[s].attach_pooled(handles[s])
+        outs[3] = nets[3].attach_pooled(handles[3])
+        for s in (0, 1, 2):
             cur.wait_stream(streams[s])
         return tuple(outs)
+
+    def _fork_event(self, device):
+        key = "ev" + str(device)
+        if key not in self._stream_cache:
+            self._stream_cache[key] = torch.cuda.Event(enable_timing=False)
+        return self._stream_cache[key]
 
     def _streams(self, device):
         key = str(device)

@@ -124,11 +124,14 @@ class _PointNetPooled(torch.autograd.Function):
     never needs gradients w.r.t. the point cloud either: inputs do not require grad)."""
 
     @staticmethod
-    def forward(ctx, pool, cfgt, pc, ref, one_hot, bufs, gdst, W1, g1, b1, W2, g2, b2, W3, g3, b3):
+    def forward(ctx, pool, cfgt, pc, ref, one_hot, bufs, gdst, launched, W1, g1, b1, W2, g2, b2, W3, g3, b3):
         plist = (W1, g1, b1, W2, g2, b2, W3, g3, b3)
         ctx.gdst = gdst
         need_grad = bool(cfgt[5])     # decided by the caller: grad mode is always off inside Function.forward
-        feat, idx, cnt, ws, desc, keep = _forward_impl(pool, cfgt, pc, ref, one_hot, bufs, plist, need_grad)
+        if launched is not None:      # kernels already enqueued by launch_pooled(); this call only creates the node
+            feat, idx, cnt, ws, desc, keep = launched
+        else:
+            feat, idx, cnt, ws, desc, keep = _forward_impl(pool, cfgt, pc, ref, one_hot, bufs, plist, need_grad)
         ctx.pool = pool
         ctx.live = need_grad
         if need_grad:
@@ -143,7 +146,7 @@ class _PointNetPooled(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dfeat, _didx, _dcnt):
         if dfeat is None:
-            return (None,) * 16
+            return (None,) * 17
         if not ctx.live:
             raise RuntimeError("fused PointNet forward ran without saved state (eval mode or no_grad)")
         L = _native.lib()
@@ -177,19 +180,45 @@ class _PointNetPooled(torch.autograd.Function):
         s1, s2, s3 = ctx.shapes
         outs = [dW[0].view(s1), dg[0], db[0], dW[1].view(s2), dg[1], db[1], dW[2].view(s3), dg[2], db[2]]
         outs = [None if gd[j] is not None else t for j, t in enumerate(outs)]
-        return (None, None, None, None, None, None, None) + tuple(outs)
+        return (None, None, None, None, None, None, None, None) + tuple(outs)
+
+
+def _cfg_tuple(dist, nsample, training, eps, momentum, params, nlc):
+    need_grad = bool(training) and torch.is_grad_enabled() and any(t.requires_grad for t in params)
+    return (float(dist), int(nsample), bool(training), float(eps), float(momentum), need_grad, bool(nlc))
+
+
+def _check_device(pc):
+    if not pc.is_cuda:
+        raise RuntimeError("frustum_convnet_amd: the PointNet hot path runs on an MI355X only "
+                           "(got a %s tensor); there is no CPU fallback" % pc.device)
+
+
+def launch_pooled(pool, dist, nsample, training, eps, momentum, pc, ref, one_hot, bufs, params, nlc=False):
+    """Enqueues the forward kernels of one scale on the current stream WITHOUT creating the autograd node and returns a
+    handle for attach_pooled().  Splitting the two lets a caller launch the scales heaviest-first while creating their
+    nodes lightest-first -- autograd runs backward nodes in reverse creation order, so the backward is heaviest-first too."""
+    _check_device(pc)
+    cfgt = _cfg_tuple(dist, nsample, training, eps, momentum, params, nlc)
+    with torch.no_grad():
+        launched = _forward_impl(pool, cfgt, pc, ref, one_hot, bufs, params, cfgt[5])
+    return (cfgt, pc, ref, one_hot, bufs, params, launched)
+
+
+def attach_pooled(pool, handle):
+    """The differentiable output of a launch_pooled() handle (call it under the stream the kernels were launched on)."""
+    cfgt, pc, ref, one_hot, bufs, params, launched = handle
+    gdst = tuple(getattr(t, "_fcn_grad", None) for t in params)
+    return _PointNetPooled.apply(pool, cfgt, pc, ref, one_hot, bufs, gdst, launched, *params)
 
 
 def pointnet_pooled(pool, dist, nsample, training, eps, momentum, pc, ref, one_hot, bufs, params, nlc=False):
     """params = (W1,g1,b1,W2,g2,b2,W3,g3,b3); bufs = ([rm1,rm2,rm3],[rv1,rv2,rv3],[nbt1,nbt2,nbt3]).
     nlc=True returns position-major (B, L, C3) features without the one-hot rows (input of the fused ConvFeatNet)."""
-    if not pc.is_cuda:
-        raise RuntimeError("frustum_convnet_amd: the PointNet hot path runs on an MI355X only "
-                           "(got a %s tensor); there is no CPU fallback" % pc.device)
-    need_grad = bool(training) and torch.is_grad_enabled() and any(t.requires_grad for t in params)
-    cfgt = (float(dist), int(nsample), bool(training), float(eps), float(momentum), need_grad, bool(nlc))
+    _check_device(pc)
+    cfgt = _cfg_tuple(dist, nsample, training, eps, momentum, params, nlc)
     gdst = tuple(getattr(t, "_fcn_grad", None) for t in params)
-    return _PointNetPooled.apply(pool, cfgt, pc, ref, one_hot, bufs, gdst, *params)
+    return _PointNetPooled.apply(pool, cfgt, pc, ref, one_hot, bufs, gdst, None, *params)
 
 
 def dense_from_entries(pool, dist, nsample, training, eps, momentum, pc, ref, bufs, params):
