@@ -22,7 +22,7 @@ class PnDesc(ctypes.Structure):
 class CnDesc(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("L", ctypes.c_int32 * 4), ("nvec", ctypes.c_int32),
                 ("reg_out", ctypes.c_int32), ("training", ctypes.c_int32),
-                ("eps", ctypes.c_float), ("momentum", ctypes.c_float)]
+                ("eps", ctypes.c_float), ("momentum", ctypes.c_float), ("prepacked", ctypes.c_int32)]
 
 
 class CnParams(ctypes.Structure):
@@ -54,7 +54,7 @@ class InpDesc(ctypes.Structure):
 
 EXPORTS = ("fcn_arch", "fcn_query_depth_point_f32", "fcn_pn_wgrad_rows", "fcn_pn_compact",
            "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_adam_step_f32", "fcn_adam_step_slots", "fcn_prepare_inputs",
-           "fcn_convnet_sizes", "fcn_convnet_forward", "fcn_convnet_backward")
+           "fcn_convnet_sizes", "fcn_convnet_pack", "fcn_convnet_forward", "fcn_convnet_backward")
 
 _lib = None
 
@@ -110,6 +110,8 @@ def lib():
     L.fcn_det_loss_tail_rows.argtypes = [c_fp] * 8 + [ctypes.c_int] * 4 + [ctypes.c_float] * 4 + [c_fp] * 3
     L.fcn_convnet_sizes.restype = ctypes.c_int
     L.fcn_convnet_sizes.argtypes = [ctypes.POINTER(CnDesc), ctypes.POINTER(ctypes.c_int64 * 6)]
+    L.fcn_convnet_pack.restype = ctypes.c_int
+    L.fcn_convnet_pack.argtypes = [ctypes.POINTER(CnDesc), ctypes.POINTER(CnParams), ctypes.POINTER(CnWs), c_fp, c_fp]
     L.fcn_convnet_forward.restype = ctypes.c_int
     L.fcn_convnet_forward.argtypes = [ctypes.POINTER(CnDesc), ctypes.POINTER(CnParams), ctypes.POINTER(CnWs),
                                       c_fp * 4, c_fp, c_fp, c_fp]

@@ -931,6 +931,40 @@ static void cn_fill_pack(const fcn_cn_desc *d, const CnPlan &P, int l, CgPack &p
     p.nvec = d->nvec; p.cin_tot = P.cin_tot[l]; p.deconv_k = P.dk[l]; p.cout_t = 256;
 }
 
+// all weights -> packed (N, Ktot) layout in one launch (heads: rows 0..1 cls_out, 2.. reg_out); one-hot -> (B, 64)
+static int cn_pack(const fcn_cn_desc *d, const fcn_cn_params *p, const CnPlan &P, const CnOffsets &O, const fcn_cn_ws *ws,
+                   const float *one_hot, hipStream_t st)
+{
+    CgPackAll t;
+    t.pre[0] = 0;
+    for (int l = 0; l < CN_NLAYER; ++l) {
+        cn_fill_pack(d, P, l, t.p[l]);
+        t.src[l] = p->W[l]; t.dst[l] = ws->wp + O.wp[l];
+        t.pre[l + 1] = t.pre[l] + (int64_t)P.N[l] * P.Ktot[l];
+        t.nrow_real[l] = P.nrow_real[l];
+    }
+    t.oh = one_hot; t.oh64 = ws->oh64; t.B = d->B; t.nvec = d->nvec;
+    hipLaunchKernelGGL(cg_pack_kernel, dim3((unsigned)((t.pre[CN_NLAYER] + (int64_t)d->B * OH_PAD + 255) / 256)), dim3(256),
+                       0, st, t);
+    FCN_CHECK_LAUNCH();
+    return 0;
+}
+
+// The packing depends on the weights and the one-hot vector only: a caller may run it early on another stream (beside
+// the PointNet scales) and then call fcn_convnet_forward with d->prepacked = 1 once that stream is joined.
+extern "C" int fcn_convnet_pack(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws, const float *one_hot,
+                                void *stream)
+{
+    if (!d || !p || !ws || !ws->wp || !ws->oh64) return FCN_E_BADARG;
+    if (d->nvec > 0 && !one_hot) return FCN_E_BADARG;
+    if (d->nvec > OH_PAD) return FCN_E_LIMIT;
+    CnPlan P;
+    FCN_TRY(cn_make_plan(d, P));
+    CnOffsets O;
+    cn_offsets(d, P, O);
+    return cn_pack(d, p, P, O, ws, one_hot, (hipStream_t)stream);
+}
+
 extern "C" int fcn_convnet_forward(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
                                    const float *const feats[4], const float *one_hot, float *logits, void *stream)
 {
@@ -948,19 +982,7 @@ extern "C" int fcn_convnet_forward(const fcn_cn_desc *d, const fcn_cn_params *p,
         hipError_t e = hipMemsetAsync(ws->stat, 0, sizeof(double) * (size_t)O.st[CN_NLAYER], st);
         if (e != hipSuccess) return (int)e;
     }
-    // pack all weights in one launch (heads: rows 0..1 cls_out, 2.. reg_out)
-    CgPackAll t;
-    t.pre[0] = 0;
-    for (int l = 0; l < CN_NLAYER; ++l) {
-        cn_fill_pack(d, P, l, t.p[l]);
-        t.src[l] = p->W[l]; t.dst[l] = ws->wp + O.wp[l];
-        t.pre[l + 1] = t.pre[l] + (int64_t)P.N[l] * P.Ktot[l];
-        t.nrow_real[l] = P.nrow_real[l];
-    }
-    t.oh = one_hot; t.oh64 = ws->oh64; t.B = d->B; t.nvec = d->nvec;
-    hipLaunchKernelGGL(cg_pack_kernel, dim3((unsigned)((t.pre[CN_NLAYER] + (int64_t)d->B * OH_PAD + 255) / 256)), dim3(256),
-                       0, st, t);
-    FCN_CHECK_LAUNCH();
+    if (!d->prepacked) FCN_TRY(cn_pack(d, p, P, O, ws, one_hot, st));
     const int order[CN_NLAYER] = {0, 1, 2, 3, 10, 4, 5, 6, 11, 7, 8, 9, 12, 13};
     bool published[CN_NLAYER];
     for (int l = 0; l < CN_NLAYER; ++l) published[l] = false;

@@ -282,9 +282,12 @@ class PointNetDet(nn.Module):
 
         logits64 = None
         if self.fused_fcn and point_cloud.is_cuda and one_hot_vec is not None:
-            from .fcn_fused import convnet_fused
+            from .fcn_fused import convnet_fused, convnet_prepack
+            # the FCN's weight re-packing depends on the weights only: start it beside the PointNet scales
+            pre = convnet_prepack(self._cn_pool, self.conv_net, self.cls_out, self.reg_out, batch_size,
+                                  [r.shape[2] for r in refs], one_hot_vec, point_cloud.device)
             feats = self.feat_net(xyz, refs, None, one_hot_vec, nlc=True)
-            logits64 = convnet_fused(self._cn_pool, self.conv_net, self.cls_out, self.reg_out, feats, one_hot_vec)
+            logits64 = convnet_fused(self._cn_pool, self.conv_net, self.cls_out, self.reg_out, feats, one_hot_vec, pre)
             lv = logits64.view(batch_size, refs[1].shape[2], 64)
             nreg = self.reg_out.weight.shape[0]
             cls_raw = lv[:, :, 0:2].permute(0, 2, 1)

@@ -39,6 +39,15 @@ class CnWorkspace:
 class CnPool:
     def __init__(self):
         self.free = {}
+        self.side = {}
+
+    def pack_stream(self, device):
+        """Side stream + event for the early weight packing (one per device)."""
+        key = str(device)
+        if key not in self.side:
+            with torch.cuda.device(device):
+                self.side[key] = (torch.cuda.Stream(device=device), torch.cuda.Event(enable_timing=False))
+        return self.side[key]
 
     def acquire(self, key, desc, device, need_grad):
         k = key + (bool(need_grad), str(device))
@@ -58,9 +67,33 @@ def _arr(ts, n=14):
     return (ctypes.c_void_p * n)(*vals)
 
 
+def _prepare(pool, cfgt, bufs, one_hot, B, Ls, dev, pt):
+    """Detached parameter views, descriptor, workspace and the C parameter struct of one forward."""
+    training, eps, momentum, need_grad = cfgt
+    Ws = [w.detach().contiguous() for w in pt[0:13]]
+    gs = [g.detach().contiguous() for g in pt[13:26]]
+    bs = [b.detach().contiguous() for b in pt[26:39]]
+    cls_w, reg_w, cls_b, reg_b = [t.detach() for t in pt[39:43]]
+    # heads as one (2 + reg_out, 768) matrix: adjacent in memory under FlatTrainState (no copy), else concatenated
+    Wh = _adjacent(cls_w, reg_w)
+    if Wh is None:
+        Wh = torch.cat([cls_w, reg_w], 0).contiguous()
+    bh = _adjacent(cls_b, reg_b)
+    if bh is None:
+        bh = torch.cat([cls_b, reg_b], 0).contiguous()
+    nvec = 0 if one_hot is None else one_hot.shape[1]
+    oh = None if one_hot is None else one_hot.detach().contiguous().float()
+    desc = CnDesc(B, (ctypes.c_int32 * 4)(*Ls), nvec, reg_w.shape[0], 1 if training else 0, eps, momentum, 0)
+    ws = pool.acquire((B,) + tuple(Ls) + (nvec, reg_w.shape[0]), desc, dev, need_grad)
+    rmeans, rvars, nbts = bufs
+    params = CnParams(_arr(Ws + [Wh]), _arr(gs), _arr(bs), _arr(rmeans), _arr(rvars), _arr(nbts), bh.data_ptr())
+    return {"Ws": Ws, "gs": gs, "bs": bs, "Wh": Wh, "bh": bh, "oh": oh, "desc": desc, "ws": ws, "params": params,
+            "event": None}
+
+
 class _ConvNetFused(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pool, cfgt, bufs, one_hot, gdst, f1, f2, f3, f4, *pt):
+    def forward(ctx, pool, cfgt, bufs, one_hot, gdst, pre, f1, f2, f3, f4, *pt):
         # pt: 13 conv weights, 13 gammas, 13 betas, cls_w, reg_w, cls_b, reg_b
         training, eps, momentum, need_grad = cfgt
         ctx.gdst = gdst
@@ -68,24 +101,14 @@ class _ConvNetFused(torch.autograd.Function):
         feats = [f.detach().contiguous() for f in (f1, f2, f3, f4)]
         B = feats[0].shape[0]
         Ls = [f.shape[1] for f in feats]
-        Ws = [w.detach().contiguous() for w in pt[0:13]]
-        gs = [g.detach().contiguous() for g in pt[13:26]]
-        bs = [b.detach().contiguous() for b in pt[26:39]]
-        cls_w, reg_w, cls_b, reg_b = [t.detach() for t in pt[39:43]]
-        # heads as one (2 + reg_out, 768) matrix: adjacent in memory under FlatTrainState (no copy), else concatenated
-        Wh = _adjacent(cls_w, reg_w)
-        if Wh is None:
-            Wh = torch.cat([cls_w, reg_w], 0).contiguous()
-        bh = _adjacent(cls_b, reg_b)
-        if bh is None:
-            bh = torch.cat([cls_b, reg_b], 0).contiguous()
-        nvec = 0 if one_hot is None else one_hot.shape[1]
-        oh = None if one_hot is None else one_hot.detach().contiguous().float()
         dev = feats[0].device
-        desc = CnDesc(B, (ctypes.c_int32 * 4)(*Ls), nvec, reg_w.shape[0], 1 if training else 0, eps, momentum)
-        ws = pool.acquire((B,) + tuple(Ls) + (nvec, reg_w.shape[0]), desc, dev, need_grad)
-        rmeans, rvars, nbts = bufs
-        params = CnParams(_arr(Ws + [Wh]), _arr(gs), _arr(bs), _arr(rmeans), _arr(rvars), _arr(nbts), bh.data_ptr())
+        if pre is None:
+            pre = _prepare(pool, cfgt, bufs, one_hot, B, Ls, dev, pt)
+        elif pre["event"] is not None:
+            torch.cuda.current_stream(dev).wait_event(pre["event"])      # the packing ran on the side stream
+        Ws, gs, bs, Wh, bh, oh, desc, ws, params = (pre[k] for k in ("Ws", "gs", "bs", "Wh", "bh", "oh", "desc", "ws",
+                                                                    "params"))
+        assert list(desc.L) == Ls and desc.B == B
         logits = torch.empty((B * Ls[1], 64), dtype=torch.float32, device=dev)
         fp = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in feats])
         with torch.cuda.device(dev):
@@ -143,7 +166,7 @@ class _ConvNetFused(torch.autograd.Function):
                 if gd[39 + j] is not None:           # flat views that are not adjacent: copy in, hand autograd nothing
                     gd[39 + j].copy_(hz[j])
                     hz[j] = None
-        return (None, None, None, None, None, dfeats[0], dfeats[1], dfeats[2], dfeats[3]) + tuple(outs) + tuple(hz)
+        return (None, None, None, None, None, None, dfeats[0], dfeats[1], dfeats[2], dfeats[3]) + tuple(outs) + tuple(hz)
 
 
 def _adjacent(a, b):
@@ -158,10 +181,7 @@ def _adjacent(a, b):
         return None
 
 
-def convnet_fused(pool, conv_net, cls_out, reg_out, feats, one_hot):
-    """feats: 4 x (B, L_s, C_s) position-major pooled features.  Returns logits (B*L2, 64)."""
-    if not feats[0].is_cuda:
-        raise RuntimeError("frustum_convnet_amd: fused ConvFeatNet runs on the GPU only")
+def _gather(conv_net, cls_out, reg_out):
     seqs = [getattr(conv_net, n) for n in LAYERS]
     Ws = [s[0].weight for s in seqs]
     gs = [s[1].weight for s in seqs]
@@ -169,10 +189,46 @@ def convnet_fused(pool, conv_net, cls_out, reg_out, feats, one_hot):
     bufs = ([s[1].running_mean for s in seqs], [s[1].running_var for s in seqs],
             [s[1].num_batches_tracked for s in seqs])
     bn0 = seqs[0][1]
-    training = conv_net.training
     pt = Ws + gs + bs + [cls_out.weight, reg_out.weight, cls_out.bias, reg_out.bias]
+    return pt, bufs, bn0
+
+
+def convnet_prepack(pool, conv_net, cls_out, reg_out, B, Ls, one_hot, device):
+    """Starts the weight re-packing of the coming convnet_fused() call on the pool's side stream (forked from the current
+    stream) and returns the handle to pass as `pre`: 25 us that overlap the PointNet scales instead of heading the FCN."""
+    pt, bufs, bn0 = _gather(conv_net, cls_out, reg_out)
+    training = conv_net.training
+    need_grad = bool(training) and torch.is_grad_enabled() and any(t.requires_grad for t in pt)
+    cfgt = (bool(training), float(bn0.eps), float(0.1 if bn0.momentum is None else bn0.momentum), need_grad)
+    cur = torch.cuda.current_stream(device)
+    side, ev = pool.pack_stream(device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        pre = _prepare(pool, cfgt, bufs, one_hot, B, list(Ls), device, pt)
+        with torch.cuda.device(device):
+            _native.check(_native.lib().fcn_convnet_pack(ctypes.byref(pre["desc"]), ctypes.byref(pre["params"]),
+                                                         ctypes.byref(pre["ws"].c),
+                                                         None if pre["oh"] is None else pre["oh"].data_ptr(),
+                                                         _native.current_stream(device)), "fcn_convnet_pack")
+        ev.record(side)
+    pre["desc"].prepacked = 1
+    pre["event"] = ev
+    pre["cfgt"] = cfgt
+    return pre
+
+
+def convnet_fused(pool, conv_net, cls_out, reg_out, feats, one_hot, pre=None):
+    """feats: 4 x (B, L_s, C_s) position-major pooled features.  Returns logits (B*L2, 64)."""
+    if not feats[0].is_cuda:
+        raise RuntimeError("frustum_convnet_amd: fused ConvFeatNet runs on the GPU only")
+    pt, bufs, bn0 = _gather(conv_net, cls_out, reg_out)
+    training = conv_net.training
     need_grad = bool(training) and torch.is_grad_enabled() and (
         any(t.requires_grad for t in pt) or any(f.requires_grad for f in feats))
     cfgt = (bool(training), float(bn0.eps), float(0.1 if bn0.momentum is None else bn0.momentum), need_grad)
+    if pre is not None and pre["cfgt"] != cfgt:        # e.g. only the features require grad: pack inline instead
+        pool.release(pre["ws"])
+        torch.cuda.current_stream(feats[0].device).wait_event(pre["event"])
+        pre = None
     gdst = tuple(getattr(t, "_fcn_grad", None) for t in pt)
-    return _ConvNetFused.apply(pool, cfgt, bufs, one_hot, gdst, feats[0], feats[1], feats[2], feats[3], *pt)
+    return _ConvNetFused.apply(pool, cfgt, bufs, one_hot, gdst, pre, feats[0], feats[1], feats[2], feats[3], *pt)

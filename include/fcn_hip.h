@@ -137,6 +137,7 @@ typedef struct fcn_cn_desc {
     int32_t reg_out;             /* regression head width (39 for KITTI)                                        */
     int32_t training;
     float   eps, momentum;
+    int32_t prepacked;           /* 1: fcn_convnet_pack already ran for these weights / one-hot (joined by the caller) */
 } fcn_cn_desc;
 
 typedef struct fcn_cn_params {
@@ -157,6 +158,9 @@ typedef struct fcn_cn_ws {
 } fcn_cn_ws;
 
 int fcn_convnet_sizes(const fcn_cn_desc *d, int64_t *out6);
+/* Weight re-packing (3.3 M floats, torch layouts -> (N, Ktot)) + one-hot padding of fcn_convnet_forward as a separate
+ * launch, so a caller can overlap it with the PointNet scales on another stream (then set d->prepacked = 1). */
+int fcn_convnet_pack(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws, const float *one_hot, void *stream);
 /* feats[s]: (B, L[s], C_s) with C = 128,128,256,512 (fcn_pn_forward with nlc = 1); logits: (B*L[1], 64) rows, columns
  * 0..1 = cls_out, 2..2+reg_out = reg_out, rest zero. */
 int fcn_convnet_forward(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
