@@ -53,8 +53,9 @@ class InpDesc(ctypes.Structure):
 
 
 EXPORTS = ("fcn_arch", "fcn_query_depth_point_f32", "fcn_pn_wgrad_rows", "fcn_pn_compact",
-           "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_adam_step_f32", "fcn_adam_step_slots", "fcn_prepare_inputs",
-           "fcn_convnet_sizes", "fcn_convnet_pack", "fcn_convnet_forward", "fcn_convnet_backward")
+           "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_adam_step_f32", "fcn_adam_step_slots", "fcn_prepare_inputs", "fcn_stamp",
+           "fcn_convnet_sizes", "fcn_convnet_pack", "fcn_convnet_forward", "fcn_convnet_forward2",
+           "fcn_convnet_backward")
 
 _lib = None
 
@@ -104,6 +105,8 @@ def lib():
     L.fcn_adam_step_f32.argtypes = [c_fp] * 4 + [ctypes.c_int64] + [c_fp] * 3
     L.fcn_prepare_inputs.restype = ctypes.c_int
     L.fcn_prepare_inputs.argtypes = [ctypes.POINTER(InpDesc)] + [c_fp] * 13 + [c_fp * 4] + [c_fp] * 7
+    L.fcn_stamp.restype = ctypes.c_int
+    L.fcn_stamp.argtypes = [c_fp, c_fp]
     L.fcn_adam_step_slots.restype = ctypes.c_int64
     L.fcn_adam_step_slots.argtypes = [ctypes.c_int64]
     L.fcn_det_loss_tail_rows.restype = ctypes.c_int
@@ -115,6 +118,9 @@ def lib():
     L.fcn_convnet_forward.restype = ctypes.c_int
     L.fcn_convnet_forward.argtypes = [ctypes.POINTER(CnDesc), ctypes.POINTER(CnParams), ctypes.POINTER(CnWs),
                                       c_fp * 4, c_fp, c_fp, c_fp]
+    L.fcn_convnet_forward2.restype = ctypes.c_int
+    L.fcn_convnet_forward2.argtypes = [ctypes.POINTER(CnDesc), ctypes.POINTER(CnParams), ctypes.POINTER(CnWs),
+                                       c_fp * 4, c_fp, c_fp, c_fp, ctypes.POINTER(c_fp)]
     L.fcn_convnet_backward.restype = ctypes.c_int
     L.fcn_convnet_backward.argtypes = [ctypes.POINTER(CnDesc), ctypes.POINTER(CnParams), ctypes.POINTER(CnWs),
                                        c_fp * 4, c_fp, c_fp, c_fp * 4, c_fp * 14, c_fp * 14, c_fp * 14, c_fp, c_fp, c_fp,

@@ -965,8 +965,23 @@ extern "C" int fcn_convnet_pack(const fcn_cn_desc *d, const fcn_cn_params *p, co
     return cn_pack(d, p, P, O, ws, one_hot, (hipStream_t)stream);
 }
 
+extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
+                                    const float *const feats[4], const float *one_hot, float *logits, void *stream,
+                                    void *const *feat_events);
+
 extern "C" int fcn_convnet_forward(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
                                    const float *const feats[4], const float *one_hot, float *logits, void *stream)
+{
+    return fcn_convnet_forward2(d, p, ws, feats, one_hot, logits, stream, nullptr);
+}
+
+// feat_events: 4 hipEvent_t (or NULL entries), recorded by the caller when pooled feature map s is complete on whatever
+// stream produced it.  `stream` waits for event s right before the FIRST layer that reads map s (block1_conv1,
+// block2_merge, block3_merge, block4_merge): the FCN starts as soon as the finest scale is pooled and its first nine
+// layers run beside the widest scale's PointNet (the long pole of the forward), instead of after all four scales.
+extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
+                                    const float *const feats[4], const float *one_hot, float *logits, void *stream,
+                                    void *const *feat_events)
 {
     if (!d || !p || !ws || !feats || !logits) return FCN_E_BADARG;
     if (!ws->y || !ws->wp || !ws->bn || !ws->stat || !ws->partial || !ws->oh64) return FCN_E_BADARG;
@@ -986,6 +1001,7 @@ extern "C" int fcn_convnet_forward(const fcn_cn_desc *d, const fcn_cn_params *p,
     const int order[CN_NLAYER] = {0, 1, 2, 3, 10, 4, 5, 6, 11, 7, 8, 9, 12, 13};
     bool published[CN_NLAYER];
     for (int l = 0; l < CN_NLAYER; ++l) published[l] = false;
+    bool waited[4] = {false, false, false, false};
     for (int q = 0; q < CN_NLAYER; ++q) {
         const int l = order[q];
         CgLayer L;
@@ -993,6 +1009,11 @@ extern "C" int fcn_convnet_forward(const fcn_cn_desc *d, const fcn_cn_params *p,
         for (int s = 0; s < P.nseg[l]; ++s) {       // the first consumer of a BN layer publishes its statistics
             const int src = P.src[l][s];
             if (src >= 0 && !published[src]) { L.seg[s].writer = 1; published[src] = true; }
+            if (src < 0 && src != -9 && feat_events && feat_events[-src - 1] && !waited[-src - 1]) {
+                hipError_t e = hipStreamWaitEvent(st, (hipEvent_t)feat_events[-src - 1], 0);
+                if (e != hipSuccess) return (int)e;
+                waited[-src - 1] = true;
+            }
         }
         if (l == 13) { L.y = logits; L.bias = p->bias; L.nbias = P.nrow_real[13]; }
         else if (tr) L.stat = ws->stat + O.st[l];
@@ -1039,7 +1060,12 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
     if (!d || !p || !ws || !feats || !dlogits || !dfeats || !dW || !dgamma || !dbeta || !dbias) return FCN_E_BADARG;
     if (!d->training) return FCN_E_BADARG;
     if (!ws->y || !ws->dz || !ws->wp || !ws->bn || !ws->bstat || !ws->coef || !ws->partial) return FCN_E_BADARG;
-    (void)stream2; (void)events;        // kept in the ABI; the weight gradients now ride in the step launches
+    // stream2 / events (4 caller-owned hipEvent_t), optional: the gradient of the widest feature map (dfeats[3]) is final
+    // after the third launch (heads, block4_deconv, block4_merge).  From there the remaining twelve launches continue
+    // on stream2 so that `stream` is free again: the caller's scale-4 PointNet backward -- the long pole -- starts beside
+    // the rest of the FCN backward instead of after it.  events[0]: fork; events[1]: dfeats[2] final (after
+    // block3_merge); events[2]: dfeats[1] final (after block2_merge); events[3]: everything final (dfeats[0], all dW).
+    const bool cont = stream2 != nullptr && events != nullptr;
     hipStream_t st = (hipStream_t)stream;
     CnPlan P;
     FCN_TRY(cn_make_plan(d, P));
@@ -1134,6 +1160,20 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
             FCN_CHECK_LAUNCH();
         }
         prev = cur; prev_blocks = cur_blocks;
+        if (cont) {
+            const int l = q < CN_NLAYER ? order[q] : -1;
+            int ev = -1;
+            if (l == 9) ev = 0; else if (l == 6) ev = 1; else if (l == 3) ev = 2; else if (q == CN_NLAYER) ev = 3;
+            if (ev >= 0) {
+                e = hipEventRecord((hipEvent_t)events[ev], st);
+                if (e != hipSuccess) return (int)e;
+            }
+            if (ev == 0) {              // hand the chain over to the continuation stream
+                e = hipStreamWaitEvent((hipStream_t)stream2, (hipEvent_t)events[0], 0);
+                if (e != hipSuccess) return (int)e;
+                st = (hipStream_t)stream2;
+            }
+        }
     }
     return 0;
 }

@@ -110,47 +110,71 @@ class PointNetFeat(nn.Module):
         self._stream_cache = {}
         # the widest scale is the long pole of the backward: its weight-gradient GEMMs run on a second stream beside
         # its data-gradient chain (bit k of FCN_PN_SIDE = scale k+1; default scale 4 only)
-        mask = int(os.environ.get("FCN_PN_SIDE", "8"))
+        # Stream topology switches (FCN_TOPO bit mask, default 0 = what measured fastest on ROCm 7.2 / MI355X):
+        #   1: scale 4 on its own forked stream too (else on the caller's stream, with a side stream for its wgrads)
+        #   2: no join after the scales; the FCN waits for each pooled map right before its first use (fcn_convnet_forward2)
+        #   4: the FCN backward continues on a second stream once the scale-4 gradient is final (fcn_fused.py)
+        # Every bit ADDS overlap on paper -- the FCN's first nine layers beside scale 4's PointNet, scale 4's backward
+        # beside the rest of the FCN backward -- and every bit measured SLOWER (15.9k -> 14.0-15.2k frustums/s): the
+        # captured branches already keep the CUs busy, and stretching the two latency-bound FCN chains costs more than
+        # the overlap returns.  Kept as tested options of the C-ABI, off by default.
+        self.topo = int(os.environ.get("FCN_TOPO", "0"))
+        mask = int(os.environ.get("FCN_PN_SIDE", "0" if self.topo & 1 else "8"))
         for k, net in enumerate((self.pointnet1, self.pointnet2, self.pointnet3, self.pointnet4)):
             net._pool.side_wgrad = bool(mask >> k & 1)
 
-    def forward(self, point_cloud, sample_pc, feat=None, one_hot_vec=None, nlc=False):
+    def forward(self, point_cloud, sample_pc, feat=None, one_hot_vec=None, nlc=False, join=True):
+        """join=False (fused FCN path): the caller's stream is NOT made to wait for the scales; self.done_events holds one
+        event per scale for the consumer to wait on (fcn_convnet_forward2 does, map by map)."""
         if one_hot_vec is not None:
             assert self.num_vec == one_hot_vec.shape[1]
         nets = (self.pointnet1, self.pointnet2, self.pointnet3, self.pointnet4)
+        self.done_events = None
         if not (self.concurrent_scales and point_cloud.is_cuda) or os.environ.get("FCN_SERIAL", "0") == "1":
             return tuple(net.forward_pooled(point_cloud, ref, one_hot_vec, nlc) for net, ref in zip(nets, sample_pc))
-        # The four scales are independent until the FCN: scales 1-3 run on three forked HIP streams and the widest
-        # (scale 4, the long pole) on the current stream, so one scale's tail (a few workgroups left on 256 CUs)
-        # overlaps the others' work; the fork/join is captured as parallel branches of the step's hipGraph.
-        #  * Launch order is heaviest first (4, 3, 1, 2): the graph executor starts branches in capture order, and the
-        #    long pole must not start after the small scales have come and gone.
-        #  * Node creation order is lightest first (1, 2, 3, 4): autograd replays each scale's backward on the stream
-        #    its node was created under, in REVERSE creation order -- heaviest first again.
+        # The four scales are independent until the FCN: scales 1-3 run on three HIP streams forked from the current one and
+        # the widest (scale 4, the long pole) on the current stream itself, captured as parallel branches of the step's
+        # hipGraph, so one scale's tail (a few workgroups left on 256 CUs) overlaps the others' work.
+        #  * Forks are flat: ROCm 7.2 stream capture crashes on a fork from an already-forked stream, and scale 4's backward
+        #    forks a second stream for its weight-gradient GEMMs -- hence scale 4 stays on the current stream.
+        #  * Launch order is heaviest first (4, 3, 1, 2); node creation order is 1, 2, 3, 4: autograd replays each scale's
+        #    backward on the stream its node was created under, in REVERSE creation order -- widest first again.
         #    launch_pooled() / attach_pooled() separate the two orders.
-        #  * Scale 4 stays on the current stream because its backward forks a second stream for the weight gradients
-        #    and ROCm 7.2 stream capture crashes on a fork from an already-forked stream (flat forks only); the forked
-        #    streams wait on an event recorded BEFORE scale 4's kernels, not on the stream itself.
         dev = point_cloud.device
         cur = torch.cuda.current_stream(dev)
-        streams = self._streams(dev)              # for scales 1, 2, 3
+        streams = self._streams(dev)
         fork = self._fork_event(dev)
         fork.record(cur)
         handles = [None] * 4
-        handles[3] = nets[3].launch_pooled(point_cloud, sample_pc[3], one_hot_vec, nlc)
-        for s in (2, 0, 1):
-            st = streams[s]
-            st.wait_event(fork)
+        s4_forked = bool(self.topo & 1)
+        sts = [streams[0], streams[1], streams[2], streams[3] if s4_forked else cur]
+        for s in ((3, 0, 1, 2) if s4_forked else (3, 2, 0, 1)):
+            st = sts[s]
+            if st is not cur:
+                st.wait_event(fork)
             with torch.cuda.stream(st):
                 handles[s] = nets[s].launch_pooled(point_cloud, sample_pc[s], one_hot_vec, nlc)
         outs = [None] * 4
-        for s in (0, 1, 2):
-            with torch.cuda.stream(streams[s]):
+        done = self._done_events(dev)
+        for s in (0, 1, 2, 3):
+            with torch.cuda.stream(sts[s]):
                 outs[s] = nets[s].attach_pooled(handles[s])
-        outs[3] = nets[3].attach_pooled(handles[3])
-        for s in (0, 1, 2):
-            cur.wait_stream(streams[s])
+                done[s].record(sts[s])
+        if not (self.topo & 2):
+            join = True
+        if join:
+            for s in (0, 1, 2, 3):
+                cur.wait_event(done[s])
+                outs[s].record_stream(cur)
+        else:
+            self.done_events = done
         return tuple(outs)
+
+    def _done_events(self, device):
+        key = "done" + str(device)
+        if key not in self._stream_cache:
+            self._stream_cache[key] = [torch.cuda.Event(enable_timing=False) for _ in range(4)]
+        return self._stream_cache[key]
 
     def _fork_event(self, device):
         key = "ev" + str(device)
@@ -161,7 +185,7 @@ class PointNetFeat(nn.Module):
     def _streams(self, device):
         key = str(device)
         if key not in self._stream_cache:
-            self._stream_cache[key] = [torch.cuda.Stream(device=device) for _ in range(3)]
+            self._stream_cache[key] = [torch.cuda.Stream(device=device) for _ in range(4)]
         return self._stream_cache[key]
 
 
@@ -286,8 +310,10 @@ class PointNetDet(nn.Module):
             # the FCN's weight re-packing depends on the weights only: start it beside the PointNet scales
             pre = convnet_prepack(self._cn_pool, self.conv_net, self.cls_out, self.reg_out, batch_size,
                                   [r.shape[2] for r in refs], one_hot_vec, point_cloud.device)
-            feats = self.feat_net(xyz, refs, None, one_hot_vec, nlc=True)
-            logits64 = convnet_fused(self._cn_pool, self.conv_net, self.cls_out, self.reg_out, feats, one_hot_vec, pre)
+            # no join after the scales: the FCN waits for each pooled map right before the first layer that reads it
+            feats = self.feat_net(xyz, refs, None, one_hot_vec, nlc=True, join=False)
+            logits64 = convnet_fused(self._cn_pool, self.conv_net, self.cls_out, self.reg_out, feats, one_hot_vec, pre,
+                                     self.feat_net.done_events)
             lv = logits64.view(batch_size, refs[1].shape[2], 64)
             nreg = self.reg_out.weight.shape[0]
             cls_raw = lv[:, :, 0:2].permute(0, 2, 1)

@@ -2,6 +2,7 @@
 csrc/fcn_net.hip).  Input: the four position-major pooled feature maps of the PointNet scales; output: row-major
 logits (B*L2, 64) (cols 0..1 cls_out, 2..40 reg_out) that feed the fused loss tail directly."""
 import ctypes
+import os
 
 import torch
 
@@ -36,10 +37,36 @@ class CnWorkspace:
                       p(self.partial), p(self.oh64))
 
 
+# gradient tensor (data_ptr) -> event its consumer must wait for: set by _ConvNetFused.backward for the feature-map
+# gradients that become final on the continuation stream, consumed by pointnet_fused._PointNetPooled.backward
+PENDING_GRADS = {}
+
+
+def wait_pending_grad(t):
+    ev = PENDING_GRADS.pop(t.data_ptr(), None)
+    if ev is not None:
+        torch.cuda.current_stream(t.device).wait_event(ev)
+
+
 class CnPool:
     def __init__(self):
         self.free = {}
         self.side = {}
+        self.cont = {}
+        self.last_done = None
+
+    def cont_stream(self, device):
+        """Continuation stream of the backward + its 4 events (caller-owned, handed to fcn_convnet_backward)."""
+        key = str(device)
+        if key not in self.cont:
+            with torch.cuda.device(device):
+                st = torch.cuda.Stream(device=device)
+                evs = [torch.cuda.Event(enable_timing=False) for _ in range(4)]
+                for ev in evs:
+                    ev.record()                     # materialise the hipEvent_t handles
+                arr = (ctypes.c_void_p * 4)(*[ev.cuda_event for ev in evs])
+            self.cont[key] = (st, evs, arr)
+        return self.cont[key]
 
     def pack_stream(self, device):
         """Side stream + event for the early weight packing (one per device)."""
@@ -93,7 +120,7 @@ def _prepare(pool, cfgt, bufs, one_hot, B, Ls, dev, pt):
 
 class _ConvNetFused(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pool, cfgt, bufs, one_hot, gdst, pre, f1, f2, f3, f4, *pt):
+    def forward(ctx, pool, cfgt, bufs, one_hot, gdst, pre, feat_events, f1, f2, f3, f4, *pt):
         # pt: 13 conv weights, 13 gammas, 13 betas, cls_w, reg_w, cls_b, reg_b
         training, eps, momentum, need_grad = cfgt
         ctx.gdst = gdst
@@ -111,10 +138,16 @@ class _ConvNetFused(torch.autograd.Function):
         assert list(desc.L) == Ls and desc.B == B
         logits = torch.empty((B * Ls[1], 64), dtype=torch.float32, device=dev)
         fp = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in feats])
+        evarr = None
+        if feat_events is not None:      # per-map completion events: the C side waits for each right before its first use
+            evarr = (ctypes.c_void_p * 4)(*[None if e is None else e.cuda_event for e in feat_events])
+            cur = torch.cuda.current_stream(dev)
+            for ft in feats:
+                ft.record_stream(cur)    # produced on the scales' streams, consumed here
         with torch.cuda.device(dev):
-            _native.check(L.fcn_convnet_forward(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(ws.c), fp,
-                                                None if oh is None else oh.data_ptr(), logits.data_ptr(),
-                                                _native.current_stream(dev)), "fcn_convnet_forward")
+            _native.check(L.fcn_convnet_forward2(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(ws.c), fp,
+                                                 None if oh is None else oh.data_ptr(), logits.data_ptr(),
+                                                 _native.current_stream(dev), evarr), "fcn_convnet_forward2")
         ctx.pool, ctx.live = pool, need_grad
         if need_grad:
             ctx.ws, ctx.desc, ctx.keep = ws, desc, (feats, oh, Ws, Wh, gs, bs, bh)
@@ -147,12 +180,31 @@ class _ConvNetFused(torch.autograd.Function):
         params = CnParams(_arr(Ws + [Wh]), _arr(gs), _arr(bs), _arr([]), _arr([]), _arr([]), bh.data_ptr())
         fp = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in feats])
         dfp = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in dfeats])
+        # continuation stream: after the third launch dfeats[3] is final and the rest of the chain moves to a second
+        # stream, so the scale-4 PointNet backward (the long pole, next on THIS stream) overlaps it.  The gradients of the
+        # other maps become final on that stream: their consumers find the event to wait for in PENDING_GRADS.
+        use_cont = bool(int(os.environ.get("FCN_TOPO", "0")) & 4)    # see det_base.PointNetFeat: measured slower, off
+        cont, evs, evarr = ctx.pool.cont_stream(dev)
+        if use_cont:
+            for t in dfeats[:3]:
+                t.record_stream(cont)
         with torch.cuda.device(dev):
             _native.check(L.fcn_convnet_backward(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(ws.c), fp,
                                                  None if oh is None else oh.data_ptr(), dlogits.data_ptr(), dfp,
                                                  _arr(dW), _arr(dg), _arr(db), dbh.data_ptr(),
-                                                 _native.current_stream(dev), None, None),
+                                                 _native.current_stream(dev),
+                                                 ctypes.c_void_p(cont.cuda_stream) if use_cont else None,
+                                                 evarr if use_cont else None),
                           "fcn_convnet_backward")
+        if not use_cont:
+            evs = [None] * 4
+        else:
+            PENDING_GRADS[dfeats[2].data_ptr()] = evs[1]
+            PENDING_GRADS[dfeats[1].data_ptr()] = evs[2]
+            PENDING_GRADS[dfeats[0].data_ptr()] = evs[3]
+        # the parameter gradients are final at evs[3] as well: whoever consumes dfeats[0] joins the continuation stream,
+        # and this stream joins it here when nobody will (no PointNet consumer, e.g. features without grad)
+        ctx.pool.last_done = evs[3]
         ctx.pool.release(ws)
         ctx.ws, ctx.live = None, False
         ncls = 2
@@ -166,7 +218,12 @@ class _ConvNetFused(torch.autograd.Function):
                 if gd[39 + j] is not None:           # flat views that are not adjacent: copy in, hand autograd nothing
                     gd[39 + j].copy_(hz[j])
                     hz[j] = None
-        return (None, None, None, None, None, None, dfeats[0], dfeats[1], dfeats[2], dfeats[3]) + tuple(outs) + tuple(hz)
+        if evs[3] is not None and (any(o is not None for o in outs) or any(h is not None for h in hz)):
+            # ordinary autograd gradients are consumed on THIS stream as soon as we return: they are final on the
+            # continuation stream only (FlatTrainState's in-place gradients need no such wait)
+            torch.cuda.current_stream(dev).wait_event(evs[3])
+        return (None, None, None, None, None, None, None, dfeats[0], dfeats[1], dfeats[2], dfeats[3]) + tuple(outs) + \
+            tuple(hz)
 
 
 def _adjacent(a, b):
@@ -217,8 +274,10 @@ def convnet_prepack(pool, conv_net, cls_out, reg_out, B, Ls, one_hot, device):
     return pre
 
 
-def convnet_fused(pool, conv_net, cls_out, reg_out, feats, one_hot, pre=None):
-    """feats: 4 x (B, L_s, C_s) position-major pooled features.  Returns logits (B*L2, 64)."""
+def convnet_fused(pool, conv_net, cls_out, reg_out, feats, one_hot, pre=None, feat_events=None):
+    """feats: 4 x (B, L_s, C_s) position-major pooled features.  Returns logits (B*L2, 64).
+    feat_events: per-map torch.cuda.Event recorded when the map is complete on its producer's stream (None: the maps
+    are already ordered before the current stream)."""
     if not feats[0].is_cuda:
         raise RuntimeError("frustum_convnet_amd: fused ConvFeatNet runs on the GPU only")
     pt, bufs, bn0 = _gather(conv_net, cls_out, reg_out)
@@ -231,4 +290,5 @@ def convnet_fused(pool, conv_net, cls_out, reg_out, feats, one_hot, pre=None):
         torch.cuda.current_stream(feats[0].device).wait_event(pre["event"])
         pre = None
     gdst = tuple(getattr(t, "_fcn_grad", None) for t in pt)
-    return _ConvNetFused.apply(pool, cfgt, bufs, one_hot, gdst, pre, feats[0], feats[1], feats[2], feats[3], *pt)
+    return _ConvNetFused.apply(pool, cfgt, bufs, one_hot, gdst, pre, feat_events, feats[0], feats[1], feats[2], feats[3],
+                               *pt)

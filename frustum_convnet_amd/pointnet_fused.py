@@ -154,6 +154,9 @@ class _PointNetPooled(torch.autograd.Function):
         Wc, gs, bs, cnt, idx, oh = ctx.keep
         dev = dfeat.device
         C1, C2, C3 = desc.C1, desc.C2, desc.C3
+        from .fcn_fused import wait_pending_grad
+        wait_pending_grad(dfeat)                  # final on the FCN backward's continuation stream (if it came from there)
+        dfeat.record_stream(torch.cuda.current_stream(dev))
         dfeat = dfeat.contiguous().float()
         # gradient destinations: the parameter's flat-buffer view when the caller trains through FlatTrainState
         # (written in place, autograd gets None), else a fresh tensor handed back to autograd

@@ -165,12 +165,19 @@ int fcn_convnet_pack(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_
  * 0..1 = cls_out, 2..2+reg_out = reg_out, rest zero. */
 int fcn_convnet_forward(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
                         const float *const feats[4], const float *one_hot, float *logits, void *stream);
+/* Same with 4 optional hipEvent_t: `stream` waits for feat_events[s] right before the first layer that reads feats[s], so
+ * the FCN runs beside the PointNet scales that are still in flight (the widest map is needed by the 10th layer only). */
+int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
+                         const float *const feats[4], const float *one_hot, float *logits, void *stream,
+                         void *const *feat_events);
 int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
                          const float *const feats[4], const float *one_hot, const float *dlogits,
                          float *const dfeats[4], float *const dW[14], float *const dgamma[14],
                          float *const dbeta[14], float *dbias, void *stream, void *stream2, void *const *events);
 /* One launch per layer: its data-gradient tiles, its weight-gradient row splits and the reduce of the previous layer's
- * splits are workgroup roles of the same kernel.  stream2 / events are ignored (kept for ABI stability; pass NULL). */
+ * splits are workgroup roles of the same kernel.  stream2 / events: NULL, or a second stream + 4 caller-owned events --
+ * after the launch that completes dfeats[3] the chain continues on stream2 (events[0] = fork, [1] = dfeats[2] final,
+ * [2] = dfeats[1] final, [3] = all outputs final), so work queued on `stream` after the call waits for dfeats[3] only. */
 
 /* ---------------------------------------------------------------------------------------------
  * Fused train-loss tail of PointNetDet.forward (models/det_base.py:373-476; focal loss models/common.py:217-232,
@@ -206,6 +213,9 @@ int fcn_det_loss_tail_rows(const float *logits, const int64_t *cls_label, const 
 int64_t fcn_adam_step_slots(int64_t n);
 int fcn_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                       const float *hyper6, int64_t *step_slots, void *stream);
+
+/* Measurement aid: stores the device's constant-rate wall clock (100 MHz ticks) into *slot, in stream order. */
+int fcn_stamp(uint64_t *slot, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * On-device construction of one training batch from raw frustum records: replaces the
