@@ -67,6 +67,9 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
 {
     __shared__ float sh[LT_THREADS / 64];
     __shared__ int last_s;
+    // row-major variant: the workgroup's LT_THREADS gradient rows are staged here (odd stride: a thread writes its own
+    // row without bank conflicts) and go out as coalesced 256-byte rows instead of 64 strided dwords per thread
+    __shared__ float gS[LT_THREADS * 65];
     const int tid = threadIdx.x;
     const int B = a.B, L2 = a.L2, R = B * L2;
     constexpr int NB = LT_NB, NS = LT_NS, NC = 3 + 2 * NB + 4 * NS;
@@ -74,7 +77,8 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
     const float per = (float)(6.283185307179586 / NB), half = (float)(6.283185307179586 / NB / 2.0);
 
     float cfg_ = 0.f, ckeep = 0.f;
-    for (int r = tid; r < R; r += LT_THREADS) {
+#pragma unroll 8
+    for (int r = tid; r < R; r += LT_THREADS) {          // every workgroup counts all labels: 8 loads in flight
         const int64_t lab = a.cls_label[r];
         cfg_ += (lab == 1) ? 1.f : 0.f;
         ckeep += (lab != -1) ? 1.f : 0.f;
@@ -112,8 +116,8 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
         }
         if (a.dcls) {
             if (a.ld) {
-                a.dcls[(int64_t)r * a.ld] = g0;
-                a.dcls[(int64_t)r * a.ld + 1] = g1;
+                gS[tid * 65] = g0;
+                gS[tid * 65 + 1] = g1;
             } else {
                 a.dcls[((int64_t)b * 2 + 0) * L2 + l] = g0;
                 a.dcls[((int64_t)b * 2 + 1) * L2 + l] = g1;
@@ -250,12 +254,21 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
         if (a.ld) {
             if (a.dcls) {
 #pragma unroll
-                for (int j = 0; j < NC; ++j) a.dcls[(int64_t)r * a.ld + 2 + j] = go[j];
-                for (int j = 2 + NC; j < a.ld; ++j) a.dcls[(int64_t)r * a.ld + j] = 0.f;
+                for (int j = 0; j < NC; ++j) gS[tid * 65 + 2 + j] = go[j];
+                for (int j = 2 + NC; j < 64; ++j) gS[tid * 65 + j] = 0.f;
             }
         } else if (a.dreg) {
 #pragma unroll
             for (int j = 0; j < NC; ++j) a.dreg[((int64_t)b * NC + j) * L2 + l] = go[j];
+        }
+    }
+    if (a.ld && a.dcls) {              // (the row loop runs at most once per thread: the grid covers R)
+        __syncthreads();
+        const int row0 = blockIdx.x * LT_THREADS;
+        const int nrow = min(LT_THREADS, R - row0);
+        for (int i = tid; i < nrow * 64; i += LT_THREADS) {
+            const int rr = i >> 6, cc = i & 63;
+            if (cc < a.ld) a.dcls[(int64_t)(row0 + rr) * a.ld + cc] = gS[rr * 65 + cc];
         }
     }
     // ---- combine the workgroups: out[1..10] accumulate, out[15] (as int) is the arrival ticket; both were zeroed by the
