@@ -114,6 +114,37 @@ def roofline_probe(model, data, reps=20):
             "avg_launch_ms": round(tot_ms / launches, 5), "launches_per_step": launches, "per_launch": per}
 
 
+def grouping_roofline(model, data, reps=50):
+    """The grouping kernel alone (SURVEY section 8d regime i, HBM-bound scan): the four fcn_query_depth_point_f32 launches of
+    one step timed with HIP events on the launch stream; algorithmic bytes = z row + centres + int64 idx + cnt."""
+    from frustum_convnet_amd.query_depth_point import query_depth_point
+    xyz = data["point_cloud"][:, :3].contiguous()
+    B, _, N = xyz.shape
+    nets = (model.feat_net.pointnet1, model.feat_net.pointnet2, model.feat_net.pointnet3, model.feat_net.pointnet4)
+    refs = [data["center_ref%d" % (s + 1)].contiguous() for s in range(4)]
+    nbytes = 0.0
+    for net, ref in zip(nets, refs):
+        Lw = ref.shape[2]
+        nbytes += B * (4.0 * N + 4.0 * Lw + 8.0 * Lw * net.nsample + 4.0 * Lw)
+
+    def run():
+        for net, ref in zip(nets, refs):
+            query_depth_point(net.dist, net.nsample, xyz, ref)
+    for _ in range(5):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    tbps = nbytes / (ms * 1e-3) / 1e12
+    return {"bound": "hbm", "kernel": "qdp_kernel x4 strides (eager launches, includes launch gaps)",
+            "bytes_per_step_algorithmic": nbytes, "ms_per_step": round(ms, 5), "achieved": round(tbps, 4), "peak": 8.0,
+            "unit": "TB/s", "frac": round(tbps / 8.0, 5)}
+
+
 def _pmc_traffic():
     """HBM bytes per launch of the dominant kernel from a committed rocprofv3 --pmc pass, if one exists."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -270,6 +301,10 @@ def main():
             out["roofline"] = roofline_probe(model, data)
         except Exception as e:  # noqa
             out["roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            out["grouping_roofline"] = grouping_roofline(model, data)
+        except Exception as e:  # noqa
+            out["grouping_roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if world == 1:
         # whole-step HBM roofline (BASELINE.json's "HBM roofline %"): fabric bytes of one step from the committed
         # rocprofv3 --pmc passes (profiles/pmc_traffic.json, tools_gpu_traffic.sh) over THIS command, divided by the

@@ -1016,7 +1016,7 @@ extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p
             }
         }
         if (l == 13) { L.y = logits; L.bias = p->bias; L.nbias = P.nrow_real[13]; }
-        else if (tr) L.stat = ws->stat + O.st[l];
+        else if (tr && !(L.dbg & 8)) L.stat = ws->stat + O.st[l];      // (dbg 8: timing ablation without the BN sums)
         const int R = d->B * P.Lout[l];
         {
             // 64-row tiles when they already give >= ~200 workgroups, else 32-row tiles (R = B*L is small here)
