@@ -307,7 +307,7 @@ def main():
             out["grouping_roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if world == 1:
         # whole-step HBM roofline (BASELINE.json's "HBM roofline %"): fabric bytes of one step from the committed
-        # rocprofv3 --pmc passes (profiles/pmc_traffic.json, tools_gpu_traffic.sh) over THIS command, divided by the
+        # rocprofv3 --pmc passes (profiles/pmc_traffic.json, tools/gpu_traffic.sh) over THIS command, divided by the
         # step time measured now; peak 8 TB/s (MI355X_MICROARCH.md).  null when no PMC summary is committed.
         try:
             sb = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["step"]["bytes_per_step"]

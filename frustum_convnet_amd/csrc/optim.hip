@@ -91,7 +91,7 @@ extern "C" int fcn_adam_step_f32(float *param, const float *grad, float *exp_avg
 // ------------------------------------------------------------------------------------------------
 // Measurement aid: one thread stores the GPU's constant-rate wall clock (100 MHz) into *slot.  Launched between the
 // phases of a step it gives phase boundaries INSIDE a replayed hipGraph without a profiler attached
-// (tools_phase_stamps.py); rocprofv3's kernel trace perturbs the overlap of the captured branches.
+// (tools/phase_stamps.py); rocprofv3's kernel trace perturbs the overlap of the captured branches.
 __global__ void stamp_kernel(unsigned long long *slot) { *slot = wall_clock64(); }
 
 extern "C" int fcn_stamp(uint64_t *slot, void *stream)

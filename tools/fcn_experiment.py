@@ -1,6 +1,6 @@
 """FCN variants timing (graph replay): MIOpen default, MIOpen benchmark mode, NLC matmul formulation."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn.functional as F
 from bench import build_model
 dev = torch.device("cuda:0")

@@ -1,6 +1,6 @@
 """Times fcn_convnet_forward alone (events) -- used with FCN_DBG ablation switches."""
 import sys, os, ctypes
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bench import build_model
 from frustum_convnet_amd import fcn_fused

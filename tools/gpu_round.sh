@@ -12,4 +12,4 @@ if [ -n "$PROF" ]; then
   cd $GRAFT_REPO_ROOT; find /tmp/prof -type f | head -20; for f in $(find /tmp/prof -name "*kernel_stats*.csv"); do cp $f gpurun_out/kernel_stats.csv; done; for f in $(find /tmp/prof -name "*kernel_trace*.csv"); do cp $f gpurun_out/kernel_trace.csv; done
   head -30 gpurun_out/kernel_stats.csv; tail -1 gpurun_out/prof_bench.txt
 fi
-if [ -n "$PHASE" ]; then echo "== phase timing"; timeout 600 python tools_phase_timing.py > gpurun_out/phase.txt 2>&1; echo "rc=$?"; cat gpurun_out/phase.txt | grep -v Warning | tail -20; fi
+if [ -n "$PHASE" ]; then echo "== phase timing"; timeout 600 python tools/phase_timing.py > gpurun_out/phase.txt 2>&1; echo "rc=$?"; cat gpurun_out/phase.txt | grep -v Warning | tail -20; fi

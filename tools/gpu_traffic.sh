@@ -4,7 +4,7 @@ mkdir -p gpurun_out; export TMPDIR=/tmp
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python $GRAFT_REPO_ROOT/tools_traffic_driver.py > $GRAFT_REPO_ROOT/gpurun_out/pmc_$c.log 2>&1; echo "$c rc=$?"
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python $GRAFT_REPO_ROOT/tools/traffic_driver.py > $GRAFT_REPO_ROOT/gpurun_out/pmc_$c.log 2>&1; echo "$c rc=$?"
   f=$(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1); cp "$f" $GRAFT_REPO_ROOT/gpurun_out/pmc_$c.csv 2>/dev/null
   tail -1 $GRAFT_REPO_ROOT/gpurun_out/pmc_$c.log; head -2 $GRAFT_REPO_ROOT/gpurun_out/pmc_$c.csv | cut -c1-400
 done

@@ -2,7 +2,7 @@
 at the joins of the captured step.  Backward boundaries come from tensor hooks (they run on the stream of the node that
 produced the gradient)."""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import bench

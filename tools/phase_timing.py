@@ -1,6 +1,6 @@
 """Phase timing of one training step with HIP events, eager and as hipGraph replays (diagnostic, not the bench)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bench import build_model
 from frustum_convnet_amd import synth

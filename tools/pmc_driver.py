@@ -1,6 +1,6 @@
 """Small driver for rocprofv3 --pmc passes: a few fwd+bwd of the 4 PointNet scales at the bench shape."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bench import build_model
 from frustum_convnet_amd import synth

@@ -1,7 +1,7 @@
 """Driver for the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes: only the roofline probe's conv GEMM launches
 (fcn_pn_conv_fwd: conv2 and conv3 of the four scales at the bench shape)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from frustum_convnet_amd import synth
