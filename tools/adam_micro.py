@@ -1,4 +1,6 @@
 """Micro-benchmark of the flat Adam step against plain torch streaming ops of the same size (bandwidth calibration)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from frustum_convnet_amd.train_state import FlatTrainState
 import bench
