@@ -189,7 +189,14 @@ def cpu_baseline(batch, npoint):
 def main():
     a = parse()
     from frustum_convnet_amd import dist as fdist, synth
-    rank, world, local = fdist.init_from_env()
+    # FCN_BENCH_BACKEND=gloo + FCN_BENCH_ONE_DEVICE=1: rehearsal of the N > 1 path with every rank on GPU 0 (a 1-GPU box
+    # cannot form an RCCL communicator); the driver's multi-GPU runs leave both unset.
+    one_dev = os.environ.get("FCN_BENCH_ONE_DEVICE", "0") == "1"
+    if one_dev:
+        torch.cuda.set_device(0)
+    rank, world, local = fdist.init_from_env(backend=os.environ.get("FCN_BENCH_BACKEND") or None)
+    if one_dev:
+        local = 0
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
