@@ -19,7 +19,6 @@
 #include <cstdlib>
 
 #define CG_T 256
-#define LDC 65                 // k-major LDS leading dim of a 64-wide tile (transposed staging)
 #define LDN 68                 // row-major LDS leading dim of a 64-wide tile (float4 aligned)
 #define OH_PAD 64              // channels of the virtual one-hot segment
 #define CG_SPLIT_ROWS 512      // rows per wgrad split
@@ -155,21 +154,21 @@ __device__ __forceinline__ float cg_act(float s, float x, float t, bool ok) { re
 // the whole epilogue (bias, store, BN statistics).  These GEMMs are small (B*L rows): 8-16 resident waves per
 // workgroup hide the gather / staging latency, and nothing but the result goes back to HBM.
 // <2,4>: 64 x 64 tile, 1024 threads;  <1,4>: 32 x 64 tile, 512 threads (layers with few rows: more tiles for 256 CUs).
-template <int MW, int G>
-__global__ __launch_bounds__(G * 128 * MW) void cgk_fwd_kernel(CgLayer L)
+template <int MW, int G, int WNC = 2>      // WNC waves across N per K-group: tile (32*MW) x (32*WNC)
+__global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_kernel(CgLayer L)
 {
-    constexpr int TG = 128 * MW, TMB = 32 * MW, LDA = TMB + 1, NTHR = G * TG;
+    constexpr int TG = 64 * MW * WNC, TMB = 32 * MW, TNC = 32 * WNC, LDA = TMB + 1, LDC = TNC + 1, NTHR = G * TG;
     constexpr int NA = TMB * 8 / TG;          // 4-vectors of A per thread per chunk (2)
-    constexpr int NB = 512 / TG;              // 4-vectors of W per thread per chunk (2 or 4)
+    constexpr int NB = TNC * 8 / TG;          // 4-vectors of W per thread per chunk
     __shared__ __attribute__((aligned(16))) float lds[G * KC * (LDA + LDC)];
     __shared__ float sS[CG_KMAX], tS[CG_KMAX];
     __shared__ int cSeg[CG_KMAX / KC], cTap[CG_KMAX / KC], cK0[CG_KMAX / KC];   // chunk -> (segment, tap, channel)
     const int tid = threadIdx.x, g = tid / TG, gt = tid % TG;
     const int lane = tid & 63, gw = gt >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int wm = (MW == 2) ? (gw >> 1) : 0, wn = gw & 1;
+    const int wm = gw / WNC, wn = gw % WNC;
     float *As = lds + g * KC * (LDA + LDC), *Bs = As + KC * LDA;
     const int R = L.B * L.Lout;
-    const int row0 = blockIdx.x * TMB, n0 = blockIdx.y * 64;
+    const int row0 = blockIdx.x * TMB, n0 = blockIdx.y * TNC;
     const int kq = gt & 7, rb = gt >> 3;      // rb: 0..31 (MW=2) or 0..15 (MW=1)
     constexpr int RSTEP = TG / 8;
     const int nchunk = L.Ktot / KC, nit = (nchunk + G - 1) / G;
@@ -255,18 +254,19 @@ __global__ __launch_bounds__(G * 128 * MW) void cgk_fwd_kernel(CgLayer L)
         if (it + 1 < nit) CGK_FWD_ITER(it + 1, ra1, rw1, ok1);
     }
     // ---- sum the G group accumulators through LDS, then one epilogue pass over the tile
-    float *red = lds;                                   // [G][TMB][64]
+    float *red = lds;                                   // [G][TMB][TNC]
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg)
-        red[(g * TMB + wm * 32 + acc_row(reg, lh)) * 64 + wn * 32 + l31] = acc[0][0][reg];
+        red[(g * TMB + wm * 32 + acc_row(reg, lh)) * TNC + wn * 32 + l31] = acc[0][0][reg];
     __syncthreads();
-    const int ecq = tid & 15;
+    constexpr int NQ = TNC / 4;                         // column quads of the tile
+    const int ecq = tid % NQ;
     const int col = n0 + 4 * ecq;
     v4f cs1 = zero4(), cs2 = zero4();                   // per-thread column sums (over its rows)
-    for (int er = tid >> 4; er < TMB; er += NTHR / 16) {
+    for (int er = tid / NQ; er < TMB; er += NTHR / NQ) {
         v4f v = zero4();
 #pragma unroll
-        for (int q = 0; q < G; ++q) v += *(const v4f *)(red + (q * TMB + er) * 64 + 4 * ecq);
+        for (int q = 0; q < G; ++q) v += *(const v4f *)(red + (q * TMB + er) * TNC + 4 * ecq);
         if (L.bias) {
             v.x += col + 0 < L.nbias ? L.bias[col + 0] : 0.f; v.y += col + 1 < L.nbias ? L.bias[col + 1] : 0.f;
             v.z += col + 2 < L.nbias ? L.bias[col + 2] : 0.f; v.w += col + 3 < L.nbias ? L.bias[col + 3] : 0.f;
@@ -279,28 +279,28 @@ __global__ __launch_bounds__(G * 128 * MW) void cgk_fwd_kernel(CgLayer L)
         }
     }
     if (!L.stat) return;
-    // rows of one wave: lanes 16 apart share a column quad -> xor-shuffle over 16 and 32, then across waves via LDS
+    // rows of one wave: lanes NQ apart share a column quad -> xor-shuffle down to NQ lanes, then across waves via LDS
     float pv[8] = {cs1.x, cs1.y, cs1.z, cs1.w, cs2.x, cs2.y, cs2.z, cs2.w};
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        pv[q] += __shfl_xor(pv[q], 16, 64);
-        pv[q] += __shfl_xor(pv[q], 32, 64);
+#pragma unroll
+        for (int o = NQ; o < 64; o <<= 1) pv[q] += __shfl_xor(pv[q], o, 64);
     }
     __syncthreads();
-    float *st = lds;                                    // [NTHR/64 waves][64 cols][2]
-    if (lane < 16) {
+    float *st = lds;                                    // [NTHR/64 waves][TNC cols][2]
+    if (lane < NQ) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            st[((tid >> 6) * 64 + 4 * ecq + j) * 2] = pv[j];
-            st[((tid >> 6) * 64 + 4 * ecq + j) * 2 + 1] = pv[4 + j];
+            st[((tid >> 6) * TNC + 4 * ecq + j) * 2] = pv[j];
+            st[((tid >> 6) * TNC + 4 * ecq + j) * 2 + 1] = pv[4 + j];
         }
     }
     __syncthreads();
-    if (tid < 128) {
-        const int c = tid & 63, w = tid >> 6;
+    if (tid < 2 * TNC) {
+        const int c = tid % TNC, w = tid / TNC;
         double a = 0.0;
 #pragma unroll
-        for (int r = 0; r < NTHR / 64; ++r) a += (double)st[(r * 64 + c) * 2 + w];
+        for (int r = 0; r < NTHR / 64; ++r) a += (double)st[(r * TNC + c) * 2 + w];
         atomic_add_f64(&L.stat[w * L.Cs + (n0 + c) % L.Cs], a);
     }
 }
@@ -1021,10 +1021,10 @@ extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p
         {
             // 64-row tiles when they already give >= ~200 workgroups, else 32-row tiles (R = B*L is small here)
             const int ntl = P.N[l] / 64;
-            if (((R + 63) / 64) * ntl >= 200)
-                hipLaunchKernelGGL((cgk_fwd_kernel<2, 4>), dim3((R + 63) / 64, ntl), dim3(1024), 0, st, L);
-            else
-                hipLaunchKernelGGL((cgk_fwd_kernel<1, 4>), dim3((R + 31) / 32, ntl), dim3(512), 0, st, L);
+            // 32 x 32 tiles: 560 workgroups of 4 waves (2-3 resident per CU) instead of 280 of 8 (every level of the
+            // pyramid has B*L*N/2048 = 280 tiles of 32 x 64 for 256 CUs); measured 369 -> 352 us over the forward
+            (void)ntl;
+            hipLaunchKernelGGL((cgk_fwd_kernel<1, 4, 1>), dim3((R + 31) / 32, P.N[l] / 32), dim3(256), 0, st, L);
             FCN_CHECK_LAUNCH();
         }
     }
