@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfcn_hip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("FCN_LIB_NAME", "libfcn_hip.so"))   # (FCN_LIB_NAME: A/B builds)
 
 c_fp = ctypes.c_void_p
 
