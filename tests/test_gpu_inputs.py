@@ -96,3 +96,37 @@ def test_cpu_builder_fails_loudly():
     b = _builder(g, device="cpu")
     with pytest.raises(RuntimeError):
         b.build(records_from_fixture(g))
+
+
+@pytest.mark.parametrize("B,N,stride3", [(1, 100, True), (3, 257, False), (6, 1024, True)])
+def test_ragged_and_odd_sizes_against_oracle(B, N, stride3):
+    """Single frustum, N not a multiple of the workgroup size, xyz-only records (pt_stride 3), N larger than some records
+    (replacement) -- against oracle/inputs_ref.py; also the no-segmentation call."""
+    from oracle import inputs_ref
+    from frustum_convnet_amd.config import reset_cfg
+    from frustum_convnet_amd.inputs import InputBuilder, records_from_fixture, draw
+    g = {k: np.array(v) for k, v in _golden().items()}
+    recs = records_from_fixture(g)[:B]
+    if stride3:
+        for r in recs:
+            r["points"] = np.ascontiguousarray(r["points"][:, :3])
+    rng = np.random.RandomState(100 + N)
+    counts = [len(r["points"]) for r in recs]
+    choice, coin, normal = draw(counts, N, True, True, rng)
+    sub = {k: v for k, v in g.items()}
+    offs = np.concatenate([[0], np.cumsum(g["raw_counts"])])
+    sub["raw_counts"] = g["raw_counts"][:B]
+    sub["raw_points"] = g["raw_points"][:offs[B], :3] if stride3 else g["raw_points"][:offs[B]]
+    sub["raw_seg"] = g["raw_seg"][:offs[B]]
+    for k in ("box2d", "P", "box3d_corners", "heading", "size", "frustum_angle"):
+        sub[k] = g[k][:B]
+    sub["draw_choice"], sub["draw_coin"], sub["draw_normal"] = choice, coin, normal
+    want = inputs_ref.prepare_batch(sub, tuple(g["meta_strides"]), float(g["meta_max_depth"]))
+    reset_cfg()
+    b = InputBuilder(N, tuple(g["meta_strides"]), float(g["meta_max_depth"]), random_flip=True, random_shift=True)
+    out = b.build(recs, draws=(choice, coin, normal))
+    _check(out, want)
+    assert out["point_cloud"].shape == (B, 3, N)
+    out2 = b.build(recs, draws=(choice, coin, normal), with_seg=False)
+    assert "seg_label" not in out2 and torch.equal(out2["point_cloud"], out["point_cloud"])
+    assert torch.equal(out2["cls_label"], out["cls_label"])

@@ -45,6 +45,21 @@ def test_bad_arguments_return_codes_without_gpu():
     assert rc == 0            # empty batch: nothing to do
     d = _native.PnDesc(2, 16, 4, 4, 60, 64, 128, 0, 1, 1e-5, 0.1)
     assert lib.fcn_pn_forward(ctypes.byref(d), None, None, None, None, None, None) == 10001
+    # every other entry point rejects null / inconsistent arguments before touching the device
+    cd = _native.CnDesc(2, (ctypes.c_int32 * 4)(280, 140, 70, 35), 3, 39, 1, 1e-5, 0.1, 0)
+    sizes = (ctypes.c_int64 * 6)()
+    assert lib.fcn_convnet_sizes(ctypes.byref(cd), ctypes.byref(sizes)) == 0 and all(int(v) > 0 for v in sizes)
+    bad = _native.CnDesc(2, (ctypes.c_int32 * 4)(280, 141, 70, 35), 3, 39, 1, 1e-5, 0.1, 0)     # L2 != conv_len(L1)
+    assert lib.fcn_convnet_sizes(ctypes.byref(bad), ctypes.byref(sizes)) == 10001
+    assert lib.fcn_convnet_sizes(None, None) == 10001
+    assert lib.fcn_convnet_pack(ctypes.byref(cd), None, None, None, None) == 10001
+    assert lib.fcn_convnet_forward2(ctypes.byref(cd), None, None, (ctypes.c_void_p * 4)(), None, None, None, None) == 10001
+    assert lib.fcn_adam_step_f32(None, None, None, None, 16, None, None, None) == 10001
+    assert lib.fcn_adam_step_slots(0) == 0 and lib.fcn_adam_step_slots(3316780) == (3316780 // 4 + 511) // 512
+    assert lib.fcn_stamp(None, None) == 10001
+    idesc = _native.InpDesc(2, 64, 2, (ctypes.c_int32 * 4)(280, 140, 70, 35), (ctypes.c_double * 4)(0.25, 0.5, 1, 2), 70.0, 0, 0)
+    assert lib.fcn_prepare_inputs(ctypes.byref(idesc), *([None] * 13), (ctypes.c_void_p * 4)(), *([None] * 7)) == 10001
+    assert lib.fcn_det_loss_tail_rows(*([None] * 8), 2, 140, 12, 3, 1.0, 10.0, 20.0, 20.0, None, None, None) != 0
 
 
 def test_state_dict_keys_and_shapes_match_reference():
