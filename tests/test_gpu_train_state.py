@@ -139,3 +139,49 @@ def test_two_step_trajectory_vs_cpu_oracle(lr):
     for it, (r, h) in enumerate(zip(ref_losses, got)):
         tol = 5e-2 if (lr > 5e-4 and it == 2) else 1e-3
         assert abs(r - h) <= tol * abs(r), (lr, ref_losses, got)
+
+
+def test_short_training_run_in_one_hipgraph():
+    """Ten optimiser steps with the whole step (forward, backward, Adam) captured once and replayed -- what bench.py
+    times: the loss falls, the step counter advances on the device, and the replayed graph gives the same parameters as
+    the same ten steps launched eagerly."""
+    from frustum_convnet_amd.train_state import FlatTrainState
+    g = load_golden("car_b4_n512")
+    data = synth.to_torch(golden_inputs(g), "cuda")
+
+    def make():
+        m = _model(g)
+        m.train()
+        return m, FlatTrainState(m, lr=1e-4, weight_decay=1e-4)
+
+    m1, s1 = make()
+    eager = []
+    for _ in range(10):
+        lo, _ = m1(data)
+        eager.append(float(lo["total_loss"]))
+        lo["total_loss"].backward()
+        s1.step()
+    assert eager[-1] < 0.6 * eager[0] and int(s1.step_count) == 10
+
+    m2, s2 = make()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                       # warm-up outside capture (allocator, workspaces)
+        lo, _ = m2(data)
+        lo["total_loss"].backward()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        lo, _ = m2(data)
+        lo["total_loss"].backward()
+        s2.adam_step()
+    # the warm-up forward moved the BN running statistics once more than the eager run; parameters are what we compare
+    losses = []
+    for _ in range(10):
+        graph.replay()
+        losses.append(float(lo["total_loss"]))
+    assert int(s2.step_count) == 10
+    assert abs(losses[-1] - eager[-1]) <= 2e-3 * abs(eager[-1]), (losses, eager)
+    d = float((s1.flat - s2.flat).abs().max())
+    assert d <= 5e-4, d
