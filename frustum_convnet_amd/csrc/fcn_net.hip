@@ -54,7 +54,8 @@ struct CgLayer {
     float *y;                  // (B*Lout, Cout) pre-BN output
     double *stat;              // sum[Cs], sumsq[Cs] or nullptr
     float eps, momentum;
-    int dbg;                   // ablation switches (env FCN_DBG): 1 skip MFMA, 2 skip global loads, 4 skip LDS staging
+    int dbg;                   // timing-ablation switches (env FCN_DBG, tools/fcn_micro.py; results are WRONG when set): 1 skip MFMA,
+                               // 2 skip global loads, 4 skip LDS staging, 8 no BN sums, 16 no BN finalisation, 32 no epilogue
 };
 
 #define SEL3(i, a0, a1, a2) ((i) == 0 ? (a0) : ((i) == 1 ? (a1) : (a2)))
@@ -112,7 +113,7 @@ __device__ __forceinline__ void cg_fill_bn(const CgLayer &L, float *sS, float *t
         if (s < L.nseg) {
             const CgSeg &S = L.seg[s];
             const int C = S.C, span = L.KT * C;
-            if (S.gamma) {
+            if (S.gamma && !(L.dbg & 16)) {
                 const bool batch = S.stat != nullptr;
                 const bool wr = pub && S.writer;
                 for (int k = tid; k < C; k += nthr) {
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_kernel(CgLayer L)
         CGK_FWD_ITER(it, ra0, rw0, ok0);
         if (it + 1 < nit) CGK_FWD_ITER(it + 1, ra1, rw1, ok1);
     }
+    if (L.dbg & 32) return;                             // (timing ablation: no epilogue)
     // ---- sum the G group accumulators through LDS, then one epilogue pass over the tile
     float *red = lds;                                   // [G][TMB][TNC]
 #pragma unroll
