@@ -17,7 +17,12 @@
  *                               models/det_base.py:75-101,134-157 (+ autograd of the same)
  *   fcn_convnet_forward/backward ConvFeatNet.forward + cls_out/reg_out (cuDNN/ATen in the reference),
  *                               models/det_base.py:196-224,367-368 (+ autograd of the same)
- *   fcn_det_loss_tail           the ~150 torch ops of the train-loss tail, models/det_base.py:373-476
+ *   fcn_convnet_pack / _forward2 the same forward with the weight re-packing split off and per-feature-map start events
+ *   fcn_det_loss_tail[_rows]    the ~150 torch ops of the train-loss tail, models/det_base.py:373-476
+ *   fcn_adam_step_f32           optim.Adam.step() of the step loop, train/train_net_det.py:131-133,321-339
+ *   fcn_prepare_inputs          the per-sample numpy work of the data loader + collate,
+ *                               datasets/provider_sample.py:137-262,270-327,396-397
+ *   fcn_stamp                   (measurement aid, no reference counterpart)
  *
  * Buffers are caller-owned.  "ws" buffers are scratch the caller provides (sizes documented per call).
  */
@@ -153,7 +158,7 @@ typedef struct fcn_cn_params {
 typedef struct fcn_cn_ws {
     float  *y, *dz, *wp, *bn;
     double *stat, *bstat;
-    float  *coef, *partial;
+    float  *coef, *partial;      /* coef: unused since BN backward is finalised by its consumers (kept in the layout) */
     float  *oh64;                /* B * 64 floats: the one-hot vector zero-padded to 64 channels */
 } fcn_cn_ws;
 
