@@ -116,7 +116,8 @@ class PointNetFeat(nn.Module):
         #   4: the FCN backward continues on a second stream once the scale-4 gradient is final (fcn_fused.py)
         # Every bit ADDS overlap on paper -- the FCN's first nine layers beside scale 4's PointNet, scale 4's backward
         # beside the rest of the FCN backward -- and every bit measured SLOWER (16.1k -> 14.0-15.3k frustums/s, also with the
-        # streams folded into the 4 hardware queues ROCm uses by default): the
+        # streams folded into the 4 hardware queues ROCm uses by default, and with a high-priority capture stream -- graph replay
+        # ignores stream priorities): the
         # captured branches already keep the CUs busy, and stretching the two latency-bound FCN chains costs more than
         # the overlap returns.  Kept as tested options of the C-ABI, off by default.
         self.topo = int(os.environ.get("FCN_TOPO", "0"))
