@@ -101,30 +101,37 @@ struct FwdArgs {
 // MODE 0: operand rows are conv1+BN1+ReLU of the entries (computed here); MODE 1: BN+ReLU of aprev.
 // Workgroup = 2 x WN waves; tile = 128 rows x (32*NT*WN) output channels.  WN = 4 (512 threads) shares one
 // staged A tile between 256 output columns, halving the BN+ReLU staging work per output element.
-template <int MODE, int NT, int WN>
-__global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(3, 4))) void fwd_gemm_kernel(FwdArgs a)
+// MT = 1: 64-row tiles, two workgroups per listed 128-row tile (scale 4's conv3: 1140 big tiles are 1.5 waves of the 768
+// resident slots -- two rounds; 2280 half tiles on 1024 slots are 2.2 half rounds).
+template <int MODE, int NT, int WN, int MT = 2>
+__global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 1 ? 4 : 3, 4))) void fwd_gemm_kernel(FwdArgs a)
 {
     constexpr int NTHR = 128 * WN;
+    constexpr int TM = 64 * MT;               // rows of the tile
+    constexpr int SUB = 128 / TM;             // workgroups per listed 128-row tile
+    constexpr int LDA = TM + 1;               // k-major staging of the TM-row tile
     constexpr int TN = 32 * NT * WN;
     constexpr int LDB = TN + 1;
-    constexpr int NA4 = 1024 / NTHR;          // float4 of A per thread per chunk (MODE 1)
+    constexpr int NA4 = TM * 8 / NTHR;        // float4 of A per thread per chunk (MODE 1)
     constexpr int NB4 = TN * 8 / NTHR;        // float4 of W per thread per chunk
-    constexpr int KPT = 4096 / NTHR;          // MODE 0: k values per thread per chunk
-    __shared__ float As[KC * LDT];
+    constexpr int KPT = KC * TM / NTHR;       // MODE 0: k values per thread per chunk
+    __shared__ float As[KC * LDA];
     __shared__ float Bs[KC * LDB];
     __shared__ float tS[MAXC];
     __shared__ float sS[MODE == 0 ? 3 * MAXC : MAXC];   // MODE 0: alpha[CIN][3]
-    __shared__ float wS[128];
+    __shared__ float wS[TM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    if ((int)blockIdx.x >= a.tiles[0]) return;
-    const int code = a.tiles[4 + blockIdx.x];
+    const int lt = blockIdx.x / SUB, sub = blockIdx.x % SUB;
+    if (lt >= a.tiles[0]) return;
+    const int code = a.tiles[4 + lt];
     const int b = code / a.tps, t = code % a.tps;
     const int nent = a.woff[(int64_t)b * (a.L + 1) + a.L];
-    const int row0 = t * 128;
-    const int nvalid = min(128, nent - row0);
+    const int row0 = t * 128 + sub * TM;
+    const int nvalid = min(TM, nent - row0);
+    if (nvalid <= 0) return;
     const int64_t grow0 = (int64_t)b * a.cap + row0;
     const int n0 = blockIdx.y * TN;
     const int CIN = a.CIN, COUT = a.COUT;
@@ -140,9 +147,9 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(3, 4))
             sS[i] = s;
         }
     }
-    if (tid < 128) wS[tid] = (tid < nvalid) ? a.ent[grow0 + tid].w : 0.f;
+    if (tid < TM) wS[tid] = (tid < nvalid) ? a.ent[grow0 + tid].w : 0.f;
     float ux = 0.f, uy = 0.f, uz = 0.f;
-    const int r0 = tid & 127;
+    const int r0 = tid % TM;
     const bool r0valid = r0 < nvalid;
     if (MODE == 0 && r0valid) {
         const float4 e = a.ent[grow0 + r0];
@@ -150,8 +157,8 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(3, 4))
     }
     __syncthreads();
 
-    f32x16 acc[2][NT];
-    acc_zero<2, NT>(acc);
+    f32x16 acc[MT][NT];
+    acc_zero<MT, NT>(acc);
     float4 ra[NA4], rw[NB4];
     const int nchunk = CIN / KC;
 
@@ -187,17 +194,17 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(3, 4))
                 for (int j = 0; j < 4; ++j) {
                     const int k = 4 * kq + j;
                     const float z = fmaf(sS[c * KC + k], v[j], tS[c * KC + k]);
-                    As[k * LDT + r] = ok ? fmaxf(z, 0.f) : 0.f;
+                    As[k * LDA + r] = ok ? fmaxf(z, 0.f) : 0.f;
                 }
             }
         } else {
-            const int part = tid >> 7;
+            const int part = tid / TM;
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
                 const int k = part * KPT + j;
                 const int kk = c * KC + k;
                 const float z = l1_pre(&sS[3 * kk], tS[kk], ux, uy, uz);
-                As[k * LDT + r0] = r0valid ? fmaxf(z, 0.f) : 0.f;
+                As[k * LDA + r0] = r0valid ? fmaxf(z, 0.f) : 0.f;
             }
         }
 #pragma unroll
@@ -210,18 +217,18 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(3, 4))
         }
         __syncthreads();
         if (c + 1 < nchunk) load_chunk(c + 1);
-        mma_chunk<2, NT, LDT, LDB>(As, Bs, wm * 64, wn * 32 * NT, acc);
+        mma_chunk<MT, NT, LDA, LDB>(As, Bs, wm * 32 * MT, wn * 32 * NT, acc);
         __syncthreads();
     }
 
     // ---- epilogue: store y (valid rows), per-channel weighted statistics
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int row = wm * 64 + mt * 32 + acc_row(reg, lh);
+                const int row = wm * 32 * MT + mt * 32 + acc_row(reg, lh);
                 const int col = n0 + wn * 32 * NT + nt * 32 + l31;
                 if (row < nvalid) a.y[(grow0 + row) * COUT + col] = acc[mt][nt][reg];
             }
@@ -231,10 +238,10 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(3, 4))
         for (int nt = 0; nt < NT; ++nt) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    const float w = wS[wm * 64 + mt * 32 + acc_row(reg, lh)];
+                    const float w = wS[wm * 32 * MT + mt * 32 + acc_row(reg, lh)];
                     const float v = acc[mt][nt][reg];
                     s1 = fmaf(w, v, s1);
                     s2 = fmaf(w * v, v, s2);
@@ -328,6 +335,8 @@ static int launch_fwd_gemm(const FwdArgs &a, int B, hipStream_t st)
     const unsigned nt = (unsigned)(B * a.tps);
     if (FCN_WIDE_TILES && a.COUT % 256 == 0) {
         hipLaunchKernelGGL((fwd_gemm_kernel<MODE, 2, 4>), dim3(nt, a.COUT / 256), dim3(512), 0, st, a);
+    } else if (MODE == 1 && a.COUT >= 512 && a.COUT % 128 == 0) {      // the widest conv3: 64 x 128 tiles
+        hipLaunchKernelGGL((fwd_gemm_kernel<MODE, 2, 2, 1>), dim3(2 * nt, a.COUT / 128), dim3(256), 0, st, a);
     } else if (a.COUT % 128 == 0) {
         hipLaunchKernelGGL((fwd_gemm_kernel<MODE, 2, 2>), dim3(nt, a.COUT / 128), dim3(256), 0, st, a);
     } else {
