@@ -370,16 +370,26 @@ struct CgPackAll {
     const float *oh;                    // one-hot (B, nvec) -> oh64 (B, OH_PAD), zero padded
     float *oh64;
     int B, nvec;
+    // the BN sum buffers of the coming forward (stat) and backward (bstat) are zeroed here too: no memset nodes on the
+    // latency-bound chains (the packing runs ahead of both, on its own stream)
+    double *z0, *z1;
+    int nz;
 };
 
 __global__ void cg_pack_kernel(CgPackAll t)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= t.pre[CN_NLAYER]) {
-        const int64_t j = i - t.pre[CN_NLAYER];
+        int64_t j = i - t.pre[CN_NLAYER];
         if (j < (int64_t)t.B * OH_PAD) {
             const int b = (int)(j / OH_PAD), v = (int)(j % OH_PAD);
             t.oh64[j] = (v < t.nvec) ? t.oh[(int64_t)b * t.nvec + v] : 0.f;
+            return;
+        }
+        j -= (int64_t)t.B * OH_PAD;
+        if (j < t.nz) {
+            if (t.z0) t.z0[j] = 0.0;
+            if (t.z1) t.z1[j] = 0.0;
         }
         return;
     }
@@ -947,8 +957,9 @@ static int cn_pack(const fcn_cn_desc *d, const fcn_cn_params *p, const CnPlan &P
         t.nrow_real[l] = P.nrow_real[l];
     }
     t.oh = one_hot; t.oh64 = ws->oh64; t.B = d->B; t.nvec = d->nvec;
-    hipLaunchKernelGGL(cg_pack_kernel, dim3((unsigned)((t.pre[CN_NLAYER] + (int64_t)d->B * OH_PAD + 255) / 256)), dim3(256),
-                       0, st, t);
+    t.z0 = d->training ? ws->stat : nullptr; t.z1 = d->training ? ws->bstat : nullptr; t.nz = O.st[CN_NLAYER];
+    hipLaunchKernelGGL(cg_pack_kernel,
+                       dim3((unsigned)((t.pre[CN_NLAYER] + (int64_t)d->B * OH_PAD + t.nz + 255) / 256)), dim3(256), 0, st, t);
     FCN_CHECK_LAUNCH();
     return 0;
 }
@@ -996,11 +1007,7 @@ extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p
     CnOffsets O;
     cn_offsets(d, P, O);
     const int tr = d->training ? 1 : 0;
-    if (tr) {
-        hipError_t e = hipMemsetAsync(ws->stat, 0, sizeof(double) * (size_t)O.st[CN_NLAYER], st);
-        if (e != hipSuccess) return (int)e;
-    }
-    if (!d->prepacked) FCN_TRY(cn_pack(d, p, P, O, ws, one_hot, st));
+    if (!d->prepacked) FCN_TRY(cn_pack(d, p, P, O, ws, one_hot, st));      // (also zeroes ws->stat / ws->bstat)
     const int order[CN_NLAYER] = {0, 1, 2, 3, 10, 4, 5, 6, 11, 7, 8, 9, 12, 13};
     bool published[CN_NLAYER];
     for (int l = 0; l < CN_NLAYER; ++l) published[l] = false;
@@ -1074,8 +1081,7 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
     FCN_TRY(cn_make_plan(d, P));
     CnOffsets O;
     cn_offsets(d, P, O);
-    hipError_t e = hipMemsetAsync(ws->bstat, 0, sizeof(double) * (size_t)O.st[CN_NLAYER], st);
-    if (e != hipSuccess) return (int)e;
+    hipError_t e = hipSuccess;          // ws->bstat was zeroed by the packing launch of this forward (cn_pack)
     const int64_t phalf = cn_partial_elems(d, P);       // ws->partial holds two of these (steps alternate)
 
     // consumers still to come for each producer layer (to know which dgrad is the last one)

@@ -624,8 +624,7 @@ extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, co
     double *bs3 = ws->bstat, *bs2 = bs3 + 2 * C3, *bsQ = bs2 + 2 * C2;
     float *coef3 = ws->coef, *coef2 = coef3 + 5 * C3;
 
-    hipError_t e = hipMemsetAsync(ws->bstat, 0, sizeof(double) * (size_t)(2 * C3 + 2 * C2 + 4 * C1), st);
-    if (e != hipSuccess) return (int)e;
+    hipError_t e = hipSuccess;          // ws->bstat was zeroed by the pool kernel of this scale's forward
 
     hipLaunchKernelGGL(poolbwd_kernel, dim3((L + PWB - 1) / PWB, C3 / 64, B), dim3(GT), 0, st, dfeat, ws->amax,
                        ws->y3, bn3, ws->gmax, bs3, L, cap, C3, C3 + d->nvec, d->nlc);

@@ -277,9 +277,12 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
 __global__ __launch_bounds__(GT) void pool_kernel(
     const float *__restrict__ y3, const float *__restrict__ bn3, const int32_t *__restrict__ woff,
     const int32_t *__restrict__ cnt, const float *__restrict__ one_hot, float *__restrict__ feat,
-    int32_t *__restrict__ amax, int L, int cap, int C3, int nvec, int nlc)
+    int32_t *__restrict__ amax, int L, int cap, int C3, int nvec, int nlc, double *__restrict__ zero_ptr, int zero_n)
 {
     __shared__ float outS[64 * (PW + 1)];
+    // the BN-backward sum buffer of this scale is zeroed by the last forward kernel: no memset node heading the backward
+    if (zero_ptr && blockIdx.x == 0 && blockIdx.z == 0)
+        for (int i = blockIdx.y * GT + threadIdx.x; i < zero_n; i += gridDim.y * GT) zero_ptr[i] = 0.0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, l0 = blockIdx.x * PW, c0 = blockIdx.y * 64;
     const int c = c0 + lane;
@@ -390,7 +393,8 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
 
     dim3 pgrid((L + PW - 1) / PW, C3 / 64, B);
     hipLaunchKernelGGL(pool_kernel, pgrid, dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, one_hot, feat,
-                       tr ? ws->amax : nullptr, L, cap, C3, d->nvec, d->nlc);
+                       tr ? ws->amax : nullptr, L, cap, C3, d->nvec, d->nlc, tr ? ws->bstat : nullptr,
+                       2 * C3 + 2 * C2 + 4 * C1);
     FCN_CHECK_LAUNCH();
     return 0;
 }

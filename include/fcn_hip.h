@@ -107,7 +107,8 @@ int fcn_pn_wgrad_rows(void);
 int fcn_pn_compact(const fcn_pn_desc *d, const float *pc /*(B,3,N)*/, const float *ref /*(B,3,L)*/,
                    const int64_t *idx, const int32_t *cnt, const fcn_pn_ws *ws, void *stream);
 
-/* Whole forward of one scale after fcn_pn_compact: feat (B, C3+nvec, L), one_hot (B,nvec) or NULL. */
+/* Whole forward of one scale after fcn_pn_compact: feat (B, C3+nvec, L), one_hot (B,nvec) or NULL.  In training mode its
+ * last kernel also zeroes ws.bstat (when non-NULL) for the fcn_pn_backward that follows. */
 int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, const int32_t *cnt,
                    const float *one_hot, const fcn_pn_ws *ws, float *feat, void *stream);
 
@@ -164,7 +165,8 @@ typedef struct fcn_cn_ws {
 
 int fcn_convnet_sizes(const fcn_cn_desc *d, int64_t *out6);
 /* Weight re-packing (3.3 M floats, torch layouts -> (N, Ktot)) + one-hot padding of fcn_convnet_forward as a separate
- * launch, so a caller can overlap it with the PointNet scales on another stream (then set d->prepacked = 1). */
+ * launch, so a caller can overlap it with the PointNet scales on another stream (then set d->prepacked = 1).  The launch
+ * also zeroes ws.stat and ws.bstat (training): fcn_convnet_forward / _backward enqueue no memset of their own. */
 int fcn_convnet_pack(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws, const float *one_hot, void *stream);
 /* feats[s]: (B, L[s], C_s) with C = 128,128,256,512 (fcn_pn_forward with nlc = 1); logits: (B*L[1], 64) rows, columns
  * 0..1 = cls_out, 2..2+reg_out = reg_out, rest zero. */
