@@ -157,7 +157,7 @@ __device__ __forceinline__ float cg_act(float s, float x, float t, bool ok) { re
 // In use: <1,4,1> (32 x 32 tile, 4 waves) -- 560 workgroups per layer; <1,4> (32 x 64) and <2,4> (64 x 64) measured
 // 5 % slower over the forward (280 tiles for 256 CUs at every level of the pyramid).
 template <int MW, int G, int WNC = 2>      // WNC waves across N per K-group: tile (32*MW) x (32*WNC)
-__global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_kernel(CgLayer L)
+__device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, const int by)
 {
     constexpr int TG = 64 * MW * WNC, TMB = 32 * MW, TNC = 32 * WNC, LDA = TMB + 1, LDC = TNC + 1, NTHR = G * TG;
     constexpr int NA = TMB * 8 / TG;          // 4-vectors of A per thread per chunk (2)
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_kernel(CgLayer L)
     const int wm = gw / WNC, wn = gw % WNC;
     float *As = lds + g * KC * (LDA + LDC), *Bs = As + KC * LDA;
     const int R = L.B * L.Lout;
-    const int row0 = blockIdx.x * TMB, n0 = blockIdx.y * TNC;
+    const int row0 = bx * TMB, n0 = by * TNC;
     const int kq = gt & 7, rb = gt >> 3;      // rb: 0..31 (MW=2) or 0..15 (MW=1)
     constexpr int RSTEP = TG / 8;
     const int nchunk = L.Ktot / KC, nit = (nchunk + G - 1) / G;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_kernel(CgLayer L)
         cg_locate(L, tid * KC, sg, tap, k0, so);
         cSeg[tid] = sg; cTap[tid] = tap; cK0[tid] = k0;
     }
-    cg_fill_bn(L, sS, tS, tid, NTHR, blockIdx.x == 0 && blockIdx.y == 0);
+    cg_fill_bn(L, sS, tS, tid, NTHR, bx == 0 && by == 0);
     // segment fields as scalars (static indices)
     const float *x0 = opaque_s(L.seg[0].x), *x1 = opaque_s(L.seg[1].x), *x2 = opaque_s(L.seg[2].x);
     const int C0 = opaque_s(L.seg[0].C), C1 = opaque_s(L.seg[1].C), C2 = opaque_s(L.seg[2].C);
@@ -308,6 +308,28 @@ __global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_kernel(CgLayer L)
     }
 }
 
+template <int MW, int G, int WNC = 2>
+__global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_kernel(CgLayer L)
+{
+    cgk_fwd_body<MW, G, WNC>(L, blockIdx.x, blockIdx.y);
+}
+
+// Two INDEPENDENT layers in one launch (a deconvolution next to the stride-2 conv that reads the same merge output):
+// workgroups [0, na) take layer A's tiles, the rest layer B's -- one launch skeleton less on the chain, and the two small
+// grids fill the CUs together.
+struct CgLayerPair {
+    CgLayer A, B;
+    int na, txa, txb;          // workgroups of A; row tiles of A and of B (tile t -> (t % tx, t / tx))
+};
+
+template <int MW, int G, int WNC>
+__global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_pair_kernel(CgLayerPair p)
+{
+    const int bid = blockIdx.x;
+    if (bid < p.na) cgk_fwd_body<MW, G, WNC>(p.A, bid % p.txa, bid / p.txa);
+    else cgk_fwd_body<MW, G, WNC>(p.B, (bid - p.na) % p.txb, (bid - p.na) / p.txb);
+}
+
 // BN-backward coefficients of one channel from the batch sums (sum dz, sum dz*xhat): gamma*rstd, mean, rstd, dbeta/M,
 // dgamma/M.  Like the forward's scale/shift they are derived by every consumer workgroup in its prologue; the
 // designated workgroup also exports dgamma / dbeta.
@@ -432,6 +454,8 @@ struct CgReduce {
     int nrow_real;
     float *dW;
     int gr;                    // split groups per workgroup (1, 2, 4, 8)
+    // gr == 0: the slot carries the heads' bias gradient instead (first launch, nothing to reduce yet):
+    // dW[n] = sum_r partial[r * nsplit + n] for n < nrow_real, one workgroup per column, nsplit = row stride, pk.N = rows
 };
 
 struct CgBwdStep {
@@ -742,6 +766,18 @@ __device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float
 __device__ __forceinline__ void cg_reduce_body(const CgReduce &q, int rid, float *smem)
 {
     const CgPack &p = q.pk;
+    if (q.gr == 0) {                    // column sum of dlogits (R = p.N rows, row stride q.nsplit): dbias of the heads
+        float t = 0.f;
+        for (int r = threadIdx.x; r < p.N; r += CGB_T) t += q.partial[(int64_t)r * q.nsplit + rid];
+        smem[threadIdx.x] = t;
+        __syncthreads();
+        for (int o = CGB_T / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) smem[threadIdx.x] += smem[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0 && rid < q.nrow_real) q.dW[rid] = smem[0];
+        return;
+    }
     const int gr = q.gr, per = CGB_T / gr;
     const int x = threadIdx.x % per, y = threadIdx.x / per;
     const int64_t e = (int64_t)rid * per + x;                   // N * Ktot is a multiple of 64 * 8
@@ -780,22 +816,6 @@ __global__ __launch_bounds__(CGB_T) void cg_bwd_step_kernel(CgBwdStep a)
     cg_dgrad_body(a.lay, a.cb, a.dz, a.lay.y, DGF(sg), DGF(segoff), DGF(ysrc), DGF(bnsrc), DGF(out), DGF(accumulate),
                   DGF(bstat_src), t % tx, t / tx, bid == 0, smem);
 #undef DGF
-}
-
-// dbias[n] = sum_r dlogits[r][n] (heads)
-__global__ void cg_colsum_kernel(const float *__restrict__ d, int R, int ld, int ncol, float *__restrict__ out)
-{
-    __shared__ float sh[256];
-    const int n = blockIdx.x;
-    float s = 0.f;
-    for (int r = threadIdx.x; r < R; r += 256) s += d[(int64_t)r * ld + n];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && n < ncol) out[n] = sh[0];
 }
 
 // ================================================================================================
@@ -1008,13 +1028,12 @@ extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p
     cn_offsets(d, P, O);
     const int tr = d->training ? 1 : 0;
     if (!d->prepacked) FCN_TRY(cn_pack(d, p, P, O, ws, one_hot, st));      // (also zeroes ws->stat / ws->bstat)
-    const int order[CN_NLAYER] = {0, 1, 2, 3, 10, 4, 5, 6, 11, 7, 8, 9, 12, 13};
+    // launches in dependency order; {4, 10} and {7, 11} are pairs of independent layers reading the same merge output
+    const int order[CN_NLAYER] = {0, 1, 2, 3, 4, 10, 5, 6, 7, 11, 8, 9, 12, 13};
     bool published[CN_NLAYER];
     for (int l = 0; l < CN_NLAYER; ++l) published[l] = false;
     bool waited[4] = {false, false, false, false};
-    for (int q = 0; q < CN_NLAYER; ++q) {
-        const int l = order[q];
-        CgLayer L;
+    auto prep = [&](int l, CgLayer &L) -> int {
         cn_fill_layer(d, p, P, O, ws, feats, one_hot, l, L);
         for (int s = 0; s < P.nseg[l]; ++s) {       // the first consumer of a BN layer publishes its statistics
             const int src = P.src[l][s];
@@ -1027,13 +1046,29 @@ extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p
         }
         if (l == 13) { L.y = logits; L.bias = p->bias; L.nbias = P.nrow_real[13]; }
         else if (tr && !(L.dbg & 8)) L.stat = ws->stat + O.st[l];      // (dbg 8: timing ablation without the BN sums)
+        return 0;
+    };
+    // 32 x 32 tiles: 560 workgroups of 4 waves (2-3 resident per CU) instead of 280 of 8 (every level of the pyramid has
+    // B*L*N/2048 = 280 tiles of 32 x 64 for 256 CUs); measured 369 -> 352 us over the forward
+    for (int q = 0; q < CN_NLAYER; ++q) {
+        const int l = order[q];
         const int R = d->B * P.Lout[l];
-        {
-            // 64-row tiles when they already give >= ~200 workgroups, else 32-row tiles (R = B*L is small here)
-            const int ntl = P.N[l] / 64;
-            // 32 x 32 tiles: 560 workgroups of 4 waves (2-3 resident per CU) instead of 280 of 8 (every level of the
-            // pyramid has B*L*N/2048 = 280 tiles of 32 x 64 for 256 CUs); measured 369 -> 352 us over the forward
-            (void)ntl;
+        const bool pair = (l == 4 || l == 7) && q + 1 < CN_NLAYER;
+        if (pair) {
+            const int l2 = order[q + 1];
+            CgLayerPair pp;
+            FCN_TRY(prep(l, pp.A));
+            FCN_TRY(prep(l2, pp.B));
+            const int R2 = d->B * P.Lout[l2];
+            pp.txa = (R + 31) / 32; pp.txb = (R2 + 31) / 32;
+            pp.na = pp.txa * (P.N[l] / 32);
+            const int nb = pp.txb * (P.N[l2] / 32);
+            hipLaunchKernelGGL((cgk_fwd_pair_kernel<1, 4, 1>), dim3(pp.na + nb), dim3(256), 0, st, pp);
+            FCN_CHECK_LAUNCH();
+            ++q;
+        } else {
+            CgLayer L;
+            FCN_TRY(prep(l, L));
             hipLaunchKernelGGL((cgk_fwd_kernel<1, 4, 1>), dim3((R + 31) / 32, P.N[l] / 32), dim3(256), 0, st, L);
             FCN_CHECK_LAUNCH();
         }
@@ -1116,8 +1151,10 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
             a.dz = (l == 13) ? dlogits : ws->dz + O.y[l];
             if (l == 13) {
                 a.lay.y = nullptr;
-                hipLaunchKernelGGL(cg_colsum_kernel, dim3(64), dim3(256), 0, st, dlogits, R, 64, P.nrow_real[13], dbias);
-                FCN_CHECK_LAUNCH();
+                // the heads' bias gradient rides in this first launch, in the (still empty) reduce slot
+                prev.partial = dlogits; prev.nsplit = 64; prev.pk.N = R; prev.nrow_real = P.nrow_real[13]; prev.dW = dbias;
+                prev.gr = 0;
+                prev_blocks = 64;
             } else {
                 a.cb.bstat = ws->bstat + O.st[l]; a.cb.gamma = p->gamma[l]; a.cb.bn = ws->bn + O.bn[l];
                 a.cb.M = (double)R * (P.dk[l] > 0 ? P.dk[l] : 1);
