@@ -804,10 +804,8 @@ __device__ __forceinline__ void cg_reduce_body(const CgReduce &q, int rid, float
     q.dW[o] = t;
 }
 
-__global__ __launch_bounds__(CGB_T) void cg_bwd_step_kernel(CgBwdStep a)
+__device__ __forceinline__ void cg_bwd_step_body(const CgBwdStep &a, const int bid, float *smem)
 {
-    __shared__ __attribute__((aligned(16))) float smem[CGB_SMEM];
-    const int bid = blockIdx.x;
     if (bid >= a.r_blk0) { cg_reduce_body(a.red, bid - a.r_blk0, smem); return; }
     if (bid >= a.w_blk0) { cg_wgrad_body(a, bid - a.w_blk0, smem); return; }
     const int role = (a.ndg > 2 && bid >= a.dg2.blk0) ? 2 : ((a.ndg > 1 && bid >= a.dg1.blk0) ? 1 : 0);
@@ -816,6 +814,27 @@ __global__ __launch_bounds__(CGB_T) void cg_bwd_step_kernel(CgBwdStep a)
     cg_dgrad_body(a.lay, a.cb, a.dz, a.lay.y, DGF(sg), DGF(segoff), DGF(ysrc), DGF(bnsrc), DGF(out), DGF(accumulate),
                   DGF(bstat_src), t % tx, t / tx, bid == 0, smem);
 #undef DGF
+}
+
+__global__ __launch_bounds__(CGB_T) void cg_bwd_step_kernel(CgBwdStep a)
+{
+    __shared__ __attribute__((aligned(16))) float smem[CGB_SMEM];
+    cg_bwd_step_body(a, blockIdx.x, smem);
+}
+
+// A chain step and an OFF-CHAIN step (the backward of a deconvolution, which only hangs off the heads) in one launch:
+// workgroups [0, na) belong to A, the rest to B.  The two must not write the same gradient buffer.
+struct CgBwdPair {
+    CgBwdStep A, B;
+    int na;
+};
+
+__global__ __launch_bounds__(CGB_T) void cg_bwd_pair_kernel(CgBwdPair p)
+{
+    __shared__ __attribute__((aligned(16))) float smem[CGB_SMEM];
+    const int bid = blockIdx.x;
+    if (bid < p.na) cg_bwd_step_body(p.A, bid, smem);
+    else cg_bwd_step_body(p.B, bid - p.na, smem);
 }
 
 // ================================================================================================
@@ -920,7 +939,8 @@ extern "C" int fcn_convnet_sizes(const fcn_cn_desc *d, int64_t *out6)
     FCN_TRY(cn_make_plan(d, P));
     CnOffsets O;
     cn_offsets(d, P, O);
-    const int64_t pmax = 2 * cn_partial_elems(d, P);   // two buffers: a step's reduce runs beside the next step's wgrad
+    const int64_t pmax = 4 * cn_partial_elems(d, P);   // (launch parity) x (chain / off-chain step): a step's reduce runs
+                                                       // beside the next launch's weight gradients
     out6[0] = O.y[CN_NLAYER];      // floats: y (and dz) of all layers
     out6[1] = O.wp[CN_NLAYER];     // floats: packed weights
     out6[2] = O.bn[CN_NLAYER];     // floats: bn scale/shift/mean/rstd
@@ -1117,7 +1137,7 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
     CnOffsets O;
     cn_offsets(d, P, O);
     hipError_t e = hipSuccess;          // ws->bstat was zeroed by the packing launch of this forward (cn_pack)
-    const int64_t phalf = cn_partial_elems(d, P);       // ws->partial holds two of these (steps alternate)
+    const int64_t pquart = cn_partial_elems(d, P);      // ws->partial holds four: (launch parity) x (chain / off-chain step)
 
     // consumers still to come for each producer layer (to know which dgrad is the last one)
     int pending[CN_NLAYER];
@@ -1128,12 +1148,11 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
     int seen[CN_NLAYER];
     for (int l = 0; l < CN_NLAYER; ++l) seen[l] = 0;
 
-    const int order[CN_NLAYER] = {13, 12, 9, 8, 7, 11, 6, 5, 4, 10, 3, 2, 1, 0};
-    CgReduce prev;                      // the reduce that rides in the next launch
-    prev.partial = nullptr; prev.nsplit = 0; prev.nrow_real = 0; prev.dW = nullptr; prev.gr = 1; cn_fill_pack(d, P, 0, prev.pk);
-    int prev_blocks = 0;
-    for (int q = 0; q <= CN_NLAYER; ++q) {
-        CgBwdStep a;
+    auto blank_reduce = [&](CgReduce &r) {
+        r.partial = nullptr; r.nsplit = 0; r.nrow_real = 0; r.dW = nullptr; r.gr = 1; cn_fill_pack(d, P, 0, r.pk);
+    };
+    // data-gradient + weight-gradient roles of layer l (l < 0: none); returns the workgroups in front of the reduce role
+    auto make_step = [&](int l, float *pbuf, CgBwdStep &a, CgReduce &own, int &own_blocks) -> int {
         a.ndg = 0; a.w_ns = 0; a.w_ny = 1; a.rows = 2 * KC; a.partial = nullptr; a.dz = nullptr;
         a.cb.bstat = nullptr; a.cb.gamma = nullptr; a.cb.bn = nullptr; a.cb.M = 1.0; a.cb.dgamma = nullptr; a.cb.dbeta = nullptr;
         CgDgSeg *dgs[3] = {&a.dg0, &a.dg1, &a.dg2};
@@ -1141,75 +1160,96 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
             dgs[s]->sg = 0; dgs[s]->segoff = 0; dgs[s]->ysrc = dgs[s]->bnsrc = nullptr; dgs[s]->out = nullptr;
             dgs[s]->accumulate = 0; dgs[s]->bstat_src = nullptr; dgs[s]->tx = 1; dgs[s]->blk0 = 0;
         }
+        blank_reduce(own);
+        own_blocks = 0;
         int nblk = 0;
-        CgReduce cur = prev;
-        int cur_blocks = 0;
-        if (q < CN_NLAYER) {
-            const int l = order[q];
-            cn_fill_layer(d, p, P, O, ws, feats, one_hot, l, a.lay);
-            const int R = d->B * P.Lout[l];
-            a.dz = (l == 13) ? dlogits : ws->dz + O.y[l];
-            if (l == 13) {
-                a.lay.y = nullptr;
-                // the heads' bias gradient rides in this first launch, in the (still empty) reduce slot
-                prev.partial = dlogits; prev.nsplit = 64; prev.pk.N = R; prev.nrow_real = P.nrow_real[13]; prev.dW = dbias;
-                prev.gr = 0;
-                prev_blocks = 64;
-            } else {
-                a.cb.bstat = ws->bstat + O.st[l]; a.cb.gamma = p->gamma[l]; a.cb.bn = ws->bn + O.bn[l];
-                a.cb.M = (double)R * (P.dk[l] > 0 ? P.dk[l] : 1);
-                a.cb.dgamma = dgamma[l]; a.cb.dbeta = dbeta[l];      // exported by workgroup 0 (a data-gradient tile)
-            }
-            // ---- data gradients into every non-constant source
-            int segoff = 0;
-            for (int s = 0; s < P.nseg[l]; ++s) {
-                const int src = P.src[l][s];
-                if (src != -9) {
-                    CgDgSeg &g = *dgs[a.ndg];
-                    g.sg = s; g.segoff = segoff;
-                    if (src >= 0) {
-                        g.ysrc = ws->y + O.y[src]; g.bnsrc = ws->bn + O.bn[src]; g.out = ws->dz + O.y[src];
-                        g.accumulate = seen[src] > 0 ? 1 : 0;
-                        seen[src] += 1;
-                        g.bstat_src = (seen[src] == pending[src]) ? ws->bstat + O.st[src] : nullptr;
-                    } else {
-                        g.out = dfeats[-src - 1];
-                    }
-                    const int Rs = d->B * a.lay.seg[s].Lsrc;
-                    g.tx = (Rs + 31) / 32;
-                    g.blk0 = nblk;
-                    nblk += g.tx * (P.C[l][s] / 64);
-                    a.ndg += 1;
-                }
-                segoff += P.KT[l] * P.C[l][s];
-            }
-            // ---- weight gradient partials of this layer
-            a.w_blk0 = nblk;
-            a.partial = ws->partial + (q & 1) * phalf;
-            a.w_ny = P.N[l] / 64;
-            cn_wgrad_split(R, a.w_ny * (P.Ktot[l] / 64), a.rows, a.w_ns);
-            nblk += a.w_ns * a.w_ny * (P.Ktot[l] / 64);
-            cur.partial = a.partial; cur.nsplit = a.w_ns; cn_fill_pack(d, P, l, cur.pk); cur.nrow_real = P.nrow_real[l];
-            cur.dW = dW[l];
-            cur.gr = a.w_ns >= 32 ? 8 : (a.w_ns >= 16 ? 4 : (a.w_ns >= 8 ? 2 : 1));
-            cur_blocks = (int)(((int64_t)P.N[l] * P.Ktot[l]) / (CGB_T / cur.gr));
-        } else {
-            cn_fill_layer(d, p, P, O, ws, feats, one_hot, 0, a.lay);      // unused by the reduce-only launch
+        if (l < 0) {
+            cn_fill_layer(d, p, P, O, ws, feats, one_hot, 0, a.lay);      // unused by a reduce-only step
             a.w_blk0 = 0;
+            return 0;
         }
-        // ---- the previous step's partials are complete: reduce them beside this step's work
-        a.r_blk0 = nblk;
-        if (prev_blocks > 0) { a.red = prev; nblk += prev_blocks; }
-        else { a.red.partial = nullptr; a.red.nsplit = 0; a.red.nrow_real = 0; a.red.dW = nullptr; a.red.gr = 1; cn_fill_pack(d, P, 0, a.red.pk); }
-        if (nblk > 0) {
-            hipLaunchKernelGGL(cg_bwd_step_kernel, dim3(nblk), dim3(CGB_T), 0, st, a);
+        cn_fill_layer(d, p, P, O, ws, feats, one_hot, l, a.lay);
+        const int R = d->B * P.Lout[l];
+        a.dz = (l == 13) ? dlogits : ws->dz + O.y[l];
+        if (l == 13) {
+            a.lay.y = nullptr;
+        } else {
+            a.cb.bstat = ws->bstat + O.st[l]; a.cb.gamma = p->gamma[l]; a.cb.bn = ws->bn + O.bn[l];
+            a.cb.M = (double)R * (P.dk[l] > 0 ? P.dk[l] : 1);
+            a.cb.dgamma = dgamma[l]; a.cb.dbeta = dbeta[l];      // exported by workgroup 0 (a data-gradient tile)
+        }
+        int segoff = 0;
+        for (int s = 0; s < P.nseg[l]; ++s) {       // data gradients into every non-constant source
+            const int src = P.src[l][s];
+            if (src != -9) {
+                CgDgSeg &g = *dgs[a.ndg];
+                g.sg = s; g.segoff = segoff;
+                if (src >= 0) {
+                    g.ysrc = ws->y + O.y[src]; g.bnsrc = ws->bn + O.bn[src]; g.out = ws->dz + O.y[src];
+                    g.accumulate = seen[src] > 0 ? 1 : 0;
+                    seen[src] += 1;
+                    g.bstat_src = (seen[src] == pending[src]) ? ws->bstat + O.st[src] : nullptr;
+                } else {
+                    g.out = dfeats[-src - 1];
+                }
+                const int Rs = d->B * a.lay.seg[s].Lsrc;
+                g.tx = (Rs + 31) / 32;
+                g.blk0 = nblk;
+                nblk += g.tx * (P.C[l][s] / 64);
+                a.ndg += 1;
+            }
+            segoff += P.KT[l] * P.C[l][s];
+        }
+        a.w_blk0 = nblk;                            // weight-gradient partials of this layer
+        a.partial = pbuf;
+        a.w_ny = P.N[l] / 64;
+        cn_wgrad_split(R, a.w_ny * (P.Ktot[l] / 64), a.rows, a.w_ns);
+        nblk += a.w_ns * a.w_ny * (P.Ktot[l] / 64);
+        own.partial = a.partial; own.nsplit = a.w_ns; cn_fill_pack(d, P, l, own.pk); own.nrow_real = P.nrow_real[l];
+        own.dW = dW[l];
+        own.gr = a.w_ns >= 32 ? 8 : (a.w_ns >= 16 ? 4 : (a.w_ns >= 8 ? 2 : 1));
+        own_blocks = (int)(((int64_t)P.N[l] * P.Ktot[l]) / (CGB_T / own.gr));
+        return nblk;
+    };
+
+    // Launch plan: the chain 13 12 9 8 7 6 5 4 3 2 1 0, with the two off-chain deconvolution steps riding along:
+    // block3_deconv (11) beside block4_conv2 (8) and block2_deconv (10) beside block3_conv2 (5) -- each BEFORE the chain
+    // step that accumulates into the same gradient buffer (7 -> dz[6], 4 -> dz[3]), never in the same launch.
+    const int chain[13] = {13, 12, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0, -1};
+    const int rider[13] = {-1, -1, -1, 11, -1, -1, 10, -1, -1, -1, -1, -1, -1};
+    CgReduce pendA, pendB;              // reduces that ride in the next launch
+    int pendA_blocks = 0, pendB_blocks = 0;
+    blank_reduce(pendA); blank_reduce(pendB);
+    // the heads' bias gradient rides in the first launch, in the (still empty) reduce slot
+    pendA.partial = dlogits; pendA.nsplit = 64; pendA.pk.N = d->B * P.Lout[13]; pendA.nrow_real = P.nrow_real[13];
+    pendA.dW = dbias; pendA.gr = 0; pendA_blocks = 64;
+    for (int k = 0; k < 13; ++k) {
+        CgBwdPair pp;
+        CgReduce ownA, ownB;
+        int ownA_blocks = 0, ownB_blocks = 0;
+        float *bufA = ws->partial + ((k & 1) * 2 + 0) * pquart, *bufB = ws->partial + ((k & 1) * 2 + 1) * pquart;
+        int nA = make_step(chain[k], bufA, pp.A, ownA, ownA_blocks);
+        pp.A.r_blk0 = nA;
+        if (pendA_blocks > 0) { pp.A.red = pendA; nA += pendA_blocks; } else blank_reduce(pp.A.red);
+        const bool needB = rider[k] >= 0 || pendB_blocks > 0;
+        int nB = 0;
+        if (needB) {
+            nB = make_step(rider[k], bufB, pp.B, ownB, ownB_blocks);
+            pp.B.r_blk0 = nB;
+            if (pendB_blocks > 0) { pp.B.red = pendB; nB += pendB_blocks; } else blank_reduce(pp.B.red);
+        }
+        pp.na = nA;
+        if (nA + nB > 0) {
+            if (nB > 0) hipLaunchKernelGGL(cg_bwd_pair_kernel, dim3(nA + nB), dim3(CGB_T), 0, st, pp);
+            else hipLaunchKernelGGL(cg_bwd_step_kernel, dim3(nA), dim3(CGB_T), 0, st, pp.A);
             FCN_CHECK_LAUNCH();
         }
-        prev = cur; prev_blocks = cur_blocks;
+        pendA = ownA; pendA_blocks = ownA_blocks;
+        pendB = ownB; pendB_blocks = ownB_blocks;
         if (cont) {
-            const int l = q < CN_NLAYER ? order[q] : -1;
+            const int l = chain[k];
             int ev = -1;
-            if (l == 9) ev = 0; else if (l == 6) ev = 1; else if (l == 3) ev = 2; else if (q == CN_NLAYER) ev = 3;
+            if (l == 9) ev = 0; else if (l == 6) ev = 1; else if (l == 3) ev = 2; else if (l == -1) ev = 3;
             if (ev >= 0) {
                 e = hipEventRecord((hipEvent_t)events[ev], st);
                 if (e != hipSuccess) return (int)e;
