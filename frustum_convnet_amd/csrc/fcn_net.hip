@@ -430,7 +430,7 @@ __global__ void cg_pack_kernel(CgPackAll t)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward: ONE launch per layer.  The data-gradient chain is a latency-bound sequence of small GEMMs (B*L rows) and
+// Backward: ONE launch per chain layer.  The data-gradient chain is a latency-bound sequence of small GEMMs (B*L rows) and
 // the weight gradients only hang off it; run as separate launches -- even on a second captured stream -- ROCm's graph
 // executor serialises them.  So each step's launch carries three kinds of workgroups, picked by block index:
 //   [0, w_blk0)       data-gradient tiles of every differentiated input segment of layer l   (the critical chain)
@@ -1126,7 +1126,7 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
     if (!d->training) return FCN_E_BADARG;
     if (!ws->y || !ws->dz || !ws->wp || !ws->bn || !ws->bstat || !ws->coef || !ws->partial) return FCN_E_BADARG;
     // stream2 / events (4 caller-owned hipEvent_t), optional: the gradient of the widest feature map (dfeats[3]) is final
-    // after the third launch (heads, block4_deconv, block4_merge).  From there the remaining twelve launches continue
+    // after the third launch (heads, block4_deconv, block4_merge).  From there the remaining launches continue
     // on stream2 so that `stream` is free again: the caller's scale-4 PointNet backward -- the long pole -- starts beside
     // the rest of the FCN backward instead of after it.  events[0]: fork; events[1]: dfeats[2] final (after
     // block3_merge); events[2]: dfeats[1] final (after block2_merge); events[3]: everything final (dfeats[0], all dW).

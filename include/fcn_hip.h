@@ -181,7 +181,7 @@ int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn
                          const float *const feats[4], const float *one_hot, const float *dlogits,
                          float *const dfeats[4], float *const dW[14], float *const dgamma[14],
                          float *const dbeta[14], float *dbias, void *stream, void *stream2, void *const *events);
-/* One launch per layer: its data-gradient tiles, its weight-gradient row splits and the reduce of the previous layer's
+/* One launch per chain layer (the two off-chain deconvolution steps ride along): its data-gradient tiles, its weight-gradient row splits and the reduce of the previous layer's
  * splits are workgroup roles of the same kernel.  stream2 / events: NULL, or a second stream + 4 caller-owned events --
  * after the launch that completes dfeats[3] the chain continues on stream2 (events[0] = fork, [1] = dfeats[2] final,
  * [2] = dfeats[1] final, [3] = all outputs final), so work queued on `stream` after the call waits for dfeats[3] only. */
