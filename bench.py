@@ -35,8 +35,8 @@ MLPS = ((64, 64, 128), (64, 64, 128), (128, 128, 256), (256, 256, 512))
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32, help="frustums per GPU")
     ap.add_argument("--npoint", type=int, default=1024)
     ap.add_argument("--eager", action="store_true", help="no hipGraph capture")
@@ -170,8 +170,6 @@ def cpu_baseline(batch, npoint):
     for k, v in sd.items():
         if v.dtype.is_floating_point and "running" not in k:
             v.requires_grad_(True)
-    cores = torch.get_num_threads()
-
     def step(b):
         data = synth.to_torch(synth.make_batch(b, npoint, seed=1234, variant="car", tilt=(0.01, 0.05)))
         t0 = time.perf_counter()
@@ -179,11 +177,22 @@ def cpu_baseline(batch, npoint):
         losses["total_loss"].backward()
         return time.perf_counter() - t0
 
-    step(2)                                # warm-up (thread pools, oneDNN primitives)
-    t = step(batch)
+    # The oracle's dense torch-CPU dataflow does not scale with threads (measured on the GPU box's 256-core host: 2.5
+    # frustums/s at 128 threads, 4.1 at 64, 5.2 at 32, 6.0 at 16, 6.3 at 8): time it at 16 and 8 threads and report the
+    # better one, with the thread count used.
+    saved = torch.get_num_threads()
+    best = None
+    for n in (16, 8):
+        torch.set_num_threads(min(n, saved))
+        step(2)                            # warm-up (thread pools, oneDNN primitives)
+        t = step(batch)
+        if best is None or t < best[0]:
+            best = (t, torch.get_num_threads())
+    torch.set_num_threads(saved)
+    t, cores = best
     return {"value": round(batch / t, 3), "unit": "frustums/s", "cores": cores, "kind": "port",
             "sample": "1 train fwd+bwd step of B=%d N=%d (same synthetic car batch shape), fp32, "
-                      "oracle/det_ref.py + oracle/qdp_ref.c, %.2f s" % (batch, npoint, t)}
+                      "oracle/det_ref.py + oracle/qdp_ref.c, %.2f s, best of 16 / 8 torch threads" % (batch, npoint, t)}
 
 
 def main():
