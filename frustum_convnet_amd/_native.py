@@ -53,7 +53,8 @@ class InpDesc(ctypes.Structure):
 
 
 EXPORTS = ("fcn_arch", "fcn_query_depth_point_f32", "fcn_pn_wgrad_rows", "fcn_pn_compact",
-           "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_adam_step_f32", "fcn_adam_step_slots", "fcn_prepare_inputs", "fcn_stamp",
+           "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_det_loss_tail_rows2",
+           "fcn_det_loss_tail_scratch_floats", "fcn_adam_step_f32", "fcn_adam_step_slots", "fcn_prepare_inputs", "fcn_stamp",
            "fcn_convnet_sizes", "fcn_convnet_pack", "fcn_convnet_forward", "fcn_convnet_forward2",
            "fcn_convnet_backward")
 
@@ -111,6 +112,10 @@ def lib():
     L.fcn_adam_step_slots.argtypes = [ctypes.c_int64]
     L.fcn_det_loss_tail_rows.restype = ctypes.c_int
     L.fcn_det_loss_tail_rows.argtypes = [c_fp] * 8 + [ctypes.c_int] * 4 + [ctypes.c_float] * 4 + [c_fp] * 3
+    L.fcn_det_loss_tail_rows2.restype = ctypes.c_int
+    L.fcn_det_loss_tail_rows2.argtypes = [c_fp] * 8 + [ctypes.c_int] * 4 + [ctypes.c_float] * 4 + [c_fp] * 5
+    L.fcn_det_loss_tail_scratch_floats.restype = ctypes.c_int
+    L.fcn_det_loss_tail_scratch_floats.argtypes = [ctypes.c_int, ctypes.c_int]
     L.fcn_convnet_sizes.restype = ctypes.c_int
     L.fcn_convnet_sizes.argtypes = [ctypes.POINTER(CnDesc), ctypes.POINTER(ctypes.c_int64 * 6)]
     L.fcn_convnet_pack.restype = ctypes.c_int

@@ -31,6 +31,11 @@ struct LossArgs {
     float w_box, w_corner, w_headreg, w_sizereg;
     int ld;                    // 0: (B,C,L2) planes above; > 0: row-major logits (B*L2, ld) in cls_raw (cols 0..1 cls,
                                // 2.. reg) and row-major gradient in dcls (all ld columns written)
+    // Optional persistent scratch (zeroed ONCE by the caller): [0] arrival ticket (int, reset by the last workgroup),
+    // [32 + 16*g ..] the partial sums of workgroup g.  With it the launch needs no memset in front, and the final sums are
+    // taken in workgroup order -- the reported scalars are reproducible bit for bit.
+    float *scratch;
+    float *total;              // optional copy of out[0] in its own buffer (the differentiable scalar of the binding)
 };
 
 __device__ __forceinline__ float block_sum(float v, float *sh)
@@ -92,12 +97,22 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
 #pragma unroll
     for (int i = 0; i < 11; ++i) acc[i] = 0.f;
 
+    if (a.ld) {                        // the workgroup's logits rows come in as coalesced 256-byte rows too
+        const int row0 = blockIdx.x * LT_THREADS;
+        const int nrow = min(LT_THREADS, R - row0);
+        for (int i = tid; i < nrow * 64; i += LT_THREADS) {
+            const int rr = i >> 6, cc = i & 63;
+            gS[rr * 65 + cc] = (cc < a.ld) ? a.cls_raw[(int64_t)(row0 + rr) * a.ld + cc] : 0.f;
+        }
+        __syncthreads();
+    }
+
     for (int r = blockIdx.x * LT_THREADS + tid; r < R; r += gridDim.x * LT_THREADS) {
         const int b = r / L2, l = r % L2;
         const int64_t lab = a.cls_label[r];
         // ---------------- focal classification loss (common.py:217-232)
-        const float c0 = a.ld ? a.cls_raw[(int64_t)r * a.ld] : a.cls_raw[((int64_t)b * 2 + 0) * L2 + l];
-        const float c1 = a.ld ? a.cls_raw[(int64_t)r * a.ld + 1] : a.cls_raw[((int64_t)b * 2 + 1) * L2 + l];
+        const float c0 = a.ld ? gS[tid * 65] : a.cls_raw[((int64_t)b * 2 + 0) * L2 + l];
+        const float c1 = a.ld ? gS[tid * 65 + 1] : a.cls_raw[((int64_t)b * 2 + 1) * L2 + l];
         const float m = fmaxf(c0, c1);
         const float e0 = expf(c0 - m), e1 = expf(c1 - m);
         const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
@@ -130,7 +145,7 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
             float o[NC];
 #pragma unroll
             for (int j = 0; j < NC; ++j)
-                o[j] = a.ld ? a.cls_raw[(int64_t)r * a.ld + 2 + j] : a.reg_raw[((int64_t)b * NC + j) * L2 + l];
+                o[j] = a.ld ? gS[tid * 65 + 2 + j] : a.reg_raw[((int64_t)b * NC + j) * L2 + l];
             const float rx = a.ref2[((int64_t)b * 3 + 0) * L2 + l], ry = a.ref2[((int64_t)b * 3 + 1) * L2 + l],
                         rz = a.ref2[((int64_t)b * 3 + 2) * L2 + l];
             const float clx = a.box_center[b * 3], cly = a.box_center[b * 3 + 1], clz = a.box_center[b * 3 + 2];
@@ -277,33 +292,56 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
 #pragma unroll
     for (int i = 1; i < 11; ++i) tot[i] = block_sum(acc[i], sh);
     if (tid == 0) {
+        int ticket;
+        if (a.scratch) {
 #pragma unroll
-        for (int i = 1; i < 11; ++i) atomicAdd(&a.out[i], tot[i]);
-        __threadfence();
-        const int ticket = atomicAdd((int *)&a.out[15], 1);
+            for (int i = 1; i < 11; ++i) a.scratch[32 + 16 * blockIdx.x + i] = tot[i];
+            __threadfence();
+            ticket = atomicAdd((int *)a.scratch, 1);
+        } else {
+#pragma unroll
+            for (int i = 1; i < 11; ++i) atomicAdd(&a.out[i], tot[i]);
+            __threadfence();
+            ticket = atomicAdd((int *)&a.out[15], 1);
+        }
         last_s = (ticket == (int)gridDim.x - 1) ? 1 : 0;
     }
     __syncthreads();
     if (last_s && tid == 0) {
         __threadfence();
         float t[11];
+        if (a.scratch) {
 #pragma unroll
-        for (int i = 1; i < 11; ++i) t[i] = __hip_atomic_load(&a.out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 1; i < 11; ++i) t[i] = 0.f;
+            for (int g = 0; g < (int)gridDim.x; ++g)
+#pragma unroll
+                for (int i = 1; i < 11; ++i)
+                    t[i] += __hip_atomic_load(&a.scratch[32 + 16 * g + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ((int *)a.scratch)[0] = 0;          // ready for the next launch
+        } else {
+#pragma unroll
+            for (int i = 1; i < 11; ++i) t[i] = __hip_atomic_load(&a.out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         const float cls = t[1] * inv_cls;
         const float center = t[2] * inv_fg, hcls = t[3] * inv_fg, hres = t[4] * inv_fg;
         const float scls = t[5] * inv_fg, sres = t[6] * inv_fg, corner = t[7] * inv_fg;
-        a.out[0] = cls + a.w_box * (center + hcls + scls + a.w_headreg * hres + a.w_sizereg * sres + a.w_corner * corner);
+        const float total = cls + a.w_box * (center + hcls + scls + a.w_headreg * hres + a.w_sizereg * sres + a.w_corner * corner);
+        a.out[0] = total;
         a.out[1] = cls; a.out[2] = center; a.out[3] = hcls; a.out[4] = hres;
         a.out[5] = scls; a.out[6] = sres; a.out[7] = corner;
         a.out[8] = t[8] / nkeep; a.out[9] = t[9] * inv_fg; a.out[10] = t[10] * inv_fg;
         a.out[11] = nfg;
+        a.out[12] = a.out[13] = a.out[14] = a.out[15] = 0.f;
+        if (a.total) a.total[0] = total;
     }
 }
 
 static int launch_loss(const LossArgs &a, hipStream_t st)
 {
-    hipError_t e = hipMemsetAsync(a.out, 0, 16 * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
+    if (!a.scratch) {                   // accumulate-into-out path: the accumulators and the ticket start from zero
+        hipError_t e = hipMemsetAsync(a.out, 0, 16 * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
     const int R = a.B * a.L2;
     hipLaunchKernelGGL(loss_tail_kernel, dim3((R + LT_THREADS - 1) / LT_THREADS), dim3(LT_THREADS), 0, st, a);
     FCN_CHECK_LAUNCH();
@@ -327,8 +365,16 @@ extern "C" int fcn_det_loss_tail(const float *cls_raw, const float *reg_raw, con
     a.box_center = box3d_center; a.box_heading = box3d_heading; a.box_size = box3d_size; a.size_class = size_class;
     a.mean_size = mean_size; a.out = out16; a.dcls = dcls; a.dreg = dreg; a.B = B; a.L2 = L2;
     a.w_box = w_box; a.w_corner = w_corner; a.w_headreg = w_headreg; a.w_sizereg = w_sizereg; a.ld = 0;
+    a.scratch = nullptr; a.total = nullptr;
     return launch_loss(a, (hipStream_t)stream);
 }
+
+extern "C" int fcn_det_loss_tail_rows2(const float *logits, const int64_t *cls_label, const float *center_ref2,
+                                       const float *box3d_center, const float *box3d_heading, const float *box3d_size,
+                                       const int64_t *size_class, const float *mean_size, int B, int L2,
+                                       int num_heading_bin, int num_size_cluster,
+                                       float w_box, float w_corner, float w_headreg, float w_sizereg,
+                                       float *out16, float *dlogits, float *scratch, float *total, void *stream);
 
 extern "C" int fcn_det_loss_tail_rows(const float *logits, const int64_t *cls_label, const float *center_ref2,
                                       const float *box3d_center, const float *box3d_heading, const float *box3d_size,
@@ -336,6 +382,23 @@ extern "C" int fcn_det_loss_tail_rows(const float *logits, const int64_t *cls_la
                                       int num_heading_bin, int num_size_cluster,
                                       float w_box, float w_corner, float w_headreg, float w_sizereg,
                                       float *out16, float *dlogits, void *stream)
+{
+    return fcn_det_loss_tail_rows2(logits, cls_label, center_ref2, box3d_center, box3d_heading, box3d_size, size_class,
+                                   mean_size, B, L2, num_heading_bin, num_size_cluster, w_box, w_corner, w_headreg,
+                                   w_sizereg, out16, dlogits, nullptr, nullptr, stream);
+}
+
+extern "C" int fcn_det_loss_tail_scratch_floats(int B, int L2)
+{
+    return (B <= 0 || L2 <= 0) ? 0 : 32 + 16 * ((B * L2 + LT_THREADS - 1) / LT_THREADS);
+}
+
+extern "C" int fcn_det_loss_tail_rows2(const float *logits, const int64_t *cls_label, const float *center_ref2,
+                                       const float *box3d_center, const float *box3d_heading, const float *box3d_size,
+                                       const int64_t *size_class, const float *mean_size, int B, int L2,
+                                       int num_heading_bin, int num_size_cluster,
+                                       float w_box, float w_corner, float w_headreg, float w_sizereg,
+                                       float *out16, float *dlogits, float *scratch, float *total, void *stream)
 {
     if (!logits || !cls_label || !center_ref2 || !box3d_center || !box3d_heading || !box3d_size || !size_class ||
         !mean_size || !out16)
@@ -347,5 +410,6 @@ extern "C" int fcn_det_loss_tail_rows(const float *logits, const int64_t *cls_la
     a.box_center = box3d_center; a.box_heading = box3d_heading; a.box_size = box3d_size; a.size_class = size_class;
     a.mean_size = mean_size; a.out = out16; a.dcls = dlogits; a.dreg = nullptr; a.B = B; a.L2 = L2;
     a.w_box = w_box; a.w_corner = w_corner; a.w_headreg = w_headreg; a.w_sizereg = w_sizereg; a.ld = 64;
+    a.scratch = scratch; a.total = total;
     return launch_loss(a, (hipStream_t)stream);
 }

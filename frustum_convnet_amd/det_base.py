@@ -270,6 +270,7 @@ class PointNetDet(nn.Module):
         # (csrc/fcn_net.hip); False runs the nn.Conv1d / BatchNorm1d modules through MIOpen.
         self.fused_fcn = True
         self._zero_cache = {}
+        self._loss_scratch = None
         from .fcn_fused import CnPool
         self._cn_pool = CnPool()
         self.last_logits = None
@@ -352,13 +353,17 @@ class PointNetDet(nn.Module):
                     size_probs.view(batch_size, -1, self.num_size_cluster))
 
         if fused_tail:
-            from .loss_fused import det_loss_tail, det_loss_tail_rows
+            from .loss_fused import det_loss_tail, det_loss_tail_rows, loss_scratch
             Lw = cfg.LOSS
             wts = (Lw.BOX_LOSS_WEIGHT, Lw.CORNER_LOSS_WEIGHT, Lw.HEAD_REG_WEIGHT, Lw.SIZE_REG_WEIGHT)
             if logits64 is not None:
+                key = (batch_size, num_out, str(logits64.device))
+                if self._loss_scratch is None or self._loss_scratch[0] != key:
+                    self._loss_scratch = (key, loss_scratch(batch_size, num_out, logits64.device))
                 losses, (a_cls, a_head, a_size) = det_loss_tail_rows(
                     logits64, batch_size, num_out, cls_label, refs[1], center_label, heading_label, size_label,
-                    size_class_label, mean_size_array, self.num_bins, self.num_size_cluster, wts)
+                    size_class_label, mean_size_array, self.num_bins, self.num_size_cluster, wts,
+                    self._loss_scratch[1])
             else:
                 losses, (a_cls, a_head, a_size) = det_loss_tail(
                     cls_raw, reg_raw, cls_label, refs[1], center_label, heading_label, size_label, size_class_label,

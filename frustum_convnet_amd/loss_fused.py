@@ -62,42 +62,49 @@ class _LossTailRows(torch.autograd.Function):
     """Same tail on the row-major (B*L2, 64) logits of the fused ConvFeatNet."""
 
     @staticmethod
-    def forward(ctx, logits, cls_label, ref2, center, heading, size, size_class, mean_size, B, L2, nb, ns, w):
+    def forward(ctx, logits, cls_label, ref2, center, heading, size, size_class, mean_size, B, L2, nb, ns, w, scratch):
         L = _native.lib()
         lg = logits.detach().contiguous()
         need = logits.requires_grad
         out = torch.empty(16, dtype=torch.float32, device=lg.device)
+        total = torch.empty((), dtype=torch.float32, device=lg.device)      # own storage: no clone of out[0]
         dlog = torch.empty_like(lg) if need else None
         args = [cls_label.contiguous(), ref2.contiguous().float(), center.contiguous().float(),
                 heading.contiguous().float(), size.contiguous().float(), size_class.contiguous(),
                 mean_size.contiguous().float()]
         with torch.cuda.device(lg.device):
-            rc = L.fcn_det_loss_tail_rows(lg.data_ptr(), *[t.data_ptr() for t in args], int(B), int(L2), int(nb),
-                                          int(ns), float(w[0]), float(w[1]), float(w[2]), float(w[3]),
-                                          out.data_ptr(), None if dlog is None else dlog.data_ptr(),
-                                          _native.current_stream(lg.device))
-        _native.check(rc, "fcn_det_loss_tail_rows")
+            rc = L.fcn_det_loss_tail_rows2(lg.data_ptr(), *[t.data_ptr() for t in args], int(B), int(L2), int(nb),
+                                           int(ns), float(w[0]), float(w[1]), float(w[2]), float(w[3]),
+                                           out.data_ptr(), None if dlog is None else dlog.data_ptr(),
+                                           None if scratch is None else scratch.data_ptr(), total.data_ptr(),
+                                           _native.current_stream(lg.device))
+        _native.check(rc, "fcn_det_loss_tail_rows2")
         ctx.need = need
         if need:
             ctx.save_for_backward(dlog)
-        total = out[0].clone()
-        rest = out.detach()
-        ctx.mark_non_differentiable(rest)
-        ctx.set_materialize_grads(False)          # no zero-filled gradient for `rest`
-        return total, rest
+        ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)          # no zero-filled gradient for `out`
+        return total, out
 
     @staticmethod
     def backward(ctx, gtotal, _grest):
         if not ctx.need or gtotal is None:
-            return (None,) * 13
+            return (None,) * 14
         (dlog,) = ctx.saved_tensors
-        return (dlog * gtotal,) + (None,) * 12
+        return (dlog * gtotal,) + (None,) * 13
+
+
+def loss_scratch(B, L2, device):
+    """Persistent scratch of the row-major loss tail (zeroed once; the kernel leaves it ready for the next launch).  One
+    per module / stream: two launches sharing it must not overlap."""
+    n = int(_native.lib().fcn_det_loss_tail_scratch_floats(int(B), int(L2)))
+    return torch.zeros(max(n, 32), dtype=torch.float32, device=device)
 
 
 def det_loss_tail_rows(logits, B, L2, cls_label, center_ref2, box3d_center, box3d_heading, box3d_size, size_class,
-                       mean_size, num_bins, num_sizes, weights):
+                       mean_size, num_bins, num_sizes, weights, scratch=None):
     total, rest = _LossTailRows.apply(logits, cls_label, center_ref2, box3d_center, box3d_heading, box3d_size,
-                                      size_class, mean_size, B, L2, num_bins, num_sizes, weights)
+                                      size_class, mean_size, B, L2, num_bins, num_sizes, weights, scratch)
     losses = {"total_loss": total}
     for i, k in enumerate(LOSS_NAMES[1:], start=1):
         losses[k] = rest[i]

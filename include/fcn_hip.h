@@ -221,6 +221,17 @@ int64_t fcn_adam_step_slots(int64_t n);
 int fcn_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                       const float *hyper6, int64_t *step_slots, void *stream);
 
+/* Same with a persistent scratch buffer (fcn_det_loss_tail_scratch_floats(B, L2) floats, zeroed ONCE by the caller, then
+ * owned by one stream at a time): no memset node in front of the launch, the workgroup partials are summed in a fixed
+ * order (the 16 scalars are reproducible bit for bit), and `total` (1 float, may be NULL) receives a copy of out16[0]. */
+int fcn_det_loss_tail_scratch_floats(int B, int L2);
+int fcn_det_loss_tail_rows2(const float *logits, const int64_t *cls_label, const float *center_ref2,
+                            const float *box3d_center, const float *box3d_heading, const float *box3d_size,
+                            const int64_t *size_class, const float *mean_size, int B, int L2,
+                            int num_heading_bin, int num_size_cluster,
+                            float w_box, float w_corner, float w_headreg, float w_sizereg,
+                            float *out16, float *dlogits, float *scratch, float *total, void *stream);
+
 /* Measurement aid: stores the device's constant-rate wall clock (100 MHz ticks) into *slot, in stream order. */
 int fcn_stamp(uint64_t *slot, void *stream);
 

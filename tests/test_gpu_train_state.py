@@ -35,8 +35,8 @@ def test_flat_layout_and_direct_gradients():
     st.grad.fill_(float("nan"))                                      # every element must be overwritten
     lo2, _ = m(data)
     lo2["total_loss"].backward()
-    # (the reported loss sums workgroup partials with fp32 atomics: last-bit run-to-run differences; gradients are exact)
-    assert abs(float(lo2["total_loss"]) - float(lo["total_loss"])) <= 1e-6 * abs(float(lo["total_loss"]))
+    # (the row-major loss tail sums its workgroup partials in a fixed order: the scalar is reproducible bit for bit)
+    assert float(lo2["total_loss"]) == float(lo["total_loss"])
     for k, p in named.items():
         assert p.grad is p._fcn_grad                                 # autograd did not replace the view
         assert torch.equal(p.grad, want[k]), k                       # same kernels, same bits, written in place
