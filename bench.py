@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-batch", type=int, default=32)
+    ap.add_argument("--precision", choices=("split", "f32", "bf16"), default=None,
+                    help="MFMA operand mode of the GEMM kernels (default: FCN_PRECISION or 'split')")
     return ap.parse_args()
 
 
@@ -197,7 +199,9 @@ def cpu_baseline(batch, npoint):
 
 def main():
     a = parse()
-    from frustum_convnet_amd import dist as fdist, synth
+    from frustum_convnet_amd import dist as fdist, synth, precision as fprec
+    if a.precision:
+        fprec.set_precision(a.precision)
     # FCN_BENCH_BACKEND=gloo + FCN_BENCH_ONE_DEVICE=1: rehearsal of the N > 1 path with every rank on GPU 0 (a 1-GPU box
     # cannot form an RCCL communicator); the driver's multi-GPU runs leave both unset.
     one_dev = os.environ.get("FCN_BENCH_ONE_DEVICE", "0") == "1"
@@ -303,7 +307,10 @@ def main():
         "value": round(a.batch * world / (ms_per_step / 1e3), 2),
         "unit": "frustums/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": {"split": "f32", "f32": "f32", "bf16": "bf16"}[fprec.get_precision()],
+        "mfma_operands": {"split": "fp16x3 (forward) / bf16x3 (backward) split of fp32 operands, fp32 accumulate",
+                          "f32": "fp32 (v_mfma_f32_32x32x2_f32)", "bf16": "bf16 single term, fp32 accumulate"}[fprec.get_precision()],
+        "data": "synthetic",
         "config": {"workload": "cfgs/det_sample.yaml KITTI-car, batch=%d/GPU, Npoint=%d, L=(280,140,70,35), "
                                "train fwd+bwd%s%s" % (a.batch, a.npoint, "" if a.no_optim else "+Adam",
                                                       "+RCCL grad all-reduce" if world > 1 else ""),

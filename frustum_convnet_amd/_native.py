@@ -16,13 +16,15 @@ class PnDesc(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("L", ctypes.c_int32), ("K", ctypes.c_int32),
                 ("C1", ctypes.c_int32), ("C2", ctypes.c_int32), ("C3", ctypes.c_int32),
                 ("nvec", ctypes.c_int32), ("training", ctypes.c_int32),
-                ("eps", ctypes.c_float), ("momentum", ctypes.c_float), ("nlc", ctypes.c_int32)]
+                ("eps", ctypes.c_float), ("momentum", ctypes.c_float), ("nlc", ctypes.c_int32),
+                ("precision", ctypes.c_int32)]
 
 
 class CnDesc(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("L", ctypes.c_int32 * 4), ("nvec", ctypes.c_int32),
                 ("reg_out", ctypes.c_int32), ("training", ctypes.c_int32),
-                ("eps", ctypes.c_float), ("momentum", ctypes.c_float), ("prepacked", ctypes.c_int32)]
+                ("eps", ctypes.c_float), ("momentum", ctypes.c_float), ("prepacked", ctypes.c_int32),
+                ("precision", ctypes.c_int32)]
 
 
 class CnParams(ctypes.Structure):

@@ -16,7 +16,6 @@
 //     mask + BN-backward sums in the epilogue), wgrad kernels reduce over rows in splits + a deterministic reduce
 //     that scatters straight into the torch weight layout.
 #include "gemm_tile.h"
-#include <cstdlib>
 
 #define CG_T 256
 #define LDN 68                 // row-major LDS leading dim of a 64-wide tile (float4 aligned)
@@ -54,8 +53,6 @@ struct CgLayer {
     float *y;                  // (B*Lout, Cout) pre-BN output
     double *stat;              // sum[Cs], sumsq[Cs] or nullptr
     float eps, momentum;
-    int dbg;                   // timing-ablation switches (env FCN_DBG, tools/fcn_micro.py; results are WRONG when set): 1 skip MFMA,
-                               // 2 skip global loads, 4 skip LDS staging, 8 no BN sums, 16 no BN finalisation, 32 no epilogue
 };
 
 #define SEL3(i, a0, a1, a2) ((i) == 0 ? (a0) : ((i) == 1 ? (a1) : (a2)))
@@ -113,7 +110,7 @@ __device__ __forceinline__ void cg_fill_bn(const CgLayer &L, float *sS, float *t
         if (s < L.nseg) {
             const CgSeg &S = L.seg[s];
             const int C = S.C, span = L.KT * C;
-            if (S.gamma && !(L.dbg & 16)) {
+            if (S.gamma) {
                 const bool batch = S.stat != nullptr;
                 const bool wr = pub && S.writer;
                 for (int k = tid; k < C; k += nthr) {
@@ -156,7 +153,7 @@ __device__ __forceinline__ float cg_act(float s, float x, float t, bool ok) { re
 // gives 4-16 resident waves per tile to hide the gather / staging latency, and nothing but the result goes back to HBM.
 // In use: <1,4,1> (32 x 32 tile, 4 waves) -- 560 workgroups per layer; <1,4> (32 x 64) and <2,4> (64 x 64) measured
 // 5 % slower over the forward (280 tiles for 256 CUs at every level of the pyramid).
-template <int MW, int G, int WNC = 2>      // WNC waves across N per K-group: tile (32*MW) x (32*WNC)
+template <int MM, int MW, int G, int WNC = 2>      // WNC waves across N per K-group: tile (32*MW) x (32*WNC)
 __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, const int by)
 {
     constexpr int TG = 64 * MW * WNC, TMB = 32 * MW, TNC = 32 * WNC, LDA = TMB + 1, LDC = TNC + 1, NTHR = G * TG;
@@ -224,38 +221,37 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         const float *sp = sS + (c_) * KC + 4 * kq, *tp = tS + (c_) * KC + 4 * kq;                                     \
         _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                              \
             const int r = rb + RSTEP * i;                                                                             \
-            As[(4 * kq + 0) * LDA + r] = cg_act(sp[0], RA[i].x, tp[0], OK[i]);                                        \
-            As[(4 * kq + 1) * LDA + r] = cg_act(sp[1], RA[i].y, tp[1], OK[i]);                                        \
-            As[(4 * kq + 2) * LDA + r] = cg_act(sp[2], RA[i].z, tp[2], OK[i]);                                        \
-            As[(4 * kq + 3) * LDA + r] = cg_act(sp[3], RA[i].w, tp[3], OK[i]);                                        \
+            float e_[4];                                                                                              \
+            enc4<MM>(cg_act(sp[0], RA[i].x, tp[0], OK[i]), cg_act(sp[1], RA[i].y, tp[1], OK[i]),                      \
+                     cg_act(sp[2], RA[i].z, tp[2], OK[i]), cg_act(sp[3], RA[i].w, tp[3], OK[i]), e_);                 \
+            As[(4 * kq + 0) * LDA + r] = e_[0]; As[(4 * kq + 1) * LDA + r] = e_[1];                                   \
+            As[(4 * kq + 2) * LDA + r] = e_[2]; As[(4 * kq + 3) * LDA + r] = e_[3];                                   \
         }                                                                                                             \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                              \
             const int n = rb + RSTEP * i;                                                                             \
-            Bs[(4 * kq + 0) * LDC + n] = RW[i].x; Bs[(4 * kq + 1) * LDC + n] = RW[i].y;                               \
-            Bs[(4 * kq + 2) * LDC + n] = RW[i].z; Bs[(4 * kq + 3) * LDC + n] = RW[i].w;                               \
+            float e_[4];                                                                                              \
+            enc4<MM>(RW[i].x, RW[i].y, RW[i].z, RW[i].w, e_);                                                         \
+            Bs[(4 * kq + 0) * LDC + n] = e_[0]; Bs[(4 * kq + 1) * LDC + n] = e_[1];                                   \
+            Bs[(4 * kq + 2) * LDC + n] = e_[2]; Bs[(4 * kq + 3) * LDC + n] = e_[3];                                   \
         }                                                                                                             \
     }
 #define CGK_FWD_ITER(it_, RA, RW, OK)                                                                                 \
     {                                                                                                                 \
         const int c = (it_) * G + g;                                                                                  \
         const bool act = c < nchunk;                                                                                  \
-        if (act && dlds) CGK_FWD_STAGE(c, RA, RW, OK);                                                                \
+        if (act) CGK_FWD_STAGE(c, RA, RW, OK);                                                                \
         __syncthreads();                                                                                              \
-        if (c + 2 * G < nchunk && dload) CGK_FWD_LOAD(c + 2 * G, RA, RW, OK);                                         \
-        if (act && dmma) mma_chunk<1, 1, LDA, LDC>(As, Bs, wm * 32, wn * 32, acc);                                    \
+        if (c + 2 * G < nchunk) CGK_FWD_LOAD(c + 2 * G, RA, RW, OK);                                         \
+        if (act) mma_chunk<MM, 1, 1, LDA, LDC>(As, Bs, wm * 32, wn * 32, acc);                                    \
         __syncthreads();                                                                                              \
     }
-    const bool dload = !(L.dbg & 2), dlds = !(L.dbg & 4), dmma = !(L.dbg & 1);
     __syncthreads();                            // sS / tS and the chunk table ready
-    if (dload) {
-        CGK_FWD_LOAD(min(g, nchunk - 1), ra0, rw0, ok0);
-        CGK_FWD_LOAD(min(g + G, nchunk - 1), ra1, rw1, ok1);
-    }
+    CGK_FWD_LOAD(min(g, nchunk - 1), ra0, rw0, ok0);
+    CGK_FWD_LOAD(min(g + G, nchunk - 1), ra1, rw1, ok1);
     for (int it = 0; it < nit; it += 2) {
         CGK_FWD_ITER(it, ra0, rw0, ok0);
         if (it + 1 < nit) CGK_FWD_ITER(it + 1, ra1, rw1, ok1);
     }
-    if (L.dbg & 32) return;                             // (timing ablation: no epilogue)
     // ---- sum the G group accumulators through LDS, then one epilogue pass over the tile
     float *red = lds;                                   // [G][TMB][TNC]
 #pragma unroll
@@ -308,10 +304,10 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     }
 }
 
-template <int MW, int G, int WNC = 2>
+template <int MM, int MW, int G, int WNC = 2>
 __global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_kernel(CgLayer L)
 {
-    cgk_fwd_body<MW, G, WNC>(L, blockIdx.x, blockIdx.y);
+    cgk_fwd_body<MM, MW, G, WNC>(L, blockIdx.x, blockIdx.y);
 }
 
 // Two INDEPENDENT layers in one launch (a deconvolution next to the stride-2 conv that reads the same merge output):
@@ -322,12 +318,12 @@ struct CgLayerPair {
     int na, txa, txb;          // workgroups of A; row tiles of A and of B (tile t -> (t % tx, t / tx))
 };
 
-template <int MW, int G, int WNC>
+template <int MM, int MW, int G, int WNC>
 __global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_pair_kernel(CgLayerPair p)
 {
     const int bid = blockIdx.x;
-    if (bid < p.na) cgk_fwd_body<MW, G, WNC>(p.A, bid % p.txa, bid / p.txa);
-    else cgk_fwd_body<MW, G, WNC>(p.B, (bid - p.na) % p.txb, (bid - p.na) / p.txb);
+    if (bid < p.na) cgk_fwd_body<MM, MW, G, WNC>(p.A, bid % p.txa, bid / p.txa);
+    else cgk_fwd_body<MM, MW, G, WNC>(p.B, (bid - p.na) % p.txb, (bid - p.na) / p.txb);
 }
 
 // BN-backward coefficients of one channel from the batch sums (sum dz, sum dz*xhat): gamma*rstd, mean, rstd, dbeta/M,
@@ -480,6 +476,7 @@ struct CgBwdStep {
 // G[rs][k] = sum_tap sum_n dy[r_out(rs,tap)][n] * Wp[n][segoff + tap*C + k]; 32 source rows x 64 source channels by 4
 // K-groups, then the producer-side epilogue: ReLU mask from its pre-BN output, accumulate (second consumer),
 // BN-backward sums.
+template <int MM>
 __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &cb, const float *dzc, const float *yc,
                                               int sgi, int segoff, const float *ysrc, const float *bnsrc, float *outp,
                                               int accumulate, double *bstat_src, int bx, int by, bool pub, float *smem)
@@ -556,9 +553,9 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
             rz[i] = ldg4(dzc + o);                         /* unconditional (clamped row), masked at store time */    \
             ry[i] = ldg4((hasbn ? yc : dzc) + o);                                                                     \
         }                                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                              \
-            const int f = gt + TG * i;                                                                                \
-            const int nn = f >> 4, cq = f & 15;                                                                       \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {       /* rows 2*pr, 2*pr+1 of one column quad (a k pair) */  \
+            const int f = gt + TG * (i >> 1);                                                                         \
+            const int nn = 2 * (f >> 4) + (i & 1), cq = f & 15;                                                       \
             rw[i] = ldg4(L.Wp + (int64_t)(nb + nn) * L.Ktot + segoff + tap * C + c0 + 4 * cq);                        \
         }                                                                                                             \
     }
@@ -578,18 +575,23 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
                     if (hasbn) d[j] = cg_dy(coefS, Cs, chb + j, d[j], yv[j]);
                     d[j] = ok[i] ? d[j] : 0.f;
                 }
-                As[(4 * kq + 0) * LDA + r] = d[0]; As[(4 * kq + 1) * LDA + r] = d[1];
-                As[(4 * kq + 2) * LDA + r] = d[2]; As[(4 * kq + 3) * LDA + r] = d[3];
+                float e_[4];
+                enc4<MM>(d[0], d[1], d[2], d[3], e_);
+                As[(4 * kq + 0) * LDA + r] = e_[0]; As[(4 * kq + 1) * LDA + r] = e_[1];
+                As[(4 * kq + 2) * LDA + r] = e_[2]; As[(4 * kq + 3) * LDA + r] = e_[3];
             }
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int f = gt + TG * i;
-                sts4(Bs + (f >> 4) * LDN + 4 * (f & 15), rw[i]);
+            for (int i = 0; i < NB; i += 2) {
+                const int f = gt + TG * (i >> 1);
+                v4f hi, lo;
+                enc2x4<MM>(rw[i], rw[i + 1], hi, lo);
+                sts4(Bs + (2 * (f >> 4)) * LDN + 4 * (f & 15), hi);
+                sts4(Bs + (2 * (f >> 4) + 1) * LDN + 4 * (f & 15), lo);
             }
         }
         __syncthreads();
         if (c + G < nchunk) CGK_DGRAD_LOAD(c + G);
-        if (act) mma_chunk<1, 1, LDA, LDN>(As, Bs, wm * 32, wn * 32, acc);
+        if (act) mma_chunk<MM, 1, 1, LDA, LDN>(As, Bs, wm * 32, wn * 32, acc);
         __syncthreads();
     }
     float *red = lds;                                   // [G][TMB][64]
@@ -652,6 +654,7 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
 
 // dWp[n][kk] = sum_r dy[r][n] * A[r][kk]; tile 64 (n) x 64 (kk); the workgroup owns rows [rbeg, rend) of one split and
 // its two 256-thread halves take alternate KC-row chunks (summed through LDS at the end).
+template <int MM>
 __device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float *smem)
 {
     const CgLayer &L = a.lay;
@@ -672,7 +675,7 @@ __device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float
     const int SC = SEL3(sg, opaque_s(L.seg[0].C), opaque_s(L.seg[1].C), opaque_s(L.seg[2].C));
     const int Sty = SEL3(sg, opaque_s(L.seg[0].type), opaque_s(L.seg[1].type), opaque_s(L.seg[2].type));
     const int SLs = SEL3(sg, opaque_s(L.seg[0].Lsrc), opaque_s(L.seg[1].Lsrc), opaque_s(L.seg[2].Lsrc));
-    const int cq = gt & 15, rr0 = gt >> 4;                // column quad, first row (rows rr0, rr0+16)
+    const int cq = gt & 15, rr0 = 2 * (gt >> 4);          // column quad, first row (rows rr0, rr0+1: a k pair)
     // per-thread constants of its 4 columns: BN-backward coefficients of dy, BN scale/shift of the A operand
     const bool hasbn = a.cb.bstat != nullptr;
     float cf[5][4], as[4], at[4];
@@ -695,14 +698,14 @@ __device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float
     // (frustum, position) of this thread's two rows, advanced by 2*KC per chunk instead of divided out of the row index
     int wb[2], wl[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { const int r = rbeg + h * KC + rr0 + 16 * i; wb[i] = r / L.Lout; wl[i] = r % L.Lout; }
+    for (int i = 0; i < 2; ++i) { const int r = rbeg + h * KC + rr0 + i; wb[i] = r / L.Lout; wl[i] = r % L.Lout; }
     const int bend = (rend - 1) / L.Lout, lend = (rend - 1) % L.Lout;
 #define CG_WGRAD_LOAD(rr)                                                                                             \
     {                                                                                                                 \
         const int r0_ = (rr);                                                                                         \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                               \
-            const bool in = r0_ + rr0 + 16 * i < rend;      /* clamped: unconditional loads, masked at store */       \
-            const int row = in ? r0_ + rr0 + 16 * i : rend - 1;                                                       \
+            const bool in = r0_ + rr0 + i < rend;           /* clamped: unconditional loads, masked at store */       \
+            const int row = in ? r0_ + rr0 + i : rend - 1;                                                            \
             const int64_t o = (int64_t)row * L.Cout + n0 + 4 * cq;                                                    \
             rz[i] = ldg4(a.dz + o);                                                                                   \
             ry[i] = ldg4((hasbn ? L.y : a.dz) + o);                                                                   \
@@ -718,11 +721,12 @@ __device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float
         const bool act = c < nch;
         const int r0 = rbeg + c * KC;
         if (act) {
+            v4f dv2[2], av2[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 float d[4] = {rz[i].x, rz[i].y, rz[i].z, rz[i].w};
                 const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
-                const bool live = (r0 + rr0 + 16 * i) < rend;
+                const bool live = (r0 + rr0 + i) < rend;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (hasbn) {
@@ -732,15 +736,22 @@ __device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float
                     d[j] = live ? d[j] : 0.f;
                 }
                 v4f dv = {d[0], d[1], d[2], d[3]};
-                sts4(As + (rr0 + 16 * i) * LDN + 4 * cq, dv);
+                dv2[i] = dv;
                 v4f av = {cg_act(as[0], rx[i].x, at[0], ok[i] && live), cg_act(as[1], rx[i].y, at[1], ok[i] && live),
                           cg_act(as[2], rx[i].z, at[2], ok[i] && live), cg_act(as[3], rx[i].w, at[3], ok[i] && live)};
-                sts4(Bs + (rr0 + 16 * i) * LDN + 4 * cq, av);
+                av2[i] = av;
             }
+            v4f hi, lo;
+            enc2x4<MM>(dv2[0], dv2[1], hi, lo);
+            sts4(As + rr0 * LDN + 4 * cq, hi);
+            sts4(As + (rr0 + 1) * LDN + 4 * cq, lo);
+            enc2x4<MM>(av2[0], av2[1], hi, lo);
+            sts4(Bs + rr0 * LDN + 4 * cq, hi);
+            sts4(Bs + (rr0 + 1) * LDN + 4 * cq, lo);
         }
         __syncthreads();
         if (c + 2 < nch) CG_WGRAD_LOAD(r0 + 2 * KC);
-        if (act) mma_chunk<1, 1, LDN, LDN>(As, Bs, wm * 32, wn * 32, acc);
+        if (act) mma_chunk<MM, 1, 1, LDN, LDN>(As, Bs, wm * 32, wn * 32, acc);
         __syncthreads();
     }
     float *red = smem;                                  // [64][64]: the second half's accumulators
@@ -804,22 +815,24 @@ __device__ __forceinline__ void cg_reduce_body(const CgReduce &q, int rid, float
     q.dW[o] = t;
 }
 
+template <int MM>
 __device__ __forceinline__ void cg_bwd_step_body(const CgBwdStep &a, const int bid, float *smem)
 {
     if (bid >= a.r_blk0) { cg_reduce_body(a.red, bid - a.r_blk0, smem); return; }
-    if (bid >= a.w_blk0) { cg_wgrad_body(a, bid - a.w_blk0, smem); return; }
+    if (bid >= a.w_blk0) { cg_wgrad_body<MM>(a, bid - a.w_blk0, smem); return; }
     const int role = (a.ndg > 2 && bid >= a.dg2.blk0) ? 2 : ((a.ndg > 1 && bid >= a.dg1.blk0) ? 1 : 0);
 #define DGF(f) SEL3(role, opaque_s(a.dg0.f), opaque_s(a.dg1.f), opaque_s(a.dg2.f))
     const int t = bid - DGF(blk0), tx = DGF(tx);
-    cg_dgrad_body(a.lay, a.cb, a.dz, a.lay.y, DGF(sg), DGF(segoff), DGF(ysrc), DGF(bnsrc), DGF(out), DGF(accumulate),
+    cg_dgrad_body<MM>(a.lay, a.cb, a.dz, a.lay.y, DGF(sg), DGF(segoff), DGF(ysrc), DGF(bnsrc), DGF(out), DGF(accumulate),
                   DGF(bstat_src), t % tx, t / tx, bid == 0, smem);
 #undef DGF
 }
 
+template <int MM>
 __global__ __launch_bounds__(CGB_T) void cg_bwd_step_kernel(CgBwdStep a)
 {
     __shared__ __attribute__((aligned(16))) float smem[CGB_SMEM];
-    cg_bwd_step_body(a, blockIdx.x, smem);
+    cg_bwd_step_body<MM>(a, blockIdx.x, smem);
 }
 
 // A chain step and an OFF-CHAIN step (the backward of a deconvolution, which only hangs off the heads) in one launch:
@@ -829,12 +842,13 @@ struct CgBwdPair {
     int na;
 };
 
+template <int MM>
 __global__ __launch_bounds__(CGB_T) void cg_bwd_pair_kernel(CgBwdPair p)
 {
     __shared__ __attribute__((aligned(16))) float smem[CGB_SMEM];
     const int bid = blockIdx.x;
-    if (bid < p.na) cg_bwd_step_body(p.A, bid, smem);
-    else cg_bwd_step_body(p.B, bid - p.na, smem);
+    if (bid < p.na) cg_bwd_step_body<MM>(p.A, bid, smem);
+    else cg_bwd_step_body<MM>(p.B, bid - p.na, smem);
 }
 
 // ================================================================================================
@@ -956,7 +970,6 @@ static void cn_fill_layer(const fcn_cn_desc *d, const fcn_cn_params *p, const Cn
     L.nseg = P.nseg[l]; L.KT = P.KT[l]; L.stride = P.stride[l]; L.pad = P.pad[l];
     L.Lin = P.Lin[l]; L.Lout = P.Lout[l]; L.B = d->B; L.Cout = P.N[l]; L.Ktot = P.Ktot[l]; L.Cs = P.Cs[l];
     L.Wp = ws->wp + O.wp[l]; L.bias = nullptr; L.nbias = 0; L.y = ws->y + O.y[l]; L.stat = nullptr;
-    { const char *e = getenv("FCN_DBG"); L.dbg = e ? atoi(e) : 0; }
     L.eps = d->eps; L.momentum = d->momentum;
     for (int s = 0; s < 3; ++s) {
         CgSeg &S = L.seg[s];
@@ -1047,6 +1060,8 @@ extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p
     CnOffsets O;
     cn_offsets(d, P, O);
     const int tr = d->training ? 1 : 0;
+    if (d->precision < 0 || d->precision > FCN_PREC_BF16) return FCN_E_BADARG;
+    const int mmf = FCN_MM_OF(d->precision, true);
     if (!d->prepacked) FCN_TRY(cn_pack(d, p, P, O, ws, one_hot, st));      // (also zeroes ws->stat / ws->bstat)
     // launches in dependency order; {4, 10} and {7, 11} are pairs of independent layers reading the same merge output
     const int order[CN_NLAYER] = {0, 1, 2, 3, 4, 10, 5, 6, 7, 11, 8, 9, 12, 13};
@@ -1065,7 +1080,7 @@ extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p
             }
         }
         if (l == 13) { L.y = logits; L.bias = p->bias; L.nbias = P.nrow_real[13]; }
-        else if (tr && !(L.dbg & 8)) L.stat = ws->stat + O.st[l];      // (dbg 8: timing ablation without the BN sums)
+        else if (tr) L.stat = ws->stat + O.st[l];
         return 0;
     };
     // 32 x 32 tiles: 560 workgroups of 4 waves (2-3 resident per CU) instead of 280 of 8 (every level of the pyramid has
@@ -1083,13 +1098,13 @@ extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p
             pp.txa = (R + 31) / 32; pp.txb = (R2 + 31) / 32;
             pp.na = pp.txa * (P.N[l] / 32);
             const int nb = pp.txb * (P.N[l2] / 32);
-            hipLaunchKernelGGL((cgk_fwd_pair_kernel<1, 4, 1>), dim3(pp.na + nb), dim3(256), 0, st, pp);
+            FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_pair_kernel<MM, 1, 4, 1>), dim3(pp.na + nb), dim3(256), 0, st, pp));
             FCN_CHECK_LAUNCH();
             ++q;
         } else {
             CgLayer L;
             FCN_TRY(prep(l, L));
-            hipLaunchKernelGGL((cgk_fwd_kernel<1, 4, 1>), dim3((R + 31) / 32, P.N[l] / 32), dim3(256), 0, st, L);
+            FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_kernel<MM, 1, 4, 1>), dim3((R + 31) / 32, P.N[l] / 32), dim3(256), 0, st, L));
             FCN_CHECK_LAUNCH();
         }
     }
@@ -1132,6 +1147,8 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
     // block3_merge); events[2]: dfeats[1] final (after block2_merge); events[3]: everything final (dfeats[0], all dW).
     const bool cont = stream2 != nullptr && events != nullptr;
     hipStream_t st = (hipStream_t)stream;
+    if (d->precision < 0 || d->precision > FCN_PREC_BF16) return FCN_E_BADARG;
+    const int mmb = FCN_MM_OF(d->precision, false);
     CnPlan P;
     FCN_TRY(cn_make_plan(d, P));
     CnOffsets O;
@@ -1240,8 +1257,8 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
         }
         pp.na = nA;
         if (nA + nB > 0) {
-            if (nB > 0) hipLaunchKernelGGL(cg_bwd_pair_kernel, dim3(nA + nB), dim3(CGB_T), 0, st, pp);
-            else hipLaunchKernelGGL(cg_bwd_step_kernel, dim3(nA), dim3(CGB_T), 0, st, pp.A);
+            if (nB > 0) { FCN_MM_SWITCH(mmb, hipLaunchKernelGGL(cg_bwd_pair_kernel<MM>, dim3(nA + nB), dim3(CGB_T), 0, st, pp)); }
+            else { FCN_MM_SWITCH(mmb, hipLaunchKernelGGL(cg_bwd_step_kernel<MM>, dim3(nA), dim3(CGB_T), 0, st, pp.A)); }
             FCN_CHECK_LAUNCH();
         }
         pendA = ownA; pendA_blocks = ownA_blocks;

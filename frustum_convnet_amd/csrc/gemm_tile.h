@@ -27,6 +27,80 @@ __device__ __forceinline__ v4f zero4() { v4f z = {0.f, 0.f, 0.f, 0.f}; return z;
 #define GT 256          // threads per workgroup
 #define KC 32           // reduction chunk staged per iteration
 
+// ------------------------------------------------------------------------------------------------
+// Matrix-core operand modes.  fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at the fp32 VECTOR rate, 1/16 of the 16-bit MFMA
+// rate on gfx950, and there is no xf32/TF32 form (cdna guide section 3).  The default mode therefore SPLITS every fp32
+// operand x into two 16-bit parts hi = rne16(x), lo = rne16(x - hi) and forms a.b as a_hi.b_lo + a_lo.b_hi + a_hi.b_hi
+// on v_mfma_f32_32x32x16_{f16,bf16} with fp32 accumulation: 3 instructions per K=16 step instead of 8 x K=2 fp32 steps at
+// twice the issue cost each -- 5.3x the fp32 matrix rate.
+//   MM_F16X3  forward GEMMs: fp16 parts, 22 significand bits kept, error ~2^-21 per product (operands are O(1)
+//             activations after BN+ReLU and weights; |x| must stay below 65504 -- an overflow shows up as inf/NaN);
+//   MM_BF16X3 backward GEMMs: bf16 parts (fp32 exponent range -- gradients span many decades), error ~2^-17 per product;
+//   MM_BF16X1 throughput mode (BASELINE config 2 "bf16"): the hi product only;
+//   MM_F32    exact fp32 MFMA (bitwise an fmaf chain), kept as the reference mode for A/B runs.
+// Measured on the CPU emulation of the whole net (tools/split_emulation.py): logits |err| vs fp64 9e-6 (f32) / 1.3e-5
+// (f16x3) / 3e-4 (bf16x3: misses the 1e-4 bar, hence fp16 forwards) / 0.13 (bf16x1); parameter gradients with a bf16x3
+// backward sit on the fp32 noise floor (2.0e-4 of max in both).
+#define MM_F32 0
+#define MM_F16X3 1
+#define MM_BF16X3 2
+#define MM_BF16X1 3
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// LDS operand layout, all modes: k-major, element (k, m) at [k * LD + m].  In the split modes two reduction-adjacent
+// values (k even, k + 1) of one row/column share two dwords: row k holds the packed HI parts {hi(x_k), hi(x_k+1)},
+// row k + 1 the packed LO parts -- exactly the register image of a 32x32x16 operand (lane (l&31, l>>5) holds
+// k = 8*(l>>5) .. +7 as four dwords), so the MFMA loop reads its operands with plain ds_read_b32 and no VALU.
+// enc2 turns such a pair into the two dwords to store (5 VALU per pair: v_cvt_pk, 2 unpack, v_pk_add, v_cvt_pk).
+template <int MM>
+__device__ __forceinline__ void enc2(float x0, float x1, float &o0, float &o1)
+{
+    if constexpr (MM == MM_F32) {
+        o0 = x0; o1 = x1;
+    } else if constexpr (MM == MM_F16X3) {
+        const f32x2 x = {x0, x1};
+        const f16x2 h = __builtin_convertvector(x, f16x2);
+        const f32x2 r = {x0 - (float)h[0], x1 - (float)h[1]};          // exact
+        const f16x2 l = __builtin_convertvector(r, f16x2);
+        o0 = __builtin_bit_cast(float, h); o1 = __builtin_bit_cast(float, l);
+    } else {
+        const f32x2 x = {x0, x1};
+        const bf16x2 h = __builtin_convertvector(x, bf16x2);
+        const uint32_t hb = __builtin_bit_cast(uint32_t, h);
+        o0 = __builtin_bit_cast(float, hb);
+        if constexpr (MM == MM_BF16X3) {
+            const f32x2 r = {x0 - __builtin_bit_cast(float, hb << 16), x1 - __builtin_bit_cast(float, hb & 0xffff0000u)};
+            const bf16x2 l = __builtin_convertvector(r, bf16x2);
+            o1 = __builtin_bit_cast(float, l);
+        } else {
+            o1 = 0.f;
+        }
+    }
+}
+// four values along the reduction index (one float4 of a row): dwords for rows k .. k+3
+template <int MM>
+__device__ __forceinline__ void enc4(float x0, float x1, float x2, float x3, float (&o)[4])
+{
+    enc2<MM>(x0, x1, o[0], o[1]);
+    enc2<MM>(x2, x3, o[2], o[3]);
+}
+// two float4 of reduction-adjacent rows (same four columns): the hi row and the lo row to store
+template <int MM>
+__device__ __forceinline__ void enc2x4(v4f a, v4f b, v4f &hi, v4f &lo)
+{
+    float h[4], l[4];
+    enc2<MM>(a.x, b.x, h[0], l[0]); enc2<MM>(a.y, b.y, h[1], l[1]);
+    enc2<MM>(a.z, b.z, h[2], l[2]); enc2<MM>(a.w, b.w, h[3], l[3]);
+    hi.x = h[0]; hi.y = h[1]; hi.z = h[2]; hi.w = h[3];
+    lo.x = l[0]; lo.y = l[1]; lo.z = l[2]; lo.w = l[3];
+}
+
 template <int MT, int NT>
 __device__ __forceinline__ void acc_zero(f32x16 (&acc)[MT][NT]) {
 #pragma unroll
@@ -37,39 +111,100 @@ __device__ __forceinline__ void acc_zero(f32x16 (&acc)[MT][NT]) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
 
+template <int MM>
+__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c)
+{
+    if constexpr (MM == MM_F16X3)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 // One KC-deep chunk: As is [KC][LDA] (m fastest), Bs is [KC][LDB] (n fastest).
-template <int MT, int NT, int LDA, int LDB>
+template <int MM, int MT, int NT, int LDA, int LDB>
 __device__ __forceinline__ void mma_chunk(const float *As, const float *Bs, int arow0, int bcol0,
                                           f32x16 (&acc)[MT][NT]) {
     const int lane = threadIdx.x & 63;
     const int l31 = lane & 31, lh = lane >> 5;
-    const float *ap = As + lh * LDA + arow0 + l31;
-    const float *bp = Bs + lh * LDB + bcol0 + l31;
-    // operands of k-step kk+2 are fetched from LDS before the MFMAs of k-step kk issue, so the ds_read latency
-    // hides behind 4 x 64 cycles of matrix work instead of stalling every step on lgkmcnt(0)
-    float a[2][MT], b[2][NT];
+    if constexpr (MM == MM_F32) {
+        const float *ap = As + lh * LDA + arow0 + l31;
+        const float *bp = Bs + lh * LDB + bcol0 + l31;
+        // operands of k-step kk+2 are fetched from LDS before the MFMAs of k-step kk issue, so the ds_read latency
+        // hides behind 4 x 64 cycles of matrix work instead of stalling every step on lgkmcnt(0)
+        float a[2][MT], b[2][NT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) a[0][i] = ap[i * 32];
+        for (int i = 0; i < MT; ++i) a[0][i] = ap[i * 32];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) b[0][j] = bp[j * 32];
+        for (int j = 0; j < NT; ++j) b[0][j] = bp[j * 32];
 #pragma unroll
-    for (int kk = 0; kk < KC; kk += 2) {
-        const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
-        if (kk + 2 < KC) {
+        for (int kk = 0; kk < KC; kk += 2) {
+            const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+            if (kk + 2 < KC) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[nxt][i] = ap[(kk + 2) * LDA + i * 32];
+                for (int i = 0; i < MT; ++i) a[nxt][i] = ap[(kk + 2) * LDA + i * 32];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) b[nxt][j] = bp[(kk + 2) * LDB + j * 32];
+                for (int j = 0; j < NT; ++j) b[nxt][j] = bp[(kk + 2) * LDB + j * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE this step's MFMAs (hipcc otherwise sinks it)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE this step's MFMAs (hipcc otherwise sinks it)
+    } else {
+        // 32x32x16: lane (l31, lh) supplies k = 8*lh + 0..7 of row/column l31 -- LDS rows 8*lh + {0,2,4,6} (hi pairs) and
+        // 8*lh + {1,3,5,7} (lo pairs) of the step, each a conflict-free ds_read_b32 (32 consecutive dwords per half-wave)
+        const uint32_t *ap = (const uint32_t *)As + (8 * lh) * LDA + arow0 + l31;
+        const uint32_t *bp = (const uint32_t *)Bs + (8 * lh) * LDB + bcol0 + l31;
+        constexpr bool X3 = (MM != MM_BF16X1);
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int ks = 0; ks < KC; ks += 16) {
+            u32x4 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    ah[i][q] = ap[(ks + 2 * q) * LDA + i * 32];
+                    if constexpr (X3) al[i][q] = ap[(ks + 2 * q + 1) * LDA + i * 32];
+                }
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bh[j][q] = bp[(ks + 2 * q) * LDB + j * 32];
+                    if constexpr (X3) bl[j][q] = bp[(ks + 2 * q + 1) * LDB + j * 32];
+                }
+            // small cross terms first, then the hi.hi product; term-major so consecutive MFMAs hit different accumulators
+            if constexpr (X3) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<MM>(ah[i], bl[j], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<MM>(al[i], bh[j], acc[i][j]);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<MM>(ah[i], bh[j], acc[i][j]);
+        }
     }
 }
+
+// host-side dispatch of a precision mode (fcn_pn_desc / fcn_cn_desc .precision) to the operand mode of a forward or a
+// backward GEMM: f(std::integral_constant<int, MM>) -> int
+#define FCN_MM_OF(prec, fwd) ((prec) == FCN_PREC_F32 ? MM_F32 : ((prec) == FCN_PREC_BF16 ? MM_BF16X1 : ((fwd) ? MM_F16X3 : MM_BF16X3)))
+#define FCN_MM_SWITCH(mm_, CALL)                                     \
+    switch (mm_) {                                                   \
+        case MM_F32: { constexpr int MM = MM_F32; CALL; } break;     \
+        case MM_F16X3: { constexpr int MM = MM_F16X3; CALL; } break; \
+        case MM_BF16X3: { constexpr int MM = MM_BF16X3; CALL; } break; \
+        default: { constexpr int MM = MM_BF16X1; CALL; } break;      \
+    }
 
 // Row (M index inside the 32x32 tile) held by accumulator register `reg` of this lane.
 __device__ __forceinline__ int acc_row(int reg, int lh) { return (reg & 3) + 8 * (reg >> 2) + 4 * lh; }

@@ -131,7 +131,7 @@ struct DgradArgs {
 // <L,1,2,2> (64 x 128) and <L,1,1,2> (64 x 64) stay under 168 VGPRs: 3 workgroups per CU instead of the 2 that the
 // 128 x 128 tile's 220 VGPRs allow -- scale 4's 570 big tiles were 1.1 waves of 512 slots (two rounds, the second
 // almost empty); 1140 half tiles on 768 slots are 1.5.
-template <int LAYER, int MT, int NT, int WN>
+template <int MM, int LAYER, int MT, int NT, int WN>
 __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT * NT <= 2 ? 3 : 2, 4)))
 void dgrad_kernel(DgradArgs a)
 {
@@ -199,9 +199,9 @@ void dgrad_kernel(DgradArgs a)
                 rz[i] = ldg4(a.dzcur + arow[i] + nq_);                                                                \
             }                                                                                                         \
         }                                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < NB4; ++i) {                                                             \
-            const int f = tid + NTHR * i;                                                                             \
-            const int nn = f / (TN / 4), cq = f % (TN / 4);                                                           \
+        _Pragma("unroll") for (int i = 0; i < NB4; ++i) {      /* rows 2*pr, 2*pr+1 of one column quad (a k pair) */  \
+            const int f = tid + NTHR * (i >> 1);                                                                      \
+            const int nn = 2 * (f / (TN / 4)) + (i & 1), cq = f % (TN / 4);                                           \
             rw[i] = ldg4(a.W + (int64_t)((cc) * KC + nn) * CPREV + k0 + 4 * cq);                                      \
         }                                                                                                             \
     }
@@ -218,7 +218,7 @@ void dgrad_kernel(DgradArgs a)
             const float zv[4] = {rz[i].x, rz[i].y, rz[i].z, rz[i].w};
             int mv[4] = {0, 0, 0, 0};
             if constexpr (LAYER == 3) { mv[0] = rm[i].x; mv[1] = rm[i].y; mv[2] = rm[i].z; mv[3] = rm[i].w; }
-            float dv[4];
+            float dv[4], ev[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = c * KC + 4 * kq + j;
@@ -227,8 +227,10 @@ void dgrad_kernel(DgradArgs a)
                 const float xh = (yv[j] - coefS[CRED + n]) * coefS[2 * CRED + n];
                 const float dy = coefS[n] * (dz - w * fmaf(xh, coefS[4 * CRED + n], coefS[3 * CRED + n]));
                 dv[j] = ok ? dy : 0.f;
-                As[(4 * kq + j) * LDA + r] = dv[j];
             }
+            enc4<MM>(dv[0], dv[1], dv[2], dv[3], ev);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) As[(4 * kq + j) * LDA + r] = ev[j];
             if constexpr (LAYER == 3) {
                 if (ok && blockIdx.y == 0)
                     *(float4 *)(a.dybuf + (grow0 + r) * CRED + c * KC + 4 * kq) =
@@ -236,14 +238,17 @@ void dgrad_kernel(DgradArgs a)
             }
         }
 #pragma unroll
-        for (int i = 0; i < NB4; ++i) {
-            const int f = tid + NTHR * i;
-            const int nn = f / (TN / 4), cq = f % (TN / 4);
-            sts4(Bs + nn * LDB + 4 * cq, rw[i]);
+        for (int i = 0; i < NB4; i += 2) {
+            const int f = tid + NTHR * (i >> 1);
+            const int nn = 2 * (f / (TN / 4)), cq = f % (TN / 4);
+            v4f hi, lo;
+            enc2x4<MM>(rw[i], rw[i + 1], hi, lo);
+            sts4(Bs + nn * LDB + 4 * cq, hi);
+            sts4(Bs + (nn + 1) * LDB + 4 * cq, lo);
         }
         __syncthreads();
         if (c + 1 < nchunk) DGRAD_LOAD(c + 1);
-        mma_chunk<MT, NT, LDA, LDB>(As, Bs, wm * 32 * MT, wn * 32 * NT, acc);
+        mma_chunk<MM, MT, NT, LDA, LDB>(As, Bs, wm * 32 * MT, wn * 32 * NT, acc);
         __syncthreads();
     }
 #undef DGRAD_LOAD
@@ -333,7 +338,7 @@ struct WgradArgs {
 // dW[n][k] = sum_rows dy[row][n] * a_prev[row][k]; workgroup tile (64*MT) x (64*NT).  Split s reduces the
 // rows of live tiles [s*tpb, (s+1)*tpb) and writes one partial; wgrad_reduce sums the live partials in a fixed
 // order (deterministic, no float atomics).
-template <int LAYER, int MT, int NT>
+template <int MM, int LAYER, int MT, int NT>
 __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ? 3 : 2, 4))) void wgrad_kernel(WgradArgs a)
 {
     constexpr int LDA = 64 * MT + 4, LDB = 64 * NT + 4;
@@ -355,7 +360,10 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
     // per-thread constant columns of the two staged operands
     const int acq = tid % (16 * MT), arr = tid / (16 * MT);
     const int bcq = tid % (16 * NT), brr = tid / (16 * NT);
-    constexpr int ARS = 16 / MT, BRS = 16 / NT;                  // row stride between a thread's float4s
+    // a thread's float4s sit in reduction-adjacent row PAIRS (rows 2*arr + {0,1} + 2*ART*p): what enc2 packs together
+    constexpr int ART = 16 / MT, BRT = 16 / NT;                  // threads along the rows of the A / B tile
+#define WG_AROW(i) (2 * arr + ((i) & 1) + 2 * ART * ((i) >> 1))
+#define WG_BROW(i) (2 * brr + ((i) & 1) + 2 * BRT * ((i) >> 1))
     float cf[5][4];
     float bs[4], bt[4], bal[4][3];
     if constexpr (LAYER == 2) {
@@ -397,7 +405,7 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
         chunk_rows(q, g0, left);
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
-            const int rr = arr + ARS * i;
+            const int rr = WG_AROW(i);
             if (rr < left) {
                 const int64_t o = (g0 + rr) * COUT + n0 + 4 * acq;
                 if constexpr (LAYER == 3) {
@@ -414,7 +422,7 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
         }
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {
-            const int rr = brr + BRS * i;
+            const int rr = WG_BROW(i);
             if (rr < left) {
                 if constexpr (LAYER == 3) rb4[i] = *(const float4 *)(a.yprev + (g0 + rr) * CIN + k0 + 4 * bcq);
                 else rb4[i] = a.ent[g0 + rr];
@@ -429,11 +437,12 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
         int64_t g0_;
         int left;
         chunk_rows(q, g0_, left);
+        v4f sa[2 * MT], sb[2 * NT];
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
-            const int rr = arr + ARS * i;
+            const int rr = WG_AROW(i);
             const bool ok = rr < left;
-            float4 v = ra[i];
+            v4f v = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
             if constexpr (LAYER == 2) {
                 const float dzv[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
                 const float yv[4] = {ra2[i].x, ra2[i].y, ra2[i].z, ra2[i].w};
@@ -443,13 +452,21 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
                     const float xh = (yv[j] - cf[1][j]) * cf[2][j];
                     o[j] = cf[0][j] * (dzv[j] - rwt[i] * fmaf(xh, cf[4][j], cf[3][j]));
                 }
-                v = ok ? make_float4(o[0], o[1], o[2], o[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v4f ov = {o[0], o[1], o[2], o[3]};
+                v = ok ? ov : zero4();
             }
-            *(float4 *)(As + rr * LDA + 4 * acq) = v;
+            sa[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * MT; i += 2) {
+            v4f hi, lo;
+            enc2x4<MM>(sa[i], sa[i + 1], hi, lo);
+            sts4(As + WG_AROW(i) * LDA + 4 * acq, hi);
+            sts4(As + WG_AROW(i + 1) * LDA + 4 * acq, lo);
         }
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {
-            const int rr = brr + BRS * i;
+            const int rr = WG_BROW(i);
             const bool ok = rr < left;
             float o[4];
             if constexpr (LAYER == 3) {
@@ -461,14 +478,23 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
                 for (int j = 0; j < 4; ++j)
                     o[j] = fmaxf(l1_pre(bal[j], bt[j], rb4[i].x, rb4[i].y, rb4[i].z), 0.f);
             }
-            *(float4 *)(Bs + rr * LDB + 4 * bcq) =
-                ok ? make_float4(o[0], o[1], o[2], o[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v4f ov = {o[0], o[1], o[2], o[3]};
+            sb[i] = ok ? ov : zero4();
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * NT; i += 2) {
+            v4f hi, lo;
+            enc2x4<MM>(sb[i], sb[i + 1], hi, lo);
+            sts4(Bs + WG_BROW(i) * LDB + 4 * bcq, hi);
+            sts4(Bs + WG_BROW(i + 1) * LDB + 4 * bcq, lo);
         }
         __syncthreads();
         if (q + 1 < nq) load_chunk(q + 1);
-        mma_chunk<MT, NT, LDA, LDB>(As, Bs, wm * 32 * MT, wn * 32 * NT, acc);
+        mma_chunk<MM, MT, NT, LDA, LDB>(As, Bs, wm * 32 * MT, wn * 32 * NT, acc);
         __syncthreads();
     }
+#undef WG_AROW
+#undef WG_BROW
 
     float *out = a.partial + (int64_t)blockIdx.x * COUT * CIN;
 #pragma unroll
@@ -550,21 +576,32 @@ __global__ void l1_finalize_kernel(const double *__restrict__ Q, const double *_
 
 // ------------------------------------------------------------------------------------------------
 template <int LAYER>
-static int launch_dgrad(const DgradArgs &a, int B, hipStream_t st)
+static int launch_dgrad(const DgradArgs &a, int B, int precision, hipStream_t st)
 {
     if (a.CRED % 64 || a.CPREV % 64 || a.CRED > MAXC) return FCN_E_BADARG;
     const unsigned nt = (unsigned)(B * a.tps);
     if (a.CPREV % 128 == 0) {          // 64 x 128 tiles, two workgroups per listed 128-row tile
-        hipLaunchKernelGGL((dgrad_kernel<LAYER, 1, 2, 2>), dim3(2 * nt, a.CPREV / 128), dim3(256), 0, st, a);
+        FCN_MM_SWITCH(FCN_MM_OF(precision, false),
+                      hipLaunchKernelGGL((dgrad_kernel<MM, LAYER, 1, 2, 2>), dim3(2 * nt, a.CPREV / 128), dim3(256), 0, st, a));
     } else {                            // 64 x 64 tiles (the 64-channel layers of scales 1 and 2: few column tiles)
-        hipLaunchKernelGGL((dgrad_kernel<LAYER, 1, 1, 2>), dim3(2 * nt, a.CPREV / 64), dim3(256), 0, st, a);
+        FCN_MM_SWITCH(FCN_MM_OF(precision, false),
+                      hipLaunchKernelGGL((dgrad_kernel<MM, LAYER, 1, 1, 2>), dim3(2 * nt, a.CPREV / 64), dim3(256), 0, st, a));
     }
     FCN_CHECK_LAUNCH();
     return 0;
 }
 
+template <int MM, int LAYER>
+static void launch_wgrad_mm(const WgradArgs &a, dim3 grid, bool m2, bool n2, hipStream_t st)
+{
+    if (m2 && n2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 2, 2>), grid, dim3(GT), 0, st, a);
+    else if (m2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 2, 1>), grid, dim3(GT), 0, st, a);
+    else if (n2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 1, 2>), grid, dim3(GT), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 1, 1>), grid, dim3(GT), 0, st, a);
+}
+
 template <int LAYER>
-static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, hipStream_t st, float *out)
+static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, int precision, hipStream_t st, float *out)
 {
     const bool m2 = (a.COUT % 128 == 0), n2 = (a.CIN % 128 == 0);
     const int oy = a.COUT / (m2 ? 128 : 64), oz = a.CIN / (n2 ? 128 : 64);
@@ -577,10 +614,7 @@ static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, hipStream_t st, flo
     if (nsplit > B * a.tps) nsplit = B * a.tps;
     if (nsplit > nsplit_cap) nsplit = nsplit_cap;
     dim3 grid(nsplit, oy, oz);
-    if (m2 && n2) hipLaunchKernelGGL((wgrad_kernel<LAYER, 2, 2>), grid, dim3(GT), 0, st, a);
-    else if (m2) hipLaunchKernelGGL((wgrad_kernel<LAYER, 2, 1>), grid, dim3(GT), 0, st, a);
-    else if (n2) hipLaunchKernelGGL((wgrad_kernel<LAYER, 1, 2>), grid, dim3(GT), 0, st, a);
-    else hipLaunchKernelGGL((wgrad_kernel<LAYER, 1, 1>), grid, dim3(GT), 0, st, a);
+    FCN_MM_SWITCH(FCN_MM_OF(precision, false), (launch_wgrad_mm<MM, LAYER>(a, grid, m2, n2, st)));
     FCN_CHECK_LAUNCH();
     const int64_t ne = (int64_t)a.COUT * a.CIN;
     const int gr = nsplit >= 128 ? 16 : (nsplit >= 64 ? 8 : (nsplit >= 32 ? 4 : (nsplit >= 16 ? 2 : 1)));
@@ -609,6 +643,7 @@ extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, co
 {
     if (!d || !p || !ws || !dfeat || !dW || !dgamma || !dbeta) return FCN_E_BADARG;
     if (!d->training) return FCN_E_BADARG;
+    if (d->precision < 0 || d->precision > FCN_PREC_BF16) return FCN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     const bool two = stream2 != nullptr && events != nullptr;
     hipStream_t sw = two ? (hipStream_t)stream2 : st;
@@ -638,7 +673,7 @@ extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, co
     g.ycur = ws->y3; g.amax = ws->amax; g.gmax = ws->gmax; g.dzcur = nullptr; g.coef = coef3; g.W = p->W[2];
     g.dybuf = ws->dy3; g.yprev = ws->y2; g.bn_prev = bn2; g.W1 = nullptr; g.dzprev = ws->dz2; g.bstat_prev = bs2;
     g.CRED = C3; g.CPREV = C2;
-    FCN_TRY(launch_dgrad<3>(g, B, st));
+    FCN_TRY(launch_dgrad<3>(g, B, d->precision, st));
 
     WgradArgs w;
     w.ent = (const float4 *)ws->ent; w.woff = ws->woff; w.tiles = ws->tiles; w.L = L; w.cap = cap; w.tps = tps;
@@ -651,7 +686,7 @@ extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, co
         e = hipStreamWaitEvent(sw, (hipEvent_t)events[0], 0);
         if (e != hipSuccess) return (int)e;
     }
-    FCN_TRY(launch_wgrad<3>(w, B, ws->nsplit, sw, dW[2]));
+    FCN_TRY(launch_wgrad<3>(w, B, ws->nsplit, d->precision, sw, dW[2]));
 
     hipLaunchKernelGGL(bnbwd_finalize_kernel, dim3((C2 + 63) / 64), dim3(64), 0, st, bs2, p->gamma[1], bn2, C2, M,
                        coef2, dgamma[1], dbeta[1]);
@@ -664,19 +699,19 @@ extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, co
         if (e != hipSuccess) return (int)e;
         w.dy = nullptr; w.dz = ws->dz2; w.ycur = ws->y2; w.coef = coef2; w.yprev = nullptr; w.bn_prev = bn1;
         w.W1 = p->W[0]; w.COUT = C2; w.CIN = C1;
-        FCN_TRY(launch_wgrad<2>(w, B, ws->nsplit, sw, dW[1]));
+        FCN_TRY(launch_wgrad<2>(w, B, ws->nsplit, d->precision, sw, dW[1]));
         e = hipEventRecord((hipEvent_t)events[2], sw);
         if (e != hipSuccess) return (int)e;
     }
     g.ycur = ws->y2; g.amax = nullptr; g.gmax = nullptr; g.dzcur = ws->dz2; g.coef = coef2; g.W = p->W[1];
     g.dybuf = nullptr; g.yprev = nullptr; g.bn_prev = bn1; g.W1 = p->W[0]; g.dzprev = nullptr; g.bstat_prev = bsQ;
     g.CRED = C2; g.CPREV = C1;
-    FCN_TRY(launch_dgrad<2>(g, B, st));
+    FCN_TRY(launch_dgrad<2>(g, B, d->precision, st));
 
     if (!two) {
         w.dy = nullptr; w.dz = ws->dz2; w.ycur = ws->y2; w.coef = coef2; w.yprev = nullptr; w.bn_prev = bn1;
         w.W1 = p->W[0]; w.COUT = C2; w.CIN = C1;
-        FCN_TRY(launch_wgrad<2>(w, B, ws->nsplit, st, dW[1]));
+        FCN_TRY(launch_wgrad<2>(w, B, ws->nsplit, d->precision, st, dW[1]));
     }
 
     hipLaunchKernelGGL(l1_finalize_kernel, dim3((C1 + 63) / 64), dim3(64), 0, st, bsQ, ws->stat + FCN_STAT_MOM,

@@ -103,7 +103,7 @@ struct FwdArgs {
 // staged A tile between 256 output columns, halving the BN+ReLU staging work per output element.
 // MT = 1: 64-row tiles, two workgroups per listed 128-row tile (scale 4's conv3: 1140 big tiles are 1.5 waves of the 768
 // resident slots -- two rounds; 2280 half tiles on 1024 slots are 2.2 half rounds).
-template <int MODE, int NT, int WN, int MT = 2>
+template <int MM, int MODE, int NT, int WN, int MT = 2>
 __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 1 ? 4 : 3, 4))) void fwd_gemm_kernel(FwdArgs a)
 {
     constexpr int NTHR = 128 * WN;
@@ -190,34 +190,43 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
                 const int r = f >> 3, kq = f & 7;
                 const bool ok = r < nvalid;
                 const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+                float z[4], e[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = 4 * kq + j;
-                    const float z = fmaf(sS[c * KC + k], v[j], tS[c * KC + k]);
-                    As[k * LDA + r] = ok ? fmaxf(z, 0.f) : 0.f;
+                    z[j] = fmaf(sS[c * KC + k], v[j], tS[c * KC + k]);
+                    z[j] = ok ? fmaxf(z[j], 0.f) : 0.f;
                 }
+                enc4<MM>(z[0], z[1], z[2], z[3], e);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) As[(4 * kq + j) * LDA + r] = e[j];
             }
         } else {
             const int part = tid / TM;
 #pragma unroll
-            for (int j = 0; j < KPT; ++j) {
+            for (int j = 0; j < KPT; j += 2) {
                 const int k = part * KPT + j;
                 const int kk = c * KC + k;
-                const float z = l1_pre(&sS[3 * kk], tS[kk], ux, uy, uz);
-                As[k * LDA + r0] = r0valid ? fmaxf(z, 0.f) : 0.f;
+                const float z0 = l1_pre(&sS[3 * kk], tS[kk], ux, uy, uz);
+                const float z1 = l1_pre(&sS[3 * kk + 3], tS[kk + 1], ux, uy, uz);
+                float e0, e1;
+                enc2<MM>(r0valid ? fmaxf(z0, 0.f) : 0.f, r0valid ? fmaxf(z1, 0.f) : 0.f, e0, e1);
+                As[k * LDA + r0] = e0;
+                As[(k + 1) * LDA + r0] = e1;
             }
         }
 #pragma unroll
         for (int i = 0; i < NB4; ++i) {
             const int f = tid + NTHR * i;
             const int n = f >> 3, kq = f & 7;
-            const float v[4] = {rw[i].x, rw[i].y, rw[i].z, rw[i].w};
+            float v[4];
+            enc4<MM>(rw[i].x, rw[i].y, rw[i].z, rw[i].w, v);
 #pragma unroll
             for (int j = 0; j < 4; ++j) Bs[(4 * kq + j) * LDB + n] = v[j];
         }
         __syncthreads();
         if (c + 1 < nchunk) load_chunk(c + 1);
-        mma_chunk<MT, NT, LDA, LDB>(As, Bs, wm * 32 * MT, wn * 32 * NT, acc);
+        mma_chunk<MM, MT, NT, LDA, LDB>(As, Bs, wm * 32 * MT, wn * 32 * NT, acc);
         __syncthreads();
     }
 
@@ -331,22 +340,30 @@ __global__ __launch_bounds__(GT) void pool_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
-static int launch_fwd_gemm(const FwdArgs &a, int B, hipStream_t st)
+template <int MM, int MODE>
+static int launch_fwd_gemm_mm(const FwdArgs &a, int B, hipStream_t st)
 {
-    if (a.CIN % 64 || a.COUT % 64 || a.CIN > MAXC) return FCN_E_BADARG;
     const unsigned nt = (unsigned)(B * a.tps);
     if (FCN_WIDE_TILES && a.COUT % 256 == 0) {
-        hipLaunchKernelGGL((fwd_gemm_kernel<MODE, 2, 4>), dim3(nt, a.COUT / 256), dim3(512), 0, st, a);
+        hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 2, 4>), dim3(nt, a.COUT / 256), dim3(512), 0, st, a);
     } else if (MODE == 1 && a.COUT >= 512 && a.COUT % 128 == 0) {      // the widest conv3: 64 x 128 tiles
-        hipLaunchKernelGGL((fwd_gemm_kernel<MODE, 2, 2, 1>), dim3(2 * nt, a.COUT / 128), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 2, 2, 1>), dim3(2 * nt, a.COUT / 128), dim3(256), 0, st, a);
     } else if (a.COUT % 128 == 0) {
-        hipLaunchKernelGGL((fwd_gemm_kernel<MODE, 2, 2>), dim3(nt, a.COUT / 128), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 2, 2>), dim3(nt, a.COUT / 128), dim3(256), 0, st, a);
     } else {
-        hipLaunchKernelGGL((fwd_gemm_kernel<MODE, 1, 2>), dim3(nt, a.COUT / 64), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 1, 2>), dim3(nt, a.COUT / 64), dim3(256), 0, st, a);
     }
     FCN_CHECK_LAUNCH();
     return 0;
+}
+
+template <int MODE>
+static int launch_fwd_gemm(const FwdArgs &a, int B, int precision, hipStream_t st)
+{
+    if (a.CIN % 64 || a.COUT % 64 || a.CIN > MAXC) return FCN_E_BADARG;
+    if (precision < 0 || precision > FCN_PREC_BF16) return FCN_E_BADARG;
+    FCN_MM_SWITCH(FCN_MM_OF(precision, true), return (launch_fwd_gemm_mm<MM, MODE>(a, B, st)));
+    return FCN_E_BADARG;
 }
 
 extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, const int32_t *cnt,
@@ -375,7 +392,7 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
     a.ent = (const float4 *)ws->ent; a.woff = ws->woff; a.tiles = ws->tiles; a.L = L; a.cap = cap; a.tps = (cap + 127) / 128;
     a.aprev = nullptr; a.bn_in = bn1; a.W1 = p->W[0]; a.W = p->W[1]; a.y = ws->y2;
     a.stat = tr ? st2 : nullptr; a.CIN = C1; a.COUT = C2;
-    FCN_TRY(launch_fwd_gemm<0>(a, B, st));
+    FCN_TRY(launch_fwd_gemm<0>(a, B, d->precision, st));
 
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C2 + 63) / 64), dim3(64), 0, st, st2, p->gamma[1], p->beta[1],
                        p->running_mean[1], p->running_var[1], p->num_batches_tracked[1], C2, tr, d->eps,
@@ -384,7 +401,7 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
 
     a.aprev = ws->y2; a.bn_in = bn2; a.W1 = nullptr; a.W = p->W[2]; a.y = ws->y3;
     a.stat = tr ? st3 : nullptr; a.CIN = C2; a.COUT = C3;
-    FCN_TRY(launch_fwd_gemm<1>(a, B, st));
+    FCN_TRY(launch_fwd_gemm<1>(a, B, d->precision, st));
 
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C3 + 63) / 64), dim3(64), 0, st, st3, p->gamma[2], p->beta[2],
                        p->running_mean[2], p->running_var[2], p->num_batches_tracked[2], C3, tr, d->eps,
@@ -416,9 +433,9 @@ extern "C" int fcn_pn_conv_fwd(const fcn_pn_desc *d, const fcn_pn_params *p, con
     if (layer == 2) {
         a.aprev = nullptr; a.bn_in = ws->bn + fcn_bn_off(0, C1, C2); a.W1 = p->W[0]; a.W = p->W[1]; a.y = ws->y2;
         a.stat = with_stats ? st2 : nullptr; a.CIN = C1; a.COUT = C2;
-        return launch_fwd_gemm<0>(a, B, st);
+        return launch_fwd_gemm<0>(a, B, d->precision, st);
     }
     a.aprev = ws->y2; a.bn_in = ws->bn + fcn_bn_off(1, C1, C2); a.W1 = nullptr; a.W = p->W[2]; a.y = ws->y3;
     a.stat = with_stats ? st3 : nullptr; a.CIN = C2; a.COUT = C3;
-    return launch_fwd_gemm<1>(a, B, st);
+    return launch_fwd_gemm<1>(a, B, d->precision, st);
 }

@@ -8,6 +8,7 @@ import torch
 
 from . import _native
 from ._native import CnDesc, CnParams, CnWs
+from . import precision as _precision
 
 LAYERS = ("block1_conv1", "block2_conv1", "block2_conv2", "block2_merge", "block3_conv1", "block3_conv2",
           "block3_merge", "block4_conv1", "block4_conv2", "block4_merge", "block2_deconv", "block3_deconv",
@@ -110,7 +111,8 @@ def _prepare(pool, cfgt, bufs, one_hot, B, Ls, dev, pt):
         bh = torch.cat([cls_b, reg_b], 0).contiguous()
     nvec = 0 if one_hot is None else one_hot.shape[1]
     oh = None if one_hot is None else one_hot.detach().contiguous().float()
-    desc = CnDesc(B, (ctypes.c_int32 * 4)(*Ls), nvec, reg_w.shape[0], 1 if training else 0, eps, momentum, 0)
+    desc = CnDesc(B, (ctypes.c_int32 * 4)(*Ls), nvec, reg_w.shape[0], 1 if training else 0, eps, momentum, 0,
+                  _precision.code())
     ws = pool.acquire((B,) + tuple(Ls) + (nvec, reg_w.shape[0]), desc, dev, need_grad)
     rmeans, rvars, nbts = bufs
     params = CnParams(_arr(Ws + [Wh]), _arr(gs), _arr(bs), _arr(rmeans), _arr(rvars), _arr(nbts), bh.data_ptr())

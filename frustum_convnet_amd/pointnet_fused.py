@@ -12,6 +12,7 @@ import torch
 from . import _native
 from ._native import PnDesc, PnParams, PnWs
 from .query_depth_point import query_depth_point
+from . import precision as _precision
 
 
 class Workspace:
@@ -100,7 +101,8 @@ def _forward_impl(pool, cfgt, pc, ref, one_hot, bufs, plist, need_grad):
     dev = pc.device
     idx, cnt = query_depth_point(dist, K, pc, ref)
     ws = pool.acquire(B, N, Lw, K, C1, C2, C3, device=dev, need_grad=need_grad)
-    desc = PnDesc(B, N, Lw, K, C1, C2, C3, nvec, 1 if training else 0, eps, momentum, 1 if nlc else 0)
+    desc = PnDesc(B, N, Lw, K, C1, C2, C3, nvec, 1 if training else 0, eps, momentum, 1 if nlc else 0,
+                  _precision.code())
     rmeans, rvars, nbts = bufs
     Wc = [W1.detach().reshape(C1, 3).contiguous(), W2.detach().reshape(C2, C1).contiguous(),
           W3.detach().reshape(C3, C2).contiguous()]

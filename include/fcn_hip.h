@@ -38,6 +38,19 @@ extern "C" {
 #define FCN_E_BADARG 10001   /* unsupported shape / null pointer */
 #define FCN_E_LIMIT  10002   /* size beyond a documented limit   */
 
+/* Matrix-core operand precision of the GEMM kernels (fcn_pn_desc.precision / fcn_cn_desc.precision).  Storage, BatchNorm
+ * statistics and accumulation are fp32 in every mode.
+ *   FCN_PREC_SPLIT  default, the parity mode: every fp32 operand is split into two 16-bit parts and a product is formed
+ *                   from three 16-bit MFMAs (fp16 parts in the forward GEMMs, bf16 parts in the backward GEMMs) -- fp32-class
+ *                   results (logits within 1e-4 of the fp32 reference) at 5.3x the fp32 matrix rate of gfx950.  Forward
+ *                   operands (activations after BN+ReLU, weights) must stay below 65504 in magnitude.
+ *   FCN_PREC_F32    exact fp32 MFMA (v_mfma_f32_32x32x2_f32): the reference mode for A/B comparisons.
+ *   FCN_PREC_BF16   throughput mode of BASELINE config 2: single bf16 MFMA per product, fp32 accumulate (logits within
+ *                   a few 1e-2 relative of the fp32 reference; grouping indices unaffected). */
+#define FCN_PREC_SPLIT 0
+#define FCN_PREC_F32   1
+#define FCN_PREC_BF16  2
+
 /* Version / build probe: returns 950 (the only arch this library is built for). */
 int fcn_arch(void);
 
@@ -67,6 +80,7 @@ typedef struct fcn_pn_desc {
     float   eps, momentum;       /* BatchNorm eps (1e-5) and momentum (0.1)                 */
     int32_t nlc;                 /* 0: feat/dfeat are (B, C3+nvec, L) as the reference returns them;
                                     1: position-major (B, L, C3), no one-hot rows (input of fcn_convnet_*) */
+    int32_t precision;           /* FCN_PREC_* (0 = split 16-bit MFMA, fp32-class)                              */
 } fcn_pn_desc;
 
 /* Parameters of the three conv+BN pairs (reference state_dict order: conv{1,2,3}.0.weight,
@@ -144,6 +158,7 @@ typedef struct fcn_cn_desc {
     int32_t training;
     float   eps, momentum;
     int32_t prepacked;           /* 1: fcn_convnet_pack already ran for these weights / one-hot (joined by the caller) */
+    int32_t precision;           /* FCN_PREC_*                                                                  */
 } fcn_cn_desc;
 
 typedef struct fcn_cn_params {
