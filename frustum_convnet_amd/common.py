@@ -45,11 +45,20 @@ def DeConv1d(i_c, o_c, k, s=1, p=0, bn=True):
     return _seq(nn.ConvTranspose1d, nn.BatchNorm1d, i_c, o_c, k, s, p, bn)
 
 
+def bn_momentum(bn):
+    """BatchNorm momentum for the HIP kernels.  momentum=None means a cumulative moving average in PyTorch, which the
+    kernels do not implement (no shipped cfg uses it): fail loudly instead of substituting a value."""
+    if bn.momentum is None:
+        raise NotImplementedError("BatchNorm with momentum=None (cumulative average) is not supported by the HIP path")
+    return float(bn.momentum)
+
+
 def masked_mean(x, mask, count=None):
     """mean of x over rows where mask is 1 (x: (R,), mask: (R,) float)."""
     if count is None:
         count = mask.sum()
-    return (x * mask).sum() / count
+    # an empty mask reports 0 (as the fused HIP tail does), not 0/0
+    return (x * mask).sum() / count.clamp(min=1.0)
 
 
 def softmax_focal_loss_ignore(prob, target, alpha=0.25, gamma=2, ignore_idx=-1):

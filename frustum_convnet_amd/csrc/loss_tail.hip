@@ -91,7 +91,9 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
     const float nfg = block_sum(cfg_, sh);
     const float nkeep = block_sum(ckeep, sh);
     const float inv_cls = 1.f / (nfg + 1e-14f);
-    const float inv_fg = 1.f / nfg;
+    // a batch without a foreground row (the reference asserts on it, det_base.py:416): the foreground means report 0
+    // instead of 0 * inf = NaN, and out[11] = nfg lets the caller see it without a host sync on the hot path
+    const float inv_fg = nfg > 0.f ? 1.f / nfg : 0.f;
 
     float acc[11];
 #pragma unroll
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
             const float clx = a.box_center[b * 3], cly = a.box_center[b * 3 + 1], clz = a.box_center[b * 3 + 2];
             const float hlab = a.box_heading[b];
             const float sl0 = a.box_size[b * 3], sl1 = a.box_size[b * 3 + 1], sl2 = a.box_size[b * 3 + 2];
-            const int sc = (int)a.size_class[b];
+            const int sc = min(max((int)a.size_class[b], 0), NS - 1);     // clamped: an out-of-range label must not index out of bounds
             const float ex0 = a.mean_size[sc * 3], ex1 = a.mean_size[sc * 3 + 1], ex2 = a.mean_size[sc * 3 + 2];
             const float wB = a.w_box * inv_fg;
 
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
         a.out[0] = total;
         a.out[1] = cls; a.out[2] = center; a.out[3] = hcls; a.out[4] = hres;
         a.out[5] = scls; a.out[6] = sres; a.out[7] = corner;
-        a.out[8] = t[8] / nkeep; a.out[9] = t[9] * inv_fg; a.out[10] = t[10] * inv_fg;
+        a.out[8] = nkeep > 0.f ? t[8] / nkeep : 0.f; a.out[9] = t[9] * inv_fg; a.out[10] = t[10] * inv_fg;
         a.out[11] = nfg;
         a.out[12] = a.out[13] = a.out[14] = a.out[15] = 0.f;
         if (a.total) a.total[0] = total;

@@ -4,12 +4,16 @@ Same constructors, forward signatures, return structures and state_dict keys (15
 feat_net.pointnet{1-4}.conv{1-3}.{0.weight,1.*}, conv_net.block*.{0.weight,1.*}, cls_out.*, reg_out.*), so
 checkpoints written by the reference's train/train_net_det.py:384-398 load unchanged.
 
-What runs where:
-  * grouping + shared MLP + max-pool + one-hot concat of every scale: hand-written HIP (csrc/), reached
-    through PointNetModule.forward_pooled.  The nn.Conv2d/BatchNorm2d children only HOLD the parameters.
-  * Conv1d FCN + heads (11 % of the dense FLOPs): MIOpen/rocBLAS through torch for now.
-  * loss tail: torch ops on device, written mask-weighted so the step has no host synchronisation
-    (the reference syncs at det_base.py:70, :414 and :495 every step).
+What runs where (all of it hand-written HIP behind the C-ABI of include/fcn_hip.h; the nn.Conv*/BatchNorm* children only
+HOLD the parameters so that state_dicts stay interchangeable):
+  * grouping + shared MLP + max-pool of every scale: csrc/grouping.hip, pointnet_fwd.hip, pointnet_bwd.hip
+    (PointNetModule.forward_pooled / launch_pooled);
+  * ConvFeatNet + heads: csrc/fcn_net.hip (implicit-GEMM forward + backward) -- `fused_fcn`;
+  * train-loss tail (8 losses, 3 accuracies, 3 IoU metrics, d total / d logits): csrc/loss_tail.hip + csrc/box_iou.hip,
+    one launch each, no host synchronisation (the reference syncs at det_base.py:70, :414 and :495 every step) -- `fused_loss`;
+  * eval decode: torch ops on the device (box_ops.py).
+`fused_fcn = False` / `fused_loss = False` are EXPLICIT opt-ins to the nn.Conv1d / torch-op formulations (GPU libraries,
+kept for A/B parity tests); nothing falls back to them silently.
 """
 import math
 
@@ -22,7 +26,7 @@ import torch.nn.functional as F
 
 from .config import cfg
 from .dataset_info import DATASET_INFO
-from .common import Conv1d, Conv2d, DeConv1d, init_params, softmax_focal_loss_ignore, get_accuracy, masked_mean
+from .common import Conv1d, Conv2d, DeConv1d, init_params, softmax_focal_loss_ignore, get_accuracy, masked_mean, bn_momentum
 from .query_depth_point import QueryDepthPoint
 from .pointnet_fused import WorkspacePool, pointnet_pooled, launch_pooled, attach_pooled
 from . import box_ops
@@ -65,7 +69,7 @@ class PointNetModule(nn.Module):
         params, bufs = self._param_pack()
         bn = self.conv1[1]
         feat, _, _ = pointnet_pooled(self._pool, self.dist, self.nsample, self.training, bn.eps,
-                                     0.1 if bn.momentum is None else bn.momentum,
+                                     bn_momentum(bn),
                                      pc.contiguous(), new_pc.contiguous(), one_hot_vec, bufs, params, nlc=nlc)
         return feat
 
@@ -74,7 +78,7 @@ class PointNetModule(nn.Module):
         params, bufs = self._param_pack()
         bn = self.conv1[1]
         return launch_pooled(self._pool, self.dist, self.nsample, self.training, bn.eps,
-                             0.1 if bn.momentum is None else bn.momentum,
+                             bn_momentum(bn),
                              pc.contiguous(), new_pc.contiguous(), one_hot_vec, bufs, params, nlc=nlc)
 
     def attach_pooled(self, handle):
@@ -90,7 +94,7 @@ class PointNetModule(nn.Module):
         bn = self.conv1[1]
         with torch.no_grad():
             return dense_from_entries(self._pool, self.dist, self.nsample, self.training, bn.eps,
-                                      0.1 if bn.momentum is None else bn.momentum,
+                                      bn_momentum(bn),
                                       pc.contiguous(), new_pc.contiguous(), bufs, params)
 
 
@@ -269,11 +273,30 @@ class PointNetDet(nn.Module):
         # fused_fcn: ConvFeatNet + heads as hand-written implicit-GEMM HIP kernels over position-major activations
         # (csrc/fcn_net.hip); False runs the nn.Conv1d / BatchNorm1d modules through MIOpen.
         self.fused_fcn = True
+        # split_backward: forward() cuts the autograd graph at the pooled feature maps; backward_split(loss, between) then
+        # runs [loss, heads, ConvFeatNet] first and the four PointNet scales second, calling `between()` in the middle --
+        # where the data-parallel step starts the all-reduce of the FCN gradients (2.9 M of the 3.3 M parameters) so that it
+        # overlaps the PointNet backward (train/train_net_det.py:126-128 + nn.DataParallel's reduce, :308-309)
+        self.split_backward = False
+        self._split = None
         self._zero_cache = {}
         self._loss_scratch = None
         from .fcn_fused import CnPool
         self._cn_pool = CnPool()
         self.last_logits = None
+
+    def backward_split(self, loss, between=None):
+        """loss.backward() in two phases (needs split_backward = True at forward time): phase 1 differentiates the loss
+        tail, heads and ConvFeatNet (their parameter gradients are final when it returns), `between()` runs, phase 2
+        differentiates the PointNet scales.  Numerically identical to loss.backward()."""
+        if self._split is None:
+            raise RuntimeError("backward_split needs a training forward with model.split_backward = True")
+        feats, leaves = self._split
+        self._split = None
+        loss.backward()
+        if between is not None:
+            between()
+        torch.autograd.backward(list(feats), [l.grad for l in leaves])
 
     def _slice_output(self, output):
         nb, ns = self.num_bins, self.num_size_cluster
@@ -308,13 +331,26 @@ class PointNetDet(nn.Module):
         mean_size_array = self._mean_size.to(device=point_cloud.device, dtype=point_cloud.dtype)
 
         logits64 = None
-        if self.fused_fcn and point_cloud.is_cuda and one_hot_vec is not None:
+        self._split = None
+        if self.fused_fcn and not point_cloud.is_cuda:
+            raise RuntimeError("frustum_convnet_amd: the hot path runs on an MI355X only (got a %s tensor); there is no "
+                               "CPU fallback" % point_cloud.device)
+        if self.fused_fcn and one_hot_vec is None:
+            raise NotImplementedError("the fused ConvFeatNet reads the one-hot class vector (data_dicts['one_hot']); set "
+                                      "model.fused_fcn = False explicitly to run the nn.Conv1d modules instead")
+        if self.fused_fcn:
             from .fcn_fused import convnet_fused, convnet_prepack
             # the FCN's weight re-packing depends on the weights only: start it beside the PointNet scales
             pre = convnet_prepack(self._cn_pool, self.conv_net, self.cls_out, self.reg_out, batch_size,
                                   [r.shape[2] for r in refs], one_hot_vec, point_cloud.device)
             # no join after the scales: the FCN waits for each pooled map right before the first layer that reads it
             feats = self.feat_net(xyz, refs, None, one_hot_vec, nlc=True, join=False)
+            if self.split_backward and self.training and torch.is_grad_enabled():
+                # two-phase backward (backward_split): the FCN sees detached leaves, so loss.backward() stops at the pooled
+                # feature maps and the PointNet scales are differentiated by a second call
+                leaves = tuple(f.detach().requires_grad_(True) for f in feats)
+                self._split = (feats, leaves)
+                feats = leaves
             logits64 = convnet_fused(self._cn_pool, self.conv_net, self.cls_out, self.reg_out, feats, one_hot_vec, pre,
                                      self.feat_net.done_events)
             lv = logits64.view(batch_size, refs[1].shape[2], 64)

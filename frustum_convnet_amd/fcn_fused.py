@@ -9,6 +9,7 @@ import torch
 from . import _native
 from ._native import CnDesc, CnParams, CnWs
 from . import precision as _precision
+from .common import bn_momentum
 
 LAYERS = ("block1_conv1", "block2_conv1", "block2_conv2", "block2_merge", "block3_conv1", "block3_conv2",
           "block3_merge", "block4_conv1", "block4_conv2", "block4_merge", "block2_deconv", "block3_deconv",
@@ -258,7 +259,7 @@ def convnet_prepack(pool, conv_net, cls_out, reg_out, B, Ls, one_hot, device):
     pt, bufs, bn0 = _gather(conv_net, cls_out, reg_out)
     training = conv_net.training
     need_grad = bool(training) and torch.is_grad_enabled() and any(t.requires_grad for t in pt)
-    cfgt = (bool(training), float(bn0.eps), float(0.1 if bn0.momentum is None else bn0.momentum), need_grad)
+    cfgt = (bool(training), float(bn0.eps), bn_momentum(bn0), need_grad)
     cur = torch.cuda.current_stream(device)
     side, ev = pool.pack_stream(device)
     side.wait_stream(cur)
@@ -286,7 +287,7 @@ def convnet_fused(pool, conv_net, cls_out, reg_out, feats, one_hot, pre=None, fe
     training = conv_net.training
     need_grad = bool(training) and torch.is_grad_enabled() and (
         any(t.requires_grad for t in pt) or any(f.requires_grad for f in feats))
-    cfgt = (bool(training), float(bn0.eps), float(0.1 if bn0.momentum is None else bn0.momentum), need_grad)
+    cfgt = (bool(training), float(bn0.eps), bn_momentum(bn0), need_grad)
     if pre is not None and pre["cfgt"] != cfgt:        # e.g. only the features require grad: pack inline instead
         pool.release(pre["ws"])
         torch.cuda.current_stream(feats[0].device).wait_event(pre["event"])

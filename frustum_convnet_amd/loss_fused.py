@@ -7,6 +7,13 @@ import torch
 
 from . import _native
 
+
+def _check_labels(cls_label, size_class, ns):
+    """The kernels read both label tensors as int64 through raw pointers: a wrong dtype would be misread silently.
+    (size_class values must lie in [0, ns): the kernel clamps them, the reference would raise an index error.)"""
+    if cls_label.dtype != torch.int64 or size_class.dtype != torch.int64:
+        raise TypeError("cls_label / size_class must be int64 (got %s / %s)" % (cls_label.dtype, size_class.dtype))
+
 LOSS_NAMES = ("total_loss", "cls_loss", "center_loss", "head_cls_loss", "head_res_loss", "size_cls_loss",
               "size_res_loss", "corners_loss")
 
@@ -15,6 +22,7 @@ class _LossTail(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cls_raw, reg_raw, cls_label, ref2, center, heading, size, size_class, mean_size, nb, ns, w):
         L = _native.lib()
+        _check_labels(cls_label, size_class, ns)
         B, _, L2 = cls_raw.shape
         cls_c, reg_c = cls_raw.detach().contiguous(), reg_raw.detach().contiguous()
         need = cls_raw.requires_grad or reg_raw.requires_grad
@@ -64,6 +72,7 @@ class _LossTailRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, cls_label, ref2, center, heading, size, size_class, mean_size, B, L2, nb, ns, w, scratch):
         L = _native.lib()
+        _check_labels(cls_label, size_class, ns)
         lg = logits.detach().contiguous()
         need = logits.requires_grad
         out = torch.empty(16, dtype=torch.float32, device=lg.device)

@@ -6,7 +6,9 @@ Parameters, gradients and both Adam moments are four contiguous fp32 buffers (13
   * the HIP backward kernels write each weight gradient STRAIGHT into its view (no autograd accumulation kernels,
     no per-tensor allocations) -- gradients are therefore overwritten, not accumulated, by every backward;
   * cls_out / reg_out weights (and biases) are adjacent, so the fused heads GEMM reads them as one matrix without a cat;
-  * the data-parallel exchange is ONE RCCL all-reduce (sum) of `grad`; the 1/world mean is folded into the
+  * the data-parallel exchange is an RCCL all-reduce (sum) of `grad` in TWO buckets cut where the backward finishes them:
+    [ConvFeatNet + heads] (2.9 M of the 3.3 M parameters) is final when the FCN backward ends and is reduced on RCCL's
+    stream while the PointNet backward still runs; [PointNet] follows it.  The 1/world of the mean is folded into the
     optimiser kernel's grad_scale;
   * the optimiser step is one streaming HIP kernel (fcn_adam_step_f32) whose step counter and hyper-parameters
     live in device memory, so it can be captured into the step's hipGraph and the learning rate changed between
@@ -63,6 +65,14 @@ class FlatTrainState:
                 p.grad = gv
                 p._fcn_grad = gv            # the HIP backward writes here and hands autograd no gradient
         self.world, self.group = int(world), group
+        # buckets in the order the backward completes them: everything after the PointNet scales (named feat_net.*,
+        # first in the buffer), then the PointNet scales
+        cut = 0
+        for n, o, p in zip(self.names, offs, params):
+            if n.startswith("feat_net."):
+                cut = max(cut, (o + p.numel() + 3) // 4 * 4)
+        self.buckets = [("fcn+heads", cut, total), ("pointnet", 0, cut)] if 0 < cut < total else [("all", 0, total)]
+        self._pending = []
         self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, 1.0 / self.world], device=dev,
                                   dtype=torch.float32)
         # one step counter per workgroup of the optimiser kernel (all equal); step_count is slot 0
@@ -83,6 +93,20 @@ class FlatTrainState:
         if self.world > 1:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.group)
 
+    def allreduce_bucket_async(self, i):
+        """Starts the summing all-reduce of bucket i on the communication stream (it waits for the work enqueued on the
+        current stream so far, nothing later): call it right after the backward phase that completes the bucket, keep
+        launching the next phase, and call wait_allreduce() before the optimiser step.  world 1: no-op."""
+        if self.world > 1:
+            _, lo, hi = self.buckets[i]
+            self._pending.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait_allreduce(self):
+        """The current stream waits for every bucket started with allreduce_bucket_async (no host block on CUDA/HIP)."""
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
     def adam_step(self):
         if self.device.type != "cuda":
             raise RuntimeError("frustum_convnet_amd: the optimiser step is a HIP kernel (MI355X only); "
@@ -95,9 +119,54 @@ class FlatTrainState:
                                               _native.current_stream(self.device)),
                           "fcn_adam_step_f32")
 
-    def step(self):
+    def step(self, zero_grad=False):
+        """all-reduce + Adam.  The HIP backward kernels OVERWRITE every gradient they own, so no zero_grad is needed
+        between steps when both fused paths are active; a model that routes some gradients through ordinary autograd
+        (PointNetDet.fused_fcn = False, torch loss tail) ACCUMULATES into the same views -- pass zero_grad=True (or call
+        zero_grad() before each forward) there.  Gradient accumulation over micro-batches is not supported by the fused
+        backward (it overwrites)."""
         self.allreduce()
         self.adam_step()
+        if zero_grad:
+            self.zero_grad()
+
+    # ---- checkpointing (reference: optimizer.state_dict() saved / restored at train/train_net_det.py:353,387)
+    def state_dict(self):
+        """torch.optim.Adam-compatible state: {'state': {i: {step, exp_avg, exp_avg_sq}}, 'param_groups': [...]}, indexed in
+        this object's parameter order (self.names)."""
+        step = int(self.step_count.item())
+        hy = [float(v) for v in self.hyper.tolist()]
+        state = {}
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            n = p.numel()
+            state[i] = {"step": torch.tensor(float(step)), "exp_avg": self.exp_avg[o:o + n].view(p.shape).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[o:o + n].view(p.shape).clone()}
+        group = {"lr": hy[0], "betas": (hy[1], hy[2]), "eps": hy[3], "weight_decay": hy[4], "amsgrad": False,
+                 "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group], "names": list(self.names)}
+
+    def load_state_dict(self, sd):
+        group = sd["param_groups"][0]
+        if len(group["params"]) != len(self.params):
+            raise ValueError("optimizer state has %d parameters, model has %d" % (len(group["params"]), len(self.params)))
+        steps = set()
+        with torch.no_grad():
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                st = sd["state"].get(i, sd["state"].get(str(i)))
+                n = p.numel()
+                if st is None:
+                    self.exp_avg[o:o + n].zero_()
+                    self.exp_avg_sq[o:o + n].zero_()
+                    continue
+                self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
+            if len(steps) > 1:
+                raise ValueError("per-parameter step counts differ (%s): the flat optimiser keeps one" % sorted(steps))
+            self._step_slots.fill_(steps.pop() if steps else 0)          # every workgroup's slot
+            b1, b2 = group["betas"]
+            self.hyper[0:5].copy_(torch.tensor([group["lr"], b1, b2, group["eps"], group["weight_decay"]],
+                                               dtype=torch.float32))
 
     def release(self):
         """Back to ordinary autograd gradients (per-tensor .grad, accumulation)."""
