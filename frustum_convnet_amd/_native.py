@@ -17,7 +17,7 @@ class PnDesc(ctypes.Structure):
                 ("C1", ctypes.c_int32), ("C2", ctypes.c_int32), ("C3", ctypes.c_int32),
                 ("nvec", ctypes.c_int32), ("training", ctypes.c_int32),
                 ("eps", ctypes.c_float), ("momentum", ctypes.c_float), ("nlc", ctypes.c_int32),
-                ("precision", ctypes.c_int32)]
+                ("precision", ctypes.c_int32), ("grouped", ctypes.c_int32)]
 
 
 class CnDesc(ctypes.Structure):
@@ -45,7 +45,7 @@ class PnParams(ctypes.Structure):
 class PnWs(ctypes.Structure):
     _fields_ = [("woff", c_fp), ("ent", c_fp), ("ewin", c_fp), ("tiles", c_fp), ("y2", c_fp), ("y3", c_fp), ("amax", c_fp),
                 ("stat", c_fp), ("bn", c_fp), ("gmax", c_fp), ("dy3", c_fp), ("dz2", c_fp), ("bstat", c_fp),
-                ("coef", c_fp), ("partial", c_fp), ("nsplit", ctypes.c_int32)]
+                ("coef", c_fp), ("partial", c_fp), ("nsplit", ctypes.c_int32), ("gmom", c_fp)]
 
 
 class InpDesc(ctypes.Structure):
@@ -54,11 +54,11 @@ class InpDesc(ctypes.Structure):
                 ("random_flip", ctypes.c_int32), ("random_shift", ctypes.c_int32)]
 
 
-EXPORTS = ("fcn_arch", "fcn_query_depth_point_f32", "fcn_pn_wgrad_rows", "fcn_pn_compact",
-           "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_det_loss_tail_rows2",
+EXPORTS = ("fcn_arch", "fcn_query_depth_point_f32", "fcn_pn_wgrad_rows", "fcn_pn_compact", "fcn_pn_group_compact",
+           "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_det_loss_tail_rows2", "fcn_det_loss_tail_rows3",
            "fcn_det_loss_tail_scratch_floats", "fcn_adam_step_f32", "fcn_adam_step_slots", "fcn_prepare_inputs", "fcn_stamp",
            "fcn_convnet_sizes", "fcn_convnet_pack", "fcn_convnet_forward", "fcn_convnet_forward2",
-           "fcn_convnet_backward")
+           "fcn_convnet_backward", "fcn_box3d_iou_pair_f32", "fcn_decode_detections", "fcn_rotate_nms_3d")
 
 _lib = None
 
@@ -90,6 +90,8 @@ def lib():
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp]
     L.fcn_pn_compact.restype = ctypes.c_int
     L.fcn_pn_compact.argtypes = [ctypes.POINTER(PnDesc), c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(PnWs), c_fp]
+    L.fcn_pn_group_compact.restype = ctypes.c_int
+    L.fcn_pn_group_compact.argtypes = [ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]
     L.fcn_pn_forward.restype = ctypes.c_int
     L.fcn_pn_forward.argtypes = [ctypes.POINTER(PnDesc), ctypes.POINTER(PnParams), c_fp, c_fp,
                                  ctypes.POINTER(PnWs), c_fp, c_fp]
@@ -116,6 +118,8 @@ def lib():
     L.fcn_det_loss_tail_rows.argtypes = [c_fp] * 8 + [ctypes.c_int] * 4 + [ctypes.c_float] * 4 + [c_fp] * 3
     L.fcn_det_loss_tail_rows2.restype = ctypes.c_int
     L.fcn_det_loss_tail_rows2.argtypes = [c_fp] * 8 + [ctypes.c_int] * 4 + [ctypes.c_float] * 4 + [c_fp] * 5
+    L.fcn_det_loss_tail_rows3.restype = ctypes.c_int
+    L.fcn_det_loss_tail_rows3.argtypes = [c_fp] * 8 + [ctypes.c_int] * 4 + [ctypes.c_float] * 5 + [c_fp] * 5
     L.fcn_det_loss_tail_scratch_floats.restype = ctypes.c_int
     L.fcn_det_loss_tail_scratch_floats.argtypes = [ctypes.c_int, ctypes.c_int]
     L.fcn_convnet_sizes.restype = ctypes.c_int
@@ -132,6 +136,12 @@ def lib():
     L.fcn_convnet_backward.argtypes = [ctypes.POINTER(CnDesc), ctypes.POINTER(CnParams), ctypes.POINTER(CnWs),
                                        c_fp * 4, c_fp, c_fp, c_fp * 4, c_fp * 14, c_fp * 14, c_fp * 14, c_fp, c_fp, c_fp,
                                        ctypes.POINTER(c_fp)]
+    L.fcn_box3d_iou_pair_f32.restype = ctypes.c_int
+    L.fcn_box3d_iou_pair_f32.argtypes = [c_fp, c_fp, ctypes.c_int, c_fp, c_fp]
+    L.fcn_decode_detections.restype = ctypes.c_int
+    L.fcn_decode_detections.argtypes = [c_fp, ctypes.c_int] + [c_fp] * 5 + [ctypes.c_int] * 5 + [c_fp] * 3
+    L.fcn_rotate_nms_3d.restype = ctypes.c_int
+    L.fcn_rotate_nms_3d.argtypes = [c_fp] * 3 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_int] + [c_fp] * 3
     _lib = L
     return L
 

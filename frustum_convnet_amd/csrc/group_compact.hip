@@ -1,0 +1,306 @@
+// Fused front of the PointNet scales: sliding-frustum grouping -> entry list, in ONE launch for all scales of a batch.
+//
+// The API form of the grouping (fcn_query_depth_point_f32, grouping.hip) materialises the reference's int64 idx (B,L,K) --
+// 6.9 MB per car batch -- only for fcn_pn_compact to read it back, followed by a one-workgroup tile-list launch, a memset and
+// the BN1 finalisation: five graph nodes and ~45 us of dependent latency per scale in front of the first MFMA
+// (query_depth_point_cuda_kernel.cu:16-65 + the gather / centre subtract of models/det_base.py:75-80).  Here the scan is
+// spread over the whole chip and the dependent steps ride on arrival counters inside the same launch:
+//   A  a workgroup takes 16 windows of one (frustum, scale); every wave scans the frustum's z row (staged in LDS) for its
+//      windows: __ballot + prefix popcount give the first K hits in index order -- the same predicate, order and truncation
+//      as the reference kernel -- stored as 16-bit point indices (a quarter of the int64 idx, never padded, scratch);
+//   B  the LAST workgroup of a (frustum, scale) to finish A scans ne = max(cnt, 1) over the windows -> window row offsets,
+//   C  writes the entry rows (centred coordinates + multiplicity) and window ids, one thread per row, and accumulates the
+//      weighted input moments in fp64;
+//   D  the LAST frustum of a scale to finish C sums the per-frustum moments in frustum order (bitwise reproducible), derives
+//      the BN1 scale / shift (+ running statistics), builds the live-tile list and zeroes the BN sum slots of the coming conv
+//      launches -- the work of bn1_finalize_kernel, tile_list_kernel and the memset of fcn_pn_compact.
+// Outputs are identical to fcn_query_depth_point_f32 + fcn_pn_compact (+ bn1_finalize): cnt, woff, ent, ewin, tiles exactly,
+// moments up to fp64 summation order (tests/test_gpu_group_compact.py).
+#include "fcn_common.h"
+
+#define GC_T 256
+#define GC_WAVES (GC_T / 64)
+#define GC_WPB 16                  // windows per workgroup in phase A (4 per wave)
+#define GC_MAX_SCALES 8
+#define GC_LDS_MAX_PTS 8192        // z row staged in LDS up to this many points
+#define GC_MOM 12                  // doubles per frustum in gmom: 10 moment sums, [10] = arrival counter (as int), [11] unused
+
+struct GcScale {
+    const float *ref;          // (B,3,L) window centres
+    float dis_z;
+    int L, K, C1, C2, C3;
+    int32_t *woff, *ewin, *tiles, *cnt;
+    float4 *ent;
+    unsigned short *ghits;     // (B,L,K) first-K hit lists as 16-bit point indices (scratch: lives in ws.y2, free until conv2)
+    double *stat;              // 16 + 2*C2 + 2*C3
+    double *gmom;              // (B,GC_MOM)
+    const float *W1, *gamma, *beta;
+    float *rmean, *rvar;
+    int64_t *nbt;
+    float *bn1;                // scale, shift, mean, rstd (4*C1)
+};
+
+struct GcArgs {
+    GcScale s[GC_MAX_SCALES];
+    const float *pc;           // (B,3,N)
+    int B, N, training, use_lds;
+    float eps, momentum;
+};
+
+// release: every wave's stores were drained by the preceding barrier; agent-scope write-back, explicit wait (hipcc may drop
+// the one behind the write-back, cdna guide G16), then the counter.  Returns true in the LAST arriver, after an acquire.
+__device__ __forceinline__ bool gc_arrive_last(int *counter, int expected)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int ticket = atomicAdd(counter, 1);
+    const bool last = ticket == expected - 1;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return last;
+}
+
+__global__ __launch_bounds__(GC_T) void group_compact_kernel(GcArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int wsum[GC_WAVES];
+    __shared__ double red[GC_WAVES][10];
+    __shared__ int last_s, carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    // the scale is workgroup-uniform: copy its descriptor out of the kernel argument with static indices only
+    GcScale S = a.s[0];
+#pragma unroll
+    for (int q = 1; q < GC_MAX_SCALES; ++q)
+        if ((int)blockIdx.z == q) S = a.s[q];
+    const int L = S.L, K = S.K, N = a.N;
+    const int nslice = (L + GC_WPB - 1) / GC_WPB;
+    if ((int)blockIdx.x >= nslice) return;
+    // LDS: phase A: z row (N floats); phases B-C (last workgroup of the frustum): cnt (L) | offs (L+1)
+    float *zs = (float *)smem;
+    int *cntS = (int *)smem;
+    int *offS = cntS + L;
+
+    const float *px = a.pc + (int64_t)b * 3 * N, *py = px + N, *pz = py + N;
+    if (a.use_lds)
+        for (int i = tid; i < N; i += GC_T) zs[i] = pz[i];
+    __syncthreads();
+
+    // ---- A: hit lists of this slice's windows (query_depth_point_cuda_kernel.cu:40-64: fabsf(z2 - z1) < dis_z in fp32,
+    // ascending k, first K)
+    const float *rx = S.ref + (int64_t)b * 3 * L, *ry = rx + L, *rz = ry + L;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int q = 0; q < GC_WPB / GC_WAVES; ++q) {
+        const int l = blockIdx.x * GC_WPB + q * GC_WAVES + wave;          // wave-uniform
+        if (l >= L) break;
+        const float z2 = rz[l];
+        unsigned short *hrow = S.ghits + ((int64_t)b * L + l) * K;
+        int c = 0;
+        for (int k0 = 0; k0 < N && c < K; k0 += 64) {
+            const int k = k0 + lane;
+            float z1 = 0.f;
+            if (k < N) z1 = a.use_lds ? zs[k] : pz[k];
+            const bool hit = (k < N) && (fabsf(z2 - z1) < S.dis_z);
+            const unsigned long long mask = __ballot(hit);
+            if (mask != 0ull) {
+                const int pos = c + (int)__popcll(mask & lt_mask);
+                if (hit && pos < K) hrow[pos] = (unsigned short)k;
+                c += (int)__popcll(mask);
+            }
+        }
+        if (lane == 0) S.cnt[(int64_t)b * L + l] = c < K ? c : K;
+    }
+    __syncthreads();
+    if (tid == 0) last_s = gc_arrive_last((int *)&S.gmom[(int64_t)b * GC_MOM + 10], nslice) ? 1 : 0;
+    __syncthreads();
+    if (!last_s) return;
+
+    // ======== the last workgroup of (frustum, scale): phases B, C for the whole frustum
+    for (int l = tid; l < L; l += GC_T) cntS[l] = __hip_atomic_load(&S.cnt[(int64_t)b * L + l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    // ---- B: exclusive scan of ne = max(cnt, 1) over the windows
+    {
+        const int per = (L + GC_T - 1) / GC_T;
+        const int l0 = min(L, tid * per), l1 = min(L, l0 + per);
+        int s = 0;
+        for (int l = l0; l < l1; ++l) s += max(cntS[l], 1);
+        int incl = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int run = incl - s;
+        for (int w = 0; w < wave; ++w) run += wsum[w];
+        for (int l = l0; l < l1; ++l) {
+            offS[l] = run;
+            run += max(cntS[l], 1);
+        }
+        if (tid == GC_T - 1) offS[L] = run;
+        __syncthreads();
+        for (int l = tid; l <= L; l += GC_T) S.woff[(int64_t)b * (L + 1) + l] = offS[l];
+    }
+    // ---- C: one thread per entry row (window by binary search in the offsets) + weighted moments of u = p - c
+    const int64_t cap = (int64_t)L * K;
+    const int nent = offS[L];
+    double m[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) m[i] = 0.0;
+    for (int e = tid; e < nent; e += GC_T) {
+        int lo = 0, hi = L;                                               // largest l with offS[l] <= e
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (offS[mid] <= e) lo = mid; else hi = mid;
+        }
+        const int l = lo, j = e - offS[l], ne = offS[l + 1] - offS[l];
+        // empty window: point 0 (the reference's zero-initialised idx row)
+        int p = 0;
+        if (cntS[l] > 0)
+            p = (int)__hip_atomic_load(&S.ghits[((int64_t)b * L + l) * K + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float ux = px[p] - rx[l], uy = py[p] - ry[l], uz = pz[p] - rz[l];
+        const float w = (j == 0) ? (float)(K - ne + 1) : 1.0f;
+        const int64_t r = (int64_t)b * cap + e;
+        S.ent[r] = make_float4(ux, uy, uz, w);
+        S.ewin[r] = l;
+        const double dw = w, dx = ux, dy = uy, dz = uz;
+        m[0] += dw;
+        m[1] += dw * dx; m[2] += dw * dy; m[3] += dw * dz;
+        m[4] += dw * dx * dx; m[5] += dw * dx * dy; m[6] += dw * dx * dz;
+        m[7] += dw * dy * dy; m[8] += dw * dy * dz; m[9] += dw * dz * dz;
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const double v = wave_sum_f64(m[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (tid < 10) {
+        double v = 0.0;
+        for (int w = 0; w < GC_WAVES; ++w) v += red[w][tid];
+        S.gmom[(int64_t)b * GC_MOM + tid] = v;
+    }
+    if (tid == 0) ((int *)&S.gmom[(int64_t)b * GC_MOM + 10])[0] = 0;      // this frustum's counter ready for the next launch
+    __syncthreads();
+
+    // ---- D: the LAST frustum of this scale to get here finalises the scale
+    if (tid == 0) last_s = gc_arrive_last(&S.tiles[1], a.B) ? 1 : 0;      // tiles[1]: arrival counter, 0 between launches
+    __syncthreads();
+    if (!last_s) return;
+    // moments in frustum order (fixed order: reproducible bit for bit)
+    if (tid < 10) {
+        double v = 0.0;
+        for (int q = 0; q < a.B; ++q) v += __hip_atomic_load(&S.gmom[(int64_t)q * GC_MOM + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        S.stat[FCN_STAT_MOM + tid] = v;
+        red[0][tid] = v;
+    }
+    // BN sum slots of the conv launches that follow
+    for (int i = 10 + tid; i < 16 + 2 * S.C2 + 2 * S.C3; i += GC_T) S.stat[i] = 0.0;
+    __syncthreads();
+    // BN1 scale / shift from the moments (conv1 is linear in u): what bn1_finalize_kernel computes
+    {
+        const double M = (double)a.B * (double)L * (double)K;
+        for (int c = tid; c < S.C1; c += GC_T) {
+            double mean, var;
+            if (a.training) {
+                const double mx = red[0][1] / M, my = red[0][2] / M, mz = red[0][3] / M;
+                const double cxx = red[0][4] / M - mx * mx, cxy = red[0][5] / M - mx * my, cxz = red[0][6] / M - mx * mz;
+                const double cyy = red[0][7] / M - my * my, cyz = red[0][8] / M - my * mz, czz = red[0][9] / M - mz * mz;
+                const double w0 = S.W1[3 * c], w1 = S.W1[3 * c + 1], w2 = S.W1[3 * c + 2];
+                mean = w0 * mx + w1 * my + w2 * mz;
+                var = w0 * (cxx * w0 + cxy * w1 + cxz * w2) + w1 * (cxy * w0 + cyy * w1 + cyz * w2) +
+                      w2 * (cxz * w0 + cyz * w1 + czz * w2);
+                if (var < 0.0) var = 0.0;
+                if (S.rmean) {
+                    S.rmean[c] = (float)((1.0 - a.momentum) * S.rmean[c] + a.momentum * mean);
+                    S.rvar[c] = (float)((1.0 - a.momentum) * S.rvar[c] + a.momentum * var * (M / (M - 1.0)));
+                    if (c == 0 && S.nbt) S.nbt[0] += 1;
+                }
+            } else {
+                mean = S.rmean[c];
+                var = S.rvar[c];
+            }
+            const double rstd = 1.0 / sqrt(var + (double)a.eps);
+            const double sc = (double)S.gamma[c] * rstd;
+            S.bn1[c] = (float)sc;
+            S.bn1[S.C1 + c] = (float)((double)S.beta[c] - mean * sc);
+            S.bn1[2 * S.C1 + c] = (float)mean;
+            S.bn1[3 * S.C1 + c] = (float)rstd;
+        }
+    }
+    // live-tile list: tiles[0] = count, tiles[4+i] = b*tps + t (frustum-major, as tile_list_kernel)
+    {
+        const int tps = (int)((cap + 127) / 128);
+        if (tid == 0) carry_s = 0;
+        __syncthreads();
+        for (int b0 = 0; b0 < a.B; b0 += GC_T) {
+            const int bb = b0 + tid;
+            int ne = 0;
+            if (bb < a.B) ne = __hip_atomic_load(&S.woff[(int64_t)bb * (L + 1) + L], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int nt = (ne + 127) / 128;
+            int incl = nt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            int base = carry_s;
+            for (int w = 0; w < wave; ++w) base += wsum[w];
+            const int off = base + incl - nt;
+            for (int t = 0; t < nt; ++t) S.tiles[4 + off + t] = bb * tps + t;
+            __syncthreads();
+            if (tid == GC_T - 1) carry_s = base + incl;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            S.tiles[0] = carry_s;
+            S.tiles[1] = 0;                                               // counter ready for the next launch
+        }
+    }
+}
+
+extern "C" int fcn_pn_group_compact(int nscale, const fcn_pn_desc *const *d, const fcn_pn_params *const *p, const float *pc,
+                                    const float *const *ref, const float *dis_z, const fcn_pn_ws *const *ws,
+                                    int32_t *const *cnt, void *stream)
+{
+    if (nscale < 1 || nscale > GC_MAX_SCALES || !d || !p || !pc || !ref || !dis_z || !ws || !cnt) return FCN_E_BADARG;
+    GcArgs a;
+    size_t lds = 0;
+    int maxslice = 1;
+    for (int s = 0; s < GC_MAX_SCALES; ++s) {
+        const int q = s < nscale ? s : 0;
+        if (!d[q] || !p[q] || !ref[q] || !ws[q] || !cnt[q]) return FCN_E_BADARG;
+        const fcn_pn_desc *D = d[q];
+        if (D->B != d[0]->B || D->N != d[0]->N || D->training != d[0]->training || D->eps != d[0]->eps ||
+            D->momentum != d[0]->momentum)
+            return FCN_E_BADARG;
+        if (D->B <= 0 || D->L <= 0 || D->K <= 0 || D->N <= 0) return FCN_E_BADARG;
+        if (D->N > 65535 || D->L > 8192 || D->K > 1024 || D->B > 65535) return FCN_E_LIMIT;       // 16-bit point indices
+        if (D->C1 % 64 || D->C2 % 64 || D->C3 % 64) return FCN_E_BADARG;
+        if (!ws[q]->woff || !ws[q]->ent || !ws[q]->ewin || !ws[q]->tiles || !ws[q]->stat || !ws[q]->bn || !ws[q]->gmom ||
+            !ws[q]->y2)
+            return FCN_E_BADARG;
+        GcScale &S = a.s[s];
+        S.ref = ref[q]; S.dis_z = dis_z[q]; S.L = D->L; S.K = D->K; S.C1 = D->C1; S.C2 = D->C2; S.C3 = D->C3;
+        S.woff = ws[q]->woff; S.ewin = ws[q]->ewin; S.tiles = ws[q]->tiles; S.cnt = cnt[q]; S.ent = (float4 *)ws[q]->ent;
+        S.ghits = (unsigned short *)ws[q]->y2;          // (B,L,K) x 2 bytes <= (B,L*K,C2) x 4 bytes; y2 is written by conv2 later
+        S.stat = ws[q]->stat; S.gmom = ws[q]->gmom;
+        S.W1 = p[q]->W[0]; S.gamma = p[q]->gamma[0]; S.beta = p[q]->beta[0]; S.rmean = p[q]->running_mean[0];
+        S.rvar = p[q]->running_var[0]; S.nbt = p[q]->num_batches_tracked[0];
+        S.bn1 = ws[q]->bn + fcn_bn_off(0, D->C1, D->C2);
+        if (!D->training && (!S.rmean || !S.rvar)) return FCN_E_BADARG;
+        const size_t need = (size_t)(2 * D->L + 1) * sizeof(int);
+        if (need > lds) lds = need;
+        const int ns_ = (D->L + GC_WPB - 1) / GC_WPB;
+        if (s < nscale && ns_ > maxslice) maxslice = ns_;
+    }
+    a.pc = pc; a.B = d[0]->B; a.N = d[0]->N; a.training = d[0]->training ? 1 : 0; a.eps = d[0]->eps; a.momentum = d[0]->momentum;
+    a.use_lds = (a.N <= GC_LDS_MAX_PTS) ? 1 : 0;
+    if (a.use_lds && (size_t)a.N * sizeof(float) > lds) lds = (size_t)a.N * sizeof(float);
+    if (lds > 64 * 1024) return FCN_E_LIMIT;
+    hipLaunchKernelGGL(group_compact_kernel, dim3(maxslice, a.B, nscale), dim3(GC_T), lds, (hipStream_t)stream, a);
+    FCN_CHECK_LAUNCH();
+    return 0;
+}

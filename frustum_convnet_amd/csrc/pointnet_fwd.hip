@@ -383,10 +383,12 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
     float *bn3 = ws->bn + fcn_bn_off(2, C1, C2);
     double *st2 = ws->stat + FCN_STAT_L2, *st3 = st2 + 2 * C2;
 
-    hipLaunchKernelGGL(bn1_finalize_kernel, dim3((C1 + 63) / 64), dim3(64), 0, st, ws->stat + FCN_STAT_MOM,
-                       p->W[0], p->gamma[0], p->beta[0], p->running_mean[0], p->running_var[0],
-                       p->num_batches_tracked[0], C1, tr, d->eps, d->momentum, M, bn1);
-    FCN_CHECK_LAUNCH();
+    if (!d->grouped) {                  // (fcn_pn_group_compact already finalised BN1 from the input moments)
+        hipLaunchKernelGGL(bn1_finalize_kernel, dim3((C1 + 63) / 64), dim3(64), 0, st, ws->stat + FCN_STAT_MOM,
+                           p->W[0], p->gamma[0], p->beta[0], p->running_mean[0], p->running_var[0],
+                           p->num_batches_tracked[0], C1, tr, d->eps, d->momentum, M, bn1);
+        FCN_CHECK_LAUNCH();
+    }
 
     FwdArgs a;
     a.ent = (const float4 *)ws->ent; a.woff = ws->woff; a.tiles = ws->tiles; a.L = L; a.cap = cap; a.tps = (cap + 127) / 128;

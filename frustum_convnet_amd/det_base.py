@@ -81,6 +81,14 @@ class PointNetModule(nn.Module):
                              bn_momentum(bn),
                              pc.contiguous(), new_pc.contiguous(), one_hot_vec, bufs, params, nlc=nlc)
 
+    def prepare_pooled(self, pc, new_pc, one_hot_vec=None, nlc=False):
+        """Workspace / descriptor of this scale for the fused front (pointnet_fused.group_compact + launch_prepared)."""
+        from .pointnet_fused import prepare_pooled
+        params, bufs = self._param_pack()
+        bn = self.conv1[1]
+        return prepare_pooled(self._pool, self.dist, self.nsample, self.training, bn.eps, bn_momentum(bn),
+                              pc.contiguous(), new_pc.contiguous(), one_hot_vec, bufs, params, nlc=nlc)
+
     def attach_pooled(self, handle):
         feat, _, _ = attach_pooled(self._pool, handle)
         return feat
@@ -111,6 +119,7 @@ class PointNetFeat(nn.Module):
         self.pointnet3 = PointNetModule(input_channel - 3, [128, 128, 256], u[2], 64, use_xyz=True, use_feature=True)
         self.pointnet4 = PointNetModule(input_channel - 3, [256, 256, 512], u[3], 128, use_xyz=True, use_feature=True)
         self.concurrent_scales = True
+        self.fused_front = os.environ.get("FCN_FUSED_FRONT", "1") != "0"
         self._stream_cache = {}
         # the widest scale is the long pole of the backward: its weight-gradient GEMMs run on a second stream beside
         # its data-gradient chain (bit k of FCN_PN_SIDE = scale k+1; default scale 4 only)
@@ -150,6 +159,13 @@ class PointNetFeat(nn.Module):
         cur = torch.cuda.current_stream(dev)
         streams = self._streams(dev)
         fork = self._fork_event(dev)
+        # fused front: grouping + compaction + BN1 of all four scales in ONE launch on the caller's stream, in front of the
+        # fork (fcn_pn_group_compact); fused_front = False keeps the API-form grouping per scale (int64 idx, 5 nodes each)
+        prepared = None
+        if self.fused_front:
+            from .pointnet_fused import group_compact, launch_prepared
+            prepared = [nets[s].prepare_pooled(point_cloud, sample_pc[s], one_hot_vec, nlc) for s in range(4)]
+            group_compact(prepared, point_cloud)
         fork.record(cur)
         handles = [None] * 4
         s4_forked = bool(self.topo & 1)
@@ -159,7 +175,10 @@ class PointNetFeat(nn.Module):
             if st is not cur:
                 st.wait_event(fork)
             with torch.cuda.stream(st):
-                handles[s] = nets[s].launch_pooled(point_cloud, sample_pc[s], one_hot_vec, nlc)
+                if prepared is not None:
+                    handles[s] = launch_prepared(prepared[s])
+                else:
+                    handles[s] = nets[s].launch_pooled(point_cloud, sample_pc[s], one_hot_vec, nlc)
         outs = [None] * 4
         done = self._done_events(dev)
         for s in (0, 1, 2, 3):
@@ -284,6 +303,40 @@ class PointNetDet(nn.Module):
         from .fcn_fused import CnPool
         self._cn_pool = CnPool()
         self.last_logits = None
+        self.last_logits64 = None
+        self.last_num_fg = None
+
+    def detect(self, data_dicts, unit_group=None, num_groups=None, method=None, thresh=None, top_k=300):
+        """Inference tail on the device (train/test_net_det.py:193-293 + :126-152): eval forward, decode into label-format
+        boxes, rotated 3-D NMS per (frame, class) group.  data_dicts may carry 'rot_angle' (B,1), 'ref_center' (B,3) and
+        'rgb_prob' (B,1) as the reference's test loader does (:201-214 defaults: zeros / ones).  unit_group (B,) int32 maps
+        each frustum to its (frame, class) group (default: every frustum its own group).
+        Returns dets (B*L2, 8) [tx,ty,tz,l,w,h,ry,score], valid (B*L2,), keep (G, top_k), keep_cnt (G,) -- device tensors;
+        with method 'top' (cfg.TEST.METHOD default) there is one candidate per frustum and no suppression is run."""
+        from . import detect as fdet
+        if self.training:
+            raise RuntimeError("detect() runs in eval mode")
+        method = cfg.TEST.METHOD if method is None else method
+        thresh = cfg.TEST.THRESH if thresh is None else thresh
+        dd = {k: v for k, v in data_dicts.items() if k not in ('box3d_center', 'rot_angle', 'ref_center', 'rgb_prob')}
+        with torch.no_grad():
+            self.forward(dd)
+        if self.last_logits64 is None:
+            raise RuntimeError("detect() needs the fused ConvFeatNet (fused_fcn = True)")
+        refs2 = data_dicts['center_ref2']
+        B, _, L2 = refs2.shape
+        dev = refs2.device
+        rot = data_dicts.get('rot_angle')
+        rot = torch.zeros(B, device=dev) if rot is None else rot.to(dev)
+        dets, valid = fdet.decode_detections(self.last_logits64, refs2, self._mean_size, rot, data_dicts.get('ref_center'),
+                                             data_dicts.get('rgb_prob'), self.num_bins, self.num_size_cluster, method)
+        if unit_group is None:
+            unit_group = torch.arange(B, dtype=torch.int32, device=dev)
+            num_groups = B
+        elif num_groups is None:
+            num_groups = int(unit_group.max().item()) + 1
+        keep, cnt = fdet.rotate_nms_3d(dets, valid, unit_group, L2, num_groups, thresh if method == 'nms' else 2.0, top_k)
+        return dets, valid, keep, cnt
 
     def backward_split(self, loss, between=None):
         """loss.backward() in two phases (needs split_backward = True at forward time): phase 1 differentiates the loss
@@ -363,6 +416,7 @@ class PointNetDet(nn.Module):
             cls_raw = self.cls_out(x)
             reg_raw = self.reg_out(x)
         self.last_logits = (cls_raw, reg_raw)
+        self.last_logits64 = logits64
 
         num_out = reg_raw.shape[2]
         fused_tail = (center_label is not None and self.fused_loss and cls_raw.is_cuda and self.iou_fn is None
@@ -396,17 +450,19 @@ class PointNetDet(nn.Module):
                 key = (batch_size, num_out, str(logits64.device))
                 if self._loss_scratch is None or self._loss_scratch[0] != key:
                     self._loss_scratch = (key, loss_scratch(batch_size, num_out, logits64.device))
-                losses, (a_cls, a_head, a_size) = det_loss_tail_rows(
+                losses, (a_cls, a_head, a_size), ious, nfg = det_loss_tail_rows(
                     logits64, batch_size, num_out, cls_label, refs[1], center_label, heading_label, size_label,
                     size_class_label, mean_size_array, self.num_bins, self.num_size_cluster, wts,
-                    self._loss_scratch[1])
+                    self._loss_scratch[1], cfg.IOU_THRESH)
             else:
-                losses, (a_cls, a_head, a_size) = det_loss_tail(
+                losses, (a_cls, a_head, a_size), ious, nfg = det_loss_tail(
                     cls_raw, reg_raw, cls_label, refs[1], center_label, heading_label, size_label, size_class_label,
                     mean_size_array, self.num_bins, self.num_size_cluster, wts)
-            zero = self._zero_scalar(a_cls)
-            metrics = {'cls_acc': a_cls, 'head_acc': a_head, 'size_acc': a_size, 'IoU_2D': zero, 'IoU_3D': zero,
-                       'IoU_' + str(cfg.IOU_THRESH): zero}
+            # IoU metrics come from the same launch (csrc/box_iou.h): validate()'s best-checkpoint criterion
+            # (train/train_net_det.py:203,365-382) works without the reference's per-step D2H + boost clipping on the host
+            self.last_num_fg = nfg      # device scalar: 0 means the batch had no foreground row (the reference asserts there)
+            metrics = {'cls_acc': a_cls, 'head_acc': a_head, 'size_acc': a_size, 'IoU_2D': ious[0], 'IoU_3D': ious[1],
+                       'IoU_' + str(cfg.IOU_THRESH): ious[2]}
             return losses, metrics
 
         # ---- training / validation branch: every loss is a mean over the foreground rows

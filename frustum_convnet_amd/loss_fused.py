@@ -55,7 +55,7 @@ class _LossTail(torch.autograd.Function):
 
 def det_loss_tail(cls_raw, reg_raw, cls_label, center_ref2, box3d_center, box3d_heading, box3d_size, size_class,
                   mean_size, num_bins, num_sizes, weights):
-    """-> (losses dict with the reference's 8 keys, accuracies (cls, head, size))."""
+    """-> (losses dict with the reference's 8 keys, accuracies (cls, head, size), IoU metrics (2D, 3D, >=0.7), nfg)."""
     if not cls_raw.is_cuda:
         raise RuntimeError("frustum_convnet_amd: fused loss tail runs on the GPU only")
     total, rest = _LossTail.apply(cls_raw, reg_raw, cls_label, center_ref2, box3d_center, box3d_heading, box3d_size,
@@ -63,14 +63,15 @@ def det_loss_tail(cls_raw, reg_raw, cls_label, center_ref2, box3d_center, box3d_
     losses = {"total_loss": total}
     for i, k in enumerate(LOSS_NAMES[1:], start=1):
         losses[k] = rest[i]
-    return losses, (rest[8], rest[9], rest[10])
+    return losses, (rest[8], rest[9], rest[10]), (rest[12], rest[13], rest[14]), rest[11]
 
 
 class _LossTailRows(torch.autograd.Function):
     """Same tail on the row-major (B*L2, 64) logits of the fused ConvFeatNet."""
 
     @staticmethod
-    def forward(ctx, logits, cls_label, ref2, center, heading, size, size_class, mean_size, B, L2, nb, ns, w, scratch):
+    def forward(ctx, logits, cls_label, ref2, center, heading, size, size_class, mean_size, B, L2, nb, ns, w, scratch,
+                iou_thresh=0.7):
         L = _native.lib()
         _check_labels(cls_label, size_class, ns)
         lg = logits.detach().contiguous()
@@ -82,12 +83,12 @@ class _LossTailRows(torch.autograd.Function):
                 heading.contiguous().float(), size.contiguous().float(), size_class.contiguous(),
                 mean_size.contiguous().float()]
         with torch.cuda.device(lg.device):
-            rc = L.fcn_det_loss_tail_rows2(lg.data_ptr(), *[t.data_ptr() for t in args], int(B), int(L2), int(nb),
+            rc = L.fcn_det_loss_tail_rows3(lg.data_ptr(), *[t.data_ptr() for t in args], int(B), int(L2), int(nb),
                                            int(ns), float(w[0]), float(w[1]), float(w[2]), float(w[3]),
-                                           out.data_ptr(), None if dlog is None else dlog.data_ptr(),
+                                           float(iou_thresh), out.data_ptr(), None if dlog is None else dlog.data_ptr(),
                                            None if scratch is None else scratch.data_ptr(), total.data_ptr(),
                                            _native.current_stream(lg.device))
-        _native.check(rc, "fcn_det_loss_tail_rows2")
+        _native.check(rc, "fcn_det_loss_tail_rows3")
         ctx.need = need
         if need:
             ctx.save_for_backward(dlog)
@@ -98,9 +99,9 @@ class _LossTailRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gtotal, _grest):
         if not ctx.need or gtotal is None:
-            return (None,) * 14
+            return (None,) * 15
         (dlog,) = ctx.saved_tensors
-        return (dlog * gtotal,) + (None,) * 13
+        return (dlog * gtotal,) + (None,) * 14
 
 
 def loss_scratch(B, L2, device):
@@ -111,10 +112,11 @@ def loss_scratch(B, L2, device):
 
 
 def det_loss_tail_rows(logits, B, L2, cls_label, center_ref2, box3d_center, box3d_heading, box3d_size, size_class,
-                       mean_size, num_bins, num_sizes, weights, scratch=None):
+                       mean_size, num_bins, num_sizes, weights, scratch=None, iou_thresh=0.7):
+    """-> (losses, (cls_acc, head_acc, size_acc), (IoU_2D, IoU_3D, IoU_>=thresh), nfg) -- all device scalars."""
     total, rest = _LossTailRows.apply(logits, cls_label, center_ref2, box3d_center, box3d_heading, box3d_size,
-                                      size_class, mean_size, B, L2, num_bins, num_sizes, weights, scratch)
+                                      size_class, mean_size, B, L2, num_bins, num_sizes, weights, scratch, iou_thresh)
     losses = {"total_loss": total}
     for i, k in enumerate(LOSS_NAMES[1:], start=1):
         losses[k] = rest[i]
-    return losses, (rest[8], rest[9], rest[10])
+    return losses, (rest[8], rest[9], rest[10]), (rest[12], rest[13], rest[14]), rest[11]

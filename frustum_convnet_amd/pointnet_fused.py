@@ -34,6 +34,8 @@ class Workspace:
         self.y3 = torch.empty((B, cap, C3), dtype=f32, device=dev)
         self.stat = torch.zeros((16 + 2 * C2 + 2 * C3,), dtype=f64, device=dev)
         self.bn = torch.empty((4 * (C1 + C2 + C3),), dtype=f32, device=dev)
+        self.gmom = torch.zeros((B * 12,), dtype=f64, device=dev)       # fcn_pn_group_compact: per-frustum moments + counter
+        self.cnt = torch.empty((B, L), dtype=i32, device=dev)           # window hit counts of the fused grouping
         self.amax = self.gmax = self.dy3 = self.dz2 = self.bstat = self.coef = self.partial = None
         self.nsplit = 0
         if need_grad:
@@ -48,7 +50,7 @@ class Workspace:
         p = lambda t: None if t is None else t.data_ptr()
         self.c = PnWs(p(self.woff), p(self.ent), p(self.ewin), p(self.tiles), p(self.y2), p(self.y3), p(self.amax),
                       p(self.stat), p(self.bn), p(self.gmax), p(self.dy3), p(self.dz2), p(self.bstat),
-                      p(self.coef), p(self.partial), self.nsplit)
+                      p(self.coef), p(self.partial), self.nsplit, p(self.gmom))
 
 
 class WorkspacePool:
@@ -88,37 +90,76 @@ def _params_struct(Ws, gammas, betas, rmeans, rvars, nbts):
     return PnParams(arr(Ws), arr(gammas), arr(betas), arr(rmeans), arr(rvars), arr(nbts))
 
 
-def _forward_impl(pool, cfgt, pc, ref, one_hot, bufs, plist, need_grad):
-    """grouping -> compaction -> fused forward of one scale; returns the workspace still held."""
+def _acquire(pool, cfgt, pc, ref, one_hot, bufs, plist, need_grad):
+    """Workspace, descriptor and C parameter struct of one scale's forward (no launch)."""
     dist, K, training, eps, momentum = cfgt[:5]
     nlc = bool(cfgt[6]) if len(cfgt) > 6 else False
     W1, g1, b1, W2, g2, b2, W3, g3, b3 = plist
-    L = _native.lib()
     B, _, N = pc.shape
     Lw = ref.shape[2]
     C1, C2, C3 = W1.shape[0], W2.shape[0], W3.shape[0]
     nvec = 0 if (one_hot is None or nlc) else one_hot.shape[1]
     dev = pc.device
-    idx, cnt = query_depth_point(dist, K, pc, ref)
     ws = pool.acquire(B, N, Lw, K, C1, C2, C3, device=dev, need_grad=need_grad)
     desc = PnDesc(B, N, Lw, K, C1, C2, C3, nvec, 1 if training else 0, eps, momentum, 1 if nlc else 0,
-                  _precision.code())
+                  _precision.code(), 0)
     rmeans, rvars, nbts = bufs
     Wc = [W1.detach().reshape(C1, 3).contiguous(), W2.detach().reshape(C2, C1).contiguous(),
           W3.detach().reshape(C3, C2).contiguous()]
     gs = [g1.detach().contiguous(), g2.detach().contiguous(), g3.detach().contiguous()]
     bs = [b1.detach().contiguous(), b2.detach().contiguous(), b3.detach().contiguous()]
     params = _params_struct(Wc, gs, bs, rmeans, rvars, nbts)
-    feat = torch.empty((B, Lw, C3) if nlc else (B, C3 + nvec, Lw), dtype=torch.float32, device=dev)
     oh = None if (one_hot is None or nlc) else one_hot.detach().contiguous().float()
+    return {"ws": ws, "desc": desc, "params": params, "Wc": Wc, "gs": gs, "bs": bs, "oh": oh, "nlc": nlc, "nvec": nvec,
+            "ref": ref, "dist": float(dist), "dims": (B, Lw, C3), "dev": dev}
+
+
+def _run_forward(h, cnt, idx):
+    """fcn_pn_forward of a prepared scale on the current stream -> the tuple _PointNetPooled keeps."""
+    L = _native.lib()
+    B, Lw, C3 = h["dims"]
+    dev = h["dev"]
+    feat = torch.empty((B, Lw, C3) if h["nlc"] else (B, C3 + h["nvec"], Lw), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        st = _native.current_stream(dev)
-        _native.check(L.fcn_pn_compact(ctypes.byref(desc), pc.data_ptr(), ref.data_ptr(), idx.data_ptr(),
-                                       cnt.data_ptr(), ctypes.byref(ws.c), st), "fcn_pn_compact")
-        _native.check(L.fcn_pn_forward(ctypes.byref(desc), ctypes.byref(params), cnt.data_ptr(),
-                                       None if oh is None else oh.data_ptr(), ctypes.byref(ws.c),
-                                       feat.data_ptr(), st), "fcn_pn_forward")
-    return feat, idx, cnt, ws, desc, (Wc, gs, bs, cnt, idx, oh)
+        _native.check(L.fcn_pn_forward(ctypes.byref(h["desc"]), ctypes.byref(h["params"]), cnt.data_ptr(),
+                                       None if h["oh"] is None else h["oh"].data_ptr(), ctypes.byref(h["ws"].c),
+                                       feat.data_ptr(), _native.current_stream(dev)), "fcn_pn_forward")
+    return feat, idx, cnt, h["ws"], h["desc"], (h["Wc"], h["gs"], h["bs"], cnt, idx, h["oh"])
+
+
+def _forward_impl(pool, cfgt, pc, ref, one_hot, bufs, plist, need_grad):
+    """API-form grouping (int64 idx) -> compaction -> fused forward of one scale; returns the workspace still held."""
+    L = _native.lib()
+    h = _acquire(pool, cfgt, pc, ref, one_hot, bufs, plist, need_grad)
+    idx, cnt = query_depth_point(h["dist"], h["desc"].K, pc, ref)
+    with torch.cuda.device(h["dev"]):
+        _native.check(L.fcn_pn_compact(ctypes.byref(h["desc"]), pc.data_ptr(), ref.data_ptr(), idx.data_ptr(),
+                                       cnt.data_ptr(), ctypes.byref(h["ws"].c), _native.current_stream(h["dev"])), "fcn_pn_compact")
+    return _run_forward(h, cnt, idx)
+
+
+def group_compact(handles, pc):
+    """ONE launch for the grouping + compaction + BN1 finalisation of every prepared scale (fcn_pn_group_compact): the
+    int64 idx of the API form is never materialised.  Marks the descriptors `grouped`."""
+    L = _native.lib()
+    n = len(handles)
+    dev = pc.device
+    arr = lambda vals: (ctypes.c_void_p * n)(*vals)
+    descs = arr([ctypes.addressof(h["desc"]) for h in handles])
+    params = arr([ctypes.addressof(h["params"]) for h in handles])
+    refs = arr([h["ref"].data_ptr() for h in handles])
+    wss = arr([ctypes.addressof(h["ws"].c) for h in handles])
+    cnts = arr([h["ws"].cnt.data_ptr() for h in handles])
+    dz = (ctypes.c_float * n)(*[h["dist"] for h in handles])
+    with torch.cuda.device(dev):
+        _native.check(L.fcn_pn_group_compact(n, descs, params, pc.data_ptr(), refs, dz, wss, cnts,
+                                             _native.current_stream(dev)), "fcn_pn_group_compact")
+    for h in handles:
+        h["desc"].grouped = 1
+
+
+def _empty_idx(dev):
+    return torch.empty((0,), dtype=torch.int64, device=dev)
 
 
 class _PointNetPooled(torch.autograd.Function):
@@ -197,6 +238,24 @@ def _check_device(pc):
     if not pc.is_cuda:
         raise RuntimeError("frustum_convnet_amd: the PointNet hot path runs on an MI355X only "
                            "(got a %s tensor); there is no CPU fallback" % pc.device)
+
+
+def prepare_pooled(pool, dist, nsample, training, eps, momentum, pc, ref, one_hot, bufs, params, nlc=False):
+    """Step 1 of the fused front: acquire this scale's workspace / descriptor.  Call group_compact() on the handles of all
+    scales (one launch), then launch_prepared() per scale on its own stream."""
+    _check_device(pc)
+    cfgt = _cfg_tuple(dist, nsample, training, eps, momentum, params, nlc)
+    h = _acquire(pool, cfgt, pc, ref, one_hot, bufs, params, cfgt[5])
+    h["args"] = (cfgt, pc, ref, one_hot, bufs, params)
+    return h
+
+
+def launch_prepared(h):
+    """fcn_pn_forward of a grouped scale on the current stream -> handle for attach_pooled()."""
+    cfgt, pc, ref, one_hot, bufs, params = h["args"]
+    with torch.no_grad():
+        launched = _run_forward(h, h["ws"].cnt, _empty_idx(h["dev"]))
+    return (cfgt, pc, ref, one_hot, bufs, params, launched)
 
 
 def launch_pooled(pool, dist, nsample, training, eps, momentum, pc, ref, one_hot, bufs, params, nlc=False):

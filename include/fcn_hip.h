@@ -22,6 +22,9 @@
  *   fcn_adam_step_f32           optim.Adam.step() of the step loop, train/train_net_det.py:131-133,321-339
  *   fcn_prepare_inputs          the per-sample numpy work of the data loader + collate,
  *                               datasets/provider_sample.py:137-262,270-327,396-397
+ *   fcn_box3d_iou_pair_f32      rbbox_iou_3d_pair, ops/pybind11/box_ops.h:173-260 (boost polygon clipping on the host)
+ *   fcn_decode_detections       the numpy decode loop of train/test_net_det.py:254-293 + from_prediction_to_label_format
+ *   fcn_rotate_nms_3d           rotate_nms_3d_cc, ops/pybind11/rbbox_iou.py:294-311 + nms_cpu.h:148-240
  *   fcn_stamp                   (measurement aid, no reference counterpart)
  *
  * Buffers are caller-owned.  "ws" buffers are scratch the caller provides (sizes documented per call).
@@ -81,6 +84,9 @@ typedef struct fcn_pn_desc {
     int32_t nlc;                 /* 0: feat/dfeat are (B, C3+nvec, L) as the reference returns them;
                                     1: position-major (B, L, C3), no one-hot rows (input of fcn_convnet_*) */
     int32_t precision;           /* FCN_PREC_* (0 = split 16-bit MFMA, fp32-class)                              */
+    int32_t grouped;             /* 1: fcn_pn_group_compact prepared ws for this call (entry list, tile list, input moments,
+                                    BN1 scale/shift + running statistics, zeroed BN sums): fcn_pn_forward skips its own
+                                    BN1 finalisation                                                              */
 } fcn_pn_desc;
 
 /* Parameters of the three conv+BN pairs (reference state_dict order: conv{1,2,3}.0.weight,
@@ -112,6 +118,9 @@ typedef struct fcn_pn_ws {
     float   *coef;               /* 5*(C3+C2) floats                                         */
     float   *partial;            /* wgrad partials: nsplit * max(C3*C2, C2*C1) floats        */
     int32_t  nsplit;             /* capacity of `partial` in splits: >= B*ceil(cap/128) (one per row tile) */
+    double  *gmom;               /* (B,12) doubles, fcn_pn_group_compact only (may be NULL otherwise): per-frustum input moments +
+                                    an arrival counter; zero it, and tiles[0..3], ONCE at allocation (the call leaves
+                                    its counters at zero) */
 } fcn_pn_ws;
 
 /* rows of one row tile (128): the caller sizes ws.tiles / ws.partial with it */
@@ -120,6 +129,16 @@ int fcn_pn_wgrad_rows(void);
 /* idx/cnt -> entry list + live-tile list + weighted input moments (ws.woff, ws.ent, ws.ewin, ws.tiles, ws.stat[0..9]) */
 int fcn_pn_compact(const fcn_pn_desc *d, const float *pc /*(B,3,N)*/, const float *ref /*(B,3,L)*/,
                    const int64_t *idx, const int32_t *cnt, const fcn_pn_ws *ws, void *stream);
+
+/* Grouping + compaction of up to 8 scales of one batch in ONE launch, without the int64 idx: for scale s, window centres
+ * ref[s] (B,3,L_s) and half height dis_z[s] produce cnt[s] (B,L_s) and ws[s]->{woff, ent, ewin, tiles, stat[0..9], bn (layer
+ * 1)} exactly as fcn_query_depth_point_f32 + fcn_pn_compact + the BN1 finalisation of fcn_pn_forward would (moments up to
+ * fp64 summation order, here fixed), zeroes the BN sum slots of ws[s]->stat and, in training mode, updates conv1's running
+ * statistics.  All scales share pc (B,3,N), B, N, training, eps, momentum; N <= 65535.  Follow with fcn_pn_forward on
+ * descriptors whose `grouped` field is 1. */
+int fcn_pn_group_compact(int nscale, const fcn_pn_desc *const *d, const fcn_pn_params *const *p, const float *pc,
+                         const float *const *ref, const float *dis_z, const fcn_pn_ws *const *ws, int32_t *const *cnt,
+                         void *stream);
 
 /* Whole forward of one scale after fcn_pn_compact: feat (B, C3+nvec, L), one_hot (B,nvec) or NULL.  In training mode its
  * last kernel also zeroes ws.bstat (when non-NULL) for the fcn_pn_backward that follows. */
@@ -207,7 +226,8 @@ int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn
  *   cls_raw (B,2,L2), reg_raw (B,3+2*NB+4*NS,L2): raw head outputs;  cls_label (B,L2) int64 in {-1,0,1};
  *   center_ref2 (B,3,L2); box3d_center (B,3); box3d_heading (B,1); box3d_size (B,3); size_class (B,1) int64;
  *   mean_size (NS,3).  NB must be 12 and NS 3 (the KITTI configuration), else FCN_E_LIMIT.
- *   out16: total, cls, center, head_cls, head_res, size_cls, size_res, corners, cls_acc, head_acc, size_acc, nfg
+ *   out16: total, cls, center, head_cls, head_res, size_cls, size_res, corners, cls_acc, head_acc, size_acc, nfg,
+ *          IoU_2D, IoU_3D, IoU_>=0.7 (see fcn_det_loss_tail_rows3)
  *   dcls / dreg: d(total)/d(cls_raw), d(total)/d(reg_raw), same layouts (NULL to skip).
  * ------------------------------------------------------------------------------------------- */
 int fcn_det_loss_tail(const float *cls_raw, const float *reg_raw, const int64_t *cls_label,
@@ -246,6 +266,43 @@ int fcn_det_loss_tail_rows2(const float *logits, const int64_t *cls_label, const
                             int num_heading_bin, int num_size_cluster,
                             float w_box, float w_corner, float w_headreg, float w_sizereg,
                             float *out16, float *dlogits, float *scratch, float *total, void *stream);
+
+/* Same with the IoU threshold of the third metric (cfg.IOU_THRESH, configs/config.py:190; the entries above use 0.7).
+ * out16[12..14] = IoU_2D, IoU_3D, IoU_>=thresh: means over the foreground rows of the BEV / 3-D overlap between the box
+ * decoded with the arg-max heading bin and size cluster and the label box (models/det_base.py:480-503, which leaves the
+ * device for ops/pybind11/box_ops.h:173-260 rbbox_iou_3d_pair on the host every step). */
+int fcn_det_loss_tail_rows3(const float *logits, const int64_t *cls_label, const float *center_ref2,
+                            const float *box3d_center, const float *box3d_heading, const float *box3d_size,
+                            const int64_t *size_class, const float *mean_size, int B, int L2,
+                            int num_heading_bin, int num_size_cluster,
+                            float w_box, float w_corner, float w_headreg, float w_sizereg, float iou_thresh,
+                            float *out16, float *dlogits, float *scratch, float *total, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Rotated-box overlap after the heads.  The reference leaves the device for all of
+ * it: numpy loops + boost::geometry polygon clipping on the host.
+ * ------------------------------------------------------------------------------------------- */
+/* rbbox_iou_3d_pair (ops/pybind11/box_ops.h:173-260, pybind "rbbox_iou_3d_pair"; call site models/det_base.py:495):
+ * corners1/corners2 (n,8,3) in the corner order of get_box3d_corners_helper -> out2 (n,2) = [BEV IoU, 3-D IoU]. */
+int fcn_box3d_iou_pair_f32(const float *corners1, const float *corners2, int n, float *out2, void *stream);
+/* The per-frustum decode loop of train/test_net_det.py:254-293 on the row-major logits (B*L2, ld) of
+ * fcn_convnet_forward (cols 0..1 cls, 2.. reg): method 1 ('nms'): every position with p_bg < p_fg, or the arg-max of p_fg
+ * when a frustum has none; method 0 ('top'): the arg-max only.  Arg-max heading bin / size cluster decode, centre =
+ * offset + center_ref2 (B,3,L2), from_prediction_to_label_format (datasets/provider_sample.py:375-387) with rot_angle (B),
+ * ref_center (B,3) or NULL (zeros), rgb_prob (B) or NULL (ones).
+ *   dets (B*L2, 8) = tx, ty, tz, l, w, h, ry, score (every row written); valid (B*L2) = selected and h,w,l >= 0.01. */
+int fcn_decode_detections(const float *logits, int ld, const float *center_ref2, const float *mean_size,
+                          const float *rot_angle, const float *ref_center, const float *rgb_prob, int B, int L2,
+                          int num_heading_bin, int num_size_cluster, int method, float *dets, int32_t *valid,
+                          void *stream);
+/* rotate_nms_3d_cc (ops/pybind11/rbbox_iou.py:294-311) -> rotate_non_max_suppression_3d_cpu (ops/pybind11/nms_cpu.h:148-240)
+ * for num_groups independent detection sets at once (one per (frame, class), train/test_net_det.py:126-152): dets rows are
+ * organised in units of rows_per_unit consecutive rows (one frustum each), unit_group (num_units) in [0, num_groups) assigns
+ * units to groups, valid (rows) or NULL marks the candidate rows.  Greedy in descending score, suppress when the rotated
+ * 3-D IoU >= thresh.  keep (num_groups, top_k): row indices in keep order; keep_cnt (num_groups): count, or -1 when a group
+ * holds more than 4096 candidates (FCN_E_LIMIT condition reported per group, the other groups are still processed). */
+int fcn_rotate_nms_3d(const float *dets, const int32_t *valid, const int32_t *unit_group, int num_units, int rows_per_unit,
+                      int num_groups, float thresh, int top_k, int32_t *keep, int32_t *keep_cnt, void *stream);
 
 /* Measurement aid: stores the device's constant-rate wall clock (100 MHz ticks) into *slot, in stream order. */
 int fcn_stamp(uint64_t *slot, void *stream);

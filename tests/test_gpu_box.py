@@ -1,0 +1,199 @@
+"""-m gpu: the rotated-box kernels (csrc/box_iou.hip) through the C-ABI against the oracle
+(oracle/box_ref.py) and the fixtures generated from the reference's python (tests/golden/make_golden_iou.py)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, golden_inputs, golden_state_dict
+from oracle import box_ref, det_ref
+from frustum_convnet_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_iou_pair_matches_golden():
+    from frustum_convnet_amd import detect
+    g = load_golden("box_iou_pairs")
+    a, b, ref = g["boxes_a"], g["boxes_b"], g["ious"]
+    exp = box_ref.iou_pair(box_ref.boxes3d2corners(a), box_ref.boxes3d2corners(b))      # == reference where it is finite
+    ok = np.isfinite(ref[:, 0])
+    assert np.abs(exp[ok] - ref[ok]).max() < 1e-9
+    ca = torch.from_numpy(box_ref.boxes3d2corners(a).astype(np.float32)).cuda()
+    cb = torch.from_numpy(box_ref.boxes3d2corners(b).astype(np.float32)).cuda()
+    got = detect.box3d_iou_pair(ca, cb).cpu().numpy()
+    print("iou pair max abs diff %.3e" % np.abs(got - exp).max())
+    assert np.abs(got - exp).max() < 5e-5
+    assert got.shape == (len(a), 2) and detect.box3d_iou_pair(ca[:0], cb[:0]).shape == (0, 2)
+
+
+def _pad_units(dets, rows):
+    n = len(dets)
+    nu = (n + rows - 1) // rows
+    out = np.zeros((nu * rows, 8), dtype=np.float32)
+    out[:n] = dets
+    valid = np.zeros(nu * rows, dtype=np.int32)
+    valid[:n] = 1
+    return out, valid, nu
+
+
+def test_rotate_nms_matches_reference_keep_lists():
+    from frustum_convnet_amd import detect
+    g = load_golden("box_nms_cases")
+    rows = 16
+    all_d, all_v, ug, bases, thr = [], [], [], [], None
+    for c in range(int(g["ncase"])):
+        d, v, nu = _pad_units(g["dets%d" % c].astype(np.float32), rows)
+        bases.append(sum(len(x) for x in all_d))
+        all_d.append(d); all_v.append(v); ug += [c] * nu
+    # one launch per threshold group; thresholds differ per case, so run case by case AND all cases that share 0.1 together
+    for c in range(int(g["ncase"])):
+        d, v, nu = _pad_units(g["dets%d" % c].astype(np.float32), rows)
+        keep, cnt = detect.rotate_nms_3d(torch.from_numpy(d).cuda(), torch.from_numpy(v).cuda(),
+                                         torch.zeros(nu, dtype=torch.int32), rows, 1, float(g["thr%d" % c]))
+        got = keep[0, :int(cnt[0])].cpu().tolist()
+        assert got == [int(x) for x in g["keep%d" % c]], (c, got, g["keep%d" % c])
+    same = [c for c in range(int(g["ncase"])) if abs(float(g["thr%d" % c]) - 0.1) < 1e-12]
+    d = np.concatenate([all_d[c] for c in same]); v = np.concatenate([all_v[c] for c in same])
+    ugs, off, base = [], 0, {}
+    for gi, c in enumerate(same):
+        base[c] = off
+        ugs += [gi] * (len(all_d[c]) // rows)
+        off += len(all_d[c])
+    # interleave an unrelated group id order to check the gather: reverse the group numbering
+    G = len(same)
+    ugs = [G - 1 - x for x in ugs]
+    keep, cnt = detect.rotate_nms_3d(torch.from_numpy(d).cuda(), torch.from_numpy(v).cuda(),
+                                     torch.tensor(ugs, dtype=torch.int32), rows, G, 0.1, top_k=5)
+    for gi, c in enumerate(same):
+        exp = [int(x) + base[c] for x in g["keep%d" % c]][:5]
+        got = keep[G - 1 - gi, :int(cnt[G - 1 - gi])].cpu().tolist()
+        assert got == exp, (c, got, exp)
+
+
+def test_decode_matches_oracle():
+    from frustum_convnet_amd import detect
+    rng = np.random.default_rng(5)
+    B, L2, nb, ns = 6, 37, 12, 3
+    nc = 3 + 2 * nb + 4 * ns
+    logits = np.zeros((B * L2, 64), dtype=np.float32)
+    logits[:, :2 + nc] = rng.normal(0, 1.0, (B * L2, 2 + nc)).astype(np.float32)
+    logits[2 * L2:3 * L2, 0] = 3.0; logits[2 * L2:3 * L2, 1] = rng.normal(-3, 0.3, L2)      # frustum 2: no foreground
+    logits[5, 2 + 3 + 2 * nb + ns:2 + nc] = -1.0                                             # row 5: zero-size box (filtered)
+    ref2 = rng.normal(0, 1, (B, 3, L2)).astype(np.float32) + np.array([0, 1, 20], dtype=np.float32)[None, :, None]
+    mean_size = det_ref.MEAN_SIZE.astype(np.float32)
+    rot = rng.uniform(-0.5, 0.5, B).astype(np.float32)
+    refc = rng.normal(0, 1, (B, 3)).astype(np.float32)
+    rgb = rng.uniform(0, 1, B).astype(np.float32)
+    for method in ("nms", "top"):
+        dets, valid = detect.decode_detections(torch.from_numpy(logits).cuda(), torch.from_numpy(ref2).cuda(),
+                                               torch.from_numpy(mean_size).cuda(), torch.from_numpy(rot).cuda(),
+                                               torch.from_numpy(refc).cuda(), torch.from_numpy(rgb).cuda(), nb, ns, method)
+        dets, valid = dets.cpu().numpy(), valid.cpu().numpy()
+        for b in range(B):
+            rows = logits[b * L2:(b + 1) * L2].astype(np.float64)
+            e = np.exp(rows[:, :2] - rows[:, :2].max(1, keepdims=True)); probs = e / e.sum(1, keepdims=True)
+            o = rows[:, 2:2 + nc]
+            per = 2 * np.pi / nb
+            ah = np.argmax(o[:, 3:3 + nb], 1); a_s = np.argmax(o[:, 3 + 2 * nb:3 + 2 * nb + ns], 1)
+            ang = ah * per + o[np.arange(L2), 3 + nb + ah] * per / 2
+            ang = np.where(ang > np.pi, ang - 2 * np.pi, ang)
+            sr = np.stack([o[np.arange(L2), 3 + 2 * nb + ns + 3 * a_s + j] for j in range(3)], 1)
+            size = sr * mean_size[a_s] + mean_size[a_s]
+            ctr = o[:, :3] + ref2[b].T
+            # the oracle decides on float32 probabilities like the reference (torch softmax in fp32)
+            p32 = torch.softmax(torch.from_numpy(logits[b * L2:(b + 1) * L2, :2]), -1).numpy()
+            exp_rows, idx = box_ref.decode_detections(p32.astype(np.float64), ctr, ang, size, float(rot[b]), refc[b].astype(np.float64),
+                                                      float(rgb[b]), method)
+            got_idx = np.nonzero(valid[b * L2:(b + 1) * L2])[0].tolist()
+            assert got_idx == idx, (method, b, got_idx, idx)
+            if idx:
+                assert np.abs(dets[b * L2 + np.array(idx)] - exp_rows).max() < 2e-4, (method, b)
+    assert valid[5] == 0
+
+
+@pytest.mark.parametrize("case", ["car_b4_n512", "people_b2_n512"])
+def test_loss_tail_iou_metrics_match_oracle(case):
+    from test_gpu_model import _model
+    from frustum_convnet_amd.config import cfg
+    g = load_golden(case)
+    data_np = golden_inputs(g)
+    data = synth.to_torch(data_np, "cuda")
+    m = _model(g)
+    m.train()
+    losses, metrics = m(data)
+    cls, reg = m.last_logits
+    B, _, L2 = reg.shape
+    reg_rows = reg.detach().permute(0, 2, 1).reshape(B * L2, -1).cpu().numpy()
+    ref2_rows = data_np["center_ref2"].transpose(0, 2, 1).reshape(B * L2, 3)
+    lab = data_np["cls_label"].reshape(-1)
+    fg = [(int(r), int(r // L2)) for r in np.nonzero(lab == 1)[0]]
+    e2, e3, et = box_ref.iou_metrics(reg_rows, ref2_rows, fg, data_np["box3d_center"], data_np["box3d_heading"].reshape(-1),
+                                     data_np["box3d_size"], det_ref.MEAN_SIZE, thresh=cfg.IOU_THRESH)
+    got = [float(metrics[k]) for k in ("IoU_2D", "IoU_3D", "IoU_" + str(cfg.IOU_THRESH))]
+    print(case, "IoU metrics", got, (e2, e3, et), "nfg", float(m.last_num_fg))
+    assert abs(got[0] - e2) < 1e-4 and abs(got[1] - e3) < 1e-4 and abs(got[2] - et) < 1e-6
+    assert int(float(m.last_num_fg)) == len(fg)
+
+
+def test_all_background_batch_is_finite():
+    """a batch without a foreground row must not produce NaN (the reference asserts, det_base.py:416)."""
+    from test_gpu_model import _model
+    g = load_golden("car_b4_n512")
+    data_np = golden_inputs(g)
+    data_np["cls_label"][:] = 0
+    data = synth.to_torch(data_np, "cuda")
+    m = _model(g)
+    m.train()
+    losses, metrics = m(data)
+    losses["total_loss"].backward()
+    vals = {k: float(v) for k, v in losses.items()}
+    assert all(np.isfinite(v) for v in vals.values()), vals
+    assert vals["center_loss"] == 0.0 and vals["corners_loss"] == 0.0 and float(m.last_num_fg) == 0.0
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+    assert float(metrics["IoU_3D"]) == 0.0
+
+
+def test_detect_pipeline_matches_oracle():
+    from test_gpu_model import _model
+    g = load_golden("car_b4_n512")
+    data_np = golden_inputs(g)
+    data = synth.to_torch(data_np, "cuda")
+    m = _model(g)
+    m.eval()
+    B = data["point_cloud"].shape[0]
+    rot = torch.linspace(-0.3, 0.3, B).cuda().view(B, 1)
+    dd = dict(data); dd["rot_angle"] = rot
+    ug = torch.tensor([0, 0, 1, 1], dtype=torch.int32)
+    dets, valid, keep, cnt = m.detect(dd, unit_group=ug, num_groups=2, method="nms", thresh=0.1)
+    L2 = data["center_ref2"].shape[2]
+    dets_c, valid_c = dets.cpu().numpy().astype(np.float64), valid.cpu().numpy()
+    for gi in range(2):
+        rows = np.nonzero((np.repeat(ug.numpy(), L2) == gi) & (valid_c != 0))[0]
+        exp = [int(rows[k]) for k in box_ref.cube_nms(dets_c[rows], 0.1)]
+        got = keep[gi, :int(cnt[gi])].cpu().tolist()
+        assert got == exp, (gi, got, exp)
+    # 'top': one candidate per frustum, all kept
+    dets, valid, keep, cnt = m.detect(dd, method="top")
+    assert valid.view(B, L2).sum(1).cpu().tolist() == [1] * B and cnt.cpu().tolist() == [1] * B
+
+
+def test_backward_split_equals_backward():
+    from test_gpu_model import _model
+    g = load_golden("car_b4_n512")
+    data = synth.to_torch(golden_inputs(g), "cuda")
+    m = _model(g)
+    m.train()
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    losses, _ = m(data)
+    losses["total_loss"].backward()
+    ref = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.load_state_dict(sd0)
+    m.zero_grad(set_to_none=True)
+    m.split_backward = True
+    called = []
+    losses, _ = m(data)
+    m.backward_split(losses["total_loss"], between=lambda: called.append(
+        all(p.grad is not None for n, p in m.named_parameters() if not n.startswith("feat_net."))))
+    assert called == [True]
+    for n, p in m.named_parameters():
+        assert torch.equal(p.grad, ref[n]), n

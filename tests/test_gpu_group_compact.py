@@ -1,0 +1,113 @@
+"""-m gpu: the fused front (fcn_pn_group_compact: grouping + compaction + tile list + input moments + BN1 of all scales in
+one launch, no int64 idx) against (1) the entry-space emulation applied to the ORACLE's idx (tests/entry_ref.compact over
+oracle/grouping.py) -- exact -- and (2) the unfused C-ABI path fcn_query_depth_point_f32 + fcn_pn_compact + BN1 finalise."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import entry_ref
+from oracle import grouping
+from frustum_convnet_amd import synth
+
+pytestmark = pytest.mark.gpu
+NS = (32, 64, 64, 128)
+MLP = ((64, 64, 128), (64, 64, 128), (128, 128, 256), (256, 256, 512))
+
+
+def _params(C, seed):
+    g = torch.Generator().manual_seed(seed)
+    W = [torch.randn(C[0], 3, generator=g) * 0.5, torch.randn(C[1], C[0], generator=g) * 0.1, torch.randn(C[2], C[1], generator=g) * 0.1]
+    gam = [torch.rand(c, generator=g) + 0.5 for c in C]
+    bet = [torch.randn(c, generator=g) * 0.1 for c in C]
+    plist = []
+    for i in range(3):
+        plist += [W[i].cuda(), gam[i].cuda(), bet[i].cuda()]
+    bufs = ([torch.zeros(c).cuda() for c in C], [torch.ones(c).cuda() for c in C],
+            [torch.zeros((), dtype=torch.int64).cuda() for c in C])
+    return plist, bufs
+
+
+@pytest.mark.parametrize("B,N,strides,variant", [(4, 512, (0.25, 0.5, 1.0, 2.0), "car"), (3, 700, (0.1, 0.2, 0.4, 0.8), "uniform"),
+                                                (32, 1024, (0.25, 0.5, 1.0, 2.0), "car"), (2, 130, (2.0, 2.0, 4.0, 8.0), "car")])
+def test_group_compact_matches_oracle_and_unfused(B, N, strides, variant):
+    from frustum_convnet_amd import pointnet_fused as pf, _native
+    data = synth.make_batch(B, N, strides=strides, seed=77, variant=variant, tilt=(0.01, 0.05))
+    pc = torch.from_numpy(data["point_cloud"]).cuda()
+    pools = [pf.WorkspacePool() for _ in range(4)]
+    handles, unf = [], []
+    for s in range(4):
+        ref = torch.from_numpy(data["center_ref%d" % (s + 1)]).cuda()
+        plist, bufs = _params(MLP[s], 10 + s)
+        cfgt = (float(strides[s]), NS[s], True, 1e-5, 0.1, False, True)
+        handles.append(pf._acquire(pools[s], cfgt, pc, ref, None, bufs, plist, False))
+        plist2, bufs2 = _params(MLP[s], 10 + s)
+        unf.append((pf._acquire(pools[s], cfgt, pc, ref, None, bufs2, plist2, False), ref, bufs2, bufs))
+    for rep in range(2):                # twice: the arrival counters must be left at zero
+        pf.group_compact(handles, pc)
+    torch.cuda.synchronize()
+    L = _native.lib()
+    for s in range(4):
+        h = handles[s]
+        K, Lw = NS[s], h["desc"].L
+        ref_np = data["center_ref%d" % (s + 1)]
+        # (1) oracle idx -> entry-space emulation: exact
+        idx_o, cnt_o = grouping.query_depth_point(float(strides[s]), K, data["point_cloud"], ref_np)
+        c = entry_ref.compact(torch.from_numpy(idx_o), torch.from_numpy(cnt_o), torch.from_numpy(data["point_cloud"]),
+                              torch.from_numpy(ref_np), K)
+        ws = h["ws"]
+        assert torch.equal(ws.cnt.cpu(), torch.from_numpy(cnt_o)), s
+        assert torch.equal(ws.woff.cpu(), c["woff"]), s
+        ent, ewin = ws.ent.cpu(), ws.ewin.cpu()
+        for b in range(B):
+            n = int(c["nent"][b])
+            assert torch.equal(ent[b, :n], c["ent"][b, :n]), (s, b)
+            assert torch.equal(ewin[b, :n], c["ewin"][b, :n]), (s, b)
+        # (2) unfused C-ABI path on a second workspace
+        hu, ref, bufs_u, bufs_f = unf[s]
+        idx, cnt = pf.query_depth_point(float(strides[s]), K, pc, ref)
+        _native.check(L.fcn_pn_compact(ctypes.byref(hu["desc"]), pc.data_ptr(), ref.data_ptr(), idx.data_ptr(), cnt.data_ptr(),
+                                       ctypes.byref(hu["ws"].c), _native.current_stream(pc.device)), "fcn_pn_compact")
+        feat_u = pf._run_forward(hu, cnt, idx)[0]
+        torch.cuda.synchronize()
+        wu = hu["ws"]
+        nt = int(wu.tiles[0])
+        assert int(ws.tiles[0]) == nt and torch.equal(ws.tiles[4:4 + nt], wu.tiles[4:4 + nt]), s
+        assert int(ws.tiles[1]) == 0 and float(ws.gmom.view(B, 12)[:, 10].abs().max()) == 0.0
+        mom_f, mom_u = ws.stat[:10].cpu().numpy(), wu.stat[:10].cpu().numpy()
+        assert np.allclose(mom_f, mom_u, rtol=1e-12, atol=1e-9), (s, mom_f, mom_u)
+        C1 = MLP[s][0]
+        assert torch.allclose(ws.bn[:4 * C1], wu.bn[:4 * C1], rtol=1e-5, atol=1e-6), s
+        # running statistics of conv1's BN: updated twice by the fused path (two launches), once by the unfused one
+        # (from zero: 0.1 * mean once, 0.9 * 0.1 * mean + 0.1 * mean = 0.19 * mean twice)
+        assert torch.allclose(bufs_f[0][0], 1.9 * bufs_u[0][0], rtol=1e-4, atol=1e-6), s
+        assert int(bufs_f[2][0]) == 2 and int(bufs_u[2][0]) == 1
+        # and the forward on the grouped workspace gives the same pooled features
+        feat_f = pf._run_forward(h, ws.cnt, pf._empty_idx(pc.device))[0]
+        torch.cuda.synchronize()
+        assert torch.allclose(feat_f, feat_u, rtol=1e-5, atol=1e-6), (s, float((feat_f - feat_u).abs().max()))
+
+
+def test_fused_front_model_matches_unfused():
+    """Whole model: fused_front on/off give the same logits (both against the golden bar) and the same gradients."""
+    from test_gpu_model import _model
+    from helpers import load_golden, golden_inputs
+    g = load_golden("car_b4_n512")
+    data = synth.to_torch(golden_inputs(g), "cuda")
+    outs = []
+    for ff in (True, False):
+        m = _model(g)
+        m.feat_net.fused_front = ff
+        m.train()
+        losses, _ = m(data)
+        losses["total_loss"].backward()
+        outs.append((torch.cat([t.flatten() for t in m.last_logits]).detach(), {n: p.grad.clone() for n, p in m.named_parameters()},
+                     {k: v.clone() for k, v in m.state_dict().items()}))
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-5
+    for n in outs[0][1]:
+        a, b = outs[0][1][n], outs[1][1][n]
+        assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-7, n
+    for k in outs[0][2]:
+        if "running" in k or k.endswith("num_batches_tracked"):
+            assert torch.allclose(outs[0][2][k].float(), outs[1][2][k].float(), rtol=1e-4, atol=1e-6), k

@@ -157,6 +157,8 @@ def test_loss_tail_matches_oracle_on_cpu():
     g = load_golden("car_b4_n512")
     data = synth.to_torch(golden_inputs(g))
     m = det_base.PointNetDet(3, num_vec=3)
+    m.fused_fcn = False            # explicit opt-in to the torch-op formulation of the tail (A/B path; the fused paths
+    m.fused_loss = False           # refuse CPU tensors)
     cls_raw = torch.from_numpy(g["cls_train"]).requires_grad_(True)
     reg_raw = torch.from_numpy(g["reg_train"]).requires_grad_(True)
     # drive only the tail: replace the feature path by fixed logits
