@@ -1,21 +1,27 @@
 #!/usr/bin/env python
 """bench.py -- frustums/sec of the hot path's training step (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--cfg car|people|refine] [--precision split|f32|bf16]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
 
-One step = the reference's train-loop body on one batch (train/train_net_det.py:120-128): forward of
-PointNetDet in train mode (grouping, 4 PointNet scales, FCN, heads, loss) + backward (+ gradient all-reduce
-over RCCL when N > 1) + Adam update, on a synthetic KITTI-car-shaped batch already resident in HBM
-(B = 32 frustums per GPU, N = 1024 points, strides (0.25,0.5,1,2) -> L = (280,140,70,35)); weak scaling.
-The step is captured once into a hipGraph and replayed (no host work in the timed region); --eager disables it.
+One step = the reference's train-loop body on one batch (train/train_net_det.py:120-133): forward of PointNetDet in train
+mode (grouping, 4 PointNet scales, FCN, heads, loss + metrics) + backward (+ gradient all-reduce over RCCL when N > 1) +
+Adam update, on a synthetic batch already resident in HBM (default: KITTI-car-shaped, B = 32 frustums per GPU, N = 1024
+points, strides (0.25,0.5,1,2) -> L = (280,140,70,35)); weak scaling.  The step is captured into hipGraph(s) and replayed
+(no host work in the timed region besides the replays and, for N > 1, the collective calls); --eager disables it.
+
+Timing: W warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize; when K steps take less than --min-time
+seconds (default 1 s) the K-step window is repeated back to back (`rounds` of K steps each, all inside ONE bracket) and
+ms_per_step is the mean over rounds * K steps -- a 40 ms window says little about a GPU that clocks by power budget.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline     -- the dominant kernel (conv GEMM, fp32 32x32x2 MFMA) timed live with HIP events
+  roofline     -- the top-time kernel family of the step, timed LIVE (HIP events around its C-ABI entry point, on the stream
+                  it is launched on, eager launches of the same step), with a `kernels` table for every entry point
   cpu_baseline -- the CPU oracle (oracle/det_ref.py + oracle/qdp_ref.c) timed on the host cores, N=1 only
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -27,9 +33,18 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+# MI355X_MICROARCH.md: dense MFMA peaks.  fp32 MFMA = the fp32 vector rate; 16-bit MFMA 2.5 PFLOP/s dense.
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_16BIT_MFMA_TFLOPS = 2500.0
+PEAK_HBM_TBPS = 8.0
 NSAMPLE = (32, 64, 64, 128)
-MLPS = ((64, 64, 128), (64, 64, 128), (128, 128, 256), (256, 256, 512))
+
+CFGS = {
+    # name: (yaml, strides, z_range of the synthetic frustums (None: 0..70 m), default N)
+    "car": ("cfgs/det_sample.yaml", (0.25, 0.5, 1.0, 2.0), None, 1024),
+    "people": ("cfgs/det_sample_people.yaml", (0.1, 0.2, 0.4, 0.8), None, 1024),
+    "refine": ("cfgs/refine_car.yaml", (0.1, 0.2, 0.4, 0.8), (-1.0, 1.0), 512),
+}
 
 
 def parse():
@@ -38,9 +53,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32, help="frustums per GPU")
-    ap.add_argument("--npoint", type=int, default=1024)
+    ap.add_argument("--npoint", type=int, default=None)
+    ap.add_argument("--cfg", choices=sorted(CFGS), default="car")
+    ap.add_argument("--min-time", type=float, default=1.0, help="minimum length of the timed region in seconds")
     ap.add_argument("--eager", action="store_true", help="no hipGraph capture")
     ap.add_argument("--no-optim", action="store_true", help="time forward+backward(+all-reduce) only")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: one all-reduce after the whole backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-batch", type=int, default=32)
@@ -49,122 +67,164 @@ def parse():
     return ap.parse_args()
 
 
-def build_model(device):
-    from frustum_convnet_amd.config import cfg, reset_cfg
+def build_model(device, cfg_name="car"):
+    from frustum_convnet_amd.config import reset_cfg, merge_cfg_from_file
     from frustum_convnet_amd import det_base, synth
-    reset_cfg()   # defaults == cfgs/det_sample.yaml hot-path keys: HEIGHT_HALF/STRIDE (0.25,0.5,1,2), KITTI
+    reset_cfg()
+    merge_cfg_from_file(os.path.join(ROOT, CFGS[cfg_name][0]))
     model = det_base.PointNetDet(3, num_vec=3, num_classes=2)
     synth.fill_state_dict(model.state_dict(), seed=7)
     return model.to(device).train()
 
 
-def roofline_probe(model, data, reps=20):
-    """Times ONLY the conv GEMM launches (layer 2 and 3 of each scale) with HIP events on the current stream
-    and returns the roofline object of the dominant kernel template (fwd_gemm_kernel, fp32 MFMA)."""
-    from frustum_convnet_amd import _native, pointnet_fused as pf
-    L = _native.lib()
-    dev = data["point_cloud"].device
-    xyz = data["point_cloud"][:, :3].contiguous()
-    nets = (model.feat_net.pointnet1, model.feat_net.pointnet2, model.feat_net.pointnet3, model.feat_net.pointnet4)
-    tot_ms = 0.0
-    tot_flops_exec = 0.0
-    tot_flops_dense = 0.0
-    tot_bytes_alg = 0.0
-    launches = 0
-    per = []
-    for s, net in enumerate(nets):
-        ref = data["center_ref%d" % (s + 1)].contiguous()
-        params, bufs = net._param_pack()
-        cfgt = (float(net.dist), int(net.nsample), True, 1e-5, 0.1)
-        with torch.no_grad():
-            feat, idx, cnt, ws, desc, keep = pf._forward_impl(net._pool, cfgt, xyz, ref, None, bufs, params, False)
-        pstruct = pf._params_struct(keep[0], keep[1], keep[2], [None] * 3, [None] * 3, [None] * 3)
-        E = int(ws.woff[:, -1].sum().item())
-        B, Lw, K = desc.B, desc.L, desc.K
-        C1, C2, C3 = desc.C1, desc.C2, desc.C3
-        for layer, cin, cout in ((2, C1, C2), (3, C2, C3)):
-            st = _native.current_stream(dev)
-            for _ in range(3):
-                _native.check(L.fcn_pn_conv_fwd(ctypes.byref(desc), ctypes.byref(pstruct), ctypes.byref(ws.c), layer, 1, st),
-                              "fcn_pn_conv_fwd")
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                L.fcn_pn_conv_fwd(ctypes.byref(desc), ctypes.byref(pstruct), ctypes.byref(ws.c), layer, 1, st)
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / reps
-            fl_exec = 2.0 * E * cin * cout
-            fl_dense = 2.0 * B * Lw * K * cin * cout
-            # compulsory bytes of the launch: operand rows once (conv2 reads the 16-B entries, conv3 the previous
-            # pre-BN output), result rows once, the weight matrix once
-            tot_bytes_alg += E * (16.0 if layer == 2 else 4.0 * cin) + 4.0 * E * cout + 4.0 * cin * cout
-            per.append({"scale": s + 1, "layer": layer, "ms": round(ms, 5), "rows": E,
-                        "tflops_executed": round(fl_exec / ms / 1e9, 2)})
-            tot_ms += ms
-            tot_flops_exec += fl_exec
-            tot_flops_dense += fl_dense
-            launches += 1
-        net._pool.release(ws)
-    achieved = tot_flops_exec / tot_ms / 1e9          # TFLOP/s over the 8 launches of one step
-    return {"bound": "mfma", "kernel": "fwd_gemm_kernel (conv2/conv3 1x1 GEMMs, fp32 v_mfma_f32_32x32x2)",
-            "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": _pmc_traffic(),
-            "bytes_per_launch_algorithmic": tot_bytes_alg / launches,
-            "flops_per_launch_executed": tot_flops_exec / launches,
-            "flops_per_launch_dense_equivalent": tot_flops_dense / launches,
-            "avg_launch_ms": round(tot_ms / launches, 5), "launches_per_step": launches, "per_launch": per}
-
-
-def grouping_roofline(model, data, reps=50):
-    """The grouping kernel alone (SURVEY section 8d regime i, HBM-bound scan): the four fcn_query_depth_point_f32 launches of
-    one step timed with HIP events on the launch stream; algorithmic bytes = z row + centres + int64 idx + cnt."""
-    from frustum_convnet_amd.query_depth_point import query_depth_point
-    xyz = data["point_cloud"][:, :3].contiguous()
-    B, _, N = xyz.shape
-    nets = (model.feat_net.pointnet1, model.feat_net.pointnet2, model.feat_net.pointnet3, model.feat_net.pointnet4)
-    refs = [data["center_ref%d" % (s + 1)].contiguous() for s in range(4)]
-    nbytes = 0.0
-    for net, ref in zip(nets, refs):
-        Lw = ref.shape[2]
-        nbytes += B * (4.0 * N + 4.0 * Lw + 8.0 * Lw * net.nsample + 4.0 * Lw)
-
-    def run():
-        for net, ref in zip(nets, refs):
-            query_depth_point(net.dist, net.nsample, xyz, ref)
-    for _ in range(5):
-        run()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    tbps = nbytes / (ms * 1e-3) / 1e12
-    return {"bound": "hbm", "kernel": "qdp_kernel x4 strides (eager launches, includes launch gaps)",
-            "bytes_per_step_algorithmic": nbytes, "ms_per_step": round(ms, 5), "achieved": round(tbps, 4), "peak": 8.0,
-            "unit": "TB/s", "frac": round(tbps / 8.0, 5)}
-
-
-def _pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 --pmc pass, if one exists."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(p):
-        try:
-            return json.load(open(p)).get("bytes_per_launch")
-        except Exception:
-            return None
-    return None
-
-
-def cpu_baseline(batch, npoint):
-    """The CPU oracle (port of the reference dataflow: dense (B,C,L,K) tensors, torch-CPU conv/BN + C grouping)
-    timed on this host: forward + backward of one batch."""
-    from oracle import det_ref
+def make_data(cfg_name, batch, npoint, seed, device):
     from frustum_convnet_amd import synth
+    _, strides, z_range, _ = CFGS[cfg_name]
+    return synth.to_torch(synth.make_batch(batch, npoint, strides=strides, seed=seed, variant="car", tilt=(0.01, 0.05),
+                                           z_range=z_range), device)
+
+
+# ------------------------------------------------------------------------------------------------
+# Live per-entry-point timing: HIP events recorded on the launch stream right around each C-ABI call of an EAGER step.
+# Every launch of a call is enqueued back to back on that stream, so the interval is the GPU time of the call's kernels.
+TIMED = ("fcn_pn_group_compact", "fcn_pn_forward", "fcn_convnet_pack", "fcn_convnet_forward2", "fcn_det_loss_tail_rows3",
+         "fcn_convnet_backward", "fcn_pn_backward2", "fcn_adam_step_f32")
+
+
+class CallTimer:
+    def __init__(self, lib):
+        self.lib, self.orig, self.rec = lib, {}, []
+
+    def __enter__(self):
+        for name in TIMED:
+            fn = getattr(self.lib, name)
+            self.orig[name] = fn
+
+            def wrap(*a, _fn=fn, _name=name):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = _fn(*a)
+                e1.record()
+                self.rec.append((_name, e0, e1, a))
+                return rc
+            setattr(self.lib, name, wrap)
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self.orig.items():
+            setattr(self.lib, name, fn)
+
+
+def fcn_flops(B, Ls, nvec=3):
+    """MACs of ConvFeatNet + heads x 2."""
+    L1, L2, L3, L4 = Ls
+    macs = ((128 + nvec) * 128 * 3 * L1 + 2 * 128 * 128 * 3 * L2 + (256 + nvec) * 128 * L2 + 128 * 256 * 3 * L3 +
+            256 * 256 * 3 * L3 + (512 + nvec) * 256 * L3 + 256 * 512 * 3 * L4 + 512 * 512 * 3 * L4 + (1024 + nvec) * 512 * L4 +
+            128 * 256 * L2 + 256 * 256 * 2 * L3 + 512 * 256 * 4 * L4 + 768 * 41 * L2)
+    return 2.0 * macs * B
+
+
+def kernel_table(model, state, data, optim, prec, reps=5):
+    """Per C-ABI entry point: launches per step, live GPU time, executed FLOPs / algorithmic bytes, fraction of its roof."""
+    from frustum_convnet_amd import _native
+    lib = _native.lib()
+    B = data["point_cloud"].shape[0]
+    Ls = [data["center_ref%d" % i].shape[2] for i in (1, 2, 3, 4)]
+    agg = {}
+    for rep in range(reps + 1):
+        with CallTimer(lib) as ct:
+            losses, _ = model(data)
+            losses["total_loss"].backward()
+            if optim:
+                state.adam_step()
+            torch.cuda.synchronize()
+        if rep == 0:
+            continue                                     # first pass: allocator / event warm-up
+        for name, e0, e1, a in ct.rec:
+            key = name
+            if name in ("fcn_pn_forward", "fcn_pn_backward2"):
+                d = a[0]._obj                      # the PnDesc behind ctypes.byref()
+                key = "%s[L=%d,K=%d,C=%d-%d-%d]" % (name, d.L, d.K, d.C1, d.C2, d.C3)
+            r = agg.setdefault(key, {"ms": 0.0, "calls": 0})
+            r["ms"] += e0.elapsed_time(e1)
+            r["calls"] += 1
+    # executed rows per scale (live entries) from the workspaces of the last forward
+    nets = (model.feat_net.pointnet1, model.feat_net.pointnet2, model.feat_net.pointnet3, model.feat_net.pointnet4)
+    E = {}
+    for net, Lw in zip(nets, Ls):
+        for lst in net._pool.free.values():
+            for ws in lst:
+                if ws.key[2] == Lw and ws.key[3] == net.nsample:
+                    E[(Lw, net.nsample)] = int(ws.woff[:, -1].sum().item())
+    peak_mm = {"split": PEAK_16BIT_MFMA_TFLOPS / 3.0, "f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_16BIT_MFMA_TFLOPS}[prec]
+    rows = []
+    ff = fcn_flops(B, Ls)
+    nparam = state.numel
+    N = data["point_cloud"].shape[2]
+    for key, r in agg.items():
+        ms = r["ms"] / reps
+        calls = r["calls"] // reps
+        row = {"entry": key, "calls_per_step": calls, "ms_per_step": round(ms, 5)}
+        flops = nbytes = None
+        if key.startswith("fcn_pn_forward") or key.startswith("fcn_pn_backward2"):
+            Lw, K = int(key.split("L=")[1].split(",")[0]), int(key.split("K=")[1].split(",")[0])
+            C1, C2, C3 = [int(v) for v in key.split("C=")[1].rstrip("]").split("-")]
+            e = E.get((Lw, K), 0)
+            fwd = 2.0 * e * (C1 * C2 + C2 * C3)
+            flops = fwd if "forward" in key else 2.0 * fwd
+            row["rows_executed"] = e
+        elif key == "fcn_convnet_forward2":
+            flops = ff
+        elif key == "fcn_convnet_backward":
+            flops = 2.0 * ff
+        elif key == "fcn_adam_step_f32":
+            nbytes = 7.0 * 4.0 * nparam
+        elif key == "fcn_pn_group_compact":
+            # algorithmic bytes of the fused front: z row + centres in, entry rows (16 B + 4 B window id) + offsets + counts out
+            nbytes = sum(B * (4.0 * N + 12.0 * Lw) + 20.0 * E.get((Lw, net.nsample), 0) + B * 8.0 * Lw
+                         for net, Lw in zip(nets, Ls))
+        if flops is not None:
+            tf = flops / (ms * 1e-3) / 1e12
+            row.update(bound="mfma", flops_executed=flops, achieved_tflops=round(tf, 2), frac=round(tf / peak_mm, 4),
+                       frac_of_fp32_mfma_peak=round(tf / PEAK_F32_MFMA_TFLOPS, 4))
+        elif nbytes is not None:
+            tb = nbytes / (ms * 1e-3) / 1e12
+            row.update(bound="hbm", bytes_algorithmic=nbytes, achieved_tbps=round(tb, 4), frac=round(tb / PEAK_HBM_TBPS, 4))
+        rows.append(row)
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return rows, peak_mm
+
+
+def source_hash():
+    """sha256 over the kernel sources: ties committed PMC numbers to the code they were measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "frustum_convnet_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kind):
+    """HBM bytes from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, tools/gpu_traffic.sh) -- only when
+    they were measured on THIS kernel source (source hash recorded next to them); stale numbers are not reported."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(p))
+    except Exception:  # noqa
+        return None, "no profiles/pmc_traffic.json"
+    if d.get("source_hash") != source_hash():
+        return None, "profiles/pmc_traffic.json was measured on other kernel sources (hash %s, now %s)" % (
+            d.get("source_hash"), source_hash())
+    return d.get(kind), None
+
+
+def cpu_baseline(batch, npoint, cfg_name):
+    """The CPU oracle (port of the reference dataflow: dense (B,C,L,K) tensors, torch-CPU conv/BN + C grouping) timed on this
+    host: forward + backward.  Three points: best of 16 / 8 torch threads (3 steps), 1 core, all cores."""
+    from oracle import det_ref
+    from frustum_convnet_amd import synth, det_base
     from frustum_convnet_amd.config import reset_cfg
-    from frustum_convnet_amd import det_base
     reset_cfg()
     m = det_base.PointNetDet(3, num_vec=3, num_classes=2)      # only for the state_dict keys/shapes
     sd = {k: v.clone() for k, v in m.state_dict().items()}
@@ -172,36 +232,51 @@ def cpu_baseline(batch, npoint):
     for k, v in sd.items():
         if v.dtype.is_floating_point and "running" not in k:
             v.requires_grad_(True)
+    _, strides, z_range, _ = CFGS[cfg_name]
+
     def step(b):
-        data = synth.to_torch(synth.make_batch(b, npoint, seed=1234, variant="car", tilt=(0.01, 0.05)))
+        data = synth.to_torch(synth.make_batch(b, npoint, strides=strides, seed=1234, variant="car", tilt=(0.01, 0.05),
+                                               z_range=z_range))
         t0 = time.perf_counter()
-        _, _, losses = det_ref.forward(sd, data, training=True)
+        _, _, losses = det_ref.forward(sd, data, strides, training=True)
         losses["total_loss"].backward()
         return time.perf_counter() - t0
 
-    # The oracle's dense torch-CPU dataflow does not scale with threads (measured on the GPU box's 256-core host: 2.5
-    # frustums/s at 128 threads, 4.1 at 64, 5.2 at 32, 6.0 at 16, 6.3 at 8): time it at 16 and 8 threads and report the
-    # better one, with the thread count used.
     saved = torch.get_num_threads()
+    ncpu = os.cpu_count() or saved
+    budget_t0 = time.perf_counter()
     best = None
     for n in (16, 8):
-        torch.set_num_threads(min(n, saved))
+        torch.set_num_threads(min(n, ncpu))
         step(2)                            # warm-up (thread pools, oneDNN primitives)
-        t = step(batch)
+        ts = [step(batch) for _ in range(3 if time.perf_counter() - budget_t0 < 20 else 1)]
+        t = float(np.median(ts))
         if best is None or t < best[0]:
-            best = (t, torch.get_num_threads())
+            best = (t, torch.get_num_threads(), len(ts))
+    variants = {}
+    torch.set_num_threads(1)
+    b1 = max(1, min(batch, 4))
+    variants["1_core"] = {"value": round(b1 / step(b1), 3), "cores": 1, "sample": "1 step of B=%d" % b1}
+    if time.perf_counter() - budget_t0 < 60:
+        torch.set_num_threads(ncpu)
+        step(2)
+        variants["all_cores"] = {"value": round(batch / step(batch), 3), "cores": ncpu, "sample": "1 step of B=%d" % batch}
     torch.set_num_threads(saved)
-    t, cores = best
+    t, cores, nst = best
     return {"value": round(batch / t, 3), "unit": "frustums/s", "cores": cores, "kind": "port",
-            "sample": "1 train fwd+bwd step of B=%d N=%d (same synthetic car batch shape), fp32, "
-                      "oracle/det_ref.py + oracle/qdp_ref.c, %.2f s, best of 16 / 8 torch threads" % (batch, npoint, t)}
+            "sample": "median of %d train fwd+bwd step(s) of B=%d N=%d (%s cfg, same synthetic batch shape), fp32, "
+                      "oracle/det_ref.py + oracle/qdp_ref.c, %.2f s/step, best of 16 / 8 torch threads (the dense torch-CPU "
+                      "dataflow does not scale further)" % (nst, batch, npoint, cfg_name, t),
+            "variants": variants, "host_cpus": ncpu}
 
 
 def main():
     a = parse()
-    from frustum_convnet_amd import dist as fdist, synth, precision as fprec
+    from frustum_convnet_amd import dist as fdist, precision as fprec
     if a.precision:
         fprec.set_precision(a.precision)
+    prec = fprec.get_precision()
+    npoint = a.npoint or CFGS[a.cfg][3]
     # FCN_BENCH_BACKEND=gloo + FCN_BENCH_ONE_DEVICE=1: rehearsal of the N > 1 path with every rank on GPU 0 (a 1-GPU box
     # cannot form an RCCL communicator); the driver's multi-GPU runs leave both unset.
     one_dev = os.environ.get("FCN_BENCH_ONE_DEVICE", "0") == "1"
@@ -218,27 +293,32 @@ def main():
     dev = torch.device("cuda", local)
 
     from frustum_convnet_amd.train_state import FlatTrainState
-    model = build_model(dev)
+    model = build_model(dev, a.cfg)
     if world > 1:
         fdist.broadcast_state(model, 0)
     # reference optimiser: Adam(lr 1e-3, weight_decay 1e-4), train/train_net_det.py:321-339.  Parameters, gradients and
-    # moments are flat buffers: the backward kernels write the gradients in place, the exchange is one all-reduce and the
-    # step one streaming kernel (capturable: step counter and hyper-parameters live on the device).
+    # moments are flat buffers: the backward kernels write the gradients in place, the exchange is a bucketed all-reduce
+    # and the step one streaming kernel (capturable: step counter and hyper-parameters live on the device).
     state = FlatTrainState(model, lr=1e-3, weight_decay=1e-4, world=world)
     optim = not a.no_optim
-    data = synth.to_torch(synth.make_batch(a.batch, a.npoint, seed=1234 + rank, variant="car", tilt=(0.01, 0.05)), dev)
+    data = make_data(a.cfg, a.batch, npoint, 1234 + rank, dev)
+    overlap = world > 1 and not a.no_overlap and not a.eager
+    model.split_backward = overlap
 
     def fwd_bwd():
         losses, _ = model(data)
-        losses["total_loss"].backward()
+        if model.split_backward:
+            model.backward_split(losses["total_loss"])
+        else:
+            losses["total_loss"].backward()
         return losses["total_loss"]
 
     use_graph = not a.eager
-    graph = None
+    graphs = None
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        for _ in range(3):                     # allocator / workspace / MIOpen find warm-up, outside capture
+        for _ in range(3):                     # allocator / workspace warm-up, outside capture
             loss = fwd_bwd()
             state.allreduce()
             if optim:
@@ -247,45 +327,81 @@ def main():
     torch.cuda.synchronize()
     if use_graph:
         try:
-            graph = torch.cuda.CUDAGraph()
             if world > 1:
                 torch.distributed.barrier()          # no collective in flight while the step is being captured
                 torch.cuda.synchronize()
-            # thread_local: RCCL's watchdog thread may query events while this thread captures
-            with torch.cuda.graph(graph, capture_error_mode="thread_local" if world > 1 else "global"):
-                loss = fwd_bwd()
-                if world == 1 and optim:
-                    state.adam_step()
+            mode = "thread_local" if world > 1 else "global"   # RCCL's watchdog thread may query events meanwhile
+            if overlap:
+                # N > 1: two graphs cut where the FCN gradients are final.  Replay A (forward, loss, FCN backward) -> start
+                # the all-reduce of the [FCN + heads] bucket on RCCL's stream -> replay B (PointNet backward) beside it ->
+                # all-reduce the PointNet bucket -> join -> Adam.
+                gA, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gA, capture_error_mode=mode):
+                    losses, _ = model(data)
+                    loss = losses["total_loss"]
+                    feats, leaves = model._split
+                    model._split = None
+                    loss.backward()
+                with torch.cuda.graph(gB, pool=gA.pool(), capture_error_mode=mode):
+                    torch.autograd.backward(list(feats), [l.grad for l in leaves])
+                graphs = (gA, gB)
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode=mode):
+                    loss = fwd_bwd()
+                    if world == 1 and optim:
+                        state.adam_step()
+                graphs = (g,)
         except Exception as e:  # noqa
             if rank == 0:
                 print("[bench] hipGraph capture failed (%s: %s); falling back to eager launches" %
                       (type(e).__name__, e), file=sys.stderr)
-            graph = None
+            graphs = None
+            overlap = False
+            model.split_backward = False
             torch.cuda.synchronize()
 
     def step():
-        if graph is not None:
-            graph.replay()
-            if world > 1:
-                state.allreduce()
-                if optim:
-                    state.adam_step()
-        else:
+        if graphs is None:
             fwd_bwd()
             state.allreduce()
             if optim:
                 state.adam_step()
+        elif len(graphs) == 2:
+            graphs[0].replay()
+            state.allreduce_bucket_async(0)          # [FCN + heads]: final after graph A
+            graphs[1].replay()
+            state.allreduce_bucket_async(1)          # [PointNet]
+            state.wait_allreduce()
+            if optim:
+                state.adam_step()
+        else:
+            graphs[0].replay()
+            if world > 1:
+                state.allreduce()
+                if optim:
+                    state.adam_step()
 
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
+    # length of one K-step window -> number of rounds for a timed region of at least --min-time seconds
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    probe = time.perf_counter() - t0
+    rounds = max(1, int(np.ceil(a.min_time / max(probe, 1e-6))))
     if world > 1:
+        rt = torch.tensor([rounds], device=dev)
+        torch.distributed.all_reduce(rt, op=torch.distributed.ReduceOp.MAX)
+        rounds = int(rt.item())
         torch.distributed.barrier()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    for _ in range(a.steps):
+    for _ in range(rounds * a.steps):
         step()
     e1.record()
     torch.cuda.synchronize()
@@ -297,51 +413,73 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
     wall = float(tt.item())
-    ms_per_step = wall * 1e3 / a.steps
+    nstep = rounds * a.steps
+    ms_per_step = wall * 1e3 / nstep
     final_loss = float(loss.item())
 
     if rank != 0:
         return
+    Ls = [data["center_ref%d" % i].shape[2] for i in (1, 2, 3, 4)]
     out = {
         "metric": "frustums/sec (train fwd+bwd) KITTI-car B=32 N=1024",
         "value": round(a.batch * world / (ms_per_step / 1e3), 2),
-        "unit": "frustums/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "unit": "frustums/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "rounds": rounds,
+        "timed_steps": nstep, "timed_seconds": round(wall, 4),
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": {"split": "f32", "f32": "f32", "bf16": "bf16"}[fprec.get_precision()],
-        "mfma_operands": {"split": "fp16x3 (forward) / bf16x3 (backward) split of fp32 operands, fp32 accumulate",
-                          "f32": "fp32 (v_mfma_f32_32x32x2_f32)", "bf16": "bf16 single term, fp32 accumulate"}[fprec.get_precision()],
+        "vs_baseline": None, "dtype": {"split": "f32", "f32": "f32", "bf16": "bf16"}[prec],
+        "mfma_operands": {"split": "fp16x3 (forward) / bf16x3 (backward) split of fp32 operands, fp32 accumulate: fp32-class",
+                          "f32": "fp32 (v_mfma_f32_32x32x2_f32)", "bf16": "bf16 single term, fp32 accumulate"}[prec],
         "data": "synthetic",
-        "config": {"workload": "cfgs/det_sample.yaml KITTI-car, batch=%d/GPU, Npoint=%d, L=(280,140,70,35), "
-                               "train fwd+bwd%s%s" % (a.batch, a.npoint, "" if a.no_optim else "+Adam",
-                                                      "+RCCL grad all-reduce" if world > 1 else ""),
+        "config": {"workload": "%s KITTI-%s, batch=%d/GPU, Npoint=%d, L=(%s), train fwd+bwd%s%s" % (
+                       CFGS[a.cfg][0], a.cfg, a.batch, npoint, ",".join(str(v) for v in Ls),
+                       "" if a.no_optim else "+Adam",
+                       ("+RCCL grad all-reduce (%s)" % ("2 buckets overlapped with the PointNet backward" if overlap else
+                                                        "one call after the backward")) if world > 1 else ""),
                    "global_batch": a.batch * world, "parallelism": "dp%d" % world,
-                   "launch": "hipGraph replay" if graph is not None else "eager"},
-        "gpu_event_ms_per_step": round(e0.elapsed_time(e1) / a.steps, 4),
+                   "launch": ("hipGraph replay x%d" % len(graphs)) if graphs is not None else "eager"},
+        "gpu_event_ms_per_step": round(e0.elapsed_time(e1) / nstep, 4),
         "final_loss": round(final_loss, 5),
     }
     if world == 1 and not a.no_roofline:
         try:
-            out["roofline"] = roofline_probe(model, data)
+            model.split_backward = False
+            rows, peak_mm = kernel_table(model, state, data, optim, prec)
+            top = next(r for r in rows if "frac" in r)
+            rl = {"kernel": top["entry"], "calls_per_step": top["calls_per_step"], "bound": top["bound"],
+                  "avg_launch_group_ms": top["ms_per_step"] / max(top["calls_per_step"], 1), "frac": top["frac"]}
+            if top["bound"] == "mfma":
+                rl.update(achieved=top["achieved_tflops"], peak=round(peak_mm, 1), unit="TFLOP/s",
+                          flops_executed_per_step=top["flops_executed"],
+                          frac_of_fp32_mfma_peak=top["frac_of_fp32_mfma_peak"],
+                          peak_note="16-bit dense MFMA peak 2500 TFLOP/s / 3 instructions per fp32-class product" if prec == "split"
+                          else ("dense bf16 MFMA peak" if prec == "bf16" else "fp32 MFMA peak"))
+            else:
+                rl.update(achieved=top["achieved_tbps"], peak=PEAK_HBM_TBPS, unit="TB/s")
+            tr, why = pmc_traffic("bytes_per_launch")
+            rl["traffic"] = tr
+            if why:
+                rl["traffic_note"] = why
+            rl["how"] = ("top-time C-ABI entry point of one step: HIP events on its launch stream around the call, eager "
+                         "launches, mean of 5 steps; FLOPs = executed (entry-space rows, real channels)")
+            rl["kernels"] = rows
+            out["roofline"] = rl
         except Exception as e:  # noqa
             out["roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        try:
-            out["grouping_roofline"] = grouping_roofline(model, data)
-        except Exception as e:  # noqa
-            out["grouping_roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if world == 1:
-        # whole-step HBM roofline (BASELINE.json's "HBM roofline %"): fabric bytes of one step from the committed
-        # rocprofv3 --pmc passes (profiles/pmc_traffic.json, tools/gpu_traffic.sh) over THIS command, divided by the
-        # step time measured now; peak 8 TB/s (MI355X_MICROARCH.md).  null when no PMC summary is committed.
-        try:
-            sb = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["step"]["bytes_per_step"]
+        # whole-step HBM roofline (BASELINE.json's "HBM roofline %"): fabric bytes of one step from the committed rocprofv3
+        # --pmc passes over THIS command and THIS kernel source, divided by the step time measured now.
+        st, why = pmc_traffic("step")
+        if st:
+            sb = st["bytes_per_step"]
             tbps = sb / (ms_per_step * 1e-3) / 1e12
             out["hbm_roofline"] = {"bound": "hbm", "bytes_per_step": sb, "bytes_per_frustum": round(sb / a.batch),
-                                   "achieved": round(tbps, 3), "peak": 8.0, "unit": "TB/s", "frac": round(tbps / 8.0, 4)}
-        except Exception:  # noqa
-            out["hbm_roofline"] = None
+                                   "achieved": round(tbps, 3), "peak": PEAK_HBM_TBPS, "unit": "TB/s",
+                                   "frac": round(tbps / PEAK_HBM_TBPS, 4)}
+        else:
+            out["hbm_roofline"] = {"traffic": None, "note": why}
     if world == 1 and not a.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_batch, a.npoint)
+            out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_batch, npoint, a.cfg)
         except Exception as e:  # noqa
             out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
     print(json.dumps(out), flush=True)

@@ -55,7 +55,7 @@ class InpDesc(ctypes.Structure):
 
 
 EXPORTS = ("fcn_arch", "fcn_query_depth_point_f32", "fcn_pn_wgrad_rows", "fcn_pn_compact", "fcn_pn_group_compact",
-           "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_det_loss_tail_rows2", "fcn_det_loss_tail_rows3",
+           "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_det_loss_tail_rows2", "fcn_det_iou_metrics",
            "fcn_det_loss_tail_scratch_floats", "fcn_adam_step_f32", "fcn_adam_step_slots", "fcn_prepare_inputs", "fcn_stamp",
            "fcn_convnet_sizes", "fcn_convnet_pack", "fcn_convnet_forward", "fcn_convnet_forward2",
            "fcn_convnet_backward", "fcn_box3d_iou_pair_f32", "fcn_decode_detections", "fcn_rotate_nms_3d")
@@ -118,8 +118,8 @@ def lib():
     L.fcn_det_loss_tail_rows.argtypes = [c_fp] * 8 + [ctypes.c_int] * 4 + [ctypes.c_float] * 4 + [c_fp] * 3
     L.fcn_det_loss_tail_rows2.restype = ctypes.c_int
     L.fcn_det_loss_tail_rows2.argtypes = [c_fp] * 8 + [ctypes.c_int] * 4 + [ctypes.c_float] * 4 + [c_fp] * 5
-    L.fcn_det_loss_tail_rows3.restype = ctypes.c_int
-    L.fcn_det_loss_tail_rows3.argtypes = [c_fp] * 8 + [ctypes.c_int] * 4 + [ctypes.c_float] * 5 + [c_fp] * 5
+    L.fcn_det_iou_metrics.restype = ctypes.c_int
+    L.fcn_det_iou_metrics.argtypes = [c_fp, ctypes.c_int] + [c_fp] * 6 + [ctypes.c_int] * 4 + [ctypes.c_float] + [c_fp] * 3
     L.fcn_det_loss_tail_scratch_floats.restype = ctypes.c_int
     L.fcn_det_loss_tail_scratch_floats.argtypes = [ctypes.c_int, ctypes.c_int]
     L.fcn_convnet_sizes.restype = ctypes.c_int

@@ -1,4 +1,5 @@
 // Rotated-box kernels after the heads:
+//   iou_metric_kernel   the IoU training metrics of models/det_base.py:480-503 (IoU_2D, IoU_3D, IoU_>=thresh) from the logits
 //   iou_pair_kernel     rbbox_iou_3d_pair, ops/pybind11/box_ops.h:173-260 (call site models/det_base.py:495): paired BEV / 3-D
 //                       IoU of two corner arrays
 //   decode_kernel       the per-frustum numpy loop of train/test_net_det.py:254-293: foreground selection (p_bg < p_fg, or the
@@ -39,6 +40,102 @@ extern "C" int fcn_box3d_iou_pair_f32(const float *corners1, const float *corner
     if (n < 0 || (n > 0 && (!corners1 || !corners2 || !out2))) return FCN_E_BADARG;
     if (n == 0) return 0;
     hipLaunchKernelGGL(iou_pair_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, corners1, corners2, n, out2);
+    FCN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// IoU training metrics (models/det_base.py:480-503): on every foreground row (cls_label == 1) the box decoded with the
+// ARG-MAX heading bin / size cluster against the label box -> means of the BEV IoU, the 3-D IoU and [3-D IoU >= thresh].
+// The reference copies both corner arrays to the host every step and clips with boost there; here it is one small launch
+// that the binding puts on a side stream BESIDE the loss tail (nothing in the backward depends on it), so the step's
+// critical path does not see it.  One thread per row; the few foreground lanes do the clipping; sums go to a persistent
+// scratch (zero between launches) and the last workgroup (arrival counter) writes the three means + the foreground count.
+#define IOM_T 128
+
+struct IouMetricArgs {
+    const float *logits;       // (B*L2, ld): cols 0..1 cls, 2.. reg
+    const int64_t *cls_label;  // (B,L2)
+    const float *ref2;         // (B,3,L2)
+    const float *box_center, *box_heading, *box_size;      // (B,3) (B,1) (B,3)
+    const float *mean_size;    // (ns,3)
+    float *scratch;            // 8 floats: [0..2] sums, [3] fg count, [4] arrival counter (as int); zero between launches
+    float *out4;               // IoU_2D, IoU_3D, IoU_>=thresh, nfg
+    int B, L2, ld, nb, ns;
+    float thresh;
+};
+
+__global__ __launch_bounds__(IOM_T) void iou_metric_kernel(IouMetricArgs a)
+{
+    __shared__ float sh[4][IOM_T / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int R = a.B * a.L2, nb = a.nb, ns = a.ns;
+    const int r = blockIdx.x * IOM_T + tid;
+    float s2 = 0.f, s3 = 0.f, st = 0.f, sn = 0.f;
+    if (r < R && a.cls_label[r] == 1) {
+        const int b = r / a.L2, l = r % a.L2;
+        const float *o = a.logits + (int64_t)r * a.ld + 2;
+        const float per = 6.283185307179586f / (float)nb, half = per * 0.5f;
+        int ah = 0, as = 0;
+        float mx = o[3];
+        for (int j = 1; j < nb; ++j)
+            if (o[3 + j] > mx) { mx = o[3 + j]; ah = j; }
+        const float *ss = o + 3 + 2 * nb;
+        mx = ss[0];
+        for (int j = 1; j < ns; ++j)
+            if (ss[j] > mx) { mx = ss[j]; as = j; }
+        float pa = (float)ah * per + o[3 + nb + ah] * half;
+        if (pa > 3.141592653589793f) pa -= 6.283185307179586f;
+        const float *sr3 = o + 3 + 2 * nb + ns + 3 * as;
+        const float m0 = a.mean_size[as * 3], m1 = a.mean_size[as * 3 + 1], m2 = a.mean_size[as * 3 + 2];
+        const float pcx = o[0] + a.ref2[((int64_t)b * 3 + 0) * a.L2 + l], pcy = o[1] + a.ref2[((int64_t)b * 3 + 1) * a.L2 + l],
+                    pcz = o[2] + a.ref2[((int64_t)b * 3 + 2) * a.L2 + l];
+        const float hl = a.box_heading[b];
+        float i2, i3;
+        fcn_iou_from_params(pcx, pcy, pcz, sr3[0] * m0 + m0, sr3[1] * m1 + m1, sr3[2] * m2 + m2, cosf(pa), sinf(pa),
+                            a.box_center[b * 3], a.box_center[b * 3 + 1], a.box_center[b * 3 + 2], a.box_size[b * 3],
+                            a.box_size[b * 3 + 1], a.box_size[b * 3 + 2], cosf(hl), sinf(hl), &i2, &i3);
+        s2 = i2; s3 = i3; st = (i3 >= a.thresh) ? 1.f : 0.f; sn = 1.f;
+    }
+    s2 = wave_sum_f32(s2); s3 = wave_sum_f32(s3); st = wave_sum_f32(st); sn = wave_sum_f32(sn);
+    if (lane == 0) { sh[0][wave] = s2; sh[1][wave] = s3; sh[2][wave] = st; sh[3][wave] = sn; }
+    __syncthreads();
+    if (tid == 0) {
+        float t[4];
+        for (int q = 0; q < 4; ++q) {
+            t[q] = 0.f;
+            for (int w = 0; w < IOM_T / 64; ++w) t[q] += sh[q][w];
+            if (t[q] != 0.f) atomicAdd(&a.scratch[q], t[q]);
+        }
+        __threadfence();
+        const int ticket = atomicAdd((int *)&a.scratch[4], 1);
+        if (ticket == (int)gridDim.x - 1) {
+            __threadfence();
+            float v[4];
+            for (int q = 0; q < 4; ++q) v[q] = __hip_atomic_load(&a.scratch[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float inv = v[3] > 0.f ? 1.f / v[3] : 0.f;
+            a.out4[0] = v[0] * inv; a.out4[1] = v[1] * inv; a.out4[2] = v[2] * inv; a.out4[3] = v[3];
+            for (int q = 0; q < 4; ++q) a.scratch[q] = 0.f;
+            ((int *)a.scratch)[4] = 0;
+        }
+    }
+}
+
+extern "C" int fcn_det_iou_metrics(const float *logits, int ld, const int64_t *cls_label, const float *center_ref2,
+                                   const float *box3d_center, const float *box3d_heading, const float *box3d_size,
+                                   const float *mean_size, int B, int L2, int num_heading_bin, int num_size_cluster,
+                                   float iou_thresh, float *scratch8, float *out4, void *stream)
+{
+    if (!logits || !cls_label || !center_ref2 || !box3d_center || !box3d_heading || !box3d_size || !mean_size || !scratch8 ||
+        !out4)
+        return FCN_E_BADARG;
+    if (B <= 0 || L2 <= 0 || num_heading_bin < 1 || num_size_cluster < 1) return FCN_E_BADARG;
+    if (ld < 2 + 3 + 2 * num_heading_bin + 4 * num_size_cluster) return FCN_E_BADARG;
+    IouMetricArgs a;
+    a.logits = logits; a.cls_label = cls_label; a.ref2 = center_ref2; a.box_center = box3d_center;
+    a.box_heading = box3d_heading; a.box_size = box3d_size; a.mean_size = mean_size; a.scratch = scratch8; a.out4 = out4;
+    a.B = B; a.L2 = L2; a.ld = ld; a.nb = num_heading_bin; a.ns = num_size_cluster; a.thresh = iou_thresh;
+    hipLaunchKernelGGL(iou_metric_kernel, dim3((B * L2 + IOM_T - 1) / IOM_T), dim3(IOM_T), 0, (hipStream_t)stream, a);
     FCN_CHECK_LAUNCH();
     return 0;
 }

@@ -3,17 +3,21 @@
 // The API form of the grouping (fcn_query_depth_point_f32, grouping.hip) materialises the reference's int64 idx (B,L,K) --
 // 6.9 MB per car batch -- only for fcn_pn_compact to read it back, followed by a one-workgroup tile-list launch, a memset and
 // the BN1 finalisation: five graph nodes and ~45 us of dependent latency per scale in front of the first MFMA
-// (query_depth_point_cuda_kernel.cu:16-65 + the gather / centre subtract of models/det_base.py:75-80).  Here the scan is
-// spread over the whole chip and the dependent steps ride on arrival counters inside the same launch:
-//   A  a workgroup takes 16 windows of one (frustum, scale); every wave scans the frustum's z row (staged in LDS) for its
-//      windows: __ballot + prefix popcount give the first K hits in index order -- the same predicate, order and truncation
-//      as the reference kernel -- stored as 16-bit point indices (a quarter of the int64 idx, never padded, scratch);
-//   B  the LAST workgroup of a (frustum, scale) to finish A scans ne = max(cnt, 1) over the windows -> window row offsets,
-//   C  writes the entry rows (centred coordinates + multiplicity) and window ids, one thread per row, and accumulates the
-//      weighted input moments in fp64;
-//   D  the LAST frustum of a scale to finish C sums the per-frustum moments in frustum order (bitwise reproducible), derives
-//      the BN1 scale / shift (+ running statistics), builds the live-tile list and zeroes the BN sum slots of the coming conv
-//      launches -- the work of bn1_finalize_kernel, tile_list_kernel and the memset of fcn_pn_compact.
+// (query_depth_point_cuda_kernel.cu:16-65 + the gather / centre subtract of models/det_base.py:75-80).  Here TWO launches serve
+// all scales of a batch:
+//   gc_hits_kernel     (chip-wide)  a workgroup takes 16 windows of one (frustum, scale); every wave scans the frustum's z row
+//                      (staged in LDS) for its windows: __ballot + prefix popcount give the first K hits in index order -- the
+//                      same predicate, order and truncation as the reference kernel -- stored as 16-bit point indices (a
+//                      quarter of the int64 idx, never padded, scratch) + the counts;
+//   gc_entries_kernel  one workgroup per (frustum, scale): scan of ne = max(cnt, 1) over the windows -> window row offsets;
+//                      entry rows (centred coordinates + multiplicity) and window ids, one thread per row; weighted input
+//                      moments in fp64.  The LAST frustum of a scale to finish (arrival counter; its 11 inputs travel as
+//                      write-through stores, no L2 write-back fence) sums the per-frustum moments in frustum order (bitwise
+//                      reproducible), derives the BN1 scale / shift (+ running statistics), builds the live-tile list and
+//                      zeroes the BN sum slots of the coming conv launches -- the work of bn1_finalize_kernel,
+//                      tile_list_kernel and the memset of fcn_pn_compact.
+// (A first version did everything in one launch with a per-frustum arrival counter behind phase A: 2304 agent-scope release
+// fences -- each an L2 write-back -- made it 82 us; the kernel boundary is the cheaper hand-off, cdna guide "boundary" row.)
 // Outputs are identical to fcn_query_depth_point_f32 + fcn_pn_compact (+ bn1_finalize): cnt, woff, ent, ewin, tiles exactly,
 // moments up to fp64 summation order (tests/test_gpu_group_compact.py).
 #include "fcn_common.h"
@@ -23,7 +27,7 @@
 #define GC_WPB 16                  // windows per workgroup in phase A (4 per wave)
 #define GC_MAX_SCALES 8
 #define GC_LDS_MAX_PTS 8192        // z row staged in LDS up to this many points
-#define GC_MOM 12                  // doubles per frustum in gmom: 10 moment sums, [10] = arrival counter (as int), [11] unused
+#define GC_MOM 12                  // doubles per frustum in gmom: 10 moment sums (+ 2 spare)
 
 struct GcScale {
     const float *ref;          // (B,3,L) window centres
@@ -47,47 +51,35 @@ struct GcArgs {
     float eps, momentum;
 };
 
-// release: every wave's stores were drained by the preceding barrier; agent-scope write-back, explicit wait (hipcc may drop
-// the one behind the write-back, cdna guide G16), then the counter.  Returns true in the LAST arriver, after an acquire.
-__device__ __forceinline__ bool gc_arrive_last(int *counter, int expected)
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int ticket = atomicAdd(counter, 1);
-    const bool last = ticket == expected - 1;
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    return last;
-}
+#define GE_T 1024
+#define GE_WAVES (GE_T / 64)
 
-__global__ __launch_bounds__(GC_T) void group_compact_kernel(GcArgs a)
+__device__ __forceinline__ GcScale gc_pick(const GcArgs &a, int z)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int wsum[GC_WAVES];
-    __shared__ double red[GC_WAVES][10];
-    __shared__ int last_s, carry_s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y;
     // the scale is workgroup-uniform: copy its descriptor out of the kernel argument with static indices only
     GcScale S = a.s[0];
 #pragma unroll
     for (int q = 1; q < GC_MAX_SCALES; ++q)
-        if ((int)blockIdx.z == q) S = a.s[q];
+        if (z == q) S = a.s[q];
+    return S;
+}
+
+// ---- launch 1: hit lists (query_depth_point_cuda_kernel.cu:40-64: fabsf(z2 - z1) < dis_z in fp32, ascending k, first K)
+__global__ __launch_bounds__(GC_T) void gc_hits_kernel(GcArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const GcScale S = gc_pick(a, (int)blockIdx.z);
     const int L = S.L, K = S.K, N = a.N;
-    const int nslice = (L + GC_WPB - 1) / GC_WPB;
-    if ((int)blockIdx.x >= nslice) return;
-    // LDS: phase A: z row (N floats); phases B-C (last workgroup of the frustum): cnt (L) | offs (L+1)
+    if ((int)blockIdx.x * GC_WPB >= L) return;
     float *zs = (float *)smem;
-    int *cntS = (int *)smem;
-    int *offS = cntS + L;
-
-    const float *px = a.pc + (int64_t)b * 3 * N, *py = px + N, *pz = py + N;
-    if (a.use_lds)
+    const float *pz = a.pc + (int64_t)b * 3 * N + 2 * (int64_t)N;
+    if (a.use_lds) {
         for (int i = tid; i < N; i += GC_T) zs[i] = pz[i];
-    __syncthreads();
-
-    // ---- A: hit lists of this slice's windows (query_depth_point_cuda_kernel.cu:40-64: fabsf(z2 - z1) < dis_z in fp32,
-    // ascending k, first K)
-    const float *rx = S.ref + (int64_t)b * 3 * L, *ry = rx + L, *rz = ry + L;
+        __syncthreads();
+    }
+    const float *rz = S.ref + (int64_t)b * 3 * L + 2 * (int64_t)L;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (int q = 0; q < GC_WPB / GC_WAVES; ++q) {
         const int l = blockIdx.x * GC_WPB + q * GC_WAVES + wave;          // wave-uniform
@@ -109,17 +101,30 @@ __global__ __launch_bounds__(GC_T) void group_compact_kernel(GcArgs a)
         }
         if (lane == 0) S.cnt[(int64_t)b * L + l] = c < K ? c : K;
     }
-    __syncthreads();
-    if (tid == 0) last_s = gc_arrive_last((int *)&S.gmom[(int64_t)b * GC_MOM + 10], nslice) ? 1 : 0;
-    __syncthreads();
-    if (!last_s) return;
+}
 
-    // ======== the last workgroup of (frustum, scale): phases B, C for the whole frustum
-    for (int l = tid; l < L; l += GC_T) cntS[l] = __hip_atomic_load(&S.cnt[(int64_t)b * L + l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// ---- launch 2: offsets, entry rows, moments; the last frustum of a scale finalises it
+__global__ __launch_bounds__(GE_T) void gc_entries_kernel(GcArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int wsum[GE_WAVES];
+    __shared__ double red[GE_WAVES][10];
+    __shared__ int last_s, carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const GcScale S = gc_pick(a, (int)blockIdx.y);
+    const int L = S.L, K = S.K, N = a.N;
+    int *cntS = (int *)smem;                   // L
+    int *offS = cntS + L;                      // L + 1
+    float *cS = (float *)(offS + L + 1);       // 3 * L window centres
+    const float *px = a.pc + (int64_t)b * 3 * N, *py = px + N, *pz = py + N;
+    const float *rx = S.ref + (int64_t)b * 3 * L;
+    for (int l = tid; l < L; l += GE_T) cntS[l] = S.cnt[(int64_t)b * L + l];
+    for (int i = tid; i < 3 * L; i += GE_T) cS[i] = rx[i];
     __syncthreads();
-    // ---- B: exclusive scan of ne = max(cnt, 1) over the windows
+    // exclusive scan of ne = max(cnt, 1) over the windows
     {
-        const int per = (L + GC_T - 1) / GC_T;
+        const int per = (L + GE_T - 1) / GE_T;
         const int l0 = min(L, tid * per), l1 = min(L, l0 + per);
         int s = 0;
         for (int l = l0; l < l1; ++l) s += max(cntS[l], 1);
@@ -137,17 +142,19 @@ __global__ __launch_bounds__(GC_T) void group_compact_kernel(GcArgs a)
             offS[l] = run;
             run += max(cntS[l], 1);
         }
-        if (tid == GC_T - 1) offS[L] = run;
+        if (tid == GE_T - 1) offS[L] = run;
         __syncthreads();
-        for (int l = tid; l <= L; l += GC_T) S.woff[(int64_t)b * (L + 1) + l] = offS[l];
+        for (int l = tid; l < L; l += GE_T) S.woff[(int64_t)b * (L + 1) + l] = offS[l];
+        // woff[b][L] (the frustum's live-row count) is read by the finalising workgroup: write-through
+        if (tid == 0) __hip_atomic_store(&S.woff[(int64_t)b * (L + 1) + L], offS[L], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // ---- C: one thread per entry row (window by binary search in the offsets) + weighted moments of u = p - c
+    // one thread per entry row (window by binary search in the offsets) + weighted moments of u = p - c
     const int64_t cap = (int64_t)L * K;
     const int nent = offS[L];
     double m[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) m[i] = 0.0;
-    for (int e = tid; e < nent; e += GC_T) {
+    for (int e = tid; e < nent; e += GE_T) {
         int lo = 0, hi = L;                                               // largest l with offS[l] <= e
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -155,10 +162,8 @@ __global__ __launch_bounds__(GC_T) void group_compact_kernel(GcArgs a)
         }
         const int l = lo, j = e - offS[l], ne = offS[l + 1] - offS[l];
         // empty window: point 0 (the reference's zero-initialised idx row)
-        int p = 0;
-        if (cntS[l] > 0)
-            p = (int)__hip_atomic_load(&S.ghits[((int64_t)b * L + l) * K + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float ux = px[p] - rx[l], uy = py[p] - ry[l], uz = pz[p] - rz[l];
+        const int p = (cntS[l] > 0) ? (int)S.ghits[((int64_t)b * L + l) * K + j] : 0;
+        const float ux = px[p] - cS[l], uy = py[p] - cS[L + l], uz = pz[p] - cS[2 * L + l];
         const float w = (j == 0) ? (float)(K - ne + 1) : 1.0f;
         const int64_t r = (int64_t)b * cap + e;
         S.ent[r] = make_float4(ux, uy, uz, w);
@@ -175,32 +180,35 @@ __global__ __launch_bounds__(GC_T) void group_compact_kernel(GcArgs a)
         if (lane == 0) red[wave][i] = v;
     }
     __syncthreads();
-    if (tid < 10) {
-        double v = 0.0;
-        for (int w = 0; w < GC_WAVES; ++w) v += red[w][tid];
-        S.gmom[(int64_t)b * GC_MOM + tid] = v;
+    if (tid == 0) {
+        // the 10 moment sums leave as write-through (agent-scope) stores; drained, then the arrival counter -- the
+        // finalising workgroup reads them with agent-scope loads: no L2 write-back fence on either side (cdna guide G16, R1)
+        for (int i = 0; i < 10; ++i) {
+            double v = 0.0;
+            for (int w = 0; w < GE_WAVES; ++w) v += red[w][i];
+            __hip_atomic_store(&S.gmom[(int64_t)b * GC_MOM + i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int ticket = atomicAdd(&S.tiles[1], 1);                     // tiles[1]: arrival counter, 0 between launches
+        last_s = (ticket == a.B - 1) ? 1 : 0;
     }
-    if (tid == 0) ((int *)&S.gmom[(int64_t)b * GC_MOM + 10])[0] = 0;      // this frustum's counter ready for the next launch
-    __syncthreads();
-
-    // ---- D: the LAST frustum of this scale to get here finalises the scale
-    if (tid == 0) last_s = gc_arrive_last(&S.tiles[1], a.B) ? 1 : 0;      // tiles[1]: arrival counter, 0 between launches
     __syncthreads();
     if (!last_s) return;
-    // moments in frustum order (fixed order: reproducible bit for bit)
-    if (tid < 10) {
+
+    // ======== the last frustum of this scale
+    if (tid < 10) {                            // moments in frustum order (fixed order: reproducible bit for bit)
         double v = 0.0;
         for (int q = 0; q < a.B; ++q) v += __hip_atomic_load(&S.gmom[(int64_t)q * GC_MOM + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         S.stat[FCN_STAT_MOM + tid] = v;
         red[0][tid] = v;
     }
     // BN sum slots of the conv launches that follow
-    for (int i = 10 + tid; i < 16 + 2 * S.C2 + 2 * S.C3; i += GC_T) S.stat[i] = 0.0;
+    for (int i = 10 + tid; i < 16 + 2 * S.C2 + 2 * S.C3; i += GE_T) S.stat[i] = 0.0;
     __syncthreads();
     // BN1 scale / shift from the moments (conv1 is linear in u): what bn1_finalize_kernel computes
     {
         const double M = (double)a.B * (double)L * (double)K;
-        for (int c = tid; c < S.C1; c += GC_T) {
+        for (int c = tid; c < S.C1; c += GE_T) {
             double mean, var;
             if (a.training) {
                 const double mx = red[0][1] / M, my = red[0][2] / M, mz = red[0][3] / M;
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(GC_T) void group_compact_kernel(GcArgs a)
         const int tps = (int)((cap + 127) / 128);
         if (tid == 0) carry_s = 0;
         __syncthreads();
-        for (int b0 = 0; b0 < a.B; b0 += GC_T) {
+        for (int b0 = 0; b0 < a.B; b0 += GE_T) {
             const int bb = b0 + tid;
             int ne = 0;
             if (bb < a.B) ne = __hip_atomic_load(&S.woff[(int64_t)bb * (L + 1) + L], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(GC_T) void group_compact_kernel(GcArgs a)
             const int off = base + incl - nt;
             for (int t = 0; t < nt; ++t) S.tiles[4 + off + t] = bb * tps + t;
             __syncthreads();
-            if (tid == GC_T - 1) carry_s = base + incl;
+            if (tid == GE_T - 1) carry_s = base + incl;
             __syncthreads();
         }
         if (tid == 0) {
@@ -291,16 +299,18 @@ extern "C" int fcn_pn_group_compact(int nscale, const fcn_pn_desc *const *d, con
         S.rvar = p[q]->running_var[0]; S.nbt = p[q]->num_batches_tracked[0];
         S.bn1 = ws[q]->bn + fcn_bn_off(0, D->C1, D->C2);
         if (!D->training && (!S.rmean || !S.rvar)) return FCN_E_BADARG;
-        const size_t need = (size_t)(2 * D->L + 1) * sizeof(int);
+        const size_t need = (size_t)(2 * D->L + 1) * sizeof(int) + (size_t)3 * D->L * sizeof(float);
         if (need > lds) lds = need;
         const int ns_ = (D->L + GC_WPB - 1) / GC_WPB;
         if (s < nscale && ns_ > maxslice) maxslice = ns_;
     }
     a.pc = pc; a.B = d[0]->B; a.N = d[0]->N; a.training = d[0]->training ? 1 : 0; a.eps = d[0]->eps; a.momentum = d[0]->momentum;
     a.use_lds = (a.N <= GC_LDS_MAX_PTS) ? 1 : 0;
-    if (a.use_lds && (size_t)a.N * sizeof(float) > lds) lds = (size_t)a.N * sizeof(float);
     if (lds > 64 * 1024) return FCN_E_LIMIT;
-    hipLaunchKernelGGL(group_compact_kernel, dim3(maxslice, a.B, nscale), dim3(GC_T), lds, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gc_hits_kernel, dim3(maxslice, a.B, nscale), dim3(GC_T), a.use_lds ? (size_t)a.N * sizeof(float) : 0, st, a);
+    FCN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gc_entries_kernel, dim3(a.B, nscale), dim3(GE_T), lds, st, a);
     FCN_CHECK_LAUNCH();
     return 0;
 }

@@ -9,8 +9,6 @@
 // then evaluates its rows, block-reduces the 8 loss sums + 3 accuracy counters and adds them to an accumulator with
 // device-scope atomics; the last workgroup to arrive (ticket) turns the sums into the final scalars.
 #include "fcn_common.h"
-#define FCN_HD __device__ __forceinline__
-#include "box_iou.h"
 
 #define LT_THREADS 128
 #define LT_NB 12          // heading bins (cfg.DATA.NUM_HEADING_BIN default, det_base.py:245)
@@ -26,9 +24,7 @@ struct LossArgs {
     const float *box_size;     // (B,3)
     const int64_t *size_class; // (B,1)
     const float *mean_size;    // (NS,3)
-    float *out;                // 16: total, cls, center, head_cls, head_res, size_cls, size_res, corners, cls_acc, head_acc, size_acc, nfg,
-                               //     IoU_2D, IoU_3D, IoU_>=thresh (means over the foreground rows, det_base.py:480-503)
-    float iou_thresh;          // cfg.IOU_THRESH (configs/config.py:190)
+    float *out;                // 16: total, cls, center, head_cls, head_res, size_cls, size_res, corners, cls_acc, head_acc, size_acc, nfg
     float *dcls;               // (B,2,L2)  d total / d cls_raw
     float *dreg;               // (B,39,L2) d total / d reg_raw
     int B, L2;
@@ -99,9 +95,9 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
     // instead of 0 * inf = NaN, and out[11] = nfg lets the caller see it without a host sync on the hot path
     const float inv_fg = nfg > 0.f ? 1.f / nfg : 0.f;
 
-    float acc[15];             // [1..10] loss / accuracy sums, [12..14] IoU metric sums
+    float acc[11];
 #pragma unroll
-    for (int i = 0; i < 15; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 11; ++i) acc[i] = 0.f;
 
     if (a.ld) {                        // the workgroup's logits rows come in as coalesced 256-byte rows too
         const int row0 = blockIdx.x * LT_THREADS;
@@ -178,14 +174,12 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
             int hc = (int)floorf(shifted / per);
             hc = hc < 0 ? 0 : (hc > NB - 1 ? NB - 1 : hc);
             const float hres = (shifted - ((float)hc * per + half)) / half;
-            int am_h = 0, am_s = 0;                  // arg-max heading bin / size cluster (accuracies, IoU metrics)
             {
                 float mx = o[3];
                 int am = 0;
 #pragma unroll
                 for (int j = 1; j < NB; ++j)
                     if (o[3 + j] > mx) { mx = o[3 + j]; am = j; }
-                am_h = am;
                 float se = 0.f, ej[NB];
 #pragma unroll
                 for (int j = 0; j < NB; ++j) { ej[j] = expf(o[3 + j] - mx); se += ej[j]; }
@@ -206,7 +200,6 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
 #pragma unroll
                 for (int j = 1; j < NS; ++j)
                     if (ss[j] > mx) { mx = ss[j]; am = j; }
-                am_s = am;
                 float se = 0.f, ej[NS];
 #pragma unroll
                 for (int j = 0; j < NS; ++j) { ej[j] = expf(ss[j] - mx); se += ej[j]; }
@@ -273,20 +266,6 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
                 go[0] += dcx; go[1] += dcy; go[2] += dcz;
                 go[so] += dl * ex0; go[so + 1] += dw * ex1; go[so + 2] += dh * ex2;
                 go[3 + NB + hc] += dang * half;
-                // ---- IoU metrics (det_base.py:480-503 -> rbbox_iou_3d_pair, ops/pybind11/box_ops.h:173-260): the box decoded
-                // with the ARG-MAX heading bin / size cluster against the label box; no gradient, no host round trip
-                {
-                    float pa = (float)am_h * per + o[3 + NB + am_h] * half;
-                    if (pa > PI) pa -= TWO_PI;
-                    const int sa = 3 + 2 * NB + NS + am_s * 3;
-                    const float m0 = a.mean_size[am_s * 3], m1 = a.mean_size[am_s * 3 + 1], m2 = a.mean_size[am_s * 3 + 2];
-                    float i2, i3;
-                    fcn_iou_from_params(pcx, pcy, pcz, o[sa] * m0 + m0, o[sa + 1] * m1 + m1, o[sa + 2] * m2 + m2, cosf(pa),
-                                        sinf(pa), clx, cly, clz, sl0, sl1, sl2, cosf(hlab), sinf(hlab), &i2, &i3);
-                    acc[12] += i2;
-                    acc[13] += i3;
-                    acc[14] += (i3 >= a.iou_thresh) ? 1.f : 0.f;
-                }
             }
         }
         if (a.ld) {
@@ -311,19 +290,19 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
     }
     // ---- combine the workgroups: out[1..10] accumulate, out[15] (as int) is the arrival ticket; both were zeroed by the
     // hipMemsetAsync in front of the launch.  Accumulators are written and read with device-scope atomics only.
-    float tot[15];
+    float tot[11];
 #pragma unroll
-    for (int i = 1; i < 15; ++i) tot[i] = (i == 11) ? 0.f : block_sum(acc[i], sh);
+    for (int i = 1; i < 11; ++i) tot[i] = block_sum(acc[i], sh);
     if (tid == 0) {
         int ticket;
         if (a.scratch) {
 #pragma unroll
-            for (int i = 1; i < 15; ++i) a.scratch[32 + 16 * blockIdx.x + i] = tot[i];
+            for (int i = 1; i < 11; ++i) a.scratch[32 + 16 * blockIdx.x + i] = tot[i];
             __threadfence();
             ticket = atomicAdd((int *)a.scratch, 1);
         } else {
 #pragma unroll
-            for (int i = 1; i < 15; ++i) atomicAdd(&a.out[i], tot[i]);
+            for (int i = 1; i < 11; ++i) atomicAdd(&a.out[i], tot[i]);
             __threadfence();
             ticket = atomicAdd((int *)&a.out[15], 1);
         }
@@ -332,18 +311,18 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
     __syncthreads();
     if (last_s && tid == 0) {
         __threadfence();
-        float t[15];
+        float t[11];
         if (a.scratch) {
 #pragma unroll
-            for (int i = 1; i < 15; ++i) t[i] = 0.f;
+            for (int i = 1; i < 11; ++i) t[i] = 0.f;
             for (int g = 0; g < (int)gridDim.x; ++g)
 #pragma unroll
-                for (int i = 1; i < 15; ++i)
+                for (int i = 1; i < 11; ++i)
                     t[i] += __hip_atomic_load(&a.scratch[32 + 16 * g + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ((int *)a.scratch)[0] = 0;          // ready for the next launch
         } else {
 #pragma unroll
-            for (int i = 1; i < 15; ++i) t[i] = __hip_atomic_load(&a.out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 1; i < 11; ++i) t[i] = __hip_atomic_load(&a.out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const float cls = t[1] * inv_cls;
         const float center = t[2] * inv_fg, hcls = t[3] * inv_fg, hres = t[4] * inv_fg;
@@ -354,8 +333,7 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
         a.out[5] = scls; a.out[6] = sres; a.out[7] = corner;
         a.out[8] = nkeep > 0.f ? t[8] / nkeep : 0.f; a.out[9] = t[9] * inv_fg; a.out[10] = t[10] * inv_fg;
         a.out[11] = nfg;
-        a.out[12] = t[12] * inv_fg; a.out[13] = t[13] * inv_fg; a.out[14] = t[14] * inv_fg;
-        a.out[15] = 0.f;
+        a.out[12] = a.out[13] = a.out[14] = a.out[15] = 0.f;
         if (a.total) a.total[0] = total;
     }
 }
@@ -389,7 +367,7 @@ extern "C" int fcn_det_loss_tail(const float *cls_raw, const float *reg_raw, con
     a.box_center = box3d_center; a.box_heading = box3d_heading; a.box_size = box3d_size; a.size_class = size_class;
     a.mean_size = mean_size; a.out = out16; a.dcls = dcls; a.dreg = dreg; a.B = B; a.L2 = L2;
     a.w_box = w_box; a.w_corner = w_corner; a.w_headreg = w_headreg; a.w_sizereg = w_sizereg; a.ld = 0;
-    a.scratch = nullptr; a.total = nullptr; a.iou_thresh = 0.7f;
+    a.scratch = nullptr; a.total = nullptr;
     return launch_loss(a, (hipStream_t)stream);
 }
 
@@ -424,18 +402,6 @@ extern "C" int fcn_det_loss_tail_rows2(const float *logits, const int64_t *cls_l
                                        float w_box, float w_corner, float w_headreg, float w_sizereg,
                                        float *out16, float *dlogits, float *scratch, float *total, void *stream)
 {
-    return fcn_det_loss_tail_rows3(logits, cls_label, center_ref2, box3d_center, box3d_heading, box3d_size, size_class,
-                                   mean_size, B, L2, num_heading_bin, num_size_cluster, w_box, w_corner, w_headreg,
-                                   w_sizereg, 0.7f, out16, dlogits, scratch, total, stream);
-}
-
-extern "C" int fcn_det_loss_tail_rows3(const float *logits, const int64_t *cls_label, const float *center_ref2,
-                                       const float *box3d_center, const float *box3d_heading, const float *box3d_size,
-                                       const int64_t *size_class, const float *mean_size, int B, int L2,
-                                       int num_heading_bin, int num_size_cluster,
-                                       float w_box, float w_corner, float w_headreg, float w_sizereg, float iou_thresh,
-                                       float *out16, float *dlogits, float *scratch, float *total, void *stream)
-{
     if (!logits || !cls_label || !center_ref2 || !box3d_center || !box3d_heading || !box3d_size || !size_class ||
         !mean_size || !out16)
         return FCN_E_BADARG;
@@ -446,6 +412,6 @@ extern "C" int fcn_det_loss_tail_rows3(const float *logits, const int64_t *cls_l
     a.box_center = box3d_center; a.box_heading = box3d_heading; a.box_size = box3d_size; a.size_class = size_class;
     a.mean_size = mean_size; a.out = out16; a.dcls = dlogits; a.dreg = nullptr; a.B = B; a.L2 = L2;
     a.w_box = w_box; a.w_corner = w_corner; a.w_headreg = w_headreg; a.w_sizereg = w_sizereg; a.ld = 64;
-    a.scratch = scratch; a.total = total; a.iou_thresh = iou_thresh;
+    a.scratch = scratch; a.total = total;
     return launch_loss(a, (hipStream_t)stream);
 }

@@ -10,7 +10,7 @@ HOLD the parameters so that state_dicts stay interchangeable):
     (PointNetModule.forward_pooled / launch_pooled);
   * ConvFeatNet + heads: csrc/fcn_net.hip (implicit-GEMM forward + backward) -- `fused_fcn`;
   * train-loss tail (8 losses, 3 accuracies, 3 IoU metrics, d total / d logits): csrc/loss_tail.hip + csrc/box_iou.hip,
-    one launch each, no host synchronisation (the reference syncs at det_base.py:70, :414 and :495 every step) -- `fused_loss`;
+    one launch each (the metrics on a side stream), no host synchronisation (the reference syncs at det_base.py:70, :414 and :495 every step) -- `fused_loss`;
   * eval decode: torch ops on the device (box_ops.py).
 `fused_fcn = False` / `fused_loss = False` are EXPLICIT opt-ins to the nn.Conv1d / torch-op formulations (GPU libraries,
 kept for A/B parity tests); nothing falls back to them silently.
@@ -302,6 +302,8 @@ class PointNetDet(nn.Module):
         self._loss_scratch = None
         from .fcn_fused import CnPool
         self._cn_pool = CnPool()
+        from .loss_fused import IouMetrics
+        self._iou_metrics = IouMetrics()
         self.last_logits = None
         self.last_logits64 = None
         self.last_num_fg = None
@@ -450,19 +452,24 @@ class PointNetDet(nn.Module):
                 key = (batch_size, num_out, str(logits64.device))
                 if self._loss_scratch is None or self._loss_scratch[0] != key:
                     self._loss_scratch = (key, loss_scratch(batch_size, num_out, logits64.device))
-                losses, (a_cls, a_head, a_size), ious, nfg = det_loss_tail_rows(
+                # IoU metrics (models/det_base.py:480-503) on a side stream beside the loss tail: validate()'s best-checkpoint
+                # criterion (train/train_net_det.py:203,365-382) works without the reference's per-step D2H + boost clipping
+                ious = self._iou_metrics(logits64, batch_size, num_out, cls_label, refs[1], center_label, heading_label,
+                                         size_label, mean_size_array, self.num_bins, self.num_size_cluster, cfg.IOU_THRESH)
+                losses, (a_cls, a_head, a_size), nfg = det_loss_tail_rows(
                     logits64, batch_size, num_out, cls_label, refs[1], center_label, heading_label, size_label,
                     size_class_label, mean_size_array, self.num_bins, self.num_size_cluster, wts,
-                    self._loss_scratch[1], cfg.IOU_THRESH)
+                    self._loss_scratch[1])
+                self._iou_metrics.join()
+                iou2, iou3, iout = ious[0], ious[1], ious[2]
             else:
-                losses, (a_cls, a_head, a_size), ious, nfg = det_loss_tail(
+                losses, (a_cls, a_head, a_size), nfg = det_loss_tail(
                     cls_raw, reg_raw, cls_label, refs[1], center_label, heading_label, size_label, size_class_label,
                     mean_size_array, self.num_bins, self.num_size_cluster, wts)
-            # IoU metrics come from the same launch (csrc/box_iou.h): validate()'s best-checkpoint criterion
-            # (train/train_net_det.py:203,365-382) works without the reference's per-step D2H + boost clipping on the host
+                iou2 = iou3 = iout = self._zero_scalar(a_cls)       # (planar A/B path: no IoU metrics)
             self.last_num_fg = nfg      # device scalar: 0 means the batch had no foreground row (the reference asserts there)
-            metrics = {'cls_acc': a_cls, 'head_acc': a_head, 'size_acc': a_size, 'IoU_2D': ious[0], 'IoU_3D': ious[1],
-                       'IoU_' + str(cfg.IOU_THRESH): ious[2]}
+            metrics = {'cls_acc': a_cls, 'head_acc': a_head, 'size_acc': a_size, 'IoU_2D': iou2, 'IoU_3D': iou3,
+                       'IoU_' + str(cfg.IOU_THRESH): iout}
             return losses, metrics
 
         # ---- training / validation branch: every loss is a mean over the foreground rows

@@ -3,9 +3,11 @@ train/train_net_det.py:308-309).
 
 Frustums are independent except for the gradient sum, so each rank keeps B_local frustums, per-rank
 BatchNorm statistics (exactly what DataParallel replicas do -- the reference has no SyncBN) and the only
-exchange step is one all-reduce (mean) of the 3.3 M-parameter gradient over RCCL/xGMI.  Parameters and
-gradients live in two flat fp32 buffers so that exchange is a single 13.3 MB collective (fully-connected
-xGMI: RCCL can drive all 7 links at once with one large message, instead of 154 small ones).
+exchange step is the all-reduce (mean) of the 3.3 M-parameter gradient over RCCL/xGMI.  Parameters and
+gradients live in flat fp32 buffers (train_state.FlatTrainState), so the exchange is two large collectives cut where
+the backward finishes them -- [ConvFeatNet + heads] 11.6 MB while the PointNet backward still runs, then [PointNet]
+1.1 MB -- instead of 154 small ones (fully-connected xGMI: RCCL drives all 7 links with one large message).
+This module holds the process-group plumbing only: rank discovery, initial broadcast, batch sharding.
 """
 import os
 
@@ -25,79 +27,6 @@ def init_from_env(backend=None):
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
-
-
-class FlatParams:
-    """Re-homes every parameter (and its .grad) of `model` as a view into one contiguous buffer."""
-
-    def __init__(self, model):
-        params = [p for p in model.parameters()]
-        assert params, "model has no parameters"
-        dev, dt = params[0].device, params[0].dtype
-        total = sum(p.numel() for p in params)
-        self.flat = torch.zeros(total, device=dev, dtype=dt)
-        self.grad = torch.zeros(total, device=dev, dtype=dt)
-        self.params = params
-        off = 0
-        with torch.no_grad():
-            for p in params:
-                n = p.numel()
-                self.flat[off:off + n].copy_(p.data.reshape(-1))
-                p.data = self.flat[off:off + n].view(p.shape)
-                p.grad = self.grad[off:off + n].view(p.shape)
-                off += n
-        self.numel = total
-
-    def zero_grad(self):
-        self.grad.zero_()
-
-    def as_parameter(self):
-        """A single leaf Parameter over the flat buffer whose .grad is the flat gradient (for the optimizer)."""
-        fp = torch.nn.Parameter(self.flat, requires_grad=True)
-        fp.grad = self.grad
-        return fp
-
-
-class GradAllReducer:
-    """Gradient mean over ranks; world_size 1 is a no-op.  Optionally split into `nbucket` chunks launched
-    back to back (each a separate RCCL call) so the tail of one overlaps the head of the next."""
-
-    def __init__(self, flat, world, nbucket=1, group=None):
-        self.flat, self.world, self.group = flat, world, group
-        n = flat.numel
-        edges = [n * i // nbucket for i in range(nbucket + 1)]
-        self.chunks = [(edges[i], edges[i + 1]) for i in range(nbucket) if edges[i + 1] > edges[i]]
-
-    def allreduce(self):
-        if self.world == 1:
-            return
-        for a, b in self.chunks:
-            dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, group=self.group)
-        self.flat.grad.div_(self.world)
-
-
-class CoalescedGradAllReducer:
-    """Gradient mean over ranks for per-tensor gradients: one flatten (single cat kernel), ONE RCCL all-reduce of the
-    13.3 MB buffer, one scatter back.  world_size 1 is a no-op."""
-
-    def __init__(self, params, world, group=None):
-        self.params, self.world, self.group = list(params), world, group
-        self.buf = None
-
-    def allreduce(self):
-        if self.world == 1:
-            return
-        grads = [p.grad for p in self.params if p.grad is not None]
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        flat.div_(self.world)
-        off = 0
-        views = []
-        for g in grads:
-            n = g.numel()
-            views.append(flat[off:off + n].view_as(g))
-            off += n
-        torch._foreach_copy_(grads, views)
 
 
 def broadcast_state(model, src=0):

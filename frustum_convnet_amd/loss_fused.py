@@ -55,7 +55,7 @@ class _LossTail(torch.autograd.Function):
 
 def det_loss_tail(cls_raw, reg_raw, cls_label, center_ref2, box3d_center, box3d_heading, box3d_size, size_class,
                   mean_size, num_bins, num_sizes, weights):
-    """-> (losses dict with the reference's 8 keys, accuracies (cls, head, size), IoU metrics (2D, 3D, >=0.7), nfg)."""
+    """-> (losses dict with the reference's 8 keys, accuracies (cls, head, size), nfg)."""
     if not cls_raw.is_cuda:
         raise RuntimeError("frustum_convnet_amd: fused loss tail runs on the GPU only")
     total, rest = _LossTail.apply(cls_raw, reg_raw, cls_label, center_ref2, box3d_center, box3d_heading, box3d_size,
@@ -63,15 +63,14 @@ def det_loss_tail(cls_raw, reg_raw, cls_label, center_ref2, box3d_center, box3d_
     losses = {"total_loss": total}
     for i, k in enumerate(LOSS_NAMES[1:], start=1):
         losses[k] = rest[i]
-    return losses, (rest[8], rest[9], rest[10]), (rest[12], rest[13], rest[14]), rest[11]
+    return losses, (rest[8], rest[9], rest[10]), rest[11]
 
 
 class _LossTailRows(torch.autograd.Function):
     """Same tail on the row-major (B*L2, 64) logits of the fused ConvFeatNet."""
 
     @staticmethod
-    def forward(ctx, logits, cls_label, ref2, center, heading, size, size_class, mean_size, B, L2, nb, ns, w, scratch,
-                iou_thresh=0.7):
+    def forward(ctx, logits, cls_label, ref2, center, heading, size, size_class, mean_size, B, L2, nb, ns, w, scratch):
         L = _native.lib()
         _check_labels(cls_label, size_class, ns)
         lg = logits.detach().contiguous()
@@ -83,12 +82,12 @@ class _LossTailRows(torch.autograd.Function):
                 heading.contiguous().float(), size.contiguous().float(), size_class.contiguous(),
                 mean_size.contiguous().float()]
         with torch.cuda.device(lg.device):
-            rc = L.fcn_det_loss_tail_rows3(lg.data_ptr(), *[t.data_ptr() for t in args], int(B), int(L2), int(nb),
+            rc = L.fcn_det_loss_tail_rows2(lg.data_ptr(), *[t.data_ptr() for t in args], int(B), int(L2), int(nb),
                                            int(ns), float(w[0]), float(w[1]), float(w[2]), float(w[3]),
-                                           float(iou_thresh), out.data_ptr(), None if dlog is None else dlog.data_ptr(),
+                                           out.data_ptr(), None if dlog is None else dlog.data_ptr(),
                                            None if scratch is None else scratch.data_ptr(), total.data_ptr(),
                                            _native.current_stream(lg.device))
-        _native.check(rc, "fcn_det_loss_tail_rows3")
+        _native.check(rc, "fcn_det_loss_tail_rows2")
         ctx.need = need
         if need:
             ctx.save_for_backward(dlog)
@@ -99,9 +98,9 @@ class _LossTailRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gtotal, _grest):
         if not ctx.need or gtotal is None:
-            return (None,) * 15
+            return (None,) * 14
         (dlog,) = ctx.saved_tensors
-        return (dlog * gtotal,) + (None,) * 14
+        return (dlog * gtotal,) + (None,) * 13
 
 
 def loss_scratch(B, L2, device):
@@ -112,11 +111,58 @@ def loss_scratch(B, L2, device):
 
 
 def det_loss_tail_rows(logits, B, L2, cls_label, center_ref2, box3d_center, box3d_heading, box3d_size, size_class,
-                       mean_size, num_bins, num_sizes, weights, scratch=None, iou_thresh=0.7):
-    """-> (losses, (cls_acc, head_acc, size_acc), (IoU_2D, IoU_3D, IoU_>=thresh), nfg) -- all device scalars."""
+                       mean_size, num_bins, num_sizes, weights, scratch=None):
+    """-> (losses, (cls_acc, head_acc, size_acc), nfg) -- all device scalars."""
     total, rest = _LossTailRows.apply(logits, cls_label, center_ref2, box3d_center, box3d_heading, box3d_size,
-                                      size_class, mean_size, B, L2, num_bins, num_sizes, weights, scratch, iou_thresh)
+                                      size_class, mean_size, B, L2, num_bins, num_sizes, weights, scratch)
     losses = {"total_loss": total}
     for i, k in enumerate(LOSS_NAMES[1:], start=1):
         losses[k] = rest[i]
-    return losses, (rest[8], rest[9], rest[10]), (rest[12], rest[13], rest[14]), rest[11]
+    return losses, (rest[8], rest[9], rest[10]), rest[11]
+
+
+class IouMetrics:
+    """IoU_2D / IoU_3D / IoU_>=thresh of models/det_base.py:480-503 from the row-major logits: one small HIP launch
+    (csrc/box_iou.hip iou_metric_kernel) on a SIDE stream beside the loss tail -- nothing in the backward depends on it, so
+    the step's critical path does not see it; join() makes the caller's stream wait for it."""
+
+    def __init__(self):
+        self.per_dev = {}
+        self._join = None
+
+    def __call__(self, logits, B, L2, cls_label, center_ref2, box3d_center, box3d_heading, box3d_size, mean_size, num_bins,
+                 num_sizes, iou_thresh):
+        dev = logits.device
+        key = str(dev)
+        if key not in self.per_dev:
+            with torch.cuda.device(dev):
+                self.per_dev[key] = (torch.cuda.Stream(device=dev), torch.cuda.Event(enable_timing=False),
+                                     torch.cuda.Event(enable_timing=False),
+                                     torch.zeros(8, dtype=torch.float32, device=dev))
+        side, ev_in, ev_out, scratch = self.per_dev[key]
+        if cls_label.dtype != torch.int64:
+            raise TypeError("cls_label must be int64 (got %s)" % cls_label.dtype)
+        lg = logits.detach()
+        out = torch.empty(4, dtype=torch.float32, device=dev)
+        args = [cls_label.contiguous(), center_ref2.contiguous().float(), box3d_center.contiguous().float(),
+                box3d_heading.contiguous().float(), box3d_size.contiguous().float(), mean_size.contiguous().float()]
+        cur = torch.cuda.current_stream(dev)
+        ev_in.record(cur)
+        side.wait_event(ev_in)
+        with torch.cuda.stream(side):
+            with torch.cuda.device(dev):
+                rc = _native.lib().fcn_det_iou_metrics(lg.data_ptr(), int(lg.shape[1]), *[t.data_ptr() for t in args], int(B),
+                                                       int(L2), int(num_bins), int(num_sizes), float(iou_thresh),
+                                                       scratch.data_ptr(), out.data_ptr(), _native.current_stream(dev))
+            _native.check(rc, "fcn_det_iou_metrics")
+            ev_out.record(side)
+        for t in [lg, out] + args:
+            t.record_stream(side)
+        self._join = (cur, ev_out)
+        return out
+
+    def join(self):
+        if self._join is not None:
+            cur, ev = self._join
+            cur.wait_event(ev)
+            self._join = None

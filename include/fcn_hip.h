@@ -22,6 +22,7 @@
  *   fcn_adam_step_f32           optim.Adam.step() of the step loop, train/train_net_det.py:131-133,321-339
  *   fcn_prepare_inputs          the per-sample numpy work of the data loader + collate,
  *                               datasets/provider_sample.py:137-262,270-327,396-397
+ *   fcn_det_iou_metrics         the IoU metrics of models/det_base.py:480-503 (D2H + boost clipping every step in the reference)
  *   fcn_box3d_iou_pair_f32      rbbox_iou_3d_pair, ops/pybind11/box_ops.h:173-260 (boost polygon clipping on the host)
  *   fcn_decode_detections       the numpy decode loop of train/test_net_det.py:254-293 + from_prediction_to_label_format
  *   fcn_rotate_nms_3d           rotate_nms_3d_cc, ops/pybind11/rbbox_iou.py:294-311 + nms_cpu.h:148-240
@@ -226,8 +227,7 @@ int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn
  *   cls_raw (B,2,L2), reg_raw (B,3+2*NB+4*NS,L2): raw head outputs;  cls_label (B,L2) int64 in {-1,0,1};
  *   center_ref2 (B,3,L2); box3d_center (B,3); box3d_heading (B,1); box3d_size (B,3); size_class (B,1) int64;
  *   mean_size (NS,3).  NB must be 12 and NS 3 (the KITTI configuration), else FCN_E_LIMIT.
- *   out16: total, cls, center, head_cls, head_res, size_cls, size_res, corners, cls_acc, head_acc, size_acc, nfg,
- *          IoU_2D, IoU_3D, IoU_>=0.7 (see fcn_det_loss_tail_rows3)
+ *   out16: total, cls, center, head_cls, head_res, size_cls, size_res, corners, cls_acc, head_acc, size_acc, nfg
  *   dcls / dreg: d(total)/d(cls_raw), d(total)/d(reg_raw), same layouts (NULL to skip).
  * ------------------------------------------------------------------------------------------- */
 int fcn_det_loss_tail(const float *cls_raw, const float *reg_raw, const int64_t *cls_label,
@@ -267,17 +267,6 @@ int fcn_det_loss_tail_rows2(const float *logits, const int64_t *cls_label, const
                             float w_box, float w_corner, float w_headreg, float w_sizereg,
                             float *out16, float *dlogits, float *scratch, float *total, void *stream);
 
-/* Same with the IoU threshold of the third metric (cfg.IOU_THRESH, configs/config.py:190; the entries above use 0.7).
- * out16[12..14] = IoU_2D, IoU_3D, IoU_>=thresh: means over the foreground rows of the BEV / 3-D overlap between the box
- * decoded with the arg-max heading bin and size cluster and the label box (models/det_base.py:480-503, which leaves the
- * device for ops/pybind11/box_ops.h:173-260 rbbox_iou_3d_pair on the host every step). */
-int fcn_det_loss_tail_rows3(const float *logits, const int64_t *cls_label, const float *center_ref2,
-                            const float *box3d_center, const float *box3d_heading, const float *box3d_size,
-                            const int64_t *size_class, const float *mean_size, int B, int L2,
-                            int num_heading_bin, int num_size_cluster,
-                            float w_box, float w_corner, float w_headreg, float w_sizereg, float iou_thresh,
-                            float *out16, float *dlogits, float *scratch, float *total, void *stream);
-
 /* ---------------------------------------------------------------------------------------------
  * Rotated-box overlap after the heads.  The reference leaves the device for all of
  * it: numpy loops + boost::geometry polygon clipping on the host.
@@ -285,6 +274,14 @@ int fcn_det_loss_tail_rows3(const float *logits, const int64_t *cls_label, const
 /* rbbox_iou_3d_pair (ops/pybind11/box_ops.h:173-260, pybind "rbbox_iou_3d_pair"; call site models/det_base.py:495):
  * corners1/corners2 (n,8,3) in the corner order of get_box3d_corners_helper -> out2 (n,2) = [BEV IoU, 3-D IoU]. */
 int fcn_box3d_iou_pair_f32(const float *corners1, const float *corners2, int n, float *out2, void *stream);
+/* IoU training metrics of models/det_base.py:480-503 (which leaves the device for rbbox_iou_3d_pair on the host every step):
+ * on the foreground rows (cls_label == 1) of the row-major logits (B*L2, ld), the box decoded with the arg-max heading bin /
+ * size cluster against the label box.  out4 = mean BEV IoU, mean 3-D IoU, fraction with 3-D IoU >= iou_thresh
+ * (cfg.IOU_THRESH), foreground count.  scratch8: 8 floats, zeroed ONCE by the caller (the launch leaves them zero). */
+int fcn_det_iou_metrics(const float *logits, int ld, const int64_t *cls_label, const float *center_ref2,
+                        const float *box3d_center, const float *box3d_heading, const float *box3d_size,
+                        const float *mean_size, int B, int L2, int num_heading_bin, int num_size_cluster,
+                        float iou_thresh, float *scratch8, float *out4, void *stream);
 /* The per-frustum decode loop of train/test_net_det.py:254-293 on the row-major logits (B*L2, ld) of
  * fcn_convnet_forward (cols 0..1 cls, 2.. reg): method 1 ('nms'): every position with p_bg < p_fg, or the arg-max of p_fg
  * when a frustum has none; method 0 ('top'): the arg-max only.  Arg-max heading bin / size cluster decode, centre =

@@ -172,9 +172,18 @@ def test_detect_pipeline_matches_oracle():
         exp = [int(rows[k]) for k in box_ref.cube_nms(dets_c[rows], 0.1)]
         got = keep[gi, :int(cnt[gi])].cpu().tolist()
         assert got == exp, (gi, got, exp)
-    # 'top': one candidate per frustum, all kept
-    dets, valid, keep, cnt = m.detect(dd, method="top")
-    assert valid.view(B, L2).sum(1).cpu().tolist() == [1] * B and cnt.cpu().tolist() == [1] * B
+    # 'top' (cfg.TEST.METHOD default): the arg-max of p_fg of each frustum, dropped when its decoded box is degenerate
+    # (random weights do produce negative sizes), nothing suppressed
+    dets_t, valid_t, keep_t, cnt_t = m.detect(dd, method="top")
+    lg = m.last_logits64.view(B, L2, 64).cpu()
+    vt = valid_t.view(B, L2).cpu().numpy()
+    dt = dets_t.view(B, L2, 8).cpu().numpy()
+    for b in range(B):
+        p1 = torch.softmax(lg[b, :, :2], -1)[:, 1].numpy()
+        top = int(np.argmax(p1))
+        ok = not (dt[b, top, 3:6] < 0.01).any()
+        assert np.nonzero(vt[b])[0].tolist() == ([top] if ok else []), b
+        assert int(cnt_t[b]) == (1 if ok else 0) and (not ok or int(keep_t[b, 0]) == b * L2 + top)
 
 
 def test_backward_split_equals_backward():
