@@ -18,6 +18,17 @@
 #include "gemm_tile.h"
 
 #define CG_T 256
+// forward tile of the K-group kernels: (32*FCN_FT_MW) x (32*FCN_FT_WNC) outputs, FCN_FT_G K-groups (tuning builds override)
+#ifndef FCN_FT_MW
+#define FCN_FT_MW 1
+#endif
+#ifndef FCN_FT_G
+#define FCN_FT_G 4
+#endif
+#ifndef FCN_FT_WNC
+#define FCN_FT_WNC 1
+#endif
+#define FCN_FT_THREADS (FCN_FT_G * 64 * FCN_FT_MW * FCN_FT_WNC)
 #define LDN 68                 // row-major LDS leading dim of a 64-wide tile (float4 aligned)
 #define OH_PAD 64              // channels of the virtual one-hot segment
 #define CG_SPLIT_ROWS 512      // rows per wgrad split
@@ -56,6 +67,22 @@ struct CgLayer {
 };
 
 #define SEL3(i, a0, a1, a2) ((i) == 0 ? (a0) : ((i) == 1 ? (a1) : (a2)))
+
+// XCD-aware tile order (cdna guide T1).  Workgroup ids are dealt to the 8 XCDs round-robin and every XCD has its own 4 MB
+// L2; with the natural order the tiles that share operand rows land on eight different L2s and each of them pulls the
+// whole weight matrix AND the whole activation matrix through the fabric (32 x 32 tiles re-read their operands ~20x:
+// block4_conv2 moved 215 MB through L2 for 10 MB of distinct data).  Here workgroup `id` of a role takes tile
+// (id % 8) * ceil(n / 8) + id / 8, so XCD k works through the CONTIGUOUS range of tiles k*per .. (k+1)*per-1 in order:
+// a range of row tiles x all column tiles -> its L2 sees 1/8 of the rows and the weights once.  Roles inside one launch
+// start at multiples of 8 workgroups (cg_pad8) so that id % 8 is the XCD for each of them.  Speed only: nothing depends on
+// the placement.
+__device__ __forceinline__ int cg_xcd_tile(int id, int n)
+{
+    const int per = (n + 7) >> 3;
+    const int t = (id & 7) * per + (id >> 3);
+    return (t < n && (id >> 3) < per) ? t : -1;
+}
+static inline int cg_pad8(int n) { return ((n + 7) / 8) * 8; }
 
 // Pins a wave-uniform value in an SGPR.  Without it LLVM rewrites "select between fields of the by-value kernel
 // struct" into "load from a dynamically selected field address", which needs the struct in memory: the whole kernarg
@@ -307,7 +334,10 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
 template <int MM, int MW, int G, int WNC = 2>
 __global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_kernel(CgLayer L)
 {
-    cgk_fwd_body<MM, MW, G, WNC>(L, blockIdx.x, blockIdx.y);
+    const int nby = L.Cout / (32 * WNC), nbx = (L.B * L.Lout + 32 * MW - 1) / (32 * MW);
+    const int t = cg_xcd_tile(blockIdx.x, nbx * nby);          // column tiles fastest: a row tile's operand rows stay in one L2
+    if (t < 0) return;
+    cgk_fwd_body<MM, MW, G, WNC>(L, t / nby, t % nby);
 }
 
 // Two INDEPENDENT layers in one launch (a deconvolution next to the stride-2 conv that reads the same merge output):
@@ -315,15 +345,20 @@ __global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_kernel(CgLayer L)
 // grids fill the CUs together.
 struct CgLayerPair {
     CgLayer A, B;
-    int na, txa, txb;          // workgroups of A; row tiles of A and of B (tile t -> (t % tx, t / tx))
+    int na;                    // workgroups of A (a multiple of 8); the rest belong to B
 };
 
 template <int MM, int MW, int G, int WNC>
 __global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_pair_kernel(CgLayerPair p)
 {
     const int bid = blockIdx.x;
-    if (bid < p.na) cgk_fwd_body<MM, MW, G, WNC>(p.A, bid % p.txa, bid / p.txa);
-    else cgk_fwd_body<MM, MW, G, WNC>(p.B, (bid - p.na) % p.txb, (bid - p.na) / p.txb);
+    const bool isA = bid < p.na;
+    const CgLayer &L = isA ? p.A : p.B;
+    const int nby = L.Cout / (32 * WNC), nbx = (L.B * L.Lout + 32 * MW - 1) / (32 * MW);
+    const int t = cg_xcd_tile(isA ? bid : bid - p.na, nbx * nby);
+    if (t < 0) return;
+    if (isA) cgk_fwd_body<MM, MW, G, WNC>(p.A, t / nby, t % nby);
+    else cgk_fwd_body<MM, MW, G, WNC>(p.B, t / nby, t % nby);
 }
 
 // BN-backward coefficients of one channel from the batch sums (sum dz, sum dz*xhat): gamma*rstd, mean, rstd, dbeta/M,
@@ -439,8 +474,8 @@ struct CgDgSeg {               // one differentiated input segment of the layer
     float *out;                // producer's dz (Rsrc x C) or the input gradient
     int accumulate;            // add to what `out` already holds (a second consumer)
     double *bstat_src;         // non-null on the LAST consumer: sum dz, sum dz*xhat of the producer
-    int tx;                    // row tiles (32 rows each); workgroup t of the segment -> (t % tx, t / tx)
-    int blk0;                  // first workgroup of this segment
+    int tx, ncb;               // row tiles (32 rows each) and 64-channel column blocks; tile t -> (t / ncb, t % ncb)
+    int blk0;                  // first workgroup of this segment (a multiple of 8)
 };
 
 struct CgReduce {
@@ -662,7 +697,11 @@ __device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float
     const int lane = tid & 63, wave = gt >> 6;
     const int l31 = lane & 31, lh = lane >> 5, wm = wave >> 1, wn = wave & 1;
     float *As = smem + h * (2 * KC * LDN), *Bs = As + KC * LDN;
-    const int bx = wid % a.w_ns, byz = wid / a.w_ns, by = byz % a.w_ny, bz = byz / a.w_ny;
+    // XCD order: the row split is the slow index, so the workgroups that reduce the same rows (all output tiles) share an L2
+    const int nyz = a.w_ny * (L.Ktot / 64);
+    const int wt = cg_xcd_tile(wid, a.w_ns * nyz);
+    if (wt < 0) return;
+    const int bx = wt / nyz, byz = wt % nyz, by = byz % a.w_ny, bz = byz / a.w_ny;
     const int R = L.B * L.Lout, Cs = L.Cs;
     const int rbeg = bx * a.rows, rend = min(R, rbeg + a.rows);
     const int n0 = by * 64, kk0 = bz * 64;
@@ -822,9 +861,11 @@ __device__ __forceinline__ void cg_bwd_step_body(const CgBwdStep &a, const int b
     if (bid >= a.w_blk0) { cg_wgrad_body<MM>(a, bid - a.w_blk0, smem); return; }
     const int role = (a.ndg > 2 && bid >= a.dg2.blk0) ? 2 : ((a.ndg > 1 && bid >= a.dg1.blk0) ? 1 : 0);
 #define DGF(f) SEL3(role, opaque_s(a.dg0.f), opaque_s(a.dg1.f), opaque_s(a.dg2.f))
-    const int t = bid - DGF(blk0), tx = DGF(tx);
+    const int ncb = DGF(ncb);
+    const int t = cg_xcd_tile(bid - DGF(blk0), DGF(tx) * ncb);
+    if (t < 0) return;
     cg_dgrad_body<MM>(a.lay, a.cb, a.dz, a.lay.y, DGF(sg), DGF(segoff), DGF(ysrc), DGF(bnsrc), DGF(out), DGF(accumulate),
-                  DGF(bstat_src), t % tx, t / tx, bid == 0, smem);
+                  DGF(bstat_src), t / ncb, t % ncb, bid == 0, smem);
 #undef DGF
 }
 
@@ -1095,16 +1136,19 @@ extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p
             FCN_TRY(prep(l, pp.A));
             FCN_TRY(prep(l2, pp.B));
             const int R2 = d->B * P.Lout[l2];
-            pp.txa = (R + 31) / 32; pp.txb = (R2 + 31) / 32;
-            pp.na = pp.txa * (P.N[l] / 32);
-            const int nb = pp.txb * (P.N[l2] / 32);
-            FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_pair_kernel<MM, 1, 4, 1>), dim3(pp.na + nb), dim3(256), 0, st, pp));
+            constexpr int TR = 32 * FCN_FT_MW, TC = 32 * FCN_FT_WNC;
+            pp.na = cg_pad8(((R + TR - 1) / TR) * (P.N[l] / TC));
+            const int nb = cg_pad8(((R2 + TR - 1) / TR) * (P.N[l2] / TC));
+            FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_pair_kernel<MM, FCN_FT_MW, FCN_FT_G, FCN_FT_WNC>), dim3(pp.na + nb),
+                                                  dim3(FCN_FT_THREADS), 0, st, pp));
             FCN_CHECK_LAUNCH();
             ++q;
         } else {
             CgLayer L;
             FCN_TRY(prep(l, L));
-            FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_kernel<MM, 1, 4, 1>), dim3((R + 31) / 32, P.N[l] / 32), dim3(256), 0, st, L));
+            constexpr int TR = 32 * FCN_FT_MW, TC = 32 * FCN_FT_WNC;
+            FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_kernel<MM, FCN_FT_MW, FCN_FT_G, FCN_FT_WNC>),
+                                                  dim3(cg_pad8(((R + TR - 1) / TR) * (P.N[l] / TC))), dim3(FCN_FT_THREADS), 0, st, L));
             FCN_CHECK_LAUNCH();
         }
     }
@@ -1175,7 +1219,7 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
         CgDgSeg *dgs[3] = {&a.dg0, &a.dg1, &a.dg2};
         for (int s = 0; s < 3; ++s) {
             dgs[s]->sg = 0; dgs[s]->segoff = 0; dgs[s]->ysrc = dgs[s]->bnsrc = nullptr; dgs[s]->out = nullptr;
-            dgs[s]->accumulate = 0; dgs[s]->bstat_src = nullptr; dgs[s]->tx = 1; dgs[s]->blk0 = 0;
+            dgs[s]->accumulate = 0; dgs[s]->bstat_src = nullptr; dgs[s]->tx = 1; dgs[s]->ncb = 1; dgs[s]->blk0 = 0;
         }
         blank_reduce(own);
         own_blocks = 0;
@@ -1211,8 +1255,9 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
                 }
                 const int Rs = d->B * a.lay.seg[s].Lsrc;
                 g.tx = (Rs + 31) / 32;
+                g.ncb = P.C[l][s] / 64;
                 g.blk0 = nblk;
-                nblk += g.tx * (P.C[l][s] / 64);
+                nblk += cg_pad8(g.tx * g.ncb);
                 a.ndg += 1;
             }
             segoff += P.KT[l] * P.C[l][s];
@@ -1221,7 +1266,7 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
         a.partial = pbuf;
         a.w_ny = P.N[l] / 64;
         cn_wgrad_split(R, a.w_ny * (P.Ktot[l] / 64), a.rows, a.w_ns);
-        nblk += a.w_ns * a.w_ny * (P.Ktot[l] / 64);
+        nblk += cg_pad8(a.w_ns * a.w_ny * (P.Ktot[l] / 64));
         own.partial = a.partial; own.nsplit = a.w_ns; cn_fill_pack(d, P, l, own.pk); own.nrow_real = P.nrow_real[l];
         own.dW = dW[l];
         own.gr = a.w_ns >= 32 ? 8 : (a.w_ns >= 16 ? 4 : (a.w_ns >= 8 ? 2 : 1));
