@@ -87,8 +87,8 @@ def make_data(cfg_name, batch, npoint, seed, device):
 # ------------------------------------------------------------------------------------------------
 # Live per-entry-point timing: HIP events recorded on the launch stream right around each C-ABI call of an EAGER step.
 # Every launch of a call is enqueued back to back on that stream, so the interval is the GPU time of the call's kernels.
-TIMED = ("fcn_pn_group_compact", "fcn_pn_forward", "fcn_convnet_pack", "fcn_convnet_forward2", "fcn_det_loss_tail_rows3",
-         "fcn_convnet_backward", "fcn_pn_backward2", "fcn_adam_step_f32")
+TIMED = ("fcn_pn_group_compact", "fcn_pn_forward", "fcn_convnet_pack", "fcn_convnet_forward2", "fcn_det_loss_tail_rows2",
+         "fcn_det_iou_metrics", "fcn_convnet_backward", "fcn_pn_backward2", "fcn_adam_step_f32")
 
 
 class CallTimer:
@@ -134,7 +134,7 @@ def kernel_table(model, state, data, optim, prec, reps=5):
     for rep in range(reps + 1):
         with CallTimer(lib) as ct:
             losses, _ = model(data)
-            losses["total_loss"].backward()
+            model.backward(losses["total_loss"])
             if optim:
                 state.adam_step()
             torch.cuda.synchronize()
@@ -307,10 +307,7 @@ def main():
 
     def fwd_bwd():
         losses, _ = model(data)
-        if model.split_backward:
-            model.backward_split(losses["total_loss"])
-        else:
-            losses["total_loss"].backward()
+        model.backward(losses["total_loss"])          # == loss.backward(), seeded with a cached unit gradient
         return losses["total_loss"]
 
     use_graph = not a.eager
@@ -341,7 +338,8 @@ def main():
                     loss = losses["total_loss"]
                     feats, leaves = model._split
                     model._split = None
-                    loss.backward()
+                    from frustum_convnet_amd.loss_fused import unit_grad
+                    loss.backward(gradient=unit_grad(loss.device))
                 with torch.cuda.graph(gB, pool=gA.pool(), capture_error_mode=mode):
                     torch.autograd.backward(list(feats), [l.grad for l in leaves])
                 graphs = (gA, gB)

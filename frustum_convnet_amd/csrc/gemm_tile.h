@@ -206,6 +206,19 @@ __device__ __forceinline__ void mma_chunk(const float *As, const float *Bs, int 
         default: { constexpr int MM = MM_BF16X1; CALL; } break;      \
     }
 
+// XCD-aware tile order (cdna guide T1).  Workgroup ids are dealt to the 8 XCDs round-robin and every XCD has its own 4 MB
+// L2: with the natural order the tiles that share operand rows land on eight different L2s (or on one L2 but a whole grid row
+// apart in time) and each pulls the shared operand through the fabric again.  Workgroup `id` takes tile
+// (id % 8) * ceil(n / 8) + id / 8: XCD k works through the CONTIGUOUS tile range k*per .. (k+1)*per-1 in order, so tiles
+// that are adjacent in that order (the column tiles of one row tile) run back to back on one L2.  -1: no tile (grid padding).
+// Speed only: nothing depends on the placement.
+__device__ __forceinline__ int fcn_xcd_tile(int id, int n)
+{
+    const int per = (n + 7) >> 3;
+    const int t = (id & 7) * per + (id >> 3);
+    return (t < n && (id >> 3) < per) ? t : -1;
+}
+
 // Row (M index inside the 32x32 tile) held by accumulator register `reg` of this lane.
 __device__ __forceinline__ int acc_row(int reg, int lh) { return (reg & 3) + 8 * (reg >> 2) + 4 * lh; }
 

@@ -75,6 +75,10 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
     // row-major variant: the workgroup's LT_THREADS gradient rows are staged here (odd stride: a thread writes its own
     // row without bank conflicts) and go out as coalesced 256-byte rows instead of 64 strided dwords per thread
     __shared__ float gS[LT_THREADS * 65];
+    // the row's regression logits and its gradient row are indexed with run-time bins (heading class, size cluster): as
+    // per-thread arrays they end up in scratch (320 B per lane, every access a trip to memory -- the kernel spent most of its
+    // 50 us there); as LDS rows (odd stride, conflict-free) dynamic indexing is free
+    __shared__ float gG[LT_THREADS * 65];
     const int tid = threadIdx.x;
     const int B = a.B, L2 = a.L2, R = B * L2;
     constexpr int NB = LT_NB, NS = LT_NS, NC = 3 + 2 * NB + 4 * NS;
@@ -133,21 +137,22 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
         }
         if (a.dcls) {
             if (a.ld) {
-                gS[tid * 65] = g0;
-                gS[tid * 65 + 1] = g1;
+                gG[tid * 65] = g0;
+                gG[tid * 65 + 1] = g1;
             } else {
                 a.dcls[((int64_t)b * 2 + 0) * L2 + l] = g0;
                 a.dcls[((int64_t)b * 2 + 1) * L2 + l] = g1;
             }
         }
-        float go[NC];
+        float *go = gG + tid * 65 + 2;
 #pragma unroll
-        for (int j = 0; j < NC; ++j) go[j] = 0.f;
+        for (int j = 0; j < 62; ++j) go[j] = 0.f;
         if (lab == 1) {
-            float o[NC];
+            if (!a.ld) {
 #pragma unroll
-            for (int j = 0; j < NC; ++j)
-                o[j] = a.ld ? gS[tid * 65 + 2 + j] : a.reg_raw[((int64_t)b * NC + j) * L2 + l];
+                for (int j = 0; j < NC; ++j) gS[tid * 65 + 2 + j] = a.reg_raw[((int64_t)b * NC + j) * L2 + l];
+            }
+            const float *o = gS + tid * 65 + 2;
             const float rx = a.ref2[((int64_t)b * 3 + 0) * L2 + l], ry = a.ref2[((int64_t)b * 3 + 1) * L2 + l],
                         rz = a.ref2[((int64_t)b * 3 + 2) * L2 + l];
             const float clx = a.box_center[b * 3], cly = a.box_center[b * 3 + 1], clz = a.box_center[b * 3 + 2];
@@ -269,11 +274,7 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
             }
         }
         if (a.ld) {
-            if (a.dcls) {
-#pragma unroll
-                for (int j = 0; j < NC; ++j) gS[tid * 65 + 2 + j] = go[j];
-                for (int j = 2 + NC; j < 64; ++j) gS[tid * 65 + j] = 0.f;
-            }
+            // (the gradient row already sits in gG)
         } else if (a.dreg) {
 #pragma unroll
             for (int j = 0; j < NC; ++j) a.dreg[((int64_t)b * NC + j) * L2 + l] = go[j];
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
         const int nrow = min(LT_THREADS, R - row0);
         for (int i = tid; i < nrow * 64; i += LT_THREADS) {
             const int rr = i >> 6, cc = i & 63;
-            if (cc < a.ld) a.dcls[(int64_t)(row0 + rr) * a.ld + cc] = gS[rr * 65 + cc];
+            if (cc < a.ld) a.dcls[(int64_t)(row0 + rr) * a.ld + cc] = gG[rr * 65 + cc];
         }
     }
     // ---- combine the workgroups: out[1..10] accumulate, out[15] (as int) is the arrival ticket; both were zeroed by the

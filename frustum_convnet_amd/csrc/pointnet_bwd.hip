@@ -118,7 +118,7 @@ struct DgradArgs {
     const float *dzcur;     // dz2 (B,cap,C2)     LAYER 2
     const float *coef;      // 5 x CRED
     const float *W;         // (CRED, CPREV) row-major = the conv weight (Cout,Cin)
-    float *dybuf;           // LAYER 3: dy3 (B,cap,C3) written by the blockIdx.y == 0 column block
+    float *dybuf;           // LAYER 3: dy3 (B,cap,C3) written by the first column block
     const float *yprev;     // LAYER 3: y2 (B,cap,C2)
     const float *bn_prev;   // scale, shift, mean, rstd of the previous layer's BN (width CPREV)
     const float *W1;        // LAYER 2: (C1,3)
@@ -151,8 +151,11 @@ void dgrad_kernel(DgradArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int lt = blockIdx.x / SUB, sub = blockIdx.x % SUB;
-    if (lt >= a.tiles[0]) return;
+    const int ny = a.CPREV / TN;                  // XCD order, column tiles fastest (see fcn_xcd_tile)
+    const int xt = fcn_xcd_tile(blockIdx.x, SUB * a.tiles[0] * ny);
+    if (xt < 0) return;
+    const int bxi = xt / ny, byi = xt % ny;
+    const int lt = bxi / SUB, sub = bxi % SUB;
     const int code = a.tiles[4 + lt];
     const int b = code / a.tps, t = code % a.tps;
     const int nent = a.woff[(int64_t)b * (a.L + 1) + a.L];
@@ -160,7 +163,7 @@ void dgrad_kernel(DgradArgs a)
     const int nvalid = min(TM, nent - row0);
     if (nvalid <= 0) return;
     const int64_t grow0 = (int64_t)b * a.cap + row0;
-    const int k0 = blockIdx.y * TN;               // first output column (channel of the previous layer)
+    const int k0 = byi * TN;                      // first output column (channel of the previous layer)
     const int CRED = a.CRED, CPREV = a.CPREV;
 
     for (int i = tid; i < 5 * CRED; i += NTHR) coefS[i] = a.coef[i];
@@ -232,7 +235,7 @@ void dgrad_kernel(DgradArgs a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) As[(4 * kq + j) * LDA + r] = ev[j];
             if constexpr (LAYER == 3) {
-                if (ok && blockIdx.y == 0)
+                if (ok && byi == 0)
                     *(float4 *)(a.dybuf + (grow0 + r) * CRED + c * KC + 4 * kq) =
                         make_float4(dv[0], dv[1], dv[2], dv[3]);
             }
@@ -582,10 +585,10 @@ static int launch_dgrad(const DgradArgs &a, int B, int precision, hipStream_t st
     const unsigned nt = (unsigned)(B * a.tps);
     if (a.CPREV % 128 == 0) {          // 64 x 128 tiles, two workgroups per listed 128-row tile
         FCN_MM_SWITCH(FCN_MM_OF(precision, false),
-                      hipLaunchKernelGGL((dgrad_kernel<MM, LAYER, 1, 2, 2>), dim3(2 * nt, a.CPREV / 128), dim3(256), 0, st, a));
+                      hipLaunchKernelGGL((dgrad_kernel<MM, LAYER, 1, 2, 2>), dim3((2 * nt * (a.CPREV / 128) + 7) / 8 * 8), dim3(256), 0, st, a));
     } else {                            // 64 x 64 tiles (the 64-channel layers of scales 1 and 2: few column tiles)
         FCN_MM_SWITCH(FCN_MM_OF(precision, false),
-                      hipLaunchKernelGGL((dgrad_kernel<MM, LAYER, 1, 1, 2>), dim3(2 * nt, a.CPREV / 64), dim3(256), 0, st, a));
+                      hipLaunchKernelGGL((dgrad_kernel<MM, LAYER, 1, 1, 2>), dim3((2 * nt * (a.CPREV / 64) + 7) / 8 * 8), dim3(256), 0, st, a));
     }
     FCN_CHECK_LAUNCH();
     return 0;

@@ -124,8 +124,13 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int lt = blockIdx.x / SUB, sub = blockIdx.x % SUB;
-    if (lt >= a.tiles[0]) return;
+    // live (row tile, column tile) pairs in XCD order, column tiles fastest: the workgroups that stage the same rows run
+    // back to back on one L2
+    const int ny = a.COUT / TN;
+    const int xt = fcn_xcd_tile(blockIdx.x, SUB * a.tiles[0] * ny);
+    if (xt < 0) return;
+    const int bxi = xt / ny, byi = xt % ny;
+    const int lt = bxi / SUB, sub = bxi % SUB;
     const int code = a.tiles[4 + lt];
     const int b = code / a.tps, t = code % a.tps;
     const int nent = a.woff[(int64_t)b * (a.L + 1) + a.L];
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
     const int nvalid = min(TM, nent - row0);
     if (nvalid <= 0) return;
     const int64_t grow0 = (int64_t)b * a.cap + row0;
-    const int n0 = blockIdx.y * TN;
+    const int n0 = byi * TN;
     const int CIN = a.CIN, COUT = a.COUT;
 
     for (int i = tid; i < CIN; i += NTHR) {
@@ -340,18 +345,20 @@ __global__ __launch_bounds__(GT) void pool_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+static inline unsigned pad8(unsigned n) { return (n + 7u) / 8u * 8u; }
+
 template <int MM, int MODE>
 static int launch_fwd_gemm_mm(const FwdArgs &a, int B, hipStream_t st)
 {
     const unsigned nt = (unsigned)(B * a.tps);
     if (FCN_WIDE_TILES && a.COUT % 256 == 0) {
-        hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 2, 4>), dim3(nt, a.COUT / 256), dim3(512), 0, st, a);
+        hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 2, 4>), dim3(pad8(nt * (a.COUT / 256))), dim3(512), 0, st, a);
     } else if (MODE == 1 && a.COUT >= 512 && a.COUT % 128 == 0) {      // the widest conv3: 64 x 128 tiles
-        hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 2, 2, 1>), dim3(2 * nt, a.COUT / 128), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 2, 2, 1>), dim3(pad8(2 * nt * (a.COUT / 128))), dim3(256), 0, st, a);
     } else if (a.COUT % 128 == 0) {
-        hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 2, 2>), dim3(nt, a.COUT / 128), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 2, 2>), dim3(pad8(nt * (a.COUT / 128))), dim3(256), 0, st, a);
     } else {
-        hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 1, 2>), dim3(nt, a.COUT / 64), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 1, 2>), dim3(pad8(nt * (a.COUT / 64))), dim3(256), 0, st, a);
     }
     FCN_CHECK_LAUNCH();
     return 0;

@@ -340,15 +340,24 @@ class PointNetDet(nn.Module):
         keep, cnt = fdet.rotate_nms_3d(dets, valid, unit_group, L2, num_groups, thresh if method == 'nms' else 2.0, top_k)
         return dets, valid, keep, cnt
 
+    def backward(self, loss):
+        """loss.backward() seeded with a cached unit gradient (loss_fused.unit_grad): two tiny kernels (ones fill, multiply by
+        one) less between the loss tail and the first backward GEMM.  Same gradients."""
+        from .loss_fused import unit_grad
+        if self._split is not None:
+            return self.backward_split(loss)
+        loss.backward(gradient=unit_grad(loss.device))
+
     def backward_split(self, loss, between=None):
         """loss.backward() in two phases (needs split_backward = True at forward time): phase 1 differentiates the loss
         tail, heads and ConvFeatNet (their parameter gradients are final when it returns), `between()` runs, phase 2
         differentiates the PointNet scales.  Numerically identical to loss.backward()."""
         if self._split is None:
             raise RuntimeError("backward_split needs a training forward with model.split_backward = True")
+        from .loss_fused import unit_grad
         feats, leaves = self._split
         self._split = None
-        loss.backward()
+        loss.backward(gradient=unit_grad(loss.device))
         if between is not None:
             between()
         torch.autograd.backward(list(feats), [l.grad for l in leaves])
