@@ -54,9 +54,14 @@ class InpDesc(ctypes.Structure):
                 ("random_flip", ctypes.c_int32), ("random_shift", ctypes.c_int32)]
 
 
+class InpRefineDesc(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("pt_stride", ctypes.c_int32), ("Lpad", ctypes.c_int32 * 4),
+                ("stride", ctypes.c_double * 4), ("random_flip", ctypes.c_int32), ("random_shift", ctypes.c_int32)]
+
+
 EXPORTS = ("fcn_arch", "fcn_query_depth_point_f32", "fcn_pn_wgrad_rows", "fcn_pn_compact", "fcn_pn_group_compact",
            "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_det_loss_tail_rows2", "fcn_det_iou_metrics",
-           "fcn_det_loss_tail_scratch_floats", "fcn_adam_step_f32", "fcn_adam_step_slots", "fcn_prepare_inputs", "fcn_stamp",
+           "fcn_det_loss_tail_scratch_floats", "fcn_adam_step_f32", "fcn_adam_step_slots", "fcn_prepare_inputs", "fcn_prepare_inputs_refine", "fcn_stamp",
            "fcn_convnet_sizes", "fcn_convnet_pack", "fcn_convnet_forward", "fcn_convnet_forward2",
            "fcn_convnet_backward", "fcn_box3d_iou_pair_f32", "fcn_decode_detections", "fcn_rotate_nms_3d")
 
@@ -110,6 +115,8 @@ def lib():
     L.fcn_adam_step_f32.argtypes = [c_fp] * 4 + [ctypes.c_int64] + [c_fp] * 3
     L.fcn_prepare_inputs.restype = ctypes.c_int
     L.fcn_prepare_inputs.argtypes = [ctypes.POINTER(InpDesc)] + [c_fp] * 13 + [c_fp * 4] + [c_fp] * 7
+    L.fcn_prepare_inputs_refine.restype = ctypes.c_int
+    L.fcn_prepare_inputs_refine.argtypes = [ctypes.POINTER(InpRefineDesc)] + [c_fp] * 12 + [c_fp * 4] + [c_fp] * 8
     L.fcn_stamp.restype = ctypes.c_int
     L.fcn_stamp.argtypes = [c_fp, c_fp]
     L.fcn_adam_step_slots.restype = ctypes.c_int64

@@ -198,12 +198,6 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     const int kq = gt & 7, rb = gt >> 3;      // rb: 0..31 (MW=2) or 0..15 (MW=1)
     constexpr int RSTEP = TG / 8;
     const int nchunk = L.Ktot / KC, nit = (nchunk + G - 1) / G;
-    if (tid < nchunk) {
-        int sg, tap, k0, so;
-        cg_locate(L, tid * KC, sg, tap, k0, so);
-        cSeg[tid] = sg; cTap[tid] = tap; cK0[tid] = k0;
-    }
-    cg_fill_bn(L, sS, tS, tid, NTHR, bx == 0 && by == 0);
     // segment fields as scalars (static indices)
     const float *x0 = opaque_s(L.seg[0].x), *x1 = opaque_s(L.seg[1].x), *x2 = opaque_s(L.seg[2].x);
     const int C0 = opaque_s(L.seg[0].C), C1 = opaque_s(L.seg[1].C), C2 = opaque_s(L.seg[2].C);
@@ -233,9 +227,14 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     // the chunk (hence the segment) is uniform within a K-group, i.e. within every wave: scalar selects
 #define CGK_FWD_LOAD(cc, RA, RW, OK)                                                                                  \
     {                                                                                                                 \
+        const int c__ = (cc);                                                                                         \
+        CGK_FWD_LOAD_AT(c__, __builtin_amdgcn_readfirstlane(cSeg[c__]), __builtin_amdgcn_readfirstlane(cTap[c__]),    \
+                        __builtin_amdgcn_readfirstlane(cK0[c__]), RA, RW, OK);                                        \
+    }
+#define CGK_FWD_LOAD_AT(cc, SG, TAP, K0, RA, RW, OK)                                                                  \
+    {                                                                                                                 \
         const int c_ = (cc);                                                                                          \
-        const int sgi = __builtin_amdgcn_readfirstlane(cSeg[c_]);                                                     \
-        const int tap = __builtin_amdgcn_readfirstlane(cTap[c_]), k0 = __builtin_amdgcn_readfirstlane(cK0[c_]);       \
+        const int sgi = (SG), tap = (TAP), k0 = (K0);                                                                 \
         const float *x = SEL3(sgi, x0, x1, x2);                                                                       \
         const int C = SEL3(sgi, C0, C1, C2), ty = SEL3(sgi, T0, T1, T2), Ls = SEL3(sgi, Q0, Q1, Q2);                  \
         _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                                \
@@ -249,7 +248,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                              \
             const int r = rb + RSTEP * i;                                                                             \
             float e_[4];                                                                                              \
-            enc4<MM>(cg_act(sp[0], RA[i].x, tp[0], OK[i]), cg_act(sp[1], RA[i].y, tp[1], OK[i]),                      \
+            enc4<MM_ENC_A>(cg_act(sp[0], RA[i].x, tp[0], OK[i]), cg_act(sp[1], RA[i].y, tp[1], OK[i]),                      \
                      cg_act(sp[2], RA[i].z, tp[2], OK[i]), cg_act(sp[3], RA[i].w, tp[3], OK[i]), e_);                 \
             As[(4 * kq + 0) * LDA + r] = e_[0]; As[(4 * kq + 1) * LDA + r] = e_[1];                                   \
             As[(4 * kq + 2) * LDA + r] = e_[2]; As[(4 * kq + 3) * LDA + r] = e_[3];                                   \
@@ -257,7 +256,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                              \
             const int n = rb + RSTEP * i;                                                                             \
             float e_[4];                                                                                              \
-            enc4<MM>(RW[i].x, RW[i].y, RW[i].z, RW[i].w, e_);                                                         \
+            enc4<MM_ENC_W>(RW[i].x, RW[i].y, RW[i].z, RW[i].w, e_);                                                         \
             Bs[(4 * kq + 0) * LDC + n] = e_[0]; Bs[(4 * kq + 1) * LDC + n] = e_[1];                                   \
             Bs[(4 * kq + 2) * LDC + n] = e_[2]; Bs[(4 * kq + 3) * LDC + n] = e_[3];                                   \
         }                                                                                                             \
@@ -272,9 +271,26 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         if (act) mma_chunk<MM, 1, 1, LDA, LDC>(As, Bs, wm * 32, wn * 32, acc);                                    \
         __syncthreads();                                                                                              \
     }
+    // The first two chunks of this K-group are requested BEFORE the prologue: they depend on neither the BatchNorm
+    // statistics nor the LDS tables (their (segment, tap, channel) comes straight from cg_locate), so their trip to L2 / HBM
+    // overlaps the fp64 finalisation below instead of following it -- one memory latency per layer off a 25-launch chain
+    {
+        int sg_, tap_, k0_, so_;
+        const int ca = min(g, nchunk - 1), cb = min(g + G, nchunk - 1);
+        cg_locate(L, ca * KC, sg_, tap_, k0_, so_);
+        CGK_FWD_LOAD_AT(ca, __builtin_amdgcn_readfirstlane(sg_), __builtin_amdgcn_readfirstlane(tap_),
+                        __builtin_amdgcn_readfirstlane(k0_), ra0, rw0, ok0);
+        cg_locate(L, cb * KC, sg_, tap_, k0_, so_);
+        CGK_FWD_LOAD_AT(cb, __builtin_amdgcn_readfirstlane(sg_), __builtin_amdgcn_readfirstlane(tap_),
+                        __builtin_amdgcn_readfirstlane(k0_), ra1, rw1, ok1);
+    }
+    if (tid < nchunk) {
+        int sg, tap, k0, so;
+        cg_locate(L, tid * KC, sg, tap, k0, so);
+        cSeg[tid] = sg; cTap[tid] = tap; cK0[tid] = k0;
+    }
+    cg_fill_bn(L, sS, tS, tid, NTHR, bx == 0 && by == 0);
     __syncthreads();                            // sS / tS and the chunk table ready
-    CGK_FWD_LOAD(min(g, nchunk - 1), ra0, rw0, ok0);
-    CGK_FWD_LOAD(min(g + G, nchunk - 1), ra1, rw1, ok1);
     for (int it = 0; it < nit; it += 2) {
         CGK_FWD_ITER(it, ra0, rw0, ok0);
         if (it + 1 < nit) CGK_FWD_ITER(it + 1, ra1, rw1, ok1);
@@ -534,14 +550,6 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
     const int kq = gt & 7, rb = gt >> 3;
     constexpr int RSTEP = TG / 8;
     const bool hasbn = cb.bstat != nullptr;
-    if (hasbn) {
-        for (int c = tid; c < Cs; c += NTHR) {
-            float cf[5];
-            cg_bnbwd_coef(cb, Cs, c, cf, pub);
-#pragma unroll
-            for (int q = 0; q < 5; ++q) coefS[q * Cs + c] = cf[q];
-        }
-    }
     int bb[NA], li[NA];
     bool rv[NA], ok[NA];
 #pragma unroll
@@ -576,11 +584,14 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
             ok_t[i][t3] = rv[i] && t3 < L.KT && t >= 0 && (t % L.stride) == 0 && lo < L.Lout;
             lo_t[i][t3] = min(max(lo, 0), L.Lout - 1);
         }
-    __syncthreads();                            // chunk table (and coefS) ready
 #define CGK_DGRAD_LOAD(cc)                                                                                            \
     {                                                                                                                 \
-        const int c_ = (cc);                                                                                          \
-        const int tap = __builtin_amdgcn_readfirstlane(cTap[c_]), nb = __builtin_amdgcn_readfirstlane(cNb[c_]);       \
+        const int c__ = (cc);                                                                                         \
+        CGK_DGRAD_LOAD_AT(__builtin_amdgcn_readfirstlane(cTap[c__]), __builtin_amdgcn_readfirstlane(cNb[c__]));       \
+    }
+#define CGK_DGRAD_LOAD_AT(TAP, NBASE)                                                                                 \
+    {                                                                                                                 \
+        const int tap = (TAP), nb = (NBASE);                                                                          \
         _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                              \
             ok[i] = SEL3(tap, ok_t[i][0], ok_t[i][1], ok_t[i][2]);                                                    \
             const int lo = SEL3(tap, lo_t[i][0], lo_t[i][1], lo_t[i][2]);                                             \
@@ -594,7 +605,21 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
             rw[i] = ldg4(L.Wp + (int64_t)(nb + nn) * L.Ktot + segoff + tap * C + c0 + 4 * cq);                        \
         }                                                                                                             \
     }
-    CGK_DGRAD_LOAD(min(g, nchunk - 1));
+    // first chunk requested BEFORE the coefficient prologue (it depends on neither the BN-backward sums nor the LDS tables):
+    // its memory latency overlaps the prologue's
+    {
+        const int c1 = min(g, nchunk - 1);
+        CGK_DGRAD_LOAD_AT(__builtin_amdgcn_readfirstlane(c1 / ncn), __builtin_amdgcn_readfirstlane((c1 % ncn) * KC));
+    }
+    if (hasbn) {
+        for (int c = tid; c < Cs; c += NTHR) {
+            float cf[5];
+            cg_bnbwd_coef(cb, Cs, c, cf, pub);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) coefS[q * Cs + c] = cf[q];
+        }
+    }
+    __syncthreads();                            // chunk table and coefS ready
     for (int it = 0; it < nit; ++it) {
         const int c = it * G + g;
         const bool act = c < nchunk;
@@ -611,7 +636,7 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
                     d[j] = ok[i] ? d[j] : 0.f;
                 }
                 float e_[4];
-                enc4<MM>(d[0], d[1], d[2], d[3], e_);
+                enc4<MM_ENC_A>(d[0], d[1], d[2], d[3], e_);
                 As[(4 * kq + 0) * LDA + r] = e_[0]; As[(4 * kq + 1) * LDA + r] = e_[1];
                 As[(4 * kq + 2) * LDA + r] = e_[2]; As[(4 * kq + 3) * LDA + r] = e_[3];
             }
@@ -619,7 +644,7 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
             for (int i = 0; i < NB; i += 2) {
                 const int f = gt + TG * (i >> 1);
                 v4f hi, lo;
-                enc2x4<MM>(rw[i], rw[i + 1], hi, lo);
+                enc2x4<MM_ENC_W>(rw[i], rw[i + 1], hi, lo);
                 sts4(Bs + (2 * (f >> 4)) * LDN + 4 * (f & 15), hi);
                 sts4(Bs + (2 * (f >> 4) + 1) * LDN + 4 * (f & 15), lo);
             }
@@ -781,10 +806,10 @@ __device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float
                 av2[i] = av;
             }
             v4f hi, lo;
-            enc2x4<MM>(dv2[0], dv2[1], hi, lo);
+            enc2x4<MM_ENC_A>(dv2[0], dv2[1], hi, lo);
             sts4(As + rr0 * LDN + 4 * cq, hi);
             sts4(As + (rr0 + 1) * LDN + 4 * cq, lo);
-            enc2x4<MM>(av2[0], av2[1], hi, lo);
+            enc2x4<MM_ENC_A>(av2[0], av2[1], hi, lo);
             sts4(Bs + rr0 * LDN + 4 * cq, hi);
             sts4(Bs + (rr0 + 1) * LDN + 4 * cq, lo);
         }

@@ -196,11 +196,25 @@ __global__ __launch_bounds__(GE_T) void gc_entries_kernel(GcArgs a)
     if (!last_s) return;
 
     // ======== the last frustum of this scale
-    if (tid < 10) {                            // moments in frustum order (fixed order: reproducible bit for bit)
-        double v = 0.0;
-        for (int q = 0; q < a.B; ++q) v += __hip_atomic_load(&S.gmom[(int64_t)q * GC_MOM + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        S.stat[FCN_STAT_MOM + tid] = v;
-        red[0][tid] = v;
+    // moments in frustum order (fixed order: reproducible bit for bit).  All B x 10 values are fetched in parallel into LDS
+    // first -- a serial chain of B agent-scope loads cost ~20 us here
+    {
+        double *gm = (double *)smem;                                       // (cntS / offS / cS are dead by now)
+        const int nv = a.B * GC_MOM;
+        const int cap = (int)(((size_t)(2 * L + 1) * sizeof(int) + (size_t)3 * L * sizeof(float)) / sizeof(double));
+        const bool fits = nv <= cap;
+        __syncthreads();
+        if (fits)
+            for (int i = tid; i < nv; i += GE_T) gm[i] = __hip_atomic_load(&S.gmom[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (tid < 10) {
+            double v = 0.0;
+            for (int q = 0; q < a.B; ++q)
+                v += fits ? gm[q * GC_MOM + tid]
+                          : __hip_atomic_load(&S.gmom[(int64_t)q * GC_MOM + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            S.stat[FCN_STAT_MOM + tid] = v;
+            red[0][tid] = v;
+        }
     }
     // BN sum slots of the conv launches that follow
     for (int i = 10 + tid; i < 16 + 2 * S.C2 + 2 * S.C3; i += GE_T) S.stat[i] = 0.0;

@@ -152,3 +152,165 @@ extern "C" int fcn_prepare_inputs(const fcn_inp_desc *d, const float *raw_pts, c
     FCN_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Refinement stage (cfgs/refine_car.yaml; datasets/provider_sample_refine.py::ProviderDataset.__getitem__ :176-315 with
+// get_center_view_point / _box3d :137-152, generate_ref :336-386, generate_labels :317-334, and collate_fn :388-419).  The
+// sample is normalised to the FIRST-STAGE PREDICTION: points and label box are translated to the predicted box centre and
+// rotated by its heading; the window centres span the predicted box's own depth extent -- in that frame the box is
+// axis-aligned at the origin, so they are (0, 0, -w/2 + l*s + s/2) for l < ceil(w / s) (np.arange(z1, z2, s)) -- a different
+// count per sample, which the reference's collate_fn pads by repeating the last centre / label up to the batch maximum
+// (Lpad, handed in by the caller).  Positive / ignore boxes are the label box scaled by 0.3 / 0.6.
+struct InpRefineArgs {
+    fcn_inp_refine_desc d;
+    const float *raw;
+    const int64_t *off;
+    const int32_t *choice;
+    const double *pred_corners, *pred_angle, *pred_size, *corners, *heading, *size, *coin, *normal;
+    float *pc, *ref[4];
+    int64_t *cls;
+    float *center, *head, *osize, *rot, *refc;
+    int32_t *lens;
+};
+
+__global__ __launch_bounds__(INP_T) void prepare_inputs_refine_kernel(InpRefineArgs a)
+{
+    __shared__ double sdist[INP_T];
+    __shared__ int sidx[INP_T];
+    __shared__ int sany;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int N = a.d.N;
+    const double *pcn = a.pred_corners + (int64_t)b * 24;
+    const double pcx = (pcn[0] + pcn[18]) / 2.0, pcy = (pcn[1] + pcn[19]) / 2.0, pcz = (pcn[2] + pcn[20]) / 2.0;
+    const double rot = a.pred_angle[b];
+    const double c = cos(rot), s = sin(rot);
+    const bool train = a.corners != nullptr;
+    const bool flip = train && a.d.random_flip && a.coin[b] > 0.5;
+    double cx = 0.0, cy = 0.0, cz = 0.0, ang = 0.0, sl = 0.0, sw = 0.0, sh = 0.0, shift = 0.0;
+    if (train) {
+        const double *cr = a.corners + (int64_t)b * 24;
+        const double dx = (cr[0] + cr[18]) / 2.0 - pcx, dy = (cr[1] + cr[19]) / 2.0 - pcy, dz = (cr[2] + cr[20]) / 2.0 - pcz;
+        cx = dx * c + dz * (-s); cy = dy; cz = dx * s + dz * c;
+        ang = a.heading[b] - rot;
+        if (flip) { cx = -cx; ang = M_PI - ang; }
+        sl = a.size[3 * b]; sw = a.size[3 * b + 1]; sh = a.size[3 * b + 2];
+        if (a.d.random_shift) {
+            const double dist = sqrt(sl * sl + sw * sw), s1 = a.d.stride[0];
+            shift = fmin(fmax(a.normal[b] * dist * 0.1, -2.0 * s1), 2.0 * s1);
+            cz += shift;
+        }
+    }
+    if (tid == 0) {
+        if (train) {
+            a.center[3 * b] = (float)cx; a.center[3 * b + 1] = (float)cy; a.center[3 * b + 2] = (float)cz;
+            a.head[b] = (float)ang;
+            a.osize[3 * b] = (float)sl; a.osize[3 * b + 1] = (float)sw; a.osize[3 * b + 2] = (float)sh;
+        }
+        a.rot[b] = (float)rot;
+        a.refc[3 * b] = (float)pcx; a.refc[3 * b + 1] = (float)pcy; a.refc[3 * b + 2] = (float)pcz;
+    }
+    // ---- points: (p - centre) rotated by the predicted heading, stored as float32
+    const int64_t o0 = a.off[b];
+    const int ps = a.d.pt_stride;
+    for (int i = tid; i < N; i += INP_T) {
+        const int64_t j = o0 + a.choice[(int64_t)b * N + i];
+        const float *p = a.raw + j * ps;
+        const double x = (double)p[0] - pcx, y = (double)p[1] - pcy, z = (double)p[2] - pcz;
+        float xr = (float)(x * c + z * (-s));
+        float zr = (float)(x * s + z * c);
+        if (flip) xr = -xr;
+        if (train && a.d.random_shift) zr = (float)((double)zr + shift);
+        float *o = a.pc + (int64_t)b * 3 * N;
+        o[i] = xr; o[N + i] = (float)y; o[2 * N + i] = zr;
+    }
+    // ---- window centres over the predicted box's depth extent, edge-padded to Lpad; labels on stride 2
+    const double w = a.pred_size[3 * b + 1];
+    const double z1 = -w / 2.0, z2 = w / 2.0;
+    const double ca = cos(ang), sa = sin(ang);
+    double best = 1e300;
+    int bidx = 0x7fffffff;
+    bool any1 = false;
+    if (tid == 0) sany = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (int sc = 0; sc < 4; ++sc) {
+        const int Lp = a.d.Lpad[sc];
+        const double st = a.d.stride[sc];
+        int Lb = (int)ceil((z2 - z1) / st);                         // len(np.arange(z1, z2, st))
+        Lb = Lb < 0 ? 0 : (Lb > Lp ? Lp : Lb);
+        if (tid == 0) a.lens[4 * b + sc] = Lb;
+        for (int l = tid; l < Lp; l += INP_T) {
+            const int le = l < Lb ? l : Lb - 1;                     // collate_fn: np.pad(..., mode='edge')
+            const double z = (z1 + (double)le * st) + st / 2.0;
+            const double xr = flip ? -0.0 : 0.0;
+            float *o = a.ref[sc] + (int64_t)b * 3 * Lp;
+            o[l] = (float)xr; o[Lp + l] = 0.f; o[2 * Lp + l] = (float)z;
+            if (sc == 1 && a.cls && l < Lb) {
+                const double dx = xr - cx, dy = 0.0 - cy, dz = z - cz;
+                const bool in1 = inp_in_box(dx, dy, dz, ca, sa, sl * 0.3, sw * 0.3, sh * 0.3);
+                const bool in2 = inp_in_box(dx, dy, dz, ca, sa, sl * 0.6, sw * 0.6, sh * 0.6);
+                a.cls[(int64_t)b * Lp + l] = in1 ? 1 : (in2 ? -1 : 0);
+                any1 = any1 || in1;
+                const double dd = sqrt(dx * dx + dy * dy + dz * dz);
+                if (dd < best) { best = dd; bidx = l; }
+            }
+        }
+    }
+    if (!a.cls) return;
+    if (any1) sany = 1;
+    sdist[tid] = best; sidx[tid] = bidx;
+    __syncthreads();
+    if (!sany) {
+        for (int o = INP_T / 2; o > 0; o >>= 1) {
+            if (tid < o) {
+                const double d2 = sdist[tid + o];
+                const int i2 = sidx[tid + o];
+                if (d2 < sdist[tid] || (d2 == sdist[tid] && i2 < sidx[tid])) { sdist[tid] = d2; sidx[tid] = i2; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0 && sidx[0] != 0x7fffffff) a.cls[(int64_t)b * a.d.Lpad[1] + sidx[0]] = 1;
+    }
+    __syncthreads();
+    __threadfence_block();
+    // edge padding of the labels: positions >= L_b repeat the last real one
+    {
+        const int Lp = a.d.Lpad[1];
+        int Lb = (int)ceil((z2 - z1) / a.d.stride[1]);
+        Lb = Lb < 0 ? 0 : (Lb > Lp ? Lp : Lb);
+        if (Lb > 0) {
+            const int64_t last = a.cls[(int64_t)b * Lp + Lb - 1];
+            for (int l = Lb + tid; l < Lp; l += INP_T) a.cls[(int64_t)b * Lp + l] = last;
+        }
+    }
+}
+
+extern "C" int fcn_prepare_inputs_refine(const fcn_inp_refine_desc *d, const float *raw_pts, const int64_t *pt_off,
+                                         const int32_t *choice, const double *pred_corners, const double *pred_angle,
+                                         const double *pred_size, const double *box3d_corners, const double *heading,
+                                         const double *size, const double *coin, const double *normal, float *point_cloud,
+                                         float *const center_ref[4], int64_t *cls_label, float *box3d_center,
+                                         float *box3d_heading, float *box3d_size, float *rot_angle, float *ref_center,
+                                         int32_t *lens, void *stream)
+{
+    if (!d || !raw_pts || !pt_off || !choice || !pred_corners || !pred_angle || !pred_size || !point_cloud || !center_ref ||
+        !rot_angle || !ref_center || !lens)
+        return FCN_E_BADARG;
+    if (d->B <= 0 || d->N <= 0 || d->pt_stride < 3) return FCN_E_BADARG;
+    const bool train = box3d_corners != nullptr;
+    if (train && (!heading || !size || !box3d_center || !box3d_heading || !box3d_size)) return FCN_E_BADARG;
+    if (!train && cls_label) return FCN_E_BADARG;
+    if (train && ((d->random_flip && !coin) || (d->random_shift && !normal))) return FCN_E_BADARG;
+    for (int s = 0; s < 4; ++s)
+        if (d->Lpad[s] <= 0 || !(d->stride[s] > 0.0) || !center_ref[s]) return FCN_E_BADARG;
+    InpRefineArgs a;
+    a.d = *d; a.raw = raw_pts; a.off = pt_off; a.choice = choice; a.pred_corners = pred_corners; a.pred_angle = pred_angle;
+    a.pred_size = pred_size; a.corners = box3d_corners; a.heading = heading; a.size = size; a.coin = coin; a.normal = normal;
+    a.pc = point_cloud;
+    for (int s = 0; s < 4; ++s) a.ref[s] = center_ref[s];
+    a.cls = cls_label; a.center = box3d_center; a.head = box3d_heading; a.osize = box3d_size; a.rot = rot_angle;
+    a.refc = ref_center; a.lens = lens;
+    hipLaunchKernelGGL(prepare_inputs_refine_kernel, dim3(d->B), dim3(INP_T), 0, (hipStream_t)stream, a);
+    FCN_CHECK_LAUNCH();
+    return 0;
+}

@@ -231,7 +231,7 @@ void dgrad_kernel(DgradArgs a)
                 const float dy = coefS[n] * (dz - w * fmaf(xh, coefS[4 * CRED + n], coefS[3 * CRED + n]));
                 dv[j] = ok ? dy : 0.f;
             }
-            enc4<MM>(dv[0], dv[1], dv[2], dv[3], ev);
+            enc4<MM_ENC_A>(dv[0], dv[1], dv[2], dv[3], ev);
 #pragma unroll
             for (int j = 0; j < 4; ++j) As[(4 * kq + j) * LDA + r] = ev[j];
             if constexpr (LAYER == 3) {
@@ -245,7 +245,7 @@ void dgrad_kernel(DgradArgs a)
             const int f = tid + NTHR * (i >> 1);
             const int nn = 2 * (f / (TN / 4)), cq = f % (TN / 4);
             v4f hi, lo;
-            enc2x4<MM>(rw[i], rw[i + 1], hi, lo);
+            enc2x4<MM_ENC_W>(rw[i], rw[i + 1], hi, lo);
             sts4(Bs + nn * LDB + 4 * cq, hi);
             sts4(Bs + (nn + 1) * LDB + 4 * cq, lo);
         }
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
 #pragma unroll
         for (int i = 0; i < 2 * MT; i += 2) {
             v4f hi, lo;
-            enc2x4<MM>(sa[i], sa[i + 1], hi, lo);
+            enc2x4<MM_ENC_A>(sa[i], sa[i + 1], hi, lo);
             sts4(As + WG_AROW(i) * LDA + 4 * acq, hi);
             sts4(As + WG_AROW(i + 1) * LDA + 4 * acq, lo);
         }
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
 #pragma unroll
         for (int i = 0; i < 2 * NT; i += 2) {
             v4f hi, lo;
-            enc2x4<MM>(sb[i], sb[i + 1], hi, lo);
+            enc2x4<MM_ENC_A>(sb[i], sb[i + 1], hi, lo);
             sts4(Bs + WG_BROW(i) * LDB + 4 * bcq, hi);
             sts4(Bs + WG_BROW(i + 1) * LDB + 4 * bcq, lo);
         }

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
                     z[j] = fmaf(sS[c * KC + k], v[j], tS[c * KC + k]);
                     z[j] = ok ? fmaxf(z[j], 0.f) : 0.f;
                 }
-                enc4<MM>(z[0], z[1], z[2], z[3], e);
+                enc4<MM_ENC_A>(z[0], z[1], z[2], z[3], e);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) As[(4 * kq + j) * LDA + r] = e[j];
             }
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
                 const float z0 = l1_pre(&sS[3 * kk], tS[kk], ux, uy, uz);
                 const float z1 = l1_pre(&sS[3 * kk + 3], tS[kk + 1], ux, uy, uz);
                 float e0, e1;
-                enc2<MM>(r0valid ? fmaxf(z0, 0.f) : 0.f, r0valid ? fmaxf(z1, 0.f) : 0.f, e0, e1);
+                enc2<MM_ENC_A>(r0valid ? fmaxf(z0, 0.f) : 0.f, r0valid ? fmaxf(z1, 0.f) : 0.f, e0, e1);
                 As[k * LDA + r0] = e0;
                 As[(k + 1) * LDA + r0] = e1;
             }
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
             const int f = tid + NTHR * i;
             const int n = f >> 3, kq = f & 7;
             float v[4];
-            enc4<MM>(rw[i].x, rw[i].y, rw[i].z, rw[i].w, v);
+            enc4<MM_ENC_W>(rw[i].x, rw[i].y, rw[i].z, rw[i].w, v);
 #pragma unroll
             for (int j = 0; j < 4; ++j) Bs[(4 * kq + j) * LDB + n] = v[j];
         }
@@ -344,6 +344,76 @@ __global__ __launch_bounds__(GT) void pool_kernel(
     }
 }
 
+// Position-major pooling (the fused path: feat (B, L, C3) feeds the ConvFeatNet GEMMs directly).  One wave per window over
+// ALL C3 channels: lane = C3/64 consecutive channels, so a row is one fully coalesced C3*4-byte read per wave (the 64-channel
+// slices of pool_kernel kept only 256 B per row in flight: 2.1 TB/s on the widest scale) and UN rows are in flight at once.
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <int VEC>
+__global__ __launch_bounds__(GT) void pool_nlc_kernel(
+    const float *__restrict__ y3, const float *__restrict__ bn3, const int32_t *__restrict__ woff,
+    const int32_t *__restrict__ cnt, float *__restrict__ feat, int32_t *__restrict__ amax, int L, int cap, int C3,
+    double *__restrict__ zero_ptr, int zero_n)
+{
+    constexpr int UN = VEC >= 8 ? 4 : 8;          // rows in flight per lane
+    // the BN-backward sum buffer of this scale is zeroed by the last forward kernel: no memset node heading the backward
+    if (zero_ptr && blockIdx.z == 0)
+        for (int i = blockIdx.x * GT + threadIdx.x; i < zero_n; i += gridDim.x * GT) zero_ptr[i] = 0.0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, l = blockIdx.x * PW + wave;
+    if (l >= L) return;
+    const int c = lane * VEC;
+    float s[VEC], t[VEC], best[VEC];
+    int arg[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { s[v] = bn3[c + v]; t[v] = bn3[C3 + c + v]; best[v] = 0.f; arg[v] = -1; }
+    if (cnt[(int64_t)b * L + l] > 0) {
+        const int32_t *wo = woff + (int64_t)b * (L + 1);
+        const int o0 = wo[l], o1 = wo[l + 1];
+        const float *yp = y3 + ((int64_t)b * cap + o0) * C3 + c;
+        int r = o0;
+        // compared in row order: the first maximum wins, like torch.max
+        for (; r + UN <= o1; r += UN, yp += UN * (int64_t)C3) {
+            float v[UN][VEC];
+#pragma unroll
+            for (int j = 0; j < UN; ++j) {
+                const float *q = yp + j * (int64_t)C3;
+                if constexpr (VEC == 2) {
+                    const v2f x = *(const v2f __attribute__((address_space(1))) *)q;
+                    v[j][0] = x.x; v[j][1] = x.y;
+                } else {
+#pragma unroll
+                    for (int h = 0; h < VEC / 4; ++h) {
+                        const v4f x = ldg4(q + 4 * h);
+                        v[j][4 * h] = x.x; v[j][4 * h + 1] = x.y; v[j][4 * h + 2] = x.z; v[j][4 * h + 3] = x.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < UN; ++j)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float u = fmaf(s[e], v[j][e], t[e]);
+                    if (u > best[e]) { best[e] = u; arg[e] = r + j; }
+                }
+        }
+        for (; r < o1; ++r, yp += C3) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float u = fmaf(s[e], yp[e], t[e]);
+                if (u > best[e]) { best[e] = u; arg[e] = r; }
+            }
+        }
+    }
+    float *fo = feat + ((int64_t)b * L + l) * C3 + c;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) fo[e] = best[e];
+    if (amax) {
+        int32_t *ao = amax + ((int64_t)b * L + l) * C3 + c;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) ao[e] = arg[e];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 static inline unsigned pad8(unsigned n) { return (n + 7u) / 8u * 8u; }
 
@@ -417,10 +487,19 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
                        d->momentum, M, bn3);
     FCN_CHECK_LAUNCH();
 
-    dim3 pgrid((L + PW - 1) / PW, C3 / 64, B);
-    hipLaunchKernelGGL(pool_kernel, pgrid, dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, one_hot, feat,
-                       tr ? ws->amax : nullptr, L, cap, C3, d->nvec, d->nlc, tr ? ws->bstat : nullptr,
-                       2 * C3 + 2 * C2 + 4 * C1);
+    const int nz = 2 * C3 + 2 * C2 + 4 * C1;
+    if (d->nlc && (C3 == 128 || C3 == 256 || C3 == 512)) {
+        dim3 pgrid((L + PW - 1) / PW, 1, B);
+        int32_t *am = tr ? ws->amax : nullptr;
+        double *zp = tr ? ws->bstat : nullptr;
+        if (C3 == 128) hipLaunchKernelGGL(pool_nlc_kernel<2>, pgrid, dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, feat, am, L, cap, C3, zp, nz);
+        else if (C3 == 256) hipLaunchKernelGGL(pool_nlc_kernel<4>, pgrid, dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, feat, am, L, cap, C3, zp, nz);
+        else hipLaunchKernelGGL(pool_nlc_kernel<8>, pgrid, dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, feat, am, L, cap, C3, zp, nz);
+    } else {
+        dim3 pgrid((L + PW - 1) / PW, C3 / 64, B);
+        hipLaunchKernelGGL(pool_kernel, pgrid, dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, one_hot, feat,
+                           tr ? ws->amax : nullptr, L, cap, C3, d->nvec, d->nlc, tr ? ws->bstat : nullptr, nz);
+    }
     FCN_CHECK_LAUNCH();
     return 0;
 }

@@ -112,3 +112,98 @@ def records_from_fixture(g):
                      "box3d": g["box3d_corners"][b], "heading": float(g["heading"][b]), "size": g["size"][b],
                      "frustum_angle": float(g["frustum_angle"][b]), "type": "Car"})
     return recs
+
+
+# ------------------------------------------------------------------------------------------------
+REFINE_KEYS = ("points", "box3d", "heading", "size", "pred_box3d", "pred_angle", "pred_size", "type")
+
+
+def draw_refine(counts, npoints, random_flip=True, random_shift=True, rng=np.random):
+    """The refine dataset's per-sample draws in its order (provider_sample_refine.py:209, :268, :282)."""
+    return draw(counts, npoints, random_flip, random_shift, rng)
+
+
+class RefineInputBuilder:
+    """Refinement-stage batches (cfgs/refine_car.yaml) from raw records + first-stage predictions, on the device
+    (C-ABI fcn_prepare_inputs_refine).  Mirrors datasets/provider_sample_refine.py::ProviderDataset.__getitem__ + collate_fn:
+    per-sample window counts differ, center_ref* / cls_label are edge-padded to the batch maximum.  The batch maxima
+    (tensor shapes) are decided on the host from the predicted box widths -- B numbers -- everything per point / per window
+    runs in the kernel."""
+
+    def __init__(self, npoints, strides=None, random_flip=False, random_shift=False, one_hot=True, device="cuda"):
+        self.npoints = int(npoints)
+        self.strides = tuple(float(s) for s in (cfg.DATA.STRIDE if strides is None else strides))
+        assert len(self.strides) == 4
+        self.random_flip, self.random_shift, self.one_hot = bool(random_flip), bool(random_shift), bool(one_hot)
+        self.device = torch.device(device)
+        self.classes = DATASET_INFO[cfg.DATA.DATASET_NAME].CLASSES
+
+    def build(self, records, draws=None, with_labels=True):
+        """records: dicts with REFINE_KEYS (points (n,>=3) float32 rect camera coordinates; box3d (8,3), heading, size (l,w,h)
+        of the label box; pred_box3d (8,3), pred_angle, pred_size of the first-stage prediction; type).  Returns the batch
+        dict on the device (+ 'lens' (B,4) int32: the per-sample window counts before padding)."""
+        if self.device.type != "cuda":
+            raise RuntimeError("frustum_convnet_amd: input construction is a HIP kernel (MI355X only); no CPU fallback")
+        from ._native import InpRefineDesc
+        B, N = len(records), self.npoints
+        counts = [len(r["points"]) for r in records]
+        if draws is None:
+            draws = draw_refine(counts, N, self.random_flip and with_labels, self.random_shift and with_labels)
+        choice, coin, normal = draws
+        stride = int(records[0]["points"].shape[1])
+        raw = np.concatenate([np.ascontiguousarray(r["points"], dtype=np.float32) for r in records], 0)
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        f64 = lambda k, shape: np.stack([np.asarray(r[k], dtype=np.float64).reshape(shape) for r in records])
+        psize = f64("pred_size", (3,))
+        # batch maxima of len(np.arange(-w/2, w/2, s)): the padded widths of the outputs
+        Lpad = [int(max(len(np.arange(-w / 2.0, w / 2.0, s)) for w in psize[:, 1])) for s in self.strides]
+        dev = self.device
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
+        t = {"raw": up(raw), "off": up(off), "choice": up(np.asarray(choice, dtype=np.int32)),
+             "pcorners": up(f64("pred_box3d", (24,))), "pangle": up(f64("pred_angle", ())), "psize": up(psize)}
+        if with_labels:
+            t.update(corners=up(f64("box3d", (24,))), heading=up(f64("heading", ())), size=up(f64("size", (3,))),
+                     coin=up(np.asarray(coin, dtype=np.float64)), normal=up(np.asarray(normal, dtype=np.float64)))
+        f32 = dict(dtype=torch.float32, device=dev)
+        out = {"point_cloud": torch.empty((B, 3, N), **f32), "rot_angle": torch.empty((B, 1), **f32),
+               "ref_center": torch.empty((B, 3), **f32), "lens": torch.empty((B, 4), dtype=torch.int32, device=dev)}
+        if with_labels:
+            out.update(cls_label=torch.empty((B, Lpad[1]), dtype=torch.int64, device=dev),
+                       box3d_center=torch.empty((B, 3), **f32), box3d_heading=torch.empty((B, 1), **f32),
+                       box3d_size=torch.empty((B, 3), **f32))
+        for s in range(4):
+            out["center_ref%d" % (s + 1)] = torch.empty((B, 3, Lpad[s]), **f32)
+        desc = InpRefineDesc(B, N, stride, (ctypes.c_int32 * 4)(*Lpad), (ctypes.c_double * 4)(*self.strides),
+                             1 if (self.random_flip and with_labels) else 0, 1 if (self.random_shift and with_labels) else 0)
+        refs = (ctypes.c_void_p * 4)(*[out["center_ref%d" % (s + 1)].data_ptr() for s in range(4)])
+        p = lambda x: None if x is None else x.data_ptr()
+        L = _native.lib()
+        with torch.cuda.device(dev):
+            _native.check(L.fcn_prepare_inputs_refine(
+                ctypes.byref(desc), p(t["raw"]), p(t["off"]), p(t["choice"]), p(t["pcorners"]), p(t["pangle"]), p(t["psize"]),
+                p(t.get("corners")), p(t.get("heading")), p(t.get("size")), p(t.get("coin")), p(t.get("normal")),
+                p(out["point_cloud"]), refs, p(out.get("cls_label")), p(out.get("box3d_center")), p(out.get("box3d_heading")),
+                p(out.get("box3d_size")), p(out["rot_angle"]), p(out["ref_center"]), p(out["lens"]),
+                _native.current_stream(dev)), "fcn_prepare_inputs_refine")
+        for v in t.values():
+            v.record_stream(torch.cuda.current_stream(dev))
+        size_class = [self.classes.index(r["type"]) for r in records]
+        if with_labels:
+            out["size_class"] = torch.tensor(size_class, dtype=torch.int64).view(B, 1).to(dev, non_blocking=True)
+        if self.one_hot:
+            oh = np.zeros((B, len(self.classes)), dtype=np.float32)
+            oh[np.arange(B), size_class] = 1.0
+            out["one_hot"] = up(oh)
+        return out
+
+
+def refine_records_from_fixture(g):
+    """tests/golden/inputs_refine_b6.npz (make_golden_inputs_refine.py) as a list of records."""
+    offs = np.concatenate([[0], np.cumsum(g["raw_counts"])])
+    recs = []
+    for b in range(len(g["raw_counts"])):
+        sl = slice(int(offs[b]), int(offs[b + 1]))
+        recs.append({"points": g["raw_points"][sl], "box3d": g["box3d_corners"][b], "heading": float(g["heading"][b]),
+                     "size": g["size"][b], "pred_box3d": g["pred_corners"][b], "pred_angle": float(g["pred_angle"][b]),
+                     "pred_size": g["pred_size"][b], "type": "Car"})
+    return recs

@@ -22,6 +22,7 @@
  *   fcn_adam_step_f32           optim.Adam.step() of the step loop, train/train_net_det.py:131-133,321-339
  *   fcn_prepare_inputs          the per-sample numpy work of the data loader + collate,
  *                               datasets/provider_sample.py:137-262,270-327,396-397
+ *   fcn_prepare_inputs_refine   the same for the refinement stage, datasets/provider_sample_refine.py:176-419
  *   fcn_det_iou_metrics         the IoU metrics of models/det_base.py:480-503 (D2H + boost clipping every step in the reference)
  *   fcn_box3d_iou_pair_f32      rbbox_iou_3d_pair, ops/pybind11/box_ops.h:173-260 (boost polygon clipping on the host)
  *   fcn_decode_detections       the numpy decode loop of train/test_net_det.py:254-293 + from_prediction_to_label_format
@@ -326,6 +327,28 @@ int fcn_prepare_inputs(const fcn_inp_desc *d, const float *raw_pts, const int64_
                        const double *coin, const double *normal, float *point_cloud, float *const center_ref[4],
                        int64_t *cls_label, float *box3d_center, float *box3d_heading, float *box3d_size,
                        float *rot_angle, int64_t *seg_label, void *stream);
+
+/* Refinement-stage variant (cfgs/refine_car.yaml; datasets/provider_sample_refine.py::ProviderDataset.__getitem__ :176-315,
+ * generate_ref :336-386, generate_labels :317-334, collate_fn :388-419): the sample is normalised to the first-stage
+ * prediction (pred_corners (B,8,3), pred_angle (B), pred_size (B,3) = l,w,h, fp64 like the pickled records): points and label
+ * box are translated to the predicted centre and rotated by its heading; the window centres span the predicted box's own
+ * depth extent -- a different count per sample; every center_ref[s] (B,3,Lpad[s]) and cls_label (B,Lpad[1]) is padded by
+ * repeating the last real entry, as the reference's collate_fn does (Lpad = the batch maxima, computed by the caller as
+ * max_b len(np.arange(-w_b/2, w_b/2, stride[s]))); lens (B,4) receives the per-sample counts.  box3d_corners == NULL:
+ * inference records (no labels; cls_label / box3d_* must be NULL).  Outputs rot_angle (B,1) = pred_angle and
+ * ref_center (B,3) = predicted centre are what from_prediction_to_label_format needs to undo the normalisation. */
+typedef struct fcn_inp_refine_desc {
+    int32_t B, N, pt_stride;
+    int32_t Lpad[4];
+    double  stride[4];
+    int32_t random_flip, random_shift;
+} fcn_inp_refine_desc;
+int fcn_prepare_inputs_refine(const fcn_inp_refine_desc *d, const float *raw_pts, const int64_t *pt_off,
+                              const int32_t *choice, const double *pred_corners, const double *pred_angle,
+                              const double *pred_size, const double *box3d_corners, const double *heading,
+                              const double *size, const double *coin, const double *normal, float *point_cloud,
+                              float *const center_ref[4], int64_t *cls_label, float *box3d_center, float *box3d_heading,
+                              float *box3d_size, float *rot_angle, float *ref_center, int32_t *lens, void *stream);
 
 #ifdef __cplusplus
 }

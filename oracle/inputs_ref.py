@@ -112,3 +112,112 @@ def prepare_batch(rec, strides, max_depth, random_flip=True, random_shift=True):
                                     float(rec["frustum_angle"][b]), rec["draw_choice"][b], float(rec["draw_coin"][b]),
                                     float(rec["draw_normal"][b]), strides, max_depth, random_flip, random_shift))
     return {k: np.stack([it[k] for it in items]) for k in items[0]}
+
+
+# ------------------------------------------------------------------------------------------------
+# Refinement stage (cfgs/refine_car.yaml): datasets/provider_sample_refine.py::ProviderDataset.__getitem__ (:176-315) with
+# generate_ref (:336-386), generate_labels (:317-334), get_center_view_* (:137-152) and collate_fn (:388-419: per-sample L
+# differs, center_ref* / cls_label edge-padded to the batch maximum).  Pinned by tests/golden/inputs_refine_b6.npz = outputs
+# of the reference's own refine ProviderDataset + collate_fn (tests/golden/make_golden_inputs_refine.py).
+
+def box_corners(center, dims, angle):
+    """datasets/data_utils.py:44-70 compute_box_3d."""
+    l, w, h = dims
+    c, s = np.cos(angle), np.sin(angle)
+    R = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+    xs = [l / 2, l / 2, -l / 2, -l / 2, l / 2, l / 2, -l / 2, -l / 2]
+    ys = [h / 2, h / 2, h / 2, h / 2, -h / 2, -h / 2, -h / 2, -h / 2]
+    zs = [w / 2, -w / 2, -w / 2, w / 2, w / 2, -w / 2, -w / 2, w / 2]
+    cor = np.dot(R, np.vstack([xs, ys, zs]))
+    cor[0] += center[0]; cor[1] += center[1]; cor[2] += center[2]
+    return cor.T
+
+
+def generate_ref_refine(pred_box3d, strides):
+    """provider_sample_refine.py:336-386: centres along the line through the front / back face centres of the box, over its
+    z extent."""
+    cz = ((pred_box3d[0] + pred_box3d[6]) / 2)[2]
+    z1, z2 = np.min(pred_box3d[:, 2]), np.max(pred_box3d[:, 2])
+    c1 = np.mean(pred_box3d[pred_box3d[:, 2] < cz], 0)
+    c2 = np.mean(pred_box3d[pred_box3d[:, 2] > cz], 0)
+    delta = c2 - c1
+    refs = []
+    for s in strides:
+        z = np.arange(z1, z2, s) + s / 2.0
+        x = (z - c1[2]) / delta[2] * delta[0] + c1[0]
+        y = (z - c1[2]) / delta[2] * delta[1] + c1[1]
+        refs.append(np.stack([x, y, z], 1))
+    return refs
+
+
+def generate_labels_refine(center, size, angle, ref):
+    """provider_sample_refine.py:317-334: boxes scaled by 0.3 (positive) / 0.6 (ignore)."""
+    labels = np.zeros(len(ref), dtype=np.int64)
+    inside1 = in_box(ref, center, size * 0.3, angle)
+    inside2 = in_box(ref, center, size * 0.6, angle)
+    labels[inside2] = -1
+    labels[inside1] = 1
+    if inside1.sum() == 0:
+        dis = np.sqrt(((ref - center[None, :]) ** 2).sum(1))
+        labels[np.argmin(dis)] = 1
+    return labels
+
+
+def prepare_sample_refine(raw_pts, pred_corners, pred_angle, pred_size, gt_corners, gt_heading, gt_size, choice, coin,
+                          normal, strides, random_flip=True, random_shift=True):
+    pc = (pred_corners[0] + pred_corners[6]) / 2.0                               # :181
+    d = raw_pts[:, :3].astype(np.float64) - pc[None, :]                          # get_center_view_point :146-152
+    xz = rotate_along_y(d[:, [0, 2]], pred_angle)
+    pts = np.stack([xz[:, 0], d[:, 1], xz[:, 1]], 1).astype(np.float32)[choice]  # stored back into the float32 record
+    zero = rotate_along_y(np.zeros((1, 2)), pred_angle)[0]                       # centre view of the predicted box itself
+    pred_box = box_corners(np.array([zero[0], 0.0, zero[1]]), pred_size, 0.0)    # :219-228
+    refs = generate_ref_refine(pred_box, strides)
+    c0 = (gt_corners[0] + gt_corners[6]) / 2.0 - pc                              # get_center_view_box3d :137-144
+    cxz = rotate_along_y(c0[None, [0, 2]], pred_angle)[0]
+    center = np.array([cxz[0], c0[1], cxz[1]], dtype=np.float64)
+    angle = gt_heading - pred_angle
+    if random_flip and coin > 0.5:                                               # :265-276
+        pts[:, 0] *= -1
+        center[0] *= -1
+        angle = np.pi - angle
+        for r in refs:
+            r[:, 0] *= -1
+    if random_shift:                                                             # :278-284
+        l, w, h = gt_size
+        dist = np.sqrt(np.sum(l ** 2 + w ** 2))
+        s1 = strides[0]
+        shift = np.clip(normal * dist * 0.1, -s1 * 2, 2 * s1)
+        pts[:, 2] = (pts[:, 2].astype(np.float64) + shift).astype(np.float32)
+        center[2] += shift
+    labels = generate_labels_refine(center, np.asarray(gt_size, dtype=np.float64), angle, refs[1])
+    out = {"point_cloud": np.ascontiguousarray(pts.T), "cls_label": labels, "box3d_center": center.astype(np.float32),
+           "box3d_heading": np.array([angle], dtype=np.float32), "box3d_size": np.asarray(gt_size).astype(np.float32),
+           "rot_angle": np.array([pred_angle], dtype=np.float32), "ref_center": pc.astype(np.float32)}
+    for i, r in enumerate(refs):
+        out["center_ref%d" % (i + 1)] = np.ascontiguousarray(r.astype(np.float32).T)
+    return out
+
+
+def collate_refine(items):
+    """provider_sample_refine.py:388-419: edge-pad the variable-length keys to the batch maximum, then stack."""
+    names = ["center_ref1", "center_ref2", "center_ref3", "center_ref4", "cls_label"]
+    out = {}
+    for k in items[0]:
+        vals = [it[k] for it in items]
+        if k in names:
+            m = max(v.shape[-1] for v in vals)
+            vals = [np.pad(v, [(0, 0)] * (v.ndim - 1) + [(0, m - v.shape[-1])], mode="edge") for v in vals]
+        out[k] = np.stack(vals)
+    return out
+
+
+def prepare_batch_refine(rec, strides, random_flip=True, random_shift=True):
+    offs = np.concatenate([[0], np.cumsum(rec["raw_counts"])])
+    items = []
+    for b in range(len(rec["raw_counts"])):
+        sl = slice(int(offs[b]), int(offs[b + 1]))
+        items.append(prepare_sample_refine(rec["raw_points"][sl], rec["pred_corners"][b], float(rec["pred_angle"][b]),
+                                           rec["pred_size"][b], rec["box3d_corners"][b], float(rec["heading"][b]),
+                                           rec["size"][b], rec["draw_choice"][b], float(rec["draw_coin"][b]),
+                                           float(rec["draw_normal"][b]), strides, random_flip, random_shift))
+    return collate_refine(items)

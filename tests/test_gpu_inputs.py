@@ -130,3 +130,39 @@ def test_ragged_and_odd_sizes_against_oracle(B, N, stride3):
     out2 = b.build(recs, draws=(choice, coin, normal), with_seg=False)
     assert "seg_label" not in out2 and torch.equal(out2["point_cloud"], out["point_cloud"])
     assert torch.equal(out2["cls_label"], out["cls_label"])
+
+
+def test_refine_builder_matches_reference_batch():
+    """fcn_prepare_inputs_refine vs the reference's refine ProviderDataset + collate_fn outputs (golden fixture): labels and
+    per-sample window counts exact, floats <= 1e-6, edge padding included."""
+    import numpy as np
+    import torch
+    from helpers import load_golden
+    from frustum_convnet_amd import inputs
+    from frustum_convnet_amd.config import reset_cfg
+    reset_cfg()
+    g = load_golden("inputs_refine_b6")
+    b = inputs.RefineInputBuilder(int(g["meta_npoint"]), strides=tuple(g["meta_strides"]), random_flip=True, random_shift=True)
+    out = b.build(inputs.refine_records_from_fixture(g), draws=(g["draw_choice"], g["draw_coin"], g["draw_normal"]))
+    torch.cuda.synchronize()
+    assert np.array_equal(out["lens"].cpu().numpy(), g["ref_lens"])
+    for k in ("point_cloud", "cls_label", "box3d_center", "box3d_heading", "box3d_size", "size_class", "center_ref1",
+              "center_ref2", "center_ref3", "center_ref4", "rot_angle", "ref_center", "one_hot"):
+        got, ref = out[k].cpu().numpy(), g["ref_" + k]
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        if got.dtype.kind == "f":
+            assert np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() <= 1e-6, k
+        else:
+            assert np.array_equal(got, ref), k
+    # inference records (no labels): same points / centres without flip and shift
+    out2 = b.build(inputs.refine_records_from_fixture(g), draws=(g["draw_choice"], g["draw_coin"] * 0, g["draw_normal"] * 0),
+                   with_labels=False)
+    assert "cls_label" not in out2 and out2["center_ref1"].shape == out["center_ref1"].shape
+    # the built batch feeds the model (variable L incl. L4 = 3)
+    from frustum_convnet_amd import det_base
+    from frustum_convnet_amd.config import cfg
+    cfg.DATA.HEIGHT_HALF = tuple(float(x) for x in g["meta_strides"]); cfg.DATA.STRIDE = cfg.DATA.HEIGHT_HALF
+    m = det_base.PointNetDet(3, num_vec=3, num_classes=2).cuda().train()
+    feed = {k: v for k, v in out.items() if k not in ("lens", "rot_angle", "ref_center")}
+    losses, _ = m(feed)
+    assert torch.isfinite(losses["total_loss"])

@@ -74,3 +74,21 @@ def test_host_draws_follow_the_reference_rng_order():
     # a record with fewer points than NUM_SAMPLES is resampled WITH replacement, the others without
     for n, c in zip(g["raw_counts"], choice):
         assert (len(np.unique(c)) == len(c)) == (n >= len(c))
+
+
+def test_refine_oracle_matches_reference_dataset_and_collate():
+    """oracle/inputs_ref.py refine restatement vs the reference's own refine ProviderDataset + collate_fn outputs
+    (tests/golden/make_golden_inputs_refine.py): per-sample L differs, the padded batch must match exactly."""
+    import numpy as np
+    from oracle import inputs_ref
+    from helpers import load_golden
+    g = load_golden("inputs_refine_b6")
+    out = inputs_ref.prepare_batch_refine(g, tuple(g["meta_strides"]))
+    assert len(set(int(v) for v in g["ref_lens"][:, 0])) > 1              # the fixture does exercise the padding
+    for k, v in out.items():
+        ref = g["ref_" + k]
+        assert v.shape == ref.shape, k
+        if v.dtype.kind == "f":
+            assert np.abs(v.astype(np.float64) - ref.astype(np.float64)).max() <= 1e-6, k
+        else:
+            assert np.array_equal(v, ref), k
