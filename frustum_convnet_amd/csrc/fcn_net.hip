@@ -266,11 +266,15 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         const int c = (it_) * G + g;                                                                                  \
         const bool act = c < nchunk;                                                                                  \
         if (act) CGK_FWD_STAGE(c, RA, RW, OK);                                                                \
-        __syncthreads();                                                                                              \
+        if constexpr (TG != 64) __syncthreads();                                                                      \
         if (c + 2 * G < nchunk) CGK_FWD_LOAD(c + 2 * G, RA, RW, OK);                                         \
         if (act) mma_chunk<MM, 1, 1, LDA, LDC>(As, Bs, wm * 32, wn * 32, acc);                                    \
-        __syncthreads();                                                                                              \
+        if constexpr (TG != 64) __syncthreads();                                                                      \
     }
+    // A K-group of ONE wave (TG == 64: the 32 x 32 tile in use) owns its LDS buffers alone and the LDS serves a wave's
+    // operations in order, so its write -> read -> write sequence needs no barrier: the four waves of the workgroup run
+    // through their chunks independently and cover each other's load latency instead of marching in lockstep (two
+    // workgroup barriers per K step before).  One barrier remains in front of the cross-group reduction below.
     // The first two chunks of this K-group are requested BEFORE the prologue: they depend on neither the BatchNorm
     // statistics nor the LDS tables (their (segment, tap, channel) comes straight from cg_locate), so their trip to L2 / HBM
     // overlaps the fp64 finalisation below instead of following it -- one memory latency per layer off a 25-launch chain
@@ -296,6 +300,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         if (it + 1 < nit) CGK_FWD_ITER(it + 1, ra1, rw1, ok1);
     }
     // ---- sum the G group accumulators through LDS, then one epilogue pass over the tile
+    if constexpr (TG == 64) __syncthreads();            // every group is done with its operand buffers (reused below)
     float *red = lds;                                   // [G][TMB][TNC]
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg)

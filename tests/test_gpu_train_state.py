@@ -185,3 +185,59 @@ def test_short_training_run_in_one_hipgraph():
     assert abs(losses[-1] - eager[-1]) <= 2e-3 * abs(eager[-1]), (losses, eager)
     d = float((s1.flat - s2.flat).abs().max())
     assert d <= 5e-4, d
+
+
+def test_two_graph_overlapped_step_equals_single_graph():
+    """The N > 1 step of bench.py -- graph A (forward, loss, FCN backward) | bucket all-reduce | graph B (PointNet backward) |
+    bucket all-reduce | Adam -- replayed at world size 1 (the collectives are no-ops) gives bit-identical parameters to the
+    single-graph step after several steps: the cut at the pooled feature maps changes the launch structure, not the math."""
+    from frustum_convnet_amd.train_state import FlatTrainState
+    from frustum_convnet_amd.loss_fused import unit_grad
+    g = load_golden("car_b4_n512")
+    data = synth.to_torch(golden_inputs(g), "cuda")
+
+    def make(split):
+        m = _model(g)
+        m.train()
+        m.split_backward = split
+        return m, FlatTrainState(m, lr=1e-4, weight_decay=1e-4)
+
+    def warm(m):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            lo, _ = m(data)
+            m.backward(lo["total_loss"])
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+
+    m1, s1 = make(False)
+    warm(m1)
+    g1 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g1):
+        lo, _ = m1(data)
+        m1.backward(lo["total_loss"])
+        s1.adam_step()
+    m2, s2 = make(True)
+    warm(m2)
+    gA, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gA):
+        lo2, _ = m2(data)
+        feats, leaves = m2._split
+        m2._split = None
+        lo2["total_loss"].backward(gradient=unit_grad(lo2["total_loss"].device))
+    with torch.cuda.graph(gB, pool=gA.pool()):
+        torch.autograd.backward(list(feats), [l.grad for l in leaves])
+    assert [n for n, _, _ in s2.buckets] == ["fcn+heads", "pointnet"]
+    for _ in range(5):
+        g1.replay()
+        gA.replay()
+        s2.allreduce_bucket_async(0)
+        gB.replay()
+        s2.allreduce_bucket_async(1)
+        s2.wait_allreduce()
+        s2.adam_step()
+    torch.cuda.synchronize()
+    assert int(s1.step_count) == 5 and int(s2.step_count) == 5
+    assert torch.equal(s1.grad, s2.grad)
+    assert torch.equal(s1.flat, s2.flat)
