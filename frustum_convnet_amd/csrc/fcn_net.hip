@@ -68,6 +68,40 @@ struct CgLayer {
 
 #define SEL3(i, a0, a1, a2) ((i) == 0 ? (a0) : ((i) == 1 ? (a1) : (a2)))
 
+// Intra-kernel phase stamps for TUNING BUILDS ONLY (-DFCN_PROBE, tools/fcn_probe.py; never compiled into the product):
+// wave 0 of every workgroup records the 100 MHz device clock at phase boundaries into a global table.
+#ifdef FCN_PROBE
+#define FCN_PROBE_MAX 65536
+__device__ unsigned long long g_fcn_probe[FCN_PROBE_MAX * 8];
+__device__ unsigned int g_fcn_probe_n;
+#define PROBE_DECL unsigned long long pb_[8]; int pbn_ = 0
+#define PROBE_STAMP() do { if (pbn_ < 7) pb_[pbn_++] = wall_clock64(); } while (0)
+#define PROBE_FLUSH(tag)                                                                                 \
+    do {                                                                                                 \
+        if (threadIdx.x == 0) {                                                                          \
+            const unsigned int s_ = atomicAdd(&g_fcn_probe_n, 1u);                                       \
+            if (s_ < FCN_PROBE_MAX) {                                                                    \
+                g_fcn_probe[s_ * 8] = (unsigned long long)(tag);                                         \
+                for (int q_ = 0; q_ < 7; ++q_) g_fcn_probe[s_ * 8 + 1 + q_] = q_ < pbn_ ? pb_[q_] : 0ull; \
+            }                                                                                            \
+        }                                                                                                \
+    } while (0)
+extern "C" int fcn_probe_read(unsigned long long *host_out, int max_records, int reset)
+{
+    unsigned int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_fcn_probe_n), sizeof(n)) != hipSuccess) return -1;
+    if ((int)n > max_records) n = max_records;
+    if (n > FCN_PROBE_MAX) n = FCN_PROBE_MAX;
+    if (n && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fcn_probe), (size_t)n * 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned int z = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_fcn_probe_n), &z, sizeof(z)); }
+    return (int)n;
+}
+#else
+#define PROBE_DECL
+#define PROBE_STAMP()
+#define PROBE_FLUSH(tag)
+#endif
+
 // XCD-aware tile order (cdna guide T1).  Workgroup ids are dealt to the 8 XCDs round-robin and every XCD has its own 4 MB
 // L2; with the natural order the tiles that share operand rows land on eight different L2s and each of them pulls the
 // whole weight matrix AND the whole activation matrix through the fabric (32 x 32 tiles re-read their operands ~20x:
@@ -195,6 +229,8 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     float *As = lds + g * KC * (LDA + LDC), *Bs = As + KC * LDA;
     const int R = L.B * L.Lout;
     const int row0 = bx * TMB, n0 = by * TNC;
+    PROBE_DECL;
+    PROBE_STAMP();                                      // 0: entry
     const int kq = gt & 7, rb = gt >> 3;      // rb: 0..31 (MW=2) or 0..15 (MW=1)
     constexpr int RSTEP = TG / 8;
     const int nchunk = L.Ktot / KC, nit = (nchunk + G - 1) / G;
@@ -288,6 +324,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         CGK_FWD_LOAD_AT(cb, __builtin_amdgcn_readfirstlane(sg_), __builtin_amdgcn_readfirstlane(tap_),
                         __builtin_amdgcn_readfirstlane(k0_), ra1, rw1, ok1);
     }
+    PROBE_STAMP();                                      // 1: first loads issued
     if (tid < nchunk) {
         int sg, tap, k0, so;
         cg_locate(L, tid * KC, sg, tap, k0, so);
@@ -295,10 +332,12 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     }
     cg_fill_bn(L, sS, tS, tid, NTHR, bx == 0 && by == 0);
     __syncthreads();                            // sS / tS and the chunk table ready
+    PROBE_STAMP();                                      // 2: prologue done
     for (int it = 0; it < nit; it += 2) {
         CGK_FWD_ITER(it, ra0, rw0, ok0);
         if (it + 1 < nit) CGK_FWD_ITER(it + 1, ra1, rw1, ok1);
     }
+    PROBE_STAMP();                                      // 3: K loop done (wave 0)
     // ---- sum the G group accumulators through LDS, then one epilogue pass over the tile
     if constexpr (TG == 64) __syncthreads();            // every group is done with its operand buffers (reused below)
     float *red = lds;                                   // [G][TMB][TNC]
@@ -306,6 +345,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     for (int reg = 0; reg < 16; ++reg)
         red[(g * TMB + wm * 32 + acc_row(reg, lh)) * TNC + wn * 32 + l31] = acc[0][0][reg];
     __syncthreads();
+    PROBE_STAMP();                                      // 4: all groups done, partials in LDS
     constexpr int NQ = TNC / 4;                         // column quads of the tile
     const int ecq = tid % NQ;
     const int col = n0 + 4 * ecq;
@@ -325,7 +365,8 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
             cs2 += v * v;
         }
     }
-    if (!L.stat) return;
+    PROBE_STAMP();                                      // 5: outputs stored
+    if (!L.stat) { PROBE_FLUSH(((unsigned long long)L.Ktot << 32) | ((unsigned long long)L.Cout << 16) | (unsigned long long)(L.Lout & 0xffff)); return; }
     // rows of one wave: lanes NQ apart share a column quad -> xor-shuffle down to NQ lanes, then across waves via LDS
     float pv[8] = {cs1.x, cs1.y, cs1.z, cs1.w, cs2.x, cs2.y, cs2.z, cs2.w};
 #pragma unroll
@@ -350,6 +391,8 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         for (int r = 0; r < NTHR / 64; ++r) a += (double)st[(r * TNC + c) * 2 + w];
         atomic_add_f64(&L.stat[w * L.Cs + (n0 + c) % L.Cs], a);
     }
+    PROBE_STAMP();                                      // 6: statistics added
+    PROBE_FLUSH(((unsigned long long)L.Ktot << 32) | ((unsigned long long)L.Cout << 16) | (unsigned long long)(L.Lout & 0xffff));
 }
 
 template <int MM, int MW, int G, int WNC = 2>
