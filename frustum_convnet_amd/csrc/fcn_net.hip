@@ -102,6 +102,17 @@ extern "C" int fcn_probe_read(unsigned long long *host_out, int max_records, int
 #define PROBE_FLUSH(tag)
 #endif
 
+// n / d and n % d for 0 <= n < 2^23 through a float reciprocal and one correction step (~10 instructions): hipcc's general
+// 32-bit division is ~40 and every workgroup of a 25-launch latency-bound chain paid a dozen of them before its first load.
+__device__ __forceinline__ void cg_divmod(int n, int d, float inv, int &q, int &r)
+{
+    q = (int)((float)n * inv);
+    r = n - q * d;
+    if (r < 0) { q -= 1; r += d; }
+    else if (r >= d) { q += 1; r -= d; }
+}
+__device__ __forceinline__ float cg_inv(int d) { return 1.0f / (float)d; }
+
 // XCD-aware tile order (cdna guide T1).  Workgroup ids are dealt to the 8 XCDs round-robin and every XCD has its own 4 MB
 // L2; with the natural order the tiles that share operand rows land on eight different L2s and each of them pulls the
 // whole weight matrix AND the whole activation matrix through the fabric (32 x 32 tiles re-read their operands ~20x:
@@ -141,8 +152,7 @@ __device__ __forceinline__ void cg_locate(const CgLayer &L, int kk, int &sg, int
         }
     }
     const int C = SEL3(sg, opaque_s(L.seg[0].C), opaque_s(L.seg[1].C), opaque_s(L.seg[2].C));
-    tap = kk / C;
-    k0 = kk % C;
+    cg_divmod(kk, C, cg_inv(C), tap, k0);               // kk < CG_KMAX
 }
 
 // RAW, UNCONDITIONAL load of A[r][kc..kc+3] of the virtual im2col matrix: the position is clamped to a valid row and
@@ -157,6 +167,17 @@ __device__ __forceinline__ v4f cg_load_raw(const CgLayer &L, const float *x, int
     ok = rvalid && lin >= 0 && lin < L.Lin;
     const int lc = min(max(lin, 0), L.Lin - 1) * linmul;
     return ldg4(x + ((int64_t)b * Lsrc + lc) * C + kc);
+}
+
+// 1 / sqrt(x) in fp64 from the fp32 rsqrt + three Newton steps (full double accuracy, x > 0 and within float range -- a
+// variance + eps): a dozen fp64 operations instead of the software sqrt + division sequences (~100) every workgroup of every
+// layer ran in its prologue
+__device__ __forceinline__ double cg_rsqrt64(double x)
+{
+    double y = (double)rsqrtf((float)x);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) y = y * (1.5 - 0.5 * x * y * y);
+    return y;
 }
 
 #define CG_KMAX 1792           // largest Ktot staged as per-column BN scale/shift (block4_conv2: 3*512 = 1536)
@@ -174,17 +195,18 @@ __device__ __forceinline__ void cg_fill_bn(const CgLayer &L, float *sS, float *t
             if (S.gamma) {
                 const bool batch = S.stat != nullptr;
                 const bool wr = pub && S.writer;
+                const double invM = 1.0 / S.M;
                 for (int k = tid; k < C; k += nthr) {
                     double mean, var;
                     if (batch) {
-                        mean = S.stat[k] / S.M;
-                        var = S.stat[C + k] / S.M - mean * mean;
+                        mean = S.stat[k] * invM;
+                        var = S.stat[C + k] * invM - mean * mean;
                         if (var < 0.0) var = 0.0;
                     } else {
                         mean = S.rmean[k];
                         var = S.rvar[k];
                     }
-                    const double rstd = 1.0 / sqrt(var + (double)L.eps);
+                    const double rstd = cg_rsqrt64(var + (double)L.eps);
                     const double sc = (double)S.gamma[k] * rstd;
                     const float fs = (float)sc, ft = (float)((double)S.beta[k] - mean * sc);
                     for (int t = 0; t < L.KT; ++t) { sS[off + t * C + k] = fs; tS[off + t * C + k] = ft; }
@@ -245,8 +267,11 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     for (int i = 0; i < NA; ++i) {
         const int gr = row0 + rb + RSTEP * i;
         rv[i] = gr < R;
-        bb[i] = rv[i] ? gr / L.Lout : 0;
-        ll[i] = rv[i] ? gr % L.Lout : 0;
+        int q_ = 0, r_ = 0;
+        if (R < (1 << 23)) cg_divmod(rv[i] ? gr : 0, L.Lout, cg_inv(L.Lout), q_, r_);
+        else { q_ = (rv[i] ? gr : 0) / L.Lout; r_ = (rv[i] ? gr : 0) % L.Lout; }
+        bb[i] = q_;
+        ll[i] = r_;
     }
     f32x16 acc[1][1];
     acc_zero<1, 1>(acc);
@@ -442,8 +467,9 @@ __device__ __forceinline__ void cg_bnbwd_coef(const CgBnBwd &q, int Cs, int c, f
     cf[0] = q.gamma[c] * rstd;
     cf[1] = q.bn[2 * Cs + c];
     cf[2] = rstd;
-    cf[3] = (float)(db / q.M);
-    cf[4] = (float)(dg / q.M);
+    const double invM = 1.0 / q.M;                      // (one division; the two per-channel quotients become products)
+    cf[3] = (float)(db * invM);
+    cf[4] = (float)(dg * invM);
     if (pub && q.dgamma) { q.dgamma[c] = (float)dg; q.dbeta[c] = (float)db; }
 }
 
@@ -604,8 +630,11 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
     for (int i = 0; i < NA; ++i) {
         const int gr = row0 + rb + RSTEP * i;
         rv[i] = gr < Rs;
-        bb[i] = rv[i] ? gr / SLsrc : 0;
-        li[i] = rv[i] ? gr % SLsrc : 0;
+        int q_ = 0, r_ = 0;
+        if (Rs < (1 << 23)) cg_divmod(rv[i] ? gr : 0, SLsrc, cg_inv(SLsrc), q_, r_);
+        else { q_ = (rv[i] ? gr : 0) / SLsrc; r_ = (rv[i] ? gr : 0) % SLsrc; }
+        bb[i] = q_;
+        li[i] = r_;
         rv[i] = rv[i] && li[i] < L.Lin;
         ok[i] = false;
     }
@@ -628,8 +657,10 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
 #pragma unroll
         for (int t3 = 0; t3 < 3; ++t3) {
             const int t = li[i] + L.pad - t3;
-            const int lo = t / L.stride;
-            ok_t[i][t3] = rv[i] && t3 < L.KT && t >= 0 && (t % L.stride) == 0 && lo < L.Lout;
+            // stride is 1 or 2 (cn_make_plan rejects anything else): shift / mask instead of a division
+            const int lo = (L.stride == 2) ? (t >> 1) : t;
+            const bool divides = (L.stride == 2) ? ((t & 1) == 0) : true;
+            ok_t[i][t3] = rv[i] && t3 < L.KT && t >= 0 && divides && lo < L.Lout;
             lo_t[i][t3] = min(max(lo, 0), L.Lout - 1);
         }
 #define CGK_DGRAD_LOAD(cc)                                                                                            \
@@ -809,9 +840,17 @@ __device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float
     const int nch = (rend - rbeg + KC - 1) / KC, nit = (nch + 1) / 2;
     // (frustum, position) of this thread's two rows, advanced by 2*KC per chunk instead of divided out of the row index
     int wb[2], wl[2];
+    const float invL = cg_inv(L.Lout);
+    const bool fastdiv = R < (1 << 23);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { const int r = rbeg + h * KC + rr0 + i; wb[i] = r / L.Lout; wl[i] = r % L.Lout; }
-    const int bend = (rend - 1) / L.Lout, lend = (rend - 1) % L.Lout;
+    for (int i = 0; i < 2; ++i) {
+        const int r = rbeg + h * KC + rr0 + i;
+        if (fastdiv) cg_divmod(r, L.Lout, invL, wb[i], wl[i]);
+        else { wb[i] = r / L.Lout; wl[i] = r % L.Lout; }
+    }
+    int bend, lend;
+    if (fastdiv) cg_divmod(rend - 1, L.Lout, invL, bend, lend);
+    else { bend = (rend - 1) / L.Lout; lend = (rend - 1) % L.Lout; }
 #define CG_WGRAD_LOAD(rr)                                                                                             \
     {                                                                                                                 \
         const int r0_ = (rr);                                                                                         \
