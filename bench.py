@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- frustums/sec of the hot path's training step (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--cfg car|people|refine] [--precision split|f32|bf16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--cfg car|people|refine|sunrgbd] [--precision split|f32|bf16]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
 
 One step = the reference's train-loop body on one batch (train/train_net_det.py:120-133): forward of PointNetDet in train
@@ -44,6 +44,8 @@ CFGS = {
     "car": ("cfgs/det_sample.yaml", (0.25, 0.5, 1.0, 2.0), None, 1024),
     "people": ("cfgs/det_sample_people.yaml", (0.1, 0.2, 0.4, 0.8), None, 1024),
     "refine": ("cfgs/refine_car.yaml", (0.1, 0.2, 0.4, 0.8), (-1.0, 1.0), 512),
+    # the five-scale SUN-RGBD variant: 8 m of depth, 10 classes, models/det_base_sunrgbd.py
+    "sunrgbd": ("cfgs/det_sample_sunrgbd.yaml", (0.1, 0.2, 0.4, 0.8, 1.6), None, 2048),
 }
 
 
@@ -72,16 +74,31 @@ def build_model(device, cfg_name="car"):
     from frustum_convnet_amd import det_base, synth
     reset_cfg()
     merge_cfg_from_file(os.path.join(ROOT, CFGS[cfg_name][0]))
-    model = det_base.PointNetDet(3, num_vec=3, num_classes=2)
+    model = _new_model(cfg_name)
     synth.fill_state_dict(model.state_dict(), seed=7)
     return model.to(device).train()
 
 
-def make_data(cfg_name, batch, npoint, seed, device):
+def _new_model(cfg_name):
+    from frustum_convnet_amd import det_base, det_base_sunrgbd
+    if cfg_name == "sunrgbd":
+        return det_base_sunrgbd.PointNetDet(3, num_vec=10, num_classes=2)
+    return det_base.PointNetDet(3, num_vec=3, num_classes=2)
+
+
+def _batch_np(cfg_name, batch, npoint, seed):
     from frustum_convnet_amd import synth
     _, strides, z_range, _ = CFGS[cfg_name]
-    return synth.to_torch(synth.make_batch(batch, npoint, strides=strides, seed=seed, variant="car", tilt=(0.01, 0.05),
-                                           z_range=z_range), device)
+    if cfg_name == "sunrgbd":
+        from frustum_convnet_amd.dataset_info import SUNRGBDCategory
+        return synth.make_batch(batch, npoint, strides=strides, max_depth=8.0, seed=seed, variant="car", tilt=(0.01, 0.05),
+                                z_range=z_range, num_classes=10, mean_sizes=SUNRGBDCategory.MEAN_SIZE_ARRAY)
+    return synth.make_batch(batch, npoint, strides=strides, seed=seed, variant="car", tilt=(0.01, 0.05), z_range=z_range)
+
+
+def make_data(cfg_name, batch, npoint, seed, device):
+    from frustum_convnet_amd import synth
+    return synth.to_torch(_batch_np(cfg_name, batch, npoint, seed), device)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -115,12 +132,14 @@ class CallTimer:
             setattr(self.lib, name, fn)
 
 
-def fcn_flops(B, Ls, nvec=3):
-    """MACs of ConvFeatNet + heads x 2."""
-    L1, L2, L3, L4 = Ls
-    macs = ((128 + nvec) * 128 * 3 * L1 + 2 * 128 * 128 * 3 * L2 + (256 + nvec) * 128 * L2 + 128 * 256 * 3 * L3 +
-            256 * 256 * 3 * L3 + (512 + nvec) * 256 * L3 + 256 * 512 * 3 * L4 + 512 * 512 * 3 * L4 + (1024 + nvec) * 512 * L4 +
-            128 * 256 * L2 + 256 * 256 * 2 * L3 + 512 * 256 * 4 * L4 + 768 * 41 * L2)
+def fcn_flops(B, Ls, nvec=3, c1=128, nout=41):
+    """MACs of ConvFeatNet + heads x 2, for 4 levels (c1 = 128, 41 head columns) or 5 (c1 = 64, 69)."""
+    w = [c1, 128, 256, 512, 512][:len(Ls)]          # block widths = pooled feature widths from level 2 on
+    macs = (128 + nvec) * w[0] * 3 * Ls[0]
+    for j in range(1, len(Ls)):
+        macs += w[j - 1] * w[j] * 3 * Ls[j] + w[j] * w[j] * 3 * Ls[j] + (2 * w[j] + nvec) * w[j] * Ls[j]
+        macs += w[j] * 256 * (1 << (j - 1)) * Ls[j]                      # deconvolution, kernel = stride = 2^(j-1)
+    macs += 256 * (len(Ls) - 1) * nout * Ls[1]
     return 2.0 * macs * B
 
 
@@ -129,7 +148,7 @@ def kernel_table(model, state, data, optim, prec, reps=5):
     from frustum_convnet_amd import _native
     lib = _native.lib()
     B = data["point_cloud"].shape[0]
-    Ls = [data["center_ref%d" % i].shape[2] for i in (1, 2, 3, 4)]
+    Ls = [data["center_ref%d" % i].shape[2] for i in range(1, 6) if ("center_ref%d" % i) in data]
     agg = {}
     for rep in range(reps + 1):
         with CallTimer(lib) as ct:
@@ -149,7 +168,7 @@ def kernel_table(model, state, data, optim, prec, reps=5):
             r["ms"] += e0.elapsed_time(e1)
             r["calls"] += 1
     # executed rows per scale (live entries) from the workspaces of the last forward
-    nets = (model.feat_net.pointnet1, model.feat_net.pointnet2, model.feat_net.pointnet3, model.feat_net.pointnet4)
+    nets = model.feat_net.nets
     E = {}
     for net, Lw in zip(nets, Ls):
         for lst in net._pool.free.values():
@@ -158,7 +177,8 @@ def kernel_table(model, state, data, optim, prec, reps=5):
                     E[(Lw, net.nsample)] = int(ws.woff[:, -1].sum().item())
     peak_mm = {"split": PEAK_16BIT_MFMA_TFLOPS / 3.0, "f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_16BIT_MFMA_TFLOPS}[prec]
     rows = []
-    ff = fcn_flops(B, Ls)
+    ff = fcn_flops(B, Ls, nvec=model.feat_net.num_vec, c1=model.conv_net.WIDTHS[0],
+                   nout=2 + model.reg_out.weight.shape[0])
     nparam = state.numel
     N = data["point_cloud"].shape[2]
     for key, r in agg.items():
@@ -223,10 +243,11 @@ def cpu_baseline(batch, npoint, cfg_name):
     """The CPU oracle (port of the reference dataflow: dense (B,C,L,K) tensors, torch-CPU conv/BN + C grouping) timed on this
     host: forward + backward.  Three points: best of 16 / 8 torch threads (3 steps), 1 core, all cores."""
     from oracle import det_ref
-    from frustum_convnet_amd import synth, det_base
-    from frustum_convnet_amd.config import reset_cfg
+    from frustum_convnet_amd import synth
+    from frustum_convnet_amd.config import reset_cfg, merge_cfg_from_file
     reset_cfg()
-    m = det_base.PointNetDet(3, num_vec=3, num_classes=2)      # only for the state_dict keys/shapes
+    merge_cfg_from_file(os.path.join(ROOT, CFGS[cfg_name][0]))
+    m = _new_model(cfg_name)      # only for the state_dict keys/shapes
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     synth.fill_state_dict(sd, seed=7)
     for k, v in sd.items():
@@ -235,8 +256,7 @@ def cpu_baseline(batch, npoint, cfg_name):
     _, strides, z_range, _ = CFGS[cfg_name]
 
     def step(b):
-        data = synth.to_torch(synth.make_batch(b, npoint, strides=strides, seed=1234, variant="car", tilt=(0.01, 0.05),
-                                               z_range=z_range))
+        data = synth.to_torch(_batch_np(cfg_name, b, npoint, 1234))
         t0 = time.perf_counter()
         _, _, losses = det_ref.forward(sd, data, strides, training=True)
         losses["total_loss"].backward()
@@ -417,7 +437,7 @@ def main():
 
     if rank != 0:
         return
-    Ls = [data["center_ref%d" % i].shape[2] for i in (1, 2, 3, 4)]
+    Ls = [data["center_ref%d" % i].shape[2] for i in range(1, 6) if ("center_ref%d" % i) in data]
     out = {
         "metric": "frustums/sec (train fwd+bwd) KITTI-car B=32 N=1024",
         "value": round(a.batch * world / (ms_per_step / 1e3), 2),

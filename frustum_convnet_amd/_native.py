@@ -20,16 +20,21 @@ class PnDesc(ctypes.Structure):
                 ("precision", ctypes.c_int32), ("grouped", ctypes.c_int32)]
 
 
+CN_MAXLEV = 5        # FCN_CN_MAXLEV
+CN_MAXLAYER = 18     # FCN_CN_MAXLAYER
+
+
 class CnDesc(ctypes.Structure):
-    _fields_ = [("B", ctypes.c_int32), ("L", ctypes.c_int32 * 4), ("nvec", ctypes.c_int32),
+    _fields_ = [("B", ctypes.c_int32), ("L", ctypes.c_int32 * CN_MAXLEV), ("nvec", ctypes.c_int32),
                 ("reg_out", ctypes.c_int32), ("training", ctypes.c_int32),
                 ("eps", ctypes.c_float), ("momentum", ctypes.c_float), ("prepacked", ctypes.c_int32),
-                ("precision", ctypes.c_int32)]
+                ("precision", ctypes.c_int32), ("nlev", ctypes.c_int32), ("c1", ctypes.c_int32)]
 
 
 class CnParams(ctypes.Structure):
-    _fields_ = [("W", c_fp * 14), ("gamma", c_fp * 14), ("beta", c_fp * 14), ("running_mean", c_fp * 14),
-                ("running_var", c_fp * 14), ("num_batches_tracked", c_fp * 14), ("bias", c_fp)]
+    _fields_ = [("W", c_fp * CN_MAXLAYER), ("gamma", c_fp * CN_MAXLAYER), ("beta", c_fp * CN_MAXLAYER),
+                ("running_mean", c_fp * CN_MAXLAYER), ("running_var", c_fp * CN_MAXLAYER),
+                ("num_batches_tracked", c_fp * CN_MAXLAYER), ("bias", c_fp)]
 
 
 class CnWs(ctypes.Structure):
@@ -62,7 +67,7 @@ class InpRefineDesc(ctypes.Structure):
 EXPORTS = ("fcn_arch", "fcn_query_depth_point_f32", "fcn_pn_wgrad_rows", "fcn_pn_compact", "fcn_pn_group_compact",
            "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_det_loss_tail_rows2", "fcn_det_iou_metrics",
            "fcn_det_loss_tail_scratch_floats", "fcn_adam_step_f32", "fcn_adam_step_slots", "fcn_prepare_inputs", "fcn_prepare_inputs_refine", "fcn_stamp",
-           "fcn_convnet_sizes", "fcn_convnet_pack", "fcn_convnet_forward", "fcn_convnet_forward2",
+           "fcn_convnet_sizes", "fcn_convnet_logits_ld", "fcn_convnet_pack", "fcn_convnet_forward", "fcn_convnet_forward2",
            "fcn_convnet_backward", "fcn_box3d_iou_pair_f32", "fcn_decode_detections", "fcn_rotate_nms_3d")
 
 _lib = None
@@ -131,18 +136,20 @@ def lib():
     L.fcn_det_loss_tail_scratch_floats.argtypes = [ctypes.c_int, ctypes.c_int]
     L.fcn_convnet_sizes.restype = ctypes.c_int
     L.fcn_convnet_sizes.argtypes = [ctypes.POINTER(CnDesc), ctypes.POINTER(ctypes.c_int64 * 6)]
+    L.fcn_convnet_logits_ld.restype = ctypes.c_int
+    L.fcn_convnet_logits_ld.argtypes = [ctypes.POINTER(CnDesc)]
     L.fcn_convnet_pack.restype = ctypes.c_int
     L.fcn_convnet_pack.argtypes = [ctypes.POINTER(CnDesc), ctypes.POINTER(CnParams), ctypes.POINTER(CnWs), c_fp, c_fp]
     L.fcn_convnet_forward.restype = ctypes.c_int
     L.fcn_convnet_forward.argtypes = [ctypes.POINTER(CnDesc), ctypes.POINTER(CnParams), ctypes.POINTER(CnWs),
-                                      c_fp * 4, c_fp, c_fp, c_fp]
+                                      c_fp * CN_MAXLEV, c_fp, c_fp, c_fp]
     L.fcn_convnet_forward2.restype = ctypes.c_int
     L.fcn_convnet_forward2.argtypes = [ctypes.POINTER(CnDesc), ctypes.POINTER(CnParams), ctypes.POINTER(CnWs),
-                                       c_fp * 4, c_fp, c_fp, c_fp, ctypes.POINTER(c_fp)]
+                                       c_fp * CN_MAXLEV, c_fp, c_fp, c_fp, ctypes.POINTER(c_fp)]
     L.fcn_convnet_backward.restype = ctypes.c_int
     L.fcn_convnet_backward.argtypes = [ctypes.POINTER(CnDesc), ctypes.POINTER(CnParams), ctypes.POINTER(CnWs),
-                                       c_fp * 4, c_fp, c_fp, c_fp * 4, c_fp * 14, c_fp * 14, c_fp * 14, c_fp, c_fp, c_fp,
-                                       ctypes.POINTER(c_fp)]
+                                       c_fp * CN_MAXLEV, c_fp, c_fp, c_fp * CN_MAXLEV, c_fp * CN_MAXLAYER, c_fp * CN_MAXLAYER,
+                                       c_fp * CN_MAXLAYER, c_fp, c_fp, c_fp, ctypes.POINTER(c_fp)]
     L.fcn_box3d_iou_pair_f32.restype = ctypes.c_int
     L.fcn_box3d_iou_pair_f32.argtypes = [c_fp, c_fp, ctypes.c_int, c_fp, c_fp]
     L.fcn_decode_detections.restype = ctypes.c_int

@@ -32,7 +32,8 @@
 #define LDN 68                 // row-major LDS leading dim of a 64-wide tile (float4 aligned)
 #define OH_PAD 64              // channels of the virtual one-hot segment
 #define CG_SPLIT_ROWS 512      // rows per wgrad split
-#define CN_NLAYER 14           // 13 conv/deconv+BN layers + heads
+#define CN_NLAYER 18           // capacity: 4 * levels - 2 layers (4 levels: 13 conv/deconv+BN + heads = 14; 5 levels: 18)
+#define CG_NSEG 4              // input segments of a layer (the 5-level heads read four deconvolution outputs)
 
 struct CgSeg {
     const float *x;            // type 0: (B*Lsrc, C) rows; type 1: one-hot zero-padded to (B, OH_PAD)
@@ -53,7 +54,7 @@ struct CgSeg {
 };
 
 struct CgLayer {
-    CgSeg seg[3];
+    CgSeg seg[CG_NSEG];
     int nseg;
     int KT, stride, pad;
     int Lin, Lout, B;          // valid input positions, output positions per frustum
@@ -67,6 +68,7 @@ struct CgLayer {
 };
 
 #define SEL3(i, a0, a1, a2) ((i) == 0 ? (a0) : ((i) == 1 ? (a1) : (a2)))
+#define SEL4(i, a0, a1, a2, a3) ((i) == 0 ? (a0) : ((i) == 1 ? (a1) : ((i) == 2 ? (a2) : (a3))))
 
 // Intra-kernel phase stamps for TUNING BUILDS ONLY (-DFCN_PROBE, tools/fcn_probe.py; never compiled into the product):
 // wave 0 of every workgroup records the 100 MHz device clock at phase boundaries into a global table.
@@ -145,13 +147,13 @@ __device__ __forceinline__ void cg_locate(const CgLayer &L, int kk, int &sg, int
 {
     sg = 0; segoff = 0;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < CG_NSEG; ++s) {
         if (s < L.nseg) {
             const int span = L.KT * L.seg[s].C;
             if (sg == s && kk >= span) { kk -= span; segoff += span; sg = s + 1; }
         }
     }
-    const int C = SEL3(sg, opaque_s(L.seg[0].C), opaque_s(L.seg[1].C), opaque_s(L.seg[2].C));
+    const int C = SEL4(sg, opaque_s(L.seg[0].C), opaque_s(L.seg[1].C), opaque_s(L.seg[2].C), opaque_s(L.seg[3].C));
     cg_divmod(kk, C, cg_inv(C), tap, k0);               // kk < CG_KMAX
 }
 
@@ -188,7 +190,7 @@ __device__ __forceinline__ void cg_fill_bn(const CgLayer &L, float *sS, float *t
 {
     int off = 0;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < CG_NSEG; ++s) {
         if (s < L.nseg) {
             const CgSeg &S = L.seg[s];
             const int C = S.C, span = L.KT * C;
@@ -257,10 +259,10 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     constexpr int RSTEP = TG / 8;
     const int nchunk = L.Ktot / KC, nit = (nchunk + G - 1) / G;
     // segment fields as scalars (static indices)
-    const float *x0 = opaque_s(L.seg[0].x), *x1 = opaque_s(L.seg[1].x), *x2 = opaque_s(L.seg[2].x);
-    const int C0 = opaque_s(L.seg[0].C), C1 = opaque_s(L.seg[1].C), C2 = opaque_s(L.seg[2].C);
-    const int T0 = opaque_s(L.seg[0].type), T1 = opaque_s(L.seg[1].type), T2 = opaque_s(L.seg[2].type);
-    const int Q0 = opaque_s(L.seg[0].Lsrc), Q1 = opaque_s(L.seg[1].Lsrc), Q2 = opaque_s(L.seg[2].Lsrc);
+    const float *x0 = opaque_s(L.seg[0].x), *x1 = opaque_s(L.seg[1].x), *x2 = opaque_s(L.seg[2].x), *x3 = opaque_s(L.seg[3].x);
+    const int C0 = opaque_s(L.seg[0].C), C1 = opaque_s(L.seg[1].C), C2 = opaque_s(L.seg[2].C), C3 = opaque_s(L.seg[3].C);
+    const int T0 = opaque_s(L.seg[0].type), T1 = opaque_s(L.seg[1].type), T2 = opaque_s(L.seg[2].type), T3 = opaque_s(L.seg[3].type);
+    const int Q0 = opaque_s(L.seg[0].Lsrc), Q1 = opaque_s(L.seg[1].Lsrc), Q2 = opaque_s(L.seg[2].Lsrc), Q3 = opaque_s(L.seg[3].Lsrc);
     int bb[NA], ll[NA];
     bool rv[NA];
 #pragma unroll
@@ -296,8 +298,8 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     {                                                                                                                 \
         const int c_ = (cc);                                                                                          \
         const int sgi = (SG), tap = (TAP), k0 = (K0);                                                                 \
-        const float *x = SEL3(sgi, x0, x1, x2);                                                                       \
-        const int C = SEL3(sgi, C0, C1, C2), ty = SEL3(sgi, T0, T1, T2), Ls = SEL3(sgi, Q0, Q1, Q2);                  \
+        const float *x = SEL4(sgi, x0, x1, x2, x3);                                                                   \
+        const int C = SEL4(sgi, C0, C1, C2, C3), ty = SEL4(sgi, T0, T1, T2, T3), Ls = SEL4(sgi, Q0, Q1, Q2, Q3);      \
         _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                                \
             RA[i] = cg_load_raw(L, x, C, Ls, ty ? 0 : 1, tap, k0 + 4 * kq, bb[i], ll[i], rv[i], OK[i]);               \
         _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                                \
@@ -485,7 +487,7 @@ __device__ __forceinline__ float cg_dy(const float *coefS, int Cs, int ch, float
 // Weight packing descriptor of one layer: conv (Cout, Cin, KT) or deconv (Cin, Cout, k) <-> packed (N, Ktot).
 struct CgPack {
     int N, Ktot, KT, nseg;
-    int C[3], choff[3], type[3];      // GEMM channels, channel offset in the torch weight, segment type
+    int C[CG_NSEG], choff[CG_NSEG], type[CG_NSEG];      // GEMM channels, channel offset in the torch weight, segment type
     int nvec, cin_tot, deconv_k, cout_t;
 };
 
@@ -497,7 +499,7 @@ __device__ __forceinline__ int64_t cg_torch_index(const CgPack &p, int n, int kk
     }
     int sg = 0;
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < CG_NSEG; ++s)
         if (s < p.nseg && sg == s && kk >= p.KT * p.C[s]) { kk -= p.KT * p.C[s]; sg = s + 1; }
     const int tap = kk / p.C[sg], k = kk % p.C[sg];
     if (p.type[sg] == 1 && k >= p.nvec) return -1;       // padding column of the virtual one-hot segment
@@ -584,7 +586,8 @@ struct CgBwdStep {
     const float *dz;           // its incoming dz (R x Cout)
     CgBnBwd cb;                // its BN backward (bstat null: no BN)
     int ndg;
-    CgDgSeg dg0, dg1, dg2;
+    CgDgSeg dg[CG_NSEG];       // read on the device through the kernarg segment only (cg_bwd_step_body), never indexed
+                               // dynamically through the by-value copy
     float *partial;            // wgrad partials of this layer
     int rows, w_ns, w_ny;      // rows per split (multiple of KC), splits, 64-row tiles of Wp
     int w_blk0, r_blk0;
@@ -596,7 +599,8 @@ struct CgBwdStep {
 // dgrad: G groups x (A [KC][36] + W [KC][LDN]) + BN-backward coefficients + chunk tables
 #define CGB_ASZ (KC * 36)
 #define CGB_LDS (CGB_G * (CGB_ASZ + KC * LDN))
-#define CGB_SMEM (CGB_LDS + 5 * CG_CMAX + 3 * (CG_KMAX / KC))
+#define CG_KBWD 2048           // largest reduction length of a data-gradient GEMM (block5_deconv: 8 * 256 output columns)
+#define CGB_SMEM (CGB_LDS + 5 * CG_CMAX + 3 * (CG_KBWD / KC))
 
 // G[rs][k] = sum_tap sum_n dy[r_out(rs,tap)][n] * Wp[n][segoff + tap*C + k]; 32 source rows x 64 source channels by 4
 // K-groups, then the producer-side epilogue: ReLU mask from its pre-BN output, accumulate (second consumer),
@@ -611,10 +615,10 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
     constexpr int ASZ = CGB_ASZ;                        // As padded so that Bs stays 16-B aligned
     float *lds = smem;
     float *coefS = smem + CGB_LDS;
-    int *cTap = (int *)(coefS + 5 * CG_CMAX), *cNb = cTap + CG_KMAX / KC, *cCh = cNb + CG_KMAX / KC;
+    int *cTap = (int *)(coefS + 5 * CG_CMAX), *cNb = cTap + CG_KBWD / KC, *cCh = cNb + CG_KBWD / KC;
     // sgi is workgroup-uniform: static-index selects, no dynamic struct indexing
-    const int SC = SEL3(sgi, opaque_s(L.seg[0].C), opaque_s(L.seg[1].C), opaque_s(L.seg[2].C));
-    const int SLsrc = SEL3(sgi, opaque_s(L.seg[0].Lsrc), opaque_s(L.seg[1].Lsrc), opaque_s(L.seg[2].Lsrc));
+    const int SC = SEL4(sgi, opaque_s(L.seg[0].C), opaque_s(L.seg[1].C), opaque_s(L.seg[2].C), opaque_s(L.seg[3].C));
+    const int SLsrc = SEL4(sgi, opaque_s(L.seg[0].Lsrc), opaque_s(L.seg[1].Lsrc), opaque_s(L.seg[2].Lsrc), opaque_s(L.seg[3].Lsrc));
     const int tid = threadIdx.x, g = tid / TG, gt = tid % TG;
     const int lane = tid & 63, gw = gt >> 6, l31 = lane & 31, lh = lane >> 5;
     const int wm = 0, wn = gw & 1;
@@ -812,12 +816,12 @@ __device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float
     int sg, tap, k0, so;
     cg_locate(L, kk0, sg, tap, k0, so);                   // kk0 is workgroup-uniform
     sg = __builtin_amdgcn_readfirstlane(sg);
-    const float *Sx = SEL3(sg, opaque_s(L.seg[0].x), opaque_s(L.seg[1].x), opaque_s(L.seg[2].x));
-    const float *Sbn = SEL3(sg, opaque_s((const float *)L.seg[0].bn), opaque_s((const float *)L.seg[1].bn),
-                            opaque_s((const float *)L.seg[2].bn));
-    const int SC = SEL3(sg, opaque_s(L.seg[0].C), opaque_s(L.seg[1].C), opaque_s(L.seg[2].C));
-    const int Sty = SEL3(sg, opaque_s(L.seg[0].type), opaque_s(L.seg[1].type), opaque_s(L.seg[2].type));
-    const int SLs = SEL3(sg, opaque_s(L.seg[0].Lsrc), opaque_s(L.seg[1].Lsrc), opaque_s(L.seg[2].Lsrc));
+    const float *Sx = SEL4(sg, opaque_s(L.seg[0].x), opaque_s(L.seg[1].x), opaque_s(L.seg[2].x), opaque_s(L.seg[3].x));
+    const float *Sbn = SEL4(sg, opaque_s((const float *)L.seg[0].bn), opaque_s((const float *)L.seg[1].bn),
+                            opaque_s((const float *)L.seg[2].bn), opaque_s((const float *)L.seg[3].bn));
+    const int SC = SEL4(sg, opaque_s(L.seg[0].C), opaque_s(L.seg[1].C), opaque_s(L.seg[2].C), opaque_s(L.seg[3].C));
+    const int Sty = SEL4(sg, opaque_s(L.seg[0].type), opaque_s(L.seg[1].type), opaque_s(L.seg[2].type), opaque_s(L.seg[3].type));
+    const int SLs = SEL4(sg, opaque_s(L.seg[0].Lsrc), opaque_s(L.seg[1].Lsrc), opaque_s(L.seg[2].Lsrc), opaque_s(L.seg[3].Lsrc));
     const int cq = gt & 15, rr0 = 2 * (gt >> 4);          // column quad, first row (rows rr0, rr0+1: a k pair)
     // per-thread constants of its 4 columns: BN-backward coefficients of dy, BN scale/shift of the A operand
     const bool hasbn = a.cb.bstat != nullptr;
@@ -967,25 +971,30 @@ __device__ __forceinline__ void cg_reduce_body(const CgReduce &q, int rid, float
 }
 
 template <int MM>
-__device__ __forceinline__ void cg_bwd_step_body(const CgBwdStep &a, const int bid, float *smem)
+__device__ __forceinline__ void cg_bwd_step_body(const CgBwdStep &a, const int bid, float *smem, const int koff)
 {
     if (bid >= a.r_blk0) { cg_reduce_body(a.red, bid - a.r_blk0, smem); return; }
     if (bid >= a.w_blk0) { cg_wgrad_body<MM>(a, bid - a.w_blk0, smem); return; }
-    const int role = (a.ndg > 2 && bid >= a.dg2.blk0) ? 2 : ((a.ndg > 1 && bid >= a.dg1.blk0) ? 1 : 0);
-#define DGF(f) SEL3(role, opaque_s(a.dg0.f), opaque_s(a.dg1.f), opaque_s(a.dg2.f))
-    const int ncb = DGF(ncb);
-    const int t = cg_xcd_tile(bid - DGF(blk0), DGF(tx) * ncb);
+    const int role = __builtin_amdgcn_readfirstlane(
+        (a.ndg > 3 && bid >= a.dg[3].blk0) ? 3 : ((a.ndg > 2 && bid >= a.dg[2].blk0) ? 2 : ((a.ndg > 1 && bid >= a.dg[1].blk0) ? 1 : 0)));
+    // The role's segment descriptor is one of four: selecting it field by field from the by-value struct costs 4 x 14 pinned
+    // SGPRs, and indexing the struct dynamically makes LLVM copy the whole kernarg struct to scratch.  It IS an array in the
+    // kernarg segment, though: a scalar load at a wave-uniform offset from the kernarg pointer fetches exactly one.
+    typedef __attribute__((address_space(4))) const char *kchar_p;
+    typedef __attribute__((address_space(4))) const CgDgSeg *kdg_p;
+    const kdg_p g = (kdg_p)((kchar_p)__builtin_amdgcn_kernarg_segment_ptr() + koff + offsetof(CgBwdStep, dg)) + role;
+    const int ncb = g->ncb;
+    const int t = cg_xcd_tile(bid - g->blk0, g->tx * ncb);
     if (t < 0) return;
-    cg_dgrad_body<MM>(a.lay, a.cb, a.dz, a.lay.y, DGF(sg), DGF(segoff), DGF(ysrc), DGF(bnsrc), DGF(out), DGF(accumulate),
-                  DGF(bstat_src), t / ncb, t % ncb, bid == 0, smem);
-#undef DGF
+    cg_dgrad_body<MM>(a.lay, a.cb, a.dz, a.lay.y, g->sg, g->segoff, g->ysrc, g->bnsrc, g->out, g->accumulate,
+                      g->bstat_src, t / ncb, t % ncb, bid == 0, smem);
 }
 
 template <int MM>
 __global__ __launch_bounds__(CGB_T) void cg_bwd_step_kernel(CgBwdStep a)
 {
     __shared__ __attribute__((aligned(16))) float smem[CGB_SMEM];
-    cg_bwd_step_body<MM>(a, blockIdx.x, smem);
+    cg_bwd_step_body<MM>(a, blockIdx.x, smem, 0);
 }
 
 // A chain step and an OFF-CHAIN step (the backward of a deconvolution, which only hangs off the heads) in one launch:
@@ -1000,19 +1009,24 @@ __global__ __launch_bounds__(CGB_T) void cg_bwd_pair_kernel(CgBwdPair p)
 {
     __shared__ __attribute__((aligned(16))) float smem[CGB_SMEM];
     const int bid = blockIdx.x;
-    if (bid < p.na) cg_bwd_step_body<MM>(p.A, bid, smem);
-    else cg_bwd_step_body<MM>(p.B, bid - p.na, smem);
+    if (bid < p.na) cg_bwd_step_body<MM>(p.A, bid, smem, (int)offsetof(CgBwdPair, A));
+    else cg_bwd_step_body<MM>(p.B, bid - p.na, smem, (int)offsetof(CgBwdPair, B));
 }
 
 // ================================================================================================
-// Host side: the fixed topology of ConvFeatNet(128, nvec) + heads.
-// layer ids:  0 b1c1  1 b2c1  2 b2c2  3 b2m  4 b3c1  5 b3c2  6 b3m  7 b4c1  8 b4c2  9 b4m  10 b2d  11 b3d  12 b4d  13 heads
+// Host side: the topology of ConvFeatNet(128, nvec) + heads for n = 4 (models/det_base.py:163-224) or n = 5 pyramid levels
+// (models/det_base_sunrgbd.py:174-251).  Layer ids (include/fcn_hip.h):
+//   0 block1_conv1;  1 + 3*(j-2) + {0,1,2}: block{j}_conv1 / _conv2 / _merge (j = 2..n);  3n-2 + (j-2): block{j}_deconv;
+//   4n-3: heads.
+// n = 4:  0 b1c1  1 b2c1  2 b2c2  3 b2m  4 b3c1  5 b3c2  6 b3m  7 b4c1  8 b4c2  9 b4m  10 b2d  11 b3d  12 b4d  13 heads
 // ================================================================================================
 struct CnPlan {
+    int nlev, nl, heads;        // levels, layers in use (4*nlev - 2), id of the heads
     int KT[CN_NLAYER], stride[CN_NLAYER], pad[CN_NLAYER], Lin[CN_NLAYER], Lout[CN_NLAYER];
     int N[CN_NLAYER], Cs[CN_NLAYER], Ktot[CN_NLAYER], dk[CN_NLAYER];
-    int nseg[CN_NLAYER], src[CN_NLAYER][3], C[CN_NLAYER][3], choff[CN_NLAYER][3];   // src: layer id, -1..-4 feats, -9 one-hot
+    int nseg[CN_NLAYER], src[CN_NLAYER][CG_NSEG], C[CN_NLAYER][CG_NSEG], choff[CN_NLAYER][CG_NSEG];   // src: layer id, -1..-5 feats, -9 one-hot
     int cin_tot[CN_NLAYER], nrow_real[CN_NLAYER];
+    int conv1[FCN_CN_MAXLEV + 1], conv2[FCN_CN_MAXLEV + 1], merge[FCN_CN_MAXLEV + 1], deconv[FCN_CN_MAXLEV + 1];   // ids by level (1-based)
 };
 
 static int conv_len(int L, int k, int s, int p) { return (L + 2 * p - k) / s + 1; }
@@ -1029,52 +1043,73 @@ static int pick_wrows(int R, int out_tiles)
     return rows;
 }
 
+static int cn_heads_width(const fcn_cn_desc *d) { return 2 + d->reg_out <= 64 ? 64 : 128; }
+
+extern "C" int fcn_convnet_logits_ld(const fcn_cn_desc *d)
+{
+    if (!d || d->reg_out < 1 || 2 + d->reg_out > 128) return -1;
+    return cn_heads_width(d);
+}
+
 static int cn_make_plan(const fcn_cn_desc *d, CnPlan &P)
 {
-    const int L1 = d->L[0], L2 = d->L[1], L3 = d->L[2], L4 = d->L[3];
-    if (conv_len(L1, 3, 2, 1) != L2 || conv_len(L2, 3, 2, 1) != L3 || conv_len(L3, 3, 2, 1) != L4) return FCN_E_BADARG;
-    if (2 * L3 < L2 || 4 * L4 < L2) return FCN_E_BADARG;
-    const int cw[10] = {128, 128, 128, 128, 256, 256, 256, 512, 512, 512};
-    const int Lo[10] = {L1, L2, L2, L2, L3, L3, L3, L4, L4, L4};
-    const int Li[10] = {L1, L1, L2, L2, L2, L3, L3, L3, L4, L4};
-    const int kt[10] = {3, 3, 3, 1, 3, 3, 1, 3, 3, 1};
-    const int st[10] = {1, 2, 1, 1, 2, 1, 1, 2, 1, 1};
-    for (int l = 0; l < CN_NLAYER; ++l) { P.dk[l] = 0; P.nseg[l] = 1; for (int s = 0; s < 3; ++s) { P.src[l][s] = 0; P.C[l][s] = 0; P.choff[l][s] = 0; } }
-    for (int l = 0; l < 10; ++l) {
-        P.KT[l] = kt[l]; P.stride[l] = st[l]; P.pad[l] = kt[l] == 3 ? 1 : 0; P.Lin[l] = Li[l]; P.Lout[l] = Lo[l];
-        P.N[l] = cw[l]; P.Cs[l] = cw[l]; P.nrow_real[l] = cw[l];
+    const int n = d->nlev ? d->nlev : 4;
+    const int c1 = d->c1 ? d->c1 : 128;
+    if (n != 4 && n != 5) return FCN_E_BADARG;
+    if (c1 != 64 && c1 != 128) return FCN_E_BADARG;
+    if (d->reg_out < 1 || 2 + d->reg_out > 128) return FCN_E_LIMIT;
+    const int *Lv = d->L;                                   // Lv[j-1]: positions of level j
+    for (int j = 1; j < n; ++j) {
+        if (conv_len(Lv[j - 1], 3, 2, 1) != Lv[j]) return FCN_E_BADARG;
+        if (j >= 2 && (Lv[j] << (j - 1)) < Lv[1]) return FCN_E_BADARG;      // the deconvolution output is cut to L2 positions
     }
-    // segments
-    P.nseg[0] = 2; P.src[0][0] = -1; P.C[0][0] = 128; P.src[0][1] = -9; P.C[0][1] = OH_PAD; P.choff[0][1] = 128;
-    P.src[1][0] = 0; P.C[1][0] = 128;  P.src[2][0] = 1; P.C[2][0] = 128;
-    P.nseg[3] = 3; P.src[3][0] = 2; P.C[3][0] = 128; P.src[3][1] = -2; P.C[3][1] = 128; P.choff[3][1] = 128;
-    P.src[3][2] = -9; P.C[3][2] = OH_PAD; P.choff[3][2] = 256;
-    P.src[4][0] = 3; P.C[4][0] = 128;  P.src[5][0] = 4; P.C[5][0] = 256;
-    P.nseg[6] = 3; P.src[6][0] = 5; P.C[6][0] = 256; P.src[6][1] = -3; P.C[6][1] = 256; P.choff[6][1] = 256;
-    P.src[6][2] = -9; P.C[6][2] = OH_PAD; P.choff[6][2] = 512;
-    P.src[7][0] = 6; P.C[7][0] = 256;  P.src[8][0] = 7; P.C[8][0] = 512;
-    P.nseg[9] = 3; P.src[9][0] = 8; P.C[9][0] = 512; P.src[9][1] = -4; P.C[9][1] = 512; P.choff[9][1] = 512;
-    P.src[9][2] = -9; P.C[9][2] = OH_PAD; P.choff[9][2] = 1024;
-    // deconvs: GEMM over input rows with N = k * 256
-    const int dsrc[3] = {3, 6, 9}, dkk[3] = {1, 2, 4}, dci[3] = {128, 256, 512}, dL[3] = {L2, L3, L4};
-    for (int q = 0; q < 3; ++q) {
-        const int l = 10 + q;
-        P.KT[l] = 1; P.stride[l] = 1; P.pad[l] = 0; P.Lin[l] = dL[q]; P.Lout[l] = dL[q];
-        P.N[l] = dkk[q] * 256; P.Cs[l] = 256; P.dk[l] = dkk[q]; P.nrow_real[l] = P.N[l];
-        P.src[l][0] = dsrc[q]; P.C[l][0] = dci[q];
-    }
-    // heads over cat(xx1, xx2[:L2], xx3[:L2]) -> 2 + out_size columns, padded to 64
-    P.KT[13] = 1; P.stride[13] = 1; P.pad[13] = 0; P.Lin[13] = L2; P.Lout[13] = L2; P.N[13] = 64; P.Cs[13] = 64;
-    P.nrow_real[13] = 2 + d->reg_out; P.nseg[13] = 3;
-    for (int s = 0; s < 3; ++s) { P.src[13][s] = 10 + s; P.C[13][s] = 256; P.choff[13][s] = 256 * s; }
-    if (P.nrow_real[13] > 64) return FCN_E_LIMIT;
+    const int bw[FCN_CN_MAXLEV + 1] = {0, c1, 128, 256, 512, 512};          // block widths by level
+    const int fc[FCN_CN_MAXLEV + 1] = {0, 128, 128, 256, 512, 512};         // pooled feature widths by level (PointNet C3)
+    P.nlev = n; P.nl = 4 * n - 2; P.heads = 4 * n - 3;
     for (int l = 0; l < CN_NLAYER; ++l) {
+        P.KT[l] = 1; P.stride[l] = 1; P.pad[l] = 0; P.Lin[l] = P.Lout[l] = 1; P.N[l] = P.Cs[l] = 64; P.nrow_real[l] = 0;
+        P.dk[l] = 0; P.nseg[l] = 1; P.Ktot[l] = 0; P.cin_tot[l] = 0;
+        for (int s = 0; s < CG_NSEG; ++s) { P.src[l][s] = 0; P.C[l][s] = 0; P.choff[l][s] = 0; }
+    }
+    auto conv = [&](int l, int kt, int st, int Li, int Lo, int width) {
+        P.KT[l] = kt; P.stride[l] = st; P.pad[l] = kt == 3 ? 1 : 0; P.Lin[l] = Li; P.Lout[l] = Lo;
+        P.N[l] = width; P.Cs[l] = width; P.nrow_real[l] = width;
+    };
+    // block1_conv1 over cat(feat1, one-hot)
+    conv(0, 3, 1, Lv[0], Lv[0], c1);
+    P.nseg[0] = 2; P.src[0][0] = -1; P.C[0][0] = fc[1]; P.src[0][1] = -9; P.C[0][1] = OH_PAD; P.choff[0][1] = fc[1];
+    P.conv1[1] = P.conv2[1] = P.merge[1] = 0; P.deconv[1] = -1;
+    for (int j = 2; j <= n; ++j) {
+        const int base = 1 + 3 * (j - 2);
+        P.conv1[j] = base; P.conv2[j] = base + 1; P.merge[j] = base + 2; P.deconv[j] = 3 * n - 2 + (j - 2);
+        conv(base, 3, 2, Lv[j - 2], Lv[j - 1], bw[j]);
+        P.src[base][0] = P.merge[j - 1]; P.C[base][0] = bw[j - 1];
+        conv(base + 1, 3, 1, Lv[j - 1], Lv[j - 1], bw[j]);
+        P.src[base + 1][0] = base; P.C[base + 1][0] = bw[j];
+        conv(base + 2, 1, 1, Lv[j - 1], Lv[j - 1], bw[j]);          // merge over cat(x, feat_j, one-hot)
+        P.nseg[base + 2] = 3;
+        P.src[base + 2][0] = base + 1; P.C[base + 2][0] = bw[j];
+        P.src[base + 2][1] = -j; P.C[base + 2][1] = fc[j]; P.choff[base + 2][1] = bw[j];
+        P.src[base + 2][2] = -9; P.C[base + 2][2] = OH_PAD; P.choff[base + 2][2] = bw[j] + fc[j];
+        // deconvolution (kernel = stride = 2^(j-2)): a GEMM over the input rows with N = k * 256
+        const int l = P.deconv[j], k = 1 << (j - 2);
+        P.KT[l] = 1; P.stride[l] = 1; P.pad[l] = 0; P.Lin[l] = Lv[j - 1]; P.Lout[l] = Lv[j - 1];
+        P.N[l] = k * 256; P.Cs[l] = 256; P.dk[l] = k; P.nrow_real[l] = P.N[l];
+        P.src[l][0] = base + 2; P.C[l][0] = bw[j];
+    }
+    // heads over cat(xx1, xx2[:L2], ...) -> 2 + reg_out columns, padded to 64 / 128
+    const int h = P.heads;
+    P.KT[h] = 1; P.stride[h] = 1; P.pad[h] = 0; P.Lin[h] = Lv[1]; P.Lout[h] = Lv[1];
+    P.N[h] = P.Cs[h] = cn_heads_width(d);
+    P.nrow_real[h] = 2 + d->reg_out; P.nseg[h] = n - 1;
+    for (int s = 0; s < n - 1; ++s) { P.src[h][s] = P.deconv[2 + s]; P.C[h][s] = 256; P.choff[h][s] = 256 * s; }
+    for (int l = 0; l < P.nl; ++l) {
         int cs = 0, ct = 0;
         for (int s = 0; s < P.nseg[l]; ++s) { cs += P.C[l][s]; ct += (P.src[l][s] == -9) ? d->nvec : P.C[l][s]; }
         P.Ktot[l] = P.KT[l] * cs;
         P.cin_tot[l] = ct;
         // LDS tables of the kernels: per-column BN scale/shift, per-chunk descriptors, BN-backward coefficients
-        if (P.Ktot[l] > CG_KMAX || P.KT[l] * P.N[l] > CG_KMAX || P.Cs[l] > 512 || P.KT[l] > 3 || P.stride[l] > 2) return FCN_E_LIMIT;
+        if (P.Ktot[l] > CG_KMAX || P.KT[l] * P.N[l] > CG_KBWD || P.Cs[l] > CG_CMAX || P.KT[l] > 3 || P.stride[l] > 2) return FCN_E_LIMIT;
     }
     return 0;
 }
@@ -1088,7 +1123,7 @@ struct CnOffsets {
 static void cn_offsets(const fcn_cn_desc *d, const CnPlan &P, CnOffsets &O)
 {
     O.y[0] = O.wp[0] = 0; O.bn[0] = O.st[0] = O.coef[0] = 0;
-    for (int l = 0; l < CN_NLAYER; ++l) {
+    for (int l = 0; l < P.nl; ++l) {
         O.y[l + 1] = O.y[l] + (int64_t)d->B * P.Lout[l] * P.N[l];
         O.wp[l + 1] = O.wp[l] + (int64_t)P.N[l] * P.Ktot[l];
         O.bn[l + 1] = O.bn[l] + 4 * P.Cs[l];
@@ -1108,23 +1143,23 @@ extern "C" int fcn_convnet_sizes(const fcn_cn_desc *d, int64_t *out6)
     cn_offsets(d, P, O);
     const int64_t pmax = 4 * cn_partial_elems(d, P);   // (launch parity) x (chain / off-chain step): a step's reduce runs
                                                        // beside the next launch's weight gradients
-    out6[0] = O.y[CN_NLAYER];      // floats: y (and dz) of all layers
-    out6[1] = O.wp[CN_NLAYER];     // floats: packed weights
-    out6[2] = O.bn[CN_NLAYER];     // floats: bn scale/shift/mean/rstd
-    out6[3] = O.st[CN_NLAYER];     // doubles: stat (and bstat)
-    out6[4] = O.coef[CN_NLAYER];   // floats: coef
+    out6[0] = O.y[P.nl];      // floats: y (and dz) of all layers
+    out6[1] = O.wp[P.nl];     // floats: packed weights
+    out6[2] = O.bn[P.nl];     // floats: bn scale/shift/mean/rstd
+    out6[3] = O.st[P.nl];     // doubles: stat (and bstat)
+    out6[4] = O.coef[P.nl];   // floats: coef
     out6[5] = pmax;                // floats: wgrad partials
     return 0;
 }
 
 static void cn_fill_layer(const fcn_cn_desc *d, const fcn_cn_params *p, const CnPlan &P, const CnOffsets &O,
-                          const fcn_cn_ws *ws, const float *const feats[4], const float *one_hot, int l, CgLayer &L)
+                          const fcn_cn_ws *ws, const float *const *feats, const float *one_hot, int l, CgLayer &L)
 {
     L.nseg = P.nseg[l]; L.KT = P.KT[l]; L.stride = P.stride[l]; L.pad = P.pad[l];
     L.Lin = P.Lin[l]; L.Lout = P.Lout[l]; L.B = d->B; L.Cout = P.N[l]; L.Ktot = P.Ktot[l]; L.Cs = P.Cs[l];
     L.Wp = ws->wp + O.wp[l]; L.bias = nullptr; L.nbias = 0; L.y = ws->y + O.y[l]; L.stat = nullptr;
     L.eps = d->eps; L.momentum = d->momentum;
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < CG_NSEG; ++s) {
         CgSeg &S = L.seg[s];
         S.x = nullptr; S.bn = nullptr; S.C = P.C[l][s]; S.Lsrc = P.Lin[l]; S.type = 0; S.nvec = 0;
         S.stat = nullptr; S.gamma = S.beta = nullptr; S.rmean = S.rvar = nullptr; S.nbt = nullptr; S.M = 1.0; S.writer = 0;
@@ -1146,7 +1181,7 @@ static void cn_fill_layer(const fcn_cn_desc *d, const fcn_cn_params *p, const Cn
 static void cn_fill_pack(const fcn_cn_desc *d, const CnPlan &P, int l, CgPack &p)
 {
     p.N = P.N[l]; p.Ktot = P.Ktot[l]; p.KT = P.KT[l]; p.nseg = P.nseg[l];
-    for (int s = 0; s < 3; ++s) { p.C[s] = P.C[l][s]; p.choff[s] = P.choff[l][s]; p.type[s] = (P.src[l][s] == -9) ? 1 : 0; }
+    for (int s = 0; s < CG_NSEG; ++s) { p.C[s] = P.C[l][s]; p.choff[s] = P.choff[l][s]; p.type[s] = (P.src[l][s] == -9) ? 1 : 0; }
     p.nvec = d->nvec; p.cin_tot = P.cin_tot[l]; p.deconv_k = P.dk[l]; p.cout_t = 256;
 }
 
@@ -1156,14 +1191,18 @@ static int cn_pack(const fcn_cn_desc *d, const fcn_cn_params *p, const CnPlan &P
 {
     CgPackAll t;
     t.pre[0] = 0;
-    for (int l = 0; l < CN_NLAYER; ++l) {
+    for (int l = 0; l < P.nl; ++l) {
         cn_fill_pack(d, P, l, t.p[l]);
         t.src[l] = p->W[l]; t.dst[l] = ws->wp + O.wp[l];
         t.pre[l + 1] = t.pre[l] + (int64_t)P.N[l] * P.Ktot[l];
         t.nrow_real[l] = P.nrow_real[l];
     }
+    for (int l = P.nl; l < CN_NLAYER; ++l) {            // unused slots: empty ranges
+        cn_fill_pack(d, P, 0, t.p[l]);
+        t.src[l] = nullptr; t.dst[l] = nullptr; t.pre[l + 1] = t.pre[l]; t.nrow_real[l] = 0;
+    }
     t.oh = one_hot; t.oh64 = ws->oh64; t.B = d->B; t.nvec = d->nvec;
-    t.z0 = d->training ? ws->stat : nullptr; t.z1 = d->training ? ws->bstat : nullptr; t.nz = O.st[CN_NLAYER];
+    t.z0 = d->training ? ws->stat : nullptr; t.z1 = d->training ? ws->bstat : nullptr; t.nz = O.st[P.nl];
     hipLaunchKernelGGL(cg_pack_kernel,
                        dim3((unsigned)((t.pre[CN_NLAYER] + (int64_t)d->B * OH_PAD + t.nz + 255) / 256)), dim3(256), 0, st, t);
     FCN_CHECK_LAUNCH();
@@ -1186,22 +1225,23 @@ extern "C" int fcn_convnet_pack(const fcn_cn_desc *d, const fcn_cn_params *p, co
 }
 
 extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
-                                    const float *const feats[4], const float *one_hot, float *logits, void *stream,
-                                    void *const *feat_events);
+                                    const float *const feats[FCN_CN_MAXLEV], const float *one_hot, float *logits,
+                                    void *stream, void *const *feat_events);
 
 extern "C" int fcn_convnet_forward(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
-                                   const float *const feats[4], const float *one_hot, float *logits, void *stream)
+                                   const float *const feats[FCN_CN_MAXLEV], const float *one_hot, float *logits,
+                                   void *stream)
 {
     return fcn_convnet_forward2(d, p, ws, feats, one_hot, logits, stream, nullptr);
 }
 
-// feat_events: 4 hipEvent_t (or NULL entries), recorded by the caller when pooled feature map s is complete on whatever
+// feat_events: nlev hipEvent_t (or NULL entries), recorded by the caller when pooled feature map s is complete on whatever
 // stream produced it.  `stream` waits for event s right before the FIRST layer that reads map s (block1_conv1,
-// block2_merge, block3_merge, block4_merge): the FCN starts as soon as the finest scale is pooled and its first nine
-// layers run beside the widest scale's PointNet (the long pole of the forward), instead of after all four scales.
+// block{j}_merge): the FCN starts as soon as the finest scale is pooled and its first layers run beside the widest
+// scale's PointNet (the long pole of the forward), instead of after all scales.
 extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
-                                    const float *const feats[4], const float *one_hot, float *logits, void *stream,
-                                    void *const *feat_events)
+                                    const float *const feats[FCN_CN_MAXLEV], const float *one_hot, float *logits,
+                                    void *stream, void *const *feat_events)
 {
     if (!d || !p || !ws || !feats || !logits) return FCN_E_BADARG;
     if (!ws->y || !ws->wp || !ws->bn || !ws->stat || !ws->partial || !ws->oh64) return FCN_E_BADARG;
@@ -1216,11 +1256,23 @@ extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p
     if (d->precision < 0 || d->precision > FCN_PREC_BF16) return FCN_E_BADARG;
     const int mmf = FCN_MM_OF(d->precision, true);
     if (!d->prepacked) FCN_TRY(cn_pack(d, p, P, O, ws, one_hot, st));      // (also zeroes ws->stat / ws->bstat)
-    // launches in dependency order; {4, 10} and {7, 11} are pairs of independent layers reading the same merge output
-    const int order[CN_NLAYER] = {0, 1, 2, 3, 4, 10, 5, 6, 7, 11, 8, 9, 12, 13};
+    // launches in dependency order; block{j}_conv1 and block{j-1}_deconv (j >= 3) are pairs of independent layers reading
+    // the same merge output and share a launch (n = 4: {4, 10} and {7, 11})
+    int order[CN_NLAYER], norder = 0;
+    bool pair_head[CN_NLAYER];
+    for (int l = 0; l < CN_NLAYER; ++l) pair_head[l] = false;
+    order[norder++] = 0;
+    for (int j = 2; j <= P.nlev; ++j) {
+        order[norder++] = P.conv1[j];
+        if (j >= 3) { pair_head[P.conv1[j]] = true; order[norder++] = P.deconv[j - 1]; }
+        order[norder++] = P.conv2[j];
+        order[norder++] = P.merge[j];
+    }
+    order[norder++] = P.deconv[P.nlev];
+    order[norder++] = P.heads;
     bool published[CN_NLAYER];
     for (int l = 0; l < CN_NLAYER; ++l) published[l] = false;
-    bool waited[4] = {false, false, false, false};
+    bool waited[FCN_CN_MAXLEV] = {false, false, false, false, false};
     auto prep = [&](int l, CgLayer &L) -> int {
         cn_fill_layer(d, p, P, O, ws, feats, one_hot, l, L);
         for (int s = 0; s < P.nseg[l]; ++s) {       // the first consumer of a BN layer publishes its statistics
@@ -1232,16 +1284,16 @@ extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p
                 waited[-src - 1] = true;
             }
         }
-        if (l == 13) { L.y = logits; L.bias = p->bias; L.nbias = P.nrow_real[13]; }
+        if (l == P.heads) { L.y = logits; L.bias = p->bias; L.nbias = P.nrow_real[l]; }
         else if (tr) L.stat = ws->stat + O.st[l];
         return 0;
     };
     // 32 x 32 tiles: 560 workgroups of 4 waves (2-3 resident per CU) instead of 280 of 8 (every level of the pyramid has
     // B*L*N/2048 = 280 tiles of 32 x 64 for 256 CUs); measured 369 -> 352 us over the forward
-    for (int q = 0; q < CN_NLAYER; ++q) {
+    for (int q = 0; q < norder; ++q) {
         const int l = order[q];
         const int R = d->B * P.Lout[l];
-        const bool pair = (l == 4 || l == 7) && q + 1 < CN_NLAYER;
+        const bool pair = pair_head[l] && q + 1 < norder;
         if (pair) {
             const int l2 = order[q + 1];
             CgLayerPair pp;
@@ -1278,7 +1330,7 @@ static void cn_wgrad_split(int R, int out_tiles, int &rows, int &ns)
 static int64_t cn_partial_elems(const fcn_cn_desc *d, const CnPlan &P)
 {
     int64_t pmax = 0;
-    for (int l = 0; l < CN_NLAYER; ++l) {
+    for (int l = 0; l < P.nl; ++l) {
         int rows, ns;
         cn_wgrad_split(d->B * P.Lout[l], (P.N[l] / 64) * (P.Ktot[l] / 64), rows, ns);
         const int64_t v = (int64_t)ns * P.N[l] * P.Ktot[l];
@@ -1288,19 +1340,19 @@ static int64_t cn_partial_elems(const fcn_cn_desc *d, const CnPlan &P)
 }
 
 extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
-                                    const float *const feats[4], const float *one_hot, const float *dlogits,
-                                    float *const dfeats[4], float *const dW[CN_NLAYER], float *const dgamma[CN_NLAYER],
-                                    float *const dbeta[CN_NLAYER], float *dbias, void *stream, void *stream2,
-                                    void *const *events)
+                                    const float *const feats[FCN_CN_MAXLEV], const float *one_hot, const float *dlogits,
+                                    float *const dfeats[FCN_CN_MAXLEV], float *const dW[CN_NLAYER],
+                                    float *const dgamma[CN_NLAYER], float *const dbeta[CN_NLAYER], float *dbias,
+                                    void *stream, void *stream2, void *const *events)
 {
     if (!d || !p || !ws || !feats || !dlogits || !dfeats || !dW || !dgamma || !dbeta || !dbias) return FCN_E_BADARG;
     if (!d->training) return FCN_E_BADARG;
     if (!ws->y || !ws->dz || !ws->wp || !ws->bn || !ws->bstat || !ws->coef || !ws->partial) return FCN_E_BADARG;
-    // stream2 / events (4 caller-owned hipEvent_t), optional: the gradient of the widest feature map (dfeats[3]) is final
-    // after the third launch (heads, block4_deconv, block4_merge).  From there the remaining launches continue
-    // on stream2 so that `stream` is free again: the caller's scale-4 PointNet backward -- the long pole -- starts beside
-    // the rest of the FCN backward instead of after it.  events[0]: fork; events[1]: dfeats[2] final (after
-    // block3_merge); events[2]: dfeats[1] final (after block2_merge); events[3]: everything final (dfeats[0], all dW).
+    // stream2 / events (nlev caller-owned hipEvent_t), optional: the gradient of the widest feature map (dfeats[nlev-1]) is
+    // final after the third launch (heads, last deconvolution, last merge).  From there the remaining launches continue
+    // on stream2 so that `stream` is free again: the caller's widest PointNet backward -- the long pole -- starts beside
+    // the rest of the FCN backward instead of after it.  events[0]: fork; events[k]: dfeats[nlev-1-k] final (after
+    // block{nlev-k}_merge), k = 1..nlev-2; events[nlev-1]: everything final (dfeats[0], all dW).
     const bool cont = stream2 != nullptr && events != nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (d->precision < 0 || d->precision > FCN_PREC_BF16) return FCN_E_BADARG;
@@ -1315,7 +1367,7 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
     // consumers still to come for each producer layer (to know which dgrad is the last one)
     int pending[CN_NLAYER];
     for (int l = 0; l < CN_NLAYER; ++l) pending[l] = 0;
-    for (int l = 0; l < CN_NLAYER; ++l)
+    for (int l = 0; l < P.nl; ++l)
         for (int s = 0; s < P.nseg[l]; ++s)
             if (P.src[l][s] >= 0) pending[P.src[l][s]] += 1;
     int seen[CN_NLAYER];
@@ -1328,8 +1380,8 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
     auto make_step = [&](int l, float *pbuf, CgBwdStep &a, CgReduce &own, int &own_blocks) -> int {
         a.ndg = 0; a.w_ns = 0; a.w_ny = 1; a.rows = 2 * KC; a.partial = nullptr; a.dz = nullptr;
         a.cb.bstat = nullptr; a.cb.gamma = nullptr; a.cb.bn = nullptr; a.cb.M = 1.0; a.cb.dgamma = nullptr; a.cb.dbeta = nullptr;
-        CgDgSeg *dgs[3] = {&a.dg0, &a.dg1, &a.dg2};
-        for (int s = 0; s < 3; ++s) {
+        CgDgSeg *dgs[CG_NSEG] = {&a.dg[0], &a.dg[1], &a.dg[2], &a.dg[3]};
+        for (int s = 0; s < CG_NSEG; ++s) {
             dgs[s]->sg = 0; dgs[s]->segoff = 0; dgs[s]->ysrc = dgs[s]->bnsrc = nullptr; dgs[s]->out = nullptr;
             dgs[s]->accumulate = 0; dgs[s]->bstat_src = nullptr; dgs[s]->tx = 1; dgs[s]->ncb = 1; dgs[s]->blk0 = 0;
         }
@@ -1343,8 +1395,8 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
         }
         cn_fill_layer(d, p, P, O, ws, feats, one_hot, l, a.lay);
         const int R = d->B * P.Lout[l];
-        a.dz = (l == 13) ? dlogits : ws->dz + O.y[l];
-        if (l == 13) {
+        a.dz = (l == P.heads) ? dlogits : ws->dz + O.y[l];
+        if (l == P.heads) {
             a.lay.y = nullptr;
         } else {
             a.cb.bstat = ws->bstat + O.st[l]; a.cb.gamma = p->gamma[l]; a.cb.bn = ws->bn + O.bn[l];
@@ -1386,18 +1438,30 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
         return nblk;
     };
 
-    // Launch plan: the chain 13 12 9 8 7 6 5 4 3 2 1 0, with the two off-chain deconvolution steps riding along:
-    // block3_deconv (11) beside block4_conv2 (8) and block2_deconv (10) beside block3_conv2 (5) -- each BEFORE the chain
-    // step that accumulates into the same gradient buffer (7 -> dz[6], 4 -> dz[3]), never in the same launch.
-    const int chain[13] = {13, 12, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0, -1};
-    const int rider[13] = {-1, -1, -1, 11, -1, -1, 10, -1, -1, -1, -1, -1, -1};
+    // Launch plan: the chain heads, last deconvolution, then merge / conv2 / conv1 of every level downwards, block1_conv1
+    // and a final reduce-only step (n = 4: 13 12 9 8 7 6 5 4 3 2 1 0 -1), with the off-chain deconvolution steps riding
+    // along: block{j-1}_deconv beside block{j}_conv2 (n = 4: 11 beside 8, 10 beside 5) -- each BEFORE the chain step that
+    // accumulates into the same gradient buffer (block{j}_conv1 -> dz[block{j-1}_merge]), never in the same launch.
+    int chain[CN_NLAYER + 1], rider[CN_NLAYER + 1], nchain = 0;
+    for (int k = 0; k <= CN_NLAYER; ++k) rider[k] = -1;
+    chain[nchain++] = P.heads;
+    chain[nchain++] = P.deconv[P.nlev];
+    for (int j = P.nlev; j >= 2; --j) {
+        chain[nchain++] = P.merge[j];
+        if (j >= 3) rider[nchain] = P.deconv[j - 1];
+        chain[nchain++] = P.conv2[j];
+        chain[nchain++] = P.conv1[j];
+    }
+    chain[nchain++] = 0;
+    chain[nchain++] = -1;
     CgReduce pendA, pendB;              // reduces that ride in the next launch
     int pendA_blocks = 0, pendB_blocks = 0;
     blank_reduce(pendA); blank_reduce(pendB);
     // the heads' bias gradient rides in the first launch, in the (still empty) reduce slot
-    pendA.partial = dlogits; pendA.nsplit = 64; pendA.pk.N = d->B * P.Lout[13]; pendA.nrow_real = P.nrow_real[13];
-    pendA.dW = dbias; pendA.gr = 0; pendA_blocks = 64;
-    for (int k = 0; k < 13; ++k) {
+    pendA.partial = dlogits; pendA.nsplit = P.N[P.heads]; pendA.pk.N = d->B * P.Lout[P.heads];
+    pendA.nrow_real = P.nrow_real[P.heads];
+    pendA.dW = dbias; pendA.gr = 0; pendA_blocks = P.N[P.heads];
+    for (int k = 0; k < nchain; ++k) {
         CgBwdPair pp;
         CgReduce ownA, ownB;
         int ownA_blocks = 0, ownB_blocks = 0;
@@ -1423,7 +1487,8 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
         if (cont) {
             const int l = chain[k];
             int ev = -1;
-            if (l == 9) ev = 0; else if (l == 6) ev = 1; else if (l == 3) ev = 2; else if (l == -1) ev = 3;
+            if (l == -1) ev = P.nlev - 1;
+            else for (int j = 2; j <= P.nlev; ++j) if (l == P.merge[j]) ev = P.nlev - j;
             if (ev >= 0) {
                 e = hipEventRecord((hipEvent_t)events[ev], st);
                 if (e != hipSuccess) return (int)e;

@@ -10,9 +10,11 @@
 // device-scope atomics; the last workgroup to arrive (ticket) turns the sums into the final scalars.
 #include "fcn_common.h"
 
-#define LT_THREADS 128
 #define LT_NB 12          // heading bins (cfg.DATA.NUM_HEADING_BIN default, det_base.py:245)
-#define LT_NS 3           // size clusters (KITTI)
+// The kernel is instantiated for NS = 3 size clusters (KITTI, 41 logits per row, 128-thread workgroups) and NS = 10
+// (SUN-RGBD, models/det_base_sunrgbd.py:271: 69 logits per row in 128-column rows, 64-thread workgroups -- the two staged
+// rows per thread must fit the LDS)
+#define LT_MIN_THREADS 64
 
 struct LossArgs {
     const float *cls_raw;      // (B,2,L2)
@@ -38,6 +40,7 @@ struct LossArgs {
     float *total;              // optional copy of out[0] in its own buffer (the differentiable scalar of the binding)
 };
 
+template <int NT>
 __device__ __forceinline__ float block_sum(float v, float *sh)
 {
     v = wave_sum_f32(v);
@@ -46,7 +49,7 @@ __device__ __forceinline__ float block_sum(float v, float *sh)
     if (lane == 0) sh[wave] = v;
     __syncthreads();
     float t = 0.f;
-    for (int w = 0; w < LT_THREADS / 64; ++w) t += sh[w];
+    for (int w = 0; w < NT / 64; ++w) t += sh[w];
     return t;
 }
 
@@ -68,20 +71,22 @@ __device__ __forceinline__ void corners8(float cx, float cy, float cz, float ang
     }
 }
 
+template <int NS, int LT_THREADS>
 __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
 {
+    constexpr int NB = LT_NB, NC = 3 + 2 * NB + 4 * NS;
+    constexpr int SW = (NC + 2) | 1;       // LDS row stride: the row's 2 + NC logits, odd
     __shared__ float sh[LT_THREADS / 64];
     __shared__ int last_s;
     // row-major variant: the workgroup's LT_THREADS gradient rows are staged here (odd stride: a thread writes its own
     // row without bank conflicts) and go out as coalesced 256-byte rows instead of 64 strided dwords per thread
-    __shared__ float gS[LT_THREADS * 65];
+    __shared__ float gS[LT_THREADS * SW];
     // the row's regression logits and its gradient row are indexed with run-time bins (heading class, size cluster): as
     // per-thread arrays they end up in scratch (320 B per lane, every access a trip to memory -- the kernel spent most of its
     // 50 us there); as LDS rows (odd stride, conflict-free) dynamic indexing is free
-    __shared__ float gG[LT_THREADS * 65];
+    __shared__ float gG[LT_THREADS * SW];
     const int tid = threadIdx.x;
     const int B = a.B, L2 = a.L2, R = B * L2;
-    constexpr int NB = LT_NB, NS = LT_NS, NC = 3 + 2 * NB + 4 * NS;
     const float TWO_PI = 6.283185307179586f, PI = 3.141592653589793f;
     const float per = (float)(6.283185307179586 / NB), half = (float)(6.283185307179586 / NB / 2.0);
 
@@ -92,8 +97,8 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
         cfg_ += (lab == 1) ? 1.f : 0.f;
         ckeep += (lab != -1) ? 1.f : 0.f;
     }
-    const float nfg = block_sum(cfg_, sh);
-    const float nkeep = block_sum(ckeep, sh);
+    const float nfg = block_sum<LT_THREADS>(cfg_, sh);
+    const float nkeep = block_sum<LT_THREADS>(ckeep, sh);
     const float inv_cls = 1.f / (nfg + 1e-14f);
     // a batch without a foreground row (the reference asserts on it, det_base.py:416): the foreground means report 0
     // instead of 0 * inf = NaN, and out[11] = nfg lets the caller see it without a host sync on the hot path
@@ -106,9 +111,11 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
     if (a.ld) {                        // the workgroup's logits rows come in as coalesced 256-byte rows too
         const int row0 = blockIdx.x * LT_THREADS;
         const int nrow = min(LT_THREADS, R - row0);
-        for (int i = tid; i < nrow * 64; i += LT_THREADS) {
-            const int rr = i >> 6, cc = i & 63;
-            gS[rr * 65 + cc] = (cc < a.ld) ? a.cls_raw[(int64_t)(row0 + rr) * a.ld + cc] : 0.f;
+        const int sh_ld = a.ld == 128 ? 7 : 6;          // ld is 64 or 128
+        for (int i = tid; i < nrow * a.ld; i += LT_THREADS) {
+            const int rr = i >> sh_ld, cc = i & (a.ld - 1);
+            const float v = a.cls_raw[(int64_t)(row0 + rr) * a.ld + cc];
+            if (cc < NC + 2) gS[rr * SW + cc] = v;
         }
         __syncthreads();
     }
@@ -117,8 +124,8 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
         const int b = r / L2, l = r % L2;
         const int64_t lab = a.cls_label[r];
         // ---------------- focal classification loss (common.py:217-232)
-        const float c0 = a.ld ? gS[tid * 65] : a.cls_raw[((int64_t)b * 2 + 0) * L2 + l];
-        const float c1 = a.ld ? gS[tid * 65 + 1] : a.cls_raw[((int64_t)b * 2 + 1) * L2 + l];
+        const float c0 = a.ld ? gS[tid * SW] : a.cls_raw[((int64_t)b * 2 + 0) * L2 + l];
+        const float c1 = a.ld ? gS[tid * SW + 1] : a.cls_raw[((int64_t)b * 2 + 1) * L2 + l];
         const float m = fmaxf(c0, c1);
         const float e0 = expf(c0 - m), e1 = expf(c1 - m);
         const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
@@ -137,22 +144,22 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
         }
         if (a.dcls) {
             if (a.ld) {
-                gG[tid * 65] = g0;
-                gG[tid * 65 + 1] = g1;
+                gG[tid * SW] = g0;
+                gG[tid * SW + 1] = g1;
             } else {
                 a.dcls[((int64_t)b * 2 + 0) * L2 + l] = g0;
                 a.dcls[((int64_t)b * 2 + 1) * L2 + l] = g1;
             }
         }
-        float *go = gG + tid * 65 + 2;
+        float *go = gG + tid * SW + 2;
 #pragma unroll
-        for (int j = 0; j < 62; ++j) go[j] = 0.f;
+        for (int j = 0; j < NC; ++j) go[j] = 0.f;
         if (lab == 1) {
             if (!a.ld) {
 #pragma unroll
-                for (int j = 0; j < NC; ++j) gS[tid * 65 + 2 + j] = a.reg_raw[((int64_t)b * NC + j) * L2 + l];
+                for (int j = 0; j < NC; ++j) gS[tid * SW + 2 + j] = a.reg_raw[((int64_t)b * NC + j) * L2 + l];
             }
-            const float *o = gS + tid * 65 + 2;
+            const float *o = gS + tid * SW + 2;
             const float rx = a.ref2[((int64_t)b * 3 + 0) * L2 + l], ry = a.ref2[((int64_t)b * 3 + 1) * L2 + l],
                         rz = a.ref2[((int64_t)b * 3 + 2) * L2 + l];
             const float clx = a.box_center[b * 3], cly = a.box_center[b * 3 + 1], clz = a.box_center[b * 3 + 2];
@@ -205,12 +212,16 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
 #pragma unroll
                 for (int j = 1; j < NS; ++j)
                     if (ss[j] > mx) { mx = ss[j]; am = j; }
-                float se = 0.f, ej[NS];
+                float se = 0.f;
 #pragma unroll
-                for (int j = 0; j < NS; ++j) { ej[j] = expf(ss[j] - mx); se += ej[j]; }
+                for (int j = 0; j < NS; ++j) {          // e_j parked in the gradient row (LDS), not in a private array
+                    const float ej = expf(ss[j] - mx);
+                    go[3 + 2 * NB + j] = ej;
+                    se += ej;
+                }
                 acc[5] += logf(se) + mx - ss[sc];
 #pragma unroll
-                for (int j = 0; j < NS; ++j) go[3 + 2 * NB + j] += wB * (ej[j] / se - (j == sc ? 1.f : 0.f));
+                for (int j = 0; j < NS; ++j) go[3 + 2 * NB + j] = wB * (go[3 + 2 * NB + j] / se - (j == sc ? 1.f : 0.f));
                 acc[10] += (am == sc) ? 1.f : 0.f;
             }
             const int so = 3 + 2 * NB + NS + sc * 3;      // the selected size-residual triple
@@ -284,16 +295,17 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
         __syncthreads();
         const int row0 = blockIdx.x * LT_THREADS;
         const int nrow = min(LT_THREADS, R - row0);
-        for (int i = tid; i < nrow * 64; i += LT_THREADS) {
-            const int rr = i >> 6, cc = i & 63;
-            if (cc < a.ld) a.dcls[(int64_t)(row0 + rr) * a.ld + cc] = gG[rr * 65 + cc];
+        const int sh_ld = a.ld == 128 ? 7 : 6;
+        for (int i = tid; i < nrow * a.ld; i += LT_THREADS) {
+            const int rr = i >> sh_ld, cc = i & (a.ld - 1);
+            a.dcls[(int64_t)(row0 + rr) * a.ld + cc] = cc < NC + 2 ? gG[rr * SW + cc] : 0.f;
         }
     }
     // ---- combine the workgroups: out[1..10] accumulate, out[15] (as int) is the arrival ticket; both were zeroed by the
     // hipMemsetAsync in front of the launch.  Accumulators are written and read with device-scope atomics only.
     float tot[11];
 #pragma unroll
-    for (int i = 1; i < 11; ++i) tot[i] = block_sum(acc[i], sh);
+    for (int i = 1; i < 11; ++i) tot[i] = block_sum<LT_THREADS>(acc[i], sh);
     if (tid == 0) {
         int ticket;
         if (a.scratch) {
@@ -339,14 +351,15 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
     }
 }
 
-static int launch_loss(const LossArgs &a, hipStream_t st)
+static int launch_loss(const LossArgs &a, int ns, hipStream_t st)
 {
     if (!a.scratch) {                   // accumulate-into-out path: the accumulators and the ticket start from zero
         hipError_t e = hipMemsetAsync(a.out, 0, 16 * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }
     const int R = a.B * a.L2;
-    hipLaunchKernelGGL(loss_tail_kernel, dim3((R + LT_THREADS - 1) / LT_THREADS), dim3(LT_THREADS), 0, st, a);
+    if (ns == 3) hipLaunchKernelGGL((loss_tail_kernel<3, 128>), dim3((R + 127) / 128), dim3(128), 0, st, a);
+    else hipLaunchKernelGGL((loss_tail_kernel<10, 64>), dim3((R + 63) / 64), dim3(64), 0, st, a);
     FCN_CHECK_LAUNCH();
     return 0;
 }
@@ -361,7 +374,7 @@ extern "C" int fcn_det_loss_tail(const float *cls_raw, const float *reg_raw, con
     if (!cls_raw || !reg_raw || !cls_label || !center_ref2 || !box3d_center || !box3d_heading || !box3d_size ||
         !size_class || !mean_size || !out16)
         return FCN_E_BADARG;
-    if (num_heading_bin != LT_NB || num_size_cluster != LT_NS) return FCN_E_LIMIT;
+    if (num_heading_bin != LT_NB || (num_size_cluster != 3 && num_size_cluster != 10)) return FCN_E_LIMIT;
     if (B <= 0 || L2 <= 0) return FCN_E_BADARG;
     LossArgs a;
     a.cls_raw = cls_raw; a.reg_raw = reg_raw; a.cls_label = cls_label; a.ref2 = center_ref2;
@@ -369,7 +382,7 @@ extern "C" int fcn_det_loss_tail(const float *cls_raw, const float *reg_raw, con
     a.mean_size = mean_size; a.out = out16; a.dcls = dcls; a.dreg = dreg; a.B = B; a.L2 = L2;
     a.w_box = w_box; a.w_corner = w_corner; a.w_headreg = w_headreg; a.w_sizereg = w_sizereg; a.ld = 0;
     a.scratch = nullptr; a.total = nullptr;
-    return launch_loss(a, (hipStream_t)stream);
+    return launch_loss(a, num_size_cluster, (hipStream_t)stream);
 }
 
 extern "C" int fcn_det_loss_tail_rows2(const float *logits, const int64_t *cls_label, const float *center_ref2,
@@ -393,7 +406,7 @@ extern "C" int fcn_det_loss_tail_rows(const float *logits, const int64_t *cls_la
 
 extern "C" int fcn_det_loss_tail_scratch_floats(int B, int L2)
 {
-    return (B <= 0 || L2 <= 0) ? 0 : 32 + 16 * ((B * L2 + LT_THREADS - 1) / LT_THREADS);
+    return (B <= 0 || L2 <= 0) ? 0 : 32 + 16 * ((B * L2 + LT_MIN_THREADS - 1) / LT_MIN_THREADS);   // (covers both workgroup sizes)
 }
 
 extern "C" int fcn_det_loss_tail_rows2(const float *logits, const int64_t *cls_label, const float *center_ref2,
@@ -406,13 +419,14 @@ extern "C" int fcn_det_loss_tail_rows2(const float *logits, const int64_t *cls_l
     if (!logits || !cls_label || !center_ref2 || !box3d_center || !box3d_heading || !box3d_size || !size_class ||
         !mean_size || !out16)
         return FCN_E_BADARG;
-    if (num_heading_bin != LT_NB || num_size_cluster != LT_NS) return FCN_E_LIMIT;
+    if (num_heading_bin != LT_NB || (num_size_cluster != 3 && num_size_cluster != 10)) return FCN_E_LIMIT;
     if (B <= 0 || L2 <= 0) return FCN_E_BADARG;
     LossArgs a;
     a.cls_raw = logits; a.reg_raw = nullptr; a.cls_label = cls_label; a.ref2 = center_ref2;
     a.box_center = box3d_center; a.box_heading = box3d_heading; a.box_size = box3d_size; a.size_class = size_class;
     a.mean_size = mean_size; a.out = out16; a.dcls = dlogits; a.dreg = nullptr; a.B = B; a.L2 = L2;
-    a.w_box = w_box; a.w_corner = w_corner; a.w_headreg = w_headreg; a.w_sizereg = w_sizereg; a.ld = 64;
+    a.w_box = w_box; a.w_corner = w_corner; a.w_headreg = w_headreg; a.w_sizereg = w_sizereg;
+    a.ld = (2 + 3 + 2 * num_heading_bin + 4 * num_size_cluster <= 64) ? 64 : 128;
     a.scratch = scratch; a.total = total;
-    return launch_loss(a, (hipStream_t)stream);
+    return launch_loss(a, num_size_cluster, (hipStream_t)stream);
 }

@@ -107,17 +107,20 @@ class PointNetModule(nn.Module):
 
 
 class PointNetFeat(nn.Module):
-    """Four scales (reference: models/det_base.py:107-159)."""
+    """Four scales (reference: models/det_base.py:107-159).  SCALES = (mlp widths, nsample) per scale; the 5-scale
+    SUN-RGBD variant (det_base_sunrgbd.py) overrides it."""
+
+    SCALES = (([64, 64, 128], 32), ([64, 64, 128], 64), ([128, 128, 256], 64), ([256, 256, 512], 128))
 
     def __init__(self, input_channel=3, num_vec=0):
         super(PointNetFeat, self).__init__()
         self.num_vec = num_vec
         u = cfg.DATA.HEIGHT_HALF
-        assert len(u) == 4
-        self.pointnet1 = PointNetModule(input_channel - 3, [64, 64, 128], u[0], 32, use_xyz=True, use_feature=True)
-        self.pointnet2 = PointNetModule(input_channel - 3, [64, 64, 128], u[1], 64, use_xyz=True, use_feature=True)
-        self.pointnet3 = PointNetModule(input_channel - 3, [128, 128, 256], u[2], 64, use_xyz=True, use_feature=True)
-        self.pointnet4 = PointNetModule(input_channel - 3, [256, 256, 512], u[3], 128, use_xyz=True, use_feature=True)
+        assert len(u) == len(self.SCALES)
+        self.num_scales = len(self.SCALES)
+        for i, (mlp, nsample) in enumerate(self.SCALES):        # children pointnet1..pointnetN, as the reference names them
+            setattr(self, "pointnet%d" % (i + 1),
+                    PointNetModule(input_channel - 3, list(mlp), u[i], nsample, use_xyz=True, use_feature=True))
         self.concurrent_scales = True
         self.fused_front = os.environ.get("FCN_FUSED_FRONT", "1") != "0"
         self._stream_cache = {}
@@ -134,21 +137,26 @@ class PointNetFeat(nn.Module):
         # captured branches already keep the CUs busy, and stretching the two latency-bound FCN chains costs more than
         # the overlap returns.  Kept as tested options of the C-ABI, off by default.
         self.topo = int(os.environ.get("FCN_TOPO", "0"))
-        mask = int(os.environ.get("FCN_PN_SIDE", "0" if self.topo & 1 else "8"))
-        for k, net in enumerate((self.pointnet1, self.pointnet2, self.pointnet3, self.pointnet4)):
+        mask = int(os.environ.get("FCN_PN_SIDE", "0" if self.topo & 1 else str(1 << (self.num_scales - 1))))
+        for k, net in enumerate(self.nets):
             net._pool.side_wgrad = bool(mask >> k & 1)
+
+    @property
+    def nets(self):
+        return tuple(getattr(self, "pointnet%d" % (i + 1)) for i in range(self.num_scales))
 
     def forward(self, point_cloud, sample_pc, feat=None, one_hot_vec=None, nlc=False, join=True):
         """join=False (fused FCN path): the caller's stream is NOT made to wait for the scales; self.done_events holds one
         event per scale for the consumer to wait on (fcn_convnet_forward2 does, map by map)."""
         if one_hot_vec is not None:
             assert self.num_vec == one_hot_vec.shape[1]
-        nets = (self.pointnet1, self.pointnet2, self.pointnet3, self.pointnet4)
+        nets = self.nets
+        ns = self.num_scales
         self.done_events = None
         if not (self.concurrent_scales and point_cloud.is_cuda) or os.environ.get("FCN_SERIAL", "0") == "1":
             return tuple(net.forward_pooled(point_cloud, ref, one_hot_vec, nlc) for net, ref in zip(nets, sample_pc))
-        # The four scales are independent until the FCN: scales 1-3 run on three HIP streams forked from the current one and
-        # the widest (scale 4, the long pole) on the current stream itself, captured as parallel branches of the step's
+        # The scales are independent until the FCN: all but the last run on HIP streams forked from the current one and
+        # the widest (the last scale, the long pole) on the current stream itself, captured as parallel branches of the step's
         # hipGraph, so one scale's tail (a few workgroups left on 256 CUs) overlaps the others' work.
         #  * Forks are flat: ROCm 7.2 stream capture crashes on a fork from an already-forked stream, and scale 4's backward
         #    forks a second stream for its weight-gradient GEMMs -- hence scale 4 stays on the current stream.
@@ -164,13 +172,14 @@ class PointNetFeat(nn.Module):
         prepared = None
         if self.fused_front:
             from .pointnet_fused import group_compact, launch_prepared
-            prepared = [nets[s].prepare_pooled(point_cloud, sample_pc[s], one_hot_vec, nlc) for s in range(4)]
+            prepared = [nets[s].prepare_pooled(point_cloud, sample_pc[s], one_hot_vec, nlc) for s in range(ns)]
             group_compact(prepared, point_cloud)
         fork.record(cur)
-        handles = [None] * 4
+        handles = [None] * ns
         s4_forked = bool(self.topo & 1)
-        sts = [streams[0], streams[1], streams[2], streams[3] if s4_forked else cur]
-        for s in ((3, 0, 1, 2) if s4_forked else (3, 2, 0, 1)):
+        sts = [streams[i] for i in range(ns - 1)] + [streams[ns - 1] if s4_forked else cur]
+        heavy_first = (ns - 1,) + tuple(range(ns - 2, 1, -1)) + (0, 1)          # 4 scales: (3, 2, 0, 1)
+        for s in (((ns - 1,) + tuple(range(ns - 1))) if s4_forked else heavy_first):
             st = sts[s]
             if st is not cur:
                 st.wait_event(fork)
@@ -179,16 +188,16 @@ class PointNetFeat(nn.Module):
                     handles[s] = launch_prepared(prepared[s])
                 else:
                     handles[s] = nets[s].launch_pooled(point_cloud, sample_pc[s], one_hot_vec, nlc)
-        outs = [None] * 4
+        outs = [None] * ns
         done = self._done_events(dev)
-        for s in (0, 1, 2, 3):
+        for s in range(ns):
             with torch.cuda.stream(sts[s]):
                 outs[s] = nets[s].attach_pooled(handles[s])
                 done[s].record(sts[s])
         if not (self.topo & 2):
             join = True
         if join:
-            for s in (0, 1, 2, 3):
+            for s in range(ns):
                 cur.wait_event(done[s])
                 outs[s].record_stream(cur)
         else:
@@ -198,7 +207,7 @@ class PointNetFeat(nn.Module):
     def _done_events(self, device):
         key = "done" + str(device)
         if key not in self._stream_cache:
-            self._stream_cache[key] = [torch.cuda.Event(enable_timing=False) for _ in range(4)]
+            self._stream_cache[key] = [torch.cuda.Event(enable_timing=False) for _ in range(self.num_scales)]
         return self._stream_cache[key]
 
     def _fork_event(self, device):
@@ -210,28 +219,33 @@ class PointNetFeat(nn.Module):
     def _streams(self, device):
         key = str(device)
         if key not in self._stream_cache:
-            self._stream_cache[key] = [torch.cuda.Stream(device=device) for _ in range(4)]
+            self._stream_cache[key] = [torch.cuda.Stream(device=device) for _ in range(self.num_scales)]
         return self._stream_cache[key]
 
 
 class ConvFeatNet(nn.Module):
-    """Conv1d FCN over the stacked frustum feature maps (reference: models/det_base.py:163-224)."""
+    """Conv1d FCN over the stacked frustum feature maps (reference: models/det_base.py:163-224).  LEVELS / WIDTHS describe
+    the pyramid: block1_conv1 has WIDTHS[0] channels, block{j}_* WIDTHS[j-1] (= the width of pooled map j), and
+    block{j}_deconv upsamples level j by 2^(j-2) to 256 channels; det_base_sunrgbd.py overrides them (5 levels, 64-wide block1)."""
+
+    LEVELS = 4
+    WIDTHS = (128, 128, 256, 512)
+    DECONV_FIRST = 2          # registration order of the deconvolutions (= state_dict / optimizer parameter order):
+                              # block2..block4 here (det_base.py:181-183), block5..block2 in det_base_sunrgbd.py:196-199
 
     def __init__(self, i_c=128, num_vec=3):
         super(ConvFeatNet, self).__init__()
-        self.block1_conv1 = Conv1d(i_c + num_vec, 128, 3, 1, 1)
-        self.block2_conv1 = Conv1d(128, 128, 3, 2, 1)
-        self.block2_conv2 = Conv1d(128, 128, 3, 1, 1)
-        self.block2_merge = Conv1d(128 + 128 + num_vec, 128, 1, 1)
-        self.block3_conv1 = Conv1d(128, 256, 3, 2, 1)
-        self.block3_conv2 = Conv1d(256, 256, 3, 1, 1)
-        self.block3_merge = Conv1d(256 + 256 + num_vec, 256, 1, 1)
-        self.block4_conv1 = Conv1d(256, 512, 3, 2, 1)
-        self.block4_conv2 = Conv1d(512, 512, 3, 1, 1)
-        self.block4_merge = Conv1d(512 + 512 + num_vec, 512, 1, 1)
-        self.block2_deconv = DeConv1d(128, 256, 1, 1, 0)
-        self.block3_deconv = DeConv1d(256, 256, 2, 2, 0)
-        self.block4_deconv = DeConv1d(512, 256, 4, 4, 0)
+        w = self.WIDTHS
+        assert len(w) == self.LEVELS
+        self.block1_conv1 = Conv1d(i_c + num_vec, w[0], 3, 1, 1)
+        for j in range(2, self.LEVELS + 1):
+            setattr(self, "block%d_conv1" % j, Conv1d(w[j - 2], w[j - 1], 3, 2, 1))
+            setattr(self, "block%d_conv2" % j, Conv1d(w[j - 1], w[j - 1], 3, 1, 1))
+            setattr(self, "block%d_merge" % j, Conv1d(w[j - 1] + w[j - 1] + num_vec, w[j - 1], 1, 1))
+        levels = range(2, self.LEVELS + 1)
+        for j in (levels if self.DECONV_FIRST == 2 else reversed(levels)):
+            k = 1 << (j - 2)
+            setattr(self, "block%d_deconv" % j, DeConv1d(w[j - 1], 256, k, k, 0))
         for m in self.modules():
             if isinstance(m, (nn.Conv1d, nn.ConvTranspose1d)):
                 nn.init.kaiming_normal_(m.weight.data, mode='fan_in')
@@ -241,23 +255,24 @@ class ConvFeatNet(nn.Module):
                 m.weight.data.fill_(1)
                 m.bias.data.zero_()
 
-    def forward(self, x1, x2, x3, x4):
-        x = self.block1_conv1(x1)
-        x = self.block2_conv2(self.block2_conv1(x))
-        xx1 = x = self.block2_merge(torch.cat([x, x2], 1))
-        x = self.block3_conv2(self.block3_conv1(x))
-        xx2 = x = self.block3_merge(torch.cat([x, x3], 1))
-        x = self.block4_conv2(self.block4_conv1(x))
-        xx3 = self.block4_merge(torch.cat([x, x4], 1))
-        xx1 = self.block2_deconv(xx1)
-        xx2 = self.block3_deconv(xx2)
-        xx3 = self.block4_deconv(xx3)
-        n = xx1.shape[-1]
-        return torch.cat([xx1, xx2[:, :, :n], xx3[:, :, :n]], 1)
+    def forward(self, *xs):
+        assert len(xs) == self.LEVELS
+        x = self.block1_conv1(xs[0])
+        ups = []
+        for j in range(2, self.LEVELS + 1):
+            x = getattr(self, "block%d_conv1" % j)(x)
+            x = getattr(self, "block%d_conv2" % j)(x)
+            x = getattr(self, "block%d_merge" % j)(torch.cat([x, xs[j - 1]], 1))
+            ups.append(getattr(self, "block%d_deconv" % j)(x))
+        n = ups[0].shape[-1]
+        return torch.cat([ups[0]] + [u[:, :, :n] for u in ups[1:]], 1)
 
 
 class PointNetDet(nn.Module):
     """Whole pipeline (reference: models/det_base.py:228-525)."""
+
+    FEAT_NET = PointNetFeat
+    CONV_NET = ConvFeatNet
 
     def __init__(self, input_channel=3, num_vec=0, num_classes=2):
         super(PointNetDet, self).__init__()
@@ -266,13 +281,16 @@ class PointNetDet(nn.Module):
         self.category_info = DATASET_INFO[dataset_name]
         self.num_size_cluster = len(self.category_info.CLASSES)
         self.mean_size_array = self.category_info.MEAN_SIZE_ARRAY
-        self.feat_net = PointNetFeat(input_channel, num_vec)
-        self.conv_net = ConvFeatNet(128, num_vec)
+        self.feat_net = self.FEAT_NET(input_channel, num_vec)
+        self.conv_net = self.CONV_NET(128, num_vec)
+        self.num_scales = self.feat_net.num_scales
+        assert self.conv_net.LEVELS == self.num_scales
         self.num_classes = num_classes
         self.num_bins = cfg.DATA.NUM_HEADING_BIN
         output_size = 3 + self.num_bins * 2 + self.num_size_cluster * 4
-        self.reg_out = nn.Conv1d(768, output_size, 1)
-        self.cls_out = nn.Conv1d(768, 2, 1)
+        head_in = 256 * (self.num_scales - 1)              # 768 (det_base.py:252-253) / 1024 (det_base_sunrgbd.py:278-279)
+        self.reg_out = nn.Conv1d(head_in, output_size, 1)
+        self.cls_out = nn.Conv1d(head_in, 2, 1)
         self.relu = nn.ReLU(True)
         nn.init.kaiming_uniform_(self.cls_out.weight, mode='fan_in')
         nn.init.kaiming_uniform_(self.reg_out.weight, mode='fan_in')
@@ -388,7 +406,7 @@ class PointNetDet(nn.Module):
         center_label = data_dicts.get('box3d_center')
         heading_label = data_dicts.get('box3d_heading')
         size_label = data_dicts.get('box3d_size')
-        refs = [data_dicts.get('center_ref%d' % i) for i in (1, 2, 3, 4)]
+        refs = [data_dicts.get('center_ref%d' % i) for i in range(1, self.num_scales + 1)]
 
         batch_size = point_cloud.shape[0]
         xyz = point_cloud[:, :3, :].contiguous()
@@ -417,13 +435,12 @@ class PointNetDet(nn.Module):
                 feats = leaves
             logits64 = convnet_fused(self._cn_pool, self.conv_net, self.cls_out, self.reg_out, feats, one_hot_vec, pre,
                                      self.feat_net.done_events)
-            lv = logits64.view(batch_size, refs[1].shape[2], 64)
+            lv = logits64.view(batch_size, refs[1].shape[2], logits64.shape[1])
             nreg = self.reg_out.weight.shape[0]
             cls_raw = lv[:, :, 0:2].permute(0, 2, 1)
             reg_raw = lv[:, :, 2:2 + nreg].permute(0, 2, 1)
         else:
-            feat1, feat2, feat3, feat4 = self.feat_net(xyz, refs, None, one_hot_vec)
-            x = self.conv_net(feat1, feat2, feat3, feat4)
+            x = self.conv_net(*self.feat_net(xyz, refs, None, one_hot_vec))
             cls_raw = self.cls_out(x)
             reg_raw = self.reg_out(x)
         self.last_logits = (cls_raw, reg_raw)
@@ -431,7 +448,7 @@ class PointNetDet(nn.Module):
 
         num_out = reg_raw.shape[2]
         fused_tail = (center_label is not None and self.fused_loss and cls_raw.is_cuda and self.iou_fn is None
-                      and not self.strict and self.num_bins == 12 and self.num_size_cluster == 3)
+                      and not self.strict and self.num_bins == 12 and self.num_size_cluster in (3, 10))
         if not fused_tail:       # the fused loss tail reads the raw logits itself: none of these copies / softmax
             cls_scores = cls_raw.permute(0, 2, 1).reshape(-1, 2)
             outputs = reg_raw.permute(0, 2, 1).reshape(-1, reg_raw.shape[1])

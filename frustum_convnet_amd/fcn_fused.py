@@ -1,19 +1,32 @@
 """Autograd binding of the fused ConvFeatNet + heads (C-ABI fcn_convnet_forward / fcn_convnet_backward,
-csrc/fcn_net.hip).  Input: the four position-major pooled feature maps of the PointNet scales; output: row-major
-logits (B*L2, 64) (cols 0..1 cls_out, 2..40 reg_out) that feed the fused loss tail directly."""
+csrc/fcn_net.hip).  Input: the four (models/det_base.py) or five (models/det_base_sunrgbd.py) position-major pooled
+feature maps of the PointNet scales; output: row-major logits (B*L2, ld) (cols 0..1 cls_out, 2.. reg_out; ld = 64 for
+KITTI's 41 columns, 128 for SUN-RGBD's 69) that feed the fused loss tail directly."""
 import ctypes
 import os
 
 import torch
 
 from . import _native
-from ._native import CnDesc, CnParams, CnWs
+from ._native import CnDesc, CnParams, CnWs, CN_MAXLEV, CN_MAXLAYER
 from . import precision as _precision
 from .common import bn_momentum
 
-LAYERS = ("block1_conv1", "block2_conv1", "block2_conv2", "block2_merge", "block3_conv1", "block3_conv2",
-          "block3_merge", "block4_conv1", "block4_conv2", "block4_merge", "block2_deconv", "block3_deconv",
-          "block4_deconv")
+def layer_names(nlev):
+    """BN layers of ConvFeatNet in the C-ABI's order (include/fcn_hip.h, fcn_cn_params): block1_conv1, block{j}_conv1 /
+    _conv2 / _merge for j = 2..nlev, then block{j}_deconv for j = 2..nlev (13 names for 4 levels, 17 for 5)."""
+    names = ["block1_conv1"]
+    for j in range(2, nlev + 1):
+        names += ["block%d_conv1" % j, "block%d_conv2" % j, "block%d_merge" % j]
+    names += ["block%d_deconv" % j for j in range(2, nlev + 1)]
+    return tuple(names)
+
+
+LAYERS = layer_names(4)
+
+
+def num_levels(conv_net):
+    return 5 if hasattr(conv_net, "block5_conv1") else 4
 
 
 class CnWorkspace:
@@ -58,15 +71,15 @@ class CnPool:
         self.last_done = None
 
     def cont_stream(self, device):
-        """Continuation stream of the backward + its 4 events (caller-owned, handed to fcn_convnet_backward)."""
+        """Continuation stream of the backward + its events (caller-owned, handed to fcn_convnet_backward)."""
         key = str(device)
         if key not in self.cont:
             with torch.cuda.device(device):
                 st = torch.cuda.Stream(device=device)
-                evs = [torch.cuda.Event(enable_timing=False) for _ in range(4)]
+                evs = [torch.cuda.Event(enable_timing=False) for _ in range(CN_MAXLEV)]
                 for ev in evs:
                     ev.record()                     # materialise the hipEvent_t handles
-                arr = (ctypes.c_void_p * 4)(*[ev.cuda_event for ev in evs])
+                arr = (ctypes.c_void_p * CN_MAXLEV)(*[ev.cuda_event for ev in evs])
             self.cont[key] = (st, evs, arr)
         return self.cont[key]
 
@@ -91,7 +104,7 @@ class CnPool:
         self.free.setdefault(ws.pool_key, []).append(ws)
 
 
-def _arr(ts, n=14):
+def _arr(ts, n=CN_MAXLAYER):
     vals = [None if t is None else t.data_ptr() for t in ts] + [None] * (n - len(ts))
     return (ctypes.c_void_p * n)(*vals)
 
@@ -99,11 +112,13 @@ def _arr(ts, n=14):
 def _prepare(pool, cfgt, bufs, one_hot, B, Ls, dev, pt):
     """Detached parameter views, descriptor, workspace and the C parameter struct of one forward."""
     training, eps, momentum, need_grad = cfgt
-    Ws = [w.detach().contiguous() for w in pt[0:13]]
-    gs = [g.detach().contiguous() for g in pt[13:26]]
-    bs = [b.detach().contiguous() for b in pt[26:39]]
-    cls_w, reg_w, cls_b, reg_b = [t.detach() for t in pt[39:43]]
-    # heads as one (2 + reg_out, 768) matrix: adjacent in memory under FlatTrainState (no copy), else concatenated
+    nlev = len(Ls)
+    nb = 4 * nlev - 3                          # BN layers: 13 (4 levels) / 17 (5 levels)
+    Ws = [w.detach().contiguous() for w in pt[0:nb]]
+    gs = [g.detach().contiguous() for g in pt[nb:2 * nb]]
+    bs = [b.detach().contiguous() for b in pt[2 * nb:3 * nb]]
+    cls_w, reg_w, cls_b, reg_b = [t.detach() for t in pt[3 * nb:3 * nb + 4]]
+    # heads as one (2 + reg_out, 256 * (nlev - 1)) matrix: adjacent in memory under FlatTrainState (no copy), else concatenated
     Wh = _adjacent(cls_w, reg_w)
     if Wh is None:
         Wh = torch.cat([cls_w, reg_w], 0).contiguous()
@@ -112,8 +127,8 @@ def _prepare(pool, cfgt, bufs, one_hot, B, Ls, dev, pt):
         bh = torch.cat([cls_b, reg_b], 0).contiguous()
     nvec = 0 if one_hot is None else one_hot.shape[1]
     oh = None if one_hot is None else one_hot.detach().contiguous().float()
-    desc = CnDesc(B, (ctypes.c_int32 * 4)(*Ls), nvec, reg_w.shape[0], 1 if training else 0, eps, momentum, 0,
-                  _precision.code())
+    desc = CnDesc(B, (ctypes.c_int32 * CN_MAXLEV)(*Ls), nvec, reg_w.shape[0], 1 if training else 0, eps, momentum, 0,
+                  _precision.code(), nlev, Ws[0].shape[0])
     ws = pool.acquire((B,) + tuple(Ls) + (nvec, reg_w.shape[0]), desc, dev, need_grad)
     rmeans, rvars, nbts = bufs
     params = CnParams(_arr(Ws + [Wh]), _arr(gs), _arr(bs), _arr(rmeans), _arr(rvars), _arr(nbts), bh.data_ptr())
@@ -123,12 +138,16 @@ def _prepare(pool, cfgt, bufs, one_hot, B, Ls, dev, pt):
 
 class _ConvNetFused(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pool, cfgt, bufs, one_hot, gdst, pre, feat_events, f1, f2, f3, f4, *pt):
-        # pt: 13 conv weights, 13 gammas, 13 betas, cls_w, reg_w, cls_b, reg_b
+    def forward(ctx, pool, cfgt, bufs, one_hot, gdst, pre, feat_events, nlev, *rest):
+        # rest: nlev pooled feature maps, then pt = nb conv weights, nb gammas, nb betas (nb = 4 * nlev - 3), cls_w, reg_w,
+        # cls_b, reg_b
         training, eps, momentum, need_grad = cfgt
         ctx.gdst = gdst
+        ctx.nlev = nlev
+        nb = 4 * nlev - 3
         L = _native.lib()
-        feats = [f.detach().contiguous() for f in (f1, f2, f3, f4)]
+        feats = [f.detach().contiguous() for f in rest[:nlev]]
+        pt = rest[nlev:]
         B = feats[0].shape[0]
         Ls = [f.shape[1] for f in feats]
         dev = feats[0].device
@@ -138,12 +157,16 @@ class _ConvNetFused(torch.autograd.Function):
             torch.cuda.current_stream(dev).wait_event(pre["event"])      # the packing ran on the side stream
         Ws, gs, bs, Wh, bh, oh, desc, ws, params = (pre[k] for k in ("Ws", "gs", "bs", "Wh", "bh", "oh", "desc", "ws",
                                                                     "params"))
-        assert list(desc.L) == Ls and desc.B == B
-        logits = torch.empty((B * Ls[1], 64), dtype=torch.float32, device=dev)
-        fp = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in feats])
+        assert list(desc.L)[:nlev] == Ls and desc.B == B
+        ld = L.fcn_convnet_logits_ld(ctypes.byref(desc))
+        if ld <= 0:
+            raise _native.NativeError("fcn_convnet_logits_ld: unsupported head width %d" % desc.reg_out)
+        logits = torch.empty((B * Ls[1], ld), dtype=torch.float32, device=dev)
+        fp = _arr(feats, CN_MAXLEV)
         evarr = None
         if feat_events is not None:      # per-map completion events: the C side waits for each right before its first use
-            evarr = (ctypes.c_void_p * 4)(*[None if e is None else e.cuda_event for e in feat_events])
+            evarr = (ctypes.c_void_p * CN_MAXLEV)(*([None if e is None else e.cuda_event for e in feat_events] +
+                                                    [None] * (CN_MAXLEV - len(feat_events))))
             cur = torch.cuda.current_stream(dev)
             for ft in feats:
                 ft.record_stream(cur)    # produced on the scales' streams, consumed here
@@ -154,7 +177,7 @@ class _ConvNetFused(torch.autograd.Function):
         ctx.pool, ctx.live = pool, need_grad
         if need_grad:
             ctx.ws, ctx.desc, ctx.keep = ws, desc, (feats, oh, Ws, Wh, gs, bs, bh)
-            ctx.shapes = [w.shape for w in pt[0:13]]
+            ctx.shapes = [w.shape for w in pt[0:nb]]
         else:
             pool.release(ws)
         return logits
@@ -168,28 +191,31 @@ class _ConvNetFused(torch.autograd.Function):
         feats, oh, Ws, Wh, gs, bs, bh = ctx.keep
         dev = dlogits.device
         dlogits = dlogits.contiguous().float()
+        nlev = ctx.nlev
+        nb = 4 * nlev - 3
         dfeats = [torch.empty_like(f) for f in feats]
         # gradient destinations: flat-buffer views under FlatTrainState (written in place, autograd gets None)
         gd = ctx.gdst
         pick = lambda j, like: gd[j] if gd[j] is not None else torch.empty_like(like)
-        dWh = None if gd[39] is None or gd[40] is None else _adjacent(gd[39], gd[40])
-        dbh = None if gd[41] is None or gd[42] is None else _adjacent(gd[41], gd[42])
+        h0 = 3 * nb                               # cls_w, reg_w, cls_b, reg_b follow the 3 * nb conv / BN parameters
+        dWh = None if gd[h0] is None or gd[h0 + 1] is None else _adjacent(gd[h0], gd[h0 + 1])
+        dbh = None if gd[h0 + 2] is None or gd[h0 + 3] is None else _adjacent(gd[h0 + 2], gd[h0 + 3])
         heads_direct = dWh is not None and dbh is not None
         if not heads_direct:
             dWh, dbh = torch.empty_like(Wh), torch.empty_like(bh)
-        dW = [pick(i, Ws[i]) for i in range(13)] + [dWh]
-        dg = [pick(13 + i, gs[i]) for i in range(13)]
-        db = [pick(26 + i, bs[i]) for i in range(13)]
+        dW = [pick(i, Ws[i]) for i in range(nb)] + [dWh]
+        dg = [pick(nb + i, gs[i]) for i in range(nb)]
+        db = [pick(2 * nb + i, bs[i]) for i in range(nb)]
         params = CnParams(_arr(Ws + [Wh]), _arr(gs), _arr(bs), _arr([]), _arr([]), _arr([]), bh.data_ptr())
-        fp = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in feats])
-        dfp = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in dfeats])
-        # continuation stream: after the third launch dfeats[3] is final and the rest of the chain moves to a second
+        fp = _arr(feats, CN_MAXLEV)
+        dfp = _arr(dfeats, CN_MAXLEV)
+        # continuation stream: after the third launch the widest map's gradient is final and the rest of the chain moves to a second
         # stream, so the scale-4 PointNet backward (the long pole, next on THIS stream) overlaps it.  The gradients of the
         # other maps become final on that stream: their consumers find the event to wait for in PENDING_GRADS.
         use_cont = bool(int(os.environ.get("FCN_TOPO", "0")) & 4)    # see det_base.PointNetFeat: measured slower, off
         cont, evs, evarr = ctx.pool.cont_stream(dev)
         if use_cont:
-            for t in dfeats[:3]:
+            for t in dfeats[:nlev - 1]:
                 t.record_stream(cont)
         with torch.cuda.device(dev):
             _native.check(L.fcn_convnet_backward(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(ws.c), fp,
@@ -200,33 +226,32 @@ class _ConvNetFused(torch.autograd.Function):
                                                  evarr if use_cont else None),
                           "fcn_convnet_backward")
         if not use_cont:
-            evs = [None] * 4
+            evs = [None] * CN_MAXLEV
         else:
-            PENDING_GRADS[dfeats[2].data_ptr()] = evs[1]
-            PENDING_GRADS[dfeats[1].data_ptr()] = evs[2]
-            PENDING_GRADS[dfeats[0].data_ptr()] = evs[3]
+            for k in range(1, nlev):                 # events[k]: dfeats[nlev-1-k] final
+                PENDING_GRADS[dfeats[nlev - 1 - k].data_ptr()] = evs[k]
         # the parameter gradients are final at evs[3] as well: whoever consumes dfeats[0] joins the continuation stream,
         # and this stream joins it here when nobody will (no PointNet consumer, e.g. features without grad)
-        ctx.pool.last_done = evs[3]
+        ev_done = evs[nlev - 1]
+        ctx.pool.last_done = ev_done
         ctx.pool.release(ws)
         ctx.ws, ctx.live = None, False
         ncls = 2
-        outs = list(dW[:13]) + dg + db
+        outs = list(dW[:nb]) + dg + db
         outs = [None if gd[j] is not None else t for j, t in enumerate(outs)]
         if heads_direct:
             hz = [None] * 4
         else:
-            hz = [dW[13][:ncls], dW[13][ncls:], dbh[:ncls], dbh[ncls:]]
+            hz = [dW[nb][:ncls], dW[nb][ncls:], dbh[:ncls], dbh[ncls:]]
             for j in range(4):
-                if gd[39 + j] is not None:           # flat views that are not adjacent: copy in, hand autograd nothing
-                    gd[39 + j].copy_(hz[j])
+                if gd[h0 + j] is not None:           # flat views that are not adjacent: copy in, hand autograd nothing
+                    gd[h0 + j].copy_(hz[j])
                     hz[j] = None
-        if evs[3] is not None and (any(o is not None for o in outs) or any(h is not None for h in hz)):
+        if ev_done is not None and (any(o is not None for o in outs) or any(h is not None for h in hz)):
             # ordinary autograd gradients are consumed on THIS stream as soon as we return: they are final on the
             # continuation stream only (FlatTrainState's in-place gradients need no such wait)
-            torch.cuda.current_stream(dev).wait_event(evs[3])
-        return (None, None, None, None, None, None, None, dfeats[0], dfeats[1], dfeats[2], dfeats[3]) + tuple(outs) + \
-            tuple(hz)
+            torch.cuda.current_stream(dev).wait_event(ev_done)
+        return (None,) * 8 + tuple(dfeats) + tuple(outs) + tuple(hz)
 
 
 def _adjacent(a, b):
@@ -242,7 +267,7 @@ def _adjacent(a, b):
 
 
 def _gather(conv_net, cls_out, reg_out):
-    seqs = [getattr(conv_net, n) for n in LAYERS]
+    seqs = [getattr(conv_net, n) for n in layer_names(num_levels(conv_net))]
     Ws = [s[0].weight for s in seqs]
     gs = [s[1].weight for s in seqs]
     bs = [s[1].bias for s in seqs]
@@ -278,7 +303,7 @@ def convnet_prepack(pool, conv_net, cls_out, reg_out, B, Ls, one_hot, device):
 
 
 def convnet_fused(pool, conv_net, cls_out, reg_out, feats, one_hot, pre=None, feat_events=None):
-    """feats: 4 x (B, L_s, C_s) position-major pooled features.  Returns logits (B*L2, 64).
+    """feats: 4 or 5 x (B, L_s, C_s) position-major pooled features.  Returns logits (B*L2, 64 | 128).
     feat_events: per-map torch.cuda.Event recorded when the map is complete on its producer's stream (None: the maps
     are already ordered before the current stream)."""
     if not feats[0].is_cuda:
@@ -293,5 +318,6 @@ def convnet_fused(pool, conv_net, cls_out, reg_out, feats, one_hot, pre=None, fe
         torch.cuda.current_stream(feats[0].device).wait_event(pre["event"])
         pre = None
     gdst = tuple(getattr(t, "_fcn_grad", None) for t in pt)
-    return _ConvNetFused.apply(pool, cfgt, bufs, one_hot, gdst, pre, feat_events, feats[0], feats[1], feats[2], feats[3],
-                               *pt)
+    if len(feats) != num_levels(conv_net):
+        raise ValueError("ConvFeatNet with %d levels got %d feature maps" % (num_levels(conv_net), len(feats)))
+    return _ConvNetFused.apply(pool, cfgt, bufs, one_hot, gdst, pre, feat_events, len(feats), *feats, *pt)

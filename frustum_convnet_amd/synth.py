@@ -59,13 +59,16 @@ def frustum_centres(stride, max_depth=70.0):
 
 
 def make_batch(batch, npoint, strides=(0.25, 0.5, 1.0, 2.0), max_depth=70.0, seed=1234,
-               variant="car", tilt=(0.0, 0.0), with_labels=True, z_range=None):
+               variant="car", tilt=(0.0, 0.0), with_labels=True, z_range=None, num_classes=3, mean_sizes=None):
     """Synthetic KITTI-car-shaped batch as a dict of numpy arrays (reference dict keys).
 
     variant: "car"     60 % foreground z ~ N(z_obj, 0.8^2), 40 % background U(0, max_depth)
              "uniform" z ~ U(0, max_depth)
     tilt:    (kx, ky) centre x,y = k * z (the reference projects the 2-D box centre along depth)
     z_range: optional (lo, hi) to confine everything (refine-stage style short frustums)
+    num_classes / mean_sizes: class count of the one-hot vector and the (num_classes, 3) mean-size table.  The defaults
+             give the KITTI batch (class 0 = Car for every sample); with a table (SUN-RGBD: 10 classes) sample b is an
+             object of class b % num_classes whose size is drawn around that class's mean.
     """
     B, N = batch, npoint
     lo, hi = (0.0, float(max_depth)) if z_range is None else z_range
@@ -87,8 +90,9 @@ def make_batch(batch, npoint, strides=(0.25, 0.5, 1.0, 2.0), max_depth=70.0, see
     pc = np.stack([x, y, z], axis=1).astype(np.float32)  # (B,3,N)
 
     out = {"point_cloud": pc}
-    one_hot = np.zeros((B, 3), dtype=np.float32)
-    one_hot[:, 0] = 1.0
+    obj_cls = np.zeros(B, dtype=np.int64) if mean_sizes is None else np.arange(B, dtype=np.int64) % num_classes
+    one_hot = np.zeros((B, num_classes), dtype=np.float32)
+    one_hot[np.arange(B), obj_cls] = 1.0
     out["one_hot"] = one_hot
     for s, stride in enumerate(strides):
         if z_range is None:
@@ -113,14 +117,15 @@ def make_batch(batch, npoint, strides=(0.25, 0.5, 1.0, 2.0), max_depth=70.0, see
                 cls[b, c + 1] = -1
             cls[b, c] = 1
         out["cls_label"] = cls
-        out["size_class"] = np.zeros((B, 1), dtype=np.int64)
+        out["size_class"] = obj_cls.reshape(B, 1).copy()
         ctr = np.zeros((B, 3), dtype=np.float64)
         ctr[:, 0] = tilt[0] * z_obj
         ctr[:, 1] = tilt[1] * z_obj
         ctr[:, 2] = z_obj
         out["box3d_center"] = ctr.astype(np.float32)
         out["box3d_heading"] = ((u("heading", (B, 1)) * 2.0 - 1.0) * np.pi).astype(np.float32)
-        size = np.array(CAR_MEAN_SIZE)[None, :] * (0.9 + 0.2 * u("size", (B, 3)))
+        base = np.array(CAR_MEAN_SIZE)[None, :] if mean_sizes is None else np.asarray(mean_sizes, dtype=np.float64)[obj_cls]
+        size = base * (0.9 + 0.2 * u("size", (B, 3)))
         out["box3d_size"] = size.astype(np.float32)
     return out
 

@@ -171,22 +171,33 @@ int fcn_pn_conv_fwd(const fcn_pn_desc *d, const fcn_pn_params *p, const fcn_pn_w
  * W[l]: the torch weight ((Cout,Cin,k) Conv1d / (Cin,Cout,k) ConvTranspose1d); W[13] = cat(cls_out.weight,
  * reg_out.weight) (2+reg_out, 768, 1), bias = cat of the two biases.
  * ------------------------------------------------------------------------------------------- */
+#define FCN_CN_MAXLEV 5          /* pyramid levels: 4 (models/det_base.py) or 5 (models/det_base_sunrgbd.py)     */
+#define FCN_CN_MAXLAYER 18       /* 4 * levels - 2 layers: 3*levels-2 convolutions, levels-1 deconvolutions, the heads */
+
 typedef struct fcn_cn_desc {
     int32_t B;
-    int32_t L[4];                /* positions of the four pooled feature maps (L[1] is the output length)      */
+    int32_t L[FCN_CN_MAXLEV];    /* positions of the pooled feature maps (L[1] is the output length); L[j+1] = conv(L[j], k3 s2 p1) */
     int32_t nvec;                /* one-hot width                                                               */
-    int32_t reg_out;             /* regression head width (39 for KITTI)                                        */
+    int32_t reg_out;             /* regression head width (39 for KITTI, 67 for SUN-RGBD); 2 + reg_out <= 128   */
     int32_t training;
     float   eps, momentum;
     int32_t prepacked;           /* 1: fcn_convnet_pack already ran for these weights / one-hot (joined by the caller) */
     int32_t precision;           /* FCN_PREC_*                                                                  */
+    int32_t nlev;                /* pyramid levels, 4 or 5 (0 = 4)                                              */
+    int32_t c1;                  /* width of block1_conv1: 128 (det_base.py:168) or 64 (det_base_sunrgbd.py:178); 0 = 128 */
 } fcn_cn_desc;
 
+/* Layer order of the parameter arrays for n = nlev levels (torch module names of ConvFeatNet):
+ *   0                      block1_conv1
+ *   1 + 3*(j-2) + {0,1,2}  block{j}_conv1, block{j}_conv2, block{j}_merge      for j = 2..n
+ *   3n-2 + (j-2)           block{j}_deconv                                      for j = 2..n
+ *   4n-3                   heads: rows 0..1 cls_out, rows 2.. reg_out, over cat of the n-1 deconvolution outputs
+ * (n = 4: 0 b1c1, 1-3 block2, 4-6 block3, 7-9 block4, 10-12 deconvs, 13 heads; n = 5: ... 10-12 block5, 13-16 deconvs, 17 heads) */
 typedef struct fcn_cn_params {
-    const float *W[14];
-    const float *gamma[14], *beta[14];
-    float *running_mean[14], *running_var[14];
-    int64_t *num_batches_tracked[14];
+    const float *W[FCN_CN_MAXLAYER];
+    const float *gamma[FCN_CN_MAXLAYER], *beta[FCN_CN_MAXLAYER];
+    float *running_mean[FCN_CN_MAXLAYER], *running_var[FCN_CN_MAXLAYER];
+    int64_t *num_batches_tracked[FCN_CN_MAXLAYER];
     const float *bias;           /* (2 + reg_out) heads bias */
 } fcn_cn_params;
 
@@ -204,30 +215,34 @@ int fcn_convnet_sizes(const fcn_cn_desc *d, int64_t *out6);
  * launch, so a caller can overlap it with the PointNet scales on another stream (then set d->prepacked = 1).  The launch
  * also zeroes ws.stat and ws.bstat (training): fcn_convnet_forward / _backward enqueue no memset of their own. */
 int fcn_convnet_pack(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws, const float *one_hot, void *stream);
-/* feats[s]: (B, L[s], C_s) with C = 128,128,256,512 (fcn_pn_forward with nlc = 1); logits: (B*L[1], 64) rows, columns
- * 0..1 = cls_out, 2..2+reg_out = reg_out, rest zero. */
+/* feats[s], s < nlev: (B, L[s], C_s) with C = 128,128,256,512(,512) (fcn_pn_forward with nlc = 1); logits: (B*L[1], ld) rows
+ * with ld = fcn_convnet_logits_ld(d) (64 when 2 + reg_out <= 64, else 128), columns 0..1 = cls_out, 2..2+reg_out = reg_out,
+ * rest zero. */
+int fcn_convnet_logits_ld(const fcn_cn_desc *d);
 int fcn_convnet_forward(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
-                        const float *const feats[4], const float *one_hot, float *logits, void *stream);
-/* Same with 4 optional hipEvent_t: `stream` waits for feat_events[s] right before the first layer that reads feats[s], so
- * the FCN runs beside the PointNet scales that are still in flight (the widest map is needed by the 10th layer only). */
+                        const float *const feats[FCN_CN_MAXLEV], const float *one_hot, float *logits, void *stream);
+/* Same with nlev optional hipEvent_t: `stream` waits for feat_events[s] right before the first layer that reads feats[s], so
+ * the FCN runs beside the PointNet scales that are still in flight (the widest map is needed by the last merge only). */
 int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
-                         const float *const feats[4], const float *one_hot, float *logits, void *stream,
+                         const float *const feats[FCN_CN_MAXLEV], const float *one_hot, float *logits, void *stream,
                          void *const *feat_events);
 int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
-                         const float *const feats[4], const float *one_hot, const float *dlogits,
-                         float *const dfeats[4], float *const dW[14], float *const dgamma[14],
-                         float *const dbeta[14], float *dbias, void *stream, void *stream2, void *const *events);
-/* One launch per chain layer (the two off-chain deconvolution steps ride along): its data-gradient tiles, its weight-gradient row splits and the reduce of the previous layer's
- * splits are workgroup roles of the same kernel.  stream2 / events: NULL, or a second stream + 4 caller-owned events --
- * after the launch that completes dfeats[3] the chain continues on stream2 (events[0] = fork, [1] = dfeats[2] final,
- * [2] = dfeats[1] final, [3] = all outputs final), so work queued on `stream` after the call waits for dfeats[3] only. */
+                         const float *const feats[FCN_CN_MAXLEV], const float *one_hot, const float *dlogits,
+                         float *const dfeats[FCN_CN_MAXLEV], float *const dW[FCN_CN_MAXLAYER],
+                         float *const dgamma[FCN_CN_MAXLAYER], float *const dbeta[FCN_CN_MAXLAYER], float *dbias,
+                         void *stream, void *stream2, void *const *events);
+/* One launch per chain layer (the off-chain deconvolution steps ride along): its data-gradient tiles, its weight-gradient
+ * row splits and the reduce of the previous layer's splits are workgroup roles of the same kernel.  stream2 / events: NULL,
+ * or a second stream + nlev caller-owned events -- after the launch that completes dfeats[nlev-1] the chain continues on
+ * stream2 (events[0] = fork, events[k] = dfeats[nlev-1-k] final for k = 1..nlev-2, events[nlev-1] = all outputs final), so
+ * work queued on `stream` after the call waits for the widest map's gradient only. */
 
 /* ---------------------------------------------------------------------------------------------
  * Fused train-loss tail of PointNetDet.forward (models/det_base.py:373-476; focal loss models/common.py:217-232,
  * huber + box corners models/model_util.py:9-19,48-72, encode/decode models/box_transform.py:5-65).
  *   cls_raw (B,2,L2), reg_raw (B,3+2*NB+4*NS,L2): raw head outputs;  cls_label (B,L2) int64 in {-1,0,1};
  *   center_ref2 (B,3,L2); box3d_center (B,3); box3d_heading (B,1); box3d_size (B,3); size_class (B,1) int64;
- *   mean_size (NS,3).  NB must be 12 and NS 3 (the KITTI configuration), else FCN_E_LIMIT.
+ *   mean_size (NS,3).  NB must be 12 and NS 3 (KITTI) or 10 (SUN-RGBD), else FCN_E_LIMIT.
  *   out16: total, cls, center, head_cls, head_res, size_cls, size_res, corners, cls_acc, head_acc, size_acc, nfg
  *   dcls / dreg: d(total)/d(cls_raw), d(total)/d(reg_raw), same layouts (NULL to skip).
  * ------------------------------------------------------------------------------------------- */
@@ -237,7 +252,8 @@ int fcn_det_loss_tail(const float *cls_raw, const float *reg_raw, const int64_t 
                       int B, int L2, int num_heading_bin, int num_size_cluster,
                       float w_box, float w_corner, float w_headreg, float w_sizereg,
                       float *out16, float *dcls, float *dreg, void *stream);
-/* Same on the row-major logits of fcn_convnet_forward: logits (B*L2, 64), dlogits same shape (fully written). */
+/* Same on the row-major logits of fcn_convnet_forward: logits (B*L2, ld), dlogits same shape (fully written); ld = 64 when
+ * 2 + 3 + 2*NB + 4*NS <= 64 (KITTI), else 128 (SUN-RGBD). */
 int fcn_det_loss_tail_rows(const float *logits, const int64_t *cls_label, const float *center_ref2,
                            const float *box3d_center, const float *box3d_heading, const float *box3d_size,
                            const int64_t *size_class, const float *mean_size, int B, int L2,

@@ -21,6 +21,12 @@ NSAMPLE = (32, 64, 64, 128)           # models/det_base.py:114-124
 MEAN_SIZE = np.array([[3.88311640418, 1.62856739989, 1.52563191462],
                       [0.84422524, 0.66068622, 1.76255119],
                       [1.76282397, 0.59706367, 1.73698127]])  # datasets/dataset_info.py:6-10
+NSAMPLE_SUNRGBD = (128, 128, 256, 256, 256)   # models/det_base_sunrgbd.py:113-128
+MEAN_SIZE_SUNRGBD = np.array([[0.765840, 1.398258, 0.472728], [2.114256, 1.620300, 0.927272],
+                              [0.404671, 1.071108, 1.688889], [0.591958, 0.552978, 0.827272],
+                              [0.695190, 1.346299, 0.736364], [0.528526, 1.002642, 1.172878],
+                              [0.500618, 0.632163, 0.683424], [0.923508, 1.867419, 0.845495],
+                              [0.791118, 1.279516, 0.718182], [0.699104, 0.454178, 0.756250]])  # datasets/dataset_info.py:24-35
 LOSS_W = dict(BOX=1.0, CORNER=10.0, HEAD_REG=20.0, SIZE_REG=20.0)  # configs/config.py:161-167
 
 
@@ -82,12 +88,14 @@ def pointnet_module(pc, ref, sd, prefix, dist, nsample, training, rec=None, grou
     return g * valid, idx, cnt
 
 
-def pointnet_feat(pc, refs, one_hot, sd, height_half, training, rec=None, keep=None):
-    """models/det_base.py:126-159 -> four pooled (B,C+3,L_s) maps."""
+def pointnet_feat(pc, refs, one_hot, sd, height_half, training, rec=None, keep=None, nsample=None):
+    """models/det_base.py:126-159 -> four pooled (B,C+3,L_s) maps (five with models/det_base_sunrgbd.py:130-170)."""
     feats = []
-    for s in range(4):
+    if nsample is None:
+        nsample = NSAMPLE if len(refs) == 4 else NSAMPLE_SUNRGBD
+    for s in range(len(refs)):
         g, idx, cnt = pointnet_module(pc, refs[s], sd, "feat_net.pointnet%d" % (s + 1),
-                                      float(height_half[s]), NSAMPLE[s], training, rec)
+                                      float(height_half[s]), nsample[s], training, rec)
         f = g.max(dim=-1)[0]
         if keep is not None:
             keep["idx%d" % (s + 1)] = idx
@@ -99,26 +107,20 @@ def pointnet_feat(pc, refs, one_hot, sd, height_half, training, rec=None, keep=N
     return feats
 
 
-def conv_feat_net(f1, f2, f3, f4, sd, training, rec=None, p="conv_net"):
-    """models/det_base.py:196-224."""
-    x = _cbr1d(f1, sd, p + ".block1_conv1", training, rec, 1, 1)
-    x = _cbr1d(x, sd, p + ".block2_conv1", training, rec, 2, 1)
-    x = _cbr1d(x, sd, p + ".block2_conv2", training, rec, 1, 1)
-    x = _cbr1d(torch.cat([x, f2], 1), sd, p + ".block2_merge", training, rec)
-    xx1 = x
-    x = _cbr1d(x, sd, p + ".block3_conv1", training, rec, 2, 1)
-    x = _cbr1d(x, sd, p + ".block3_conv2", training, rec, 1, 1)
-    x = _cbr1d(torch.cat([x, f3], 1), sd, p + ".block3_merge", training, rec)
-    xx2 = x
-    x = _cbr1d(x, sd, p + ".block4_conv1", training, rec, 2, 1)
-    x = _cbr1d(x, sd, p + ".block4_conv2", training, rec, 1, 1)
-    x = _cbr1d(torch.cat([x, f4], 1), sd, p + ".block4_merge", training, rec)
-    xx3 = x
-    xx1 = _dbr1d(xx1, sd, p + ".block2_deconv", training, rec, 1)
-    xx2 = _dbr1d(xx2, sd, p + ".block3_deconv", training, rec, 2)
-    xx3 = _dbr1d(xx3, sd, p + ".block4_deconv", training, rec, 4)
-    Lk = xx1.shape[-1]
-    return torch.cat([xx1, xx2[:, :, :Lk], xx3[:, :, :Lk]], 1)
+def conv_feat_net(*feats, sd, training, rec=None, p="conv_net"):
+    """models/det_base.py:196-224 (four maps) / models/det_base_sunrgbd.py:213-251 (five): block1_conv1, then per level j
+    >= 2 the stride-2 conv1, conv2 and the 1x1 merge with map j; every merge output is upsampled by block{j}_deconv
+    (kernel = stride = 2^(j-2)), cut to the length of the first and concatenated."""
+    x = _cbr1d(feats[0], sd, p + ".block1_conv1", training, rec, 1, 1)
+    ups = []
+    for j in range(2, len(feats) + 1):
+        x = _cbr1d(x, sd, p + ".block%d_conv1" % j, training, rec, 2, 1)
+        x = _cbr1d(x, sd, p + ".block%d_conv2" % j, training, rec, 1, 1)
+        x = _cbr1d(torch.cat([x, feats[j - 1]], 1), sd, p + ".block%d_merge" % j, training, rec)
+        ups.append((j, x))
+    ups = [_dbr1d(xx, sd, p + ".block%d_deconv" % j, training, rec, 1 << (j - 2)) for j, xx in ups]
+    Lk = ups[0].shape[-1]
+    return torch.cat([ups[0]] + [u[:, :, :Lk] for u in ups[1:]], 1)
 
 
 def heads(x, sd):
@@ -168,13 +170,18 @@ def size_decode(off, mean_size, cid):
     return sel * ex + ex
 
 
-def loss_tail(cls_raw, reg_raw, data, nb=12, ncls=3):
-    """Returns dict of the 8 loss scalars of models/det_base.py:505-514."""
+def loss_tail(cls_raw, reg_raw, data, nb=12, ncls=None, mean_size=None):
+    """Returns dict of the 8 loss scalars of models/det_base.py:505-514 (ncls / mean_size default to the dataset the head
+    width belongs to: 39 columns KITTI, 67 SUN-RGBD)."""
+    if ncls is None:
+        ncls = (reg_raw.shape[1] - 3 - 2 * nb) // 4
+    if mean_size is None:
+        mean_size = MEAN_SIZE if ncls == 3 else MEAN_SIZE_SUNRGBD
     B, _, L2 = cls_raw.shape
     cls = cls_raw.permute(0, 2, 1).reshape(-1, 2)
     out = reg_raw.permute(0, 2, 1).reshape(-1, reg_raw.shape[1])
     ref2 = data["center_ref2"].permute(0, 2, 1).reshape(-1, 3)
-    mean_size = torch.from_numpy(MEAN_SIZE).to(cls.dtype)
+    mean_size = torch.from_numpy(np.asarray(mean_size)).to(cls.dtype)
     prob = F.softmax(cls, -1)
     lab = data["cls_label"].view(-1)
     fg = (lab == 1).nonzero().view(-1)
@@ -224,9 +231,10 @@ def loss_tail(cls_raw, reg_raw, data, nb=12, ncls=3):
 
 
 def forward(sd, data, height_half=(0.25, 0.5, 1.0, 2.0), training=True, rec=None, keep=None, with_loss=True):
-    """Whole path.  Returns (cls_raw (B,2,L2), reg_raw (B,39,L2), losses or None)."""
+    """Whole path.  Returns (cls_raw (B,2,L2), reg_raw (B,39|67,L2), losses or None).  Four or five scales by the
+    center_ref keys present (and len(height_half))."""
     pc = data["point_cloud"][:, :3, :].contiguous()
-    refs = [data["center_ref%d" % i] for i in (1, 2, 3, 4)]
+    refs = [data["center_ref%d" % i] for i in range(1, 6) if ("center_ref%d" % i) in data]
     feats = pointnet_feat(pc, refs, data.get("one_hot"), sd, height_half, training, rec, keep)
     x = conv_feat_net(*feats, sd=sd, training=training, rec=rec)
     cls_raw, reg_raw = heads(x, sd)

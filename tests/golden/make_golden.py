@@ -9,7 +9,8 @@ Stand-ins injected before importing models/det_base.py (both unbuildable here, S
   ops.pybind11.box_ops_cc                  -> rbbox_iou_3d_pair returning zeros (boost::geometry absent;
                                               feeds no_grad metrics only, det_base.py:480-503)
 
-Usage:  python tests/golden/make_golden.py      (rewrites tests/golden/*.npz)
+Usage:  python tests/golden/make_golden.py           (rewrites the KITTI-model fixtures tests/golden/*.npz)
+        python tests/golden/make_golden.py sunrgbd   (writes sunrgbd_b4_n1024.npz from models/det_base_sunrgbd.py)
 """
 import hashlib
 import os
@@ -65,15 +66,16 @@ def _sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def _ref_model(height_half, seed=7):
+def _ref_model(height_half, seed=7, module="models.det_base", dataset="KITTI", num_vec=3):
     from configs.config import cfg
     cfg.immutable(False)
     cfg.DATA.HEIGHT_HALF = tuple(height_half)
     cfg.DATA.STRIDE = tuple(height_half)
+    cfg.DATA.DATASET_NAME = dataset
     import importlib
-    import models.det_base as det_base
+    det_base = importlib.import_module(module)
     importlib.reload(det_base)
-    model = det_base.PointNetDet(3, num_vec=3, num_classes=2)
+    model = det_base.PointNetDet(3, num_vec=num_vec, num_classes=2)
     synth.fill_state_dict(model.state_dict(), seed=seed)
     return model
 
@@ -88,11 +90,20 @@ def _capture_feats(model):
 
 
 def run_case(name, batch, npoint, strides, variant, tilt, z_range=None, full_idx=True, logit_samples=None,
-             grads=True, seed=1234):
-    data_np = synth.make_batch(batch, npoint, strides=strides, seed=seed, variant=variant, tilt=tilt,
-                               z_range=z_range)
+             grads=True, seed=1234, sunrgbd=False):
+    nscale = len(strides)
+    if sunrgbd:     # models/det_base_sunrgbd.py with the SUN-RGBD class table (cfgs/det_sample_sunrgbd.yaml)
+        from oracle.det_ref import MEAN_SIZE_SUNRGBD, NSAMPLE_SUNRGBD
+        data_np = synth.make_batch(batch, npoint, strides=strides, max_depth=8.0, seed=seed, variant=variant, tilt=tilt,
+                                   z_range=z_range, num_classes=10, mean_sizes=MEAN_SIZE_SUNRGBD)
+        model = _ref_model(strides, module="models.det_base_sunrgbd", dataset="SUNRGBD", num_vec=10)
+        nsamples = NSAMPLE_SUNRGBD
+    else:
+        data_np = synth.make_batch(batch, npoint, strides=strides, seed=seed, variant=variant, tilt=tilt,
+                                   z_range=z_range)
+        model = _ref_model(strides)
+        nsamples = (32, 64, 64, 128)
     data = synth.to_torch(data_np)
-    model = _ref_model(strides)
     keys = list(model.state_dict().keys())
     shapes = [tuple(v.shape) for v in model.state_dict().values()]
     out = {"meta_batch": batch, "meta_npoint": npoint, "meta_strides": np.array(strides),
@@ -102,8 +113,7 @@ def run_case(name, batch, npoint, strides, variant, tilt, z_range=None, full_idx
 
     # grouping through the stand-in (oracle), recorded per scale
     pc = data["point_cloud"][:, :3].contiguous()
-    nsamples = (32, 64, 64, 128)
-    for s in range(4):
+    for s in range(nscale):
         idx, cnt = grouping.query_depth_point(float(strides[s]), nsamples[s], pc.numpy(),
                                               data["center_ref%d" % (s + 1)].numpy())
         i2, c2 = grouping.query_depth_point_numpy(float(strides[s]), nsamples[s], pc.numpy(),
@@ -123,7 +133,7 @@ def run_case(name, batch, npoint, strides, variant, tilt, z_range=None, full_idx
     hk2 = model.reg_out.register_forward_hook(lambda m, i, o: caught.__setitem__("reg", o.detach().clone()))
     losses, metrics = model(data)
     feats = store["feats"]
-    for s in range(4):
+    for s in range(nscale):
         f = feats[s].numpy()
         out["feat%d_sum" % (s + 1)] = np.array([f.astype(np.float64).sum(), np.abs(f).astype(np.float64).sum()])
         out["feat%d_b0" % (s + 1)] = f[0, ::7, :].copy()           # every 7th channel of sample 0
@@ -145,7 +155,10 @@ def run_case(name, batch, npoint, strides, variant, tilt, z_range=None, full_idx
                   "feat_net.pointnet1.conv1.0.weight", "feat_net.pointnet1.conv1.1.weight",
                   "feat_net.pointnet1.conv1.1.bias", "feat_net.pointnet4.conv3.0.weight",
                   "feat_net.pointnet4.conv3.1.weight", "feat_net.pointnet2.conv2.0.weight",
-                  "conv_net.block1_conv1.0.weight"):
+                  "conv_net.block1_conv1.0.weight", "feat_net.pointnet5.conv3.0.weight",
+                  "conv_net.block5_deconv.0.weight", "conv_net.block5_merge.1.weight"):
+            if k not in named:
+                continue
             g = named[k].grad.numpy()
             if g.size > 40000:
                 g = g.reshape(g.shape[0], -1)[::8, ::4]
@@ -164,7 +177,7 @@ def run_case(name, batch, npoint, strides, variant, tilt, z_range=None, full_idx
     # eval-mode forward with the updated running stats, labels dropped -> 6-tuple
     model.eval()
     ev = {k: v for k, v in data.items() if k in ("point_cloud", "one_hot", "center_ref1", "center_ref2",
-                                                 "center_ref3", "center_ref4")}
+                                                 "center_ref3", "center_ref4", "center_ref5")}
     with torch.no_grad():
         tup = model(ev)
     out["cls_eval"] = caught["cls"][sel].numpy()
@@ -198,6 +211,10 @@ def main():
     torch.set_num_threads(8)
     _inject_standins()
     sys.path.insert(0, REF)
+    if len(sys.argv) > 1 and sys.argv[1] == "sunrgbd":     # only the 5-scale fixture (the others stay as committed)
+        run_case("sunrgbd_b4_n1024", 4, 1024, (0.1, 0.2, 0.4, 0.8, 1.6), "car", (0.01, 0.05), full_idx=False,
+                 sunrgbd=True)
+        return
     testpy_case()
     car = (0.25, 0.5, 1.0, 2.0)
     ppl = (0.1, 0.2, 0.4, 0.8)

@@ -17,6 +17,12 @@ def load_golden(name):
 def golden_inputs(g):
     zr = g["meta_z_range"]
     z_range = None if np.isnan(zr[0]) else (float(zr[0]), float(zr[1]))
+    if len(g["meta_strides"]) == 5:          # the SUN-RGBD fixture (tests/golden/make_golden.py sunrgbd): 8 m, 10 classes
+        from oracle.det_ref import MEAN_SIZE_SUNRGBD
+        return synth.make_batch(int(g["meta_batch"]), int(g["meta_npoint"]), strides=tuple(g["meta_strides"]),
+                                max_depth=8.0, seed=int(g["meta_seed"]), variant=str(g["meta_variant"]),
+                                tilt=tuple(g["meta_tilt"]), z_range=z_range, num_classes=10,
+                                mean_sizes=MEAN_SIZE_SUNRGBD)
     return synth.make_batch(int(g["meta_batch"]), int(g["meta_npoint"]), strides=tuple(g["meta_strides"]),
                             seed=int(g["meta_seed"]), variant=str(g["meta_variant"]),
                             tilt=tuple(g["meta_tilt"]), z_range=z_range)

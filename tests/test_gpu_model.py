@@ -14,11 +14,17 @@ TOL = 1e-4
 
 def _model(g):
     from frustum_convnet_amd.config import cfg, reset_cfg
-    from frustum_convnet_amd import det_base
+    from frustum_convnet_amd import det_base, det_base_sunrgbd
     reset_cfg()
     cfg.DATA.HEIGHT_HALF = tuple(float(x) for x in g["meta_strides"])
     cfg.DATA.STRIDE = cfg.DATA.HEIGHT_HALF
-    m = det_base.PointNetDet(3, num_vec=3, num_classes=2)
+    if len(cfg.DATA.HEIGHT_HALF) == 5:          # cfgs/det_sample_sunrgbd.yaml
+        cfg.DATA.DATASET_NAME = "SUNRGBD"
+        cfg.DATA.MAX_DEPTH = 8
+        cfg.IOU_THRESH = 0.25
+        m = det_base_sunrgbd.PointNetDet(3, num_vec=10, num_classes=2)
+    else:
+        m = det_base.PointNetDet(3, num_vec=3, num_classes=2)
     sd = golden_state_dict(g)
     assert list(m.state_dict().keys()) == list(sd.keys())
     m.load_state_dict(sd, strict=True)
@@ -26,7 +32,7 @@ def _model(g):
 
 
 @pytest.mark.parametrize("case", ["car_b4_n512", "car_b4_n512_uniform", "people_b2_n512", "refine_b4_n512",
-                                  "car_b32_n1024"])
+                                  "car_b32_n1024", "sunrgbd_b4_n1024"])
 def test_train_eval_parity(case):
     g = load_golden(case)
     data = synth.to_torch(golden_inputs(g), "cuda")
@@ -73,7 +79,7 @@ def test_train_eval_parity(case):
     # eval branch: 6-tuple from running statistics
     m.eval()
     ev = {k: v for k, v in data.items() if k in ("point_cloud", "one_hot", "center_ref1", "center_ref2",
-                                                 "center_ref3", "center_ref4")}
+                                                 "center_ref3", "center_ref4", "center_ref5")}
     with torch.no_grad():
         tup = m(ev)
     cls, reg = m.last_logits

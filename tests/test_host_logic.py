@@ -46,20 +46,46 @@ def test_bad_arguments_return_codes_without_gpu():
     d = _native.PnDesc(2, 16, 4, 4, 60, 64, 128, 0, 1, 1e-5, 0.1)
     assert lib.fcn_pn_forward(ctypes.byref(d), None, None, None, None, None, None) == 10001
     # every other entry point rejects null / inconsistent arguments before touching the device
-    cd = _native.CnDesc(2, (ctypes.c_int32 * 4)(280, 140, 70, 35), 3, 39, 1, 1e-5, 0.1, 0)
+    cd = _native.CnDesc(2, (ctypes.c_int32 * 5)(280, 140, 70, 35), 3, 39, 1, 1e-5, 0.1, 0)
     sizes = (ctypes.c_int64 * 6)()
     assert lib.fcn_convnet_sizes(ctypes.byref(cd), ctypes.byref(sizes)) == 0 and all(int(v) > 0 for v in sizes)
-    bad = _native.CnDesc(2, (ctypes.c_int32 * 4)(280, 141, 70, 35), 3, 39, 1, 1e-5, 0.1, 0)     # L2 != conv_len(L1)
+    bad = _native.CnDesc(2, (ctypes.c_int32 * 5)(280, 141, 70, 35), 3, 39, 1, 1e-5, 0.1, 0)     # L2 != conv_len(L1)
     assert lib.fcn_convnet_sizes(ctypes.byref(bad), ctypes.byref(sizes)) == 10001
     assert lib.fcn_convnet_sizes(None, None) == 10001
+    assert lib.fcn_convnet_logits_ld(ctypes.byref(cd)) == 64
+    # the 5-level plan of models/det_base_sunrgbd.py: L = 80..5, block1 64 wide, 67 regression columns -> 128-wide rows
+    c5 = _native.CnDesc(2, (ctypes.c_int32 * 5)(80, 40, 20, 10, 5), 10, 67, 1, 1e-5, 0.1, 0, 0, 5, 64)
+    assert lib.fcn_convnet_sizes(ctypes.byref(c5), ctypes.byref(sizes)) == 0 and all(int(v) > 0 for v in sizes)
+    assert lib.fcn_convnet_logits_ld(ctypes.byref(c5)) == 128
+    bad5 = _native.CnDesc(2, (ctypes.c_int32 * 5)(80, 40, 20, 10, 4), 10, 67, 1, 1e-5, 0.1, 0, 0, 5, 64)
+    assert lib.fcn_convnet_sizes(ctypes.byref(bad5), ctypes.byref(sizes)) == 10001
+    bad6 = _native.CnDesc(2, (ctypes.c_int32 * 5)(80, 40, 20, 10, 5), 10, 67, 1, 1e-5, 0.1, 0, 0, 6, 64)
+    assert lib.fcn_convnet_sizes(ctypes.byref(bad6), ctypes.byref(sizes)) == 10001
     assert lib.fcn_convnet_pack(ctypes.byref(cd), None, None, None, None) == 10001
-    assert lib.fcn_convnet_forward2(ctypes.byref(cd), None, None, (ctypes.c_void_p * 4)(), None, None, None, None) == 10001
+    assert lib.fcn_convnet_forward2(ctypes.byref(cd), None, None, (ctypes.c_void_p * 5)(), None, None, None, None) == 10001
     assert lib.fcn_adam_step_f32(None, None, None, None, 16, None, None, None) == 10001
     assert lib.fcn_adam_step_slots(0) == 0 and lib.fcn_adam_step_slots(3316780) == (3316780 // 4 + 511) // 512
     assert lib.fcn_stamp(None, None) == 10001
     idesc = _native.InpDesc(2, 64, 2, (ctypes.c_int32 * 4)(280, 140, 70, 35), (ctypes.c_double * 4)(0.25, 0.5, 1, 2), 70.0, 0, 0)
     assert lib.fcn_prepare_inputs(ctypes.byref(idesc), *([None] * 13), (ctypes.c_void_p * 4)(), *([None] * 7)) == 10001
     assert lib.fcn_det_loss_tail_rows(*([None] * 8), 2, 140, 12, 3, 1.0, 10.0, 20.0, 20.0, None, None, None) != 0
+
+
+def test_sunrgbd_state_dict_matches_reference():
+    """Keys, ORDER (it is the optimizer's parameter order in a checkpoint) and shapes of models/det_base_sunrgbd.py."""
+    from frustum_convnet_amd.config import cfg, reset_cfg
+    from frustum_convnet_amd import det_base_sunrgbd
+    reset_cfg()
+    g = load_golden("sunrgbd_b4_n1024")
+    cfg.DATA.HEIGHT_HALF = tuple(float(x) for x in g["meta_strides"])
+    cfg.DATA.DATASET_NAME = "SUNRGBD"
+    m = det_base_sunrgbd.PointNetDet(3, num_vec=10, num_classes=2)
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["state_keys"]]
+    for k, s in zip(g["state_keys"], g["state_shapes"]):
+        shape = tuple(int(x) for x in str(s).strip("()").split(",") if x.strip())
+        assert tuple(sd[str(k)].shape) == shape, k
+    reset_cfg()
 
 
 def test_state_dict_keys_and_shapes_match_reference():
