@@ -225,9 +225,10 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kind):
-    """HBM bytes from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, tools/gpu_traffic.sh) -- only when
-    they were measured on THIS kernel source (source hash recorded next to them); stale numbers are not reported."""
+def pmc_traffic(kind, entry=None):
+    """HBM bytes from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, written by tools/pmc_summarize.py from
+    tools/gpu_traffic.sh) -- only when they were measured on THESE kernel sources.  kind "step": the whole-step record;
+    kind "entry": {"launches_per_step", "bytes_per_step", "bytes_per_launch"} of one C-ABI entry point."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         d = json.load(open(p))
@@ -236,6 +237,9 @@ def pmc_traffic(kind):
     if d.get("source_hash") != source_hash():
         return None, "profiles/pmc_traffic.json was measured on other kernel sources (hash %s, now %s)" % (
             d.get("source_hash"), source_hash())
+    if kind == "entry":
+        e = d.get("entries", {}).get(entry)
+        return (e, None) if e else (None, "no PMC record for %s" % entry)
     return d.get(kind), None
 
 
@@ -473,8 +477,13 @@ def main():
                           else ("dense bf16 MFMA peak" if prec == "bf16" else "fp32 MFMA peak"))
             else:
                 rl.update(achieved=top["achieved_tbps"], peak=PEAK_HBM_TBPS, unit="TB/s")
-            tr, why = pmc_traffic("bytes_per_launch")
-            rl["traffic"] = tr
+            tr, why = pmc_traffic("entry", top["entry"].split("[")[0])
+            rl["traffic"] = tr["bytes_per_launch"] if tr else None
+            if tr:
+                rl["traffic_note"] = ("HBM bytes per launch of this entry point's kernels (%d launches, %.1f MB per step): "
+                                      "1024 * (2 * FETCH_SIZE + WRITE_SIZE) from separate rocprofv3 --pmc passes over the "
+                                      "replayed step (profiles/pmc_traffic.json)" % (tr["launches_per_step"],
+                                                                                     tr["bytes_per_step"] / 1e6))
             if why:
                 rl["traffic_note"] = why
             rl["how"] = ("top-time C-ABI entry point of one step: HIP events on its launch stream around the call, eager "

@@ -212,8 +212,13 @@ def main():
     _inject_standins()
     sys.path.insert(0, REF)
     if len(sys.argv) > 1 and sys.argv[1] == "sunrgbd":     # only the 5-scale fixture (the others stay as committed)
+        # seed 1329: of seeds 1234..1329 the one whose ConvFeatNet pre-ReLU activations stay furthest from zero (1.3e-5 in
+        # the fp64 oracle).  With seed 1234 one block3_conv1 activation sat at 1.2e-6 -- inside fp32 noise -- and the
+        # side of the ReLU kink it fell on moved the gradient norms of the early layers by 1 % (reference fp32 and the
+        # fp64 oracle on one side, a decomposed-BN fp32 evaluation and the HIP path on the other): a fixture must not
+        # test a coin flip.
         run_case("sunrgbd_b4_n1024", 4, 1024, (0.1, 0.2, 0.4, 0.8, 1.6), "car", (0.01, 0.05), full_idx=False,
-                 sunrgbd=True)
+                 sunrgbd=True, seed=1329)
         return
     testpy_case()
     car = (0.25, 0.5, 1.0, 2.0)

@@ -1,5 +1,6 @@
-"""-m gpu: size-independent properties at BASELINE.json's full size (KITTI-car, B=32, N=1024, 4 strides), where the CPU
-oracle is too slow to be the checker for every element."""
+"""-m gpu: size-independent properties at BASELINE.json's full sizes (B=32: KITTI-car N=1024 L=(280,140,70,35); people
+N=1024 L=(700,350,175,88); refine N=512 L=(20,10,5,3); SUN-RGBD N=2048, 5 scales L=(80,40,20,10,5)), where the CPU oracle
+is too slow to be the checker for every element."""
 import numpy as np
 import pytest
 import torch
@@ -10,28 +11,51 @@ pytestmark = pytest.mark.gpu
 B, N = 32, 1024
 
 
-def _full_batch(seed=4321):
-    return synth.to_torch(synth.make_batch(B, N, seed=seed, variant="car", tilt=(0.01, 0.05)), "cuda")
+# name: (strides, z_range, N, nsample per scale)
+CONFIGS = {
+    "car": ((0.25, 0.5, 1.0, 2.0), None, 1024, (32, 64, 64, 128)),
+    "people": ((0.1, 0.2, 0.4, 0.8), None, 1024, (32, 64, 64, 128)),
+    "refine": ((0.1, 0.2, 0.4, 0.8), (-1.0, 1.0), 512, (32, 64, 64, 128)),
+    "sunrgbd": ((0.1, 0.2, 0.4, 0.8, 1.6), None, 2048, (128, 128, 256, 256, 256)),
+}
 
 
-def _model(seed=7):
-    from frustum_convnet_amd.config import reset_cfg
-    from frustum_convnet_amd import det_base
+def _full_batch(seed=4321, cfg_name="car"):
+    strides, z_range, npoint, _ = CONFIGS[cfg_name]
+    if cfg_name == "sunrgbd":
+        from frustum_convnet_amd.dataset_info import SUNRGBDCategory
+        d = synth.make_batch(B, npoint, strides=strides, max_depth=8.0, seed=seed, variant="car", tilt=(0.01, 0.05),
+                             num_classes=10, mean_sizes=SUNRGBDCategory.MEAN_SIZE_ARRAY)
+    else:
+        d = synth.make_batch(B, npoint, strides=strides, seed=seed, variant="car", tilt=(0.01, 0.05), z_range=z_range)
+    return synth.to_torch(d, "cuda")
+
+
+def _model(seed=7, cfg_name="car"):
+    from frustum_convnet_amd.config import cfg, reset_cfg
+    from frustum_convnet_amd import det_base, det_base_sunrgbd
     reset_cfg()
-    m = det_base.PointNetDet(3, num_vec=3, num_classes=2)
+    cfg.DATA.HEIGHT_HALF = CONFIGS[cfg_name][0]
+    cfg.DATA.STRIDE = CONFIGS[cfg_name][0]
+    if cfg_name == "sunrgbd":
+        cfg.DATA.DATASET_NAME = "SUNRGBD"
+        m = det_base_sunrgbd.PointNetDet(3, num_vec=10, num_classes=2)
+    else:
+        m = det_base.PointNetDet(3, num_vec=3, num_classes=2)
     synth.fill_state_dict(m.state_dict(), seed=seed)
     return m.cuda()
 
 
-def test_grouping_structure_full_size():
+@pytest.mark.parametrize("cfg_name", sorted(CONFIGS))
+def test_grouping_structure_full_size(cfg_name):
     """Every window: the first cnt slots ascend strictly (points are taken in index order), lie inside the window
     (|z - zc| < dis_z, strict, fp32), the remaining slots repeat the first hit, cnt = min(hits, nsample) against a
     brute-force fp32 count, empty windows are all-zero."""
     from frustum_convnet_amd.query_depth_point import query_depth_point
-    data = _full_batch()
+    data = _full_batch(cfg_name=cfg_name)
     pc = data["point_cloud"][:, :3].contiguous()
     z = pc[:, 2, :]
-    for s, (dist, K) in enumerate(((0.25, 32), (0.5, 64), (1.0, 64), (2.0, 128))):
+    for s, (dist, K) in enumerate(zip(CONFIGS[cfg_name][0], CONFIGS[cfg_name][3])):
         ref = data["center_ref%d" % (s + 1)].contiguous()
         idx, cnt = query_depth_point(dist, K, pc, ref)
         zc = ref[:, 2, :]
@@ -53,13 +77,14 @@ def test_grouping_structure_full_size():
         assert bool(((ri == k) | ~live).all())
 
 
-def test_full_step_is_bitwise_reproducible():
+@pytest.mark.parametrize("cfg_name", sorted(CONFIGS))
+def test_full_step_is_bitwise_reproducible(cfg_name):
     """Two runs of the same full-size step give identical logits and identical gradients, bit for bit (no atomics on
     activations or gradients; BN sums are fp64 atomics of per-tile fp32 partials)."""
-    data = _full_batch()
+    data = _full_batch(cfg_name=cfg_name)
     outs = []
     for _ in range(2):
-        m = _model()
+        m = _model(cfg_name=cfg_name)
         m.train()
         lo, _ = m(data)
         lo["total_loss"].backward()
@@ -88,13 +113,14 @@ def test_eval_outputs_are_independent_of_the_rest_of_the_batch():
             assert float((reg - reg_all[sel]).abs().max()) < 1e-4
 
 
-def test_train_statistics_are_the_only_coupling_between_frustums():
+@pytest.mark.parametrize("cfg_name", ["car", "sunrgbd"])
+def test_train_statistics_are_the_only_coupling_between_frustums(cfg_name):
     """Training-mode BatchNorm couples the frustums ONLY through the batch statistics: duplicating the whole batch
     (2B frustums) leaves mean / biased variance unchanged, hence the logits of the first copy (1e-4)."""
-    data = _full_batch()
+    data = _full_batch(cfg_name=cfg_name)
     half = {k: v[:8].contiguous() for k, v in data.items()}
     dup = {k: torch.cat([v, v], 0) for k, v in half.items()}
-    m1, m2 = _model(), _model()
+    m1, m2 = _model(cfg_name=cfg_name), _model(cfg_name=cfg_name)
     m1.train()
     m2.train()
     with torch.no_grad():

@@ -47,13 +47,10 @@ def test_logits_losses_running_stats(case):
 @pytest.mark.parametrize("case", ["car_b4_n512", "sunrgbd_b4_n1024"])
 def test_gradients(case):
     g = load_golden(case)
-    # The 5-scale case runs the oracle in fp64: its decomposed BatchNorm (mean / var / rsqrt as separate fp32 ops) is
-    # noisier in the backward than the reference's native batch_norm kernels -- at this fixture's loss (83, gradient norms
-    # up to 1.6e3) the fp32 oracle is 9e-3 off the reference on pointnet1.conv1 while the fp64 oracle agrees to 6e-6.
-    dt = torch.float64 if case.startswith("sunrgbd") else torch.float32
+    # (the 5-scale fixture's seed is chosen away from ReLU kinks -- tests/golden/make_golden.py: one activation inside fp32
+    # noise of zero moved these norms by 1 % depending on the side it fell on)
     data = synth.to_torch(golden_inputs(g))
-    data = {k: (v.to(dt) if v.dtype.is_floating_point else v) for k, v in data.items()}
-    sd = golden_state_dict(g, dtype=dt)
+    sd = golden_state_dict(g)
     for k, v in sd.items():
         if v.dtype.is_floating_point and "running" not in k:
             v.requires_grad_(True)

@@ -4,7 +4,7 @@ path = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/kernel_trace.csv'
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('loss_tail_kernel')]
-a, b = idx[15], idx[16]
+a, b = idx[-2], idx[-1]
 t0 = int(rows[a]['Start_Timestamp'])
 print("step window us", (int(rows[b]['Start_Timestamp']) - t0) / 1e3, "kernels", b - a)
 agg = collections.OrderedDict()
