@@ -165,12 +165,30 @@ def test_cfg_merge_semantics(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/cfgs"), reason="reference only exists in the build container")
-@pytest.mark.parametrize("name", ["det_sample.yaml", "det_sample_people.yaml", "refine_car.yaml"])
+@pytest.mark.parametrize("name", ["det_sample.yaml", "det_sample_people.yaml", "refine_car.yaml",
+                                  "det_sample_sunrgbd.yaml"])
 def test_reference_yaml_loads_unchanged(name):
     from frustum_convnet_amd import config
     cfg = config.reset_cfg()
     config.merge_cfg_from_file(os.path.join("/root/reference/cfgs", name))
-    assert len(cfg.DATA.HEIGHT_HALF) == 4 and cfg.TRAIN.WEIGHT_DECAY == 0.0001
+    if "sunrgbd" in name:
+        assert len(cfg.DATA.HEIGHT_HALF) == 5 and cfg.DATA.DATASET_NAME == "SUNRGBD" and cfg.IOU_THRESH == 0.25
+        assert cfg.MODEL.FILE == "models/det_base_sunrgbd.py" and cfg.DATA.NUM_SAMPLES == 2048
+    else:
+        assert len(cfg.DATA.HEIGHT_HALF) == 4 and cfg.TRAIN.WEIGHT_DECAY == 0.0001
+    config.reset_cfg()
+
+
+def test_own_sunrgbd_yaml_builds_the_five_scale_model():
+    from frustum_convnet_amd import config, det_base_sunrgbd
+    cfg = config.reset_cfg()
+    config.merge_cfg_from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cfgs",
+                                            "det_sample_sunrgbd.yaml"))
+    m = det_base_sunrgbd.PointNetDet(3, num_vec=10, num_classes=2)
+    assert m.num_scales == 5 and m.reg_out.weight.shape == (67, 1024, 1) and m.num_size_cluster == 10
+    assert [n.nsample for n in m.feat_net.nets] == [128, 128, 256, 256, 256]
+    assert m.conv_net.block1_conv1[0].weight.shape == (64, 138, 3)
+    assert m.conv_net.block5_deconv[0].weight.shape == (512, 256, 8)
     config.reset_cfg()
 
 
