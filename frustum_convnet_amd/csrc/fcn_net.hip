@@ -1421,6 +1421,9 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
                 g.tx = (Rs + 31) / 32;
                 g.ncb = P.C[l][s] / 64;
                 g.blk0 = nblk;
+#if (FCN_EXP & 8)       // timing experiment (tools build, wrong gradients): one data-gradient tile per segment only
+                g.tx = 1; g.ncb = 1;
+#endif
                 nblk += cg_pad8(g.tx * g.ncb);
                 a.ndg += 1;
             }
@@ -1430,6 +1433,9 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
         a.partial = pbuf;
         a.w_ny = P.N[l] / 64;
         cn_wgrad_split(R, a.w_ny * (P.Ktot[l] / 64), a.rows, a.w_ns);
+#if (FCN_EXP & 4)       // timing experiment (tools build, wrong gradients): the chain without its weight-gradient roles
+        a.w_ns = 0;
+#endif
         nblk += cg_pad8(a.w_ns * a.w_ny * (P.Ktot[l] / 64));
         own.partial = a.partial; own.nsplit = a.w_ns; cn_fill_pack(d, P, l, own.pk); own.nrow_real = P.nrow_real[l];
         own.dW = dW[l];

@@ -20,7 +20,7 @@ def main():
     for src in srcs:
         path = src if os.path.exists(src) else os.path.join(fb.CSRC, src)
         cmd = ["/opt/rocm/bin/hipcc"] + [f for f in fb.FLAGS if f not in ("-shared",)] + \
-              ["-c", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", path, "-o", "/dev/null"]
+              [f for f in os.environ.get("FCN_EXTRA_FLAGS", "").split() if f] + ["-c", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", path, "-o", "/dev/null"]
         err = subprocess.run(cmd, capture_output=True, text=True).stderr
         rows, cur = [], None
         for line in err.split("\n"):
