@@ -608,10 +608,15 @@ static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, int precision, hipS
 {
     const bool m2 = (a.COUT % 128 == 0), n2 = (a.CIN % 128 == 0);
     const int oy = a.COUT / (m2 ? 128 : 64), oz = a.CIN / (n2 ? 128 : 64);
-    // one full wave of workgroups per launch (768 = 3 per CU; the 128 x 128 tile of layer 2 needs 182 VGPRs: 2 per CU);
-    // each split takes ceil(live_tiles / nsplit) row tiles (computed on the device, where the live count is known),
-    // so splits stay balanced whatever the occupancy of the frustums.
-    const int slots = (LAYER == 2 && m2 && n2) ? 512 : 768;
+    // 384 workgroup slots per launch (256 for the 128 x 128 tile of layer 2), swept on MI355X over 256 / 384 / 768 / 1536:
+    // every split writes a full (COUT, CIN) partial that the reduce reads back (at 768 slots 150 MB written + read per
+    // step), and fewer, longer splits amortise the per-workgroup prologue -- 768 -> 384 took 14 us off the PointNet backward.
+    // Each split takes ceil(live_tiles / nsplit) row tiles (computed on the device, where the live count is known), so
+    // splits stay balanced whatever the occupancy of the frustums.
+#ifndef FCN_WG_SLOTS
+#define FCN_WG_SLOTS 384
+#endif
+    const int slots = (LAYER == 2 && m2 && n2) ? (FCN_WG_SLOTS * 2) / 3 : FCN_WG_SLOTS;
     int nsplit = slots / (oy * oz);
     if (nsplit < 1) nsplit = 1;
     if (nsplit > B * a.tps) nsplit = B * a.tps;
