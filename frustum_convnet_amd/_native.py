@@ -59,6 +59,12 @@ class InpDesc(ctypes.Structure):
                 ("random_flip", ctypes.c_int32), ("random_shift", ctypes.c_int32)]
 
 
+class Inp5Desc(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("pt_stride", ctypes.c_int32), ("L", ctypes.c_int32 * 5),
+                ("stride", ctypes.c_double * 5), ("max_depth", ctypes.c_double),
+                ("random_flip", ctypes.c_int32), ("random_shift", ctypes.c_int32)]
+
+
 class InpRefineDesc(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("pt_stride", ctypes.c_int32), ("Lpad", ctypes.c_int32 * 4),
                 ("stride", ctypes.c_double * 4), ("random_flip", ctypes.c_int32), ("random_shift", ctypes.c_int32)]
@@ -66,7 +72,7 @@ class InpRefineDesc(ctypes.Structure):
 
 EXPORTS = ("fcn_arch", "fcn_query_depth_point_f32", "fcn_pn_wgrad_rows", "fcn_pn_compact", "fcn_pn_group_compact",
            "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_det_loss_tail_rows2", "fcn_det_iou_metrics",
-           "fcn_det_loss_tail_scratch_floats", "fcn_adam_step_f32", "fcn_adam_step_slots", "fcn_prepare_inputs", "fcn_prepare_inputs_refine", "fcn_stamp",
+           "fcn_det_loss_tail_scratch_floats", "fcn_adam_step_f32", "fcn_adam_step_slots", "fcn_prepare_inputs", "fcn_prepare_inputs_refine", "fcn_prepare_inputs_sunrgbd", "fcn_stamp",
            "fcn_convnet_sizes", "fcn_convnet_logits_ld", "fcn_convnet_pack", "fcn_convnet_forward", "fcn_convnet_forward2",
            "fcn_convnet_backward", "fcn_box3d_iou_pair_f32", "fcn_decode_detections", "fcn_rotate_nms_3d")
 
@@ -120,6 +126,8 @@ def lib():
     L.fcn_adam_step_f32.argtypes = [c_fp] * 4 + [ctypes.c_int64] + [c_fp] * 3
     L.fcn_prepare_inputs.restype = ctypes.c_int
     L.fcn_prepare_inputs.argtypes = [ctypes.POINTER(InpDesc)] + [c_fp] * 13 + [c_fp * 4] + [c_fp] * 7
+    L.fcn_prepare_inputs_sunrgbd.restype = ctypes.c_int
+    L.fcn_prepare_inputs_sunrgbd.argtypes = [ctypes.POINTER(Inp5Desc)] + [c_fp] * 15 + [c_fp * 5] + [c_fp] * 7
     L.fcn_prepare_inputs_refine.restype = ctypes.c_int
     L.fcn_prepare_inputs_refine.argtypes = [ctypes.POINTER(InpRefineDesc)] + [c_fp] * 12 + [c_fp * 4] + [c_fp] * 8
     L.fcn_stamp.restype = ctypes.c_int

@@ -8,18 +8,30 @@
 //   centres: arange(0, max_depth, stride) + stride/2 on the ray through the 2-D box centre (calibration P), rotated
 //   labels:  +1 inside the half-size box, -1 inside the full box, nearest centre when none is inside the half box
 // fp64 where numpy computes in fp64, rounded to fp32 exactly where the reference stores fp32.
+// The same kernel serves the SUN-RGBD loader (datasets/provider_sample_sunrgbd.py::ProviderDataset.__getitem__ :116-263 with
+// generate_ref :283-326 and project_image_to_upright_camera :28-59): five strides, window centres through the camera
+// matrix K and the tilt rotation Rtilt instead of the KITTI projection P, and an extra height shift in the augmentation.
 #include "fcn_common.h"
 #include "../../include/fcn_hip.h"
 
 #define INP_T 256
 
+struct InpDescG {              // both entry points in one shape
+    int B, N, pt_stride, nsc;
+    int L[5];
+    double stride[5], max_depth;
+    int random_flip, random_shift;
+};
+
 struct InpArgs {
-    fcn_inp_desc d;
+    InpDescG d;
     const float *raw;
     const int64_t *off, *raw_seg;
     const int32_t *choice;
     const double *fangle, *box2d, *P, *corners, *heading, *size, *coin, *normal;
-    float *pc, *ref[4];
+    const double *K, *Rtilt;   // SUN-RGBD: (B,3,3) camera matrix and tilt rotation (P == nullptr then)
+    const double *hshift;      // SUN-RGBD: the uniform [0,1) draw of the height shift (random_shift), else nullptr
+    float *pc, *ref[5];
     int64_t *cls;
     float *center, *head, *osize, *rot;
     int64_t *seg;
@@ -43,7 +55,7 @@ __global__ __launch_bounds__(INP_T) void prepare_inputs_kernel(InpArgs a)
     const double c = cos(rot), s = sin(rot);
     const double *cr = a.corners + (int64_t)b * 24;
     const double c0x = (cr[0] + cr[18]) / 2.0, c0y = (cr[1] + cr[19]) / 2.0, c0z = (cr[2] + cr[20]) / 2.0;
-    double cx = c0x * c + c0z * (-s), cy = c0y, cz = c0x * s + c0z * c;
+    double cx = c0x * c + c0z * (-s), cy = c0y, cz = c0x * s + c0z * c;     // (cy: the height shift below moves it)
     double ang = a.heading[b] - rot;
     const bool flip = a.d.random_flip && a.coin[b] > 0.5;
     if (flip) { cx = -cx; ang = M_PI - ang; }
@@ -55,6 +67,10 @@ __global__ __launch_bounds__(INP_T) void prepare_inputs_kernel(InpArgs a)
         shift = fmin(fmax(shift + cz, 0.0), a.d.max_depth) - cz;
         cz += shift;
     }
+    // provider_sample_sunrgbd.py:228-230: height_shift = np.random.random() * 0.4 - 0.2 on the points' y and the box centre
+    const bool has_h = a.d.random_shift && a.hshift != nullptr;
+    const double hsh = has_h ? a.hshift[b] * 0.4 - 0.2 : 0.0;
+    if (has_h) cy += hsh;
     if (tid == 0) {
         a.center[3 * b] = (float)cx; a.center[3 * b + 1] = (float)cy; a.center[3 * b + 2] = (float)cz;
         a.head[b] = (float)ang;
@@ -72,14 +88,25 @@ __global__ __launch_bounds__(INP_T) void prepare_inputs_kernel(InpArgs a)
         float zr = (float)(x * s + z * c);
         if (flip) xr = -xr;
         if (a.d.random_shift) zr = (float)((double)zr + shift);
+        float yr = p[1];
+        if (has_h) yr = (float)((double)yr + hsh);         // float32 record += float64 scalar
         float *o = a.pc + (int64_t)b * 3 * N;
-        o[i] = xr; o[N + i] = p[1]; o[2 * N + i] = zr;
+        o[i] = xr; o[N + i] = yr; o[2 * N + i] = zr;
         if (a.seg) a.seg[(int64_t)b * N + i] = a.raw_seg[j];
     }
-    // ---- frustum centres of the four strides, labels on stride 2
-    const double *P = a.P + (int64_t)b * 12;
-    const double cu = P[2], cv = P[6], fu = P[0], fv = P[5];
-    const double bx = P[3] / (-fu), by = P[7] / (-fv);
+    // ---- frustum centres of the strides, labels on stride 2
+    const bool upright = a.P == nullptr;
+    double cu, cv, fu, fv, bx = 0.0, by = 0.0;
+    double Rt[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (!upright) {
+        const double *P = a.P + (int64_t)b * 12;
+        cu = P[2]; cv = P[6]; fu = P[0]; fv = P[5];
+        bx = P[3] / (-fu); by = P[7] / (-fv);
+    } else {
+        const double *K = a.K + (int64_t)b * 9;
+        cu = K[2]; cv = K[5]; fu = K[0]; fv = K[4];
+        for (int i = 0; i < 9; ++i) Rt[i] = a.Rtilt[(int64_t)b * 9 + i];
+    }
     const double u0 = (a.box2d[4 * b] + a.box2d[4 * b + 2]) / 2.0, v0 = (a.box2d[4 * b + 1] + a.box2d[4 * b + 3]) / 2.0;
     const double ca = cos(ang), sa = sin(ang);
     double best = 1e300;
@@ -88,12 +115,21 @@ __global__ __launch_bounds__(INP_T) void prepare_inputs_kernel(InpArgs a)
     if (tid == 0) sany = 0;
     __syncthreads();
 #pragma unroll 1
-    for (int sc = 0; sc < 4; ++sc) {
+    for (int sc = 0; sc < a.d.nsc; ++sc) {
         const int L = a.d.L[sc];
         const double st = a.d.stride[sc];
         for (int l = tid; l < L; l += INP_T) {
-            const double z = (double)l * st + st / 2.0;
-            const double x = ((u0 - cu) * z) / fu + bx, y = ((v0 - cv) * z) / fv + by;
+            const double zd = (double)l * st + st / 2.0;
+            double x = ((u0 - cu) * zd) / fu + bx, y = ((v0 - cv) * zd) / fv + by, z = zd;
+            if (upright) {
+                // project_image_to_upright_camera (provider_sample_sunrgbd.py:44-59): camera (x, y, z) -> depth frame
+                // (x, z, -y) -> Rtilt . -> (X, -Z, Y)
+                const double d0 = x, d1 = zd, d2 = -y;
+                const double u_0 = Rt[0] * d0 + Rt[1] * d1 + Rt[2] * d2;
+                const double u_1 = Rt[3] * d0 + Rt[4] * d1 + Rt[5] * d2;
+                const double u_2 = Rt[6] * d0 + Rt[7] * d1 + Rt[8] * d2;
+                x = u_0; y = -u_2; z = u_1;
+            }
             double xr = x * c + z * (-s);
             const double zr = x * s + z * c;
             if (flip) xr = -xr;
@@ -143,10 +179,46 @@ extern "C" int fcn_prepare_inputs(const fcn_inp_desc *d, const float *raw_pts, c
     for (int s = 0; s < 4; ++s)
         if (d->L[s] <= 0 || !(d->stride[s] > 0.0) || !center_ref[s]) return FCN_E_BADARG;
     InpArgs a;
-    a.d = *d; a.raw = raw_pts; a.off = pt_off; a.raw_seg = raw_seg; a.choice = choice; a.fangle = frustum_angle;
+    a.d.B = d->B; a.d.N = d->N; a.d.pt_stride = d->pt_stride; a.d.nsc = 4; a.d.max_depth = d->max_depth;
+    a.d.random_flip = d->random_flip; a.d.random_shift = d->random_shift;
+    for (int s = 0; s < 5; ++s) { a.d.L[s] = s < 4 ? d->L[s] : 0; a.d.stride[s] = s < 4 ? d->stride[s] : 1.0; a.ref[s] = s < 4 ? center_ref[s] : nullptr; }
+    a.raw = raw_pts; a.off = pt_off; a.raw_seg = raw_seg; a.choice = choice; a.fangle = frustum_angle;
     a.box2d = box2d; a.P = P; a.corners = box3d_corners; a.heading = heading; a.size = size; a.coin = coin; a.normal = normal;
+    a.K = nullptr; a.Rtilt = nullptr; a.hshift = nullptr;
     a.pc = point_cloud;
-    for (int s = 0; s < 4; ++s) a.ref[s] = center_ref[s];
+    a.cls = cls_label; a.center = box3d_center; a.head = box3d_heading; a.osize = box3d_size; a.rot = rot_angle; a.seg = seg_label;
+    hipLaunchKernelGGL(prepare_inputs_kernel, dim3(d->B), dim3(INP_T), 0, (hipStream_t)stream, a);
+    FCN_CHECK_LAUNCH();
+    return 0;
+}
+
+// SUN-RGBD loader (cfgs/det_sample_sunrgbd.yaml; datasets/provider_sample_sunrgbd.py:116-326): five strides, centres through
+// K and Rtilt, depth + height shift.
+extern "C" int fcn_prepare_inputs_sunrgbd(const fcn_inp5_desc *d, const float *raw_pts, const int64_t *pt_off,
+                                          const int64_t *raw_seg, const int32_t *choice, const double *frustum_angle,
+                                          const double *box2d, const double *K, const double *Rtilt,
+                                          const double *box3d_corners, const double *heading, const double *size,
+                                          const double *coin, const double *normal, const double *hshift,
+                                          float *point_cloud, float *const center_ref[5], int64_t *cls_label,
+                                          float *box3d_center, float *box3d_heading, float *box3d_size, float *rot_angle,
+                                          int64_t *seg_label, void *stream)
+{
+    if (!d || !raw_pts || !pt_off || !choice || !frustum_angle || !box2d || !K || !Rtilt || !point_cloud || !center_ref ||
+        !box3d_center || !box3d_heading || !box3d_size || !rot_angle)
+        return FCN_E_BADARG;
+    if (!box3d_corners || !heading || !size) return FCN_E_BADARG;
+    if (d->B <= 0 || d->N <= 0 || d->pt_stride < 3) return FCN_E_BADARG;
+    if ((d->random_flip && !coin) || (d->random_shift && (!normal || !hshift)) || (seg_label && !raw_seg)) return FCN_E_BADARG;
+    for (int s = 0; s < 5; ++s)
+        if (d->L[s] <= 0 || !(d->stride[s] > 0.0) || !center_ref[s]) return FCN_E_BADARG;
+    InpArgs a;
+    a.d.B = d->B; a.d.N = d->N; a.d.pt_stride = d->pt_stride; a.d.nsc = 5; a.d.max_depth = d->max_depth;
+    a.d.random_flip = d->random_flip; a.d.random_shift = d->random_shift;
+    for (int s = 0; s < 5; ++s) { a.d.L[s] = d->L[s]; a.d.stride[s] = d->stride[s]; a.ref[s] = center_ref[s]; }
+    a.raw = raw_pts; a.off = pt_off; a.raw_seg = raw_seg; a.choice = choice; a.fangle = frustum_angle;
+    a.box2d = box2d; a.P = nullptr; a.corners = box3d_corners; a.heading = heading; a.size = size; a.coin = coin; a.normal = normal;
+    a.K = K; a.Rtilt = Rtilt; a.hshift = d->random_shift ? hshift : nullptr;
+    a.pc = point_cloud;
     a.cls = cls_label; a.center = box3d_center; a.head = box3d_heading; a.osize = box3d_size; a.rot = rot_angle; a.seg = seg_label;
     hipLaunchKernelGGL(prepare_inputs_kernel, dim3(d->B), dim3(INP_T), 0, (hipStream_t)stream, a);
     FCN_CHECK_LAUNCH();

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _native
-from ._native import InpDesc
+from ._native import InpDesc, Inp5Desc
 from .config import cfg
 from .dataset_info import DATASET_INFO
 
@@ -100,6 +100,104 @@ class InputBuilder:
             oh[np.arange(B), size_class] = 1.0
             out["one_hot"] = up(oh)
         return out
+
+
+def draw_sunrgbd(counts, npoints, random_flip=True, random_shift=True, rng=np.random):
+    """The SUN-RGBD loader's per-sample draws, in its order (provider_sample_sunrgbd.py:144, :211, :224, :228): resample
+    (WITH replacement only when the frustum has fewer points than npoints), flip coin, depth-shift normal, height-shift
+    uniform."""
+    choice, coin, normal, hshift = [], [], [], []
+    for n in counts:
+        choice.append(rng.choice(int(n), npoints, int(n) < npoints))
+        coin.append(rng.random() if random_flip else 0.0)
+        normal.append(rng.randn() if random_shift else 0.0)
+        hshift.append(rng.random() if random_shift else 0.5)
+    f = lambda v: np.asarray(v, dtype=np.float64)
+    return np.stack(choice).astype(np.int32), f(coin), f(normal), f(hshift)
+
+
+class SunrgbdInputBuilder:
+    """Batch construction of datasets/provider_sample_sunrgbd.py::ProviderDataset (+ default_collate) on the device: five
+    strides, window centres through the camera matrix K and the tilt rotation Rtilt.  Records: points (n,>=3) float32 in
+    upright camera coordinates, seg (n,), box2d (4,), K (3,3), Rtilt (3,3), box3d (8,3), heading, size (l,w,h),
+    frustum_angle, type."""
+
+    def __init__(self, npoints, strides=None, max_depth=None, random_flip=False, random_shift=False, one_hot=True,
+                 device="cuda"):
+        self.npoints = int(npoints)
+        self.strides = tuple(float(s) for s in (cfg.DATA.STRIDE if strides is None else strides))
+        self.max_depth = float(cfg.DATA.MAX_DEPTH if max_depth is None else max_depth)
+        assert len(self.strides) == 5
+        self.L = [len(np.arange(0, self.max_depth, s)) for s in self.strides]
+        self.random_flip, self.random_shift, self.one_hot = bool(random_flip), bool(random_shift), bool(one_hot)
+        self.device = torch.device(device)
+        self.classes = DATASET_INFO["SUNRGBD"].CLASSES
+
+    def build(self, records, draws=None, with_seg=True):
+        """draws: (choice (B,N) int32, coin (B), normal (B), hshift (B)) or None to draw like the reference."""
+        if self.device.type != "cuda":
+            raise RuntimeError("frustum_convnet_amd: input construction is a HIP kernel (MI355X only); no CPU fallback")
+        B, N = len(records), self.npoints
+        counts = [len(r["points"]) for r in records]
+        if draws is None:
+            draws = draw_sunrgbd(counts, N, self.random_flip, self.random_shift)
+        choice, coin, normal, hshift = draws
+        stride = int(records[0]["points"].shape[1])
+        raw = np.concatenate([np.ascontiguousarray(r["points"], dtype=np.float32) for r in records], 0)
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        f64 = lambda k, shape: np.stack([np.asarray(r[k], dtype=np.float64).reshape(shape) for r in records])
+        dev = self.device
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
+        t = {"raw": up(raw), "off": up(off), "choice": up(np.asarray(choice, dtype=np.int32)),
+             "fangle": up(f64("frustum_angle", ())), "box2d": up(f64("box2d", (4,))), "K": up(f64("K", (9,))),
+             "R": up(f64("Rtilt", (9,))), "corners": up(f64("box3d", (24,))), "heading": up(f64("heading", ())),
+             "size": up(f64("size", (3,))), "coin": up(np.asarray(coin, dtype=np.float64)),
+             "normal": up(np.asarray(normal, dtype=np.float64)), "hshift": up(np.asarray(hshift, dtype=np.float64))}
+        seg_raw = None
+        if with_seg:
+            seg_raw = up(np.concatenate([np.asarray(r["seg"]).astype(np.int64) for r in records], 0))
+        f32 = dict(dtype=torch.float32, device=dev)
+        out = {"point_cloud": torch.empty((B, 3, N), **f32), "rot_angle": torch.empty((B, 1), **f32),
+               "cls_label": torch.empty((B, self.L[1]), dtype=torch.int64, device=dev),
+               "box3d_center": torch.empty((B, 3), **f32), "box3d_heading": torch.empty((B, 1), **f32),
+               "box3d_size": torch.empty((B, 3), **f32)}
+        for s in range(5):
+            out["center_ref%d" % (s + 1)] = torch.empty((B, 3, self.L[s]), **f32)
+        if with_seg:
+            out["seg_label"] = torch.empty((B, N), dtype=torch.int64, device=dev)
+        desc = Inp5Desc(B, N, stride, (ctypes.c_int32 * 5)(*self.L), (ctypes.c_double * 5)(*self.strides), self.max_depth,
+                        1 if self.random_flip else 0, 1 if self.random_shift else 0)
+        refs = (ctypes.c_void_p * 5)(*[out["center_ref%d" % (s + 1)].data_ptr() for s in range(5)])
+        p = lambda x: None if x is None else x.data_ptr()
+        L = _native.lib()
+        with torch.cuda.device(dev):
+            _native.check(L.fcn_prepare_inputs_sunrgbd(
+                ctypes.byref(desc), p(t["raw"]), p(t["off"]), p(seg_raw), p(t["choice"]), p(t["fangle"]), p(t["box2d"]),
+                p(t["K"]), p(t["R"]), p(t["corners"]), p(t["heading"]), p(t["size"]), p(t["coin"]), p(t["normal"]),
+                p(t["hshift"]), p(out["point_cloud"]), refs, p(out["cls_label"]), p(out["box3d_center"]),
+                p(out["box3d_heading"]), p(out["box3d_size"]), p(out["rot_angle"]), p(out.get("seg_label")),
+                _native.current_stream(dev)), "fcn_prepare_inputs_sunrgbd")
+        for v in t.values():
+            v.record_stream(torch.cuda.current_stream(dev))
+        size_class = [self.classes.index(r["type"]) for r in records]
+        out["size_class"] = torch.tensor(size_class, dtype=torch.int64).view(B, 1).to(dev, non_blocking=True)
+        if self.one_hot:
+            oh = np.zeros((B, len(self.classes)), dtype=np.float32)
+            oh[np.arange(B), size_class] = 1.0
+            out["one_hot"] = up(oh)
+        return out
+
+
+def sunrgbd_records_from_fixture(g):
+    """tests/golden/inputs_sunrgbd_b6.npz (make_golden_inputs_sunrgbd.py) as a list of records."""
+    offs = np.concatenate([[0], np.cumsum(g["raw_counts"])])
+    recs = []
+    for b in range(len(g["raw_counts"])):
+        sl = slice(int(offs[b]), int(offs[b + 1]))
+        recs.append({"points": g["raw_points"][sl], "seg": g["raw_seg"][sl], "box2d": g["box2d"][b], "K": g["K"][b],
+                     "Rtilt": g["Rtilt"][b], "box3d": g["box3d_corners"][b], "heading": float(g["heading"][b]),
+                     "size": g["size"][b], "frustum_angle": float(g["frustum_angle"][b]), "type": str(g["types"][b])})
+    return recs
 
 
 def records_from_fixture(g):

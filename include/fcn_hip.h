@@ -23,6 +23,7 @@
  *   fcn_prepare_inputs          the per-sample numpy work of the data loader + collate,
  *                               datasets/provider_sample.py:137-262,270-327,396-397
  *   fcn_prepare_inputs_refine   the same for the refinement stage, datasets/provider_sample_refine.py:176-419
+ *   fcn_prepare_inputs_sunrgbd  the same for the SUN-RGBD loader, datasets/provider_sample_sunrgbd.py:116-326
  *   fcn_det_iou_metrics         the IoU metrics of models/det_base.py:480-503 (D2H + boost clipping every step in the reference)
  *   fcn_box3d_iou_pair_f32      rbbox_iou_3d_pair, ops/pybind11/box_ops.h:173-260 (boost polygon clipping on the host)
  *   fcn_decode_detections       the numpy decode loop of train/test_net_det.py:254-293 + from_prediction_to_label_format
@@ -343,6 +344,24 @@ int fcn_prepare_inputs(const fcn_inp_desc *d, const float *raw_pts, const int64_
                        const double *coin, const double *normal, float *point_cloud, float *const center_ref[4],
                        int64_t *cls_label, float *box3d_center, float *box3d_heading, float *box3d_size,
                        float *rot_angle, int64_t *seg_label, void *stream);
+
+/* SUN-RGBD variant (cfgs/det_sample_sunrgbd.yaml; datasets/provider_sample_sunrgbd.py::ProviderDataset.__getitem__ :116-263,
+ * generate_ref :283-326, project_image_to_upright_camera :28-59): five strides; the window centres go through the camera
+ * matrix K (B,3,3) and the tilt rotation Rtilt (B,3,3) -- camera (x,y,z) -> (x,z,-y) -> Rtilt . -> (X,-Z,Y) -- instead of
+ * the KITTI projection; random_shift also draws a height shift, hshift (B) = the np.random.random() value in [0,1), applied
+ * as hshift*0.4-0.2 to the points' y and the box centre.  Everything else as fcn_prepare_inputs. */
+typedef struct fcn_inp5_desc {
+    int32_t B, N, pt_stride;
+    int32_t L[5];
+    double  stride[5], max_depth;
+    int32_t random_flip, random_shift;
+} fcn_inp5_desc;
+int fcn_prepare_inputs_sunrgbd(const fcn_inp5_desc *d, const float *raw_pts, const int64_t *pt_off, const int64_t *raw_seg,
+                               const int32_t *choice, const double *frustum_angle, const double *box2d, const double *K,
+                               const double *Rtilt, const double *box3d_corners, const double *heading, const double *size,
+                               const double *coin, const double *normal, const double *hshift, float *point_cloud,
+                               float *const center_ref[5], int64_t *cls_label, float *box3d_center, float *box3d_heading,
+                               float *box3d_size, float *rot_angle, int64_t *seg_label, void *stream);
 
 /* Refinement-stage variant (cfgs/refine_car.yaml; datasets/provider_sample_refine.py::ProviderDataset.__getitem__ :176-315,
  * generate_ref :336-386, generate_labels :317-334, collate_fn :388-419): the sample is normalised to the first-stage

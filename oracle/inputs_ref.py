@@ -221,3 +221,87 @@ def prepare_batch_refine(rec, strides, random_flip=True, random_shift=True):
                                            rec["size"][b], rec["draw_choice"][b], float(rec["draw_coin"][b]),
                                            float(rec["draw_normal"][b]), strides, random_flip, random_shift))
     return collate_refine(items)
+
+
+# ------------------------------------------------------------------------------------------------
+# SUN-RGBD loader (cfgs/det_sample_sunrgbd.yaml): datasets/provider_sample_sunrgbd.py::ProviderDataset.__getitem__
+# (:116-263) with generate_ref (:283-326), project_image_to_camera / _to_upright_camera (:28-59), generate_labels (:265-281).
+# Differences from the KITTI loader above: five strides; the centres go through K and Rtilt; np.random.choice replaces only
+# when the frustum has fewer points than npoints (:144); random_shift draws a height shift too (:228-230).  Pinned by
+# tests/golden/inputs_sunrgbd_b6.npz = outputs of the reference's own ProviderDataset (make_golden_inputs_sunrgbd.py).
+
+def project_image_to_upright_camera(uv_depth, K, Rtilt):
+    """provider_sample_sunrgbd.py:28-59."""
+    c_u, c_v, f_u, f_v = K[0, 2], K[1, 2], K[0, 0], K[1, 1]
+    x = ((uv_depth[:, 0] - c_u) * uv_depth[:, 2]) / f_u
+    y = ((uv_depth[:, 1] - c_v) * uv_depth[:, 2]) / f_v
+    depth = np.stack([x, uv_depth[:, 2], -y], 1)                    # X, Y, Z -> X, Z, -Y
+    up = (Rtilt @ depth.T).T
+    return np.stack([up[:, 0], -up[:, 2], up[:, 1]], 1)             # X, Y, Z -> X, -Z, Y
+
+
+def generate_ref_sunrgbd(box2d, K, Rtilt, strides, max_depth):
+    """provider_sample_sunrgbd.py:283-326."""
+    cx, cy = (box2d[0] + box2d[2]) / 2.0, (box2d[1] + box2d[3]) / 2.0
+    refs = []
+    for s in strides:
+        z = np.arange(0, max_depth, s) + s / 2.0
+        uvd = np.stack([np.full_like(z, cx), np.full_like(z, cy), z], 1)
+        refs.append(project_image_to_upright_camera(uvd, K, Rtilt))
+    return refs
+
+
+def prepare_sample_sunrgbd(raw_pts, raw_seg, box2d, K, Rtilt, box3d_corners, heading, size, frustum_angle, choice, coin,
+                           normal, hshift, strides, max_depth, random_flip=True, random_shift=True):
+    """One training sample with rotate-to-centre, provider_sample_sunrgbd.py:116-263.  hshift: the np.random.random() draw
+    behind the height shift (:228)."""
+    rot = np.pi / 2.0 + frustum_angle                                           # :328-331
+    xz = rotate_along_y(raw_pts[:, [0, 2]], rot).astype(raw_pts.dtype)          # stored back into the record's dtype
+    pts = np.stack([xz[:, 0], raw_pts[:, 1], xz[:, 1]], 1)[choice]              # :133-150
+    seg = raw_seg[choice]
+    refs = generate_ref_sunrgbd(box2d, K, Rtilt, strides, max_depth)
+    for r in refs:                                                              # :158-163
+        r[:, [0, 2]] = rotate_along_y(r[:, [0, 2]], rot)
+    c0 = (box3d_corners[0] + box3d_corners[6]) / 2.0                            # :339-344
+    cxz = rotate_along_y(c0[None, [0, 2]], rot)[0]
+    center = np.array([cxz[0], c0[1], cxz[1]], dtype=np.float64)
+    angle = heading - rot                                                       # :198-201
+    if random_flip and coin > 0.5:                                              # :208-220
+        pts[:, 0] *= -1
+        center[0] *= -1
+        angle = np.pi - angle
+        for r in refs:
+            r[:, 0] *= -1
+    if random_shift:                                                            # :222-230
+        l, w, h = size
+        dist = np.sqrt(np.sum(l ** 2 + w ** 2))
+        shift = np.clip(normal * dist * 0.2, -0.5 * dist, 0.5 * dist)
+        shift = np.clip(shift + center[2], 0, max_depth) - center[2]
+        pts[:, 2] = (pts[:, 2].astype(np.float64) + shift).astype(pts.dtype)
+        center[2] += shift
+        height_shift = hshift * 0.4 - 0.2
+        pts[:, 1] = (pts[:, 1].astype(np.float64) + height_shift).astype(pts.dtype)
+        center[1] += height_shift
+    labels = generate_labels(center, np.asarray(size, dtype=np.float64), angle, refs[1])     # :232, :265-281
+    out = {"point_cloud": np.ascontiguousarray(pts.astype(np.float32).T), "rot_angle": np.array([rot], dtype=np.float32),
+           "cls_label": labels, "box3d_center": center.astype(np.float32),
+           "box3d_heading": np.array([angle], dtype=np.float32), "box3d_size": np.asarray(size).astype(np.float32),
+           "seg_label": seg.astype(np.int64)}
+    for i, r in enumerate(refs):
+        out["center_ref%d" % (i + 1)] = np.ascontiguousarray(r.astype(np.float32).T)
+    return out
+
+
+def prepare_batch_sunrgbd(rec, strides, max_depth, random_flip=True, random_shift=True):
+    """rec: the fixture's layout (raw_points, raw_seg, raw_counts, box2d, K, Rtilt, box3d_corners, heading, size,
+    frustum_angle, draw_choice, draw_coin, draw_normal, draw_hshift).  Returns the collated batch."""
+    offs = np.concatenate([[0], np.cumsum(rec["raw_counts"])])
+    items = []
+    for b in range(len(rec["raw_counts"])):
+        sl = slice(int(offs[b]), int(offs[b + 1]))
+        items.append(prepare_sample_sunrgbd(rec["raw_points"][sl], rec["raw_seg"][sl], rec["box2d"][b], rec["K"][b],
+                                            rec["Rtilt"][b], rec["box3d_corners"][b], float(rec["heading"][b]),
+                                            rec["size"][b], float(rec["frustum_angle"][b]), rec["draw_choice"][b],
+                                            float(rec["draw_coin"][b]), float(rec["draw_normal"][b]),
+                                            float(rec["draw_hshift"][b]), strides, max_depth, random_flip, random_shift))
+    return {k: np.stack([it[k] for it in items]) for k in items[0]}

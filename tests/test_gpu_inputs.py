@@ -166,3 +166,52 @@ def test_refine_builder_matches_reference_batch():
     feed = {k: v for k, v in out.items() if k not in ("lens", "rot_angle", "ref_center")}
     losses, _ = m(feed)
     assert torch.isfinite(losses["total_loss"])
+
+
+def test_sunrgbd_builder_matches_reference_batch():
+    """fcn_prepare_inputs_sunrgbd (five strides, centres through K / Rtilt, depth + height shift) against the outputs of the
+    reference's own provider_sample_sunrgbd.ProviderDataset, with the recorded draws and with the same numpy seed."""
+    from frustum_convnet_amd.config import reset_cfg
+    from frustum_convnet_amd.inputs import SunrgbdInputBuilder, sunrgbd_records_from_fixture
+    reset_cfg()
+    g = np.load(os.path.join(HERE, "golden", "inputs_sunrgbd_b6.npz"))
+    b = SunrgbdInputBuilder(int(g["meta_npoint"]), tuple(g["meta_strides"]), float(g["meta_max_depth"]),
+                            random_flip=True, random_shift=True)
+    recs = sunrgbd_records_from_fixture(g)
+    keys = FLOAT_KEYS + ("center_ref5",)
+    for draws in ((g["draw_choice"], g["draw_coin"], g["draw_normal"], g["draw_hshift"]), None):
+        if draws is None:
+            np.random.seed(777)                 # make_golden_inputs_sunrgbd.py seeds the reference run with this
+        out = b.build(recs, draws=draws)
+        assert torch.equal(out["cls_label"].cpu(), torch.from_numpy(g["ref_cls_label"]))
+        assert torch.equal(out["seg_label"].cpu(), torch.from_numpy(g["ref_seg_label"]))
+        assert torch.equal(out["size_class"].cpu(), torch.from_numpy(g["ref_size_class"]))
+        assert torch.equal(out["one_hot"].cpu(), torch.from_numpy(g["ref_one_hot"]))
+        for k in keys:
+            ref = g["ref_" + k]
+            got = out[k].cpu().numpy()
+            assert got.shape == ref.shape and out[k].dtype == torch.float32, k
+            d = np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()
+            assert d <= 1e-6 * max(1.0, np.abs(ref).max()), (k, d)
+
+
+def test_sunrgbd_batch_feeds_the_five_scale_model():
+    from frustum_convnet_amd.config import cfg, reset_cfg
+    from frustum_convnet_amd import det_base_sunrgbd, synth
+    from frustum_convnet_amd.inputs import SunrgbdInputBuilder, sunrgbd_records_from_fixture
+    reset_cfg()
+    g = np.load(os.path.join(HERE, "golden", "inputs_sunrgbd_b6.npz"))
+    cfg.DATA.HEIGHT_HALF = tuple(float(x) for x in g["meta_strides"])
+    cfg.DATA.STRIDE = cfg.DATA.HEIGHT_HALF
+    cfg.DATA.DATASET_NAME = "SUNRGBD"
+    cfg.DATA.MAX_DEPTH = float(g["meta_max_depth"])
+    b = SunrgbdInputBuilder(int(g["meta_npoint"]), random_flip=True, random_shift=True)
+    data = b.build(sunrgbd_records_from_fixture(g), draws=(g["draw_choice"], g["draw_coin"], g["draw_normal"], g["draw_hshift"]))
+    m = det_base_sunrgbd.PointNetDet(3, num_vec=10, num_classes=2)
+    synth.fill_state_dict(m.state_dict(), seed=7)
+    m = m.cuda().train()
+    losses, metrics = m(data)
+    losses["total_loss"].backward()
+    assert all(torch.isfinite(v).all() for v in losses.values())
+    assert float(m.last_num_fg) == float((data["cls_label"] == 1).sum())
+    reset_cfg()

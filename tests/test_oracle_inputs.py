@@ -92,3 +92,26 @@ def test_refine_oracle_matches_reference_dataset_and_collate():
             assert np.abs(v.astype(np.float64) - ref.astype(np.float64)).max() <= 1e-6, k
         else:
             assert np.array_equal(v, ref), k
+
+
+def test_sunrgbd_oracle_matches_reference_provider():
+    """oracle/inputs_ref.py SUN-RGBD restatement vs the reference's own provider_sample_sunrgbd.ProviderDataset outputs
+    (tests/golden/make_golden_inputs_sunrgbd.py): five strides through K / Rtilt, depth + height shift."""
+    g = np.load(os.path.join(HERE, "golden", "inputs_sunrgbd_b6.npz"))
+    out = inputs_ref.prepare_batch_sunrgbd(g, tuple(g["meta_strides"]), float(g["meta_max_depth"]))
+    assert np.array_equal(out["cls_label"], g["ref_cls_label"])
+    assert np.array_equal(out["seg_label"], g["ref_seg_label"])
+    for k in ("point_cloud", "center_ref1", "center_ref2", "center_ref3", "center_ref4", "center_ref5", "box3d_center",
+              "box3d_heading", "box3d_size", "rot_angle"):
+        ref = g["ref_" + k]
+        got = out[k].reshape(ref.shape)
+        d = np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()
+        assert d <= 1e-6 * max(1.0, np.abs(ref).max()), (k, d)
+    assert (g["raw_counts"] < g["meta_npoint"]).any() and (g["raw_counts"] > g["meta_npoint"]).any()
+    assert (g["draw_coin"] > 0.5).any() and (g["draw_coin"] <= 0.5).any()
+    # the draws follow the loader's order: same seed, same draws (and replacement only for the short frustum)
+    from frustum_convnet_amd.inputs import draw_sunrgbd
+    np.random.seed(777)
+    choice, coin, normal, hshift = draw_sunrgbd(g["raw_counts"], int(g["meta_npoint"]), True, True)
+    assert np.array_equal(choice, g["draw_choice"]) and np.array_equal(coin, g["draw_coin"])
+    assert np.array_equal(normal, g["draw_normal"]) and np.array_equal(hshift, g["draw_hshift"])
