@@ -344,39 +344,46 @@ __global__ __launch_bounds__(GT) void pool_kernel(
     }
 }
 
-// Position-major pooling (the fused path: feat (B, L, C3) feeds the ConvFeatNet GEMMs directly).  One wave per window over
-// ALL C3 channels: lane = C3/64 consecutive channels, so a row is one fully coalesced C3*4-byte read per wave (the 64-channel
-// slices of pool_kernel kept only 256 B per row in flight: 2.1 TB/s on the widest scale) and UN rows are in flight at once.
+// Position-major pooling (the fused path: feat (B, L, C3) feeds the ConvFeatNet GEMMs directly).  A wave covers ALL C3
+// channels of a row: lane = C3/64 consecutive channels, so a row is one fully coalesced C3*4-byte read per wave (the
+// 64-channel slices of pool_kernel kept only 256 B per row in flight: 2.1 TB/s on the widest scale) and UN rows are in flight
+// at once.  WPW waves share one window, taking its UN-row batches round-robin: the row walk of a window is a serial chain of
+// memory round trips, and a full window (nsample rows: 32 batches of 4 on the widest scale) set the kernel's duration --
+// 58 us for 74 MB -- while most waves had finished long before.  The partial (max, arg-max) pairs meet in LDS; ties go to
+// the earlier row, like torch.max.
 typedef float v2f __attribute__((ext_vector_type(2)));
-template <int VEC>
+template <int VEC, int WPW>
 __global__ __launch_bounds__(GT) void pool_nlc_kernel(
     const float *__restrict__ y3, const float *__restrict__ bn3, const int32_t *__restrict__ woff,
     const int32_t *__restrict__ cnt, float *__restrict__ feat, int32_t *__restrict__ amax, int L, int cap, int C3,
     double *__restrict__ zero_ptr, int zero_n)
 {
     constexpr int UN = VEC >= 8 ? 4 : 8;          // rows in flight per lane
+    constexpr int WIN = PW / WPW;                 // windows per workgroup
+    __shared__ float bS[WPW > 1 ? GT * VEC : 1];
+    __shared__ int aS[WPW > 1 ? GT * VEC : 1];
     // the BN-backward sum buffer of this scale is zeroed by the last forward kernel: no memset node heading the backward
     if (zero_ptr && blockIdx.z == 0)
         for (int i = blockIdx.x * GT + threadIdx.x; i < zero_n; i += gridDim.x * GT) zero_ptr[i] = 0.0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.z, l = blockIdx.x * PW + wave;
-    if (l >= L) return;
+    const int b = blockIdx.z, l = blockIdx.x * WIN + wave / WPW, part = wave % WPW;
+    const bool live = l < L;
     const int c = lane * VEC;
     float s[VEC], t[VEC], best[VEC];
     int arg[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) { s[v] = bn3[c + v]; t[v] = bn3[C3 + c + v]; best[v] = 0.f; arg[v] = -1; }
-    if (cnt[(int64_t)b * L + l] > 0) {
+    if (live && cnt[(int64_t)b * L + l] > 0) {
         const int32_t *wo = woff + (int64_t)b * (L + 1);
         const int o0 = wo[l], o1 = wo[l + 1];
-        const float *yp = y3 + ((int64_t)b * cap + o0) * C3 + c;
-        int r = o0;
-        // compared in row order: the first maximum wins, like torch.max
-        for (; r + UN <= o1; r += UN, yp += UN * (int64_t)C3) {
+        const float *ybase = y3 + (int64_t)b * cap * C3 + c;
+        // batches part, part + WPW, ...: rows past the window's end are loaded from its last row (unconditional loads) and
+        // skipped in the comparison; rows are compared in row order, the first maximum wins
+        for (int r = o0 + part * UN; r < o1; r += WPW * UN) {
             float v[UN][VEC];
 #pragma unroll
             for (int j = 0; j < UN; ++j) {
-                const float *q = yp + j * (int64_t)C3;
+                const float *q = ybase + (int64_t)min(r + j, o1 - 1) * C3;
                 if constexpr (VEC == 2) {
                     const v2f x = *(const v2f __attribute__((address_space(1))) *)q;
                     v[j][0] = x.x; v[j][1] = x.y;
@@ -389,21 +396,32 @@ __global__ __launch_bounds__(GT) void pool_nlc_kernel(
                 }
             }
 #pragma unroll
-            for (int j = 0; j < UN; ++j)
+            for (int j = 0; j < UN; ++j) {
+                const bool ok = r + j < o1;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     const float u = fmaf(s[e], v[j][e], t[e]);
-                    if (u > best[e]) { best[e] = u; arg[e] = r + j; }
+                    if (ok && u > best[e]) { best[e] = u; arg[e] = r + j; }
                 }
-        }
-        for (; r < o1; ++r, yp += C3) {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const float u = fmaf(s[e], yp[e], t[e]);
-                if (u > best[e]) { best[e] = u; arg[e] = r; }
             }
         }
     }
+    if constexpr (WPW > 1) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { bS[e * GT + tid] = best[e]; aS[e * GT + tid] = arg[e]; }
+        __syncthreads();
+        if (part != 0) return;
+#pragma unroll
+        for (int q = 1; q < WPW; ++q)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float b2 = bS[e * GT + tid + 64 * q];
+                const int a2 = aS[e * GT + tid + 64 * q];
+                // (arg >= 0 implies best > 0; equal maxima: the earlier row)
+                if (b2 > best[e] || (b2 == best[e] && a2 >= 0 && (arg[e] < 0 || a2 < arg[e]))) { best[e] = b2; arg[e] = a2; }
+            }
+    }
+    if (!live) return;
     float *fo = feat + ((int64_t)b * L + l) * C3 + c;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) fo[e] = best[e];
@@ -489,12 +507,17 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
 
     const int nz = 2 * C3 + 2 * C2 + 4 * C1;
     if (d->nlc && (C3 == 128 || C3 == 256 || C3 == 512)) {
-        dim3 pgrid((L + PW - 1) / PW, 1, B);
         int32_t *am = tr ? ws->amax : nullptr;
         double *zp = tr ? ws->bstat : nullptr;
-        if (C3 == 128) hipLaunchKernelGGL(pool_nlc_kernel<2>, pgrid, dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, feat, am, L, cap, C3, zp, nz);
-        else if (C3 == 256) hipLaunchKernelGGL(pool_nlc_kernel<4>, pgrid, dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, feat, am, L, cap, C3, zp, nz);
-        else hipLaunchKernelGGL(pool_nlc_kernel<8>, pgrid, dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, feat, am, L, cap, C3, zp, nz);
+        // waves per window by the window capacity (nsample): 4 from 128 rows up, else 1 (measured: two waves per window at
+        // nsample 64 are SLOWER than one -- 83 -> 96 us for the scale -- the exchange costs more than the shorter walk saves)
+#define FCN_POOL_LAUNCH(VEC_)                                                                                         \
+        if (K >= 128) hipLaunchKernelGGL((pool_nlc_kernel<VEC_, 4>), dim3(L, 1, B), dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, feat, am, L, cap, C3, zp, nz); \
+        else hipLaunchKernelGGL((pool_nlc_kernel<VEC_, 1>), dim3((L + PW - 1) / PW, 1, B), dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, feat, am, L, cap, C3, zp, nz);
+        if (C3 == 128) { FCN_POOL_LAUNCH(2) }
+        else if (C3 == 256) { FCN_POOL_LAUNCH(4) }
+        else { FCN_POOL_LAUNCH(8) }
+#undef FCN_POOL_LAUNCH
     } else {
         dim3 pgrid((L + PW - 1) / PW, C3 / 64, B);
         hipLaunchKernelGGL(pool_kernel, pgrid, dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, one_hot, feat,

@@ -3,7 +3,7 @@ import csv, collections, sys
 path = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/kernel_trace.csv'
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('loss_tail_kernel')]
+idx = [i for i, r in enumerate(rows) if 'loss_tail_kernel' in r['Kernel_Name']]
 a, b = idx[-2], idx[-1]
 t0 = int(rows[a]['Start_Timestamp'])
 print("step window us", (int(rows[b]['Start_Timestamp']) - t0) / 1e3, "kernels", b - a)
