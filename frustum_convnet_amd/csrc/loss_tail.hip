@@ -55,10 +55,9 @@ __device__ __forceinline__ float block_sum(float v, float *sh)
 
 __device__ __forceinline__ float pymod(float a, float b) { return a - b * floorf(a / b); }
 
-__device__ __forceinline__ void corners8(float cx, float cy, float cz, float ang, float l, float w, float h,
+__device__ __forceinline__ void corners8(float cx, float cy, float cz, float c, float s, float l, float w, float h,
                                          float (&px)[8], float (&py)[8], float (&pz)[8])
 {
-    const float c = cosf(ang), s = sinf(ang);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const float sx = (k & 2) ? -0.5f : 0.5f;                         // + + - - + + - -
@@ -243,9 +242,13 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
                 const float pl = o[so] * ex0 + ex0, pw = o[so + 1] * ex1 + ex1, ph = o[so + 2] * ex2 + ex2;
                 const float pcx = rx + o[0], pcy = ry + o[1], pcz = rz + o[2];
                 float px[8], py[8], pz[8], gx[8], gy[8], gz[8], fx[8], fy[8], fz[8];
-                corners8(pcx, pcy, pcz, ang, pl, pw, ph, px, py, pz);
-                corners8(clx, cly, clz, hlab, sl0, sl1, sl2, gx, gy, gz);
-                corners8(clx, cly, clz, hlab + PI, sl0, sl1, sl2, fx, fy, fz);
+                // one cos / sin pair per angle (the precise fp32 routines are the long pole of this lane: the row's work is
+                // serial); the flipped label box takes cos / sin of hlab + pi evaluated like the reference does
+                const float c = cosf(ang), s = sinf(ang);
+                const float hf = hlab + PI;
+                corners8(pcx, pcy, pcz, c, s, pl, pw, ph, px, py, pz);
+                corners8(clx, cly, clz, cosf(hlab), sinf(hlab), sl0, sl1, sl2, gx, gy, gz);
+                corners8(clx, cly, clz, cosf(hf), sinf(hf), sl0, sl1, sl2, fx, fy, fz);
                 float d1 = 0.f, d2 = 0.f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -260,7 +263,6 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
                 const float q = fminf(cd, 1.f);
                 acc[7] += 0.5f * q * q + (cd - q);
                 const float wk = wB * a.w_corner * q * 0.125f;
-                const float c = cosf(ang), s = sinf(ang);
                 float dcx = 0.f, dcy = 0.f, dcz = 0.f, dl = 0.f, dw = 0.f, dh = 0.f, dang = 0.f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
