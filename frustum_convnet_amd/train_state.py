@@ -10,9 +10,10 @@ Parameters, gradients and both Adam moments are four contiguous fp32 buffers (13
     [ConvFeatNet + heads] (2.9 M of the 3.3 M parameters) is final when the FCN backward ends and is reduced on RCCL's
     stream while the PointNet backward still runs; [PointNet] follows it.  The 1/world of the mean is folded into the
     optimiser kernel's grad_scale;
-  * the optimiser step is one streaming HIP kernel (fcn_adam_step_f32) whose step counter and hyper-parameters
+  * the optimiser step is a streaming HIP kernel (fcn_adam_step_f32) PER BUCKET whose step counters and hyper-parameters
     live in device memory, so it can be captured into the step's hipGraph and the learning rate changed between
-    replays.
+    replays; adam_step_bucket(0) can run as soon as the FCN gradients are final (and reduced), beside the PointNet backward,
+    leaving only the small PointNet bucket's update at the end of the step (bench.py does that).
 """
 import ctypes
 
@@ -75,9 +76,12 @@ class FlatTrainState:
         self._pending = []
         self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, 1.0 / self.world], device=dev,
                                   dtype=torch.float32)
-        # one step counter per workgroup of the optimiser kernel (all equal); step_count is slot 0
-        nslot = int(_native.lib().fcn_adam_step_slots(ctypes.c_int64(total)))
-        self._step_slots = torch.zeros(max(nslot, 1), device=dev, dtype=torch.int64)
+        # one step counter per workgroup of the optimiser kernel (all equal); every bucket's launch has its own range of
+        # slots; step_count is slot 0
+        self._slot_off = [0]
+        for _, lo, hi in self.buckets:
+            self._slot_off.append(self._slot_off[-1] + max(int(_native.lib().fcn_adam_step_slots(ctypes.c_int64(hi - lo))), 1))
+        self._step_slots = torch.zeros(self._slot_off[-1], device=dev, dtype=torch.int64)
         self.step_count = self._step_slots[0:1]
         self.device = dev
 
@@ -107,17 +111,27 @@ class FlatTrainState:
             w.wait()
         self._pending = []
 
-    def adam_step(self):
+    def adam_step_bucket(self, i):
+        """The optimiser step of bucket i alone (its gradients must be final -- and reduced for world > 1 -- on the current
+        stream).  Every bucket must be stepped exactly once per training step, in any order, on any streams."""
         if self.device.type != "cuda":
             raise RuntimeError("frustum_convnet_amd: the optimiser step is a HIP kernel (MI355X only); "
                                "there is no CPU fallback")
+        _, lo, hi = self.buckets[i]
         L = _native.lib()
+        off = 4 * lo                                     # bytes; bucket boundaries are 16-byte aligned
         with torch.cuda.device(self.device):
-            _native.check(L.fcn_adam_step_f32(self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
-                                              self.exp_avg_sq.data_ptr(), ctypes.c_int64(self.numel),
-                                              self.hyper.data_ptr(), self._step_slots.data_ptr(),
+            _native.check(L.fcn_adam_step_f32(self.flat.data_ptr() + off, self.grad.data_ptr() + off,
+                                              self.exp_avg.data_ptr() + off, self.exp_avg_sq.data_ptr() + off,
+                                              ctypes.c_int64(hi - lo), self.hyper.data_ptr(),
+                                              self._step_slots.data_ptr() + 8 * self._slot_off[i],
                                               _native.current_stream(self.device)),
                           "fcn_adam_step_f32")
+
+    def adam_step(self):
+        """The optimiser step of every bucket on the current stream."""
+        for i in range(len(self.buckets)):
+            self.adam_step_bucket(i)
 
     def step(self, zero_grad=False):
         """all-reduce + Adam.  The HIP backward kernels OVERWRITE every gradient they own, so no zero_grad is needed
