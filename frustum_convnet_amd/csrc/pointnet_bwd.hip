@@ -26,6 +26,41 @@
 
 extern "C" int fcn_pn_wgrad_rows(void) { return WG_ROWS; }
 
+// Intra-kernel cycle accounting of the data-gradient GEMM for TUNING BUILDS ONLY (-DFCN_PROBE, tools/pn_probe.py; never
+// compiled into the product): wave 0 of every workgroup sums the shader-clock cycles it spends in each phase of the K loop.
+#ifdef FCN_PROBE
+#define PNP_MAX 32768
+__device__ unsigned long long g_pn_probe[PNP_MAX * 8];
+__device__ unsigned int g_pn_probe_n;
+#define PNP_DECL unsigned long long pa_[6] = {0, 0, 0, 0, 0, 0}; unsigned long long pt_ = clock64(), pt0_ = pt_
+#define PNP_ADD(i) do { const unsigned long long n_ = clock64(); pa_[i] += n_ - pt_; pt_ = n_; } while (0)
+#define PNP_FLUSH(tag)                                                                                   \
+    do {                                                                                                 \
+        if (threadIdx.x == 0) {                                                                          \
+            const unsigned int s_ = atomicAdd(&g_pn_probe_n, 1u);                                        \
+            if (s_ < PNP_MAX) {                                                                          \
+                g_pn_probe[s_ * 8] = (unsigned long long)(tag);                                          \
+                g_pn_probe[s_ * 8 + 1] = clock64() - pt0_;                                               \
+                for (int q_ = 0; q_ < 6; ++q_) g_pn_probe[s_ * 8 + 2 + q_] = pa_[q_];                    \
+            }                                                                                            \
+        }                                                                                                \
+    } while (0)
+extern "C" int fcn_pn_probe_read(unsigned long long *host_out, int max_records, int reset)
+{
+    unsigned int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_pn_probe_n), sizeof(n)) != hipSuccess) return -1;
+    if ((int)n > max_records) n = max_records;
+    if (n > PNP_MAX) n = PNP_MAX;
+    if (n && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pn_probe), (size_t)n * 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned int z = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_pn_probe_n), &z, sizeof(z)); }
+    return (int)n;
+}
+#else
+#define PNP_DECL
+#define PNP_ADD(i)
+#define PNP_FLUSH(tag)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // One wave = one window x 64 channels (lane = channel); a workgroup covers PWB consecutive windows, stages
 // its dfeat tile through LDS (dfeat is (B,C,L): 64-B runs along L), routes the gradient to the max rows and
@@ -166,6 +201,7 @@ void dgrad_kernel(DgradArgs a)
     const int k0 = byi * TN;                      // first output column (channel of the previous layer)
     const int CRED = a.CRED, CPREV = a.CPREV;
 
+    PNP_DECL;
     for (int i = tid; i < 5 * CRED; i += NTHR) coefS[i] = a.coef[i];
     if (tid < TM) uS[tid] = (tid < nvalid) ? a.ent[grow0 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int kq = tid & 7, rb = tid >> 3;
@@ -209,8 +245,10 @@ void dgrad_kernel(DgradArgs a)
         }                                                                                                             \
     }
 
+    PNP_ADD(0);                                   // 0: prologue (tables, coefficients, first barrier)
     DGRAD_LOAD(0);
     for (int c = 0; c < nchunk; ++c) {
+        PNP_ADD(1);                               // 1: issue of the global loads (+ loop overhead)
 #pragma unroll
         for (int i = 0; i < NA4; ++i) {
             const int r = rb + RSTEP * i;
@@ -249,13 +287,19 @@ void dgrad_kernel(DgradArgs a)
             sts4(Bs + nn * LDB + 4 * cq, hi);
             sts4(Bs + (nn + 1) * LDB + 4 * cq, lo);
         }
+        PNP_ADD(2);                               // 2: wait for the loads + operand transform + LDS stores
         __syncthreads();
+        PNP_ADD(3);                               // 3: barrier in front of the MFMA phase
         if (c + 1 < nchunk) DGRAD_LOAD(c + 1);
+        PNP_ADD(1);
         mma_chunk<MM, MT, NT, LDA, LDB>(As, Bs, wm * 32 * MT, wn * 32 * NT, acc);
+        PNP_ADD(4);                               // 4: LDS operand reads + MFMAs
         __syncthreads();
+        PNP_ADD(3);                               // (3: both barriers)
     }
 #undef DGRAD_LOAD
 
+    PNP_ADD(3);
     // ---- epilogue: ReLU mask of the previous layer, its BN-backward statistics
     constexpr int NS = (LAYER == 3) ? 2 : 4;
     float st[NT][NS];
@@ -267,18 +311,28 @@ void dgrad_kernel(DgradArgs a)
         for (int q = 0; q < NS; ++q) st[nt][q] = 0.f;
         if constexpr (LAYER == 3) {
             const float pm = a.bn_prev[2 * CPREV + col], pr = a.bn_prev[3 * CPREV + col];
+            // ALL loads of the previous layer's output first, then the masked stores: interleaved, every store to dzprev may
+            // alias the next yprev load as far as the compiler knows, and the 32 load -> store pairs of a lane ran one memory
+            // round trip after the other -- 37-50 % of a workgroup's cycles (tools/pn_probe.py) for 16 KB in and out
+            float yv[MT][16];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = min(wm * 32 * MT + mt * 32 + acc_row(reg, lh), nvalid - 1);      // clamped, unconditional
+                    yv[mt][reg] = a.yprev[(grow0 + row) * CPREV + col];
+                }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int row = wm * 32 * MT + mt * 32 + acc_row(reg, lh);
                     if (row < nvalid) {
-                        const int64_t o = (grow0 + row) * CPREV + col;
-                        const float yv = a.yprev[o];
-                        const float dz = (fmaf(ps, yv, pt) > 0.f) ? acc[mt][nt][reg] : 0.f;
-                        a.dzprev[o] = dz;
+                        const float y = yv[mt][reg];
+                        const float dz = (fmaf(ps, y, pt) > 0.f) ? acc[mt][nt][reg] : 0.f;
+                        a.dzprev[(grow0 + row) * CPREV + col] = dz;
                         st[nt][0] += dz;
-                        st[nt][1] = fmaf(dz, (yv - pm) * pr, st[nt][1]);
+                        st[nt][1] = fmaf(dz, (y - pm) * pr, st[nt][1]);
                     }
                 }
         } else {
@@ -301,6 +355,7 @@ void dgrad_kernel(DgradArgs a)
 #pragma unroll
         for (int q = 0; q < NS; ++q) st[nt][q] += __shfl_xor(st[nt][q], 32, 64);
     }
+    PNP_ADD(5);                                   // 5: epilogue -- ReLU mask (loads of the previous layer's output), dz stores
     float *red = As;      // [wn][nt][l31][NS], written by wm == 1
     if (wm == 1 && lh == 0) {
 #pragma unroll
@@ -320,6 +375,8 @@ void dgrad_kernel(DgradArgs a)
             }
         }
     }
+    PNP_FLUSH(((unsigned long long)LAYER << 48) | ((unsigned long long)CRED << 32) | ((unsigned long long)CPREV << 16) |
+              (unsigned long long)nvalid);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,42 @@
+"""Cycle accounting of the PointNet data-gradient GEMM (tuning build libfcn_hip_pnprobe.so, -DFCN_PROBE; not the product).
+    python tools/build_variant.py pnprobe -DFCN_PROBE
+    FCN_LIB_NAME=libfcn_hip_pnprobe.so python tools/pn_probe.py [cfg]
+Per kernel shape (layer, K = CRED, N = CPREV): workgroups, mean shader-clock cycles of wave 0 per workgroup and their split
+over the phases of the K loop: prologue | load issue | wait for loads + operand transform + LDS stores | barrier | LDS reads +
+MFMAs | epilogue (ReLU mask + dz stores); the rest is the statistics reduction + atomics."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import bench
+from frustum_convnet_amd import _native
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "car"
+serial = os.environ.get("FCN_SERIAL", "0") == "1"
+dev = torch.device("cuda", 0)
+model = bench.build_model(dev, cfg)
+data = bench.make_data(cfg, 32, bench.CFGS[cfg][3], 1234, dev)
+L = _native.lib()
+L.fcn_pn_probe_read.restype = ctypes.c_int
+L.fcn_pn_probe_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+buf = np.zeros((32768, 8), dtype=np.uint64)
+for it in range(3):
+    losses, _ = model(data)
+    torch.cuda.synchronize()
+    L.fcn_pn_probe_read(buf.ctypes.data, 32768, 1)          # forward launches none of the probed kernels: reset
+    losses["total_loss"].backward()
+    torch.cuda.synchronize()
+    n = L.fcn_pn_probe_read(buf.ctypes.data, 32768, 1)
+rec = buf[:n].astype(np.int64)
+print("records", n, "(scales %s)" % ("serialised" if serial else "concurrent"))
+names = ["prologue", "load issue", "wait+transform+lds st", "barriers", "lds rd + mfma", "epilogue mask+store"]
+tags = rec[:, 0] >> 16
+for t in sorted(set(tags)):
+    r = rec[tags == t]
+    full = r[(r[:, 0] & 0xffff) == 64]                        # full 64-row tiles
+    tot = full[:, 1].astype(np.float64)
+    ph = full[:, 2:8].astype(np.float64)
+    K = (t >> 16) & 0xffff
+    print("layer %d K=%4d N=%4d  wg %5d (full %5d)  cycles/wg %8.0f (max %8.0f) = %.1f us @2.4GHz, %5.0f per chunk | " % (
+        t >> 32, K, t & 0xffff, len(r), len(full), tot.mean(), tot.max(), tot.mean() / 2400.0, ph[:, 1:5].sum(1).mean() / (K / 32)) +
+          "  ".join("%s %4.1f%%" % (nm, 100 * ph[:, i].mean() / tot.mean()) for i, nm in enumerate(names)))
