@@ -19,6 +19,7 @@
 #define LDT 129                 // transposed (k-major) staging of a 128-row tile
 #define MAXC 512
 #define WG_ROWS 128             // rows of one row tile (wgrad splits are multiples of it)
+#define WG_TMAX 256             // row tiles per weight-gradient split (their lookup table lives in LDS)
 #define PWB 16                  // windows per poolbwd workgroup (4 per wave, their loads issued together)
 #ifndef FCN_WIDE_TILES
 #define FCN_WIDE_TILES 0
@@ -404,6 +405,11 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
     constexpr int LDA = 64 * MT + 4, LDB = 64 * NT + 4;
     __shared__ __attribute__((aligned(16))) float As[KC * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[KC * LDB];
+    // (first row, live rows) of the split's row tiles, looked up ONCE: per chunk, the walk tile list -> frustum -> live-row
+    // count was two dependent memory round trips in front of every chunk's loads AND again in front of its staging, and the
+    // "load or zero" branches behind it made the compiler wait for every load at once -- tools/pn_probe.py: 45-60 % of the
+    // kernel's cycles between them, 13-19 % in the MFMA phase
+    __shared__ int tG0[WG_TMAX], tLeft[WG_TMAX];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -416,6 +422,13 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
     const int nq = (t_end - t_beg) * 4;                 // 32-row chunks to reduce
     const int n0 = blockIdx.y * 64 * MT, k0 = blockIdx.z * 64 * NT;
     const int COUT = a.COUT, CIN = a.CIN;
+    for (int i = tid; i < t_end - t_beg; i += GT) {     // (launch_wgrad keeps a split within WG_TMAX tiles)
+        const int code = a.tiles[4 + t_beg + i];
+        const int b = code / a.tps, t = code % a.tps;
+        tG0[i] = b * a.cap + t * 128;
+        tLeft[i] = a.woff[(int64_t)b * (a.L + 1) + a.L] - t * 128;
+    }
+    __syncthreads();
 
     // per-thread constant columns of the two staged operands
     const int acq = tid % (16 * MT), arr = tid / (16 * MT);
@@ -444,6 +457,7 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
         }
     }
 
+    PNP_DECL;
     f32x16 acc[MT][NT];
     acc_zero<MT, NT>(acc);
     float4 ra[2 * MT], ra2[2 * MT], rb4[2 * NT];
@@ -451,58 +465,53 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
 
     // chunk q -> (global row of its first row, number of valid rows left in its tile from there)
     auto chunk_rows = [&](int q, int64_t &g0, int &left) __attribute__((always_inline)) {
-        const int code = a.tiles[4 + t_beg + (q >> 2)];
-        const int b = code / a.tps, t = code % a.tps;
-        const int nent = a.woff[(int64_t)b * (a.L + 1) + a.L];
-        const int r0 = t * 128 + (q & 3) * KC;
-        g0 = (int64_t)b * a.cap + r0;
-        left = nent - r0;                                      // may be <= 0 for the tail chunks of a tile
+        const int r0 = (q & 3) * KC;
+        g0 = (int64_t)tG0[q >> 2] + r0;
+        left = tLeft[q >> 2] - r0;                             // may be <= 0 for the tail chunks of a tile
     };
 
     auto load_chunk = [&](int q) __attribute__((always_inline)) {
         int64_t g0;
         int left;
         chunk_rows(q, g0, left);
+        // unconditional loads from a clamped row (inside the frustum's region even when the chunk holds no live row); rows
+        // past `left` are zeroed when the registers go to LDS
+        const int lastr = max(left, 1) - 1;
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
-            const int rr = WG_AROW(i);
-            if (rr < left) {
-                const int64_t o = (g0 + rr) * COUT + n0 + 4 * acq;
-                if constexpr (LAYER == 3) {
-                    ra[i] = *(const float4 *)(a.dy + o);
-                } else {
-                    ra[i] = *(const float4 *)(a.dz + o);
-                    ra2[i] = *(const float4 *)(a.ycur + o);
-                    rwt[i] = a.ent[g0 + rr].w;
-                }
+            const int rr = min(WG_AROW(i), lastr);
+            const int64_t o = (g0 + rr) * COUT + n0 + 4 * acq;
+            if constexpr (LAYER == 3) {
+                ra[i] = *(const float4 *)(a.dy + o);
             } else {
-                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (LAYER == 2) { ra2[i] = make_float4(0.f, 0.f, 0.f, 0.f); rwt[i] = 0.f; }
+                ra[i] = *(const float4 *)(a.dz + o);
+                ra2[i] = *(const float4 *)(a.ycur + o);
+                rwt[i] = a.ent[g0 + rr].w;
             }
         }
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {
-            const int rr = WG_BROW(i);
-            if (rr < left) {
-                if constexpr (LAYER == 3) rb4[i] = *(const float4 *)(a.yprev + (g0 + rr) * CIN + k0 + 4 * bcq);
-                else rb4[i] = a.ent[g0 + rr];
-            } else {
-                rb4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            const int rr = min(WG_BROW(i), lastr);
+            if constexpr (LAYER == 3) rb4[i] = *(const float4 *)(a.yprev + (g0 + rr) * CIN + k0 + 4 * bcq);
+            else rb4[i] = a.ent[g0 + rr];
         }
     };
 
+    PNP_ADD(0);                                   // 0: prologue
     load_chunk(0);
     for (int q = 0; q < nq; ++q) {
+        PNP_ADD(1);                               // 1: chunk lookup + issue of the global loads
         int64_t g0_;
         int left;
         chunk_rows(q, g0_, left);
+        PNP_ADD(5);                               // 5: chunk lookup at the loop top (tile list -> live rows)
         v4f sa[2 * MT], sb[2 * NT];
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
             const int rr = WG_AROW(i);
             const bool ok = rr < left;
-            v4f v = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+            const v4f rv = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+            v4f v = ok ? rv : zero4();
             if constexpr (LAYER == 2) {
                 const float dzv[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
                 const float yv[4] = {ra2[i].x, ra2[i].y, ra2[i].z, ra2[i].w};
@@ -548,10 +557,15 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
             sts4(Bs + WG_BROW(i) * LDB + 4 * bcq, hi);
             sts4(Bs + WG_BROW(i + 1) * LDB + 4 * bcq, lo);
         }
+        PNP_ADD(2);                               // 2: wait for the loads + operand transform + LDS stores
         __syncthreads();
+        PNP_ADD(3);                               // 3: barriers
         if (q + 1 < nq) load_chunk(q + 1);
+        PNP_ADD(1);
         mma_chunk<MM, MT, NT, LDA, LDB>(As, Bs, wm * 32 * MT, wn * 32 * NT, acc);
+        PNP_ADD(4);                               // 4: LDS operand reads + MFMAs
         __syncthreads();
+        PNP_ADD(3);
     }
 #undef WG_AROW
 #undef WG_BROW
@@ -567,6 +581,8 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
                 const int k = k0 + wn * 32 * NT + nt * 32 + l31;
                 out[(int64_t)n * CIN + k] = acc[mt][nt][reg];
             }
+    PNP_FLUSH(((unsigned long long)(10 + LAYER) << 48) | ((unsigned long long)COUT << 32) | ((unsigned long long)CIN << 16) |
+              (unsigned long long)64);
 }
 
 // out[i] = sum over the live splits in a fixed order (deterministic).  The 256-thread workgroup covers 256 / gr
@@ -675,6 +691,7 @@ static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, int precision, hipS
 #endif
     const int slots = (LAYER == 2 && m2 && n2) ? (FCN_WG_SLOTS * 2) / 3 : FCN_WG_SLOTS;
     int nsplit = slots / (oy * oz);
+    if (nsplit < (B * a.tps + WG_TMAX - 1) / WG_TMAX) nsplit = (B * a.tps + WG_TMAX - 1) / WG_TMAX;      // tiles per split <= WG_TMAX
     if (nsplit < 1) nsplit = 1;
     if (nsplit > B * a.tps) nsplit = B * a.tps;
     if (nsplit > nsplit_cap) nsplit = nsplit_cap;

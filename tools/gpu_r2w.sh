@@ -1,9 +1,9 @@
 #!/bin/bash
-# dgrad<3> with the arg-max / routed-gradient maps of the tile's windows fetched once per workgroup: parity, probe, A/B
+# PointNet backward GEMMs after the probe-guided fixes: parity, probe, A/B against the previous build on one box
 mkdir -p gpurun_out; export TMPDIR=/tmp
 O=gpurun_out
-timeout 900 python -m pytest tests/test_gpu_pointnet.py tests/test_gpu_model.py -m gpu -q 2>&1 | tail -2
-FCN_LIB_NAME=libfcn_hip_pnprobe.so timeout 300 python tools/pn_probe.py car 2>&1 | grep "layer 3" | cut -c1-330
+timeout 900 python -m pytest tests/test_gpu_pointnet.py tests/test_gpu_model.py tests/test_gpu_properties.py -m gpu -q 2>&1 | tail -2
+FCN_LIB_NAME=libfcn_hip_pnprobe.so timeout 300 python tools/pn_probe.py car 2>&1 | grep "wgrad" | cut -c1-330
 run() { n=$1; shift
   env "$@" timeout 400 python bench.py --steps 200 --warmup 30 --no-cpu-baseline > $O/bench_w_$n.txt 2> $O/bench_w_$n.err; echo "== $n rc=$?"
   python - <<PY

@@ -37,6 +37,10 @@ for t in sorted(set(tags)):
     tot = full[:, 1].astype(np.float64)
     ph = full[:, 2:8].astype(np.float64)
     K = (t >> 16) & 0xffff
-    print("layer %d K=%4d N=%4d  wg %5d (full %5d)  cycles/wg %8.0f (max %8.0f) = %.1f us @2.4GHz, %5.0f per chunk | " % (
-        t >> 32, K, t & 0xffff, len(r), len(full), tot.mean(), tot.max(), tot.mean() / 2400.0, ph[:, 1:5].sum(1).mean() / (K / 32)) +
-          "  ".join("%s %4.1f%%" % (nm, 100 * ph[:, i].mean() / tot.mean()) for i, nm in enumerate(names)))
+    lay = t >> 32
+    nm_ = list(names)
+    if lay >= 10:                                   # weight-gradient kernels: slot 5 = chunk lookup at the loop top
+        nm_[5] = "chunk lookup"
+    print("%s %d M/K=%4d N=%4d  wg %5d (full %5d)  cycles/wg %8.0f (max %8.0f) = %.1f us @2.4GHz | " % (
+        "wgrad" if lay >= 10 else "dgrad", lay % 10, K, t & 0xffff, len(r), len(full), tot.mean(), tot.max(), tot.mean() / 2400.0) +
+          "  ".join("%s %4.1f%%" % (nm, 100 * ph[:, i].mean() / tot.mean()) for i, nm in enumerate(nm_)))
