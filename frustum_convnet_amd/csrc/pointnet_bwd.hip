@@ -209,14 +209,16 @@ void dgrad_kernel(DgradArgs a)
     constexpr int RSTEP = NTHR / 8;               // rows between a thread's consecutive A quads
     // loads are UNCONDITIONAL on a clamped row (a "load or zero" branch makes hipcc wait for the load at once); rows
     // past nvalid are zeroed when the registers go to LDS
-    int64_t arow[NA4];    // element offset of this thread's (clamped) rows in a (rows, CRED) buffer
-    int64_t wbase[NA4];   // LAYER 3: offset of the row's window in the (B, L, CRED) arg-max / routed-gradient maps
+    // 32-bit element offsets (launch_dgrad checks B * cap * max(CRED, CPREV) < 2^31): half the registers and address
+    // arithmetic of int64
+    int arow[NA4];        // element offset of this thread's (clamped) rows in a (rows, CRED) buffer
+    int wbase[NA4];       // LAYER 3: offset of the row's window in the (B, L, CRED) arg-max / routed-gradient maps
 #pragma unroll
     for (int i = 0; i < NA4; ++i) {
         const int rc = min(rb + RSTEP * i, nvalid - 1);
-        arow[i] = (grow0 + rc) * CRED;
+        arow[i] = ((int)grow0 + rc) * CRED;
         wbase[i] = 0;
-        if constexpr (LAYER == 3) wbase[i] = ((int64_t)b * a.L + a.ewin[grow0 + rc]) * CRED;
+        if constexpr (LAYER == 3) wbase[i] = (b * a.L + a.ewin[grow0 + rc]) * CRED;
     }
     __syncthreads();
 
@@ -242,7 +244,7 @@ void dgrad_kernel(DgradArgs a)
         _Pragma("unroll") for (int i = 0; i < NB4; ++i) {      /* rows 2*pr, 2*pr+1 of one column quad (a k pair) */  \
             const int f = tid + NTHR * (i >> 1);                                                                      \
             const int nn = 2 * (f / (TN / 4)) + (i & 1), cq = f % (TN / 4);                                           \
-            rw[i] = ldg4(a.W + (int64_t)((cc) * KC + nn) * CPREV + k0 + 4 * cq);                                      \
+            rw[i] = ldg4(a.W + ((cc) * KC + nn) * CPREV + k0 + 4 * cq);                                      \
         }                                                                                                             \
     }
 
@@ -464,15 +466,16 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
     float rwt[2 * MT];
 
     // chunk q -> (global row of its first row, number of valid rows left in its tile from there)
-    auto chunk_rows = [&](int q, int64_t &g0, int &left) __attribute__((always_inline)) {
+    // (32-bit element offsets throughout: launch_wgrad checks B * cap * max(COUT, CIN) < 2^31 -- the 64-bit multiplies of
+    // the per-chunk address arithmetic were a visible part of the load-issue phase)
+    auto chunk_rows = [&](int q, int &g0, int &left) __attribute__((always_inline)) {
         const int r0 = (q & 3) * KC;
-        g0 = (int64_t)tG0[q >> 2] + r0;
+        g0 = tG0[q >> 2] + r0;
         left = tLeft[q >> 2] - r0;                             // may be <= 0 for the tail chunks of a tile
     };
 
     auto load_chunk = [&](int q) __attribute__((always_inline)) {
-        int64_t g0;
-        int left;
+        int g0, left;
         chunk_rows(q, g0, left);
         // unconditional loads from a clamped row (inside the frustum's region even when the chunk holds no live row); rows
         // past `left` are zeroed when the registers go to LDS
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
             const int rr = min(WG_AROW(i), lastr);
-            const int64_t o = (g0 + rr) * COUT + n0 + 4 * acq;
+            const int o = (g0 + rr) * COUT + n0 + 4 * acq;
             if constexpr (LAYER == 3) {
                 ra[i] = *(const float4 *)(a.dy + o);
             } else {
@@ -501,8 +504,7 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
     load_chunk(0);
     for (int q = 0; q < nq; ++q) {
         PNP_ADD(1);                               // 1: chunk lookup + issue of the global loads
-        int64_t g0_;
-        int left;
+        int g0_, left;
         chunk_rows(q, g0_, left);
         PNP_ADD(5);                               // 5: chunk lookup at the loop top (tile list -> live rows)
         v4f sa[2 * MT], sb[2 * NT];
@@ -655,6 +657,7 @@ template <int LAYER>
 static int launch_dgrad(const DgradArgs &a, int B, int precision, hipStream_t st)
 {
     if (a.CRED % 64 || a.CPREV % 64 || a.CRED > MAXC) return FCN_E_BADARG;
+    if ((int64_t)B * a.cap * (a.CRED > a.CPREV ? a.CRED : a.CPREV) >= (int64_t)1 << 31) return FCN_E_LIMIT;   // 32-bit offsets
     const unsigned nt = (unsigned)(B * a.tps);
     if (a.CPREV % 128 == 0) {          // 64 x 128 tiles, two workgroups per listed 128-row tile
         FCN_MM_SWITCH(FCN_MM_OF(precision, false),
@@ -690,6 +693,7 @@ static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, int precision, hipS
 #define FCN_WG_SLOTS 384
 #endif
     const int slots = (LAYER == 2 && m2 && n2) ? (FCN_WG_SLOTS * 2) / 3 : FCN_WG_SLOTS;
+    if ((int64_t)B * a.cap * (a.COUT > a.CIN ? a.COUT : a.CIN) >= (int64_t)1 << 31) return FCN_E_LIMIT;   // 32-bit offsets
     int nsplit = slots / (oy * oz);
     if (nsplit < (B * a.tps + WG_TMAX - 1) / WG_TMAX) nsplit = (B * a.tps + WG_TMAX - 1) / WG_TMAX;      // tiles per split <= WG_TMAX
     if (nsplit < 1) nsplit = 1;

@@ -173,15 +173,17 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
             for (int i = 0; i < NA4; ++i) {
                 const int f = tid + NTHR * i;
                 const int r = f >> 3, kq = f & 7;
-                ra[i] = (r < nvalid) ? *(const float4 *)(a.aprev + (grow0 + r) * CIN + c * KC + 4 * kq)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+                // unconditional, from a clamped row (a "load or zero" select makes the compiler wait for the load at
+                // once); rows past nvalid are zeroed when the registers go to LDS.  32-bit element offsets
+                // (launch_fwd_gemm checks B * cap * CIN < 2^31).
+                ra[i] = *(const float4 *)(a.aprev + ((int)grow0 + min(r, nvalid - 1)) * CIN + c * KC + 4 * kq);
             }
         }
 #pragma unroll
         for (int i = 0; i < NB4; ++i) {
             const int f = tid + NTHR * i;
             const int n = f >> 3, kq = f & 7;
-            rw[i] = *(const float4 *)(a.W + (int64_t)(n0 + n) * CIN + c * KC + 4 * kq);
+            rw[i] = *(const float4 *)(a.W + (n0 + n) * CIN + c * KC + 4 * kq);
         }
     };
 
@@ -456,6 +458,7 @@ template <int MODE>
 static int launch_fwd_gemm(const FwdArgs &a, int B, int precision, hipStream_t st)
 {
     if (a.CIN % 64 || a.COUT % 64 || a.CIN > MAXC) return FCN_E_BADARG;
+    if ((int64_t)B * a.cap * (a.CIN > a.COUT ? a.CIN : a.COUT) >= (int64_t)1 << 31) return FCN_E_LIMIT;      // 32-bit offsets
     if (precision < 0 || precision > FCN_PREC_BF16) return FCN_E_BADARG;
     FCN_MM_SWITCH(FCN_MM_OF(precision, true), return (launch_fwd_gemm_mm<MM, MODE>(a, B, st)));
     return FCN_E_BADARG;

@@ -3,7 +3,7 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp
 O=gpurun_out
 timeout 900 python -m pytest tests/test_gpu_pointnet.py tests/test_gpu_model.py tests/test_gpu_properties.py -m gpu -q 2>&1 | tail -2
-FCN_LIB_NAME=libfcn_hip_pnprobe.so timeout 300 python tools/pn_probe.py car 2>&1 | grep "wgrad" | cut -c1-330
+FCN_LIB_NAME=libfcn_hip_pnprobe.so timeout 300 python tools/pn_probe.py car 2>&1 | grep "grad" | cut -c1-330
 run() { n=$1; shift
   env "$@" timeout 400 python bench.py --steps 200 --warmup 30 --no-cpu-baseline > $O/bench_w_$n.txt 2> $O/bench_w_$n.err; echo "== $n rc=$?"
   python - <<PY
@@ -11,7 +11,7 @@ import json
 d=json.loads(open("$O/bench_w_$n.txt").read().strip().splitlines()[-1])
 print(d["value"], d["ms_per_step"])
 for r in d["roofline"]["kernels"]:
-    if r["entry"].startswith("fcn_pn_backward2"): print("  %-46s %.4f ms" % (r["entry"], r["ms_per_step"]))
+    if r["entry"].startswith("fcn_pn_"): print("  %-46s %.4f ms" % (r["entry"], r["ms_per_step"]))
 PY
 }
 run prev FCN_LIB_NAME=libfcn_hip_prev.so
