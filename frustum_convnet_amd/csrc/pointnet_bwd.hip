@@ -86,14 +86,20 @@ __global__ __launch_bounds__(GT) void poolbwd_kernel(
     constexpr int NW = PWB / 4;
     int am[NW];
     float gg[NW], yy[NW];
+    // unconditional loads from clamped positions (a "load or default" select makes the compiler wait for each load at once):
+    // the four arg-max loads, then the four gathers they address, are in flight together
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
         const int l = l0 + wave + 4 * q;
-        am[q] = (l < L) ? amax[((int64_t)b * L + l) * C3 + c] : -1;
-        gg[q] = (l < L && nlc) ? dfeat[((int64_t)b * L + l) * C3 + c] : 0.f;
+        const int64_t o = ((int64_t)b * L + min(l, L - 1)) * C3 + c;
+        am[q] = amax[o];
+        gg[q] = nlc ? dfeat[o] : 0.f;
     }
 #pragma unroll
-    for (int q = 0; q < NW; ++q) yy[q] = (am[q] >= 0) ? y3[((int64_t)b * cap + am[q]) * C3 + c] : 0.f;
+    for (int q = 0; q < NW; ++q) {
+        if (l0 + wave + 4 * q >= L) am[q] = -1;
+        yy[q] = y3[((int64_t)b * cap + max(am[q], 0)) * C3 + c];
+    }
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
         const int wl = wave + 4 * q, l = l0 + wl;
