@@ -483,9 +483,11 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
     auto load_chunk = [&](int q) __attribute__((always_inline)) {
         int g0, left;
         chunk_rows(q, g0, left);
-        // unconditional loads from a clamped row (inside the frustum's region even when the chunk holds no live row); rows
-        // past `left` are zeroed when the registers go to LDS
+        // unconditional loads from a clamped row; rows past `left` are zeroed when the registers go to LDS.  A chunk without
+        // a live row (the tail of a tile: cap need not be a multiple of 128, so its rows may lie past the buffer) reads the
+        // tile's first row, which is live.
         const int lastr = max(left, 1) - 1;
+        if (left <= 0) g0 = tG0[q >> 2];
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
             const int rr = min(WG_AROW(i), lastr);
