@@ -70,17 +70,18 @@ def test_rotate_nms_matches_reference_keep_lists():
         assert got == exp, (c, got, exp)
 
 
-def test_decode_matches_oracle():
+@pytest.mark.parametrize("ns,ld", [(3, 64), (10, 128)])        # KITTI head rows (41 of 64 columns) / SUN-RGBD (69 of 128)
+def test_decode_matches_oracle(ns, ld):
     from frustum_convnet_amd import detect
     rng = np.random.default_rng(5)
-    B, L2, nb, ns = 6, 37, 12, 3
+    B, L2, nb = 6, 37, 12
     nc = 3 + 2 * nb + 4 * ns
-    logits = np.zeros((B * L2, 64), dtype=np.float32)
+    logits = np.zeros((B * L2, ld), dtype=np.float32)
     logits[:, :2 + nc] = rng.normal(0, 1.0, (B * L2, 2 + nc)).astype(np.float32)
     logits[2 * L2:3 * L2, 0] = 3.0; logits[2 * L2:3 * L2, 1] = rng.normal(-3, 0.3, L2)      # frustum 2: no foreground
     logits[5, 2 + 3 + 2 * nb + ns:2 + nc] = -1.0                                             # row 5: zero-size box (filtered)
     ref2 = rng.normal(0, 1, (B, 3, L2)).astype(np.float32) + np.array([0, 1, 20], dtype=np.float32)[None, :, None]
-    mean_size = det_ref.MEAN_SIZE.astype(np.float32)
+    mean_size = (det_ref.MEAN_SIZE if ns == 3 else det_ref.MEAN_SIZE_SUNRGBD).astype(np.float32)
     rot = rng.uniform(-0.5, 0.5, B).astype(np.float32)
     refc = rng.normal(0, 1, (B, 3)).astype(np.float32)
     rgb = rng.uniform(0, 1, B).astype(np.float32)
@@ -111,7 +112,7 @@ def test_decode_matches_oracle():
     assert valid[5] == 0
 
 
-@pytest.mark.parametrize("case", ["car_b4_n512", "people_b2_n512"])
+@pytest.mark.parametrize("case", ["car_b4_n512", "people_b2_n512", "sunrgbd_b4_n1024"])
 def test_loss_tail_iou_metrics_match_oracle(case):
     from test_gpu_model import _model
     from frustum_convnet_amd.config import cfg
@@ -128,7 +129,9 @@ def test_loss_tail_iou_metrics_match_oracle(case):
     lab = data_np["cls_label"].reshape(-1)
     fg = [(int(r), int(r // L2)) for r in np.nonzero(lab == 1)[0]]
     e2, e3, et = box_ref.iou_metrics(reg_rows, ref2_rows, fg, data_np["box3d_center"], data_np["box3d_heading"].reshape(-1),
-                                     data_np["box3d_size"], det_ref.MEAN_SIZE, thresh=cfg.IOU_THRESH)
+                                     data_np["box3d_size"],
+                                     det_ref.MEAN_SIZE if reg.shape[1] == 39 else det_ref.MEAN_SIZE_SUNRGBD,
+                                     ns=3 if reg.shape[1] == 39 else 10, thresh=cfg.IOU_THRESH)
     got = [float(metrics[k]) for k in ("IoU_2D", "IoU_3D", "IoU_" + str(cfg.IOU_THRESH))]
     print(case, "IoU metrics", got, (e2, e3, et), "nfg", float(m.last_num_fg))
     assert abs(got[0] - e2) < 1e-4 and abs(got[1] - e3) < 1e-4 and abs(got[2] - et) < 1e-6
