@@ -7,6 +7,11 @@
 
 #define FCN_WAVE 64
 
+// dynamic LDS of a kernel (size given at launch); a macro so that the host emulation of tests/host_harness can map it
+#ifndef FCN_DYN_LDS
+#define FCN_DYN_LDS(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define FCN_CHECK_LAUNCH()                         \

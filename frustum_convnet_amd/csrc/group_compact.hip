@@ -67,7 +67,7 @@ __device__ __forceinline__ GcScale gc_pick(const GcArgs &a, int z)
 // ---- launch 1: hit lists (query_depth_point_cuda_kernel.cu:40-64: fabsf(z2 - z1) < dis_z in fp32, ascending k, first K)
 __global__ __launch_bounds__(GC_T) void gc_hits_kernel(GcArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    FCN_DYN_LDS(unsigned char, smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
     const GcScale S = gc_pick(a, (int)blockIdx.z);
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(GC_T) void gc_hits_kernel(GcArgs a)
 // ---- launch 2: offsets, entry rows, moments; the last frustum of a scale finalises it
 __global__ __launch_bounds__(GE_T) void gc_entries_kernel(GcArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    FCN_DYN_LDS(unsigned char, smem);
     __shared__ int wsum[GE_WAVES];
     __shared__ double red[GE_WAVES][10];
     __shared__ int last_s, carry_s;

@@ -16,11 +16,14 @@ from frustum_convnet_amd import _native as N                                   #
 from frustum_convnet_amd.fcn_fused import layer_names                          # noqa: E402
 
 
-def load_emu(force=False):
+def emu_path(force=False):
     sys.path.insert(0, os.path.join(ROOT, "tests", "host_harness"))
     import build_emu
-    path = build_emu.build(force=force)
-    L = ctypes.CDLL(path)
+    return build_emu.build(force=force)
+
+
+def load_emu(force=False):
+    L = ctypes.CDLL(emu_path(force))
     fp = N.c_fp
     L.fcn_convnet_sizes.argtypes = [ctypes.POINTER(N.CnDesc), ctypes.POINTER(ctypes.c_int64 * 6)]
     L.fcn_convnet_logits_ld.argtypes = [ctypes.POINTER(N.CnDesc)]

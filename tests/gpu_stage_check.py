@@ -40,12 +40,38 @@ def make_case(B, N, stride, K, mlp, dist, seed=5, variant="car", span=70.0):
     return pc, ref, sd, one_hot
 
 
-def run_stages(B, N, stride, K, mlp, dist, seed=5, variant="car", verbose=True):
-    """Returns dict stage -> (max abs diff, scale) comparing HIP vs CPU emulation / oracle."""
+def _emu_forward(pf, cfgt, pcg, refg, one_hot, bufs, plist):
+    """The launch sequence of query_depth_point + pointnet_fused._forward_impl on CPU tensors: used when the library behind
+    _native.lib() is the host emulation of the kernels (tests/host_harness/build_emu.py), which takes host pointers."""
+    import ctypes
+    from frustum_convnet_amd import _native
+    L = _native.lib()
+    dist, K = cfgt[0], cfgt[1]
+    b, _, n = pcg.shape
+    m = refg.size(2)
+    idx = torch.empty((b, m, K), dtype=torch.int64)
+    cnt = torch.empty((b, m), dtype=torch.int32)
+    _native.check(L.fcn_query_depth_point_f32(pcg.data_ptr() + 4 * 2 * n, 1, 3 * n, refg.data_ptr() + 4 * 2 * m, 1, 3 * m,
+                                              b, n, m, float(dist), int(K), idx.data_ptr(), cnt.data_ptr(), None),
+                  "fcn_query_depth_point_f32")
+    h = pf._acquire(pf.WorkspacePool(), cfgt, pcg, refg, one_hot, bufs, plist, True)
+    _native.check(L.fcn_pn_compact(ctypes.byref(h["desc"]), pcg.data_ptr(), refg.data_ptr(), idx.data_ptr(), cnt.data_ptr(),
+                                   ctypes.byref(h["ws"].c), None), "fcn_pn_compact")
+    Bq, Lw, C3 = h["dims"]
+    feat = torch.empty((Bq, C3 + h["nvec"], Lw), dtype=torch.float32)
+    _native.check(L.fcn_pn_forward(ctypes.byref(h["desc"]), ctypes.byref(h["params"]), cnt.data_ptr(),
+                                   None if h["oh"] is None else h["oh"].data_ptr(), ctypes.byref(h["ws"].c),
+                                   feat.data_ptr(), None), "fcn_pn_forward")
+    return idx, cnt, (feat, idx, cnt, h["ws"], h["desc"], (h["Wc"], h["gs"], h["bs"], cnt, idx, h["oh"]))
+
+
+def run_stages(B, N, stride, K, mlp, dist, seed=5, variant="car", verbose=True, emu=False):
+    """Returns dict stage -> (max abs diff, scale) comparing HIP vs CPU emulation / oracle.  emu: the library behind
+    _native.lib() is the host emulation of the kernels -- same checks on CPU tensors, no stream, no synchronisation."""
     from frustum_convnet_amd import pointnet_fused as pf
     from frustum_convnet_amd.query_depth_point import query_depth_point
 
-    dev = torch.device("cuda:0")
+    dev = torch.device("cpu") if emu else torch.device("cuda:0")
     pc, ref, sd, one_hot = make_case(B, N, stride, K, mlp, dist, seed, variant)
     L = ref.shape[2]
     res = {}
@@ -81,9 +107,6 @@ def run_stages(B, N, stride, K, mlp, dist, seed=5, variant="car", verbose=True):
 
     # ---- HIP side
     pcg, refg = pc.to(dev), ref.to(dev)
-    idx_g, cnt_g = query_depth_point(dist, K, pcg, refg)
-    rec("idx", idx_g, idx_o, exact=True)
-    rec("cnt", cnt_g, cnt_o, exact=True)
 
     sdg = {k: v.clone().to(dev) for k, v in sd.items()}
     plist = []
@@ -95,8 +118,14 @@ def run_stages(B, N, stride, K, mlp, dist, seed=5, variant="car", verbose=True):
             [sdg["m.conv%d.1.num_batches_tracked" % j] for j in (1, 2, 3)])
     pool = pf.WorkspacePool()
     cfgt = (float(dist), int(K), True, 1e-5, 0.1)
-    feat, idx2, cnt2, ws, desc, keep = pf._forward_impl(pool, cfgt, pcg, refg, one_hot.to(dev), bufs, plist, True)
-    torch.cuda.synchronize()
+    if emu:
+        idx_g, cnt_g, (feat, idx2, cnt2, ws, desc, keep) = _emu_forward(pf, cfgt, pcg, refg, one_hot, bufs, plist)
+    else:
+        idx_g, cnt_g = query_depth_point(dist, K, pcg, refg)
+        feat, idx2, cnt2, ws, desc, keep = pf._forward_impl(pool, cfgt, pcg, refg, one_hot.to(dev), bufs, plist, True)
+        torch.cuda.synchronize()
+    rec("idx", idx_g, idx_o, exact=True)
+    rec("cnt", cnt_g, cnt_o, exact=True)
     nent = c["nent"]
     rec("woff", ws.woff, c["woff"], exact=True)
 
@@ -143,9 +172,10 @@ def run_stages(B, N, stride, K, mlp, dist, seed=5, variant="car", verbose=True):
     arr = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
     dfg = dfeat.to(dev).contiguous()
     rc = _native.lib().fcn_pn_backward(ctypes.byref(desc), ctypes.byref(params), dfg.data_ptr(), ctypes.byref(ws.c),
-                                       arr(dW), arr(dg), arr(db), _native.current_stream(dev))
+                                       arr(dW), arr(dg), arr(db), None if emu else _native.current_stream(dev))
     assert rc == 0, rc
-    torch.cuda.synchronize()
+    if not emu:
+        torch.cuda.synchronize()
     rec("dy3", live(ws.dy3), r["dy3"])
     zmask2 = (f["y2"] * f["s"][1] + f["t"][1] > 0).float()
     rec("dz2", live(ws.dz2), r["G2"] * zmask2)
@@ -153,7 +183,8 @@ def run_stages(B, N, stride, K, mlp, dist, seed=5, variant="car", verbose=True):
         rec("dW%d" % j, dW[j - 1], r["dW%d" % j])
         rec("dgamma%d" % j, dg[j - 1], r["dg%d" % j])
         rec("dbeta%d" % j, db[j - 1], r["db%d" % j])
-    pool.release(ws)
+    if not emu:
+        pool.release(ws)
 
     # ---- dense oracle cross-check of the pooled features (independent of entry_ref)
     g, _, _ = det_ref.pointnet_module(pc, ref, sd, "m", dist, K, True, None, group=(idx_np, cnt_np))

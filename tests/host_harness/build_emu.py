@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "frustum_convnet_amd", "csrc")
 OUT = os.path.join(HERE, "_build", "libfcn_emu.so")
-SOURCES = ["fcn_net.hip"]
+SOURCES = ["fcn_net.hip", "grouping.hip", "group_compact.hip", "pointnet_fwd.hip", "pointnet_bwd.hip", "loss_tail.hip", "optim.hip", "inputs.hip", "box_iou.hip"]
 CLANG = os.environ.get("FCN_HOST_CLANG", "/opt/rocm/lib/llvm/bin/clang++")
 
 

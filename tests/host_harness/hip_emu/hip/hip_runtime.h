@@ -31,6 +31,21 @@
 // `asm volatile("" : "+s"(v));` (an SGPR pin, no code) -> `;`
 #define asm
 #define volatile(...)
+// occupancy hints mean nothing on the host (`__attribute__((amdgpu_waves_per_eu(a, b)))` -> `__attribute__((unused))`)
+#define amdgpu_waves_per_eu(...) unused
+
+// dynamic LDS: one buffer per launch, sized by the launch's shared-memory argument
+#define FCN_DYN_LDS(T, name) T *name = (T *)emu::dyn_lds
+
+struct float2 { float x, y; };
+struct float3 { float x, y, z; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+inline float2 make_float2(float x, float y) { return {x, y}; }
+inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+inline int2 make_int2(int x, int y) { return {x, y}; }
+inline int4 make_int4(int x, int y, int z, int w) { return {x, y, z, w}; }
 
 struct dim3 {
     unsigned x, y, z;
@@ -42,6 +57,7 @@ enum hipError_t { hipSuccess = 0, hipErrorInvalidValue = 1 };
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 #define HIP_SYMBOL(x) x
 #define hipMemcpyFromSymbol(dst, sym, n) (memcpy((dst), &(sym), (n)), hipSuccess)
 #define hipMemcpyToSymbol(sym, src, n) (memcpy(&(sym), (src), (n)), hipSuccess)
@@ -65,10 +81,12 @@ inline Idx bidx, bdim, gdim;
 inline Group wg, waves[MAXT / 64];
 inline unsigned char slots[MAXT / 64][64][64];        // per wave, per lane: a collective's deposit (<= 64 bytes)
 inline const void *kernarg = nullptr;
+inline unsigned char *dyn_lds = nullptr;
 inline const std::function<void()> *body = nullptr;
 inline long n_switch = 0;
 
 inline void yield() { ++n_switch; swapcontext(&cur->ctx, &sched); }
+inline bool lane_live(int lane) { const int t = cur->wave * 64 + lane; return t < (int)bdim.x && !g_lanes[t].done; }
 inline void group_barrier(Group &g)
 {
     const int my = g.gen;
@@ -87,18 +105,22 @@ inline void trampoline()
     swapcontext(&cur->ctx, &sched);
 }
 template <class F>
-inline void launch(dim3 grid, dim3 block, const F &f, const void *karg)
+inline void launch(dim3 grid, dim3 block, size_t shm, const F &f, const void *karg)
 {
     const int nt = (int)(block.x * block.y * block.z);
-    if (nt > MAXT || block.y != 1 || block.z != 1 || grid.y != 1 || grid.z != 1) { fprintf(stderr, "emu: unsupported launch shape\n"); abort(); }
+    if (nt > MAXT || block.y != 1 || block.z != 1) { fprintf(stderr, "emu: unsupported launch shape\n"); abort(); }
     if (!g_stacks) g_stacks = (char *)malloc(STACK * MAXT);
+    std::vector<unsigned char> dyn(shm + 64);
+    dyn_lds = (unsigned char *)(((uintptr_t)dyn.data() + 63) & ~(uintptr_t)63);
     const std::function<void()> fn = f;
     body = &fn;
     kernarg = karg;
     bdim = {block.x, 1, 1};
-    gdim = {grid.x, 1, 1};
+    gdim = {grid.x, grid.y, grid.z};
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
     for (unsigned b = 0; b < grid.x; ++b) {
-        bidx = {b, 0, 0};
+        bidx = {b, by, bz};
         wg = Group();
         wg.alive = nt;
         for (int w = 0; w < (nt + 63) / 64; ++w) { waves[w] = Group(); waves[w].alive = std::min(64, nt - 64 * w); }
@@ -127,6 +149,7 @@ inline void launch(dim3 grid, dim3 block, const F &f, const void *karg)
     }
     cur = nullptr;
     body = nullptr;
+    dyn_lds = nullptr;
 }
 template <class T, class... R>
 inline const void *first_arg(const T &a, const R &...) { return &a; }
@@ -186,6 +209,27 @@ inline T shfl_xor(T v, int mask)
     done();
     return r;
 }
+template <class T>
+inline T shfl_from(T v, int src_lane)          // src_lane differs per lane (computed by the caller)
+{
+    static_assert(sizeof(T) <= 64, "deposit slot");
+    deposit(&v, sizeof(v));
+    T r;
+    memcpy(&r, peer(src_lane & 63), sizeof(T));
+    done();
+    return r;
+}
+inline unsigned long long ballot(bool p)
+{
+    // exited lanes contribute 0 (their slots are cleared when they leave, see trampoline)
+    unsigned char b = p ? 1 : 0;
+    deposit(&b, 1);
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l)
+        if (lane_live(l) && *(const unsigned char *)peer(l)) m |= 1ull << l;
+    done();
+    return m;
+}
 inline const char __attribute__((address_space(4))) *kernarg_ptr()
 {
     return (const char __attribute__((address_space(4))) *)(uintptr_t)kernarg;
@@ -197,11 +241,26 @@ inline const char __attribute__((address_space(4))) *kernarg_ptr()
 #define blockDim (emu::bdim)
 #define gridDim (emu::gdim)
 #define hipLaunchKernelGGL(kern, grid, block, shm, stream, ...) \
-    emu::launch((grid), (block), [&]() { kern(__VA_ARGS__); }, emu::first_arg(__VA_ARGS__))
+    emu::launch((grid), (block), (size_t)(shm), [&]() { kern(__VA_ARGS__); }, emu::first_arg(__VA_ARGS__))
 
 inline void __syncthreads() { emu::group_barrier(emu::wg); }
+inline void __threadfence() {}
+inline void __threadfence_block() {}
 template <class T>
 inline T __shfl_xor(T v, int mask, int = 64) { return emu::shfl_xor(v, mask); }
+template <class T>
+inline T __shfl_up(T v, unsigned delta, int = 64) { const int l = emu::cur->lane; return emu::shfl_from(v, l >= (int)delta ? l - (int)delta : l); }
+template <class T>
+inline T __shfl_down(T v, unsigned delta, int = 64) { const int l = emu::cur->lane; return emu::shfl_from(v, l + (int)delta < 64 ? l + (int)delta : l); }
+template <class T>
+inline T __shfl(T v, int src, int = 64) { return emu::shfl_from(v, src); }
+inline unsigned long long __ballot(int p) { return emu::ballot(p != 0); }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline long long clock64() { return 0; }
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __hip_atomic_load(p, order, scope) (*(p))
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 // wave-synchronous LDS exchange: on the GPU the 64 lanes execute in lockstep and this builtin only pins the compiler's
@@ -216,6 +275,7 @@ template <class T>
 inline T emu_fetch_add(T *p, T v) { const T o = *p; *p = o + v; return o; }
 #define __hip_atomic_fetch_add(p, v, order, scope) emu_fetch_add((p), (v))
 inline unsigned atomicAdd(unsigned *p, unsigned v) { return emu_fetch_add(p, v); }
+inline int atomicAdd(int *p, int v) { return emu_fetch_add(p, v); }
 inline float atomicAdd(float *p, float v) { return emu_fetch_add(p, v); }
 inline unsigned long long wall_clock64() { return 0ull; }
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
