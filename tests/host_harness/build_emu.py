@@ -1,25 +1,63 @@
-"""TEST INFRASTRUCTURE ONLY.  Compiles kernel sources of frustum_convnet_amd/csrc UNMODIFIED for the host against the HIP
-stand-in of tests/host_harness/hip_emu (clang++ -x c++): python tests/host_harness/build_emu.py -> _build/libfcn_emu.so.
-Used by tests/test_emu_fcn.py to run the FCN kernels' exact index arithmetic / LDS choreography on the CPU against the oracle."""
+"""TEST INFRASTRUCTURE ONLY.  Compiles the kernel sources of frustum_convnet_amd/csrc for the HOST against the HIP stand-in of
+tests/host_harness/hip_emu (clang++ -x c++): python tests/host_harness/build_emu.py -> _build/libfcn_emu.so with the
+library's whole C-ABI.  tests/test_emu_*.py run the kernels' exact index arithmetic / LDS choreography / reductions on the CPU
+against the oracles with it.
+
+The sources are compiled from a copy under _build/src with TWO mechanical substitutions (PATCHES below), both about things a
+sequential host execution cannot express and neither touching arithmetic:
+  * `extern __shared__ ... T name[];` (dynamic LDS) -> a pointer to the per-launch buffer of the emulation;
+  * the barrier-free K loop of the FCN forward hands LDS data between the lanes of ONE wave, which is ordered by the
+    hardware's lockstep execution: the emulation runs lanes as coroutines and needs an explicit wave-level rendezvous there
+    (`__builtin_amdgcn_wave_barrier()`, which the stand-in maps to one).
+A source that already spells these out (FCN_DYN_LDS, wave barriers in place) is left as it is."""
 import os
+import re
+import shutil
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "frustum_convnet_amd", "csrc")
-OUT = os.path.join(HERE, "_build", "libfcn_emu.so")
-SOURCES = ["fcn_net.hip", "grouping.hip", "group_compact.hip", "pointnet_fwd.hip", "pointnet_bwd.hip", "loss_tail.hip", "optim.hip", "inputs.hip", "box_iou.hip"]
+BUILD = os.path.join(HERE, "_build")
+OUT = os.path.join(BUILD, "libfcn_emu.so")
+SOURCES = ["fcn_net.hip", "grouping.hip", "group_compact.hip", "pointnet_fwd.hip", "pointnet_bwd.hip", "loss_tail.hip",
+           "optim.hip", "inputs.hip", "box_iou.hip"]
 CLANG = os.environ.get("FCN_HOST_CLANG", "/opt/rocm/lib/llvm/bin/clang++")
+
+PATCHES = [
+    (re.compile(r"extern\s+__shared__\s+__attribute__\(\(aligned\(16\)\)\)\s+([A-Za-z_ ]+?)\s+(\w+)\[\];"),
+     r"\1 *\2 = (\1 *)emu::dyn_lds;"),
+    (re.compile(r"if constexpr \(TG != 64\) __syncthreads\(\);(\s*\\)"),
+     r"if constexpr (TG != 64) __syncthreads(); else __builtin_amdgcn_wave_barrier();\1"),
+]
+
+
+def _stage_sources():
+    dst = os.path.join(BUILD, "src", "frustum_convnet_amd", "csrc")
+    inc = os.path.join(BUILD, "src", "include")
+    os.makedirs(dst, exist_ok=True)
+    os.makedirs(inc, exist_ok=True)
+    shutil.copy(os.path.join(ROOT, "include", "fcn_hip.h"), inc)
+    for f in os.listdir(CSRC):
+        if not f.endswith((".hip", ".h")):
+            continue
+        text = open(os.path.join(CSRC, f)).read()
+        for pat, rep in PATCHES:
+            text = pat.sub(rep, text)
+        with open(os.path.join(dst, f), "w") as fh:
+            fh.write(text)
+    return dst
 
 
 def build(force=False, extra=()):
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "hip_emu", "hip", "hip_runtime.h"), __file__]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "hip_emu", "hip", "hip_runtime.h"), __file__,
+                                                                os.path.join(ROOT, "include", "fcn_hip.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    src = _stage_sources()
     cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-g0", "-mf16c", "-fPIC", "-shared", "-ffp-contract=off", "-w",
-           "-I", os.path.join(HERE, "hip_emu")] + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+           "-I", os.path.join(HERE, "hip_emu")] + list(extra) + [os.path.join(src, s) for s in SOURCES] + ["-o", OUT]
     subprocess.check_call(cmd)
     return OUT
 
