@@ -17,3 +17,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _emulate_gpu_tests(request):
+    """FCN_EMULATE=1: run the -m gpu tests on the CPU against the host emulation of the kernels (tests/emu_shim.py) -- a
+    development aid (`FCN_EMULATE=1 python -m pytest tests -m gpu -k ...` before spending GPU minutes); the driver's GPU run
+    never sets it."""
+    if os.environ.get("FCN_EMULATE", "0") == "1" and request.node.get_closest_marker("gpu") is not None:
+        from emu_shim import emulated_gpu
+        with emulated_gpu():
+            yield
+    else:
+        yield

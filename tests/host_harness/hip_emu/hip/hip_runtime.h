@@ -9,6 +9,7 @@
 // from the operand registers the 64 lanes deposit, with the gfx950 operand layouts (lane l: row/column l % 32, reduction
 // index block l / 32).  Wave-uniform helpers (readfirstlane, SGPR pins) are the identity.
 #pragma once
+#include <setjmp.h>
 #include <ucontext.h>
 
 #include <algorithm>
@@ -66,10 +67,13 @@ namespace emu {
 struct Idx { unsigned x, y, z; };
 struct Group { int arrived = 0, gen = 0, alive = 0; };
 struct Lane {
-    ucontext_t ctx;
+    ucontext_t ctx;       // first entry only; later switches go through jb (no signal-mask system call per switch)
+    jmp_buf jb;
     Idx tidx;
     int lane, wave;
-    bool done;
+    bool done, started;
+    const Group *wait_g;  // blocked in a rendezvous of this group since generation wait_gen (the scheduler skips it until that can change)
+    int wait_gen;
 };
 constexpr int MAXT = 1024;
 constexpr size_t STACK = 512 * 1024;
@@ -77,6 +81,7 @@ inline Lane g_lanes[MAXT];
 inline char *g_stacks = nullptr;
 inline Lane *cur = nullptr;
 inline ucontext_t sched;
+inline jmp_buf sched_jb;
 inline Idx bidx, bdim, gdim;
 inline Group wg, waves[MAXT / 64];
 inline unsigned char slots[MAXT / 64][64][64];        // per wave, per lane: a collective's deposit (<= 64 bytes)
@@ -85,16 +90,19 @@ inline unsigned char *dyn_lds = nullptr;
 inline const std::function<void()> *body = nullptr;
 inline long n_switch = 0;
 
-inline void yield() { ++n_switch; swapcontext(&cur->ctx, &sched); }
+inline void yield() { ++n_switch; if (!_setjmp(cur->jb)) _longjmp(sched_jb, 1); }
 inline bool lane_live(int lane) { const int t = cur->wave * 64 + lane; return t < (int)bdim.x && !g_lanes[t].done; }
 inline void group_barrier(Group &g)
 {
     const int my = g.gen;
     g.arrived++;
+    cur->wait_g = &g;
+    cur->wait_gen = my;
     while (g.gen == my) {
         if (g.arrived >= g.alive) { g.arrived = 0; g.gen++; break; }
         yield();
     }
+    cur->wait_g = nullptr;
 }
 inline void trampoline()
 {
@@ -102,7 +110,7 @@ inline void trampoline()
     cur->done = true;
     wg.alive--;
     waves[cur->wave].alive--;
-    swapcontext(&cur->ctx, &sched);
+    _longjmp(sched_jb, 1);
 }
 template <class F>
 inline void launch(dim3 grid, dim3 block, size_t shm, const F &f, const void *karg)
@@ -130,6 +138,8 @@ inline void launch(dim3 grid, dim3 block, size_t shm, const F &f, const void *ka
             L.lane = t & 63;
             L.wave = t >> 6;
             L.done = false;
+            L.started = false;
+            L.wait_g = nullptr;
             getcontext(&L.ctx);
             L.ctx.uc_stack.ss_sp = g_stacks + STACK * t;
             L.ctx.uc_stack.ss_size = STACK;
@@ -139,11 +149,24 @@ inline void launch(dim3 grid, dim3 block, size_t shm, const F &f, const void *ka
         int live = nt;
         while (live > 0) {
             live = 0;
+            int ran = 0;
             for (int t = 0; t < nt; ++t) {
                 if (g_lanes[t].done) continue;
                 cur = &g_lanes[t];
-                swapcontext(&sched, &cur->ctx);
+                if (cur->wait_g && cur->wait_g->gen == cur->wait_gen && cur->wait_g->arrived < cur->wait_g->alive) { ++live; continue; }
+                ++ran;
+                if (!_setjmp(sched_jb)) {
+                    if (cur->started) _longjmp(cur->jb, 1);
+                    cur->started = true;
+                    swapcontext(&sched, &cur->ctx);
+                }
                 if (!g_lanes[t].done) ++live;
+            }
+            if (live > 0 && ran == 0) {       // every live thread waits for threads that will never arrive
+                fprintf(stderr, "emu: deadlock in workgroup (%u,%u,%u): %d threads blocked in a barrier / wave collective that the "
+                                "others never reach (divergent __syncthreads, or a collective under lane-divergent control flow)\n",
+                        bidx.x, bidx.y, bidx.z, live);
+                abort();
             }
         }
     }

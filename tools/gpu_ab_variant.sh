@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B of a tuning build against the product library on ONE box: parity subset with the variant, then alternating bench
-# runs and the phase anatomy of both.  VARIANT names frustum_convnet_amd/libfcn_hip_<VARIANT>.so (tools/build_variant.py).
+# A/B of a tuning build against the product library on ONE box: parity subset with the variant (TESTS, KEXPR), then alternating
+# bench runs and the phase anatomy of both.  VARIANT names frustum_convnet_amd/libfcn_hip_<VARIANT>.so (tools/build_variant.py).
 mkdir -p gpurun_out; O=gpurun_out; V=${VARIANT:-wg}; export TMPDIR=/tmp
 echo "== parity subset with $V"
-FCN_LIB_NAME=libfcn_hip_$V.so timeout 150 python -m pytest tests/test_gpu_model.py -x -q -k "train_eval_parity or fused_convnet or gradients_vs" > $O/ab_${V}_pytest.txt 2>&1; echo "rc=$?"; tail -3 $O/ab_${V}_pytest.txt
+FCN_LIB_NAME=libfcn_hip_$V.so timeout 150 python -m pytest ${TESTS:-tests/test_gpu_model.py} -x -q ${KEXPR:+-k "$KEXPR"} > $O/ab_${V}_pytest.txt 2>&1; echo "rc=$?"; tail -3 $O/ab_${V}_pytest.txt
 for i in 1 2; do
   for lib in prod $V; do
     if [ $lib = prod ]; then unset FCN_LIB_NAME; else export FCN_LIB_NAME=libfcn_hip_$lib.so; fi
