@@ -361,18 +361,35 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
         last_s = (ticket == (int)gridDim.x - 1) ? 1 : 0;
     }
     __syncthreads();
-    if (last_s && tid == 0) {
+    // The last workgroup sums the partials.  With the scratch buffer: IN WORKGROUP ORDER (reproducible scalars), but not by
+    // one thread walking gridDim.x x 10 dependent loads (35 memory round trips on the critical path): thread g fetches the
+    // ten partials of workgroups g, g + T, ... (independent loads, summed in that fixed order), then thread 0 adds the
+    // per-thread sums in thread order from LDS.
+    if (last_s && a.scratch) {
         __threadfence();
+        float pt_[11];
+#pragma unroll
+        for (int i = 1; i < 11; ++i) pt_[i] = 0.f;
+        for (int g = tid; g < (int)gridDim.x; g += LT_THREADS)
+#pragma unroll
+            for (int i = 1; i < 11; ++i)
+                pt_[i] += __hip_atomic_load(&a.scratch[32 + 16 * g + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 1; i < 11; ++i) gG[tid * 11 + i] = pt_[i];        // (gG is free: the gradient rows have left)
+    }
+    __syncthreads();
+    if (last_s && tid == 0) {
         float t[11];
         if (a.scratch) {
 #pragma unroll
             for (int i = 1; i < 11; ++i) t[i] = 0.f;
-            for (int g = 0; g < (int)gridDim.x; ++g)
+            const int nth = min((int)gridDim.x, LT_THREADS);
+            for (int g = 0; g < nth; ++g)
 #pragma unroll
-                for (int i = 1; i < 11; ++i)
-                    t[i] += __hip_atomic_load(&a.scratch[32 + 16 * g + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int i = 1; i < 11; ++i) t[i] += gG[g * 11 + i];
             ((int *)a.scratch)[0] = 0;          // ready for the next launch
         } else {
+            __threadfence();
 #pragma unroll
             for (int i = 1; i < 11; ++i) t[i] = __hip_atomic_load(&a.out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }

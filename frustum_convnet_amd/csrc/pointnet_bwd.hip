@@ -595,36 +595,38 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
 // layer has few elements but hundreds of splits (a few independent loads per thread, group sum through LDS), a big one
 // the opposite (one thread per element).
 #define WR_T 256
+// (each thread owns FOUR consecutive elements: 16-byte loads -- a quarter of the load instructions of the dword version and
+// four times the bytes in flight per thread; 100 us of kernel time per step went through here at ~1.6 TB/s)
 __global__ __launch_bounds__(WR_T) void wgrad_reduce_kernel(const float *__restrict__ partial,
                                                             const int32_t *__restrict__ tiles, int nsplit, int gr,
                                                             int64_t nelem, float *__restrict__ out)
 {
-    __shared__ float sh[WR_T];
+    __shared__ __attribute__((aligned(16))) float sh[WR_T * 4];
     const int per = WR_T / gr;
     const int x = threadIdx.x % per, y = threadIdx.x / per;
-    const int64_t i = (int64_t)blockIdx.x * per + x;            // nelem is a multiple of 256
+    const int64_t i = ((int64_t)blockIdx.x * per + x) * 4;      // nelem is a multiple of 1024
     const int ntile = tiles[0];
     const int tpb = (ntile + nsplit - 1) / nsplit;
     const int nsp = tpb > 0 ? (ntile + tpb - 1) / tpb : 0;
     const float *p = partial + i;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    v4f s0 = zero4(), s1 = zero4(), s2 = zero4(), s3 = zero4();
     int sp = y;
     for (; sp + 3 * gr < nsp; sp += 4 * gr) {
-        s0 += p[(int64_t)sp * nelem];
-        s1 += p[(int64_t)(sp + gr) * nelem];
-        s2 += p[(int64_t)(sp + 2 * gr) * nelem];
-        s3 += p[(int64_t)(sp + 3 * gr) * nelem];
+        s0 += ldg4(p + (int64_t)sp * nelem);
+        s1 += ldg4(p + (int64_t)(sp + gr) * nelem);
+        s2 += ldg4(p + (int64_t)(sp + 2 * gr) * nelem);
+        s3 += ldg4(p + (int64_t)(sp + 3 * gr) * nelem);
     }
-    for (; sp < nsp; sp += gr) s0 += p[(int64_t)sp * nelem];
-    float t = (s0 + s1) + (s2 + s3);
+    for (; sp < nsp; sp += gr) s0 += ldg4(p + (int64_t)sp * nelem);
+    v4f t = (s0 + s1) + (s2 + s3);
     if (gr > 1) {
-        sh[y * per + x] = t;
+        sts4(sh + 4 * (y * per + x), t);
         __syncthreads();
         if (y != 0) return;
-        t = 0.f;
-        for (int q = 0; q < gr; ++q) t += sh[q * per + x];
+        t = zero4();
+        for (int q = 0; q < gr; ++q) t += *(const v4f *)(sh + 4 * (q * per + x));
     }
-    out[i] = t;
+    sts4(out + i, t);
 }
 
 // dW1, dgamma1, dbeta1 from Q = sum_e dz1 (1, u) and the forward's weighted moments of u.
@@ -640,10 +642,11 @@ __global__ void l1_finalize_kernel(const double *__restrict__ Q, const double *_
     const double mean = bn1[2 * C + c], rstd = bn1[3 * C + c];
     const double db = q0;
     const double dg = rstd * (w[0] * qu[0] + w[1] * qu[1] + w[2] * qu[2] - mean * q0);
-    const double mu[3] = {mom[1] / M, mom[2] / M, mom[3] / M};
-    const double m2[3][3] = {{mom[4] / M, mom[5] / M, mom[6] / M},
-                             {mom[5] / M, mom[7] / M, mom[8] / M},
-                             {mom[6] / M, mom[8] / M, mom[9] / M}};
+    const double iM = 1.0 / M;          // (one fp64 division instead of twelve: the last launch of the scale's backward chain)
+    const double mu[3] = {mom[1] * iM, mom[2] * iM, mom[3] * iM};
+    const double m2[3][3] = {{mom[4] * iM, mom[5] * iM, mom[6] * iM},
+                             {mom[5] * iM, mom[7] * iM, mom[8] * iM},
+                             {mom[6] * iM, mom[8] * iM, mom[9] * iM}};
     const double kk = (double)gamma[c] * rstd;
     for (int j = 0; j < 3; ++j) {
         const double wm2 = w[0] * m2[0][j] + w[1] * m2[1][j] + w[2] * m2[2][j];
@@ -706,8 +709,9 @@ static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, int precision, hipS
     FCN_MM_SWITCH(FCN_MM_OF(precision, false), (launch_wgrad_mm<MM, LAYER>(a, grid, m2, n2, st)));
     FCN_CHECK_LAUNCH();
     const int64_t ne = (int64_t)a.COUT * a.CIN;
+    if (((uintptr_t)out & 15) != 0) return FCN_E_BADARG;        // the reduce writes 16-byte vectors (include/fcn_hip.h)
     const int gr = nsplit >= 128 ? 16 : (nsplit >= 64 ? 8 : (nsplit >= 32 ? 4 : (nsplit >= 16 ? 2 : 1)));
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(ne / (WR_T / gr))), dim3(WR_T), 0, st, a.partial, a.tiles,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(ne / (4 * (WR_T / gr)))), dim3(WR_T), 0, st, a.partial, a.tiles,
                        nsplit, gr, ne, out);
     FCN_CHECK_LAUNCH();
     return 0;
