@@ -1,5 +1,5 @@
 """The fast part of the -m gpu suite, run on the CPU: the SAME test functions (grouping, rotated-box kernels, input
-construction, the fused front, and the whole model against the golden vectors of the reference for two configurations) with
+construction, the fused front, and the whole model against the golden vectors of the reference for two configurations, every parameter gradient against the fp64 oracle) with
 the package's GPU-only Python layer pointed at the host emulation of the kernels (tests/emu_shim.py + tests/host_harness).
 The hardware run of these tests stays the parity gate; this tier catches index / layout / reduction mistakes -- in the kernels
 and in the host code that drives them -- without a GPU.  (FCN_EMULATE=1 python -m pytest tests -m gpu -k ... runs any other
@@ -40,6 +40,7 @@ CASES = [
     ("test_gpu_group_compact", "test_group_compact_matches_oracle_and_unfused", (4, 512, (0.25, 0.5, 1.0, 2.0), "car")),
     ("test_gpu_model", "test_train_eval_parity", ("refine_b4_n512",)),
     ("test_gpu_model", "test_train_eval_parity", ("people_b2_n512",)),
+    ("test_gpu_model", "test_gradients_vs_fp64_oracle", ()),
 ]
 
 
