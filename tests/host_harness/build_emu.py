@@ -56,7 +56,7 @@ def build(force=False, extra=()):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT
     src = _stage_sources()
-    cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-g0", "-mf16c", "-fPIC", "-shared", "-ffp-contract=off", "-w",
+    cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-g0", "-mf16c", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-w",
            "-I", os.path.join(HERE, "hip_emu")] + list(extra) + [os.path.join(src, s) for s in SOURCES] + ["-o", OUT]
     subprocess.check_call(cmd)
     return OUT

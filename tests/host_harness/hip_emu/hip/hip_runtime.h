@@ -19,7 +19,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -27,7 +31,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline
-#define __shared__ static
+#define __shared__ static thread_local      // one workgroup per host thread at a time
 #define __launch_bounds__(...)
 // `asm volatile("" : "+s"(v));` (an SGPR pin, no code) -> `;`
 #define asm
@@ -77,20 +81,27 @@ struct Lane {
 };
 constexpr int MAXT = 1024;
 constexpr size_t STACK = 512 * 1024;
-inline Lane g_lanes[MAXT];
-inline char *g_stacks = nullptr;
-inline Lane *cur = nullptr;
-inline ucontext_t sched;
-inline jmp_buf sched_jb;
-inline Idx bidx, bdim, gdim;
-inline Group wg, waves[MAXT / 64];
-inline unsigned char slots[MAXT / 64][64][64];        // per wave, per lane: a collective's deposit (<= 64 bytes)
+// per OS thread (a worker runs one workgroup at a time): the workgroup's coroutines and rendezvous state
+inline thread_local Lane *g_lanes = nullptr;
+inline thread_local char *g_stacks = nullptr;
+inline thread_local Lane *cur = nullptr;
+inline thread_local ucontext_t sched;
+inline thread_local jmp_buf sched_jb;
+inline thread_local Idx bidx;
+inline thread_local Group wg, waves[MAXT / 64];
+inline thread_local unsigned char (*slots)[64][64] = nullptr;   // per wave, per lane: a collective's deposit (<= 64 bytes)
+inline thread_local unsigned char *dyn_lds = nullptr;
+inline thread_local std::vector<unsigned char> *dyn_buf = nullptr;
+// per launch, shared by the workers (read-only while it runs)
+inline Idx bdim, gdim;
 inline const void *kernarg = nullptr;
-inline unsigned char *dyn_lds = nullptr;
 inline const std::function<void()> *body = nullptr;
-inline long n_switch = 0;
+inline size_t job_shm = 0;
+inline int job_nt = 0;
+inline std::atomic<long> job_next{0};
+inline long job_total = 0;
 
-inline void yield() { ++n_switch; if (!_setjmp(cur->jb)) _longjmp(sched_jb, 1); }
+inline void yield() { if (!_setjmp(cur->jb)) _longjmp(sched_jb, 1); }
 inline bool lane_live(int lane) { const int t = cur->wave * 64 + lane; return t < (int)bdim.x && !g_lanes[t].done; }
 inline void group_barrier(Group &g)
 {
@@ -112,67 +123,141 @@ inline void trampoline()
     waves[cur->wave].alive--;
     _longjmp(sched_jb, 1);
 }
+// one workgroup, start to end, on the calling OS thread
+inline void run_workgroup(long id)
+{
+    const int nt = job_nt;
+    if (!g_stacks) {
+        g_stacks = (char *)malloc(STACK * MAXT);
+        g_lanes = new Lane[MAXT];
+        slots = (unsigned char (*)[64][64])malloc(sizeof(unsigned char) * (MAXT / 64) * 64 * 64);
+        dyn_buf = new std::vector<unsigned char>();
+    }
+    if (dyn_buf->size() < job_shm + 64) dyn_buf->resize(job_shm + 64);
+    dyn_lds = (unsigned char *)(((uintptr_t)dyn_buf->data() + 63) & ~(uintptr_t)63);
+    const long gxy = (long)gdim.x * gdim.y;
+    bidx = {(unsigned)(id % gdim.x), (unsigned)((id % gxy) / gdim.x), (unsigned)(id / gxy)};
+    wg = Group();
+    wg.alive = nt;
+    for (int w = 0; w < (nt + 63) / 64; ++w) { waves[w] = Group(); waves[w].alive = std::min(64, nt - 64 * w); }
+    for (int t = 0; t < nt; ++t) {
+        Lane &L = g_lanes[t];
+        L.tidx = {(unsigned)t, 0, 0};
+        L.lane = t & 63;
+        L.wave = t >> 6;
+        L.done = false;
+        L.started = false;
+        L.wait_g = nullptr;
+        getcontext(&L.ctx);
+        L.ctx.uc_stack.ss_sp = g_stacks + STACK * t;
+        L.ctx.uc_stack.ss_size = STACK;
+        L.ctx.uc_link = &sched;
+        makecontext(&L.ctx, (void (*)())trampoline, 0);
+    }
+    int live = nt;
+    while (live > 0) {
+        live = 0;
+        int ran = 0;
+        for (int t = 0; t < nt; ++t) {
+            if (g_lanes[t].done) continue;
+            cur = &g_lanes[t];
+            if (cur->wait_g && cur->wait_g->gen == cur->wait_gen && cur->wait_g->arrived < cur->wait_g->alive) { ++live; continue; }
+            ++ran;
+            if (!_setjmp(sched_jb)) {
+                if (cur->started) _longjmp(cur->jb, 1);
+                cur->started = true;
+                swapcontext(&sched, &cur->ctx);
+            }
+            if (!g_lanes[t].done) ++live;
+        }
+        if (live > 0 && ran == 0) {       // every live thread waits for threads that will never arrive
+            fprintf(stderr, "emu: deadlock in workgroup (%u,%u,%u): %d threads blocked in a barrier / wave collective that the "
+                            "others never reach (divergent __syncthreads, or a collective under lane-divergent control flow)\n",
+                    bidx.x, bidx.y, bidx.z, live);
+            abort();
+        }
+    }
+    cur = nullptr;
+}
+inline void drain_job()
+{
+    for (;;) {
+        const long id = job_next.fetch_add(1);
+        if (id >= job_total) break;
+        run_workgroup(id);
+    }
+}
+// Persistent workers (FCN_EMU_THREADS, default min(8, cores)): the workgroups of a launch are independent except for atomics
+// (real ones here) and "last workgroup" tickets, so they run on several host cores; a launch returns when all are done.
+struct Pool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    long gen = 0;
+    int busy = 0;
+    bool stop = false;
+    int n = 1;
+    Pool()
+    {
+        const char *e = getenv("FCN_EMU_THREADS");
+        n = e ? atoi(e) : (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+        if (n < 1) n = 1;
+        for (int i = 1; i < n; ++i)
+            th.emplace_back([this] {
+                long seen = 0;
+                for (;;) {
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv_go.wait(lk, [&] { return stop || gen != seen; });
+                        if (stop) return;
+                        seen = gen;
+                    }
+                    drain_job();
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (--busy == 0) cv_done.notify_all();
+                    }
+                }
+            });
+    }
+    ~Pool()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv_go.notify_all();
+        for (auto &t : th) t.join();
+    }
+    void run()
+    {
+        if (n == 1 || job_total < 4) { drain_job(); return; }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            busy = n - 1;
+            ++gen;
+        }
+        cv_go.notify_all();
+        drain_job();
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return busy == 0; });
+    }
+};
+inline Pool &pool() { static Pool p; return p; }
+
 template <class F>
 inline void launch(dim3 grid, dim3 block, size_t shm, const F &f, const void *karg)
 {
     const int nt = (int)(block.x * block.y * block.z);
     if (nt > MAXT || block.y != 1 || block.z != 1) { fprintf(stderr, "emu: unsupported launch shape\n"); abort(); }
-    if (!g_stacks) g_stacks = (char *)malloc(STACK * MAXT);
-    std::vector<unsigned char> dyn(shm + 64);
-    dyn_lds = (unsigned char *)(((uintptr_t)dyn.data() + 63) & ~(uintptr_t)63);
     const std::function<void()> fn = f;
     body = &fn;
     kernarg = karg;
     bdim = {block.x, 1, 1};
     gdim = {grid.x, grid.y, grid.z};
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-    for (unsigned by = 0; by < grid.y; ++by)
-    for (unsigned b = 0; b < grid.x; ++b) {
-        bidx = {b, by, bz};
-        wg = Group();
-        wg.alive = nt;
-        for (int w = 0; w < (nt + 63) / 64; ++w) { waves[w] = Group(); waves[w].alive = std::min(64, nt - 64 * w); }
-        for (int t = 0; t < nt; ++t) {
-            Lane &L = g_lanes[t];
-            L.tidx = {(unsigned)t, 0, 0};
-            L.lane = t & 63;
-            L.wave = t >> 6;
-            L.done = false;
-            L.started = false;
-            L.wait_g = nullptr;
-            getcontext(&L.ctx);
-            L.ctx.uc_stack.ss_sp = g_stacks + STACK * t;
-            L.ctx.uc_stack.ss_size = STACK;
-            L.ctx.uc_link = &sched;
-            makecontext(&L.ctx, (void (*)())trampoline, 0);
-        }
-        int live = nt;
-        while (live > 0) {
-            live = 0;
-            int ran = 0;
-            for (int t = 0; t < nt; ++t) {
-                if (g_lanes[t].done) continue;
-                cur = &g_lanes[t];
-                if (cur->wait_g && cur->wait_g->gen == cur->wait_gen && cur->wait_g->arrived < cur->wait_g->alive) { ++live; continue; }
-                ++ran;
-                if (!_setjmp(sched_jb)) {
-                    if (cur->started) _longjmp(cur->jb, 1);
-                    cur->started = true;
-                    swapcontext(&sched, &cur->ctx);
-                }
-                if (!g_lanes[t].done) ++live;
-            }
-            if (live > 0 && ran == 0) {       // every live thread waits for threads that will never arrive
-                fprintf(stderr, "emu: deadlock in workgroup (%u,%u,%u): %d threads blocked in a barrier / wave collective that the "
-                                "others never reach (divergent __syncthreads, or a collective under lane-divergent control flow)\n",
-                        bidx.x, bidx.y, bidx.z, live);
-                abort();
-            }
-        }
-    }
-    cur = nullptr;
+    job_shm = shm;
+    job_nt = nt;
+    job_total = (long)grid.x * grid.y * grid.z;
+    job_next.store(0);
+    pool().run();
     body = nullptr;
-    dyn_lds = nullptr;
 }
 template <class T, class... R>
 inline const void *first_arg(const T &a, const R &...) { return &a; }
@@ -267,8 +352,8 @@ inline const char __attribute__((address_space(4))) *kernarg_ptr()
     emu::launch((grid), (block), (size_t)(shm), [&]() { kern(__VA_ARGS__); }, emu::first_arg(__VA_ARGS__))
 
 inline void __syncthreads() { emu::group_barrier(emu::wg); }
-inline void __threadfence() {}
-inline void __threadfence_block() {}
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 template <class T>
 inline T __shfl_xor(T v, int mask, int = 64) { return emu::shfl_xor(v, mask); }
 template <class T>
@@ -282,8 +367,12 @@ inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline long long clock64() { return 0; }
-#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
-#define __hip_atomic_load(p, order, scope) (*(p))
+template <class T, class V>
+inline void emu_atomic_store(T *p, V v) { T t = (T)v; __atomic_store(p, &t, __ATOMIC_SEQ_CST); }
+template <class T>
+inline T emu_atomic_load(const T *p) { T t; __atomic_load(const_cast<T *>(p), &t, __ATOMIC_SEQ_CST); return t; }
+#define __hip_atomic_store(p, v, order, scope) emu_atomic_store((p), (v))
+#define __hip_atomic_load(p, order, scope) emu_atomic_load((p))
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 // wave-synchronous LDS exchange: on the GPU the 64 lanes execute in lockstep and this builtin only pins the compiler's
@@ -295,7 +384,24 @@ inline long long clock64() { return 0; }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu::mfma_32x32x2_f32((a), (b), (c))
 #define __HIP_MEMORY_SCOPE_AGENT 0
 template <class T>
-inline T emu_fetch_add(T *p, T v) { const T o = *p; *p = o + v; return o; }
+inline T emu_fetch_add(T *p, T v)          // real atomics: workgroups run on several host threads
+{
+    if constexpr (std::is_integral<T>::value) {
+        return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST);
+    } else {
+        typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type U;
+        U *q = (U *)p;
+        U o = __atomic_load_n(q, __ATOMIC_SEQ_CST);
+        for (;;) {
+            T ov;
+            memcpy(&ov, &o, sizeof(T));
+            const T nv = ov + v;
+            U n;
+            memcpy(&n, &nv, sizeof(T));
+            if (__atomic_compare_exchange_n(q, &o, n, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) return ov;
+        }
+    }
+}
 #define __hip_atomic_fetch_add(p, v, order, scope) emu_fetch_add((p), (v))
 inline unsigned atomicAdd(unsigned *p, unsigned v) { return emu_fetch_add(p, v); }
 inline int atomicAdd(int *p, int v) { return emu_fetch_add(p, v); }

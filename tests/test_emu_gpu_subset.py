@@ -1,9 +1,12 @@
-"""The fast part of the -m gpu suite, run on the CPU: the SAME test functions (grouping, rotated-box kernels, input
-construction, the fused front, and the whole model against the golden vectors of the reference for two configurations, every parameter gradient against the fp64 oracle) with
+"""Most of the -m gpu suite, run on the CPU: the SAME test functions (grouping, rotated-box kernels and IoU metrics, input
+construction, the fused front, every stage of a PointNet scale, the fused FCN against the module path, and the whole model
+against the golden vectors of the reference for the car, people, refine and SUN-RGBD configurations -- train + eval logits,
+losses, gradient norms, running statistics --, every parameter gradient against the fp64 oracle, decode + NMS pipeline) with
 the package's GPU-only Python layer pointed at the host emulation of the kernels (tests/emu_shim.py + tests/host_harness).
 The hardware run of these tests stays the parity gate; this tier catches index / layout / reduction mistakes -- in the kernels
 and in the host code that drives them -- without a GPU.  (FCN_EMULATE=1 python -m pytest tests -m gpu -k ... runs any other
-GPU test the same way; whole-model cases take about a minute each, hipGraph tests cannot be emulated.)"""
+GPU test the same way.  Not here: the B=32 full-size cases (minutes), hipGraph capture / replay and RCCL (cannot be emulated),
+and the tests that assert the package REFUSES CPU tensors -- inside the shim it cannot tell.)"""
 import importlib
 import os
 import shutil
@@ -21,30 +24,68 @@ CASES = [
     ("test_gpu_grouping", "test_golden_sha", ("car_b32_n1024",)),
     ("test_gpu_grouping", "test_golden_sha", ("people_b2_n512",)),
     ("test_gpu_grouping", "test_ragged_shapes", (1, 1, 1, 1, 0.5)),
+    ("test_gpu_grouping", "test_ragged_shapes", (2, 63, 5, 7, 0.3)),
     ("test_gpu_grouping", "test_ragged_shapes", (2, 65, 17, 64, 0.3)),
     ("test_gpu_grouping", "test_ragged_shapes", (3, 1000, 33, 200, 0.05)),
     ("test_gpu_grouping", "test_ragged_shapes", (1, 20000, 9, 16, 0.01)),
+    ("test_gpu_grouping", "test_ragged_shapes", (2, 300, 70, 1, 1.0)),
     ("test_gpu_grouping", "test_boundary_is_strict_and_fp32", ()),
     ("test_gpu_grouping", "test_kernel_native_layout_matches", ()),
     ("test_gpu_box", "test_iou_pair_matches_golden", ()),
     ("test_gpu_box", "test_rotate_nms_matches_reference_keep_lists", ()),
     ("test_gpu_box", "test_decode_matches_oracle", (3, 64)),
     ("test_gpu_box", "test_decode_matches_oracle", (10, 128)),
+    ("test_gpu_box", "test_loss_tail_iou_metrics_match_oracle", ("car_b4_n512",)),
+    ("test_gpu_box", "test_loss_tail_iou_metrics_match_oracle", ("people_b2_n512",)),
+    ("test_gpu_box", "test_loss_tail_iou_metrics_match_oracle", ("sunrgbd_b4_n1024",)),
+    ("test_gpu_box", "test_all_background_batch_is_finite", ()),
+    ("test_gpu_box", "test_detect_pipeline_matches_oracle", ()),
+    ("test_gpu_box", "test_backward_split_equals_backward", ()),
     ("test_gpu_inputs", "test_golden_batch_with_recorded_draws", ()),
     ("test_gpu_inputs", "test_same_numpy_seed_reproduces_the_reference_batch", ()),
+    ("test_gpu_inputs", "test_against_oracle_without_augmentation_and_nearest_fallback", (False, False)),
     ("test_gpu_inputs", "test_against_oracle_without_augmentation_and_nearest_fallback", (True, False)),
     ("test_gpu_inputs", "test_against_oracle_without_augmentation_and_nearest_fallback", (False, True)),
+    ("test_gpu_inputs", "test_ragged_and_odd_sizes_against_oracle", (1, 100, True)),
     ("test_gpu_inputs", "test_ragged_and_odd_sizes_against_oracle", (3, 257, False)),
+    ("test_gpu_inputs", "test_ragged_and_odd_sizes_against_oracle", (6, 1024, True)),
     ("test_gpu_inputs", "test_refine_builder_matches_reference_batch", ()),
     ("test_gpu_inputs", "test_sunrgbd_builder_matches_reference_batch", ()),
+    ("test_gpu_inputs", "test_built_batch_feeds_the_model", ()),
     ("test_gpu_group_compact", "test_group_compact_matches_oracle_and_unfused", (4, 512, (0.25, 0.5, 1.0, 2.0), "car")),
-    ("test_gpu_model", "test_train_eval_parity", ("refine_b4_n512",)),
+    ("test_gpu_group_compact", "test_group_compact_matches_oracle_and_unfused", (3, 700, (0.1, 0.2, 0.4, 0.8), "uniform")),
+    ("test_gpu_group_compact", "test_group_compact_matches_oracle_and_unfused", (2, 130, (2.0, 2.0, 4.0, 8.0), "car")),
+    # (B4_N512_s0.25_K32_C128 of gpu_stage_check.CASES is left to the hardware: with the emulation's accumulation order ONE
+    # pre-ReLU activation of that draw lands on the other side of zero -- DESIGN.md section 5 on ReLU kinks)
+    ("test_gpu_pointnet", "test_stages", ((2, 128, 3.5, 16, (64, 64, 128), 1.0),)),
+    ("test_gpu_pointnet", "test_stages", ((3, 200, 2.5, 32, (64, 64, 128), 0.7),)),
+    ("test_gpu_pointnet", "test_stages", ((4, 512, 0.5, 64, (64, 64, 128), 0.5),)),
+    ("test_gpu_pointnet", "test_stages", ((4, 512, 1.0, 64, (128, 128, 256), 1.0),)),
+    ("test_gpu_pointnet", "test_stages", ((4, 512, 2.0, 128, (256, 256, 512), 2.0),)),
+    ("test_gpu_pointnet", "test_uniform_variant_full_windows", ()),
+    ("test_gpu_model", "test_train_eval_parity", ("car_b4_n512",)),
+    ("test_gpu_model", "test_train_eval_parity", ("car_b4_n512_uniform",)),
     ("test_gpu_model", "test_train_eval_parity", ("people_b2_n512",)),
+    ("test_gpu_model", "test_train_eval_parity", ("refine_b4_n512",)),
+    ("test_gpu_model", "test_train_eval_parity", ("sunrgbd_b4_n1024",)),
+    ("test_gpu_model", "test_dense_module_api_matches_oracle", ()),
+    ("test_gpu_model", "test_two_forwards_before_backward_do_not_share_workspace", ()),
+    ("test_gpu_model", "test_fused_loss_tail_matches_torch_tail", ()),
+    ("test_gpu_model", "test_fused_convnet_matches_module_path", ("car_b4_n512",)),
+    ("test_gpu_model", "test_fused_convnet_matches_module_path", ("refine_b4_n512",)),
+    ("test_gpu_model", "test_fused_convnet_matches_module_path", ("people_b2_n512",)),
     ("test_gpu_model", "test_gradients_vs_fp64_oracle", ()),
 ]
 
 
-@pytest.mark.parametrize("mod,fn,args", CASES, ids=["%s-%s" % (c[1], "_".join(str(a) for a in c[2]))[:70] for c in CASES])
+def _ident(c):
+    a = c[2]
+    if a and isinstance(a[0], tuple):
+        a = a[0]
+    return ("%s-%s" % (c[1][5:], "_".join(str(x) for x in a)))[:72].replace(" ", "")
+
+
+@pytest.mark.parametrize("mod,fn,args", CASES, ids=[_ident(c) for c in CASES])
 def test_gpu_test_under_emulation(mod, fn, args):
     from emu_shim import emulated_gpu
     m = importlib.import_module(mod)
