@@ -8,6 +8,8 @@ no device-side transposes (the reference copies both inputs to (B,N,3) on every 
 query_depth_point.py:29-30 -- the kernel here reads the contiguous z row of the (B,3,N) layout through
 explicit strides) and the outputs are fully written by the kernel (no zero-fill pass).
 Outputs are integer tensors, hence non-differentiable, as in the reference (backward returns None).
+The module also takes float64 inputs like the reference's dispatch (narrowed to fp32, which is what the reference's kernel
+does with them); the functional form asserts float32.
 """
 import torch
 from torch import nn
@@ -64,4 +66,10 @@ class QueryDepthPoint(nn.Module):
 
     def forward(self, xyz1, xyz2):
         with torch.no_grad():
-            return query_depth_point(self.dis_z, self.nsample, xyz1.detach(), xyz2.detach())
+            xyz1, xyz2 = xyz1.detach(), xyz2.detach()
+            if xyz1.dtype == torch.float64 and xyz2.dtype == torch.float64:
+                # The reference dispatches double too (query_depth_point_cuda_kernel.cu:77) but its kernel narrows both depths
+                # to float before it compares them (`float z1 = ...`, `fabsf(z2 - z1) < dis_z`, .cu:40,48): the result IS the
+                # fp32 result on the narrowed inputs, so narrowing here reproduces it exactly.
+                xyz1, xyz2 = xyz1.float(), xyz2.float()
+            return query_depth_point(self.dis_z, self.nsample, xyz1, xyz2)

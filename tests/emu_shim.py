@@ -28,6 +28,8 @@ class _CudaToCpu(TorchFunctionMode):
             kwargs["device"] = torch.device("cpu")
         if any(_is_cuda_dev(a) for a in args):
             args = tuple(torch.device("cpu") if _is_cuda_dev(a) else a for a in args)
+            if getattr(func, "__name__", "") == "to":
+                kwargs["copy"] = True         # t.to("cuda") copies on the device too
         return func(*args, **kwargs)
 
 
@@ -66,7 +68,9 @@ def emulated_gpu():
         _native.LIB_PATH, _native._lib = emu_path(), None
         _native.current_stream = lambda device=None: None
         T.is_cuda = property(lambda self: True)
-        T.cuda = lambda self, *a, **k: self
+        # a COPY, as on the device: the storage then comes from torch's allocator (which the guard-page interposer of
+        # tests/host_harness/guard watches) and no longer from numpy's
+        T.cuda = lambda self, *a, **k: self.clone()
         T.record_stream = lambda self, s: None
         C.device = _Inert
         C.Stream = _Inert

@@ -78,3 +78,18 @@ def test_kernel_native_layout_matches():
     a = query_depth_point(0.5, 64, pc, ref)
     b = query_depth_point_bn3(0.5, 64, pc.permute(0, 2, 1).contiguous(), ref.permute(0, 2, 1).contiguous())
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_double_inputs_are_narrowed_like_the_reference_kernel():
+    """The reference dispatches double (query_depth_point_cuda_kernel.cu:77) and narrows both depths to float inside
+    (.cu:40,48): the module must return what the fp32 op returns on the narrowed inputs."""
+    from frustum_convnet_amd.query_depth_point import QueryDepthPoint
+    rng = np.random.RandomState(3)
+    xyz1 = torch.from_numpy(rng.uniform(-1, 1, (2, 3, 200))).cuda()            # float64
+    xyz2 = torch.from_numpy(rng.uniform(-1, 1, (2, 3, 17))).cuda()
+    op = QueryDepthPoint(0.2, 8)
+    i64, c64 = op(xyz1, xyz2)
+    i32, c32 = op(xyz1.float(), xyz2.float())
+    assert torch.equal(i64, i32) and torch.equal(c64, c32)
+    e_idx, e_cnt = grouping.query_depth_point_numpy(0.2, 8, xyz1.float().cpu().numpy(), xyz2.float().cpu().numpy())
+    assert np.array_equal(i64.cpu().numpy(), e_idx) and np.array_equal(c64.cpu().numpy(), e_cnt)
