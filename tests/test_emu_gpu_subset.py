@@ -5,7 +5,8 @@ losses, gradient norms, running statistics --, every parameter gradient against 
 the package's GPU-only Python layer pointed at the host emulation of the kernels (tests/emu_shim.py + tests/host_harness).
 The hardware run of these tests stays the parity gate; this tier catches index / layout / reduction mistakes -- in the kernels
 and in the host code that drives them -- without a GPU.  (FCN_EMULATE=1 python -m pytest tests -m gpu -k ... runs any other
-GPU test the same way.  Not here: the B=32 full-size cases (minutes), hipGraph capture / replay and RCCL (cannot be emulated),
+GPU test the same way.  Not here: the B=32 full-size cases (minutes) and a few
+whole-model cases that add run time but no new kernel path, hipGraph capture / replay and RCCL (cannot be emulated),
 and the tests that assert the package REFUSES CPU tensors -- inside the shim it cannot tell.)"""
 import importlib
 import os
@@ -41,7 +42,6 @@ CASES = [
     ("test_gpu_box", "test_loss_tail_iou_metrics_match_oracle", ("sunrgbd_b4_n1024",)),
     ("test_gpu_box", "test_all_background_batch_is_finite", ()),
     ("test_gpu_box", "test_detect_pipeline_matches_oracle", ()),
-    ("test_gpu_box", "test_backward_split_equals_backward", ()),
     ("test_gpu_inputs", "test_golden_batch_with_recorded_draws", ()),
     ("test_gpu_inputs", "test_same_numpy_seed_reproduces_the_reference_batch", ()),
     ("test_gpu_inputs", "test_against_oracle_without_augmentation_and_nearest_fallback", (False, False)),
@@ -52,7 +52,6 @@ CASES = [
     ("test_gpu_inputs", "test_ragged_and_odd_sizes_against_oracle", (6, 1024, True)),
     ("test_gpu_inputs", "test_refine_builder_matches_reference_batch", ()),
     ("test_gpu_inputs", "test_sunrgbd_builder_matches_reference_batch", ()),
-    ("test_gpu_inputs", "test_built_batch_feeds_the_model", ()),
     ("test_gpu_group_compact", "test_group_compact_matches_oracle_and_unfused", (4, 512, (0.25, 0.5, 1.0, 2.0), "car")),
     ("test_gpu_group_compact", "test_group_compact_matches_oracle_and_unfused", (3, 700, (0.1, 0.2, 0.4, 0.8), "uniform")),
     ("test_gpu_group_compact", "test_group_compact_matches_oracle_and_unfused", (2, 130, (2.0, 2.0, 4.0, 8.0), "car")),
@@ -65,14 +64,11 @@ CASES = [
     ("test_gpu_pointnet", "test_stages", ((4, 512, 2.0, 128, (256, 256, 512), 2.0),)),
     ("test_gpu_pointnet", "test_uniform_variant_full_windows", ()),
     ("test_gpu_model", "test_train_eval_parity", ("car_b4_n512",)),
-    ("test_gpu_model", "test_train_eval_parity", ("car_b4_n512_uniform",)),
     ("test_gpu_model", "test_train_eval_parity", ("people_b2_n512",)),
     ("test_gpu_model", "test_train_eval_parity", ("refine_b4_n512",)),
     ("test_gpu_model", "test_train_eval_parity", ("sunrgbd_b4_n1024",)),
     ("test_gpu_model", "test_dense_module_api_matches_oracle", ()),
-    ("test_gpu_model", "test_two_forwards_before_backward_do_not_share_workspace", ()),
     ("test_gpu_model", "test_fused_loss_tail_matches_torch_tail", ()),
-    ("test_gpu_model", "test_fused_convnet_matches_module_path", ("car_b4_n512",)),
     ("test_gpu_model", "test_fused_convnet_matches_module_path", ("refine_b4_n512",)),
     ("test_gpu_model", "test_fused_convnet_matches_module_path", ("people_b2_n512",)),
     ("test_gpu_model", "test_gradients_vs_fp64_oracle", ()),
