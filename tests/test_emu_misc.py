@@ -37,3 +37,18 @@ def test_emulated_adam_matches_torch_adam(n):
         assert int(slots.min()) == step + 1 and int(slots.max()) == step + 1        # every workgroup advanced its counter
         err = float((p.double() - ref.detach()).abs().max())
         assert err < 2e-6, (step, err)
+
+
+def test_smoke_entry_under_emulation():
+    """__graft_entry__.smoke() (the driver's first call on the GPU box) end to end on the CPU: same code path, emulated kernels."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import __graft_entry__ as entry
+    from emu_shim import emulated_gpu
+    saved = torch.cuda.is_available
+    with emulated_gpu():
+        torch.cuda.is_available = lambda: True
+        try:
+            entry.smoke()
+        finally:
+            torch.cuda.is_available = saved
