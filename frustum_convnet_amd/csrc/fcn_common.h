@@ -7,6 +7,11 @@
 
 #define FCN_WAVE 64
 
+// dynamic LDS of a kernel (size given at launch); a macro so that the host emulation of tests/host_harness can map it
+#ifndef FCN_DYN_LDS
+#define FCN_DYN_LDS(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define FCN_CHECK_LAUNCH()                         \
@@ -35,6 +40,39 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
 
 __device__ __forceinline__ void atomic_add_f64(double *p, double v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Coefficients of a BatchNorm backward, derived by every CONSUMER workgroup from the batch sums (a few fp64 products per
+// channel) instead of by a one-workgroup launch between two layers of a latency-bound chain:
+//   dy = c0 * (dz - (c3 + xhat * c4)),  xhat = (y - c1) * c2
+//   c0 = gamma * rstd, c1 = mean, c2 = rstd, c3 = sum(dz) / M, c4 = sum(dz * xhat) / M
+// bstat: sum dz [C], sum dz * xhat [C] (final when the consumer starts); bn: scale, shift, mean, rstd [C] of the forward.
+struct FcnBnBwd {
+    const double *bstat;
+    const float *gamma, *bn;
+    double invM;
+    float *dgamma, *dbeta;     // exported by the workgroup flagged `pub` (fp32), or null
+};
+__device__ __forceinline__ void fcn_bnbwd_coef(const FcnBnBwd &q, int C, int c, float (&cf)[5], bool pub)
+{
+    const double db = q.bstat[c], dg = q.bstat[C + c];
+    const float rstd = q.bn[3 * C + c];
+    cf[0] = q.gamma[c] * rstd;
+    cf[1] = q.bn[2 * C + c];
+    cf[2] = rstd;
+    cf[3] = (float)(db * q.invM);
+    cf[4] = (float)(dg * q.invM);
+    if (pub && q.dgamma) { q.dgamma[c] = (float)dg; q.dbeta[c] = (float)db; }
+}
+
+// 1 / sqrt(x) in fp64 from the fp32 rsqrt + three Newton steps (full double accuracy for x > 0 within float range -- a
+// variance + eps): a dozen fp64 operations instead of the software sqrt + division sequences (~100 instructions)
+__device__ __forceinline__ double fcn_rsqrt64(double x)
+{
+    double y = (double)rsqrtf((float)x);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) y = y * (1.5 - 0.5 * x * y * y);
+    return y;
 }
 
 // Layout of fcn_pn_ws.stat (doubles)

@@ -329,15 +329,17 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         const int c = (it_) * G + g;                                                                                  \
         const bool act = c < nchunk;                                                                                  \
         if (act) CGK_FWD_STAGE(c, RA, RW, OK);                                                                \
-        if constexpr (TG != 64) __syncthreads();                                                                      \
+        if constexpr (TG != 64) __syncthreads(); else __builtin_amdgcn_wave_barrier();                                \
         if (c + 2 * G < nchunk) CGK_FWD_LOAD(c + 2 * G, RA, RW, OK);                                         \
         if (act) mma_chunk<MM, 1, 1, LDA, LDC>(As, Bs, wm * 32, wn * 32, acc);                                    \
-        if constexpr (TG != 64) __syncthreads();                                                                      \
+        if constexpr (TG != 64) __syncthreads(); else __builtin_amdgcn_wave_barrier();                                \
     }
     // A K-group of ONE wave (TG == 64: the 32 x 32 tile in use) owns its LDS buffers alone and the LDS serves a wave's
     // operations in order, so its write -> read -> write sequence needs no barrier: the four waves of the workgroup run
     // through their chunks independently and cover each other's load latency instead of marching in lockstep (two
     // workgroup barriers per K step before).  One barrier remains in front of the cross-group reduction below.
+    // (__builtin_amdgcn_wave_barrier emits no instruction: it keeps the COMPILER from moving one lane's LDS reads of
+    // other lanes' values above its own stores, or its next stores above those reads.)
     // The first two chunks of this K-group are requested BEFORE the prologue: they depend on neither the BatchNorm
     // statistics nor the LDS tables (their (segment, tap, channel) comes straight from cg_locate), so their trip to L2 / HBM
     // overlaps the fp64 finalisation below instead of following it -- one memory latency per layer off a 25-launch chain
@@ -595,38 +597,46 @@ struct CgBwdStep {
 };
 
 #define CGB_T 512
-#define CGB_G 4
-// dgrad: G groups x (A [KC][36] + W [KC][LDN]) + BN-backward coefficients + chunk tables
-#define CGB_ASZ (KC * 36)
-#define CGB_LDS (CGB_G * (CGB_ASZ + KC * LDN))
+#define CGB_G 8                // K-groups of a data-gradient tile: ONE wave each
+#define CGB_KH 16              // reduction chunk of a K-group (one 32x32x16 step)
+#define CGB_LDA 34             // A leading dimension: 4 * LDA = 8 (mod 32) spreads a half-wave's ds_write_b32 over all banks
+// G waves x (A [KH][LDA or LDW] + B [KH][LDN]) + BN-backward coefficients + chunk tables
+#define CGB_LDW 36             // leading dimension of the weight-gradient role's dy operand (float4 stores: rows 16-B aligned)
+#define CGB_ASZ (CGB_KH * CGB_LDW)
+#define CGB_WSZ (CGB_ASZ + CGB_KH * LDN)     // one wave's operand buffers (both roles)
+#define CGB_LDS (CGB_G * CGB_WSZ)
 #define CG_KBWD 2048           // largest reduction length of a data-gradient GEMM (block5_deconv: 8 * 256 output columns)
-#define CGB_SMEM (CGB_LDS + 5 * CG_CMAX + 3 * (CG_KBWD / KC))
+#define CGB_SMEM (CGB_LDS + 5 * CG_CMAX + 3 * (CG_KBWD / CGB_KH))
 
-// G[rs][k] = sum_tap sum_n dy[r_out(rs,tap)][n] * Wp[n][segoff + tap*C + k]; 32 source rows x 64 source channels by 4
+// G[rs][k] = sum_tap sum_n dy[r_out(rs,tap)][n] * Wp[n][segoff + tap*C + k]; 32 source rows x 64 source channels by 8
 // K-groups, then the producer-side epilogue: ReLU mask from its pre-BN output, accumulate (second consumer),
 // BN-backward sums.
+// A K-group is ONE wave: it owns its LDS operand buffers alone and the LDS serves a wave's operations in order, so the
+// write -> read -> write sequence of its K loop needs no barrier (cgk_fwd_body does the same).  The groups take 16-deep
+// chunks g, g + 8, ...: a wave stages the same number of operand values per step as a wave of the former two-wave groups
+// did with 32-deep chunks (32 x 16 of dy + 16 x 64 of W), and computes the whole 32 x 64 tile of its chunk.
 template <int MM>
 __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &cb, const float *dzc, const float *yc,
                                               int sgi, int segoff, const float *ysrc, const float *bnsrc, float *outp,
                                               int accumulate, double *bstat_src, int bx, int by, bool pub, float *smem)
 {
-    constexpr int G = CGB_G, TG = 128, TMB = 32, LDA = TMB + 1, NTHR = G * TG;
-    constexpr int NA = TMB * 8 / TG, NB = 512 / TG;
-    constexpr int ASZ = CGB_ASZ;                        // As padded so that Bs stays 16-B aligned
+    constexpr int G = CGB_G, KH = CGB_KH, TMB = 32, LDA = CGB_LDA, NTHR = G * 64;
+    constexpr int NA = TMB * (KH / 4) / 64, NB = KH * 16 / 64;      // 4-vectors of dy (2) and W (4) per lane per chunk
+    constexpr int ASZ = CGB_ASZ, NCH = CG_KBWD / KH;
+    static_assert(NTHR == CGB_T && NA == 2 && NB == 4 && (ASZ % 4) == 0 && KH * LDA <= ASZ, "dgrad lane mapping");
     float *lds = smem;
     float *coefS = smem + CGB_LDS;
-    int *cTap = (int *)(coefS + 5 * CG_CMAX), *cNb = cTap + CG_KBWD / KC, *cCh = cNb + CG_KBWD / KC;
+    int *cTap = (int *)(coefS + 5 * CG_CMAX), *cNb = cTap + NCH, *cCh = cNb + NCH;
     // sgi is workgroup-uniform: static-index selects, no dynamic struct indexing
     const int SC = SEL4(sgi, opaque_s(L.seg[0].C), opaque_s(L.seg[1].C), opaque_s(L.seg[2].C), opaque_s(L.seg[3].C));
     const int SLsrc = SEL4(sgi, opaque_s(L.seg[0].Lsrc), opaque_s(L.seg[1].Lsrc), opaque_s(L.seg[2].Lsrc), opaque_s(L.seg[3].Lsrc));
-    const int tid = threadIdx.x, g = tid / TG, gt = tid % TG;
-    const int lane = tid & 63, gw = gt >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int wm = 0, wn = gw & 1;
-    float *As = lds + g * (ASZ + KC * LDN), *Bs = As + ASZ;
+    const int tid = threadIdx.x, g = tid >> 6;
+    const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+    float *As = lds + g * CGB_WSZ, *Bs = As + ASZ;
     const int C = SC, Rs = L.B * SLsrc, Cs = L.Cs;
     const int row0 = bx * TMB, c0 = by * 64;
-    const int kq = gt & 7, rb = gt >> 3;
-    constexpr int RSTEP = TG / 8;
+    const int kq = lane & 3, rb = lane >> 2;            // dy: 4 column quads x 16 rows per pass
+    constexpr int RSTEP = 16;
     const bool hasbn = cb.bstat != nullptr;
     int bb[NA], li[NA];
     bool rv[NA], ok[NA];
@@ -642,31 +652,16 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
         rv[i] = rv[i] && li[i] < L.Lin;
         ok[i] = false;
     }
-    f32x16 acc[1][1];
-    acc_zero<1, 1>(acc);
+    f32x16 acc[1][2];
+    acc_zero<1, 2>(acc);
     v4f rz[NA], ry[NA], rw[NB];
-    const int ncn = L.Cout / KC, nchunk = L.KT * ncn, nit = (nchunk + G - 1) / G;
+    const int ncn = L.Cout / KH, nchunk = L.KT * ncn, nit = (nchunk + G - 1) / G;
     // No integer division inside the reduction loop (each one is ~40 VALU instructions and the loop body is otherwise
-    // ~100): the (tap, column base, BN channel base) of every chunk comes from a small LDS table, and the output
-    // position a source row meets through tap t -- (li + pad - t) / stride, valid when it divides -- is precomputed
-    // per tap into registers that are picked with wave-uniform selects.
+    // ~100): the (tap, column base, BN channel base) of every chunk comes from a small LDS table.
     if (tid < nchunk) {
-        const int tp = tid / ncn, nb = (tid % ncn) * KC;
+        const int tp = tid / ncn, nb = (tid % ncn) * KH;
         cTap[tid] = tp; cNb[tid] = nb; cCh[tid] = nb % Cs;
     }
-    int lo_t[NA][3];
-    bool ok_t[NA][3];
-#pragma unroll
-    for (int i = 0; i < NA; ++i)
-#pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3) {
-            const int t = li[i] + L.pad - t3;
-            // stride is 1 or 2 (cn_make_plan rejects anything else): shift / mask instead of a division
-            const int lo = (L.stride == 2) ? (t >> 1) : t;
-            const bool divides = (L.stride == 2) ? ((t & 1) == 0) : true;
-            ok_t[i][t3] = rv[i] && t3 < L.KT && t >= 0 && divides && lo < L.Lout;
-            lo_t[i][t3] = min(max(lo, 0), L.Lout - 1);
-        }
 #define CGK_DGRAD_LOAD(cc)                                                                                            \
     {                                                                                                                 \
         const int c__ = (cc);                                                                                         \
@@ -676,14 +671,18 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
     {                                                                                                                 \
         const int tap = (TAP), nb = (NBASE);                                                                          \
         _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                              \
-            ok[i] = SEL3(tap, ok_t[i][0], ok_t[i][1], ok_t[i][2]);                                                    \
-            const int lo = SEL3(tap, lo_t[i][0], lo_t[i][1], lo_t[i][2]);                                             \
+            /* the output position source row li meets through tap t: (li + pad - t) / stride when it divides; */   \
+            /* stride is 1 or 2 (cn_make_plan rejects anything else): shift / mask instead of a division */          \
+            const int t_ = li[i] + L.pad - tap;                                                                       \
+            const int lq = (L.stride == 2) ? (t_ >> 1) : t_;                                                          \
+            ok[i] = rv[i] && t_ >= 0 && ((L.stride == 2) ? ((t_ & 1) == 0) : true) && lq < L.Lout;                    \
+            const int lo = min(max(lq, 0), L.Lout - 1);                                                               \
             const int64_t o = ((int64_t)bb[i] * L.Lout + lo) * L.Cout + nb + 4 * kq;                                  \
             rz[i] = ldg4(dzc + o);                         /* unconditional (clamped row), masked at store time */    \
             ry[i] = ldg4((hasbn ? yc : dzc) + o);                                                                     \
         }                                                                                                             \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {       /* rows 2*pr, 2*pr+1 of one column quad (a k pair) */  \
-            const int f = gt + TG * (i >> 1);                                                                         \
+            const int f = lane + 64 * (i >> 1);                                                                       \
             const int nn = 2 * (f >> 4) + (i & 1), cq = f & 15;                                                       \
             rw[i] = ldg4(L.Wp + (int64_t)(nb + nn) * L.Ktot + segoff + tap * C + c0 + 4 * cq);                        \
         }                                                                                                             \
@@ -692,7 +691,7 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
     // its memory latency overlaps the prologue's
     {
         const int c1 = min(g, nchunk - 1);
-        CGK_DGRAD_LOAD_AT(__builtin_amdgcn_readfirstlane(c1 / ncn), __builtin_amdgcn_readfirstlane((c1 % ncn) * KC));
+        CGK_DGRAD_LOAD_AT(__builtin_amdgcn_readfirstlane(c1 / ncn), __builtin_amdgcn_readfirstlane((c1 % ncn) * KH));
     }
     if (hasbn) {
         for (int c = tid; c < Cs; c += NTHR) {
@@ -705,8 +704,8 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
     __syncthreads();                            // chunk table and coefS ready
     for (int it = 0; it < nit; ++it) {
         const int c = it * G + g;
-        const bool act = c < nchunk;
-        if (act) {
+        if (c >= nchunk) break;                 // wave-uniform: no barrier inside the loop
+        {
             const int chb = __builtin_amdgcn_readfirstlane(cCh[c]) + 4 * kq;     // BN channel of this thread's first column
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
@@ -725,22 +724,40 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
             }
 #pragma unroll
             for (int i = 0; i < NB; i += 2) {
-                const int f = gt + TG * (i >> 1);
+                const int f = lane + 64 * (i >> 1);
                 v4f hi, lo;
                 enc2x4<MM_ENC_W>(rw[i], rw[i + 1], hi, lo);
                 sts4(Bs + (2 * (f >> 4)) * LDN + 4 * (f & 15), hi);
                 sts4(Bs + (2 * (f >> 4) + 1) * LDN + 4 * (f & 15), lo);
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();        // (compiler only) the stores above before the operand reads of every lane
         if (c + G < nchunk) CGK_DGRAD_LOAD(c + G);
-        if (act) mma_chunk<MM, 1, 1, LDA, LDN>(As, Bs, wm * 32, wn * 32, acc);
-        __syncthreads();
+        mma_chunk<MM, 1, 2, LDA, LDN, KH>(As, Bs, 0, 0, acc);
+        __builtin_amdgcn_wave_barrier();        // ... and those reads before the next chunk's stores
     }
-    float *red = lds;                                   // [G][TMB][64]
+    // sum of the 8 group accumulators through LDS in two rounds (8 x 32 x 64 floats do not fit): groups 4..7 park theirs,
+    // groups 0..3 add them to their own and park the sums for the epilogue pass
+    constexpr int GE = G / 2;
+    float *red = lds;                                   // [GE][TMB][64]
+    __syncthreads();                            // every group is done with its operand buffers
+    if (g >= GE) {
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg)
-        red[(g * TMB + wm * 32 + acc_row(reg, lh)) * 64 + wn * 32 + l31] = acc[0][0][reg];
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                red[((g - GE) * TMB + acc_row(reg, lh)) * 64 + j * 32 + l31] = acc[0][j][reg];
+    }
+    __syncthreads();
+    if (g < GE) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                float *rp = red + (g * TMB + acc_row(reg, lh)) * 64 + j * 32 + l31;
+                *rp = acc[0][j][reg] + *rp;
+            }
+    }
     __syncthreads();
     const int ecq = tid & 15;
     const int col = c0 + 4 * ecq;
@@ -755,7 +772,7 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
         if (row >= Rs) continue;
         v4f gsum = zero4();
 #pragma unroll
-        for (int q = 0; q < G; ++q) gsum += *(const v4f *)(red + (q * TMB + er) * 64 + 4 * ecq);
+        for (int q = 0; q < GE; ++q) gsum += *(const v4f *)(red + (q * TMB + er) * 64 + 4 * ecq);
         const int64_t o = (int64_t)row * C + col;
         v4f xh = zero4();
         if (bnsrc) {
@@ -795,16 +812,19 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
     }
 }
 
-// dWp[n][kk] = sum_r dy[r][n] * A[r][kk]; tile 64 (n) x 64 (kk); the workgroup owns rows [rbeg, rend) of one split and
-// its two 256-thread halves take alternate KC-row chunks (summed through LDS at the end).
+// dWp[n][kk] = sum_r dy[r][n] * A[r][kk]; tile 64 (n) x 64 (kk); the workgroup owns rows [rbeg, rend) of one split.
+// Its eight waves are four row-chunk STREAMS (16-row chunks s, s + 4, ...) x two halves of the n side: a wave stages the
+// 16 x 32 slice of dy and the 16 x 64 slice of A of its chunk into LDS buffers of its own and computes 32 (n) x 64 (kk) --
+// nothing is shared between waves, so the loop has no barrier (the A slice is staged by both waves of a stream: its
+// transform is one fma + max per value).  The stream accumulators are summed through LDS at the end.
 template <int MM>
 __device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float *smem)
 {
+    constexpr int KH = CGB_KH, NS = CGB_G / 2, LDW = CGB_LDW;
     const CgLayer &L = a.lay;
-    const int tid = threadIdx.x, h = tid >> 8, gt = tid & 255;
-    const int lane = tid & 63, wave = gt >> 6;
-    const int l31 = lane & 31, lh = lane >> 5, wm = wave >> 1, wn = wave & 1;
-    float *As = smem + h * (2 * KC * LDN), *Bs = As + KC * LDN;
+    const int tid = threadIdx.x, w = tid >> 6, st = w >> 1, wm = w & 1;
+    const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+    float *As = smem + w * CGB_WSZ, *Bs = As + CGB_ASZ;
     // XCD order: the row split is the slow index, so the workgroups that reduce the same rows (all output tiles) share an L2
     const int nyz = a.w_ny * (L.Ktot / 64);
     const int wt = cg_xcd_tile(wid, a.w_ns * nyz);
@@ -812,7 +832,7 @@ __device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float
     const int bx = wt / nyz, byz = wt % nyz, by = byz % a.w_ny, bz = byz / a.w_ny;
     const int R = L.B * L.Lout, Cs = L.Cs;
     const int rbeg = bx * a.rows, rend = min(R, rbeg + a.rows);
-    const int n0 = by * 64, kk0 = bz * 64;
+    const int n0 = by * 64 + wm * 32, kk0 = bz * 64;
     int sg, tap, k0, so;
     cg_locate(L, kk0, sg, tap, k0, so);                   // kk0 is workgroup-uniform
     sg = __builtin_amdgcn_readfirstlane(sg);
@@ -822,35 +842,40 @@ __device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float
     const int SC = SEL4(sg, opaque_s(L.seg[0].C), opaque_s(L.seg[1].C), opaque_s(L.seg[2].C), opaque_s(L.seg[3].C));
     const int Sty = SEL4(sg, opaque_s(L.seg[0].type), opaque_s(L.seg[1].type), opaque_s(L.seg[2].type), opaque_s(L.seg[3].type));
     const int SLs = SEL4(sg, opaque_s(L.seg[0].Lsrc), opaque_s(L.seg[1].Lsrc), opaque_s(L.seg[2].Lsrc), opaque_s(L.seg[3].Lsrc));
-    const int cq = gt & 15, rr0 = 2 * (gt >> 4);          // column quad, first row (rows rr0, rr0+1: a k pair)
-    // per-thread constants of its 4 columns: BN-backward coefficients of dy, BN scale/shift of the A operand
+    // dy slice: 8 column quads x 8 row pairs (rows 2*pa, 2*pa + 1: a k pair); A slice: 16 column quads x 4 row pairs, twice
+    const int cqa = lane & 7, pa = lane >> 3;
+    const int cqb = lane & 15, pb = lane >> 4;
+    // constants of the tile's 64 + 64 columns in LDS (registers are short: 4 waves per SIMD): BN-backward coefficients of dy
+    // [5][64], BN scale / shift of the A operand [2][64]
     const bool hasbn = a.cb.bstat != nullptr;
-    float cf[5][4], as[4], at[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int ch = (n0 + 4 * cq + j) % Cs;
+    float *cfS = smem + CGB_LDS, *abS = cfS + 5 * 64;
+    if (tid < 64) {
         float c5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-        if (hasbn) cg_bnbwd_coef(a.cb, Cs, ch, c5, false);
+        if (hasbn) cg_bnbwd_coef(a.cb, Cs, (by * 64 + tid) % Cs, c5, false);
 #pragma unroll
-        for (int q = 0; q < 5; ++q) cf[q][j] = c5[q];
-        as[j] = Sbn ? Sbn[k0 + 4 * cq + j] : 1.f;
-        at[j] = Sbn ? Sbn[SC + k0 + 4 * cq + j] : 0.f;
+        for (int q = 0; q < 5; ++q) cfS[q * 64 + tid] = c5[q];
+    } else if (tid < 128) {
+        const int j = tid - 64;
+        abS[j] = Sbn ? Sbn[k0 + j] : 1.f;
+        abS[64 + j] = Sbn ? Sbn[SC + k0 + j] : 0.f;
     }
-    f32x16 acc[1][1];
-    acc_zero<1, 1>(acc);
-    v4f rz[2], ry[2], rx[2];
-    bool ok[2];
+    const float *cfp = cfS + wm * 32 + 4 * cqa, *abp = abS + 4 * cqb;
+    f32x16 acc[1][2];
+    acc_zero<1, 2>(acc);
+    v4f rz[2], ry[2], rx[4];
+    bool ok[4];
     const int xC = SC, xLs = SLs, xlm = Sty ? 0 : 1;
-    const int nch = (rend - rbeg + KC - 1) / KC, nit = (nch + 1) / 2;
-    // (frustum, position) of this thread's two rows, advanced by 2*KC per chunk instead of divided out of the row index
+    const int nch = (rend - rbeg + KH - 1) / KH, nit = (nch + NS - 1) / NS;
+    // (frustum, position) of the FIRST row of this thread's two A row pairs, advanced by NS*KH per chunk instead of divided
+    // out of the row index; the second row of a pair is the next position (or position 0 of the next frustum)
     int wb[2], wl[2];
     const float invL = cg_inv(L.Lout);
     const bool fastdiv = R < (1 << 23);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = rbeg + h * KC + rr0 + i;
-        if (fastdiv) cg_divmod(r, L.Lout, invL, wb[i], wl[i]);
-        else { wb[i] = r / L.Lout; wl[i] = r % L.Lout; }
+    for (int p2 = 0; p2 < 2; ++p2) {
+        const int r = rbeg + st * KH + 2 * (pb + 4 * p2);
+        if (fastdiv) cg_divmod(r, L.Lout, invL, wb[p2], wl[p2]);
+        else { wb[p2] = r / L.Lout; wl[p2] = r % L.Lout; }
     }
     int bend, lend;
     if (fastdiv) cg_divmod(rend - 1, L.Lout, invL, bend, lend);
@@ -859,69 +884,106 @@ __device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float
     {                                                                                                                 \
         const int r0_ = (rr);                                                                                         \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                               \
-            const bool in = r0_ + rr0 + i < rend;           /* clamped: unconditional loads, masked at store */       \
-            const int row = in ? r0_ + rr0 + i : rend - 1;                                                            \
-            const int64_t o = (int64_t)row * L.Cout + n0 + 4 * cq;                                                    \
+            const int row = min(r0_ + 2 * pa + i, rend - 1);    /* clamped: unconditional loads, masked at store */   \
+            const int64_t o = (int64_t)row * L.Cout + n0 + 4 * cqa;                                                   \
             rz[i] = ldg4(a.dz + o);                                                                                   \
             ry[i] = ldg4((hasbn ? L.y : a.dz) + o);                                                                   \
-            rx[i] = cg_load_raw(L, Sx, xC, xLs, xlm, tap, k0 + 4 * cq, in ? wb[i] : bend, in ? wl[i] : lend, true,    \
-                                ok[i]);                                                                               \
-            wl[i] += 2 * KC;                                                                                          \
-            while (wl[i] >= L.Lout) { wl[i] -= L.Lout; wb[i] += 1; }                                                  \
+        }                                                                                                             \
+        _Pragma("unroll") for (int p2 = 0; p2 < 2; ++p2) {                                                            \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
+                const bool in = r0_ + 2 * (pb + 4 * p2) + i < rend;                                                   \
+                const bool wrap = i == 1 && wl[p2] + 1 >= L.Lout;                                                     \
+                const int b_ = wrap ? wb[p2] + 1 : wb[p2], l_ = wrap ? 0 : wl[p2] + i;                                \
+                rx[2 * p2 + i] = cg_load_raw(L, Sx, xC, xLs, xlm, tap, k0 + 4 * cqb, in ? b_ : bend, in ? l_ : lend,  \
+                                             true, ok[2 * p2 + i]);                                                   \
+            }                                                                                                         \
+            wl[p2] += NS * KH;                                                                                        \
+            while (wl[p2] >= L.Lout) { wl[p2] -= L.Lout; wb[p2] += 1; }                                               \
         }                                                                                                             \
     }
-    if (h < nch) CG_WGRAD_LOAD(rbeg + h * KC);
+    if (st < nch) CG_WGRAD_LOAD(rbeg + st * KH);
+    __syncthreads();                            // cfS / abS ready
     for (int it = 0; it < nit; ++it) {
-        const int c = 2 * it + h;
-        const bool act = c < nch;
-        const int r0 = rbeg + c * KC;
-        if (act) {
-            v4f dv2[2], av2[2];
+        const int c = NS * it + st;
+        if (c >= nch) break;                    // wave-uniform: no barrier inside the loop
+        const int r0 = rbeg + c * KH;
+        {
+            v4f dv2[2];
+            {
+                const v4f f0 = *(const v4f *)cfp, f1 = *(const v4f *)(cfp + 64), f2 = *(const v4f *)(cfp + 128),
+                          f3 = *(const v4f *)(cfp + 192), f4 = *(const v4f *)(cfp + 256);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                float d[4] = {rz[i].x, rz[i].y, rz[i].z, rz[i].w};
-                const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
-                const bool live = (r0 + rr0 + i) < rend;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (hasbn) {
-                        const float xh = (yv[j] - cf[1][j]) * cf[2][j];
-                        d[j] = cf[0][j] * (d[j] - fmaf(xh, cf[4][j], cf[3][j]));
+                for (int i = 0; i < 2; ++i) {
+                    v4f d = rz[i];
+                    if (hasbn) {                // elementwise, the same operation order as cg_dy
+                        const v4f xh = (ry[i] - f1) * f2;
+                        v4f m;
+                        m.x = fmaf(xh.x, f4.x, f3.x); m.y = fmaf(xh.y, f4.y, f3.y);
+                        m.z = fmaf(xh.z, f4.z, f3.z); m.w = fmaf(xh.w, f4.w, f3.w);
+                        d = f0 * (d - m);
                     }
-                    d[j] = live ? d[j] : 0.f;
+                    const bool live = (r0 + 2 * pa + i) < rend;
+                    dv2[i] = live ? d : zero4();
                 }
-                v4f dv = {d[0], d[1], d[2], d[3]};
-                dv2[i] = dv;
-                v4f av = {cg_act(as[0], rx[i].x, at[0], ok[i] && live), cg_act(as[1], rx[i].y, at[1], ok[i] && live),
-                          cg_act(as[2], rx[i].z, at[2], ok[i] && live), cg_act(as[3], rx[i].w, at[3], ok[i] && live)};
-                av2[i] = av;
             }
+            const v4f as = *(const v4f *)abp, at = *(const v4f *)(abp + 64);
             v4f hi, lo;
             enc2x4<MM_ENC_A>(dv2[0], dv2[1], hi, lo);
-            sts4(As + rr0 * LDN + 4 * cq, hi);
-            sts4(As + (rr0 + 1) * LDN + 4 * cq, lo);
-            enc2x4<MM_ENC_A>(av2[0], av2[1], hi, lo);
-            sts4(Bs + rr0 * LDN + 4 * cq, hi);
-            sts4(Bs + (rr0 + 1) * LDN + 4 * cq, lo);
-        }
-        __syncthreads();
-        if (c + 2 < nch) CG_WGRAD_LOAD(r0 + 2 * KC);
-        if (act) mma_chunk<MM, 1, 1, LDN, LDN>(As, Bs, wm * 32, wn * 32, acc);
-        __syncthreads();
-    }
-    float *red = smem;                                  // [64][64]: the second half's accumulators
-    if (h == 1) {
+            sts4(As + (2 * pa) * LDW + 4 * cqa, hi);
+            sts4(As + (2 * pa + 1) * LDW + 4 * cqa, lo);
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) red[(wm * 32 + acc_row(reg, lh)) * 64 + wn * 32 + l31] = acc[0][0][reg];
+            for (int p2 = 0; p2 < 2; ++p2) {
+                v4f av2[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int q = 2 * p2 + i;
+                    const bool live = ok[q] && (r0 + 2 * (pb + 4 * p2) + i) < rend;
+                    v4f av = {cg_act(as.x, rx[q].x, at.x, live), cg_act(as.y, rx[q].y, at.y, live),
+                              cg_act(as.z, rx[q].z, at.z, live), cg_act(as.w, rx[q].w, at.w, live)};
+                    av2[i] = av;
+                }
+                enc2x4<MM_ENC_A>(av2[0], av2[1], hi, lo);
+                sts4(Bs + (2 * (pb + 4 * p2)) * LDN + 4 * cqb, hi);
+                sts4(Bs + (2 * (pb + 4 * p2) + 1) * LDN + 4 * cqb, lo);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();        // (compiler only) the stores above before the operand reads of every lane
+        if (c + NS < nch) CG_WGRAD_LOAD(r0 + NS * KH);
+        mma_chunk<MM, 1, 2, LDW, LDN, KH>(As, Bs, 0, 0, acc);
+        __builtin_amdgcn_wave_barrier();        // ... and those reads before the next chunk's stores
+    }
+    // streams 2, 3 park their accumulators, streams 0, 1 add them to their own; stream 1 parks the sum, stream 0 adds it and
+    // writes the split's partial
+    float *red = smem + (((st & 1) * 2 + wm) * 32) * 64;    // [2 slots][2 halves][32][64]
+    __syncthreads();                            // every wave is done with its operand buffers
+    if (st >= 2) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) red[acc_row(reg, lh) * 64 + j * 32 + l31] = acc[0][j][reg];
     }
     __syncthreads();
-    if (h == 0) {
+    if (st < 2) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                float *rp = red + acc_row(reg, lh) * 64 + j * 32 + l31;
+                acc[0][j][reg] += *rp;
+                if (st == 1) *rp = acc[0][j][reg];
+            }
+    }
+    __syncthreads();
+    if (st == 0) {
+        const float *r1 = smem + ((2 + wm) * 32) * 64;      // stream 1's slot
         float *out = a.partial + (int64_t)bx * L.Cout * L.Ktot;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int rr = wm * 32 + acc_row(reg, lh), cc = wn * 32 + l31;
-            out[(int64_t)(n0 + rr) * L.Ktot + kk0 + cc] = acc[0][0][reg] + red[rr * 64 + cc];
-        }
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int rr = acc_row(reg, lh), cc = j * 32 + l31;
+                out[(int64_t)(n0 + rr) * L.Ktot + kk0 + cc] = acc[0][j][reg] + r1[rr * 64 + cc];
+            }
     }
 }
 
@@ -973,8 +1035,15 @@ __device__ __forceinline__ void cg_reduce_body(const CgReduce &q, int rid, float
 template <int MM>
 __device__ __forceinline__ void cg_bwd_step_body(const CgBwdStep &a, const int bid, float *smem, const int koff)
 {
+#ifndef CGB_NO_REDUCE
     if (bid >= a.r_blk0) { cg_reduce_body(a.red, bid - a.r_blk0, smem); return; }
+#endif
+#ifndef CGB_NO_WGRAD
     if (bid >= a.w_blk0) { cg_wgrad_body<MM>(a, bid - a.w_blk0, smem); return; }
+#endif
+#ifdef CGB_NO_DGRAD
+    return;
+#endif
     const int role = __builtin_amdgcn_readfirstlane(
         (a.ndg > 3 && bid >= a.dg[3].blk0) ? 3 : ((a.ndg > 2 && bid >= a.dg[2].blk0) ? 2 : ((a.ndg > 1 && bid >= a.dg[1].blk0) ? 1 : 0)));
     // The role's segment descriptor is one of four: selecting it field by field from the by-value struct costs 4 x 14 pinned
@@ -991,7 +1060,7 @@ __device__ __forceinline__ void cg_bwd_step_body(const CgBwdStep &a, const int b
 }
 
 template <int MM>
-__global__ __launch_bounds__(CGB_T) void cg_bwd_step_kernel(CgBwdStep a)
+__global__ __launch_bounds__(CGB_T, 4) void cg_bwd_step_kernel(CgBwdStep a)
 {
     __shared__ __attribute__((aligned(16))) float smem[CGB_SMEM];
     cg_bwd_step_body<MM>(a, blockIdx.x, smem, 0);
@@ -1005,7 +1074,7 @@ struct CgBwdPair {
 };
 
 template <int MM>
-__global__ __launch_bounds__(CGB_T) void cg_bwd_pair_kernel(CgBwdPair p)
+__global__ __launch_bounds__(CGB_T, 4) void cg_bwd_pair_kernel(CgBwdPair p)
 {
     __shared__ __attribute__((aligned(16))) float smem[CGB_SMEM];
     const int bid = blockIdx.x;

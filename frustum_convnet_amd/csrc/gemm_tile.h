@@ -128,8 +128,8 @@ __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c)
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// One KC-deep chunk: As is [KC][LDA] (m fastest), Bs is [KC][LDB] (n fastest).
-template <int MM, int MT, int NT, int LDA, int LDB>
+// One KCH-deep chunk (KC unless stated): As is [KCH][LDA] (m fastest), Bs is [KCH][LDB] (n fastest).
+template <int MM, int MT, int NT, int LDA, int LDB, int KCH = KC>
 __device__ __forceinline__ void mma_chunk(const float *As, const float *Bs, int arow0, int bcol0,
                                           f32x16 (&acc)[MT][NT]) {
     const int lane = threadIdx.x & 63;
@@ -145,9 +145,9 @@ __device__ __forceinline__ void mma_chunk(const float *As, const float *Bs, int 
 #pragma unroll
         for (int j = 0; j < NT; ++j) b[0][j] = bp[j * 32];
 #pragma unroll
-        for (int kk = 0; kk < KC; kk += 2) {
+        for (int kk = 0; kk < KCH; kk += 2) {
             const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
-            if (kk + 2 < KC) {
+            if (kk + 2 < KCH) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) a[nxt][i] = ap[(kk + 2) * LDA + i * 32];
 #pragma unroll
@@ -168,7 +168,7 @@ __device__ __forceinline__ void mma_chunk(const float *As, const float *Bs, int 
         const uint32_t *bp = (const uint32_t *)Bs + (8 * lh) * LDB + bcol0 + l31;
         constexpr bool X3 = (MM != MM_BF16X1);
 #pragma unroll
-        for (int ks = 0; ks < KC; ks += 16) {
+        for (int ks = 0; ks < KCH; ks += 16) {
             u32x4 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
             for (int i = 0; i < MT; ++i)

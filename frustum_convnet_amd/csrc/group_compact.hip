@@ -67,7 +67,7 @@ __device__ __forceinline__ GcScale gc_pick(const GcArgs &a, int z)
 // ---- launch 1: hit lists (query_depth_point_cuda_kernel.cu:40-64: fabsf(z2 - z1) < dis_z in fp32, ascending k, first K)
 __global__ __launch_bounds__(GC_T) void gc_hits_kernel(GcArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    FCN_DYN_LDS(unsigned char, smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
     const GcScale S = gc_pick(a, (int)blockIdx.z);
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(GC_T) void gc_hits_kernel(GcArgs a)
 // ---- launch 2: offsets, entry rows, moments; the last frustum of a scale finalises it
 __global__ __launch_bounds__(GE_T) void gc_entries_kernel(GcArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    FCN_DYN_LDS(unsigned char, smem);
     __shared__ int wsum[GE_WAVES];
     __shared__ double red[GE_WAVES][10];
     __shared__ int last_s, carry_s;
@@ -225,9 +225,11 @@ __global__ __launch_bounds__(GE_T) void gc_entries_kernel(GcArgs a)
         for (int c = tid; c < S.C1; c += GE_T) {
             double mean, var;
             if (a.training) {
-                const double mx = red[0][1] / M, my = red[0][2] / M, mz = red[0][3] / M;
-                const double cxx = red[0][4] / M - mx * mx, cxy = red[0][5] / M - mx * my, cxz = red[0][6] / M - mx * mz;
-                const double cyy = red[0][7] / M - my * my, cyz = red[0][8] / M - my * mz, czz = red[0][9] / M - mz * mz;
+                // (one fp64 division, no software sqrt: this workgroup is the tail of the front every scale waits for)
+                const double iM = 1.0 / M;
+                const double mx = red[0][1] * iM, my = red[0][2] * iM, mz = red[0][3] * iM;
+                const double cxx = red[0][4] * iM - mx * mx, cxy = red[0][5] * iM - mx * my, cxz = red[0][6] * iM - mx * mz;
+                const double cyy = red[0][7] * iM - my * my, cyz = red[0][8] * iM - my * mz, czz = red[0][9] * iM - mz * mz;
                 const double w0 = S.W1[3 * c], w1 = S.W1[3 * c + 1], w2 = S.W1[3 * c + 2];
                 mean = w0 * mx + w1 * my + w2 * mz;
                 var = w0 * (cxx * w0 + cxy * w1 + cxz * w2) + w1 * (cxy * w0 + cyy * w1 + cyz * w2) +
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(GE_T) void gc_entries_kernel(GcArgs a)
                 mean = S.rmean[c];
                 var = S.rvar[c];
             }
-            const double rstd = 1.0 / sqrt(var + (double)a.eps);
+            const double rstd = fcn_rsqrt64(var + (double)a.eps);
             const double sc = (double)S.gamma[c] * rstd;
             S.bn1[c] = (float)sc;
             S.bn1[S.C1 + c] = (float)((double)S.beta[c] - mean * sc);

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(QDP_THREADS) void qdp_kernel(
     const float *__restrict__ ctr_z, int64_t ct_stride, int64_t ct_bstride,
     int n, int m, float dis_z, int nsample, int64_t *__restrict__ idx, int32_t *__restrict__ cnt, int use_lds)
 {
-    extern __shared__ __attribute__((aligned(16))) float zs[];
+    FCN_DYN_LDS(float, zs);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(CP_THREADS) void compact_kernel(
     const int32_t *__restrict__ cnt, int N, int L, int K,
     int32_t *__restrict__ woff, float4 *__restrict__ ent, int32_t *__restrict__ ewin, double *__restrict__ mom)
 {
-    extern __shared__ __attribute__((aligned(16))) int offs[];     // L+1
+    FCN_DYN_LDS(int, offs);        // L+1
     __shared__ int wsum[4];
     __shared__ double red[4][10];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

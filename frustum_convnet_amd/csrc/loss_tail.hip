@@ -89,12 +89,52 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
     const float TWO_PI = 6.283185307179586f, PI = 3.141592653589793f;
     const float per = (float)(6.283185307179586 / NB), half = (float)(6.283185307179586 / NB / 2.0);
 
+    // The workgroup's logits rows (row-major variant) are REQUESTED FIRST, as 16-byte loads into registers, so that their
+    // trip overlaps the label count below; they go to LDS after it.  (One dword per loop iteration, as before, was a chain of
+    // ~64 dependent memory round trips per thread: most of the kernel's 46 us on the critical path between the FCN's forward
+    // and backward.)
+    typedef float lt_v4f __attribute__((ext_vector_type(4)));
+    typedef const lt_v4f __attribute__((address_space(1))) *lt_gv4fp;
+    constexpr int LT_NV = 16;                            // float4 per thread per batch
+    const int row0 = blockIdx.x * LT_THREADS;
+    const int nrow = min(LT_THREADS, R - row0);
+    const int q4 = a.ld >> 2;                            // float4 per row: 16 or 32
+    const int sh_q = a.ld == 128 ? 5 : 4;
+    const int nbatch = a.ld ? (q4 + LT_NV - 1) / LT_NV : 0;       // 1 (ld 64) or 2 (ld 128)
+    lt_v4f lv[LT_NV];
+#define LT_LOAD_BATCH(bt)                                                                                             \
+    _Pragma("unroll") for (int k = 0; k < LT_NV; ++k) {                                                               \
+        const int i = tid + LT_THREADS * (k + LT_NV * (bt));                                                          \
+        const int rr = min(i >> sh_q, nrow - 1), c4 = i & (q4 - 1);     /* clamped row: unconditional loads */         \
+        lv[k] = *(lt_gv4fp)(a.cls_raw + (int64_t)(row0 + rr) * a.ld + 4 * c4);                                        \
+    }
+#define LT_STAGE_BATCH(bt)                                                                                            \
+    _Pragma("unroll") for (int k = 0; k < LT_NV; ++k) {                                                               \
+        const int i = tid + LT_THREADS * (k + LT_NV * (bt));                                                          \
+        const int rr = i >> sh_q, c4 = i & (q4 - 1);                                                                  \
+        if (rr < nrow) {                                                                                              \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                             \
+                if (4 * c4 + j < NC + 2) gS[rr * SW + 4 * c4 + j] = lv[k][j];                                         \
+        }                                                                                                             \
+    }
+    if (a.ld) LT_LOAD_BATCH(0);
+
     float cfg_ = 0.f, ckeep = 0.f;
+    {                                   // every workgroup counts all labels: two per 16-byte load, 8 loads in flight
+        typedef long long lt_v2l __attribute__((ext_vector_type(2)));
+        typedef const lt_v2l __attribute__((address_space(1))) *lt_gv2lp;
+        const int R2 = R >> 1;
 #pragma unroll 8
-    for (int r = tid; r < R; r += LT_THREADS) {          // every workgroup counts all labels: 8 loads in flight
-        const int64_t lab = a.cls_label[r];
-        cfg_ += (lab == 1) ? 1.f : 0.f;
-        ckeep += (lab != -1) ? 1.f : 0.f;
+        for (int r = tid; r < R2; r += LT_THREADS) {
+            const lt_v2l lab = *(lt_gv2lp)(a.cls_label + 2 * r);
+            cfg_ += ((lab[0] == 1) ? 1.f : 0.f) + ((lab[1] == 1) ? 1.f : 0.f);
+            ckeep += ((lab[0] != -1) ? 1.f : 0.f) + ((lab[1] != -1) ? 1.f : 0.f);
+        }
+        if ((R & 1) && tid == 0) {
+            const int64_t lab = a.cls_label[R - 1];
+            cfg_ += (lab == 1) ? 1.f : 0.f;
+            ckeep += (lab != -1) ? 1.f : 0.f;
+        }
     }
     const float nfg = block_sum<LT_THREADS>(cfg_, sh);
     const float nkeep = block_sum<LT_THREADS>(ckeep, sh);
@@ -107,14 +147,11 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
 #pragma unroll
     for (int i = 0; i < 11; ++i) acc[i] = 0.f;
 
-    if (a.ld) {                        // the workgroup's logits rows come in as coalesced 256-byte rows too
-        const int row0 = blockIdx.x * LT_THREADS;
-        const int nrow = min(LT_THREADS, R - row0);
-        const int sh_ld = a.ld == 128 ? 7 : 6;          // ld is 64 or 128
-        for (int i = tid; i < nrow * a.ld; i += LT_THREADS) {
-            const int rr = i >> sh_ld, cc = i & (a.ld - 1);
-            const float v = a.cls_raw[(int64_t)(row0 + rr) * a.ld + cc];
-            if (cc < NC + 2) gS[rr * SW + cc] = v;
+    if (a.ld) {
+        LT_STAGE_BATCH(0);
+        if (nbatch > 1) {
+            LT_LOAD_BATCH(1);
+            LT_STAGE_BATCH(1);
         }
         __syncthreads();
     }
@@ -295,12 +332,12 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
     }
     if (a.ld && a.dcls) {              // (the row loop runs at most once per thread: the grid covers R)
         __syncthreads();
-        const int row0 = blockIdx.x * LT_THREADS;
-        const int nrow = min(LT_THREADS, R - row0);
-        const int sh_ld = a.ld == 128 ? 7 : 6;
-        for (int i = tid; i < nrow * a.ld; i += LT_THREADS) {
-            const int rr = i >> sh_ld, cc = i & (a.ld - 1);
-            a.dcls[(int64_t)(row0 + rr) * a.ld + cc] = cc < NC + 2 ? gG[rr * SW + cc] : 0.f;
+        for (int i = tid; i < nrow * q4; i += LT_THREADS) {        // 16-byte stores: a quarter of the store instructions
+            const int rr = i >> sh_q, c4 = i & (q4 - 1);
+            lt_v4f v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = 4 * c4 + j < NC + 2 ? gG[rr * SW + 4 * c4 + j] : 0.f;
+            *(lt_v4f *)(a.dcls + (int64_t)(row0 + rr) * a.ld + 4 * c4) = v;
         }
     }
     // ---- combine the workgroups: out[1..10] accumulate, out[15] (as int) is the arrival ticket; both were zeroed by the
@@ -324,18 +361,35 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
         last_s = (ticket == (int)gridDim.x - 1) ? 1 : 0;
     }
     __syncthreads();
-    if (last_s && tid == 0) {
+    // The last workgroup sums the partials.  With the scratch buffer: IN WORKGROUP ORDER (reproducible scalars), but not by
+    // one thread walking gridDim.x x 10 dependent loads (35 memory round trips on the critical path): thread g fetches the
+    // ten partials of workgroups g, g + T, ... (independent loads, summed in that fixed order), then thread 0 adds the
+    // per-thread sums in thread order from LDS.
+    if (last_s && a.scratch) {
         __threadfence();
+        float pt_[11];
+#pragma unroll
+        for (int i = 1; i < 11; ++i) pt_[i] = 0.f;
+        for (int g = tid; g < (int)gridDim.x; g += LT_THREADS)
+#pragma unroll
+            for (int i = 1; i < 11; ++i)
+                pt_[i] += __hip_atomic_load(&a.scratch[32 + 16 * g + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 1; i < 11; ++i) gG[tid * 11 + i] = pt_[i];        // (gG is free: the gradient rows have left)
+    }
+    __syncthreads();
+    if (last_s && tid == 0) {
         float t[11];
         if (a.scratch) {
 #pragma unroll
             for (int i = 1; i < 11; ++i) t[i] = 0.f;
-            for (int g = 0; g < (int)gridDim.x; ++g)
+            const int nth = min((int)gridDim.x, LT_THREADS);
+            for (int g = 0; g < nth; ++g)
 #pragma unroll
-                for (int i = 1; i < 11; ++i)
-                    t[i] += __hip_atomic_load(&a.scratch[32 + 16 * g + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int i = 1; i < 11; ++i) t[i] += gG[g * 11 + i];
             ((int *)a.scratch)[0] = 0;          // ready for the next launch
         } else {
+            __threadfence();
 #pragma unroll
             for (int i = 1; i < 11; ++i) t[i] = __hip_atomic_load(&a.out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }

@@ -129,25 +129,6 @@ __global__ __launch_bounds__(GT) void poolbwd_kernel(
     }
 }
 
-// coef[0..5) x C : gamma*rstd, mean, rstd, dbeta/M, dgamma/M ; also exports dgamma/dbeta (fp32)
-__global__ void bnbwd_finalize_kernel(const double *__restrict__ bstat, const float *__restrict__ gamma,
-                                      const float *__restrict__ bn, int C, double M,
-                                      float *__restrict__ coef, float *__restrict__ dgamma,
-                                      float *__restrict__ dbeta)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double db = bstat[c], dg = bstat[C + c];
-    const float rstd = bn[3 * C + c];
-    coef[c] = gamma[c] * rstd;
-    coef[C + c] = bn[2 * C + c];
-    coef[2 * C + c] = rstd;
-    coef[3 * C + c] = (float)(db / M);
-    coef[4 * C + c] = (float)(dg / M);
-    dgamma[c] = (float)dg;
-    dbeta[c] = (float)db;
-}
-
 // ------------------------------------------------------------------------------------------------
 struct DgradArgs {
     const float4 *ent;      // (B,cap)
@@ -158,7 +139,7 @@ struct DgradArgs {
     const int32_t *amax;    // (B,L,C3)           LAYER 3
     const float *gmax;      // (B,L,C3)           LAYER 3
     const float *dzcur;     // dz2 (B,cap,C2)     LAYER 2
-    const float *coef;      // 5 x CRED
+    FcnBnBwd cb;            // BN backward of the layer being differentiated (width CRED), finalised HERE by every workgroup
     const float *W;         // (CRED, CPREV) row-major = the conv weight (Cout,Cin)
     float *dybuf;           // LAYER 3: dy3 (B,cap,C3) written by the first column block
     const float *yprev;     // LAYER 3: y2 (B,cap,C2)
@@ -194,6 +175,12 @@ void dgrad_kernel(DgradArgs a)
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int ny = a.CPREV / TN;                  // XCD order, column tiles fastest (see fcn_xcd_tile)
+    if (blockIdx.x == 0 && a.cb.dgamma) {         // workgroup 0 always exists (the grid is padded): it exports dgamma / dbeta
+        for (int c = tid; c < a.CRED; c += NTHR) {
+            a.cb.dgamma[c] = (float)a.cb.bstat[a.CRED + c];
+            a.cb.dbeta[c] = (float)a.cb.bstat[c];
+        }
+    }
     const int xt = fcn_xcd_tile(blockIdx.x, SUB * a.tiles[0] * ny);
     if (xt < 0) return;
     const int bxi = xt / ny, byi = xt % ny;
@@ -209,7 +196,12 @@ void dgrad_kernel(DgradArgs a)
     const int CRED = a.CRED, CPREV = a.CPREV;
 
     PNP_DECL;
-    for (int i = tid; i < 5 * CRED; i += NTHR) coefS[i] = a.coef[i];
+    for (int c = tid; c < CRED; c += NTHR) {
+        float cf[5];
+        fcn_bnbwd_coef(a.cb, CRED, c, cf, false);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) coefS[q * CRED + c] = cf[q];
+    }
     if (tid < TM) uS[tid] = (tid < nvalid) ? a.ent[grow0 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int kq = tid & 7, rb = tid >> 3;
     constexpr int RSTEP = NTHR / 8;               // rows between a thread's consecutive A quads
@@ -396,7 +388,7 @@ struct WgradArgs {
     const float *dy;        // LAYER 3: dy3 (B,cap,C3)
     const float *dz;        // LAYER 2: dz2 (B,cap,C2)
     const float *ycur;      // LAYER 2: y2 (for xhat2)
-    const float *coef;      // LAYER 2: 5 x C2
+    FcnBnBwd cb;            // LAYER 2: BN2 backward, finalised by every workgroup
     const float *yprev;     // LAYER 3: y2 -> a2
     const float *bn_prev;   // scale, shift of the previous layer's BN
     const float *W1;        // LAYER 2
@@ -449,9 +441,12 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
     float bs[4], bt[4], bal[4][3];
     if constexpr (LAYER == 2) {
 #pragma unroll
-        for (int q = 0; q < 5; ++q)
+        for (int j = 0; j < 4; ++j) {
+            float c5[5];
+            fcn_bnbwd_coef(a.cb, COUT, n0 + 4 * acq + j, c5, false);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) cf[q][j] = a.coef[q * COUT + n0 + 4 * acq + j];
+            for (int q = 0; q < 5; ++q) cf[q][j] = c5[q];
+        }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -600,36 +595,38 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
 // layer has few elements but hundreds of splits (a few independent loads per thread, group sum through LDS), a big one
 // the opposite (one thread per element).
 #define WR_T 256
+// (each thread owns FOUR consecutive elements: 16-byte loads -- a quarter of the load instructions of the dword version and
+// four times the bytes in flight per thread; 100 us of kernel time per step went through here at ~1.6 TB/s)
 __global__ __launch_bounds__(WR_T) void wgrad_reduce_kernel(const float *__restrict__ partial,
                                                             const int32_t *__restrict__ tiles, int nsplit, int gr,
                                                             int64_t nelem, float *__restrict__ out)
 {
-    __shared__ float sh[WR_T];
+    __shared__ __attribute__((aligned(16))) float sh[WR_T * 4];
     const int per = WR_T / gr;
     const int x = threadIdx.x % per, y = threadIdx.x / per;
-    const int64_t i = (int64_t)blockIdx.x * per + x;            // nelem is a multiple of 256
+    const int64_t i = ((int64_t)blockIdx.x * per + x) * 4;      // nelem is a multiple of 1024
     const int ntile = tiles[0];
     const int tpb = (ntile + nsplit - 1) / nsplit;
     const int nsp = tpb > 0 ? (ntile + tpb - 1) / tpb : 0;
     const float *p = partial + i;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    v4f s0 = zero4(), s1 = zero4(), s2 = zero4(), s3 = zero4();
     int sp = y;
     for (; sp + 3 * gr < nsp; sp += 4 * gr) {
-        s0 += p[(int64_t)sp * nelem];
-        s1 += p[(int64_t)(sp + gr) * nelem];
-        s2 += p[(int64_t)(sp + 2 * gr) * nelem];
-        s3 += p[(int64_t)(sp + 3 * gr) * nelem];
+        s0 += ldg4(p + (int64_t)sp * nelem);
+        s1 += ldg4(p + (int64_t)(sp + gr) * nelem);
+        s2 += ldg4(p + (int64_t)(sp + 2 * gr) * nelem);
+        s3 += ldg4(p + (int64_t)(sp + 3 * gr) * nelem);
     }
-    for (; sp < nsp; sp += gr) s0 += p[(int64_t)sp * nelem];
-    float t = (s0 + s1) + (s2 + s3);
+    for (; sp < nsp; sp += gr) s0 += ldg4(p + (int64_t)sp * nelem);
+    v4f t = (s0 + s1) + (s2 + s3);
     if (gr > 1) {
-        sh[y * per + x] = t;
+        sts4(sh + 4 * (y * per + x), t);
         __syncthreads();
         if (y != 0) return;
-        t = 0.f;
-        for (int q = 0; q < gr; ++q) t += sh[q * per + x];
+        t = zero4();
+        for (int q = 0; q < gr; ++q) t += *(const v4f *)(sh + 4 * (q * per + x));
     }
-    out[i] = t;
+    sts4(out + i, t);
 }
 
 // dW1, dgamma1, dbeta1 from Q = sum_e dz1 (1, u) and the forward's weighted moments of u.
@@ -645,10 +642,11 @@ __global__ void l1_finalize_kernel(const double *__restrict__ Q, const double *_
     const double mean = bn1[2 * C + c], rstd = bn1[3 * C + c];
     const double db = q0;
     const double dg = rstd * (w[0] * qu[0] + w[1] * qu[1] + w[2] * qu[2] - mean * q0);
-    const double mu[3] = {mom[1] / M, mom[2] / M, mom[3] / M};
-    const double m2[3][3] = {{mom[4] / M, mom[5] / M, mom[6] / M},
-                             {mom[5] / M, mom[7] / M, mom[8] / M},
-                             {mom[6] / M, mom[8] / M, mom[9] / M}};
+    const double iM = 1.0 / M;          // (one fp64 division instead of twelve: the last launch of the scale's backward chain)
+    const double mu[3] = {mom[1] * iM, mom[2] * iM, mom[3] * iM};
+    const double m2[3][3] = {{mom[4] * iM, mom[5] * iM, mom[6] * iM},
+                             {mom[5] * iM, mom[7] * iM, mom[8] * iM},
+                             {mom[6] * iM, mom[8] * iM, mom[9] * iM}};
     const double kk = (double)gamma[c] * rstd;
     for (int j = 0; j < 3; ++j) {
         const double wm2 = w[0] * m2[0][j] + w[1] * m2[1][j] + w[2] * m2[2][j];
@@ -711,8 +709,9 @@ static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, int precision, hipS
     FCN_MM_SWITCH(FCN_MM_OF(precision, false), (launch_wgrad_mm<MM, LAYER>(a, grid, m2, n2, st)));
     FCN_CHECK_LAUNCH();
     const int64_t ne = (int64_t)a.COUT * a.CIN;
+    if (((uintptr_t)out & 15) != 0) return FCN_E_BADARG;        // the reduce writes 16-byte vectors (include/fcn_hip.h)
     const int gr = nsplit >= 128 ? 16 : (nsplit >= 64 ? 8 : (nsplit >= 32 ? 4 : (nsplit >= 16 ? 2 : 1)));
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(ne / (WR_T / gr))), dim3(WR_T), 0, st, a.partial, a.tiles,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(ne / (4 * (WR_T / gr)))), dim3(WR_T), 0, st, a.partial, a.tiles,
                        nsplit, gr, ne, out);
     FCN_CHECK_LAUNCH();
     return 0;
@@ -751,20 +750,16 @@ extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, co
     const float *bn2 = ws->bn + fcn_bn_off(1, C1, C2);
     const float *bn3 = ws->bn + fcn_bn_off(2, C1, C2);
     double *bs3 = ws->bstat, *bs2 = bs3 + 2 * C3, *bsQ = bs2 + 2 * C2;
-    float *coef3 = ws->coef, *coef2 = coef3 + 5 * C3;
 
     hipError_t e = hipSuccess;          // ws->bstat was zeroed by the pool kernel of this scale's forward
 
     hipLaunchKernelGGL(poolbwd_kernel, dim3((L + PWB - 1) / PWB, C3 / 64, B), dim3(GT), 0, st, dfeat, ws->amax,
                        ws->y3, bn3, ws->gmax, bs3, L, cap, C3, C3 + d->nvec, d->nlc);
     FCN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bnbwd_finalize_kernel, dim3((C3 + 63) / 64), dim3(64), 0, st, bs3, p->gamma[2], bn3, C3, M,
-                       coef3, dgamma[2], dbeta[2]);
-    FCN_CHECK_LAUNCH();
-
     DgradArgs g;
     g.ent = (const float4 *)ws->ent; g.woff = ws->woff; g.tiles = ws->tiles; g.ewin = ws->ewin; g.L = L; g.cap = cap; g.tps = tps;
-    g.ycur = ws->y3; g.amax = ws->amax; g.gmax = ws->gmax; g.dzcur = nullptr; g.coef = coef3; g.W = p->W[2];
+    g.ycur = ws->y3; g.amax = ws->amax; g.gmax = ws->gmax; g.dzcur = nullptr; g.W = p->W[2];
+    g.cb.bstat = bs3; g.cb.gamma = p->gamma[2]; g.cb.bn = bn3; g.cb.invM = 1.0 / M; g.cb.dgamma = dgamma[2]; g.cb.dbeta = dbeta[2];
     g.dybuf = ws->dy3; g.yprev = ws->y2; g.bn_prev = bn2; g.W1 = nullptr; g.dzprev = ws->dz2; g.bstat_prev = bs2;
     g.CRED = C3; g.CPREV = C2;
     FCN_TRY(launch_dgrad<3>(g, B, d->precision, st));
@@ -772,7 +767,8 @@ extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, co
     WgradArgs w;
     w.ent = (const float4 *)ws->ent; w.woff = ws->woff; w.tiles = ws->tiles; w.L = L; w.cap = cap; w.tps = tps;
     w.partial = ws->partial;
-    w.dy = ws->dy3; w.dz = nullptr; w.ycur = nullptr; w.coef = nullptr; w.yprev = ws->y2; w.bn_prev = bn2;
+    w.dy = ws->dy3; w.dz = nullptr; w.ycur = nullptr; w.yprev = ws->y2; w.bn_prev = bn2;
+    w.cb.bstat = nullptr; w.cb.gamma = nullptr; w.cb.bn = nullptr; w.cb.invM = 1.0 / M; w.cb.dgamma = nullptr; w.cb.dbeta = nullptr;
     w.W1 = nullptr; w.COUT = C3; w.CIN = C2;
     if (two) {     // dy3 is final: conv3's weight gradient can run beside the rest of the chain
         e = hipEventRecord((hipEvent_t)events[0], st);
@@ -782,28 +778,27 @@ extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, co
     }
     FCN_TRY(launch_wgrad<3>(w, B, ws->nsplit, d->precision, sw, dW[2]));
 
-    hipLaunchKernelGGL(bnbwd_finalize_kernel, dim3((C2 + 63) / 64), dim3(64), 0, st, bs2, p->gamma[1], bn2, C2, M,
-                       coef2, dgamma[1], dbeta[1]);
-    FCN_CHECK_LAUNCH();
-
-    if (two) {     // coef2 is final (dz2 was by events[0]): conv2's weight gradient follows conv3's on the side stream
+    if (two) {     // dz2 and its BN-backward sums were final at events[0]: conv2's weight gradient follows conv3's on the side stream
         e = hipEventRecord((hipEvent_t)events[1], st);
         if (e != hipSuccess) return (int)e;
         e = hipStreamWaitEvent(sw, (hipEvent_t)events[1], 0);
         if (e != hipSuccess) return (int)e;
-        w.dy = nullptr; w.dz = ws->dz2; w.ycur = ws->y2; w.coef = coef2; w.yprev = nullptr; w.bn_prev = bn1;
+        w.dy = nullptr; w.dz = ws->dz2; w.ycur = ws->y2; w.yprev = nullptr; w.bn_prev = bn1;
+        w.cb.bstat = bs2; w.cb.gamma = p->gamma[1]; w.cb.bn = bn2;
         w.W1 = p->W[0]; w.COUT = C2; w.CIN = C1;
         FCN_TRY(launch_wgrad<2>(w, B, ws->nsplit, d->precision, sw, dW[1]));
         e = hipEventRecord((hipEvent_t)events[2], sw);
         if (e != hipSuccess) return (int)e;
     }
-    g.ycur = ws->y2; g.amax = nullptr; g.gmax = nullptr; g.dzcur = ws->dz2; g.coef = coef2; g.W = p->W[1];
+    g.ycur = ws->y2; g.amax = nullptr; g.gmax = nullptr; g.dzcur = ws->dz2; g.W = p->W[1];
+    g.cb.bstat = bs2; g.cb.gamma = p->gamma[1]; g.cb.bn = bn2; g.cb.dgamma = dgamma[1]; g.cb.dbeta = dbeta[1];
     g.dybuf = nullptr; g.yprev = nullptr; g.bn_prev = bn1; g.W1 = p->W[0]; g.dzprev = nullptr; g.bstat_prev = bsQ;
     g.CRED = C2; g.CPREV = C1;
     FCN_TRY(launch_dgrad<2>(g, B, d->precision, st));
 
     if (!two) {
-        w.dy = nullptr; w.dz = ws->dz2; w.ycur = ws->y2; w.coef = coef2; w.yprev = nullptr; w.bn_prev = bn1;
+        w.dy = nullptr; w.dz = ws->dz2; w.ycur = ws->y2; w.yprev = nullptr; w.bn_prev = bn1;
+        w.cb.bstat = bs2; w.cb.gamma = p->gamma[1]; w.cb.bn = bn2;
         w.W1 = p->W[0]; w.COUT = C2; w.CIN = C1;
         FCN_TRY(launch_wgrad<2>(w, B, ws->nsplit, d->precision, st, dW[1]));
     }

@@ -62,10 +62,13 @@ __global__ void bn_finalize_kernel(const double *__restrict__ stat, const float 
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    // (one fp64 division per thread, none per statistic, and no software sqrt: this launch sits between two layers of a
+    // latency-bound chain)
     double mean, var;
     if (training) {
-        mean = stat[c] / M;
-        var = stat[C + c] / M - mean * mean;
+        const double invM = 1.0 / M;
+        mean = stat[c] * invM;
+        var = stat[C + c] * invM - mean * mean;
         if (var < 0.0) var = 0.0;
         if (rmean) {
             rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mean);
@@ -76,7 +79,7 @@ __global__ void bn_finalize_kernel(const double *__restrict__ stat, const float 
         mean = rmean[c];
         var = rvar[c];
     }
-    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double rstd = fcn_rsqrt64(var + (double)eps);
     const double s = (double)gamma[c] * rstd;
     bn[c] = (float)s;
     bn[C + c] = (float)((double)beta[c] - mean * s);
@@ -96,7 +99,45 @@ struct FwdArgs {
     float *y;              // (B,cap,COUT)
     double *stat;          // sum[COUT], sumsq[COUT] or nullptr (eval)
     int L, cap, CIN, COUT, tps;
+    // MODE 1 with gamma_in set: the BN in front of this conv is FINALISED BY ITS CONSUMER -- every workgroup derives scale /
+    // shift in its prologue from the batch sums (training) or the running statistics (eval) instead of waiting for a
+    // one-workgroup launch between the two GEMMs; workgroup 0 also publishes scale, shift, mean, rstd (the backward reads
+    // them) and updates the running statistics.  gamma_in null: bn_in holds finished scale / shift.
+    const double *stat_in;      // sum[CIN], sumsq[CIN], or nullptr (eval)
+    const float *gamma_in, *beta_in;
+    float *rmean_in, *rvar_in;
+    int64_t *nbt_in;
+    float *bn_pub;              // 4 x CIN
+    double M;
+    float eps, momentum;
 };
+
+__device__ __forceinline__ void fwd_bn_in(const FwdArgs &a, int i, bool pub, float &fs, float &ft)
+{
+    const int C = a.CIN;
+    double mean, var;
+    if (a.stat_in) {
+        const double invM = 1.0 / a.M;
+        mean = a.stat_in[i] * invM;
+        var = a.stat_in[C + i] * invM - mean * mean;
+        if (var < 0.0) var = 0.0;
+    } else {
+        mean = a.rmean_in[i];
+        var = a.rvar_in[i];
+    }
+    const double rstd = fcn_rsqrt64(var + (double)a.eps);
+    const double sc = (double)a.gamma_in[i] * rstd;
+    fs = (float)sc;
+    ft = (float)((double)a.beta_in[i] - mean * sc);
+    if (pub) {
+        a.bn_pub[i] = fs; a.bn_pub[C + i] = ft; a.bn_pub[2 * C + i] = (float)mean; a.bn_pub[3 * C + i] = (float)rstd;
+        if (a.stat_in && a.rmean_in) {
+            a.rmean_in[i] = (float)((1.0 - a.momentum) * a.rmean_in[i] + a.momentum * mean);
+            a.rvar_in[i] = (float)((1.0 - a.momentum) * a.rvar_in[i] + a.momentum * var * (a.M / (a.M - 1.0)));
+            if (i == 0 && a.nbt_in) a.nbt_in[0] += 1;
+        }
+    }
+}
 
 // MODE 0: operand rows are conv1+BN1+ReLU of the entries (computed here); MODE 1: BN+ReLU of aprev.
 // Workgroup = 2 x WN waves; tile = 128 rows x (32*NT*WN) output channels.  WN = 4 (512 threads) shares one
@@ -127,6 +168,14 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
     // live (row tile, column tile) pairs in XCD order, column tiles fastest: the workgroups that stage the same rows run
     // back to back on one L2
     const int ny = a.COUT / TN;
+    if constexpr (MODE == 1) {
+        if (blockIdx.x == 0 && a.gamma_in) {     // workgroup 0 always exists (the grid is padded) whatever the live-tile list holds
+            for (int i = tid; i < a.CIN; i += NTHR) {
+                float fs, ft;
+                fwd_bn_in(a, i, true, fs, ft);
+            }
+        }
+    }
     const int xt = fcn_xcd_tile(blockIdx.x, SUB * a.tiles[0] * ny);
     if (xt < 0) return;
     const int bxi = xt / ny, byi = xt % ny;
@@ -142,8 +191,14 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
     const int CIN = a.CIN, COUT = a.COUT;
 
     for (int i = tid; i < CIN; i += NTHR) {
-        const float s = a.bn_in[i];
-        tS[i] = a.bn_in[CIN + i];
+        float s, t;
+        if (MODE == 1 && a.gamma_in) {
+            fwd_bn_in(a, i, false, s, t);
+        } else {
+            s = a.bn_in[i];
+            t = a.bn_in[CIN + i];
+        }
+        tS[i] = t;
         if constexpr (MODE == 0) {
             sS[3 * i] = s * a.W1[3 * i];
             sS[3 * i + 1] = s * a.W1[3 * i + 1];
@@ -492,15 +547,15 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
     a.ent = (const float4 *)ws->ent; a.woff = ws->woff; a.tiles = ws->tiles; a.L = L; a.cap = cap; a.tps = (cap + 127) / 128;
     a.aprev = nullptr; a.bn_in = bn1; a.W1 = p->W[0]; a.W = p->W[1]; a.y = ws->y2;
     a.stat = tr ? st2 : nullptr; a.CIN = C1; a.COUT = C2;
+    a.stat_in = nullptr; a.gamma_in = a.beta_in = nullptr; a.rmean_in = a.rvar_in = nullptr; a.nbt_in = nullptr; a.bn_pub = nullptr;
+    a.M = M; a.eps = d->eps; a.momentum = d->momentum;
     FCN_TRY(launch_fwd_gemm<0>(a, B, d->precision, st));
 
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C2 + 63) / 64), dim3(64), 0, st, st2, p->gamma[1], p->beta[1],
-                       p->running_mean[1], p->running_var[1], p->num_batches_tracked[1], C2, tr, d->eps,
-                       d->momentum, M, bn2);
-    FCN_CHECK_LAUNCH();
-
+    // BN2 is finalised by conv3's workgroups (no launch in between)
     a.aprev = ws->y2; a.bn_in = bn2; a.W1 = nullptr; a.W = p->W[2]; a.y = ws->y3;
     a.stat = tr ? st3 : nullptr; a.CIN = C2; a.COUT = C3;
+    a.stat_in = tr ? st2 : nullptr; a.gamma_in = p->gamma[1]; a.beta_in = p->beta[1];
+    a.rmean_in = p->running_mean[1]; a.rvar_in = p->running_var[1]; a.nbt_in = p->num_batches_tracked[1]; a.bn_pub = bn2;
     FCN_TRY(launch_fwd_gemm<1>(a, B, d->precision, st));
 
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C3 + 63) / 64), dim3(64), 0, st, st3, p->gamma[2], p->beta[2],
@@ -544,6 +599,8 @@ extern "C" int fcn_pn_conv_fwd(const fcn_pn_desc *d, const fcn_pn_params *p, con
     double *st2 = ws->stat + FCN_STAT_L2, *st3 = st2 + 2 * C2;
     FwdArgs a;
     a.ent = (const float4 *)ws->ent; a.woff = ws->woff; a.tiles = ws->tiles; a.L = L; a.cap = cap; a.tps = (cap + 127) / 128;
+    a.stat_in = nullptr; a.gamma_in = a.beta_in = nullptr; a.rmean_in = a.rvar_in = nullptr; a.nbt_in = nullptr; a.bn_pub = nullptr;
+    a.M = 1.0; a.eps = d->eps; a.momentum = d->momentum;       // the BN in front is read finished from ws->bn
     if (layer == 2) {
         a.aprev = nullptr; a.bn_in = ws->bn + fcn_bn_off(0, C1, C2); a.W1 = p->W[0]; a.W = p->W[1]; a.y = ws->y2;
         a.stat = with_stats ? st2 : nullptr; a.CIN = C1; a.COUT = C2;

@@ -148,7 +148,8 @@ int fcn_pn_group_compact(int nscale, const fcn_pn_desc *const *d, const fcn_pn_p
 int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, const int32_t *cnt,
                    const float *one_hot, const fcn_pn_ws *ws, float *feat, void *stream);
 
-/* Backward: dfeat (B, C3+nvec, L) -> dW[3], dgamma[3], dbeta[3] (overwritten, not accumulated). */
+/* Backward: dfeat (B, C3+nvec, L) -> dW[3], dgamma[3], dbeta[3] (overwritten, not accumulated).  dW[1] and dW[2] must be
+ * 16-byte aligned (FCN_E_BADARG otherwise): the fixed-order sum of the split partials writes 16-byte vectors. */
 int fcn_pn_backward(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dfeat,
                     const fcn_pn_ws *ws, float *dW[3], float *dgamma[3], float *dbeta[3], void *stream);
 
