@@ -294,30 +294,16 @@ def cpu_baseline(batch, npoint, cfg_name):
             "variants": variants, "host_cpus": ncpu}
 
 
-def main():
-    a = parse()
+def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=None, npoint=None):
+    """Builds the model + flat train state for one configuration, captures the step into hipGraph(s), warms up and times
+    rounds * steps replays inside ONE barrier + synchronize bracket.  Returns a dict with the timing and the live objects
+    (model / state / data) the roofline table needs."""
     from frustum_convnet_amd import dist as fdist, precision as fprec
-    if a.precision:
-        fprec.set_precision(a.precision)
-    prec = fprec.get_precision()
-    npoint = a.npoint or CFGS[a.cfg][3]
-    # FCN_BENCH_BACKEND=gloo + FCN_BENCH_ONE_DEVICE=1: rehearsal of the N > 1 path with every rank on GPU 0 (a 1-GPU box
-    # cannot form an RCCL communicator); the driver's multi-GPU runs leave both unset.
-    one_dev = os.environ.get("FCN_BENCH_ONE_DEVICE", "0") == "1"
-    if one_dev:
-        torch.cuda.set_device(0)
-    rank, world, local = fdist.init_from_env(backend=os.environ.get("FCN_BENCH_BACKEND") or None)
-    if one_dev:
-        local = 0
-    if world != a.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
     from frustum_convnet_amd.train_state import FlatTrainState
-    model = build_model(dev, a.cfg)
+    fprec.set_precision(prec)
+    batch = batch or a.batch
+    npoint = npoint or CFGS[cfg_name][3]
+    model = build_model(dev, cfg_name)
     if world > 1:
         fdist.broadcast_state(model, 0)
     # reference optimiser: Adam(lr 1e-3, weight_decay 1e-4), train/train_net_det.py:321-339.  Parameters, gradients and
@@ -325,7 +311,7 @@ def main():
     # and the step one streaming kernel (capturable: step counter and hyper-parameters live on the device).
     state = FlatTrainState(model, lr=1e-3, weight_decay=1e-4, world=world)
     optim = not a.no_optim
-    data = make_data(a.cfg, a.batch, npoint, 1234 + rank, dev)
+    data = make_data(cfg_name, batch, npoint, 1234 + rank, dev)
     overlap = world > 1 and not a.no_overlap and not a.eager
     model.split_backward = overlap
 
@@ -360,12 +346,11 @@ def main():
                 with torch.cuda.graph(gA, capture_error_mode=mode):
                     losses, _ = model(data)
                     loss = losses["total_loss"]
-                    feats, leaves = model._split
-                    model._split = None
+                    pending = model.take_split()
                     from frustum_convnet_amd.loss_fused import unit_grad
                     loss.backward(gradient=unit_grad(loss.device))
                 with torch.cuda.graph(gB, pool=gA.pool(), capture_error_mode=mode):
-                    torch.autograd.backward(list(feats), [l.grad for l in leaves])
+                    pending.backward()
                 graphs = (gA, gB)
             else:
                 g = torch.cuda.CUDAGraph()
@@ -404,16 +389,16 @@ def main():
                 if optim:
                     state.adam_step()
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
-    # length of one K-step window -> number of rounds for a timed region of at least --min-time seconds
+    # length of one K-step window -> number of rounds for a timed region of at least min_time seconds
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
     probe = time.perf_counter() - t0
-    rounds = max(1, int(np.ceil(a.min_time / max(probe, 1e-6))))
+    rounds = max(1, int(np.ceil(min_time / max(probe, 1e-6))))
     if world > 1:
         rt = torch.tensor([rounds], device=dev)
         torch.distributed.all_reduce(rt, op=torch.distributed.ReduceOp.MAX)
@@ -423,7 +408,7 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    for _ in range(rounds * a.steps):
+    for _ in range(rounds * steps):
         step()
     e1.record()
     torch.cuda.synchronize()
@@ -435,9 +420,68 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
     wall = float(tt.item())
-    nstep = rounds * a.steps
-    ms_per_step = wall * 1e3 / nstep
-    final_loss = float(loss.item())
+    nstep = rounds * steps
+    Ls = [data["center_ref%d" % i].shape[2] for i in range(1, 6) if ("center_ref%d" % i) in data]
+    return {"model": model, "state": state, "data": data, "graphs": graphs, "overlap": overlap, "optim": optim,
+            "rounds": rounds, "nstep": nstep, "wall": wall, "ms_per_step": wall * 1e3 / nstep,
+            "gpu_event_ms_per_step": e0.elapsed_time(e1) / nstep, "final_loss": float(loss.item()),
+            "batch": batch, "npoint": npoint, "Ls": Ls}
+
+
+def workload_name(cfg_name, batch, npoint, Ls, optim=True, extra=""):
+    return "%s KITTI-%s, batch=%d/GPU, Npoint=%d, L=(%s), train fwd+bwd%s%s" % (
+        CFGS[cfg_name][0], cfg_name, batch, npoint, ",".join(str(v) for v in Ls), "+Adam" if optim else "", extra)
+
+
+# the other BASELINE.json configurations (4: people, 5: refine; 2's bf16 throughput mode) and SURVEY f-4's SUN-RGBD variant,
+# each timed in a short window of the same kind after the headline line's measurement (N = 1 only)
+OTHER_CONFIGS = (("people", "split"), ("refine", "split"), ("sunrgbd", "split"), ("car", "bf16"))
+
+
+def other_configs(a, dev, min_time=0.35):
+    out = []
+    for cfg_name, prec in OTHER_CONFIGS:
+        try:
+            m = measure(a, cfg_name, prec, 20, 10, min_time, dev, 0, 1)
+            out.append({"cfg": cfg_name, "precision": prec, "dtype": "bf16" if prec == "bf16" else "f32",
+                        "workload": workload_name(cfg_name, m["batch"], m["npoint"], m["Ls"], m["optim"]),
+                        "value": round(m["batch"] / (m["ms_per_step"] / 1e3), 2), "unit": "frustums/s",
+                        "ms_per_step": round(m["ms_per_step"], 4), "timed_steps": m["nstep"],
+                        "timed_seconds": round(m["wall"], 4), "final_loss": round(m["final_loss"], 5)})
+            del m
+        except Exception as e:  # noqa
+            out.append({"cfg": cfg_name, "precision": prec, "error": "%s: %s" % (type(e).__name__, e)})
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    a = parse()
+    from frustum_convnet_amd import dist as fdist, precision as fprec
+    if a.precision:
+        fprec.set_precision(a.precision)
+    prec = fprec.get_precision()
+    npoint = a.npoint or CFGS[a.cfg][3]
+    # FCN_BENCH_BACKEND=gloo + FCN_BENCH_ONE_DEVICE=1: rehearsal of the N > 1 path with every rank on GPU 0 (a 1-GPU box
+    # cannot form an RCCL communicator); the driver's multi-GPU runs leave both unset.
+    one_dev = os.environ.get("FCN_BENCH_ONE_DEVICE", "0") == "1"
+    if one_dev:
+        torch.cuda.set_device(0)
+    rank, world, local = fdist.init_from_env(backend=os.environ.get("FCN_BENCH_BACKEND") or None)
+    if one_dev:
+        local = 0
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    m = measure(a, a.cfg, prec, a.steps, a.warmup, a.min_time, dev, rank, world, npoint=npoint)
+    model, state, data, graphs, overlap, optim = m["model"], m["state"], m["data"], m["graphs"], m["overlap"], m["optim"]
+    rounds, nstep, wall, ms_per_step, final_loss = m["rounds"], m["nstep"], m["wall"], m["ms_per_step"], m["final_loss"]
+    gpu_event_ms = m["gpu_event_ms_per_step"]
 
     if rank != 0:
         return

@@ -1,6 +1,7 @@
 // ConvFeatNet + heads (models/det_base.py:163-224,250-251,365-368) as hand-written HIP: every Conv1d /
-// ConvTranspose1d (+ BatchNorm1d + ReLU) is one implicit-GEMM launch on fp32 MFMA over position-major (NLC)
-// activations, forward and backward.
+// ConvTranspose1d (+ BatchNorm1d + ReLU) is one implicit-GEMM launch over position-major (NLC) activations, forward and
+// backward, on the 16-bit matrix cores with split fp32 operands (gemm_tile.h: fp16x3 forward, bf16x3 backward, fp32
+// accumulate; exact fp32 MFMA and single-term bf16 are the other two operand modes).
 //
 // The reference runs this part through cuDNN/ATen on (B,C,L) tensors: 13 convs + 13 BN + ReLUs + cats, each its
 // own kernel(s); on MI355X the MIOpen path spends most of its time in layout transposes and tiny elementwise

@@ -1,11 +1,13 @@
-// 32x32x2 f32 MFMA tile machinery shared by the forward / dgrad / wgrad kernels.
+// MFMA tile machinery shared by the PointNet forward / dgrad / wgrad kernels and (operand encoding, fragment reads) the FCN.
 //
 // Workgroup = 256 threads = 4 waves arranged 2 (M) x 2 (N); each wave owns MT x NT MFMA tiles of
 // 32x32, i.e. the workgroup tile is (64*MT) x (64*NT).  Operands are staged k-major in LDS
 // ([k][m] and [k][n], leading dimension padded to an odd number of dwords) so that the MFMA operand
-// reads -- lane l needs A[m0 + (l&31)][k + (l>>5)] and B[k + (l>>5)][n0 + (l&31)] -- are 32 consecutive
-// dwords per half-wave: conflict-free ds_read_b32.  v_mfma_f32_32x32x2_f32 is exact fp32 (bitwise an
-// fmaf chain, cdna guide section 3), which is what keeps the logits within 1e-4 of the fp32 reference.
+// reads are 32 consecutive dwords per half-wave: conflict-free ds_read_b32.
+// Default arithmetic (MM_F16X3 / MM_BF16X3 below): every fp32 operand is split into two 16-bit parts while it is staged and a
+// product is three v_mfma_f32_32x32x16_{f16,bf16} with fp32 accumulation -- fp32-class results (logits within 1e-4 of the
+// fp32 reference, parity-tested) at 5.3x the fp32 matrix rate.  MM_F32 (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain)
+// is kept as the A/B reference mode, MM_BF16X1 as the throughput mode.
 #pragma once
 #include "fcn_common.h"
 

@@ -100,6 +100,11 @@ class PointNetModule(nn.Module):
         from .pointnet_fused import dense_from_entries
         params, bufs = self._param_pack()
         bn = self.conv1[1]
+        if torch.is_grad_enabled() and (pc.requires_grad or any(p.requires_grad for p in params)):
+            # models/det_base.py:62-103 returns a tensor with a graph; this dense view has none -- refuse rather than hand a
+            # caller that trains through the module API silently-missing gradients
+            raise RuntimeError("PointNetModule.forward is an inspection API without autograd: call it under torch.no_grad() "
+                               "(training goes through forward_pooled / PointNetFeat, which are differentiable)")
         with torch.no_grad():
             return dense_from_entries(self._pool, self.dist, self.nsample, self.training, bn.eps,
                                       bn_momentum(bn),
@@ -268,6 +273,21 @@ class ConvFeatNet(nn.Module):
         return torch.cat([ups[0]] + [u[:, :, :n] for u in ups[1:]], 1)
 
 
+class _PendingPointNetBackward:
+    """Phase 2 of a split backward (PointNetDet.take_split)."""
+
+    def __init__(self, model, feats, leaves):
+        self.model, self.feats, self.leaves = model, feats, leaves
+
+    def backward(self):
+        if any(l.grad is None for l in self.leaves):
+            raise RuntimeError("phase 2 of the split backward before phase 1: differentiate the loss first")
+        torch.autograd.backward(list(self.feats), [l.grad for l in self.leaves])
+        if self.model._pending_split is self:
+            self.model._pending_split = None
+        self.feats = self.leaves = None
+
+
 class PointNetDet(nn.Module):
     """Whole pipeline (reference: models/det_base.py:228-525)."""
 
@@ -316,6 +336,7 @@ class PointNetDet(nn.Module):
         # overlaps the PointNet backward (train/train_net_det.py:126-128 + nn.DataParallel's reduce, :308-309)
         self.split_backward = False
         self._split = None
+        self._pending_split = None
         self._zero_cache = {}
         self._loss_scratch = None
         from .fcn_fused import CnPool
@@ -366,19 +387,32 @@ class PointNetDet(nn.Module):
             return self.backward_split(loss)
         loss.backward(gradient=unit_grad(loss.device))
 
+    def take_split(self):
+        """Hands over phase 2 of a split backward (the PointNet scales' part of the graph) as an object with .backward();
+        the caller differentiates the loss itself first (phase 1).  Until the returned object's backward() has run, the
+        model counts as holding a half-finished backward: the next forward and FlatTrainState's optimiser step raise."""
+        if self._split is None:
+            raise RuntimeError("take_split needs a training forward with model.split_backward = True")
+        pending = _PendingPointNetBackward(self, *self._split)
+        self._split = None
+        self._pending_split = pending
+        return pending
+
+    def backward_pending(self):
+        """True while phase 2 of a split backward has not run: the PointNet gradients in the flat buffer are the previous
+        step's (the HIP backward overwrites, nothing zeroes them)."""
+        return self._split is not None or self._pending_split is not None
+
     def backward_split(self, loss, between=None):
         """loss.backward() in two phases (needs split_backward = True at forward time): phase 1 differentiates the loss
         tail, heads and ConvFeatNet (their parameter gradients are final when it returns), `between()` runs, phase 2
         differentiates the PointNet scales.  Numerically identical to loss.backward()."""
-        if self._split is None:
-            raise RuntimeError("backward_split needs a training forward with model.split_backward = True")
         from .loss_fused import unit_grad
-        feats, leaves = self._split
-        self._split = None
+        pending = self.take_split()
         loss.backward(gradient=unit_grad(loss.device))
         if between is not None:
             between()
-        torch.autograd.backward(list(feats), [l.grad for l in leaves])
+        pending.backward()
 
     def _slice_output(self, output):
         nb, ns = self.num_bins, self.num_size_cluster
@@ -413,7 +447,12 @@ class PointNetDet(nn.Module):
         mean_size_array = self._mean_size.to(device=point_cloud.device, dtype=point_cloud.dtype)
 
         logits64 = None
-        self._split = None
+        if self.backward_pending():
+            # (a plain loss.backward() after a split forward differentiates only the loss tail, heads and ConvFeatNet)
+            self._split = self._pending_split = None
+            raise RuntimeError("PointNetDet: the previous forward ran with split_backward = True and its backward was never "
+                               "finished (use model.backward(loss) / backward_split(loss) / take_split().backward()): the "
+                               "PointNet gradients would silently be the previous step's")
         if self.fused_fcn and not point_cloud.is_cuda:
             raise RuntimeError("frustum_convnet_amd: the hot path runs on an MI355X only (got a %s tensor); there is no "
                                "CPU fallback" % point_cloud.device)

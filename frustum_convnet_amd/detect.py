@@ -9,6 +9,7 @@ No CPU fallback: CPU tensors raise.
 """
 import ctypes
 
+import numpy as np
 import torch
 
 from . import _native
@@ -42,8 +43,20 @@ def decode_detections(logits, center_ref2, mean_size, rot_angle, ref_center=None
     lg = logits.detach().contiguous().float()
     assert lg.shape[0] == B * L2
     dev = lg.device
-    f = lambda t: None if t is None else t.detach().reshape(-1).contiguous().float()
-    ref2, ms, rot, rc, rgb = center_ref2.detach().contiguous().float(), f(mean_size), f(rot_angle), f(ref_center), f(rgb_prob)
+    # every optional tensor may arrive as the reference's test loader yields it -- a CPU tensor (train/test_net_det.py:201-214)
+    # -- and is moved to the logits' device here: a host pointer handed to the kernel faults the GPU
+    def f(t, shape, what):
+        if t is None:
+            return None
+        t = t.detach().to(device=dev, dtype=torch.float32)
+        if t.numel() != int(np.prod(shape)):
+            raise ValueError("decode_detections: %s has %d elements, expected shape %s" % (what, t.numel(), tuple(shape)))
+        return t.reshape(-1).contiguous()
+    if tuple(center_ref2.shape[:2]) != (B, 3):
+        raise ValueError("decode_detections: center_ref2 must be (B,3,L2), got %s" % (tuple(center_ref2.shape),))
+    ref2 = center_ref2.detach().to(device=dev, dtype=torch.float32).contiguous()
+    ms, rot = f(mean_size, (num_sizes, 3), "mean_size"), f(rot_angle, (B,), "rot_angle")
+    rc, rgb = f(ref_center, (B, 3), "ref_center"), f(rgb_prob, (B,), "rgb_prob")
     dets = torch.empty((B * L2, 8), dtype=torch.float32, device=dev)
     valid = torch.empty((B * L2,), dtype=torch.int32, device=dev)
     p = lambda t: None if t is None else t.data_ptr()

@@ -235,6 +235,11 @@ class RefineInputBuilder:
         self.random_flip, self.random_shift, self.one_hot = bool(random_flip), bool(random_shift), bool(one_hot)
         self.device = torch.device(device)
         self.classes = DATASET_INFO[cfg.DATA.DATASET_NAME].CLASSES
+        if not cfg.DATA.RTC:
+            # provider_sample_refine.py:225-262: without RTC generate_ref() runs on the UN-rotated predicted box (z extent, a
+            # line through the box) and rot_angle / ref_center are zeros -- a different geometry from the kernel's
+            raise NotImplementedError("RefineInputBuilder implements the cfg.DATA.RTC = True geometry only (every shipped "
+                                      "refine cfg sets it: cfgs/refine_car.yaml, cfgs/refine_people.yaml)")
 
     def build(self, records, draws=None, with_labels=True):
         """records: dicts with REFINE_KEYS (points (n,>=3) float32 rect camera coordinates; box3d (8,3), heading, size (l,w,h)
@@ -292,6 +297,10 @@ class RefineInputBuilder:
             oh = np.zeros((B, len(self.classes)), dtype=np.float32)
             oh[np.arange(B), size_class] = 1.0
             out["one_hot"] = up(oh)
+        if not with_labels:
+            # from_rgb_detection path (provider_sample_refine.py:404-419): the 2-D detector's score travels with the sample and
+            # becomes the detection score's prior in detect() (train/test_net_det.py:214,279)
+            out["rgb_prob"] = up(np.asarray([float(r.get("prob", 1.0)) for r in records], dtype=np.float32).reshape(B, 1))
         return out
 
 

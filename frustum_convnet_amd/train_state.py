@@ -16,6 +16,7 @@ Parameters, gradients and both Adam moments are four contiguous fp32 buffers (13
     leaving only the small PointNet bucket's update at the end of the step (bench.py does that).
 """
 import ctypes
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -37,6 +38,11 @@ class FlatTrainState:
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, world=1, group=None):
         named = _ordered_parameters(model)
         assert named, "model has no parameters"
+        self._model = weakref.ref(model)
+        # position of every flat-order parameter in model.parameters() order: that is the index torch.optim.Adam (and a
+        # checkpoint of the reference, train/train_net_det.py:353,387) uses for its per-parameter state
+        model_order = {n: i for i, (n, _) in enumerate(model.named_parameters())}
+        self.param_index = [model_order[n] for n, _ in named]
         params = [p for _, p in named]
         dev = params[0].device
         for p in params:
@@ -114,6 +120,10 @@ class FlatTrainState:
     def adam_step_bucket(self, i):
         """The optimiser step of bucket i alone (its gradients must be final -- and reduced for world > 1 -- on the current
         stream).  Every bucket must be stepped exactly once per training step, in any order, on any streams."""
+        m = self._model()
+        if m is not None and getattr(m, "backward_pending", None) is not None and m.backward_pending():
+            raise RuntimeError("FlatTrainState: the model holds a half-finished split backward (forward with split_backward = "
+                               "True, then only phase 1 differentiated): the PointNet gradients are the previous step's")
         if self.device.type != "cuda":
             raise RuntimeError("frustum_convnet_amd: the optimiser step is a HIP kernel (MI355X only); "
                                "there is no CPU fallback")
@@ -146,27 +156,53 @@ class FlatTrainState:
 
     # ---- checkpointing (reference: optimizer.state_dict() saved / restored at train/train_net_det.py:353,387)
     def state_dict(self):
-        """torch.optim.Adam-compatible state: {'state': {i: {step, exp_avg, exp_avg_sq}}, 'param_groups': [...]}, indexed in
-        this object's parameter order (self.names)."""
+        """torch.optim.Adam's state layout: {'state': {i: {step, exp_avg, exp_avg_sq}}, 'param_groups': [...]} with i the
+        position of the parameter in model.parameters() -- the order Adam(model.parameters()) of the reference indexes its
+        state by, NOT the order of the flat buffer (which keeps the head tensors adjacent at its tail).  'names' lists the
+        parameter names in that same order (an extra key torch ignores)."""
         step = int(self.step_count.item())
         hy = [float(v) for v in self.hyper.tolist()]
-        state = {}
-        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+        state, names = {}, [None] * len(self.params)
+        for k, (p, o) in enumerate(zip(self.params, self.offsets)):
             n = p.numel()
+            i = self.param_index[k]
+            names[i] = self.names[k]
             state[i] = {"step": torch.tensor(float(step)), "exp_avg": self.exp_avg[o:o + n].view(p.shape).clone(),
                         "exp_avg_sq": self.exp_avg_sq[o:o + n].view(p.shape).clone()}
+        state = {i: state[i] for i in sorted(state)}
         group = {"lr": hy[0], "betas": (hy[1], hy[2]), "eps": hy[3], "weight_decay": hy[4], "amsgrad": False,
                  "params": list(range(len(self.params)))}
-        return {"state": state, "param_groups": [group], "names": list(self.names)}
+        return {"state": state, "param_groups": [group], "names": names}
 
     def load_state_dict(self, sd):
+        """Accepts this object's state_dict() and torch.optim.Adam(model.parameters()).state_dict() of the same model (the
+        reference's checkpoints).  When 'names' is present the entries are matched BY NAME; every moment's shape is checked
+        against its parameter before anything is copied."""
         group = sd["param_groups"][0]
         if len(group["params"]) != len(self.params):
             raise ValueError("optimizer state has %d parameters, model has %d" % (len(group["params"]), len(self.params)))
+        names = sd.get("names")
+        if names is not None:
+            if sorted(names) != sorted(self.names):
+                raise ValueError("optimizer state names do not match the model's parameters")
+            where = {n: i for i, n in enumerate(names)}
+            index = [where[n] for n in self.names]
+        else:
+            index = self.param_index
+        ids = group["params"]
+        entries = []
+        for k, p in enumerate(self.params):
+            key = ids[index[k]]
+            st = sd["state"].get(key, sd["state"].get(str(key)))
+            if st is not None:
+                for f in ("exp_avg", "exp_avg_sq"):
+                    if tuple(st[f].shape) != tuple(p.shape):
+                        raise ValueError("optimizer state entry %s (%s): %s has shape %s, the parameter %s" % (
+                            key, self.names[k], f, tuple(st[f].shape), tuple(p.shape)))
+            entries.append(st)
         steps = set()
         with torch.no_grad():
-            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
-                st = sd["state"].get(i, sd["state"].get(str(i)))
+            for st, p, o in zip(entries, self.params, self.offsets):
                 n = p.numel()
                 if st is None:
                     self.exp_avg[o:o + n].zero_()

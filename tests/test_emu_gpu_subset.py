@@ -42,6 +42,8 @@ CASES = [
     ("test_gpu_box", "test_loss_tail_iou_metrics_match_oracle", ("sunrgbd_b4_n1024",)),
     ("test_gpu_box", "test_all_background_batch_is_finite", ()),
     ("test_gpu_box", "test_detect_pipeline_matches_oracle", ()),
+    ("test_gpu_box", "test_detect_matches_reference_test_loop", ("full",)),
+    ("test_gpu_box", "test_half_finished_split_backward_is_refused", ()),
     ("test_gpu_inputs", "test_golden_batch_with_recorded_draws", ()),
     ("test_gpu_inputs", "test_same_numpy_seed_reproduces_the_reference_batch", ()),
     ("test_gpu_inputs", "test_against_oracle_without_augmentation_and_nearest_fallback", (False, False)),

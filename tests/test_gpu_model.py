@@ -1,4 +1,4 @@
-"""-m gpu: the whole drop-in PointNetDet (HIP grouping + fused PointNet scales, MIOpen FCN, loss tail)
+"""-m gpu: the whole drop-in PointNetDet (fused front + PointNet scales, implicit-GEMM ConvFeatNet + heads, loss tail -- all HIP)
 against golden vectors captured from the reference's own modules (tests/golden/make_golden.py).
 Tolerances (north_star): idx bit-exact (test_gpu_grouping), raw cls/box logits abs 1e-4 fp32."""
 import numpy as np
@@ -109,7 +109,10 @@ def test_dense_module_api_matches_oracle():
     m.train()
     pc = torch.from_numpy(data_np["point_cloud"]).cuda()
     ref = torch.from_numpy(data_np["center_ref3"]).cuda()
-    out = m.feat_net.pointnet3(pc, None, ref)
+    with pytest.raises(RuntimeError, match="without autograd"):       # the reference's return carries a graph;
+        m.feat_net.pointnet3(pc, None, ref)                            # this one does not and says so
+    with torch.no_grad():
+        out = m.feat_net.pointnet3(pc, None, ref)
     sd = golden_state_dict(g)
     exp, _, _ = det_ref.pointnet_module(torch.from_numpy(data_np["point_cloud"]), torch.from_numpy(data_np["center_ref3"]),
                                         sd, "feat_net.pointnet3", 1.0, 64, True)

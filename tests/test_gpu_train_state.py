@@ -223,11 +223,12 @@ def test_two_graph_overlapped_step_equals_single_graph():
     gA, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
     with torch.cuda.graph(gA):
         lo2, _ = m2(data)
-        feats, leaves = m2._split
-        m2._split = None
+        pending = m2.take_split()
         lo2["total_loss"].backward(gradient=unit_grad(lo2["total_loss"].device))
+        assert m2.backward_pending()
     with torch.cuda.graph(gB, pool=gA.pool()):
-        torch.autograd.backward(list(feats), [l.grad for l in leaves])
+        pending.backward()
+    assert not m2.backward_pending()
     assert [n for n, _, _ in s2.buckets] == ["fcn+heads", "pointnet"]
     for _ in range(5):
         g1.replay()

@@ -165,7 +165,7 @@ def test_cfg_merge_semantics(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/cfgs"), reason="reference only exists in the build container")
-@pytest.mark.parametrize("name", ["det_sample.yaml", "det_sample_people.yaml", "refine_car.yaml",
+@pytest.mark.parametrize("name", ["det_sample.yaml", "det_sample_people.yaml", "refine_car.yaml", "refine_people.yaml",
                                   "det_sample_sunrgbd.yaml"])
 def test_reference_yaml_loads_unchanged(name):
     from frustum_convnet_amd import config
@@ -176,6 +176,21 @@ def test_reference_yaml_loads_unchanged(name):
         assert cfg.MODEL.FILE == "models/det_base_sunrgbd.py" and cfg.DATA.NUM_SAMPLES == 2048
     else:
         assert len(cfg.DATA.HEIGHT_HALF) == 4 and cfg.TRAIN.WEIGHT_DECAY == 0.0001
+    config.reset_cfg()
+
+
+def test_shipped_yamls_carry_the_reference_hot_path_keys():
+    """Every cfg the reference ships for this path has a counterpart under cfgs/ with the same hot-path values (strides, window
+    half heights, N, class selection, IoU threshold): cfgs/*.yaml is the surface north_star keeps."""
+    from frustum_convnet_amd import config
+    want = {"det_sample.yaml": ((0.25, 0.5, 1.0, 2.0), 1024, True, 0.7), "det_sample_people.yaml": ((0.1, 0.2, 0.4, 0.8), 1024, False, 0.5),
+            "refine_car.yaml": ((0.1, 0.2, 0.4, 0.8), 512, True, 0.7), "refine_people.yaml": ((0.05, 0.1, 0.2, 0.4), 512, False, 0.5)}
+    for name, (strides, n, car, thr) in want.items():
+        cfg = config.reset_cfg()
+        config.merge_cfg_from_file(os.path.join(ROOT, "cfgs", name))
+        assert cfg.DATA.STRIDE == strides and cfg.DATA.HEIGHT_HALF == strides and cfg.DATA.NUM_SAMPLES == n, name
+        assert cfg.DATA.CAR_ONLY is car and cfg.DATA.PEOPLE_ONLY is (not car) and cfg.IOU_THRESH == thr, name
+        assert cfg.DATA.RTC is True and cfg.DATA.WITH_EXTRA_FEAT is False
     config.reset_cfg()
 
 
@@ -255,3 +270,52 @@ def test_flat_train_state_layout_on_cpu():
         st.adam_step()
     st.release()
     assert all(p.grad is None for p in st.params)
+
+
+def test_optimizer_state_interchanges_with_torch_adam():
+    """the reference checkpoints optim.Adam(model.parameters()).state_dict() (train/train_net_det.py:353,387), whose
+    per-parameter state is indexed in model.parameters() order (..., reg_out.weight, reg_out.bias, cls_out.weight,
+    cls_out.bias).  FlatTrainState keeps the head tensors adjacent in ITS buffer but emits / accepts that order."""
+    import pytest
+    from frustum_convnet_amd.config import reset_cfg
+    from frustum_convnet_amd import det_base
+    from frustum_convnet_amd.train_state import FlatTrainState
+    reset_cfg()
+    torch.manual_seed(3)
+    ref = det_base.PointNetDet(3, num_vec=3, num_classes=2)
+    opt = torch.optim.Adam(ref.parameters(), lr=2e-3, weight_decay=1e-4)
+    for p in ref.parameters():
+        p.grad = torch.randn_like(p)
+    opt.step()
+    for p in ref.parameters():
+        p.grad = torch.randn_like(p)
+    opt.step()
+    sd_ref = opt.state_dict()
+    m = det_base.PointNetDet(3, num_vec=3, num_classes=2)
+    st = FlatTrainState(m, lr=1e-3)
+    st.load_state_dict(sd_ref)                          # a reference optimizer checkpoint: no 'names', model order
+    views = {n: (st.exp_avg[o:o + p.numel()].view(p.shape), st.exp_avg_sq[o:o + p.numel()].view(p.shape))
+             for n, p, o in zip(st.names, st.params, st.offsets)}
+    for n, p in ref.named_parameters():
+        assert torch.equal(views[n][0], opt.state[p]["exp_avg"]), n
+        assert torch.equal(views[n][1], opt.state[p]["exp_avg_sq"]), n
+    assert int(st._step_slots.min()) == 2 and abs(float(st.hyper[0]) - 2e-3) < 1e-9
+    # and back: torch.optim.Adam(model.parameters()) of the reference loads what this object writes
+    sd = st.state_dict()
+    assert sd["names"] == [n for n, _ in ref.named_parameters()]
+    opt2 = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    opt2.load_state_dict({"state": sd["state"], "param_groups": sd["param_groups"]})
+    for p in ref.parameters():
+        assert torch.equal(opt2.state[p]["exp_avg"], opt.state[p]["exp_avg"])
+        assert float(opt2.state[p]["step"]) == 2.0
+    # by-name matching survives a permuted dict; a wrong shape is refused before anything is copied
+    perm = list(range(len(sd["names"])))[::-1]
+    sd_perm = {"state": {k: sd["state"][i] for k, i in enumerate(perm)}, "param_groups": sd["param_groups"],
+               "names": [sd["names"][i] for i in perm]}
+    st2 = FlatTrainState(det_base.PointNetDet(3, num_vec=3, num_classes=2), lr=1e-3)
+    st2.load_state_dict(sd_perm)
+    assert torch.equal(st2.exp_avg, st.exp_avg) and torch.equal(st2.exp_avg_sq, st.exp_avg_sq)
+    bad = {"state": dict(sd["state"]), "param_groups": sd["param_groups"]}
+    bad["state"][0], bad["state"][3] = bad["state"][3], bad["state"][0]
+    with pytest.raises(ValueError, match="shape"):
+        st2.load_state_dict(bad)

@@ -90,3 +90,29 @@ def test_device_clip_core_arithmetic_on_host(host_lib):
     out2 = np.zeros((n, 2), dtype=np.float32)
     host_lib.host_iou_from_corners(ca.ctypes.data_as(fp), cb.ctypes.data_as(fp), n, out2.ctypes.data_as(fp))
     assert np.abs(out2 - ref).max() < 5e-5, np.abs(out2 - ref).max()
+
+
+@pytest.mark.parametrize("variant", ["full", "plain", "allbg"])
+@pytest.mark.parametrize("method", ["nms", "top"])
+def test_decode_matches_reference_test_loop(variant, method):
+    """oracle/box_ref.decode_detections against the rows the reference's own test() loop (train/test_net_det.py:193-293, run
+    by tests/golden/make_golden_decode.py with the reference model's eval outputs) produced: foreground selection with its
+    arg-max fallback, score = p_fg + rgb_prob, from_prediction_to_label_format, the too-small filter, row order."""
+    g = load_golden("decode_b6_n512")
+    probs = g["allbg_cls_probs"] if variant == "allbg" else g["eval_cls_probs"]
+    B = probs.shape[0]
+    rows, counts = g["rows_%s_%s" % (variant, method)], g["counts_%s_%s" % (variant, method)]
+    extras = variant != "plain"
+    off = 0
+    for b in range(B):
+        refc = g["ref_center"][b].astype(np.float64) if extras else np.zeros(3)       # test_net_det.py:205-211 defaults
+        rgb = float(g["rgb_prob"][b, 0]) if extras else 1.0
+        got, _ = box_ref.decode_detections(probs[b].astype(np.float64), g["eval_center"][b].astype(np.float64),
+                                           g["eval_heading"][b].astype(np.float64), g["eval_size"][b].astype(np.float64),
+                                           float(g["rot_angle"][b, 0]), refc, rgb, method)
+        exp = rows[off:off + counts[b]][:, [4, 5, 6, 9, 8, 7, 10, 11]]      # (tx,ty,tz,h,w,l,ry,score) -> (tx,ty,tz,l,w,h,ry,score)
+        off += counts[b]
+        assert got.shape == exp.shape, (b, got.shape, exp.shape)
+        # the reference computes these in float32 (its rows are float32 values): one float32 ulp of slack
+        assert (np.abs(got - exp) <= 1e-6 + 2.5e-7 * np.abs(exp)).all(), (b, np.abs(got - exp).max())
+    assert off == len(rows) and (counts > 0).all()
