@@ -17,7 +17,9 @@ ms_per_step is the mean over rounds * K steps -- a 40 ms window says little abou
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline     -- the top-time kernel family of the step, timed LIVE (HIP events around its C-ABI entry point, on the stream
                   it is launched on, eager launches of the same step), with a `kernels` table for every entry point
-  cpu_baseline -- the CPU oracle (oracle/det_ref.py + oracle/qdp_ref.c) timed on the host cores, N=1 only
+  configs      -- short timed windows (>= 0.35 s each) of the other BASELINE.json configurations: people, refine, the
+                  SUN-RGBD variant and the bf16 throughput mode of the car config (N=1, default car / split invocation only)
+  cpu_baseline -- the CPU oracle (oracle/det_ref.py + oracle/qdp_ref.c) timed on the host cores, N=1 only, <= ~30 s
 """
 import argparse
 import ctypes
@@ -63,6 +65,7 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one all-reduce after the whole backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short windows of the other configurations")
     ap.add_argument("--cpu-baseline-batch", type=int, default=32)
     ap.add_argument("--precision", choices=("split", "f32", "bf16"), default=None,
                     help="MFMA operand mode of the GEMM kernels (default: FCN_PRECISION or 'split')")
@@ -245,7 +248,7 @@ def pmc_traffic(kind, entry=None):
 
 def cpu_baseline(batch, npoint, cfg_name):
     """The CPU oracle (port of the reference dataflow: dense (B,C,L,K) tensors, torch-CPU conv/BN + C grouping) timed on this
-    host: forward + backward.  Three points: best of 16 / 8 torch threads (3 steps), 1 core, all cores."""
+    host: forward + backward.  Two points: best of 16 / 8 torch threads (one B=32 step each) and 1 core (B=4) -- bounded to ~30 s."""
     from oracle import det_ref
     from frustum_convnet_amd import synth
     from frustum_convnet_amd.config import reset_cfg, merge_cfg_from_file
@@ -268,30 +271,33 @@ def cpu_baseline(batch, npoint, cfg_name):
 
     saved = torch.get_num_threads()
     ncpu = os.cpu_count() or saved
+    # BOUNDED: <= ~30 s of CPU work in total (the old three-point sweep took 290 s of a 298 s run, 134 s of it one
+    # all-core step).  One B=32 step at the thread count that measured best on these hosts (16; the dense torch-CPU dataflow
+    # does not scale further: 5.7 frustums/s at 16 threads, 0.25 at 256), one 1-core step at B=4; 8 threads only while the
+    # budget lasts.  Warm-ups (thread pools, oneDNN primitives) at B=2.
     budget_t0 = time.perf_counter()
+    spent = lambda: time.perf_counter() - budget_t0
     best = None
-    for n in (16, 8):
+    for n, limit in ((16, 1e9), (8, 12.0)):
+        if spent() > limit:
+            break
         torch.set_num_threads(min(n, ncpu))
-        step(2)                            # warm-up (thread pools, oneDNN primitives)
-        ts = [step(batch) for _ in range(3 if time.perf_counter() - budget_t0 < 20 else 1)]
-        t = float(np.median(ts))
-        if best is None or t < best[0]:
-            best = (t, torch.get_num_threads(), len(ts))
-    variants = {}
-    torch.set_num_threads(1)
-    b1 = max(1, min(batch, 4))
-    variants["1_core"] = {"value": round(b1 / step(b1), 3), "cores": 1, "sample": "1 step of B=%d" % b1}
-    if time.perf_counter() - budget_t0 < 60:
-        torch.set_num_threads(ncpu)
         step(2)
-        variants["all_cores"] = {"value": round(batch / step(batch), 3), "cores": ncpu, "sample": "1 step of B=%d" % batch}
+        t = step(batch)
+        if best is None or t < best[0]:
+            best = (t, torch.get_num_threads(), 1)
+    variants = {}
+    if spent() < 24.0:
+        torch.set_num_threads(1)
+        b1 = max(1, min(batch, 4))
+        variants["1_core"] = {"value": round(b1 / step(b1), 3), "cores": 1, "sample": "1 step of B=%d" % b1}
     torch.set_num_threads(saved)
     t, cores, nst = best
     return {"value": round(batch / t, 3), "unit": "frustums/s", "cores": cores, "kind": "port",
-            "sample": "median of %d train fwd+bwd step(s) of B=%d N=%d (%s cfg, same synthetic batch shape), fp32, "
+            "sample": "%d train fwd+bwd step of B=%d N=%d (%s cfg, same synthetic batch shape), fp32, "
                       "oracle/det_ref.py + oracle/qdp_ref.c, %.2f s/step, best of 16 / 8 torch threads (the dense torch-CPU "
-                      "dataflow does not scale further)" % (nst, batch, npoint, cfg_name, t),
-            "variants": variants, "host_cpus": ncpu}
+                      "dataflow does not scale further); bounded to ~30 s in total" % (nst, batch, npoint, cfg_name, t),
+            "variants": variants, "host_cpus": ncpu, "seconds_spent": round(spent(), 1)}
 
 
 def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=None, npoint=None):
@@ -485,7 +491,7 @@ def main():
 
     if rank != 0:
         return
-    Ls = [data["center_ref%d" % i].shape[2] for i in range(1, 6) if ("center_ref%d" % i) in data]
+    Ls = m["Ls"]
     out = {
         "metric": "frustums/sec (train fwd+bwd) KITTI-car B=32 N=1024",
         "value": round(a.batch * world / (ms_per_step / 1e3), 2),
@@ -503,7 +509,7 @@ def main():
                                                         "one call after the backward")) if world > 1 else ""),
                    "global_batch": a.batch * world, "parallelism": "dp%d" % world,
                    "launch": ("hipGraph replay x%d" % len(graphs)) if graphs is not None else "eager"},
-        "gpu_event_ms_per_step": round(e0.elapsed_time(e1) / nstep, 4),
+        "gpu_event_ms_per_step": round(gpu_event_ms, 4),
         "final_loss": round(final_loss, 5),
     }
     if world == 1 and not a.no_roofline:
@@ -548,6 +554,13 @@ def main():
                                    "frac": round(tbps / PEAK_HBM_TBPS, 4)}
         else:
             out["hbm_roofline"] = {"traffic": None, "note": why}
+    if world == 1 and not a.no_configs and a.cfg == "car" and prec == "split" and not a.eager:
+        # the other BASELINE.json configurations, driver-visible in the same line: free the headline model first
+        del model, state, data, graphs, m
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        out["configs"] = other_configs(a, dev)
+        fprec.set_precision(prec)
     if world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_batch, npoint, a.cfg)
