@@ -1,7 +1,10 @@
-"""-m gpu, needs >= 2 GPUs (skipped on a one-GPU box): two ranks over RCCL run the overlapped data-parallel step of
+"""-m gpu.  (a) needs >= 2 GPUs (skipped on a one-GPU box): two ranks over RCCL run the overlapped data-parallel step of
 bench.py on the REAL PointNetDet (two-phase backward, bucketed asynchronous all-reduce, flat Adam) and check that
 (1) the all-reduced gradient equals the mean of the two ranks' local gradients and (2) the parameters stay identical on both
-ranks after three steps (reference semantics: nn.DataParallel's gradient reduce, train/train_net_det.py:308-309,120-128)."""
+ranks after three steps (reference semantics: nn.DataParallel's gradient reduce, train/train_net_det.py:308-309,120-128).
+(b) runs on ANY box: the same N = 2 code path with both ranks on GPU 0 and gloo as the transport (a one-GPU box cannot form an
+RCCL communicator) -- and in bench.py's form: the step captured as TWO hipGraphs cut where the FCN gradients are final, the
+[FCN + heads] bucket reduced between the replays, the PointNet bucket after the second, one Adam launch per bucket."""
 import os
 import socket
 import sys
@@ -19,6 +22,94 @@ def _free_port():
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+def _worker_graphs_one_gpu(rank, world, port, q):
+    """Both ranks on cuda:0 over gloo; the overlapped step as bench.py runs it for N > 1 (measure(): graphs A and B)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from frustum_convnet_amd import dist as fdist, synth
+    from frustum_convnet_amd.train_state import FlatTrainState
+    from frustum_convnet_amd.loss_fused import unit_grad
+    from helpers import load_golden, golden_inputs
+    from test_gpu_model import _model
+    torch.cuda.set_device(0)
+    r, w, _ = fdist.init_from_env(backend="gloo")
+    g = load_golden("car_b4_n512")
+    full = golden_inputs(g)
+    data = synth.to_torch({k: v[rank * 2:(rank + 1) * 2] for k, v in full.items()}, "cuda")     # 2 frustums per rank
+    m = _model(g)
+    m.train()
+    m.split_backward = True
+    fdist.broadcast_state(m, 0)
+    st = FlatTrainState(m, lr=1e-4, weight_decay=1e-4, world=world)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                      # allocator / workspace warm-up outside capture
+        lo, _ = m(data)
+        m.backward(lo["total_loss"])
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    dist.barrier()
+    gA, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gA, capture_error_mode="thread_local"):
+        lo, _ = m(data)
+        pending = m.take_split()
+        lo["total_loss"].backward(gradient=unit_grad(lo["total_loss"].device))
+    with torch.cuda.graph(gB, pool=gA.pool(), capture_error_mode="thread_local"):
+        pending.backward()
+    assert [n for n, _, _ in st.buckets] == ["fcn+heads", "pointnet"]
+    ok_grad = True
+    for it in range(3):
+        gA.replay()
+        torch.cuda.synchronize()
+        local0 = st.grad[st.buckets[0][1]:st.buckets[0][2]].clone()           # [FCN + heads]: final after graph A
+        st.allreduce_bucket_async(0)
+        gB.replay()
+        torch.cuda.synchronize()
+        local1 = st.grad[st.buckets[1][1]:st.buckets[1][2]].clone()           # [PointNet]: final after graph B
+        st.allreduce_bucket_async(1)
+        st.wait_allreduce()
+        torch.cuda.synchronize()
+        for bi, loc in ((0, local0), (1, local1)):
+            both = [torch.zeros_like(loc) for _ in range(world)]
+            dist.all_gather(both, loc)
+            mean = sum(both) / world
+            got = st.grad[st.buckets[bi][1]:st.buckets[bi][2]] * float(st.hyper[5])
+            ok_grad = ok_grad and bool(torch.allclose(got, mean, rtol=1e-5, atol=1e-8))
+            ok_grad = ok_grad and bool((both[0] != both[1]).any())            # the ranks really saw different frustums
+        st.adam_step()
+    torch.cuda.synchronize()
+    flats = [torch.zeros_like(st.flat) for _ in range(world)]
+    dist.all_gather(flats, st.flat)
+    q.put((rank, ok_grad, bool(torch.equal(flats[0], flats[1])), int(st.step_count)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(worker, world=2, timeout=600):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout)
+        if p.is_alive():
+            p.kill()                 # (the exact process this test started)
+            p.join()
+        assert p.exitcode == 0
+    return [q.get(timeout=5) for _ in range(world)]
+
+
+def test_two_rank_two_graph_step_on_one_gpu_over_gloo():
+    got = _run(_worker_graphs_one_gpu)
+    assert all(g[1] and g[2] and g[3] == 3 for g in got), got
 
 
 def _worker(rank, world, port, q):
@@ -65,16 +156,5 @@ def _worker(rank, world, port, q):
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL)")
 def test_two_rank_overlapped_step_over_rccl():
-    import torch.multiprocessing as mp
-    world = 2
-    port = _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(600)
-        assert p.exitcode == 0
-    got = [q.get(timeout=5) for _ in range(world)]
+    got = _run(_worker)
     assert all(g[1] and g[2] for g in got), got
