@@ -72,7 +72,7 @@ class InpRefineDesc(ctypes.Structure):
 
 EXPORTS = ("fcn_arch", "fcn_query_depth_point_f32", "fcn_pn_wgrad_rows", "fcn_pn_compact", "fcn_pn_group_compact",
            "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_det_loss_tail_rows2", "fcn_det_iou_metrics",
-           "fcn_det_loss_tail_scratch_floats", "fcn_adam_step_f32", "fcn_adam_step_slots", "fcn_prepare_inputs", "fcn_prepare_inputs_refine", "fcn_prepare_inputs_sunrgbd", "fcn_stamp",
+           "fcn_det_loss_tail_scratch_floats", "fcn_adam_step_f32", "fcn_sgd_step_f32", "fcn_adam_step_slots", "fcn_prepare_inputs", "fcn_prepare_inputs_refine", "fcn_prepare_inputs_sunrgbd", "fcn_stamp",
            "fcn_convnet_sizes", "fcn_convnet_logits_ld", "fcn_convnet_pack", "fcn_convnet_forward", "fcn_convnet_forward2",
            "fcn_convnet_backward", "fcn_box3d_iou_pair_f32", "fcn_decode_detections", "fcn_rotate_nms_3d")
 
@@ -124,6 +124,8 @@ def lib():
     L.fcn_det_loss_tail.argtypes = [c_fp] * 9 + [ctypes.c_int] * 4 + [ctypes.c_float] * 4 + [c_fp] * 4
     L.fcn_adam_step_f32.restype = ctypes.c_int
     L.fcn_adam_step_f32.argtypes = [c_fp] * 4 + [ctypes.c_int64] + [c_fp] * 3
+    L.fcn_sgd_step_f32.restype = ctypes.c_int
+    L.fcn_sgd_step_f32.argtypes = [c_fp] * 3 + [ctypes.c_int64] + [c_fp] * 2
     L.fcn_prepare_inputs.restype = ctypes.c_int
     L.fcn_prepare_inputs.argtypes = [ctypes.POINTER(InpDesc)] + [c_fp] * 13 + [c_fp * 4] + [c_fp] * 7
     L.fcn_prepare_inputs_sunrgbd.restype = ctypes.c_int

@@ -16,6 +16,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno
          "-ffp-contract=off"]
 
 
+OBJ = os.path.join(CSRC, "_obj")
+
+
+def _deps_mtime():
+    return max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS + [os.path.abspath(__file__)])
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
@@ -24,15 +31,40 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and not _stale():
-        return LIB
+def build(force=False, verbose=True, lib=None, extra_flags=()):
+    """Compiles every source to an object (in parallel; only the ones older than their source / the headers) and links them.
+    lib / extra_flags: tuning builds (tools/build_variant.py) -- objects of such a build are never cached."""
+    variant = lib is not None or bool(extra_flags)
+    lib = lib or LIB
+    if not force and not variant and not _stale():
+        return lib
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    cflags = [f for f in FLAGS if f != "-shared"] + list(extra_flags)
+    objdir = OBJ + ("_variant_%d" % os.getpid() if variant else "")
+    os.makedirs(objdir, exist_ok=True)
+    hdr_t = _deps_mtime()
+
+    def compile_one(src):
+        path, obj = os.path.join(CSRC, src), os.path.join(objdir, src.replace(".hip", ".o"))
+        if not force and not variant and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_t):
+            return obj
+        cmd = [hipcc] + cflags + ["-c", path, "-o", obj]
+        if verbose:
+            print("[fcn build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib]
     if verbose:
         print("[fcn build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    if variant:
+        import shutil
+        shutil.rmtree(objdir, ignore_errors=True)
+    return lib
 
 
 if __name__ == "__main__":

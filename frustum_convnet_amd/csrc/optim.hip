@@ -89,6 +89,39 @@ extern "C" int fcn_adam_step_f32(float *param, const float *grad, float *exp_avg
 }
 
 // ------------------------------------------------------------------------------------------------
+// The 'sgd' branch of the step loop (train/train_net_det.py:325-327: optim.SGD(lr, momentum, weight_decay)), same flat buffers.
+// torch.optim.SGD arithmetic with dampening 0: g' = wd * p + g * grad_scale; buf = momentum * buf + g'; p -= lr * buf.  (torch
+// seeds the buffer with the first gradient: identical to the recurrence from a zero buffer, so there is no step counter.)
+__global__ __launch_bounds__(ADAM_T) void sgd_kernel(float *p, const float *g, float *buf, int64_t n, const float *hyper)
+{
+    const float lr = hyper[0], mu = hyper[1], wd = hyper[2], gs = hyper[3];
+    const int64_t n4 = n >> 2, i = (int64_t)blockIdx.x * ADAM_T + threadIdx.x;
+    if (i < n4) {
+        const v4f pp = ldg4(p + 4 * i);
+        const v4f b = mu * ldg4(buf + 4 * i) + (wd * pp + ldg4(g + 4 * i) * gs);
+        sts4(buf + 4 * i, b);
+        sts4(p + 4 * i, pp - lr * b);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t j = (n4 << 2) + threadIdx.x;
+        const float b = mu * buf[j] + (wd * p[j] + g[j] * gs);
+        buf[j] = b;
+        p[j] -= lr * b;
+    }
+}
+
+extern "C" int fcn_sgd_step_f32(float *param, const float *grad, float *momentum_buf, int64_t n, const float *hyper4,
+                                void *stream)
+{
+    if (!param || !grad || !momentum_buf || !hyper4 || n < 4) return FCN_E_BADARG;
+    if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)momentum_buf) & 15) return FCN_E_BADARG;
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)(((n >> 2) + ADAM_T - 1) / ADAM_T)), dim3(ADAM_T), 0, (hipStream_t)stream,
+                       param, grad, momentum_buf, n, hyper4);
+    FCN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Measurement aid: one thread stores the GPU's constant-rate wall clock (100 MHz) into *slot.  Launched between the
 // phases of a step it gives phase boundaries INSIDE a replayed hipGraph without a profiler attached
 // (tools/phase_stamps.py); rocprofv3's kernel trace perturbs the overlap of the captured branches.

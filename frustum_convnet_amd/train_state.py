@@ -10,10 +10,12 @@ Parameters, gradients and both Adam moments are four contiguous fp32 buffers (13
     [ConvFeatNet + heads] (2.9 M of the 3.3 M parameters) is final when the FCN backward ends and is reduced on RCCL's
     stream while the PointNet backward still runs; [PointNet] follows it.  The 1/world of the mean is folded into the
     optimiser kernel's grad_scale;
-  * the optimiser step is a streaming HIP kernel (fcn_adam_step_f32) PER BUCKET whose step counters and hyper-parameters
-    live in device memory, so it can be captured into the step's hipGraph and the learning rate changed between
-    replays; adam_step_bucket(0) can run as soon as the FCN gradients are final (and reduced), beside the PointNet backward,
-    leaving only the small PointNet bucket's update at the end of the step (bench.py does that).
+  * the optimiser step is a streaming HIP kernel PER BUCKET (fcn_adam_step_f32, or fcn_sgd_step_f32 for the reference's 'sgd'
+    branch) whose step counters and hyper-parameters live in device memory, so it can be captured into the step's hipGraph and
+    the learning rate changed between replays (set_lr + lr_for_epoch = the reference's StepLR / MultiStepLR + MIN_LR clamp).
+    adam_step_bucket(i) steps one bucket alone; bench.py steps BOTH buckets after the whole backward (adam_step()): stepping the
+    [FCN + heads] bucket early, beside the PointNet backward, measured 2 % slower -- the per-bucket form
+    stays in the API and is covered by tests/test_gpu_train_state.py.
 """
 import ctypes
 import weakref
@@ -34,8 +36,23 @@ def _ordered_parameters(model):
     return rest + tail
 
 
+def lr_for_epoch(epoch, base_lr, lr_steps, gamma, min_lr=0.0):
+    """Learning rate of the reference's schedule at `epoch` (train/train_net_det.py:98-105,334-339): MultiStepLR over
+    `lr_steps` when there are several milestones, StepLR(step_size = lr_steps[0]) when there is one, clamped from below by
+    cfg.TRAIN.MIN_LR.  Feed it to FlatTrainState.set_lr() at the top of every epoch."""
+    if len(lr_steps) > 1:
+        lr = base_lr * gamma ** sum(1 for m in lr_steps if epoch >= m)
+    else:
+        lr = base_lr * gamma ** (epoch // int(lr_steps[0]))
+    return max(lr, min_lr) if min_lr > 0 else lr
+
+
 class FlatTrainState:
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, world=1, group=None):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, world=1, group=None,
+                 optimizer="adam", momentum=0.9):
+        if optimizer not in ("adam", "sgd"):
+            raise ValueError("optimizer must be 'adam' or 'sgd' (cfg.TRAIN.OPTIMIZER, train/train_net_det.py:321-329)")
+        self.optimizer = optimizer
         named = _ordered_parameters(model)
         assert named, "model has no parameters"
         self._model = weakref.ref(model)
@@ -80,8 +97,12 @@ class FlatTrainState:
                 cut = max(cut, (o + p.numel() + 3) // 4 * 4)
         self.buckets = [("fcn+heads", cut, total), ("pointnet", 0, cut)] if 0 < cut < total else [("all", 0, total)]
         self._pending = []
-        self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, 1.0 / self.world], device=dev,
-                                  dtype=torch.float32)
+        if optimizer == "sgd":          # lr, momentum, weight_decay, grad_scale; the momentum buffer lives in exp_avg
+            self.hyper = torch.tensor([lr, momentum, weight_decay, 1.0 / self.world, 0.0, 1.0 / self.world], device=dev,
+                                      dtype=torch.float32)
+        else:
+            self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, 1.0 / self.world], device=dev,
+                                      dtype=torch.float32)
         # one step counter per workgroup of the optimiser kernel (all equal); every bucket's launch has its own range of
         # slots; step_count is slot 0
         self._slot_off = [0]
@@ -130,6 +151,15 @@ class FlatTrainState:
         _, lo, hi = self.buckets[i]
         L = _native.lib()
         off = 4 * lo                                     # bytes; bucket boundaries are 16-byte aligned
+        if self.optimizer == "sgd":
+            with torch.cuda.device(self.device):
+                _native.check(L.fcn_sgd_step_f32(self.flat.data_ptr() + off, self.grad.data_ptr() + off,
+                                                 self.exp_avg.data_ptr() + off, ctypes.c_int64(hi - lo),
+                                                 self.hyper.data_ptr(), _native.current_stream(self.device)),
+                              "fcn_sgd_step_f32")
+            if i == 0:
+                self._step_slots[0:1] += 1          # (bookkeeping only: SGD has no bias correction)
+            return
         with torch.cuda.device(self.device):
             _native.check(L.fcn_adam_step_f32(self.flat.data_ptr() + off, self.grad.data_ptr() + off,
                                               self.exp_avg.data_ptr() + off, self.exp_avg_sq.data_ptr() + off,
@@ -163,6 +193,14 @@ class FlatTrainState:
         step = int(self.step_count.item())
         hy = [float(v) for v in self.hyper.tolist()]
         state, names = {}, [None] * len(self.params)
+        if self.optimizer == "sgd":           # torch.optim.SGD's layout: {'momentum_buffer': tensor} per parameter
+            for k, (p, o) in enumerate(zip(self.params, self.offsets)):
+                i = self.param_index[k]
+                names[i] = self.names[k]
+                state[i] = {"momentum_buffer": self.exp_avg[o:o + p.numel()].view(p.shape).clone()}
+            group = {"lr": hy[0], "momentum": hy[1], "dampening": 0, "weight_decay": hy[2], "nesterov": False,
+                     "params": list(range(len(self.params)))}
+            return {"state": {i: state[i] for i in sorted(state)}, "param_groups": [group], "names": names, "step": step}
         for k, (p, o) in enumerate(zip(self.params, self.offsets)):
             n = p.numel()
             i = self.param_index[k]
@@ -191,15 +229,28 @@ class FlatTrainState:
             index = self.param_index
         ids = group["params"]
         entries = []
+        fields = ("momentum_buffer",) if self.optimizer == "sgd" else ("exp_avg", "exp_avg_sq")
         for k, p in enumerate(self.params):
             key = ids[index[k]]
             st = sd["state"].get(key, sd["state"].get(str(key)))
             if st is not None:
-                for f in ("exp_avg", "exp_avg_sq"):
+                for f in fields:
                     if tuple(st[f].shape) != tuple(p.shape):
                         raise ValueError("optimizer state entry %s (%s): %s has shape %s, the parameter %s" % (
                             key, self.names[k], f, tuple(st[f].shape), tuple(p.shape)))
             entries.append(st)
+        if self.optimizer == "sgd":
+            with torch.no_grad():
+                for st, p, o in zip(entries, self.params, self.offsets):
+                    n = p.numel()
+                    if st is None or st.get("momentum_buffer") is None:
+                        self.exp_avg[o:o + n].zero_()
+                    else:
+                        self.exp_avg[o:o + n].copy_(st["momentum_buffer"].reshape(-1))
+                self._step_slots.fill_(int(sd.get("step", 0)))
+                self.hyper[0:3].copy_(torch.tensor([group["lr"], group["momentum"], group["weight_decay"]],
+                                                   dtype=torch.float32))
+            return
         steps = set()
         with torch.no_grad():
             for st, p, o in zip(entries, self.params, self.offsets):

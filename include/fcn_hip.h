@@ -20,6 +20,7 @@
  *   fcn_convnet_pack / _forward2 the same forward with the weight re-packing split off and per-feature-map start events
  *   fcn_det_loss_tail[_rows]    the ~150 torch ops of the train-loss tail, models/det_base.py:373-476
  *   fcn_adam_step_f32           optim.Adam.step() of the step loop, train/train_net_det.py:131-133,321-339
+ *   fcn_sgd_step_f32            optim.SGD.step() (momentum) of the same loop's 'sgd' branch, train/train_net_det.py:325-327
  *   fcn_prepare_inputs          the per-sample numpy work of the data loader + collate,
  *                               datasets/provider_sample.py:137-262,270-327,396-397
  *   fcn_prepare_inputs_refine   the same for the refinement stage, datasets/provider_sample_refine.py:176-419
@@ -274,6 +275,11 @@ int fcn_det_loss_tail_rows(const float *logits, const int64_t *cls_label, const 
 int64_t fcn_adam_step_slots(int64_t n);
 int fcn_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                       const float *hyper6, int64_t *step_slots, void *stream);
+
+/* The 'sgd' branch of the same loop (train/train_net_det.py:325-327 optim.SGD(lr, momentum, weight_decay)): torch.optim.SGD
+ * arithmetic (L2 weight decay, dampening 0, no Nesterov) over the same flat buffers; momentum_buf starts at zero.
+ *   hyper4 (device): lr, momentum, weight_decay, grad_scale. */
+int fcn_sgd_step_f32(float *param, const float *grad, float *momentum_buf, int64_t n, const float *hyper4, void *stream);
 
 /* Same with a persistent scratch buffer (fcn_det_loss_tail_scratch_floats(B, L2) floats, zeroed ONCE by the caller, then
  * owned by one stream at a time): no memset node in front of the launch, the workgroup partials are summed in a fixed

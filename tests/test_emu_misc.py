@@ -39,6 +39,44 @@ def test_emulated_adam_matches_torch_adam(n):
         assert err < 2e-6, (step, err)
 
 
+@pytest.mark.parametrize("n", [4, 1001, 70000])
+def test_emulated_sgd_matches_torch_sgd(n):
+    """fcn_sgd_step_f32 against torch.optim.SGD(momentum, weight_decay) -- the 'sgd' branch of train/train_net_det.py:325-327."""
+    from emu_fcn import emu_path
+    L = ctypes.CDLL(emu_path())
+    L.fcn_sgd_step_f32.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64] + [ctypes.c_void_p] * 2
+    g = torch.Generator().manual_seed(n)
+    p0 = torch.randn(n, generator=g)
+    lr, mu, wd, gscale = 1e-2, 0.9, 1e-4, 0.5
+    ref = torch.nn.Parameter(p0.clone().double())
+    opt = torch.optim.SGD([ref], lr=lr, momentum=mu, weight_decay=wd)
+    p, buf = p0.clone(), torch.zeros(n)
+    hyper = torch.tensor([lr, mu, wd, gscale], dtype=torch.float32)
+    for step in range(4):
+        grad = torch.randn(n, generator=g)
+        ref.grad = grad.double() * gscale
+        opt.step()
+        assert L.fcn_sgd_step_f32(p.data_ptr(), grad.data_ptr(), buf.data_ptr(), n, hyper.data_ptr(), None) == 0
+        assert float((p.double() - ref.detach()).abs().max()) < 2e-6, step
+        assert float((buf.double() - opt.state[ref]["momentum_buffer"]).abs().max()) < 2e-6, step
+    assert L.fcn_sgd_step_f32(p.data_ptr(), grad.data_ptr(), buf.data_ptr(), 3, hyper.data_ptr(), None) != 0     # n < 4 refused
+
+
+def test_lr_schedule_matches_torch_schedulers():
+    """lr_for_epoch = StepLR / MultiStepLR as train/train_net_det.py:334-339 builds them + the MIN_LR clamp of :98-103."""
+    from frustum_convnet_amd.train_state import lr_for_epoch
+    for steps in ([20], [20, 35], [3, 5, 9]):
+        w = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([w], lr=1e-3)
+        sch = (torch.optim.lr_scheduler.MultiStepLR(opt, milestones=steps, gamma=0.1) if len(steps) > 1 else
+               torch.optim.lr_scheduler.StepLR(opt, step_size=steps[0], gamma=0.1))
+        for epoch in range(50):
+            want = max(opt.param_groups[0]["lr"], 1e-5)
+            assert abs(lr_for_epoch(epoch, 1e-3, steps, 0.1, 1e-5) - want) < 1e-12, (steps, epoch)
+            opt.step()
+            sch.step()
+
+
 def test_smoke_entry_under_emulation():
     """__graft_entry__.smoke() (the driver's first call on the GPU box) end to end on the CPU: same code path, emulated kernels."""
     import sys

@@ -96,6 +96,49 @@ def test_flat_adam_matches_torch_adam():
     assert torch.equal(before, st.flat) and int(st.step_count) == 4
 
 
+def test_buckets_stepped_separately_and_sgd_matches_torch():
+    """ adam_step_bucket(i) alone, in either order, equals adam_step(); and the 'sgd' optimiser of the reference's
+    step loop (train/train_net_det.py:325-327) against torch.optim.SGD on the same gradients."""
+    from frustum_convnet_amd.train_state import FlatTrainState
+    g = load_golden("car_b4_n512")
+    data = synth.to_torch(golden_inputs(g), "cuda")
+    models = [_model(g) for _ in range(3)]
+    states = [FlatTrainState(m, lr=1e-4, weight_decay=1e-4) for m in models[:2]]
+    for m in models:
+        m.train()
+    for it in range(2):
+        for m in models[:2]:
+            lo, _ = m(data)
+            m.backward(lo["total_loss"])
+        states[0].adam_step()
+        states[1].adam_step_bucket(1)                 # PointNet bucket first, then [FCN + heads]
+        states[1].adam_step_bucket(0)
+    torch.cuda.synchronize()
+    assert torch.equal(states[0].flat, states[1].flat) and int(states[1]._step_slots.min()) == 2
+    # SGD + momentum
+    a, b = models[2], _model(g)
+    b.train()
+    opt = torch.optim.SGD(a.parameters(), lr=1e-4, momentum=0.9, weight_decay=1e-4)
+    st = FlatTrainState(b, lr=1e-4, weight_decay=1e-4, optimizer="sgd", momentum=0.9)
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    for it in range(2):
+        opt.zero_grad(set_to_none=True)
+        la, _ = a(data)
+        la["total_loss"].backward()
+        opt.step()
+        lb, _ = b(data)
+        b.backward(lb["total_loss"])
+        st.step()
+    worst = max(float((pa[k] - pb[k]).abs().max()) for k in pa)
+    print("flat SGD vs torch.optim.SGD after 2 steps: max |dparam| %.2e" % worst)
+    assert worst < 2e-5
+    sd = st.state_dict()
+    opt2 = torch.optim.SGD(a.parameters(), lr=1e-3, momentum=0.5)
+    opt2.load_state_dict({"state": sd["state"], "param_groups": sd["param_groups"]})      # torch's layout, model order
+    for p in a.parameters():
+        assert torch.allclose(opt2.state[p]["momentum_buffer"], opt.state[p]["momentum_buffer"], rtol=1e-3, atol=1e-5)
+
+
 @pytest.mark.parametrize("lr", [1e-3, 1e-4])
 def test_two_step_trajectory_vs_cpu_oracle(lr):
     """Loss after 0, 1 and 2 Adam(lr, wd 1e-4) steps from the same weights: HIP step loop vs oracle/det_ref.py stepped by
