@@ -39,7 +39,7 @@ class CnParams(ctypes.Structure):
 
 class CnWs(ctypes.Structure):
     _fields_ = [("y", c_fp), ("dz", c_fp), ("wp", c_fp), ("bn", c_fp), ("stat", c_fp), ("bstat", c_fp),
-                ("coef", c_fp), ("partial", c_fp), ("oh64", c_fp)]
+                ("coef", c_fp), ("partial", c_fp), ("oh64", c_fp), ("flags", c_fp)]
 
 
 class PnParams(ctypes.Structure):
@@ -50,7 +50,7 @@ class PnParams(ctypes.Structure):
 class PnWs(ctypes.Structure):
     _fields_ = [("woff", c_fp), ("ent", c_fp), ("ewin", c_fp), ("tiles", c_fp), ("y2", c_fp), ("y3", c_fp), ("amax", c_fp),
                 ("stat", c_fp), ("bn", c_fp), ("gmax", c_fp), ("dy3", c_fp), ("dz2", c_fp), ("bstat", c_fp),
-                ("coef", c_fp), ("partial", c_fp), ("nsplit", ctypes.c_int32), ("gmom", c_fp)]
+                ("coef", c_fp), ("partial", c_fp), ("nsplit", ctypes.c_int32), ("gmom", c_fp), ("wenc", c_fp), ("flags", c_fp)]
 
 
 class InpDesc(ctypes.Structure):
@@ -71,12 +71,15 @@ class InpRefineDesc(ctypes.Structure):
 
 
 EXPORTS = ("fcn_arch", "fcn_query_depth_point_f32", "fcn_pn_wgrad_rows", "fcn_pn_compact", "fcn_pn_group_compact",
-           "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_det_loss_tail_rows2", "fcn_det_iou_metrics",
+           "fcn_pn_pack_weights", "fcn_pn_pack_weights_all", "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_det_loss_tail_rows2", "fcn_det_iou_metrics",
            "fcn_det_loss_tail_scratch_floats", "fcn_adam_step_f32", "fcn_sgd_step_f32", "fcn_adam_step_slots", "fcn_prepare_inputs", "fcn_prepare_inputs_refine", "fcn_prepare_inputs_sunrgbd", "fcn_stamp",
            "fcn_convnet_sizes", "fcn_convnet_logits_ld", "fcn_convnet_pack", "fcn_convnet_forward", "fcn_convnet_forward2",
            "fcn_convnet_backward", "fcn_box3d_iou_pair_f32", "fcn_decode_detections", "fcn_rotate_nms_3d")
 
 _lib = None
+
+
+FLAG_NONFINITE = 1      # FCN_FLAG_NONFINITE
 
 
 class NativeError(RuntimeError):
@@ -108,6 +111,11 @@ def lib():
     L.fcn_pn_compact.argtypes = [ctypes.POINTER(PnDesc), c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(PnWs), c_fp]
     L.fcn_pn_group_compact.restype = ctypes.c_int
     L.fcn_pn_group_compact.argtypes = [ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]
+    if hasattr(L, "fcn_pn_pack_weights") or "FCN_LIB_NAME" not in os.environ:     # (A/B builds of older kernel sources lack them)
+        L.fcn_pn_pack_weights.restype = ctypes.c_int
+        L.fcn_pn_pack_weights.argtypes = [ctypes.POINTER(PnDesc), ctypes.POINTER(PnParams), ctypes.POINTER(PnWs), c_fp]
+        L.fcn_pn_pack_weights_all.restype = ctypes.c_int
+        L.fcn_pn_pack_weights_all.argtypes = [ctypes.c_int, c_fp, c_fp, c_fp, c_fp]
     L.fcn_pn_forward.restype = ctypes.c_int
     L.fcn_pn_forward.argtypes = [ctypes.POINTER(PnDesc), ctypes.POINTER(PnParams), c_fp, c_fp,
                                  ctypes.POINTER(PnWs), c_fp, c_fp]

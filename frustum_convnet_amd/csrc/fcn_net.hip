@@ -66,6 +66,7 @@ struct CgLayer {
     float *y;                  // (B*Lout, Cout) pre-BN output
     double *stat;              // sum[Cs], sumsq[Cs] or nullptr
     float eps, momentum;
+    int32_t *flags;            // sticky numeric flags (fcn_cn_ws.flags) or nullptr
 };
 
 #define SEL3(i, a0, a1, a2) ((i) == 0 ? (a0) : ((i) == 1 ? (a1) : (a2)))
@@ -393,6 +394,11 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
             sts4(L.y + (int64_t)row * L.Cout + col, v);
             cs1 += v;
             cs2 += v * v;
+            // fp16 operand parts overflow at |x| >= 65504 (inf - inf = NaN in the products, which the next layer's ReLU would
+            // turn into a silent zero): a non-finite output raises the sticky flag of the workspace
+            if constexpr (MM == MM_F16X3) {
+                if (!(fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w) < 3.0e38f) && L.flags) atomicOr(L.flags, FCN_FLAG_NONFINITE);
+            }
         }
     }
     PROBE_STAMP();                                      // 5: outputs stored
@@ -1227,7 +1233,7 @@ static void cn_fill_layer(const fcn_cn_desc *d, const fcn_cn_params *p, const Cn
 {
     L.nseg = P.nseg[l]; L.KT = P.KT[l]; L.stride = P.stride[l]; L.pad = P.pad[l];
     L.Lin = P.Lin[l]; L.Lout = P.Lout[l]; L.B = d->B; L.Cout = P.N[l]; L.Ktot = P.Ktot[l]; L.Cs = P.Cs[l];
-    L.Wp = ws->wp + O.wp[l]; L.bias = nullptr; L.nbias = 0; L.y = ws->y + O.y[l]; L.stat = nullptr;
+    L.Wp = ws->wp + O.wp[l]; L.bias = nullptr; L.nbias = 0; L.y = ws->y + O.y[l]; L.stat = nullptr; L.flags = ws->flags;
     L.eps = d->eps; L.momentum = d->momentum;
     for (int s = 0; s < CG_NSEG; ++s) {
         CgSeg &S = L.seg[s];

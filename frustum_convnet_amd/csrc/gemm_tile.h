@@ -57,6 +57,7 @@ __device__ __forceinline__ v4f zero4() { v4f z = {0.f, 0.f, 0.f, 0.f}; return z;
 #define MM_BF16X1 3
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int acc_row_c(int reg, int lh) { return (reg & 3) + 8 * (reg >> 2) + 4 * lh; }
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -203,6 +204,119 @@ __device__ __forceinline__ void mma_chunk(const float *As, const float *Bs, int 
                 for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<MM>(ah[i], bh[j], acc[i][j]);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// "kb-major" operand images (PointNet forward / data-gradient GEMMs).  One u32x4 is EXACTLY what a lane feeds a 32x32x16 MFMA:
+// the four packed dwords of 8 reduction-adjacent values of one row / column.  A 32-deep chunk of a T-row operand tile is two
+// planes (hi parts, lo parts) of [4 k-blocks][LDR] u32x4, LDR = T + 2:
+//   * fragment read  = ONE ds_read_b128 per operand part (256 B/clk; the k-major dword layout above needs four ds_read_b32 at
+//     128 B/clk -- the PointNet GEMMs were bound by their LDS traffic, not by the matrix pipe);
+//   * staging write  = ONE ds_write_b128 per part for the 8 values a thread loaded from 32 contiguous bytes of a row;
+//   * the weight operand is PRE-ENCODED in this order in global memory once per step (pn_pack_*: fcn_pn_ws.wenc), so its
+//     staging is a plain 16-byte copy, lane-linear in global memory and in LDS (no VALU, LDS-DMA ready);
+//   * LDR = T + 2 keeps both conflict-free: 16 consecutive rows of one k-block cover all 64 banks for the b128 reads; the
+//     8-lane groups of a b128 write (2 rows x 4 k-blocks, k-block stride 4 * LDR = 8 mod 32 dwords) cover 32 distinct banks.
+// MM_F32 keeps the same geometry with raw floats: plane 0 = values 0..3 of the k-block, plane 1 = values 4..7.
+#define KB_PAD 2
+template <int T>
+struct KbTile {
+    static constexpr int LDR = T + KB_PAD;     // u32x4 per k-block row
+    static constexpr int PLANE = 4 * LDR;      // u32x4 per plane of a 32-deep chunk
+    static constexpr int U4 = 2 * PLANE;       // u32x4 per chunk
+};
+
+template <int MM>
+__device__ __forceinline__ void enc8(const float (&x)[8], u32x4 &hi, u32x4 &lo)
+{
+    if constexpr (MM == MM_F32) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { hi[q] = __builtin_bit_cast(uint32_t, x[q]); lo[q] = __builtin_bit_cast(uint32_t, x[4 + q]); }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float h, l;
+            enc2<MM>(x[2 * q], x[2 * q + 1], h, l);
+            hi[q] = __builtin_bit_cast(uint32_t, h);
+            lo[q] = __builtin_bit_cast(uint32_t, l);
+        }
+    }
+}
+
+typedef const u32x4 __attribute__((address_space(1))) *gu4p;
+__device__ __forceinline__ u32x4 ldgu4(const u32x4 *p) { return *(gu4p)p; }
+
+// One 32-deep chunk: A is a KbTile<TA> image, B a KbTile<TB> image (LDRA / LDRB = their LDR).
+template <int MM, int MT, int NT, int LDRA, int LDRB>
+__device__ __forceinline__ void mma_chunk_kb(const u32x4 *A, const u32x4 *B, int arow0, int bcol0, f32x16 (&acc)[MT][NT])
+{
+    const int lane = threadIdx.x & 63;
+    const int l31 = lane & 31, lh = lane >> 5;
+    if constexpr (MM == MM_F32) {
+        const float *Af = (const float *)A, *Bf = (const float *)B;
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 2) {
+            const int k = kk + lh, kb = k >> 3, j = k & 7;
+            float a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = Af[(((j >> 2) * 4 + kb) * LDRA + arow0 + i * 32 + l31) * 4 + (j & 3)];
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn) b[jn] = Bf[(((j >> 2) * 4 + kb) * LDRB + bcol0 + jn * 32 + l31) * 4 + (j & 3)];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[jn], acc[i][jn], 0, 0, 0);
+        }
+    } else {
+        constexpr bool X3 = (MM != MM_BF16X1);
+        const u32x4 *ap = A + lh * LDRA + arow0 + l31;
+        const u32x4 *bp = B + lh * LDRB + bcol0 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                ah[i] = ap[2 * ks * LDRA + i * 32];
+                if constexpr (X3) al[i] = ap[(4 + 2 * ks) * LDRA + i * 32];
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                bh[j] = bp[2 * ks * LDRB + j * 32];
+                if constexpr (X3) bl[j] = bp[(4 + 2 * ks) * LDRB + j * 32];
+            }
+            if constexpr (X3) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<MM>(ah[i], bl[j], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<MM>(al[i], bh[j], acc[i][j]);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<MM>(ah[i], bh[j], acc[i][j]);
+        }
+    }
+}
+
+// Epilogue transposition patch of one wave: a 32 x 32 accumulator tile (lane = column, registers = rows) goes through a
+// wave-private 32 x EP_LD float patch and comes back row-major, 4 consecutive columns per lane (idx = lane + 64 q: row idx >> 3,
+// column quad idx & 7) -- so outputs leave as 16-byte stores (a quarter of the store instructions of one dword per lane).
+#define EP_LD 36
+#define EP_FLOATS (32 * EP_LD)
+__device__ __forceinline__ void ep_put(float *patch, const f32x16 &acc, int l31, int lh)
+{
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) patch[acc_row_c(reg, lh) * EP_LD + l31] = acc[reg];
+}
+__device__ __forceinline__ v4f ep_get(const float *patch, int lane, int q)
+{
+    const int idx = lane + 64 * q;
+    return *(const v4f *)(patch + (idx >> 3) * EP_LD + 4 * (idx & 7));
 }
 
 // host-side dispatch of a precision mode (fcn_pn_desc / fcn_cn_desc .precision) to the operand mode of a forward or a

@@ -304,7 +304,7 @@ extern "C" int fcn_pn_group_compact(int nscale, const fcn_pn_desc *const *d, con
         if (D->N > 65535 || D->L > 8192 || D->K > 1024 || D->B > 65535) return FCN_E_LIMIT;       // 16-bit point indices
         if (D->C1 % 64 || D->C2 % 64 || D->C3 % 64) return FCN_E_BADARG;
         if (!ws[q]->woff || !ws[q]->ent || !ws[q]->ewin || !ws[q]->tiles || !ws[q]->stat || !ws[q]->bn || !ws[q]->gmom ||
-            !ws[q]->y2)
+            !ws[q]->y2 || !ws[q]->wenc)
             return FCN_E_BADARG;
         GcScale &S = a.s[s];
         S.ref = ref[q]; S.dis_z = dis_z[q]; S.L = D->L; S.K = D->K; S.C1 = D->C1; S.C2 = D->C2; S.C3 = D->C3;
@@ -324,6 +324,8 @@ extern "C" int fcn_pn_group_compact(int nscale, const fcn_pn_desc *const *d, con
     a.use_lds = (a.N <= GC_LDS_MAX_PTS) ? 1 : 0;
     if (lds > 64 * 1024) return FCN_E_LIMIT;
     hipStream_t st = (hipStream_t)stream;
+    // split-encoded conv2 / conv3 weights of every scale (read by the GEMMs of fcn_pn_forward / fcn_pn_backward)
+    FCN_TRY(fcn_pn_pack_weights_all(nscale, d, p, ws, stream));
     hipLaunchKernelGGL(gc_hits_kernel, dim3(maxslice, a.B, nscale), dim3(GC_T), a.use_lds ? (size_t)a.N * sizeof(float) : 0, st, a);
     FCN_CHECK_LAUNCH();
     hipLaunchKernelGGL(gc_entries_kernel, dim3(a.B, nscale), dim3(GE_T), lds, st, a);

@@ -24,6 +24,9 @@
 #ifndef FCN_WIDE_TILES
 #define FCN_WIDE_TILES 0
 #endif
+#ifndef FCN_DG2_OCC
+#define FCN_DG2_OCC 3        // waves per SIMD the 64 x 128 data-gradient tile of layer 2 is compiled for (4: 128 VGPRs + 32 B scratch)
+#endif
 
 extern "C" int fcn_pn_wgrad_rows(void) { return WG_ROWS; }
 
@@ -140,7 +143,7 @@ struct DgradArgs {
     const float *gmax;      // (B,L,C3)           LAYER 3
     const float *dzcur;     // dz2 (B,cap,C2)     LAYER 2
     FcnBnBwd cb;            // BN backward of the layer being differentiated (width CRED), finalised HERE by every workgroup
-    const float *W;         // (CRED, CPREV) row-major = the conv weight (Cout,Cin)
+    const u32x4 *Wenc;      // data-gradient image of the conv weight (pn_pack_*, pointnet_fwd.hip): [CRED/32][2][4][CPREV]
     float *dybuf;           // LAYER 3: dy3 (B,cap,C3) written by the first column block
     const float *yprev;     // LAYER 3: y2 (B,cap,C2)
     const float *bn_prev;   // scale, shift, mean, rstd of the previous layer's BN (width CPREV)
@@ -154,22 +157,25 @@ struct DgradArgs {
 // <L,1,2,2> (64 x 128) and <L,1,1,2> (64 x 64) stay under 168 VGPRs: 3 workgroups per CU instead of the 2 that the
 // 128 x 128 tile's 220 VGPRs allow -- scale 4's 570 big tiles were 1.1 waves of 512 slots (two rounds, the second
 // almost empty); 1140 half tiles on 768 slots are 1.5.
+// Operands in the kb-major images of gemm_tile.h: dy rows built 8 reduction-adjacent channels at a time (one ds_write_b128
+// per part), the weight from its pre-encoded data-gradient image (plain 16-byte copies), fragments by ds_read_b128.
 template <int MM, int LAYER, int MT, int NT, int WN>
-__global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT * NT <= 2 ? 3 : 2, 4)))
+__global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT * NT <= 2 ? (LAYER == 2 ? FCN_DG2_OCC : 3) : 2, 4)))
 void dgrad_kernel(DgradArgs a)
 {
     constexpr int NTHR = 128 * WN;
     constexpr int TM = 64 * MT;               // rows of the tile
     constexpr int TN = 32 * NT * WN;
-    constexpr int LDA = TM + 1;               // k-major staging of the TM-row tile
-    constexpr int LDB = TN + 4;
-    constexpr int NA4 = TM * 8 / NTHR;        // row-quads of the A tile per thread per chunk
-    constexpr int NB4 = TN * 8 / NTHR;        // float4 of W per thread per chunk
+    constexpr int LDRA = KbTile<TM>::LDR, LDRB = KbTile<TN>::LDR;
+    constexpr int NA8 = TM * 4 / NTHR;        // (row, k-block) items of the A tile per thread per chunk
+    constexpr int NB = TN * 8 / NTHR;         // u32x4 of the encoded weight per thread per chunk
     constexpr int SUB = 128 / TM;             // workgroups per 128-row tile of the live-tile list
-    __shared__ __attribute__((aligned(16))) float As[KC * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[KC * LDB];
-    __shared__ float coefS[5 * MAXC];
+    constexpr int OPU4 = KbTile<TM>::U4 + KbTile<TN>::U4, EPU4 = (NTHR / 64) * EP_FLOATS / 4;
+    constexpr int LDSU4 = OPU4 > EPU4 ? OPU4 : EPU4;      // operand images; the waves' epilogue patches alias them
+    __shared__ u32x4 lds4[LDSU4];
+    __shared__ __attribute__((aligned(16))) float coefS[5 * MAXC];
     __shared__ __attribute__((aligned(16))) float4 uS[TM];      // (ux,uy,uz,w) of the tile rows
+    u32x4 *Ab = lds4, *Bb = lds4 + KbTile<TM>::U4;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -203,47 +209,43 @@ void dgrad_kernel(DgradArgs a)
         for (int q = 0; q < 5; ++q) coefS[q * CRED + c] = cf[q];
     }
     if (tid < TM) uS[tid] = (tid < nvalid) ? a.ent[grow0 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const int kq = tid & 7, rb = tid >> 3;
-    constexpr int RSTEP = NTHR / 8;               // rows between a thread's consecutive A quads
     // loads are UNCONDITIONAL on a clamped row (a "load or zero" branch makes hipcc wait for the load at once); rows
     // past nvalid are zeroed when the registers go to LDS
     // 32-bit element offsets (launch_dgrad checks B * cap * max(CRED, CPREV) < 2^31): half the registers and address
     // arithmetic of int64
-    int arow[NA4];        // element offset of this thread's (clamped) rows in a (rows, CRED) buffer
-    int wbase[NA4];       // LAYER 3: offset of the row's window in the (B, L, CRED) arg-max / routed-gradient maps
+    int arow[NA8];        // element offset of this thread's (clamped) rows in a (rows, CRED) buffer
+    int wbase[NA8];       // LAYER 3: offset of the row's window in the (B, L, CRED) arg-max / routed-gradient maps
 #pragma unroll
-    for (int i = 0; i < NA4; ++i) {
-        const int rc = min(rb + RSTEP * i, nvalid - 1);
-        arow[i] = ((int)grow0 + rc) * CRED;
+    for (int i = 0; i < NA8; ++i) {
+        const int f = tid + NTHR * i;
+        const int rc = min(f >> 2, nvalid - 1);
+        arow[i] = ((int)grow0 + rc) * CRED + 8 * (f & 3);
         wbase[i] = 0;
-        if constexpr (LAYER == 3) wbase[i] = (b * a.L + a.ewin[grow0 + rc]) * CRED;
+        if constexpr (LAYER == 3) wbase[i] = (b * a.L + a.ewin[grow0 + rc]) * CRED + 8 * (f & 3);
     }
     __syncthreads();
 
     f32x16 acc[MT][NT];
     acc_zero<MT, NT>(acc);
-    v4f ry[NA4], rz[NA4];
-    v4i rm[NA4];
-    v4f rw[NB4];
+    v4f ry[2 * NA8], rz[2 * NA8];
+    v4i rm[2 * NA8];
+    u32x4 rw[NB];
     const int nchunk = CRED / KC;
+    const u32x4 *wsrc = a.Wenc + k0 + (tid % TN) + (int64_t)(tid / TN) * CPREV;     // item f = tid + NTHR*i: column f % TN, (plane, k-block) f / TN
 
 #define DGRAD_LOAD(cc)                                                                                                \
     {                                                                                                                 \
-        const int nq_ = (cc) * KC + 4 * kq;                                                                           \
-        _Pragma("unroll") for (int i = 0; i < NA4; ++i) {                                                             \
-            ry[i] = ldg4(a.ycur + arow[i] + nq_);                                                                     \
+        const int nq_ = (cc) * KC;                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < NA8; ++i) {                                                             \
+            ry[2 * i] = ldg4(a.ycur + arow[i] + nq_); ry[2 * i + 1] = ldg4(a.ycur + arow[i] + nq_ + 4);               \
             if constexpr (LAYER == 3) {                                                                               \
-                rm[i] = ldg4i(a.amax + wbase[i] + nq_);                                                               \
-                rz[i] = ldg4(a.gmax + wbase[i] + nq_);                                                                \
+                rm[2 * i] = ldg4i(a.amax + wbase[i] + nq_); rm[2 * i + 1] = ldg4i(a.amax + wbase[i] + nq_ + 4);       \
+                rz[2 * i] = ldg4(a.gmax + wbase[i] + nq_); rz[2 * i + 1] = ldg4(a.gmax + wbase[i] + nq_ + 4);         \
             } else {                                                                                                  \
-                rz[i] = ldg4(a.dzcur + arow[i] + nq_);                                                                \
+                rz[2 * i] = ldg4(a.dzcur + arow[i] + nq_); rz[2 * i + 1] = ldg4(a.dzcur + arow[i] + nq_ + 4);         \
             }                                                                                                         \
         }                                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < NB4; ++i) {      /* rows 2*pr, 2*pr+1 of one column quad (a k pair) */  \
-            const int f = tid + NTHR * (i >> 1);                                                                      \
-            const int nn = 2 * (f / (TN / 4)) + (i & 1), cq = f % (TN / 4);                                           \
-            rw[i] = ldg4(a.W + ((cc) * KC + nn) * CPREV + k0 + 4 * cq);                                      \
-        }                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) rw[i] = ldgu4(wsrc + ((int64_t)(cc) * 8 + i * (NTHR / TN)) * CPREV); \
     }
 
     PNP_ADD(0);                                   // 0: prologue (tables, coefficients, first barrier)
@@ -251,49 +253,63 @@ void dgrad_kernel(DgradArgs a)
     for (int c = 0; c < nchunk; ++c) {
         PNP_ADD(1);                               // 1: issue of the global loads (+ loop overhead)
 #pragma unroll
-        for (int i = 0; i < NA4; ++i) {
-            const int r = rb + RSTEP * i;
+        for (int i = 0; i < NA8; ++i) {
+            const int f = tid + NTHR * i;
+            const int r = f >> 2, kb = f & 3;
             const bool ok = r < nvalid;
             const float w = uS[r].w;
             const int rloc = row0 + r;
-            const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
-            const float zv[4] = {rz[i].x, rz[i].y, rz[i].z, rz[i].w};
-            int mv[4] = {0, 0, 0, 0};
-            if constexpr (LAYER == 3) { mv[0] = rm[i].x; mv[1] = rm[i].y; mv[2] = rm[i].z; mv[3] = rm[i].w; }
-            float dv[4], ev[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = c * KC + 4 * kq + j;
-                float dz = zv[j];
-                if constexpr (LAYER == 3) dz = (mv[j] == rloc) ? zv[j] : 0.f;
-                const float xh = (yv[j] - coefS[CRED + n]) * coefS[2 * CRED + n];
-                const float dy = coefS[n] * (dz - w * fmaf(xh, coefS[4 * CRED + n], coefS[3 * CRED + n]));
-                dv[j] = ok ? dy : 0.f;
-            }
-            enc4<MM_ENC_A>(dv[0], dv[1], dv[2], dv[3], ev);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) As[(4 * kq + j) * LDA + r] = ev[j];
+            const float yv[8] = {ry[2 * i].x, ry[2 * i].y, ry[2 * i].z, ry[2 * i].w, ry[2 * i + 1].x, ry[2 * i + 1].y, ry[2 * i + 1].z, ry[2 * i + 1].w};
+            const float zv[8] = {rz[2 * i].x, rz[2 * i].y, rz[2 * i].z, rz[2 * i].w, rz[2 * i + 1].x, rz[2 * i + 1].y, rz[2 * i + 1].z, rz[2 * i + 1].w};
+            int mv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             if constexpr (LAYER == 3) {
-                if (ok && byi == 0)
-                    *(float4 *)(a.dybuf + (grow0 + r) * CRED + c * KC + 4 * kq) =
-                        make_float4(dv[0], dv[1], dv[2], dv[3]);
+                mv[0] = rm[2 * i].x; mv[1] = rm[2 * i].y; mv[2] = rm[2 * i].z; mv[3] = rm[2 * i].w;
+                mv[4] = rm[2 * i + 1].x; mv[5] = rm[2 * i + 1].y; mv[6] = rm[2 * i + 1].z; mv[7] = rm[2 * i + 1].w;
+            }
+            const int nb = c * KC + 8 * kb;
+            float dv[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {             // four channels at a time: 20 coefficient registers live, not 40
+                float cfv[5][4];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const v4f c4 = *(const v4f *)(coefS + q * CRED + nb + 4 * h);
+                    cfv[q][0] = c4.x; cfv[q][1] = c4.y; cfv[q][2] = c4.z; cfv[q][3] = c4.w;
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int j = 4 * h + jj;
+                    float dz = zv[j];
+                    if constexpr (LAYER == 3) dz = (mv[j] == rloc) ? zv[j] : 0.f;
+                    const float xh = (yv[j] - cfv[1][jj]) * cfv[2][jj];
+                    const float dy = cfv[0][jj] * (dz - w * fmaf(xh, cfv[4][jj], cfv[3][jj]));
+                    dv[j] = ok ? dy : 0.f;
+                }
+            }
+            u32x4 hi, lo;
+            enc8<MM_ENC_A>(dv, hi, lo);
+            Ab[kb * LDRA + r] = hi;
+            Ab[(4 + kb) * LDRA + r] = lo;
+            if constexpr (LAYER == 3) {
+                if (ok && byi == 0) {
+                    float *o = a.dybuf + (grow0 + r) * CRED + nb;
+                    const v4f d0 = {dv[0], dv[1], dv[2], dv[3]}, d1 = {dv[4], dv[5], dv[6], dv[7]};
+                    sts4(o, d0);
+                    sts4(o + 4, d1);
+                }
             }
         }
 #pragma unroll
-        for (int i = 0; i < NB4; i += 2) {
-            const int f = tid + NTHR * (i >> 1);
-            const int nn = 2 * (f / (TN / 4)), cq = f % (TN / 4);
-            v4f hi, lo;
-            enc2x4<MM_ENC_W>(rw[i], rw[i + 1], hi, lo);
-            sts4(Bs + nn * LDB + 4 * cq, hi);
-            sts4(Bs + (nn + 1) * LDB + 4 * cq, lo);
+        for (int i = 0; i < NB; ++i) {
+            const int f = tid + NTHR * i;
+            Bb[(f / TN) * LDRB + (f % TN)] = rw[i];
         }
         PNP_ADD(2);                               // 2: wait for the loads + operand transform + LDS stores
         __syncthreads();
         PNP_ADD(3);                               // 3: barrier in front of the MFMA phase
         if (c + 1 < nchunk) DGRAD_LOAD(c + 1);
         PNP_ADD(1);
-        mma_chunk<MM, MT, NT, LDA, LDB>(As, Bs, wm * 32 * MT, wn * 32 * NT, acc);
+        mma_chunk_kb<MM, MT, NT, LDRA, LDRB>(Ab, Bb, wm * 32 * MT, wn * 32 * NT, acc);
         PNP_ADD(4);                               // 4: LDS operand reads + MFMAs
         __syncthreads();
         PNP_ADD(3);                               // (3: both barriers)
@@ -303,40 +319,67 @@ void dgrad_kernel(DgradArgs a)
     PNP_ADD(3);
     // ---- epilogue: ReLU mask of the previous layer, its BN-backward statistics
     constexpr int NS = (LAYER == 3) ? 2 : 4;
-    float st[NT][NS];
+    float st[NT][NS];           // LAYER 2: per lane column l31; LAYER 3: lanes 0..7 hold (column quad lane, component j) in st3
+    float st3[NT][2][4];
+    if constexpr (LAYER == 3) {
+        // through the wave's transposition patch: the previous layer's output comes in and the masked gradient goes out as
+        // 16-byte accesses, 4 consecutive columns per lane (all four loads of a tile in flight before the first store: a store
+        // to dzprev may alias the next yprev load as far as the compiler knows)
+        float *patch = (float *)lds4 + wave * EP_FLOATS;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int col = k0 + wn * 32 * NT + nt * 32 + l31;
-        const float ps = a.bn_prev[col], pt = a.bn_prev[CPREV + col];
+        for (int nt = 0; nt < NT; ++nt) {
+            const int cq = k0 + wn * 32 * NT + nt * 32 + 4 * (lane & 7);
+            const v4f ps = ldg4(a.bn_prev + cq), pt = ldg4(a.bn_prev + CPREV + cq);
+            const v4f pm = ldg4(a.bn_prev + 2 * CPREV + cq), pr = ldg4(a.bn_prev + 3 * CPREV + cq);
+            v4f s0 = zero4(), s1 = zero4();
 #pragma unroll
-        for (int q = 0; q < NS; ++q) st[nt][q] = 0.f;
-        if constexpr (LAYER == 3) {
-            const float pm = a.bn_prev[2 * CPREV + col], pr = a.bn_prev[3 * CPREV + col];
-            // ALL loads of the previous layer's output first, then the masked stores: interleaved, every store to dzprev may
-            // alias the next yprev load as far as the compiler knows, and the 32 load -> store pairs of a lane ran one memory
-            // round trip after the other -- 37-50 % of a workgroup's cycles (tools/pn_probe.py) for 16 KB in and out
-            float yv[MT][16];
+            for (int mt = 0; mt < MT; ++mt) {
+                const int rbase = wm * 32 * MT + mt * 32;
+                v4f yv[4];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int row = min(wm * 32 * MT + mt * 32 + acc_row(reg, lh), nvalid - 1);      // clamped, unconditional
-                    yv[mt][reg] = a.yprev[(grow0 + row) * CPREV + col];
+                for (int q = 0; q < 4; ++q) {
+                    const int row = min(rbase + ((lane + 64 * q) >> 3), nvalid - 1);       // clamped, unconditional
+                    yv[q] = ldg4(a.yprev + (grow0 + row) * CPREV + cq);
                 }
+                ep_put(patch, acc[mt][nt], l31, lh);
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int row = wm * 32 * MT + mt * 32 + acc_row(reg, lh);
+                for (int q = 0; q < 4; ++q) {
+                    const int row = rbase + ((lane + 64 * q) >> 3);
+                    const v4f g = ep_get(patch, lane, q);
                     if (row < nvalid) {
-                        const float y = yv[mt][reg];
-                        const float dz = (fmaf(ps, y, pt) > 0.f) ? acc[mt][nt][reg] : 0.f;
-                        a.dzprev[(grow0 + row) * CPREV + col] = dz;
-                        st[nt][0] += dz;
-                        st[nt][1] = fmaf(dz, (y - pm) * pr, st[nt][1]);
+                        const v4f y = yv[q];
+                        v4f dz;
+                        dz.x = (fmaf(ps.x, y.x, pt.x) > 0.f) ? g.x : 0.f;
+                        dz.y = (fmaf(ps.y, y.y, pt.y) > 0.f) ? g.y : 0.f;
+                        dz.z = (fmaf(ps.z, y.z, pt.z) > 0.f) ? g.z : 0.f;
+                        dz.w = (fmaf(ps.w, y.w, pt.w) > 0.f) ? g.w : 0.f;
+                        sts4(a.dzprev + (grow0 + row) * CPREV + cq, dz);
+                        s0 += dz;
+                        s1 += dz * ((y - pm) * pr);
                     }
                 }
-        } else {
+                __builtin_amdgcn_wave_barrier();
+            }
+            const float sv[2][4] = {{s0.x, s0.y, s0.z, s0.w}, {s1.x, s1.y, s1.z, s1.w}};
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = sv[q][j];
+                    v += __shfl_xor(v, 8, 64);
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    st3[nt][q][j] = v;
+                }
+        }
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = k0 + wn * 32 * NT + nt * 32 + l31;
+            const float ps = a.bn_prev[col], pt = a.bn_prev[CPREV + col];
+#pragma unroll
+            for (int q = 0; q < NS; ++q) st[nt][q] = 0.f;
             const float al[3] = {ps * a.W1[3 * col], ps * a.W1[3 * col + 1], ps * a.W1[3 * col + 2]};
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -352,20 +395,43 @@ void dgrad_kernel(DgradArgs a)
                         st[nt][3] = fmaf(dz, u.z, st[nt][3]);
                     }
                 }
-        }
 #pragma unroll
-        for (int q = 0; q < NS; ++q) st[nt][q] += __shfl_xor(st[nt][q], 32, 64);
+            for (int q = 0; q < NS; ++q) st[nt][q] += __shfl_xor(st[nt][q], 32, 64);
+        }
     }
     PNP_ADD(5);                                   // 5: epilogue -- ReLU mask (loads of the previous layer's output), dz stores
-    float *red = As;      // [wn][nt][l31][NS], written by wm == 1
-    if (wm == 1 && lh == 0) {
+    __syncthreads();                              // (LAYER 3: every wave is done with its patch, which `red` aliases)
+    float *red = (float *)lds4;      // [wn][nt][column 0..31][NS], written by wm == 1
+    if constexpr (LAYER == 3) {
+        if (wm == 1 && lane < 8) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q = 0; q < NS; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) red[(((wn * NT + nt) * 32 + 4 * lane + j) * NS) + q] = st3[nt][q][j];
+        }
+    } else if (wm == 1 && lh == 0) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int q = 0; q < NS; ++q) red[(((wn * NT + nt) * 32 + l31) * NS) + q] = st[nt][q];
     }
     __syncthreads();
-    if (wm == 0 && lh == 0) {
+    if constexpr (LAYER == 3) {
+        if (wm == 0 && lane < 8) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q = 0; q < NS; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = k0 + wn * 32 * NT + nt * 32 + 4 * lane + j;
+                        const double v = (double)st3[nt][q][j] + (double)red[(((wn * NT + nt) * 32 + 4 * lane + j) * NS) + q];
+                        atomic_add_f64(&a.bstat_prev[q * CPREV + col], v);
+                    }
+        }
+    } else if (wm == 0 && lh == 0) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int col = k0 + wn * 32 * NT + nt * 32 + l31;
@@ -735,7 +801,7 @@ extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, co
                                 void *stream, void *stream2, void *const *events)
 {
     if (!d || !p || !ws || !dfeat || !dW || !dgamma || !dbeta) return FCN_E_BADARG;
-    if (!d->training) return FCN_E_BADARG;
+    if (!d->training || !ws->wenc) return FCN_E_BADARG;
     if (d->precision < 0 || d->precision > FCN_PREC_BF16) return FCN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     const bool two = stream2 != nullptr && events != nullptr;
@@ -758,7 +824,8 @@ extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, co
     FCN_CHECK_LAUNCH();
     DgradArgs g;
     g.ent = (const float4 *)ws->ent; g.woff = ws->woff; g.tiles = ws->tiles; g.ewin = ws->ewin; g.L = L; g.cap = cap; g.tps = tps;
-    g.ycur = ws->y3; g.amax = ws->amax; g.gmax = ws->gmax; g.dzcur = nullptr; g.W = p->W[2];
+    g.ycur = ws->y3; g.amax = ws->amax; g.gmax = ws->gmax; g.dzcur = nullptr;
+    g.Wenc = (const u32x4 *)(ws->wenc + 2 * (int64_t)C2 * C1 + (int64_t)C3 * C2);            // G3 (pn_wenc_off(3))
     g.cb.bstat = bs3; g.cb.gamma = p->gamma[2]; g.cb.bn = bn3; g.cb.invM = 1.0 / M; g.cb.dgamma = dgamma[2]; g.cb.dbeta = dbeta[2];
     g.dybuf = ws->dy3; g.yprev = ws->y2; g.bn_prev = bn2; g.W1 = nullptr; g.dzprev = ws->dz2; g.bstat_prev = bs2;
     g.CRED = C3; g.CPREV = C2;
@@ -790,7 +857,8 @@ extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, co
         e = hipEventRecord((hipEvent_t)events[2], sw);
         if (e != hipSuccess) return (int)e;
     }
-    g.ycur = ws->y2; g.amax = nullptr; g.gmax = nullptr; g.dzcur = ws->dz2; g.W = p->W[1];
+    g.ycur = ws->y2; g.amax = nullptr; g.gmax = nullptr; g.dzcur = ws->dz2;
+    g.Wenc = (const u32x4 *)(ws->wenc + (int64_t)C2 * C1 + (int64_t)C3 * C2);                // G2 (pn_wenc_off(2))
     g.cb.bstat = bs2; g.cb.gamma = p->gamma[1]; g.cb.bn = bn2; g.cb.dgamma = dgamma[1]; g.cb.dbeta = dbeta[1];
     g.dybuf = nullptr; g.yprev = nullptr; g.bn_prev = bn1; g.W1 = p->W[0]; g.dzprev = nullptr; g.bstat_prev = bsQ;
     g.CRED = C2; g.CPREV = C1;

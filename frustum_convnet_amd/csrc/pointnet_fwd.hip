@@ -88,6 +88,124 @@ __global__ void bn_finalize_kernel(const double *__restrict__ stat, const float 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Encoded weight images of one scale (fcn_pn_ws.wenc; gemm_tile.h "kb-major").  Weights change once per step, the GEMMs read
+// them hundreds of times: they are split-encoded ONCE per step into the register image of the MFMA operand, so the GEMM loops
+// stage them with plain 16-byte copies (no VALU).  Four images, each as many floats as its weight:
+//   F2, F3  forward operand of conv2 / conv3 (reduction over Cin):  [Cin/32][plane][4][Cout] u32x4 <- W[n][32c + 8kb + 0..7]
+//   G2, G3  data-gradient operand (reduction over Cout):            [Cout/32][plane][4][Cin] u32x4 <- W[32c + 8kb + 0..7][k]
+// Offsets in floats: F2 0, F3 C2*C1, G2 C2*C1 + C3*C2, G3 2*C2*C1 + C3*C2.
+__host__ __device__ inline int64_t pn_wenc_off(int img, int C1, int C2, int C3)
+{
+    const int64_t a = (int64_t)C2 * C1, b = (int64_t)C3 * C2;
+    return img == 0 ? 0 : (img == 1 ? a : (img == 2 ? a + b : 2 * a + b));
+}
+__host__ __device__ inline int64_t pn_wenc_floats(int C1, int C2, int C3) { return 2 * ((int64_t)C2 * C1 + (int64_t)C3 * C2); }
+
+// item t of one image: one (chunk, k-block, column) -> both planes
+template <int MM>
+__device__ __forceinline__ void pn_pack_item(const float *__restrict__ W, int COUT, int CIN, bool grad, int t, u32x4 *__restrict__ img)
+{
+    const int NC = grad ? CIN : COUT;                   // columns of the image
+    const int n = t % NC, r = t / NC, kb = r & 3, c = r >> 2;
+    float x[8];
+    if (!grad) {
+        const v4f a = ldg4(W + (int64_t)n * CIN + c * KC + 8 * kb), b = ldg4(W + (int64_t)n * CIN + c * KC + 8 * kb + 4);
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = W[(int64_t)(c * KC + 8 * kb + j) * CIN + n];
+    }
+    u32x4 hi, lo;
+    enc8<MM>(x, hi, lo);
+    img[((int64_t)c * 8 + kb) * NC + n] = hi;
+    img[((int64_t)c * 8 + 4 + kb) * NC + n] = lo;
+}
+
+struct PackArgs {
+    const float *W2, *W3;
+    float *wenc;
+    int C1, C2, C3, precision;
+};
+
+// items of a scale: each image has Cout*Cin/8 of them
+__device__ __forceinline__ void pn_pack_range(const PackArgs &a, int first, int step)
+{
+    const int n2 = a.C2 * a.C1 / 8, n3 = a.C3 * a.C2 / 8;
+    u32x4 *F2 = (u32x4 *)(a.wenc + pn_wenc_off(0, a.C1, a.C2, a.C3)), *F3 = (u32x4 *)(a.wenc + pn_wenc_off(1, a.C1, a.C2, a.C3));
+    u32x4 *G2 = (u32x4 *)(a.wenc + pn_wenc_off(2, a.C1, a.C2, a.C3)), *G3 = (u32x4 *)(a.wenc + pn_wenc_off(3, a.C1, a.C2, a.C3));
+    const int mmf = FCN_MM_OF(a.precision, true), mmb = FCN_MM_OF(a.precision, false);
+    for (int t = first; t < 2 * (n2 + n3); t += step) {
+        const bool grad = t >= n2 + n3;
+        const int u = grad ? t - (n2 + n3) : t;
+        const bool l3 = u >= n2;
+        const int v = l3 ? u - n2 : u;
+        const float *W = l3 ? a.W3 : a.W2;
+        const int COUT = l3 ? a.C3 : a.C2, CIN = l3 ? a.C2 : a.C1;
+        u32x4 *img = grad ? (l3 ? G3 : G2) : (l3 ? F3 : F2);
+        const int mm = grad ? mmb : mmf;
+        if (mm == MM_F32) pn_pack_item<MM_F32>(W, COUT, CIN, grad, v, img);
+        else if (mm == MM_F16X3) pn_pack_item<MM_F16X3>(W, COUT, CIN, grad, v, img);
+        else if (mm == MM_BF16X3) pn_pack_item<MM_BF16X3>(W, COUT, CIN, grad, v, img);
+        else pn_pack_item<MM_BF16X1>(W, COUT, CIN, grad, v, img);
+    }
+}
+
+__global__ __launch_bounds__(256) void pn_pack_kernel(PackArgs a)
+{
+    pn_pack_range(a, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+}
+
+// (also called by fcn_pn_group_compact's launcher for all scales of a batch)
+extern "C" int fcn_pn_pack_weights(const fcn_pn_desc *d, const fcn_pn_params *p, const fcn_pn_ws *ws, void *stream)
+{
+    if (!d || !p || !ws || !ws->wenc || !p->W[1] || !p->W[2]) return FCN_E_BADARG;
+    if (d->C1 % 64 || d->C2 % 64 || d->C3 % 64) return FCN_E_BADARG;
+    if (d->precision < 0 || d->precision > FCN_PREC_BF16 || ((uintptr_t)ws->wenc & 15)) return FCN_E_BADARG;
+    PackArgs a;
+    a.W2 = p->W[1]; a.W3 = p->W[2]; a.wenc = ws->wenc; a.C1 = d->C1; a.C2 = d->C2; a.C3 = d->C3; a.precision = d->precision;
+    const int items = 2 * (d->C2 * d->C1 + d->C3 * d->C2) / 8;
+    hipLaunchKernelGGL(pn_pack_kernel, dim3((items + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    FCN_CHECK_LAUNCH();
+    return 0;
+}
+
+struct PackAll {
+    PackArgs s[8];
+};
+__global__ __launch_bounds__(256) void pn_pack_all_kernel(PackAll a)
+{
+    // the scale is workgroup-uniform: static indices only (a dynamically indexed kernel argument goes through scratch)
+    PackArgs S = a.s[0];
+#pragma unroll
+    for (int q = 1; q < 8; ++q)
+        if ((int)blockIdx.y == q) S = a.s[q];
+    pn_pack_range(S, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+}
+
+extern "C" int fcn_pn_pack_weights_all(int nscale, const fcn_pn_desc *const *d, const fcn_pn_params *const *p,
+                                       const fcn_pn_ws *const *ws, void *stream)
+{
+    if (nscale < 1 || nscale > 8 || !d || !p || !ws) return FCN_E_BADARG;
+    PackAll a;
+    int maxitems = 0;
+    for (int s = 0; s < 8; ++s) {
+        const int q = s < nscale ? s : 0;
+        if (!d[q] || !p[q] || !ws[q] || !ws[q]->wenc || !p[q]->W[1] || !p[q]->W[2]) return FCN_E_BADARG;
+        if (d[q]->C1 % 64 || d[q]->C2 % 64 || d[q]->C3 % 64) return FCN_E_BADARG;
+        if (d[q]->precision < 0 || d[q]->precision > FCN_PREC_BF16 || ((uintptr_t)ws[q]->wenc & 15)) return FCN_E_BADARG;
+        PackArgs &S = a.s[s];
+        S.W2 = p[q]->W[1]; S.W3 = p[q]->W[2]; S.wenc = ws[q]->wenc; S.C1 = d[q]->C1; S.C2 = d[q]->C2; S.C3 = d[q]->C3;
+        S.precision = d[q]->precision;
+        const int items = 2 * (S.C2 * S.C1 + S.C3 * S.C2) / 8;
+        if (s < nscale && items > maxitems) maxitems = items;
+    }
+    // a few items per thread: the widest scale sets the grid, the narrow ones finish early
+    hipLaunchKernelGGL(pn_pack_all_kernel, dim3((maxitems + 1023) / 1024, nscale), dim3(256), 0, (hipStream_t)stream, a);
+    FCN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 struct FwdArgs {
     const float4 *ent;     // (B,cap) rows (ux,uy,uz,w)
     const int32_t *woff;   // (B,L+1)
@@ -95,7 +213,8 @@ struct FwdArgs {
     const float *aprev;    // MODE 1: (B,cap,CIN) pre-BN output of the previous conv
     const float *bn_in;    // scale[CIN], shift[CIN] of the BN in front of this conv
     const float *W1;       // MODE 0: (CIN,3)
-    const float *W;        // (COUT,CIN)
+    const u32x4 *Wenc;     // forward image of the conv weight (pn_pack_*): [CIN/32][2][4][COUT]
+    int32_t *flags;        // sticky numeric flags (fcn_pn_ws.flags) or nullptr
     float *y;              // (B,cap,COUT)
     double *stat;          // sum[COUT], sumsq[COUT] or nullptr (eval)
     int L, cap, CIN, COUT, tps;
@@ -150,17 +269,18 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
     constexpr int NTHR = 128 * WN;
     constexpr int TM = 64 * MT;               // rows of the tile
     constexpr int SUB = 128 / TM;             // workgroups per listed 128-row tile
-    constexpr int LDA = TM + 1;               // k-major staging of the TM-row tile
     constexpr int TN = 32 * NT * WN;
-    constexpr int LDB = TN + 1;
-    constexpr int NA4 = TM * 8 / NTHR;        // float4 of A per thread per chunk (MODE 1)
-    constexpr int NB4 = TN * 8 / NTHR;        // float4 of W per thread per chunk
-    constexpr int KPT = KC * TM / NTHR;       // MODE 0: k values per thread per chunk
-    __shared__ float As[KC * LDA];
-    __shared__ float Bs[KC * LDB];
-    __shared__ float tS[MAXC];
-    __shared__ float sS[MODE == 0 ? 3 * MAXC : MAXC];   // MODE 0: alpha[CIN][3]
+    constexpr int LDRA = KbTile<TM>::LDR, LDRB = KbTile<TN>::LDR;
+    constexpr int NA8 = TM * 4 / NTHR;        // (row, k-block) items of A per thread per chunk (MODE 1)
+    constexpr int NB = TN * 8 / NTHR;         // u32x4 of the encoded weight per thread per chunk
+    constexpr int KBT = 4 * TM / NTHR;        // MODE 0: k-blocks per thread per chunk
+    constexpr int OPU4 = KbTile<TM>::U4 + KbTile<TN>::U4, EPU4 = (NTHR / 64) * EP_FLOATS / 4;
+    constexpr int LDSU4 = OPU4 > EPU4 ? OPU4 : EPU4;      // operand images; the waves' epilogue patches alias them
+    __shared__ u32x4 lds4[LDSU4];
+    __shared__ __attribute__((aligned(16))) float tS[MAXC];
+    __shared__ __attribute__((aligned(16))) float sS[MODE == 0 ? 3 * MAXC : MAXC];   // MODE 0: alpha[CIN][3]
     __shared__ float wS[TM];
+    u32x4 *Ab = lds4, *Bb = lds4 + KbTile<TM>::U4;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -189,6 +309,28 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
     const int64_t grow0 = (int64_t)b * a.cap + row0;
     const int n0 = byi * TN;
     const int CIN = a.CIN, COUT = a.COUT;
+
+    u32x4 rw[NB];
+    v4f ra[MODE == 1 ? 2 * NA8 : 1];
+    const u32x4 *wsrc = a.Wenc + n0 + (tid % TN) + (int64_t)(tid / TN) * COUT;      // item f = tid + NTHR*i: column f % TN, (plane, k-block) f / TN
+    auto load_chunk = [&](int c) __attribute__((always_inline)) {
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < NA8; ++i) {
+                const int f = tid + NTHR * i;
+                const int r = f >> 2, kb = f & 3;
+                // unconditional, from a clamped row (a "load or zero" select makes the compiler wait for the load at
+                // once); rows past nvalid are zeroed when the registers go to LDS.  32-bit element offsets
+                // (launch_fwd_gemm checks B * cap * CIN < 2^31).
+                const float *q = a.aprev + ((int)grow0 + min(r, nvalid - 1)) * CIN + c * KC + 8 * kb;
+                ra[2 * i] = ldg4(q);
+                ra[2 * i + 1] = ldg4(q + 4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rw[i] = ldgu4(wsrc + ((int64_t)c * 8 + i * (NTHR / TN)) * COUT);
+    };
+    load_chunk(0);             // in flight across the prologue below
 
     for (int i = tid; i < CIN; i += NTHR) {
         float s, t;
@@ -219,92 +361,86 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
 
     f32x16 acc[MT][NT];
     acc_zero<MT, NT>(acc);
-    float4 ra[NA4], rw[NB4];
     const int nchunk = CIN / KC;
 
-    auto load_chunk = [&](int c) __attribute__((always_inline)) {
-        if constexpr (MODE == 1) {
-#pragma unroll
-            for (int i = 0; i < NA4; ++i) {
-                const int f = tid + NTHR * i;
-                const int r = f >> 3, kq = f & 7;
-                // unconditional, from a clamped row (a "load or zero" select makes the compiler wait for the load at
-                // once); rows past nvalid are zeroed when the registers go to LDS.  32-bit element offsets
-                // (launch_fwd_gemm checks B * cap * CIN < 2^31).
-                ra[i] = *(const float4 *)(a.aprev + ((int)grow0 + min(r, nvalid - 1)) * CIN + c * KC + 4 * kq);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NB4; ++i) {
-            const int f = tid + NTHR * i;
-            const int n = f >> 3, kq = f & 7;
-            rw[i] = *(const float4 *)(a.W + (n0 + n) * CIN + c * KC + 4 * kq);
-        }
-    };
-
-    load_chunk(0);
     for (int c = 0; c < nchunk; ++c) {
-        // ---- registers -> LDS (k-major), applying the input BN + ReLU
+        // ---- registers -> LDS (kb-major images), applying the input BN + ReLU
         if constexpr (MODE == 1) {
 #pragma unroll
-            for (int i = 0; i < NA4; ++i) {
+            for (int i = 0; i < NA8; ++i) {
                 const int f = tid + NTHR * i;
-                const int r = f >> 3, kq = f & 7;
+                const int r = f >> 2, kb = f & 3;
                 const bool ok = r < nvalid;
-                const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-                float z[4], e[4];
+                const float v[8] = {ra[2 * i].x, ra[2 * i].y, ra[2 * i].z, ra[2 * i].w,
+                                    ra[2 * i + 1].x, ra[2 * i + 1].y, ra[2 * i + 1].z, ra[2 * i + 1].w};
+                const v4f s0 = *(const v4f *)(sS + c * KC + 8 * kb), s1 = *(const v4f *)(sS + c * KC + 8 * kb + 4);
+                const v4f t0 = *(const v4f *)(tS + c * KC + 8 * kb), t1 = *(const v4f *)(tS + c * KC + 8 * kb + 4);
+                const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                const float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                float z[8];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = 4 * kq + j;
-                    z[j] = fmaf(sS[c * KC + k], v[j], tS[c * KC + k]);
-                    z[j] = ok ? fmaxf(z[j], 0.f) : 0.f;
-                }
-                enc4<MM_ENC_A>(z[0], z[1], z[2], z[3], e);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) As[(4 * kq + j) * LDA + r] = e[j];
+                for (int j = 0; j < 8; ++j) z[j] = ok ? fmaxf(fmaf(sv[j], v[j], tv[j]), 0.f) : 0.f;
+                u32x4 hi, lo;
+                enc8<MM_ENC_A>(z, hi, lo);
+                Ab[kb * LDRA + r] = hi;
+                Ab[(4 + kb) * LDRA + r] = lo;
             }
         } else {
             const int part = tid / TM;
 #pragma unroll
-            for (int j = 0; j < KPT; j += 2) {
-                const int k = part * KPT + j;
-                const int kk = c * KC + k;
-                const float z0 = l1_pre(&sS[3 * kk], tS[kk], ux, uy, uz);
-                const float z1 = l1_pre(&sS[3 * kk + 3], tS[kk + 1], ux, uy, uz);
-                float e0, e1;
-                enc2<MM_ENC_A>(r0valid ? fmaxf(z0, 0.f) : 0.f, r0valid ? fmaxf(z1, 0.f) : 0.f, e0, e1);
-                As[k * LDA + r0] = e0;
-                As[(k + 1) * LDA + r0] = e1;
+            for (int q = 0; q < KBT; ++q) {
+                const int kb = part * KBT + q;
+                float z[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int kk = c * KC + 8 * kb + j;
+                    const float zz = l1_pre(&sS[3 * kk], tS[kk], ux, uy, uz);
+                    z[j] = r0valid ? fmaxf(zz, 0.f) : 0.f;
+                }
+                u32x4 hi, lo;
+                enc8<MM_ENC_A>(z, hi, lo);
+                Ab[kb * LDRA + r0] = hi;
+                Ab[(4 + kb) * LDRA + r0] = lo;
             }
         }
 #pragma unroll
-        for (int i = 0; i < NB4; ++i) {
+        for (int i = 0; i < NB; ++i) {
             const int f = tid + NTHR * i;
-            const int n = f >> 3, kq = f & 7;
-            float v[4];
-            enc4<MM_ENC_W>(rw[i].x, rw[i].y, rw[i].z, rw[i].w, v);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) Bs[(4 * kq + j) * LDB + n] = v[j];
+            Bb[(f / TN) * LDRB + (f % TN)] = rw[i];       // (plane, k-block) row f / TN of the image
         }
         __syncthreads();
         if (c + 1 < nchunk) load_chunk(c + 1);
-        mma_chunk<MM, MT, NT, LDA, LDB>(As, Bs, wm * 32 * MT, wn * 32 * NT, acc);
+        mma_chunk_kb<MM, MT, NT, LDRA, LDRB>(Ab, Bb, wm * 32 * MT, wn * 32 * NT, acc);
         __syncthreads();
     }
 
-    // ---- epilogue: store y (valid rows), per-channel weighted statistics
+    // ---- epilogue: y out as 16-byte stores through the wave's transposition patch, per-channel weighted statistics
+    float *patch = (float *)lds4 + wave * EP_FLOATS;          // (the operand buffers are free after the last barrier)
+    bool bad = false;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt) {
+            ep_put(patch, acc[mt][nt], l31, lh);
+            __builtin_amdgcn_wave_barrier();
+            const int rbase = wm * 32 * MT + mt * 32, cbase = n0 + wn * 32 * NT + nt * 32;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int row = wm * 32 * MT + mt * 32 + acc_row(reg, lh);
-                const int col = n0 + wn * 32 * NT + nt * 32 + l31;
-                if (row < nvalid) a.y[(grow0 + row) * COUT + col] = acc[mt][nt][reg];
+            for (int q = 0; q < 4; ++q) {
+                const int idx = lane + 64 * q, row = rbase + (idx >> 3);
+                const v4f v = ep_get(patch, lane, q);
+                if constexpr (MM == MM_F16X3) bad |= !(fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w) < 3.0e38f);
+                if (row < nvalid) sts4(a.y + (grow0 + row) * COUT + cbase + 4 * (idx & 7), v);
             }
+            __builtin_amdgcn_wave_barrier();
+        }
+    if constexpr (MM == MM_F16X3) {
+        // fp16 operand parts overflow at |x| >= 65504 (inf - inf = NaN in the products, which a later ReLU would turn into a
+        // silent zero): a non-finite output raises the sticky flag of the workspace
+        if (a.flags && __ballot(bad) != 0ull && lane == 0) atomicOr(a.flags, FCN_FLAG_NONFINITE);
+    }
     if (a.stat) {
-        float *red = As;   // free after the last barrier: [wn][nt*32+l31][2] written by the wm==1 waves
+        __syncthreads();                                      // every wave is done with its patch (red aliases them)
+        float *red = (float *)lds4;   // [wn][nt*32+l31][2] written by the wm==1 waves
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             float s1 = 0.f, s2 = 0.f;
@@ -522,7 +658,7 @@ static int launch_fwd_gemm(const FwdArgs &a, int B, int precision, hipStream_t s
 extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, const int32_t *cnt,
                               const float *one_hot, const fcn_pn_ws *ws, float *feat, void *stream)
 {
-    if (!d || !p || !ws || !cnt || !feat) return FCN_E_BADARG;
+    if (!d || !p || !ws || !cnt || !feat || !ws->wenc) return FCN_E_BADARG;
     if (d->C1 % 64 || d->C2 % 64 || d->C3 % 64 || d->C1 > MAXC || d->C2 > MAXC) return FCN_E_BADARG;
     if (d->nvec > 0 && !one_hot && !d->nlc) return FCN_E_BADARG;
     if (d->nvec * PW > GT) return FCN_E_LIMIT;
@@ -536,7 +672,8 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
     float *bn3 = ws->bn + fcn_bn_off(2, C1, C2);
     double *st2 = ws->stat + FCN_STAT_L2, *st3 = st2 + 2 * C2;
 
-    if (!d->grouped) {                  // (fcn_pn_group_compact already finalised BN1 from the input moments)
+    if (!d->grouped) {                  // (fcn_pn_group_compact already finalised BN1 from the input moments and packed the weights)
+        FCN_TRY(fcn_pn_pack_weights(d, p, ws, stream));
         hipLaunchKernelGGL(bn1_finalize_kernel, dim3((C1 + 63) / 64), dim3(64), 0, st, ws->stat + FCN_STAT_MOM,
                            p->W[0], p->gamma[0], p->beta[0], p->running_mean[0], p->running_var[0],
                            p->num_batches_tracked[0], C1, tr, d->eps, d->momentum, M, bn1);
@@ -545,14 +682,15 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
 
     FwdArgs a;
     a.ent = (const float4 *)ws->ent; a.woff = ws->woff; a.tiles = ws->tiles; a.L = L; a.cap = cap; a.tps = (cap + 127) / 128;
-    a.aprev = nullptr; a.bn_in = bn1; a.W1 = p->W[0]; a.W = p->W[1]; a.y = ws->y2;
+    a.aprev = nullptr; a.bn_in = bn1; a.W1 = p->W[0]; a.Wenc = (const u32x4 *)(ws->wenc + pn_wenc_off(0, C1, C2, C3)); a.y = ws->y2;
+    a.flags = ws->flags;
     a.stat = tr ? st2 : nullptr; a.CIN = C1; a.COUT = C2;
     a.stat_in = nullptr; a.gamma_in = a.beta_in = nullptr; a.rmean_in = a.rvar_in = nullptr; a.nbt_in = nullptr; a.bn_pub = nullptr;
     a.M = M; a.eps = d->eps; a.momentum = d->momentum;
     FCN_TRY(launch_fwd_gemm<0>(a, B, d->precision, st));
 
     // BN2 is finalised by conv3's workgroups (no launch in between)
-    a.aprev = ws->y2; a.bn_in = bn2; a.W1 = nullptr; a.W = p->W[2]; a.y = ws->y3;
+    a.aprev = ws->y2; a.bn_in = bn2; a.W1 = nullptr; a.Wenc = (const u32x4 *)(ws->wenc + pn_wenc_off(1, C1, C2, C3)); a.y = ws->y3;
     a.stat = tr ? st3 : nullptr; a.CIN = C2; a.COUT = C3;
     a.stat_in = tr ? st2 : nullptr; a.gamma_in = p->gamma[1]; a.beta_in = p->beta[1];
     a.rmean_in = p->running_mean[1]; a.rvar_in = p->running_var[1]; a.nbt_in = p->num_batches_tracked[1]; a.bn_pub = bn2;
@@ -592,8 +730,9 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
 extern "C" int fcn_pn_conv_fwd(const fcn_pn_desc *d, const fcn_pn_params *p, const fcn_pn_ws *ws, int layer,
                                int with_stats, void *stream)
 {
-    if (!d || !p || !ws || (layer != 2 && layer != 3)) return FCN_E_BADARG;
+    if (!d || !p || !ws || (layer != 2 && layer != 3) || !ws->wenc) return FCN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
+    FCN_TRY(fcn_pn_pack_weights(d, p, ws, stream));
     const int B = d->B, L = d->L, K = d->K, C1 = d->C1, C2 = d->C2, C3 = d->C3;
     const int cap = L * K;
     double *st2 = ws->stat + FCN_STAT_L2, *st3 = st2 + 2 * C2;
@@ -601,12 +740,13 @@ extern "C" int fcn_pn_conv_fwd(const fcn_pn_desc *d, const fcn_pn_params *p, con
     a.ent = (const float4 *)ws->ent; a.woff = ws->woff; a.tiles = ws->tiles; a.L = L; a.cap = cap; a.tps = (cap + 127) / 128;
     a.stat_in = nullptr; a.gamma_in = a.beta_in = nullptr; a.rmean_in = a.rvar_in = nullptr; a.nbt_in = nullptr; a.bn_pub = nullptr;
     a.M = 1.0; a.eps = d->eps; a.momentum = d->momentum;       // the BN in front is read finished from ws->bn
+    a.flags = ws->flags;
     if (layer == 2) {
-        a.aprev = nullptr; a.bn_in = ws->bn + fcn_bn_off(0, C1, C2); a.W1 = p->W[0]; a.W = p->W[1]; a.y = ws->y2;
+        a.aprev = nullptr; a.bn_in = ws->bn + fcn_bn_off(0, C1, C2); a.W1 = p->W[0]; a.Wenc = (const u32x4 *)(ws->wenc + pn_wenc_off(0, C1, C2, C3)); a.y = ws->y2;
         a.stat = with_stats ? st2 : nullptr; a.CIN = C1; a.COUT = C2;
         return launch_fwd_gemm<0>(a, B, d->precision, st);
     }
-    a.aprev = ws->y2; a.bn_in = ws->bn + fcn_bn_off(1, C1, C2); a.W1 = nullptr; a.W = p->W[2]; a.y = ws->y3;
+    a.aprev = ws->y2; a.bn_in = ws->bn + fcn_bn_off(1, C1, C2); a.W1 = nullptr; a.Wenc = (const u32x4 *)(ws->wenc + pn_wenc_off(1, C1, C2, C3)); a.y = ws->y3;
     a.stat = with_stats ? st3 : nullptr; a.CIN = C2; a.COUT = C3;
     return launch_fwd_gemm<1>(a, B, d->precision, st);
 }

@@ -379,6 +379,31 @@ class PointNetDet(nn.Module):
         keep, cnt = fdet.rotate_nms_3d(dets, valid, unit_group, L2, num_groups, thresh if method == 'nms' else 2.0, top_k)
         return dets, valid, keep, cnt
 
+    def numeric_flags(self, device=None):
+        """OR of the sticky FCN_FLAG_* bits the forward GEMMs of this model have raised so far, as a device int32 tensor (no
+        host synchronisation; .item() it whenever convenient -- every N steps, at a checkpoint).  Bit FCN_FLAG_NONFINITE (1): a
+        forward GEMM produced a non-finite output -- in the default split precision the fp16 operand parts overflow at
+        |x| >= 65504, and the following ReLU would turn the resulting NaN into a silent zero."""
+        pools = [n._pool for n in self.feat_net.nets] + [self._cn_pool]
+        ts = [t for pl in pools for k, t in pl._flags.items() if device is None or k == str(device)]
+        if not ts:
+            return torch.zeros(1, dtype=torch.int32, device=device if device is not None else self.reg_out.weight.device)
+        out = ts[0].clone()
+        for t in ts[1:]:
+            out |= t
+        return out
+
+    def check_numerics(self):
+        """Raises FloatingPointError when a numeric flag is up (synchronises); clears the flags."""
+        f = int(self.numeric_flags().item())
+        for pl in [n._pool for n in self.feat_net.nets] + [self._cn_pool]:
+            for t in pl._flags.values():
+                t.zero_()
+        if f & 1:
+            raise FloatingPointError("frustum_convnet_amd: a forward GEMM produced a non-finite value (fp16 operand overflow in "
+                                     "split precision, |x| >= 65504, or a genuine overflow); rerun with precision 'f32' or 'bf16'")
+        return f
+
     def backward(self, loss):
         """loss.backward() seeded with a cached unit gradient (loss_fused.unit_grad): two tiny kernels (ones fill, multiply by
         one) less between the loss tail and the first backward GEMM.  Same gradients."""

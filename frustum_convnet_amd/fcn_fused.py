@@ -30,7 +30,7 @@ def num_levels(conv_net):
 
 
 class CnWorkspace:
-    def __init__(self, desc, device, need_grad):
+    def __init__(self, desc, device, need_grad, flags=None):
         L = _native.lib()
         sizes = (ctypes.c_int64 * 6)()
         _native.check(L.fcn_convnet_sizes(ctypes.byref(desc), ctypes.byref(sizes)), "fcn_convnet_sizes")
@@ -47,9 +47,10 @@ class CnWorkspace:
             self.dz = torch.empty(ny, dtype=f32, device=device)
             self.bstat = torch.zeros(nst, dtype=f64, device=device)
             self.coef = torch.empty(ncoef, dtype=f32, device=device)
+        self.flags = flags if flags is not None else torch.zeros(1, dtype=torch.int32, device=device)
         p = lambda t: None if t is None else t.data_ptr()
         self.c = CnWs(p(self.y), p(self.dz), p(self.wp), p(self.bn), p(self.stat), p(self.bstat), p(self.coef),
-                      p(self.partial), p(self.oh64))
+                      p(self.partial), p(self.oh64), p(self.flags))
 
 
 # gradient tensor (data_ptr) -> event its consumer must wait for: set by _ConvNetFused.backward for the feature-map
@@ -69,6 +70,14 @@ class CnPool:
         self.side = {}
         self.cont = {}
         self.last_done = None
+        self._flags = {}
+
+    def flags(self, device):
+        """Sticky FCN_FLAG_* bits of every workspace of this pool on `device` (one int32 tensor, zeroed at creation)."""
+        key = str(device)
+        if key not in self._flags:
+            self._flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        return self._flags[key]
 
     def cont_stream(self, device):
         """Continuation stream of the backward + its events (caller-owned, handed to fcn_convnet_backward)."""
@@ -96,7 +105,7 @@ class CnPool:
         lst = self.free.setdefault(k, [])
         if lst:
             return lst.pop()
-        ws = CnWorkspace(desc, device, need_grad)
+        ws = CnWorkspace(desc, device, need_grad, flags=self.flags(device))
         ws.pool_key = k
         return ws
 

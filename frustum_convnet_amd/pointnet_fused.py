@@ -19,7 +19,7 @@ class Workspace:
     """Caller-owned scratch of one scale (fcn_pn_ws).  Persistent across steps, recycled through the
     owning module's free list so that two forwards in flight (before their backwards) never share one."""
 
-    def __init__(self, B, N, L, K, C1, C2, C3, device, need_grad):
+    def __init__(self, B, N, L, K, C1, C2, C3, device, need_grad, flags=None):
         cap = L * K
         f32, i32, f64 = torch.float32, torch.int32, torch.float64
         dev = device
@@ -36,6 +36,8 @@ class Workspace:
         self.bn = torch.empty((4 * (C1 + C2 + C3),), dtype=f32, device=dev)
         self.gmom = torch.zeros((B * 12,), dtype=f64, device=dev)       # fcn_pn_group_compact: per-frustum moments + counter
         self.cnt = torch.empty((B, L), dtype=i32, device=dev)           # window hit counts of the fused grouping
+        self.wenc = torch.empty((2 * (C2 * C1 + C3 * C2),), dtype=f32, device=dev)      # split-encoded conv2 / conv3 weights
+        self.flags = flags if flags is not None else torch.zeros((1,), dtype=i32, device=dev)      # sticky FCN_FLAG_* bits
         self.amax = self.gmax = self.dy3 = self.dz2 = self.bstat = self.coef = self.partial = None
         self.nsplit = 0
         if need_grad:
@@ -50,7 +52,7 @@ class Workspace:
         p = lambda t: None if t is None else t.data_ptr()
         self.c = PnWs(p(self.woff), p(self.ent), p(self.ewin), p(self.tiles), p(self.y2), p(self.y3), p(self.amax),
                       p(self.stat), p(self.bn), p(self.gmax), p(self.dy3), p(self.dz2), p(self.bstat),
-                      p(self.coef), p(self.partial), self.nsplit, p(self.gmom))
+                      p(self.coef), p(self.partial), self.nsplit, p(self.gmom), p(self.wenc), p(self.flags))
 
 
 class WorkspacePool:
@@ -58,6 +60,14 @@ class WorkspacePool:
         self.free = {}
         self.side = {}
         self.side_wgrad = False     # weight-gradient GEMMs of the backward on a second stream (fcn_pn_backward2)
+        self._flags = {}
+
+    def flags(self, device):
+        """Sticky FCN_FLAG_* bits of every workspace of this pool on `device` (one int32 tensor, zeroed at creation)."""
+        key = str(device)
+        if key not in self._flags:
+            self._flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        return self._flags[key]
 
     def side_stream(self, device):
         """Second HIP stream + 3 events (caller-owned, handed to fcn_pn_backward2) per device."""
@@ -77,7 +87,7 @@ class WorkspacePool:
         lst = self.free.setdefault(k, [])
         if lst:
             return lst.pop()
-        ws = Workspace(*key, device=device, need_grad=need_grad)
+        ws = Workspace(*key, device=device, need_grad=need_grad, flags=self.flags(device))
         ws.pool_key = k
         return ws
 

@@ -125,7 +125,18 @@ typedef struct fcn_pn_ws {
     double  *gmom;               /* (B,12) doubles, fcn_pn_group_compact only (may be NULL otherwise): per-frustum input moments +
                                     an arrival counter; zero it, and tiles[0..3], ONCE at allocation (the call leaves
                                     its counters at zero) */
+    float   *wenc;               /* 2*(C2*C1 + C3*C2) floats, 16-byte aligned: the conv2 / conv3 weights split-encoded in MFMA
+                                    operand order (forward + data-gradient images), rewritten by every forward
+                                    (fcn_pn_pack_weights[_all]) and read by the forward and backward GEMMs                    */
+    int32_t *flags;              /* 1 int32 of sticky FCN_FLAG_* bits, or NULL: zero it once, read it whenever convenient    */
 } fcn_pn_ws;
+
+/* Sticky numeric flags (fcn_pn_ws.flags, fcn_cn_ws.flags): the kernels only ever OR bits in.
+ *   FCN_FLAG_NONFINITE  a forward GEMM produced a non-finite output.  In FCN_PREC_SPLIT the forward operands are split into
+ *                       fp16 parts, which overflow at |x| >= 65504 (the products turn into inf - inf = NaN and the next ReLU
+ *                       would silently turn that into 0): results of this step are not to be trusted -- rerun in FCN_PREC_F32
+ *                       or FCN_PREC_BF16, whose operands keep the fp32 exponent range. */
+#define FCN_FLAG_NONFINITE 1
 
 /* rows of one row tile (128): the caller sizes ws.tiles / ws.partial with it */
 int fcn_pn_wgrad_rows(void);
@@ -143,6 +154,12 @@ int fcn_pn_compact(const fcn_pn_desc *d, const float *pc /*(B,3,N)*/, const floa
 int fcn_pn_group_compact(int nscale, const fcn_pn_desc *const *d, const fcn_pn_params *const *p, const float *pc,
                          const float *const *ref, const float *dis_z, const fcn_pn_ws *const *ws, int32_t *const *cnt,
                          void *stream);
+
+/* Split-encodes the conv2 / conv3 weights of one scale into ws->wenc (one small launch).  fcn_pn_forward does it itself on
+ * descriptors with grouped == 0; fcn_pn_group_compact does it for all its scales (fcn_pn_pack_weights_all, one launch). */
+int fcn_pn_pack_weights(const fcn_pn_desc *d, const fcn_pn_params *p, const fcn_pn_ws *ws, void *stream);
+int fcn_pn_pack_weights_all(int nscale, const fcn_pn_desc *const *d, const fcn_pn_params *const *p,
+                            const fcn_pn_ws *const *ws, void *stream);
 
 /* Whole forward of one scale after fcn_pn_compact: feat (B, C3+nvec, L), one_hot (B,nvec) or NULL.  In training mode its
  * last kernel also zeroes ws.bstat (when non-NULL) for the fcn_pn_backward that follows. */
@@ -211,6 +228,7 @@ typedef struct fcn_cn_ws {
     double *stat, *bstat;
     float  *coef, *partial;      /* coef: unused since BN backward is finalised by its consumers (kept in the layout) */
     float  *oh64;                /* B * 64 floats: the one-hot vector zero-padded to 64 channels */
+    int32_t *flags;              /* 1 int32 of sticky FCN_FLAG_* bits, or NULL (see fcn_pn_ws.flags) */
 } fcn_cn_ws;
 
 int fcn_convnet_sizes(const fcn_cn_desc *d, int64_t *out6);

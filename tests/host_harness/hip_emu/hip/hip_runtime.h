@@ -406,6 +406,7 @@ inline T emu_fetch_add(T *p, T v)          // real atomics: workgroups run on se
 inline unsigned atomicAdd(unsigned *p, unsigned v) { return emu_fetch_add(p, v); }
 inline int atomicAdd(int *p, int v) { return emu_fetch_add(p, v); }
 inline float atomicAdd(float *p, float v) { return emu_fetch_add(p, v); }
+inline int atomicOr(int *p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned long long wall_clock64() { return 0ull; }
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 template <class T>

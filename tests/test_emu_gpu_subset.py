@@ -74,6 +74,7 @@ CASES = [
     ("test_gpu_model", "test_fused_convnet_matches_module_path", ("refine_b4_n512",)),
     ("test_gpu_model", "test_fused_convnet_matches_module_path", ("people_b2_n512",)),
     ("test_gpu_model", "test_gradients_vs_fp64_oracle", ()),
+    ("test_gpu_model", "test_fp16_operand_overflow_raises_the_flag", ()),
 ]
 
 

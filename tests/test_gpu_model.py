@@ -290,3 +290,41 @@ def test_bf16_mode_logits(case):
     cls2, reg2 = m2.last_logits
     assert np.abs(cls2[sel].detach().cpu().numpy() - g["cls_train"]).max() < TOL
     assert np.abs(reg2[sel].detach().cpu().numpy() - g["reg_train"]).max() < TOL
+
+
+def test_fp16_operand_overflow_raises_the_flag():
+    """in split precision the forward operands are fp16 x 3 and overflow at |x| >= 65504.  With a BatchNorm
+    gamma scaled by 1e4 (activations of order 1e5) the affected products are inf - inf = NaN, which the next ReLU would turn
+    into a silent 0: the forward GEMMs raise a sticky flag instead -- never a silent wrong answer.  The same weights in the
+    fp32 operand mode stay finite and raise nothing."""
+    from frustum_convnet_amd import precision
+    g = load_golden("car_b4_n512")
+    data = synth.to_torch(golden_inputs(g), "cuda")
+    m = _model(g)
+    m.train()
+    losses, _ = m(data)
+    assert int(m.numeric_flags().item()) == 0                  # ordinary weights: clean
+    assert m.check_numerics() == 0
+    for where in ("feat_net.pointnet3.conv2.1.weight", "conv_net.block2_conv1.1.weight"):
+        m2 = _model(g)
+        m2.train()
+        with torch.no_grad():
+            dict(m2.named_parameters())[where].mul_(1e4)
+        losses, _ = m2(data)
+        torch.cuda.synchronize()
+        flags = int(m2.numeric_flags().item())
+        finite = bool(torch.isfinite(m2.last_logits64).all())
+        print("gamma x 1e4 at %s: flags %d, logits finite %s" % (where, flags, finite))
+        assert flags & 1, where
+        with pytest.raises(FloatingPointError):
+            m2.check_numerics()
+        assert int(m2.numeric_flags().item()) == 0             # cleared by the check
+        with precision.precision("f32"):
+            m3 = _model(g)
+            m3.train()
+            with torch.no_grad():
+                dict(m3.named_parameters())[where].mul_(1e4)
+            m3(data)
+            assert int(m3.numeric_flags().item()) == 0, where
+            assert bool(torch.isfinite(m3.last_logits64).all())
+
