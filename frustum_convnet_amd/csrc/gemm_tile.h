@@ -243,6 +243,28 @@ __device__ __forceinline__ void enc8(const float (&x)[8], u32x4 &hi, u32x4 &lo)
     }
 }
 
+// Stores the four reduction-adjacent values k = 4*kq .. 4*kq + 3 (chunk-local) of row r into a kb-major chunk image: one
+// ds_write_b64 per part.  A thread that loaded ONE 16-byte piece of a row uses this -- the wave's load instruction then covers
+// 8 rows x 128 contiguous bytes; having a thread load both halves of a k-block (32 B) instead makes every load instruction
+// touch half lines of 16 rows (measured: the data-gradient kernels 15 % slower).
+typedef float v2f_kb __attribute__((ext_vector_type(2)));
+template <int MM, int LDR>
+__device__ __forceinline__ void kb_store4(u32x4 *img, int r, int kq, float x0, float x1, float x2, float x3)
+{
+    const int kb = kq >> 1, half = kq & 1;
+    if constexpr (MM == MM_F32) {
+        const v4f v = {x0, x1, x2, x3};
+        *(v4f *)(img + (half * 4 + kb) * LDR + r) = v;
+    } else {
+        float h0, l0, h1, l1;
+        enc2<MM>(x0, x1, h0, l0);
+        enc2<MM>(x2, x3, h1, l1);
+        const v2f_kb h = {h0, h1}, l = {l0, l1};
+        *(v2f_kb *)((float *)(img + kb * LDR + r) + 2 * half) = h;
+        if constexpr (MM != MM_BF16X1) *(v2f_kb *)((float *)(img + (4 + kb) * LDR + r) + 2 * half) = l;
+    }
+}
+
 typedef const u32x4 __attribute__((address_space(1))) *gu4p;
 __device__ __forceinline__ u32x4 ldgu4(const u32x4 *p) { return *(gu4p)p; }
 

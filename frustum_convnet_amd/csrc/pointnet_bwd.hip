@@ -167,7 +167,7 @@ void dgrad_kernel(DgradArgs a)
     constexpr int TM = 64 * MT;               // rows of the tile
     constexpr int TN = 32 * NT * WN;
     constexpr int LDRA = KbTile<TM>::LDR, LDRB = KbTile<TN>::LDR;
-    constexpr int NA8 = TM * 4 / NTHR;        // (row, k-block) items of the A tile per thread per chunk
+    constexpr int NA4 = TM * 8 / NTHR;        // 16-byte pieces of the A tile per thread per chunk
     constexpr int NB = TN * 8 / NTHR;         // u32x4 of the encoded weight per thread per chunk
     constexpr int SUB = 128 / TM;             // workgroups per 128-row tile of the live-tile list
     constexpr int OPU4 = KbTile<TM>::U4 + KbTile<TN>::U4, EPU4 = (NTHR / 64) * EP_FLOATS / 4;
@@ -213,22 +213,22 @@ void dgrad_kernel(DgradArgs a)
     // past nvalid are zeroed when the registers go to LDS
     // 32-bit element offsets (launch_dgrad checks B * cap * max(CRED, CPREV) < 2^31): half the registers and address
     // arithmetic of int64
-    int arow[NA8];        // element offset of this thread's (clamped) rows in a (rows, CRED) buffer
-    int wbase[NA8];       // LAYER 3: offset of the row's window in the (B, L, CRED) arg-max / routed-gradient maps
+    int arow[NA4];        // element offset of this thread's piece (clamped row) in a (rows, CRED) buffer
+    int wbase[NA4];       // LAYER 3: offset of the piece in its row's window of the (B, L, CRED) arg-max / routed-gradient maps
 #pragma unroll
-    for (int i = 0; i < NA8; ++i) {
+    for (int i = 0; i < NA4; ++i) {
         const int f = tid + NTHR * i;
-        const int rc = min(f >> 2, nvalid - 1);
-        arow[i] = ((int)grow0 + rc) * CRED + 8 * (f & 3);
+        const int rc = min(f >> 3, nvalid - 1);
+        arow[i] = ((int)grow0 + rc) * CRED + 4 * (f & 7);
         wbase[i] = 0;
-        if constexpr (LAYER == 3) wbase[i] = (b * a.L + a.ewin[grow0 + rc]) * CRED + 8 * (f & 3);
+        if constexpr (LAYER == 3) wbase[i] = (b * a.L + a.ewin[grow0 + rc]) * CRED + 4 * (f & 7);
     }
     __syncthreads();
 
     f32x16 acc[MT][NT];
     acc_zero<MT, NT>(acc);
-    v4f ry[2 * NA8], rz[2 * NA8];
-    v4i rm[2 * NA8];
+    v4f ry[NA4], rz[NA4];
+    v4i rm[NA4];
     u32x4 rw[NB];
     const int nchunk = CRED / KC;
     const u32x4 *wsrc = a.Wenc + k0 + (tid % TN) + (int64_t)(tid / TN) * CPREV;     // item f = tid + NTHR*i: column f % TN, (plane, k-block) f / TN
@@ -236,13 +236,13 @@ void dgrad_kernel(DgradArgs a)
 #define DGRAD_LOAD(cc)                                                                                                \
     {                                                                                                                 \
         const int nq_ = (cc) * KC;                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < NA8; ++i) {                                                             \
-            ry[2 * i] = ldg4(a.ycur + arow[i] + nq_); ry[2 * i + 1] = ldg4(a.ycur + arow[i] + nq_ + 4);               \
+        _Pragma("unroll") for (int i = 0; i < NA4; ++i) {                                                             \
+            ry[i] = ldg4(a.ycur + arow[i] + nq_);                                                                     \
             if constexpr (LAYER == 3) {                                                                               \
-                rm[2 * i] = ldg4i(a.amax + wbase[i] + nq_); rm[2 * i + 1] = ldg4i(a.amax + wbase[i] + nq_ + 4);       \
-                rz[2 * i] = ldg4(a.gmax + wbase[i] + nq_); rz[2 * i + 1] = ldg4(a.gmax + wbase[i] + nq_ + 4);         \
+                rm[i] = ldg4i(a.amax + wbase[i] + nq_);                                                               \
+                rz[i] = ldg4(a.gmax + wbase[i] + nq_);                                                                \
             } else {                                                                                                  \
-                rz[2 * i] = ldg4(a.dzcur + arow[i] + nq_); rz[2 * i + 1] = ldg4(a.dzcur + arow[i] + nq_ + 4);         \
+                rz[i] = ldg4(a.dzcur + arow[i] + nq_);                                                                \
             }                                                                                                         \
         }                                                                                                             \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) rw[i] = ldgu4(wsrc + ((int64_t)(cc) * 8 + i * (NTHR / TN)) * CPREV); \
@@ -253,49 +253,37 @@ void dgrad_kernel(DgradArgs a)
     for (int c = 0; c < nchunk; ++c) {
         PNP_ADD(1);                               // 1: issue of the global loads (+ loop overhead)
 #pragma unroll
-        for (int i = 0; i < NA8; ++i) {
+        for (int i = 0; i < NA4; ++i) {
             const int f = tid + NTHR * i;
-            const int r = f >> 2, kb = f & 3;
+            const int r = f >> 3, kq = f & 7;
             const bool ok = r < nvalid;
             const float w = uS[r].w;
             const int rloc = row0 + r;
-            const float yv[8] = {ry[2 * i].x, ry[2 * i].y, ry[2 * i].z, ry[2 * i].w, ry[2 * i + 1].x, ry[2 * i + 1].y, ry[2 * i + 1].z, ry[2 * i + 1].w};
-            const float zv[8] = {rz[2 * i].x, rz[2 * i].y, rz[2 * i].z, rz[2 * i].w, rz[2 * i + 1].x, rz[2 * i + 1].y, rz[2 * i + 1].z, rz[2 * i + 1].w};
-            int mv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if constexpr (LAYER == 3) {
-                mv[0] = rm[2 * i].x; mv[1] = rm[2 * i].y; mv[2] = rm[2 * i].z; mv[3] = rm[2 * i].w;
-                mv[4] = rm[2 * i + 1].x; mv[5] = rm[2 * i + 1].y; mv[6] = rm[2 * i + 1].z; mv[7] = rm[2 * i + 1].w;
+            const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
+            const float zv[4] = {rz[i].x, rz[i].y, rz[i].z, rz[i].w};
+            int mv[4] = {0, 0, 0, 0};
+            if constexpr (LAYER == 3) { mv[0] = rm[i].x; mv[1] = rm[i].y; mv[2] = rm[i].z; mv[3] = rm[i].w; }
+            const int nb = c * KC + 4 * kq;
+            float cfv[5][4];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const v4f c4 = *(const v4f *)(coefS + q * CRED + nb);
+                cfv[q][0] = c4.x; cfv[q][1] = c4.y; cfv[q][2] = c4.z; cfv[q][3] = c4.w;
             }
-            const int nb = c * KC + 8 * kb;
-            float dv[8];
+            float dv[4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {             // four channels at a time: 20 coefficient registers live, not 40
-                float cfv[5][4];
-#pragma unroll
-                for (int q = 0; q < 5; ++q) {
-                    const v4f c4 = *(const v4f *)(coefS + q * CRED + nb + 4 * h);
-                    cfv[q][0] = c4.x; cfv[q][1] = c4.y; cfv[q][2] = c4.z; cfv[q][3] = c4.w;
-                }
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int j = 4 * h + jj;
-                    float dz = zv[j];
-                    if constexpr (LAYER == 3) dz = (mv[j] == rloc) ? zv[j] : 0.f;
-                    const float xh = (yv[j] - cfv[1][jj]) * cfv[2][jj];
-                    const float dy = cfv[0][jj] * (dz - w * fmaf(xh, cfv[4][jj], cfv[3][jj]));
-                    dv[j] = ok ? dy : 0.f;
-                }
+            for (int j = 0; j < 4; ++j) {
+                float dz = zv[j];
+                if constexpr (LAYER == 3) dz = (mv[j] == rloc) ? zv[j] : 0.f;
+                const float xh = (yv[j] - cfv[1][j]) * cfv[2][j];
+                const float dy = cfv[0][j] * (dz - w * fmaf(xh, cfv[4][j], cfv[3][j]));
+                dv[j] = ok ? dy : 0.f;
             }
-            u32x4 hi, lo;
-            enc8<MM_ENC_A>(dv, hi, lo);
-            Ab[kb * LDRA + r] = hi;
-            Ab[(4 + kb) * LDRA + r] = lo;
+            kb_store4<MM_ENC_A, LDRA>(Ab, r, kq, dv[0], dv[1], dv[2], dv[3]);
             if constexpr (LAYER == 3) {
                 if (ok && byi == 0) {
-                    float *o = a.dybuf + (grow0 + r) * CRED + nb;
-                    const v4f d0 = {dv[0], dv[1], dv[2], dv[3]}, d1 = {dv[4], dv[5], dv[6], dv[7]};
-                    sts4(o, d0);
-                    sts4(o + 4, d1);
+                    const v4f d0 = {dv[0], dv[1], dv[2], dv[3]};
+                    sts4(a.dybuf + (grow0 + r) * CRED + nb, d0);
                 }
             }
         }

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
     constexpr int SUB = 128 / TM;             // workgroups per listed 128-row tile
     constexpr int TN = 32 * NT * WN;
     constexpr int LDRA = KbTile<TM>::LDR, LDRB = KbTile<TN>::LDR;
-    constexpr int NA8 = TM * 4 / NTHR;        // (row, k-block) items of A per thread per chunk (MODE 1)
+    constexpr int NA4 = TM * 8 / NTHR;        // 16-byte pieces of A per thread per chunk (MODE 1)
     constexpr int NB = TN * 8 / NTHR;         // u32x4 of the encoded weight per thread per chunk
     constexpr int KBT = 4 * TM / NTHR;        // MODE 0: k-blocks per thread per chunk
     constexpr int OPU4 = KbTile<TM>::U4 + KbTile<TN>::U4, EPU4 = (NTHR / 64) * EP_FLOATS / 4;
@@ -311,20 +311,18 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
     const int CIN = a.CIN, COUT = a.COUT;
 
     u32x4 rw[NB];
-    v4f ra[MODE == 1 ? 2 * NA8 : 1];
+    v4f ra[MODE == 1 ? NA4 : 1];
     const u32x4 *wsrc = a.Wenc + n0 + (tid % TN) + (int64_t)(tid / TN) * COUT;      // item f = tid + NTHR*i: column f % TN, (plane, k-block) f / TN
     auto load_chunk = [&](int c) __attribute__((always_inline)) {
         if constexpr (MODE == 1) {
 #pragma unroll
-            for (int i = 0; i < NA8; ++i) {
+            for (int i = 0; i < NA4; ++i) {
                 const int f = tid + NTHR * i;
-                const int r = f >> 2, kb = f & 3;
+                const int r = f >> 3, kq = f & 7;
                 // unconditional, from a clamped row (a "load or zero" select makes the compiler wait for the load at
                 // once); rows past nvalid are zeroed when the registers go to LDS.  32-bit element offsets
                 // (launch_fwd_gemm checks B * cap * CIN < 2^31).
-                const float *q = a.aprev + ((int)grow0 + min(r, nvalid - 1)) * CIN + c * KC + 8 * kb;
-                ra[2 * i] = ldg4(q);
-                ra[2 * i + 1] = ldg4(q + 4);
+                ra[i] = ldg4(a.aprev + ((int)grow0 + min(r, nvalid - 1)) * CIN + c * KC + 4 * kq);
             }
         }
 #pragma unroll
@@ -367,23 +365,14 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
         // ---- registers -> LDS (kb-major images), applying the input BN + ReLU
         if constexpr (MODE == 1) {
 #pragma unroll
-            for (int i = 0; i < NA8; ++i) {
+            for (int i = 0; i < NA4; ++i) {
                 const int f = tid + NTHR * i;
-                const int r = f >> 2, kb = f & 3;
+                const int r = f >> 3, kq = f & 7;
                 const bool ok = r < nvalid;
-                const float v[8] = {ra[2 * i].x, ra[2 * i].y, ra[2 * i].z, ra[2 * i].w,
-                                    ra[2 * i + 1].x, ra[2 * i + 1].y, ra[2 * i + 1].z, ra[2 * i + 1].w};
-                const v4f s0 = *(const v4f *)(sS + c * KC + 8 * kb), s1 = *(const v4f *)(sS + c * KC + 8 * kb + 4);
-                const v4f t0 = *(const v4f *)(tS + c * KC + 8 * kb), t1 = *(const v4f *)(tS + c * KC + 8 * kb + 4);
-                const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-                const float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-                float z[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) z[j] = ok ? fmaxf(fmaf(sv[j], v[j], tv[j]), 0.f) : 0.f;
-                u32x4 hi, lo;
-                enc8<MM_ENC_A>(z, hi, lo);
-                Ab[kb * LDRA + r] = hi;
-                Ab[(4 + kb) * LDRA + r] = lo;
+                const v4f s4 = *(const v4f *)(sS + c * KC + 4 * kq), t4 = *(const v4f *)(tS + c * KC + 4 * kq);
+                const float z0 = ok ? fmaxf(fmaf(s4.x, ra[i].x, t4.x), 0.f) : 0.f, z1 = ok ? fmaxf(fmaf(s4.y, ra[i].y, t4.y), 0.f) : 0.f;
+                const float z2 = ok ? fmaxf(fmaf(s4.z, ra[i].z, t4.z), 0.f) : 0.f, z3 = ok ? fmaxf(fmaf(s4.w, ra[i].w, t4.w), 0.f) : 0.f;
+                kb_store4<MM_ENC_A, LDRA>(Ab, r, kq, z0, z1, z2, z3);
             }
         } else {
             const int part = tid / TM;

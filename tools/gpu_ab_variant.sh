@@ -9,12 +9,22 @@ fi
 for i in 1 2; do
   for lib in prod $V; do
     if [ $lib = prod ]; then unset FCN_LIB_NAME; else export FCN_LIB_NAME=libfcn_hip_$lib.so; fi
-    timeout 90 python bench.py --no-cpu-baseline --no-roofline --min-time 1.5 > $O/ab_${lib}_$i.json 2> $O/ab_${lib}_$i.err
+    timeout 90 python bench.py --no-cpu-baseline --no-roofline --no-configs --min-time 1.5 > $O/ab_${lib}_$i.json 2> $O/ab_${lib}_$i.err
     echo "$lib $i: $(python -c "import json,sys; d=json.loads(open('$O/ab_${lib}_$i.json').read().strip().split(chr(10))[-1]); print(d['value'], d['ms_per_step'])" 2>&1 | tail -1)"
   done
 done
-[ -n "$SKIP_PHASES" ] && exit 0
+if [ -z "$SKIP_PHASES" ]; then
 for lib in prod $V; do
   if [ $lib = prod ]; then unset FCN_LIB_NAME; else export FCN_LIB_NAME=libfcn_hip_$lib.so; fi
   timeout 90 python tools/phase_stamps.py > $O/ab_${lib}_phases.txt 2>&1; echo "-- phases $lib"; tail -8 $O/ab_${lib}_phases.txt
 done
+fi
+if [ -n "$PROF" ]; then      # per-kernel averages of both libraries (rocprofv3 kernel trace over a short bench run)
+for lib in prod $V; do
+  if [ $lib = prod ]; then unset FCN_LIB_NAME; else export FCN_LIB_NAME=libfcn_hip_$lib.so; fi
+  R=$GRAFT_REPO_ROOT; cd /tmp; rm -rf /tmp/prof_$lib
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$lib -o b -- python $R/bench.py --steps 20 --warmup 3 --min-time 0 --no-cpu-baseline --no-roofline --no-configs > /dev/null 2>&1
+  cd $R; for f in $(find /tmp/prof_$lib -name "*kernel_stats*.csv"); do cp $f $O/ab_${lib}_kernel_stats.csv; done
+  echo "-- kernel stats $lib"; head -14 $O/ab_${lib}_kernel_stats.csv | cut -d, -f1-4 | cut -c1-150
+done
+fi
