@@ -170,8 +170,7 @@ void dgrad_kernel(DgradArgs a)
     constexpr int NA4 = TM * 8 / NTHR;        // 16-byte pieces of the A tile per thread per chunk
     constexpr int NB = TN * 8 / NTHR;         // u32x4 of the encoded weight per thread per chunk
     constexpr int SUB = 128 / TM;             // workgroups per 128-row tile of the live-tile list
-    constexpr int OPU4 = KbTile<TM>::U4 + KbTile<TN>::U4, EPU4 = (NTHR / 64) * EP_FLOATS / 4;
-    constexpr int LDSU4 = OPU4 > EPU4 ? OPU4 : EPU4;      // operand images; the waves' epilogue patches alias them
+    constexpr int LDSU4 = KbTile<TM>::U4 + KbTile<TN>::U4;
     __shared__ u32x4 lds4[LDSU4];
     __shared__ __attribute__((aligned(16))) float coefS[5 * MAXC];
     __shared__ __attribute__((aligned(16))) float4 uS[TM];      // (ux,uy,uz,w) of the tile rows
@@ -307,67 +306,43 @@ void dgrad_kernel(DgradArgs a)
     PNP_ADD(3);
     // ---- epilogue: ReLU mask of the previous layer, its BN-backward statistics
     constexpr int NS = (LAYER == 3) ? 2 : 4;
-    float st[NT][NS];           // LAYER 2: per lane column l31; LAYER 3: lanes 0..7 hold (column quad lane, component j) in st3
-    float st3[NT][2][4];
-    if constexpr (LAYER == 3) {
-        // through the wave's transposition patch: the previous layer's output comes in and the masked gradient goes out as
-        // 16-byte accesses, 4 consecutive columns per lane (all four loads of a tile in flight before the first store: a store
-        // to dzprev may alias the next yprev load as far as the compiler knows)
-        float *patch = (float *)lds4 + wave * EP_FLOATS;
+    float st[NT][NS];
+    // (LAYER 3 through a transposition patch -- the previous layer's output in and the masked gradient out as 16-byte accesses,
+    // 4 columns per lane -- measured 20 % (64 x 128 tiles) to 100 % (64 x 64) SLOWER than this register form on MI355X: four
+    // loads in flight per lane instead of sixteen, and 24 cross-lane sums per column tile instead of 2)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int cq = k0 + wn * 32 * NT + nt * 32 + 4 * (lane & 7);
-            const v4f ps = ldg4(a.bn_prev + cq), pt = ldg4(a.bn_prev + CPREV + cq);
-            const v4f pm = ldg4(a.bn_prev + 2 * CPREV + cq), pr = ldg4(a.bn_prev + 3 * CPREV + cq);
-            v4f s0 = zero4(), s1 = zero4();
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = k0 + wn * 32 * NT + nt * 32 + l31;
+        const float ps = a.bn_prev[col], pt = a.bn_prev[CPREV + col];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int rbase = wm * 32 * MT + mt * 32;
-                v4f yv[4];
+        for (int q = 0; q < NS; ++q) st[nt][q] = 0.f;
+        if constexpr (LAYER == 3) {
+            const float pm = a.bn_prev[2 * CPREV + col], pr = a.bn_prev[3 * CPREV + col];
+            // ALL loads of the previous layer's output first, then the masked stores: interleaved, every store to dzprev may
+            // alias the next yprev load as far as the compiler knows, and the 32 load -> store pairs of a lane ran one memory
+            // round trip after the other -- 37-50 % of a workgroup's cycles (tools/pn_probe.py) for 16 KB in and out
+            float yv[MT][16];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int row = min(rbase + ((lane + 64 * q) >> 3), nvalid - 1);       // clamped, unconditional
-                    yv[q] = ldg4(a.yprev + (grow0 + row) * CPREV + cq);
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = min(wm * 32 * MT + mt * 32 + acc_row(reg, lh), nvalid - 1);      // clamped, unconditional
+                    yv[mt][reg] = a.yprev[(grow0 + row) * CPREV + col];
                 }
-                ep_put(patch, acc[mt][nt], l31, lh);
-                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int row = rbase + ((lane + 64 * q) >> 3);
-                    const v4f g = ep_get(patch, lane, q);
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = wm * 32 * MT + mt * 32 + acc_row(reg, lh);
                     if (row < nvalid) {
-                        const v4f y = yv[q];
-                        v4f dz;
-                        dz.x = (fmaf(ps.x, y.x, pt.x) > 0.f) ? g.x : 0.f;
-                        dz.y = (fmaf(ps.y, y.y, pt.y) > 0.f) ? g.y : 0.f;
-                        dz.z = (fmaf(ps.z, y.z, pt.z) > 0.f) ? g.z : 0.f;
-                        dz.w = (fmaf(ps.w, y.w, pt.w) > 0.f) ? g.w : 0.f;
-                        sts4(a.dzprev + (grow0 + row) * CPREV + cq, dz);
-                        s0 += dz;
-                        s1 += dz * ((y - pm) * pr);
+                        const float y = yv[mt][reg];
+                        const float dz = (fmaf(ps, y, pt) > 0.f) ? acc[mt][nt][reg] : 0.f;
+                        a.dzprev[(grow0 + row) * CPREV + col] = dz;
+                        st[nt][0] += dz;
+                        st[nt][1] = fmaf(dz, (y - pm) * pr, st[nt][1]);
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
-            }
-            const float sv[2][4] = {{s0.x, s0.y, s0.z, s0.w}, {s1.x, s1.y, s1.z, s1.w}};
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = sv[q][j];
-                    v += __shfl_xor(v, 8, 64);
-                    v += __shfl_xor(v, 16, 64);
-                    v += __shfl_xor(v, 32, 64);
-                    st3[nt][q][j] = v;
-                }
-        }
-    } else {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int col = k0 + wn * 32 * NT + nt * 32 + l31;
-            const float ps = a.bn_prev[col], pt = a.bn_prev[CPREV + col];
-#pragma unroll
-            for (int q = 0; q < NS; ++q) st[nt][q] = 0.f;
+        } else {
             const float al[3] = {ps * a.W1[3 * col], ps * a.W1[3 * col + 1], ps * a.W1[3 * col + 2]};
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -383,43 +358,20 @@ void dgrad_kernel(DgradArgs a)
                         st[nt][3] = fmaf(dz, u.z, st[nt][3]);
                     }
                 }
-#pragma unroll
-            for (int q = 0; q < NS; ++q) st[nt][q] += __shfl_xor(st[nt][q], 32, 64);
         }
+#pragma unroll
+        for (int q = 0; q < NS; ++q) st[nt][q] += __shfl_xor(st[nt][q], 32, 64);
     }
     PNP_ADD(5);                                   // 5: epilogue -- ReLU mask (loads of the previous layer's output), dz stores
-    __syncthreads();                              // (LAYER 3: every wave is done with its patch, which `red` aliases)
-    float *red = (float *)lds4;      // [wn][nt][column 0..31][NS], written by wm == 1
-    if constexpr (LAYER == 3) {
-        if (wm == 1 && lane < 8) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int q = 0; q < NS; ++q)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) red[(((wn * NT + nt) * 32 + 4 * lane + j) * NS) + q] = st3[nt][q][j];
-        }
-    } else if (wm == 1 && lh == 0) {
+    float *red = (float *)lds4;      // [wn][nt][l31][NS], written by wm == 1 (the operand images are free after the last barrier)
+    if (wm == 1 && lh == 0) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int q = 0; q < NS; ++q) red[(((wn * NT + nt) * 32 + l31) * NS) + q] = st[nt][q];
     }
     __syncthreads();
-    if constexpr (LAYER == 3) {
-        if (wm == 0 && lane < 8) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int q = 0; q < NS; ++q)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int col = k0 + wn * 32 * NT + nt * 32 + 4 * lane + j;
-                        const double v = (double)st3[nt][q][j] + (double)red[(((wn * NT + nt) * 32 + 4 * lane + j) * NS) + q];
-                        atomic_add_f64(&a.bstat_prev[q * CPREV + col], v);
-                    }
-        }
-    } else if (wm == 0 && lh == 0) {
+    if (wm == 0 && lh == 0) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int col = k0 + wn * 32 * NT + nt * 32 + l31;

@@ -19,6 +19,9 @@
 #ifndef FCN_WIDE_TILES
 #define FCN_WIDE_TILES 0
 #endif
+#ifndef FCN_FWD_EPI_DIRECT
+#define FCN_FWD_EPI_DIRECT 0
+#endif
 
 // ------------------------------------------------------------------------------------------------
 __global__ void bn1_finalize_kernel(const double *__restrict__ mom, const float *__restrict__ W1,
@@ -404,8 +407,22 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
     }
 
     // ---- epilogue: y out as 16-byte stores through the wave's transposition patch, per-channel weighted statistics
-    float *patch = (float *)lds4 + wave * EP_FLOATS;          // (the operand buffers are free after the last barrier)
     bool bad = false;
+#if FCN_FWD_EPI_DIRECT      // (tuning builds: one dword per lane straight from the accumulator layout -- the round-2 epilogue)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = wm * 32 * MT + mt * 32 + acc_row(reg, lh);
+                const int col = n0 + wn * 32 * NT + nt * 32 + l31;
+                const float v = acc[mt][nt][reg];
+                if constexpr (MM == MM_F16X3) bad |= !(fabsf(v) < 3.0e38f);
+                if (row < nvalid) a.y[(grow0 + row) * COUT + col] = v;
+            }
+#else
+    float *patch = (float *)lds4 + wave * EP_FLOATS;          // (the operand buffers are free after the last barrier)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -422,6 +439,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
             }
             __builtin_amdgcn_wave_barrier();
         }
+#endif
     if constexpr (MM == MM_F16X3) {
         // fp16 operand parts overflow at |x| >= 65504 (inf - inf = NaN in the products, which a later ReLU would turn into a
         // silent zero): a non-finite output raises the sticky flag of the workspace
