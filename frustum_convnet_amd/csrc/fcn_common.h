@@ -42,20 +42,39 @@ __device__ __forceinline__ void atomic_add_f64(double *p, double v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// REPLICATED statistic slots.  The BatchNorm sums (forward: sum / sum of squares; backward: sum dz / sum dz*xhat) are fp64
+// atomics of per-workgroup partials.  Atomics on ONE address are served one after the other by the memory side (~18 ns each on
+// MI355X): a launch of 600 workgroups that all add to the same 128 channel slots spent 5-11 us of a 14-17 us kernel there
+// (timing builds without the atomics: PointNet conv3 of the narrow scales 16.9 -> 11.5 us, their data-gradient kernels 23 us of
+// 93 per scale).  Every slot therefore exists FCN_STAT_REP times; a workgroup adds to replica blockIdx.x % FCN_STAT_REP (its XCD)
+// and every consumer sums the replicas in replica order (fcn_rep_sum).  A replica block is `stride` doubles apart.
+#ifndef FCN_STAT_REP
+#define FCN_STAT_REP 8
+#endif
+__device__ __forceinline__ double fcn_rep_sum(const double *p, int stride)
+{
+    double v = p[0];
+#pragma unroll
+    for (int r = 1; r < FCN_STAT_REP; ++r) v += p[(int64_t)r * stride];
+    return v;
+}
+__device__ __forceinline__ int fcn_rep_id() { return (int)(blockIdx.x % FCN_STAT_REP); }
+
 // Coefficients of a BatchNorm backward, derived by every CONSUMER workgroup from the batch sums (a few fp64 products per
 // channel) instead of by a one-workgroup launch between two layers of a latency-bound chain:
 //   dy = c0 * (dz - (c3 + xhat * c4)),  xhat = (y - c1) * c2
 //   c0 = gamma * rstd, c1 = mean, c2 = rstd, c3 = sum(dz) / M, c4 = sum(dz * xhat) / M
 // bstat: sum dz [C], sum dz * xhat [C] (final when the consumer starts); bn: scale, shift, mean, rstd [C] of the forward.
 struct FcnBnBwd {
-    const double *bstat;
+    const double *bstat;       // replica 0 of [sum dz [C], sum dz * xhat [C]]
+    int rep_stride;            // doubles between replicas (fcn_rep_sum)
     const float *gamma, *bn;
     double invM;
     float *dgamma, *dbeta;     // exported by the workgroup flagged `pub` (fp32), or null
 };
 __device__ __forceinline__ void fcn_bnbwd_coef(const FcnBnBwd &q, int C, int c, float (&cf)[5], bool pub)
 {
-    const double db = q.bstat[c], dg = q.bstat[C + c];
+    const double db = fcn_rep_sum(q.bstat + c, q.rep_stride), dg = fcn_rep_sum(q.bstat + C + c, q.rep_stride);
     const float rstd = q.bn[3 * C + c];
     cf[0] = q.gamma[c] * rstd;
     cf[1] = q.bn[2 * C + c];
@@ -79,8 +98,10 @@ __device__ __forceinline__ double fcn_rsqrt64(double x)
 //   [0]      sum w          (= B*L*K)
 //   [1..3]   sum w*u
 //   [4..9]   sum w*u*u^T    (xx,xy,xz,yy,yz,zz)
-//   [16 .. 16+2*C2)            layer-2 sum, sumsq
-//   [16+2*C2 .. 16+2*C2+2*C3)  layer-3 sum, sumsq
+//   then FCN_STAT_REP replica blocks of 2*C2 + 2*C3 doubles, block r at 16 + r * (2*C2 + 2*C3):
+//     [0 .. 2*C2)            layer-2 sum, sumsq
+//     [2*C2 .. 2*C2+2*C3)    layer-3 sum, sumsq
+// fcn_pn_ws.bstat: FCN_STAT_REP replica blocks of 2*C3 + 2*C2 + 4*C1 doubles (dbeta3, dgamma3, dbeta2, dgamma2, Q[4][C1])
 #define FCN_STAT_MOM 0
 #define FCN_STAT_L2 16
 

@@ -19,6 +19,18 @@
 #include "gemm_tile.h"
 
 #define CG_T 256
+// replicas of the FCN's BatchNorm sum slots (fcn_common.h: same-address fp64 atomics are served one at a time).  Every
+// consumer workgroup of this latency-bound chain sums them in its prologue, so fewer than the PointNet kernels' 8.
+#ifndef FCN_CG_REP
+#define FCN_CG_REP 4
+#endif
+__device__ __forceinline__ double cg_rep_sum(const double *p, int stride)
+{
+    double v = p[0];
+#pragma unroll
+    for (int r = 1; r < FCN_CG_REP; ++r) v += p[(int64_t)r * stride];
+    return v;
+}
 // forward tile of the K-group kernels: (32*FCN_FT_MW) x (32*FCN_FT_WNC) outputs, FCN_FT_G K-groups (tuning builds override)
 #ifndef FCN_FT_MW
 #define FCN_FT_MW 1
@@ -64,8 +76,9 @@ struct CgLayer {
     const float *bias;         // (nbias) or nullptr
     int nbias;
     float *y;                  // (B*Lout, Cout) pre-BN output
-    double *stat;              // sum[Cs], sumsq[Cs] or nullptr
+    double *stat;              // sum[Cs], sumsq[Cs] (replica 0) or nullptr
     float eps, momentum;
+    int rep_stride;            // doubles between the replica blocks of every stat pointer of this layer (the whole arena)
     int32_t *flags;            // sticky numeric flags (fcn_cn_ws.flags) or nullptr
 };
 
@@ -203,8 +216,8 @@ __device__ __forceinline__ void cg_fill_bn(const CgLayer &L, float *sS, float *t
                 for (int k = tid; k < C; k += nthr) {
                     double mean, var;
                     if (batch) {
-                        mean = S.stat[k] * invM;
-                        var = S.stat[C + k] * invM - mean * mean;
+                        mean = cg_rep_sum(S.stat + k, L.rep_stride) * invM;
+                        var = cg_rep_sum(S.stat + C + k, L.rep_stride) * invM - mean * mean;
                         if (var < 0.0) var = 0.0;
                     } else {
                         mean = S.rmean[k];
@@ -425,7 +438,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         double a = 0.0;
 #pragma unroll
         for (int r = 0; r < NTHR / 64; ++r) a += (double)st[(r * TNC + c) * 2 + w];
-        atomic_add_f64(&L.stat[w * L.Cs + (n0 + c) % L.Cs], a);
+        atomic_add_f64(&L.stat[(int64_t)(blockIdx.x % FCN_CG_REP) * L.rep_stride + w * L.Cs + (n0 + c) % L.Cs], a);
     }
     PROBE_STAMP();                                      // 6: statistics added
     PROBE_FLUSH(((unsigned long long)L.Ktot << 32) | ((unsigned long long)L.Cout << 16) | (unsigned long long)(L.Lout & 0xffff));
@@ -465,7 +478,8 @@ __global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_pair_kernel(CgLayer
 // dgamma/M.  Like the forward's scale/shift they are derived by every consumer workgroup in its prologue; the
 // designated workgroup also exports dgamma / dbeta.
 struct CgBnBwd {
-    const double *bstat;       // sum dz [Cs], sum dz*xhat [Cs] (final); nullptr: the layer has no BN (heads)
+    const double *bstat;       // sum dz [Cs], sum dz*xhat [Cs] (final, replica 0); nullptr: the layer has no BN (heads)
+    int rep_stride;            // doubles between replica blocks (the whole bstat arena)
     const float *gamma, *bn;   // bn: (scale, shift, mean, rstd) published by the forward
     double M;
     float *dgamma, *dbeta;     // non-null on the launch that exports them
@@ -473,7 +487,7 @@ struct CgBnBwd {
 
 __device__ __forceinline__ void cg_bnbwd_coef(const CgBnBwd &q, int Cs, int c, float (&cf)[5], bool pub)
 {
-    const double db = q.bstat[c], dg = q.bstat[Cs + c];
+    const double db = cg_rep_sum(q.bstat + c, q.rep_stride), dg = cg_rep_sum(q.bstat + Cs + c, q.rep_stride);
     const float rstd = q.bn[3 * Cs + c];
     cf[0] = q.gamma[c] * rstd;
     cf[1] = q.bn[2 * Cs + c];
@@ -815,7 +829,7 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
         double v = 0.0;
 #pragma unroll
         for (int r = 0; r < NTHR / 64; ++r) v += (double)st[(r * 64 + c) * 2 + w];
-        atomic_add_f64(&bstat_src[w * C + c0 + c], v);
+        atomic_add_f64(&bstat_src[(int64_t)(blockIdx.x % FCN_CG_REP) * cb.rep_stride + w * C + c0 + c], v);
     }
 }
 
@@ -1222,7 +1236,7 @@ extern "C" int fcn_convnet_sizes(const fcn_cn_desc *d, int64_t *out6)
     out6[0] = O.y[P.nl];      // floats: y (and dz) of all layers
     out6[1] = O.wp[P.nl];     // floats: packed weights
     out6[2] = O.bn[P.nl];     // floats: bn scale/shift/mean/rstd
-    out6[3] = O.st[P.nl];     // doubles: stat (and bstat)
+    out6[3] = (int64_t)FCN_CG_REP * O.st[P.nl];     // doubles: stat (and bstat), FCN_CG_REP replica blocks each
     out6[4] = O.coef[P.nl];   // floats: coef
     out6[5] = pmax;                // floats: wgrad partials
     return 0;
@@ -1234,7 +1248,7 @@ static void cn_fill_layer(const fcn_cn_desc *d, const fcn_cn_params *p, const Cn
     L.nseg = P.nseg[l]; L.KT = P.KT[l]; L.stride = P.stride[l]; L.pad = P.pad[l];
     L.Lin = P.Lin[l]; L.Lout = P.Lout[l]; L.B = d->B; L.Cout = P.N[l]; L.Ktot = P.Ktot[l]; L.Cs = P.Cs[l];
     L.Wp = ws->wp + O.wp[l]; L.bias = nullptr; L.nbias = 0; L.y = ws->y + O.y[l]; L.stat = nullptr; L.flags = ws->flags;
-    L.eps = d->eps; L.momentum = d->momentum;
+    L.eps = d->eps; L.momentum = d->momentum; L.rep_stride = O.st[P.nl];
     for (int s = 0; s < CG_NSEG; ++s) {
         CgSeg &S = L.seg[s];
         S.x = nullptr; S.bn = nullptr; S.C = P.C[l][s]; S.Lsrc = P.Lin[l]; S.type = 0; S.nvec = 0;
@@ -1278,7 +1292,7 @@ static int cn_pack(const fcn_cn_desc *d, const fcn_cn_params *p, const CnPlan &P
         t.src[l] = nullptr; t.dst[l] = nullptr; t.pre[l + 1] = t.pre[l]; t.nrow_real[l] = 0;
     }
     t.oh = one_hot; t.oh64 = ws->oh64; t.B = d->B; t.nvec = d->nvec;
-    t.z0 = d->training ? ws->stat : nullptr; t.z1 = d->training ? ws->bstat : nullptr; t.nz = O.st[P.nl];
+    t.z0 = d->training ? ws->stat : nullptr; t.z1 = d->training ? ws->bstat : nullptr; t.nz = FCN_CG_REP * O.st[P.nl];
     hipLaunchKernelGGL(cg_pack_kernel,
                        dim3((unsigned)((t.pre[CN_NLAYER] + (int64_t)d->B * OH_PAD + t.nz + 255) / 256)), dim3(256), 0, st, t);
     FCN_CHECK_LAUNCH();
@@ -1455,7 +1469,7 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
     // data-gradient + weight-gradient roles of layer l (l < 0: none); returns the workgroups in front of the reduce role
     auto make_step = [&](int l, float *pbuf, CgBwdStep &a, CgReduce &own, int &own_blocks) -> int {
         a.ndg = 0; a.w_ns = 0; a.w_ny = 1; a.rows = 2 * KC; a.partial = nullptr; a.dz = nullptr;
-        a.cb.bstat = nullptr; a.cb.gamma = nullptr; a.cb.bn = nullptr; a.cb.M = 1.0; a.cb.dgamma = nullptr; a.cb.dbeta = nullptr;
+        a.cb.bstat = nullptr; a.cb.rep_stride = O.st[P.nl]; a.cb.gamma = nullptr; a.cb.bn = nullptr; a.cb.M = 1.0; a.cb.dgamma = nullptr; a.cb.dbeta = nullptr;
         CgDgSeg *dgs[CG_NSEG] = {&a.dg[0], &a.dg[1], &a.dg[2], &a.dg[3]};
         for (int s = 0; s < CG_NSEG; ++s) {
             dgs[s]->sg = 0; dgs[s]->segoff = 0; dgs[s]->ysrc = dgs[s]->bnsrc = nullptr; dgs[s]->out = nullptr;

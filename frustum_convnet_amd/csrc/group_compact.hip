@@ -36,7 +36,7 @@ struct GcScale {
     int32_t *woff, *ewin, *tiles, *cnt;
     float4 *ent;
     unsigned short *ghits;     // (B,L,K) first-K hit lists as 16-bit point indices (scratch: lives in ws.y2, free until conv2)
-    double *stat;              // 16 + 2*C2 + 2*C3
+    double *stat;              // 16 + FCN_STAT_REP * (2*C2 + 2*C3)
     double *gmom;              // (B,GC_MOM)
     const float *W1, *gamma, *beta;
     float *rmean, *rvar;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(GE_T) void gc_entries_kernel(GcArgs a)
         }
     }
     // BN sum slots of the conv launches that follow
-    for (int i = 10 + tid; i < 16 + 2 * S.C2 + 2 * S.C3; i += GE_T) S.stat[i] = 0.0;
+    for (int i = 10 + tid; i < 16 + FCN_STAT_REP * (2 * S.C2 + 2 * S.C3); i += GE_T) S.stat[i] = 0.0;      // every replica block
     __syncthreads();
     // BN1 scale / shift from the moments (conv1 is linear in u): what bn1_finalize_kernel computes
     {

@@ -198,7 +198,7 @@ extern "C" int fcn_pn_compact(const fcn_pn_desc *d, const float *pc, const float
     if (d->B <= 0 || d->L <= 0 || d->K <= 0 || d->N <= 0) return FCN_E_BADARG;
     if (d->L > 8192 || d->K > 1024 || d->B > 65535) return FCN_E_LIMIT;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(ws->stat, 0, sizeof(double) * (size_t)(16 + 2 * d->C2 + 2 * d->C3), st);
+    hipError_t e = hipMemsetAsync(ws->stat, 0, sizeof(double) * (size_t)(16 + FCN_STAT_REP * (2 * d->C2 + 2 * d->C3)), st);
     if (e != hipSuccess) return (int)e;
     dim3 grid(CP_SLICES, d->B);
     hipLaunchKernelGGL(compact_kernel, grid, dim3(CP_THREADS), sizeof(int) * (size_t)(d->L + 1), st,

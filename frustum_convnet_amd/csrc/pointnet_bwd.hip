@@ -24,11 +24,18 @@
 #ifndef FCN_WIDE_TILES
 #define FCN_WIDE_TILES 0
 #endif
+// TIMING EXPERIMENTS ONLY (tuning builds, results are wrong when set): FCN_XB bits in dgrad_kernel -- 1: A-side loads for the first
+// chunk only, 2: W loads first chunk only, 4: staging first chunk only, 8: no MFMAs, 16: no epilogue, 32: no dz stores, 64: no
+// statistics atomics, 128: no dy3 store
+#ifndef FCN_XB
+#define FCN_XB 0
+#endif
 #ifndef FCN_DG2_OCC
 #define FCN_DG2_OCC 3        // waves per SIMD the 64 x 128 data-gradient tile of layer 2 is compiled for (4: 128 VGPRs + 32 B scratch)
 #endif
 
 extern "C" int fcn_pn_wgrad_rows(void) { return WG_ROWS; }
+extern "C" int fcn_stat_replicas(void) { return FCN_STAT_REP; }
 
 // Intra-kernel cycle accounting of the data-gradient GEMM for TUNING BUILDS ONLY (-DFCN_PROBE, tools/pn_probe.py; never
 // compiled into the product): wave 0 of every workgroup sums the shader-clock cycles it spends in each phase of the K loop.
@@ -71,7 +78,7 @@ extern "C" int fcn_pn_probe_read(unsigned long long *host_out, int max_records, 
 // reduces dbeta3 / dgamma3 over its windows before one fp64 atomic pair per channel.
 __global__ __launch_bounds__(GT) void poolbwd_kernel(
     const float *__restrict__ dfeat, const int32_t *__restrict__ amax, const float *__restrict__ y3,
-    const float *__restrict__ bn3, float *__restrict__ gmax, double *__restrict__ bstat,
+    const float *__restrict__ bn3, float *__restrict__ gmax, double *__restrict__ bstat, int rep_stride,
     int L, int cap, int C3, int CT, int nlc)
 {
     __shared__ float dS[64 * (PWB + 1)];
@@ -127,8 +134,9 @@ __global__ __launch_bounds__(GT) void poolbwd_kernel(
             a += (double)red[(w * 64 + tid) * 2];
             g += (double)red[(w * 64 + tid) * 2 + 1];
         }
-        atomic_add_f64(&bstat[c0 + tid], a);
-        atomic_add_f64(&bstat[C3 + c0 + tid], g);
+        double *br = bstat + (int64_t)((blockIdx.x + blockIdx.z) % FCN_STAT_REP) * rep_stride;
+        atomic_add_f64(&br[c0 + tid], a);
+        atomic_add_f64(&br[C3 + c0 + tid], g);
     }
 }
 
@@ -149,7 +157,7 @@ struct DgradArgs {
     const float *bn_prev;   // scale, shift, mean, rstd of the previous layer's BN (width CPREV)
     const float *W1;        // LAYER 2: (C1,3)
     float *dzprev;          // LAYER 3: dz2 out (B,cap,C2)
-    double *bstat_prev;     // LAYER 3: dbeta2[C2], dgamma2[C2]; LAYER 2: Q[4][C1]
+    double *bstat_prev;     // LAYER 3: dbeta2[C2], dgamma2[C2]; LAYER 2: Q[4][C1] -- replica 0 (stride cb.rep_stride)
     int L, cap, CRED, CPREV, tps;
 };
 
@@ -182,8 +190,8 @@ void dgrad_kernel(DgradArgs a)
     const int ny = a.CPREV / TN;                  // XCD order, column tiles fastest (see fcn_xcd_tile)
     if (blockIdx.x == 0 && a.cb.dgamma) {         // workgroup 0 always exists (the grid is padded): it exports dgamma / dbeta
         for (int c = tid; c < a.CRED; c += NTHR) {
-            a.cb.dgamma[c] = (float)a.cb.bstat[a.CRED + c];
-            a.cb.dbeta[c] = (float)a.cb.bstat[c];
+            a.cb.dgamma[c] = (float)fcn_rep_sum(a.cb.bstat + a.CRED + c, a.cb.rep_stride);
+            a.cb.dbeta[c] = (float)fcn_rep_sum(a.cb.bstat + c, a.cb.rep_stride);
         }
     }
     const int xt = fcn_xcd_tile(blockIdx.x, SUB * a.tiles[0] * ny);
@@ -235,6 +243,7 @@ void dgrad_kernel(DgradArgs a)
 #define DGRAD_LOAD(cc)                                                                                                \
     {                                                                                                                 \
         const int nq_ = (cc) * KC;                                                                                    \
+        if (!((FCN_XB & 1) && (cc) > 0))                                                                              \
         _Pragma("unroll") for (int i = 0; i < NA4; ++i) {                                                             \
             ry[i] = ldg4(a.ycur + arow[i] + nq_);                                                                     \
             if constexpr (LAYER == 3) {                                                                               \
@@ -244,6 +253,7 @@ void dgrad_kernel(DgradArgs a)
                 rz[i] = ldg4(a.dzcur + arow[i] + nq_);                                                                \
             }                                                                                                         \
         }                                                                                                             \
+        if (!((FCN_XB & 2) && (cc) > 0))                                                                              \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) rw[i] = ldgu4(wsrc + ((int64_t)(cc) * 8 + i * (NTHR / TN)) * CPREV); \
     }
 
@@ -251,6 +261,7 @@ void dgrad_kernel(DgradArgs a)
     DGRAD_LOAD(0);
     for (int c = 0; c < nchunk; ++c) {
         PNP_ADD(1);                               // 1: issue of the global loads (+ loop overhead)
+        if ((FCN_XB & 4) && c > 0) goto staged;
 #pragma unroll
         for (int i = 0; i < NA4; ++i) {
             const int f = tid + NTHR * i;
@@ -280,7 +291,7 @@ void dgrad_kernel(DgradArgs a)
             }
             kb_store4<MM_ENC_A, LDRA>(Ab, r, kq, dv[0], dv[1], dv[2], dv[3]);
             if constexpr (LAYER == 3) {
-                if (ok && byi == 0) {
+                if (ok && byi == 0 && !(FCN_XB & 128)) {
                     const v4f d0 = {dv[0], dv[1], dv[2], dv[3]};
                     sts4(a.dybuf + (grow0 + r) * CRED + nb, d0);
                 }
@@ -291,12 +302,13 @@ void dgrad_kernel(DgradArgs a)
             const int f = tid + NTHR * i;
             Bb[(f / TN) * LDRB + (f % TN)] = rw[i];
         }
+    staged:
         PNP_ADD(2);                               // 2: wait for the loads + operand transform + LDS stores
         __syncthreads();
         PNP_ADD(3);                               // 3: barrier in front of the MFMA phase
         if (c + 1 < nchunk) DGRAD_LOAD(c + 1);
         PNP_ADD(1);
-        mma_chunk_kb<MM, MT, NT, LDRA, LDRB>(Ab, Bb, wm * 32 * MT, wn * 32 * NT, acc);
+        if (!(FCN_XB & 8)) mma_chunk_kb<MM, MT, NT, LDRA, LDRB>(Ab, Bb, wm * 32 * MT, wn * 32 * NT, acc);
         PNP_ADD(4);                               // 4: LDS operand reads + MFMAs
         __syncthreads();
         PNP_ADD(3);                               // (3: both barriers)
@@ -304,6 +316,7 @@ void dgrad_kernel(DgradArgs a)
 #undef DGRAD_LOAD
 
     PNP_ADD(3);
+    if (FCN_XB & 16) { if (acc[0][0][0] == 123.456f) a.bstat_prev[0] = 0.0; return; }
     // ---- epilogue: ReLU mask of the previous layer, its BN-backward statistics
     constexpr int NS = (LAYER == 3) ? 2 : 4;
     float st[NT][NS];
@@ -337,7 +350,7 @@ void dgrad_kernel(DgradArgs a)
                     if (row < nvalid) {
                         const float y = yv[mt][reg];
                         const float dz = (fmaf(ps, y, pt) > 0.f) ? acc[mt][nt][reg] : 0.f;
-                        a.dzprev[(grow0 + row) * CPREV + col] = dz;
+                        if (!(FCN_XB & 32)) a.dzprev[(grow0 + row) * CPREV + col] = dz;
                         st[nt][0] += dz;
                         st[nt][1] = fmaf(dz, (y - pm) * pr, st[nt][1]);
                     }
@@ -378,7 +391,9 @@ void dgrad_kernel(DgradArgs a)
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
                 const double v = (double)st[nt][q] + (double)red[(((wn * NT + nt) * 32 + l31) * NS) + q];
-                atomic_add_f64(&a.bstat_prev[q * CPREV + col], v);
+                double *br = a.bstat_prev + (int64_t)fcn_rep_id() * a.cb.rep_stride;
+                if (!(FCN_XB & 64)) atomic_add_f64(&br[q * CPREV + col], v);
+                else if (v == 123.456) br[0] = v;
             }
         }
     }
@@ -636,14 +651,15 @@ __global__ __launch_bounds__(WR_T) void wgrad_reduce_kernel(const float *__restr
 }
 
 // dW1, dgamma1, dbeta1 from Q = sum_e dz1 (1, u) and the forward's weighted moments of u.
-__global__ void l1_finalize_kernel(const double *__restrict__ Q, const double *__restrict__ mom,
+__global__ void l1_finalize_kernel(const double *__restrict__ Qr, int rep_stride, const double *__restrict__ mom,
                                    const float *__restrict__ W1, const float *__restrict__ gamma,
                                    const float *__restrict__ bn1, int C, double M,
                                    float *__restrict__ dW1, float *__restrict__ dgamma, float *__restrict__ dbeta)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double q0 = Q[c], qu[3] = {Q[C + c], Q[2 * C + c], Q[3 * C + c]};
+    const double q0 = fcn_rep_sum(Qr + c, rep_stride);
+    const double qu[3] = {fcn_rep_sum(Qr + C + c, rep_stride), fcn_rep_sum(Qr + 2 * C + c, rep_stride), fcn_rep_sum(Qr + 3 * C + c, rep_stride)};
     const double w[3] = {W1[3 * c], W1[3 * c + 1], W1[3 * c + 2]};
     const double mean = bn1[2 * C + c], rstd = bn1[3 * C + c];
     const double db = q0;
@@ -755,18 +771,19 @@ extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, co
     const float *bn1 = ws->bn + fcn_bn_off(0, C1, C2);
     const float *bn2 = ws->bn + fcn_bn_off(1, C1, C2);
     const float *bn3 = ws->bn + fcn_bn_off(2, C1, C2);
+    const int brs = 2 * C3 + 2 * C2 + 4 * C1;        // doubles per replica block of ws->bstat
     double *bs3 = ws->bstat, *bs2 = bs3 + 2 * C3, *bsQ = bs2 + 2 * C2;
 
     hipError_t e = hipSuccess;          // ws->bstat was zeroed by the pool kernel of this scale's forward
 
     hipLaunchKernelGGL(poolbwd_kernel, dim3((L + PWB - 1) / PWB, C3 / 64, B), dim3(GT), 0, st, dfeat, ws->amax,
-                       ws->y3, bn3, ws->gmax, bs3, L, cap, C3, C3 + d->nvec, d->nlc);
+                       ws->y3, bn3, ws->gmax, bs3, brs, L, cap, C3, C3 + d->nvec, d->nlc);
     FCN_CHECK_LAUNCH();
     DgradArgs g;
     g.ent = (const float4 *)ws->ent; g.woff = ws->woff; g.tiles = ws->tiles; g.ewin = ws->ewin; g.L = L; g.cap = cap; g.tps = tps;
     g.ycur = ws->y3; g.amax = ws->amax; g.gmax = ws->gmax; g.dzcur = nullptr;
     g.Wenc = (const u32x4 *)(ws->wenc + 2 * (int64_t)C2 * C1 + (int64_t)C3 * C2);            // G3 (pn_wenc_off(3))
-    g.cb.bstat = bs3; g.cb.gamma = p->gamma[2]; g.cb.bn = bn3; g.cb.invM = 1.0 / M; g.cb.dgamma = dgamma[2]; g.cb.dbeta = dbeta[2];
+    g.cb.bstat = bs3; g.cb.rep_stride = brs; g.cb.gamma = p->gamma[2]; g.cb.bn = bn3; g.cb.invM = 1.0 / M; g.cb.dgamma = dgamma[2]; g.cb.dbeta = dbeta[2];
     g.dybuf = ws->dy3; g.yprev = ws->y2; g.bn_prev = bn2; g.W1 = nullptr; g.dzprev = ws->dz2; g.bstat_prev = bs2;
     g.CRED = C3; g.CPREV = C2;
     FCN_TRY(launch_dgrad<3>(g, B, d->precision, st));
@@ -775,7 +792,7 @@ extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, co
     w.ent = (const float4 *)ws->ent; w.woff = ws->woff; w.tiles = ws->tiles; w.L = L; w.cap = cap; w.tps = tps;
     w.partial = ws->partial;
     w.dy = ws->dy3; w.dz = nullptr; w.ycur = nullptr; w.yprev = ws->y2; w.bn_prev = bn2;
-    w.cb.bstat = nullptr; w.cb.gamma = nullptr; w.cb.bn = nullptr; w.cb.invM = 1.0 / M; w.cb.dgamma = nullptr; w.cb.dbeta = nullptr;
+    w.cb.bstat = nullptr; w.cb.rep_stride = brs; w.cb.gamma = nullptr; w.cb.bn = nullptr; w.cb.invM = 1.0 / M; w.cb.dgamma = nullptr; w.cb.dbeta = nullptr;
     w.W1 = nullptr; w.COUT = C3; w.CIN = C2;
     if (two) {     // dy3 is final: conv3's weight gradient can run beside the rest of the chain
         e = hipEventRecord((hipEvent_t)events[0], st);
@@ -811,7 +828,7 @@ extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, co
         FCN_TRY(launch_wgrad<2>(w, B, ws->nsplit, d->precision, st, dW[1]));
     }
 
-    hipLaunchKernelGGL(l1_finalize_kernel, dim3((C1 + 63) / 64), dim3(64), 0, st, bsQ, ws->stat + FCN_STAT_MOM,
+    hipLaunchKernelGGL(l1_finalize_kernel, dim3((C1 + 63) / 64), dim3(64), 0, st, bsQ, brs, ws->stat + FCN_STAT_MOM,
                        p->W[0], p->gamma[0], bn1, C1, M, dW[0], dgamma[0], dbeta[0]);
     FCN_CHECK_LAUNCH();
     if (two) {

@@ -22,6 +22,12 @@
 #ifndef FCN_FWD_EPI_DIRECT
 #define FCN_FWD_EPI_DIRECT 0
 #endif
+// TIMING EXPERIMENTS ONLY (tuning builds, results are wrong when set): FCN_X bits -- 1: A loaded for the first chunk only,
+// 2: W loaded for the first chunk only, 4: LDS staging for the first chunk only, 8: no MFMAs, 16: no output stores / statistics,
+// 32: no output stores (statistics kept), 64: no statistics atomics
+#ifndef FCN_X
+#define FCN_X 0
+#endif
 
 // ------------------------------------------------------------------------------------------------
 __global__ void bn1_finalize_kernel(const double *__restrict__ mom, const float *__restrict__ W1,
@@ -58,7 +64,7 @@ __global__ void bn1_finalize_kernel(const double *__restrict__ mom, const float 
     bn[3 * C + c] = (float)rstd;
 }
 
-__global__ void bn_finalize_kernel(const double *__restrict__ stat, const float *__restrict__ gamma,
+__global__ void bn_finalize_kernel(const double *__restrict__ stat, int rep_stride, const float *__restrict__ gamma,
                                    const float *__restrict__ beta, float *rmean, float *rvar, int64_t *nbt,
                                    int C, int training, float eps, float momentum, double M,
                                    float *__restrict__ bn)
@@ -70,8 +76,8 @@ __global__ void bn_finalize_kernel(const double *__restrict__ stat, const float 
     double mean, var;
     if (training) {
         const double invM = 1.0 / M;
-        mean = stat[c] * invM;
-        var = stat[C + c] * invM - mean * mean;
+        mean = fcn_rep_sum(stat + c, rep_stride) * invM;
+        var = fcn_rep_sum(stat + C + c, rep_stride) * invM - mean * mean;
         if (var < 0.0) var = 0.0;
         if (rmean) {
             rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mean);
@@ -225,7 +231,8 @@ struct FwdArgs {
     // shift in its prologue from the batch sums (training) or the running statistics (eval) instead of waiting for a
     // one-workgroup launch between the two GEMMs; workgroup 0 also publishes scale, shift, mean, rstd (the backward reads
     // them) and updates the running statistics.  gamma_in null: bn_in holds finished scale / shift.
-    const double *stat_in;      // sum[CIN], sumsq[CIN], or nullptr (eval)
+    const double *stat_in;      // replica 0 of sum[CIN], sumsq[CIN], or nullptr (eval)
+    int rep_stride;             // doubles between the replica blocks of stat / stat_in
     const float *gamma_in, *beta_in;
     float *rmean_in, *rvar_in;
     int64_t *nbt_in;
@@ -240,8 +247,8 @@ __device__ __forceinline__ void fwd_bn_in(const FwdArgs &a, int i, bool pub, flo
     double mean, var;
     if (a.stat_in) {
         const double invM = 1.0 / a.M;
-        mean = a.stat_in[i] * invM;
-        var = a.stat_in[C + i] * invM - mean * mean;
+        mean = fcn_rep_sum(a.stat_in + i, a.rep_stride) * invM;
+        var = fcn_rep_sum(a.stat_in + C + i, a.rep_stride) * invM - mean * mean;
         if (var < 0.0) var = 0.0;
     } else {
         mean = a.rmean_in[i];
@@ -318,6 +325,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
     const u32x4 *wsrc = a.Wenc + n0 + (tid % TN) + (int64_t)(tid / TN) * COUT;      // item f = tid + NTHR*i: column f % TN, (plane, k-block) f / TN
     auto load_chunk = [&](int c) __attribute__((always_inline)) {
         if constexpr (MODE == 1) {
+            if (!((FCN_X & 1) && c > 0))
 #pragma unroll
             for (int i = 0; i < NA4; ++i) {
                 const int f = tid + NTHR * i;
@@ -328,6 +336,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
                 ra[i] = ldg4(a.aprev + ((int)grow0 + min(r, nvalid - 1)) * CIN + c * KC + 4 * kq);
             }
         }
+        if (!((FCN_X & 2) && c > 0))
 #pragma unroll
         for (int i = 0; i < NB; ++i) rw[i] = ldgu4(wsrc + ((int64_t)c * 8 + i * (NTHR / TN)) * COUT);
     };
@@ -366,6 +375,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
 
     for (int c = 0; c < nchunk; ++c) {
         // ---- registers -> LDS (kb-major images), applying the input BN + ReLU
+        if ((FCN_X & 4) && c > 0) goto staged;
         if constexpr (MODE == 1) {
 #pragma unroll
             for (int i = 0; i < NA4; ++i) {
@@ -400,13 +410,15 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
             const int f = tid + NTHR * i;
             Bb[(f / TN) * LDRB + (f % TN)] = rw[i];       // (plane, k-block) row f / TN of the image
         }
+    staged:
         __syncthreads();
         if (c + 1 < nchunk) load_chunk(c + 1);
-        mma_chunk_kb<MM, MT, NT, LDRA, LDRB>(Ab, Bb, wm * 32 * MT, wn * 32 * NT, acc);
+        if (!(FCN_X & 8)) mma_chunk_kb<MM, MT, NT, LDRA, LDRB>(Ab, Bb, wm * 32 * MT, wn * 32 * NT, acc);
         __syncthreads();
     }
 
     // ---- epilogue: y out as 16-byte stores through the wave's transposition patch, per-channel weighted statistics
+    if (FCN_X & 16) { if (acc[0][0][0] == 123.456f) a.y[0] = 0.f; return; }
     bool bad = false;
 #if FCN_FWD_EPI_DIRECT      // (tuning builds: one dword per lane straight from the accumulator layout -- the round-2 epilogue)
 #pragma unroll
@@ -435,7 +447,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
                 const int idx = lane + 64 * q, row = rbase + (idx >> 3);
                 const v4f v = ep_get(patch, lane, q);
                 if constexpr (MM == MM_F16X3) bad |= !(fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w) < 3.0e38f);
-                if (row < nvalid) sts4(a.y + (grow0 + row) * COUT + cbase + 4 * (idx & 7), v);
+                if (row < nvalid && !(FCN_X & 32)) sts4(a.y + (grow0 + row) * COUT + cbase + 4 * (idx & 7), v);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -476,8 +488,11 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
                 const int col = n0 + wn * 32 * NT + nt * 32 + l31;
                 const double s1 = (double)acc[0][nt][0] + (double)red[((wn * NT + nt) * 32 + l31) * 2];
                 const double s2 = (double)acc[0][nt][1] + (double)red[((wn * NT + nt) * 32 + l31) * 2 + 1];
-                atomic_add_f64(&a.stat[col], s1);
-                atomic_add_f64(&a.stat[COUT + col], s2);
+                double *sr = a.stat + (int64_t)fcn_rep_id() * a.rep_stride;
+                if (!(FCN_X & 64)) {
+                    atomic_add_f64(&sr[col], s1);
+                    atomic_add_f64(&sr[COUT + col], s2);
+                } else if (s1 == 123.456) sr[col] = s2;
             }
         }
     }
@@ -693,7 +708,7 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
     a.flags = ws->flags;
     a.stat = tr ? st2 : nullptr; a.CIN = C1; a.COUT = C2;
     a.stat_in = nullptr; a.gamma_in = a.beta_in = nullptr; a.rmean_in = a.rvar_in = nullptr; a.nbt_in = nullptr; a.bn_pub = nullptr;
-    a.M = M; a.eps = d->eps; a.momentum = d->momentum;
+    a.M = M; a.eps = d->eps; a.momentum = d->momentum; a.rep_stride = 2 * C2 + 2 * C3;
     FCN_TRY(launch_fwd_gemm<0>(a, B, d->precision, st));
 
     // BN2 is finalised by conv3's workgroups (no launch in between)
@@ -703,12 +718,12 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
     a.rmean_in = p->running_mean[1]; a.rvar_in = p->running_var[1]; a.nbt_in = p->num_batches_tracked[1]; a.bn_pub = bn2;
     FCN_TRY(launch_fwd_gemm<1>(a, B, d->precision, st));
 
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C3 + 63) / 64), dim3(64), 0, st, st3, p->gamma[2], p->beta[2],
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C3 + 63) / 64), dim3(64), 0, st, st3, 2 * C2 + 2 * C3, p->gamma[2], p->beta[2],
                        p->running_mean[2], p->running_var[2], p->num_batches_tracked[2], C3, tr, d->eps,
                        d->momentum, M, bn3);
     FCN_CHECK_LAUNCH();
 
-    const int nz = 2 * C3 + 2 * C2 + 4 * C1;
+    const int nz = FCN_STAT_REP * (2 * C3 + 2 * C2 + 4 * C1);
     if (d->nlc && (C3 == 128 || C3 == 256 || C3 == 512)) {
         int32_t *am = tr ? ws->amax : nullptr;
         double *zp = tr ? ws->bstat : nullptr;
@@ -738,8 +753,7 @@ extern "C" int fcn_pn_conv_fwd(const fcn_pn_desc *d, const fcn_pn_params *p, con
                                int with_stats, void *stream)
 {
     if (!d || !p || !ws || (layer != 2 && layer != 3) || !ws->wenc) return FCN_E_BADARG;
-    hipStream_t st = (hipStream_t)stream;
-    FCN_TRY(fcn_pn_pack_weights(d, p, ws, stream));
+    hipStream_t st = (hipStream_t)stream;          // (ws->wenc as the forward left it)
     const int B = d->B, L = d->L, K = d->K, C1 = d->C1, C2 = d->C2, C3 = d->C3;
     const int cap = L * K;
     double *st2 = ws->stat + FCN_STAT_L2, *st3 = st2 + 2 * C2;
@@ -747,6 +761,7 @@ extern "C" int fcn_pn_conv_fwd(const fcn_pn_desc *d, const fcn_pn_params *p, con
     a.ent = (const float4 *)ws->ent; a.woff = ws->woff; a.tiles = ws->tiles; a.L = L; a.cap = cap; a.tps = (cap + 127) / 128;
     a.stat_in = nullptr; a.gamma_in = a.beta_in = nullptr; a.rmean_in = a.rvar_in = nullptr; a.nbt_in = nullptr; a.bn_pub = nullptr;
     a.M = 1.0; a.eps = d->eps; a.momentum = d->momentum;       // the BN in front is read finished from ws->bn
+    a.rep_stride = 2 * C2 + 2 * C3;
     a.flags = ws->flags;
     if (layer == 2) {
         a.aprev = nullptr; a.bn_in = ws->bn + fcn_bn_off(0, C1, C2); a.W1 = p->W[0]; a.Wenc = (const u32x4 *)(ws->wenc + pn_wenc_off(0, C1, C2, C3)); a.y = ws->y2;

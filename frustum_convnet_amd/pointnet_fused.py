@@ -28,11 +28,12 @@ class Workspace:
         self.ent = torch.empty((B, cap, 4), dtype=f32, device=dev)
         self.ewin = torch.empty((B, cap), dtype=i32, device=dev)
         rows = _native.lib().fcn_pn_wgrad_rows()
+        rep = _native.lib().fcn_stat_replicas() if hasattr(_native.lib(), "fcn_stat_replicas") else 1
         ntile_max = B * ((cap + rows - 1) // rows)
         self.tiles = torch.zeros((4 + ntile_max,), dtype=i32, device=dev)
         self.y2 = torch.empty((B, cap, C2), dtype=f32, device=dev)
         self.y3 = torch.empty((B, cap, C3), dtype=f32, device=dev)
-        self.stat = torch.zeros((16 + 2 * C2 + 2 * C3,), dtype=f64, device=dev)
+        self.stat = torch.zeros((16 + rep * (2 * C2 + 2 * C3),), dtype=f64, device=dev)
         self.bn = torch.empty((4 * (C1 + C2 + C3),), dtype=f32, device=dev)
         self.gmom = torch.zeros((B * 12,), dtype=f64, device=dev)       # fcn_pn_group_compact: per-frustum moments + counter
         self.cnt = torch.empty((B, L), dtype=i32, device=dev)           # window hit counts of the fused grouping
@@ -46,7 +47,7 @@ class Workspace:
             self.gmax = torch.empty((B, L, C3), dtype=f32, device=dev)
             self.dy3 = torch.empty((B, cap, C3), dtype=f32, device=dev)
             self.dz2 = torch.empty((B, cap, C2), dtype=f32, device=dev)
-            self.bstat = torch.zeros((2 * C3 + 2 * C2 + 4 * C1,), dtype=f64, device=dev)
+            self.bstat = torch.zeros((rep * (2 * C3 + 2 * C2 + 4 * C1),), dtype=f64, device=dev)
             self.coef = torch.empty((5 * (C3 + C2),), dtype=f32, device=dev)
             self.partial = torch.empty((self.nsplit * max(C3 * C2, C2 * C1),), dtype=f32, device=dev)
         p = lambda t: None if t is None else t.data_ptr()

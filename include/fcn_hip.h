@@ -112,13 +112,14 @@ typedef struct fcn_pn_ws {
     float   *y2;                 /* (B, cap, C2) conv2 output (pre-BN)                       */
     float   *y3;                 /* (B, cap, C3) conv3 output (pre-BN)                       */
     int32_t *amax;               /* (B, L, C3)  row of the pooled max, -1 = no gradient      */
-    double  *stat;               /* 16 + 2*C2 + 2*C3 doubles: input moments, sum/sumsq       */
+    double  *stat;               /* 16 + fcn_stat_replicas() * (2*C2 + 2*C3) doubles: input moments, then the
+                                    replicated sum / sumsq blocks of conv2 and conv3                        */
     float   *bn;                 /* 4*(C1+C2+C3) floats: per layer scale, shift, mean, rstd  */
     /* backward only */
     float   *gmax;               /* (B, L, C3)  dfeat routed to the max rows                 */
     float   *dy3;                /* (B, cap, C3)                                             */
     float   *dz2;                /* (B, cap, C2)                                             */
-    double  *bstat;              /* 2*C3 + 2*C2 + 4*C1 doubles                               */
+    double  *bstat;              /* fcn_stat_replicas() * (2*C3 + 2*C2 + 4*C1) doubles       */
     float   *coef;               /* 5*(C3+C2) floats                                         */
     float   *partial;            /* wgrad partials: nsplit * max(C3*C2, C2*C1) floats        */
     int32_t  nsplit;             /* capacity of `partial` in splits: >= B*ceil(cap/128) (one per row tile) */
@@ -140,6 +141,9 @@ typedef struct fcn_pn_ws {
 
 /* rows of one row tile (128): the caller sizes ws.tiles / ws.partial with it */
 int fcn_pn_wgrad_rows(void);
+/* copies of every BatchNorm sum slot (8): same-address fp64 atomics are served one at a time, so workgroups spread over
+ * replicas and the consumers sum them in a fixed order; the caller sizes ws.stat / ws.bstat with it */
+int fcn_stat_replicas(void);
 
 /* idx/cnt -> entry list + live-tile list + weighted input moments (ws.woff, ws.ent, ws.ewin, ws.tiles, ws.stat[0..9]) */
 int fcn_pn_compact(const fcn_pn_desc *d, const float *pc /*(B,3,N)*/, const float *ref /*(B,3,L)*/,
