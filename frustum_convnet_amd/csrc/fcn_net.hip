@@ -73,6 +73,7 @@ struct CgLayer {
     int Lin, Lout, B;          // valid input positions, output positions per frustum
     int Cout, Ktot, Cs;        // GEMM N, GEMM K = KT * sum(C), BN channels (col % Cs)
     const float *Wp;           // packed (Cout, Ktot)
+    const u32x4 *Wenc;         // its forward image, split-encoded in MFMA operand order: [Ktot/32][plane][4][Cout] (cg_pack_kernel)
     const float *bias;         // (nbias) or nullptr
     int nbias;
     float *y;                  // (B*Lout, Cout) pre-BN output
@@ -256,16 +257,19 @@ __device__ __forceinline__ float cg_act(float s, float x, float t, bool ok) { re
 template <int MM, int MW, int G, int WNC = 2>      // WNC waves across N per K-group: tile (32*MW) x (32*WNC)
 __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, const int by)
 {
-    constexpr int TG = 64 * MW * WNC, TMB = 32 * MW, TNC = 32 * WNC, LDA = TMB + 1, LDC = TNC + 1, NTHR = G * TG;
-    constexpr int NA = TMB * 8 / TG;          // 4-vectors of A per thread per chunk (2)
-    constexpr int NB = TNC * 8 / TG;          // 4-vectors of W per thread per chunk
-    __shared__ __attribute__((aligned(16))) float lds[G * KC * (LDA + LDC)];
-    __shared__ float sS[CG_KMAX], tS[CG_KMAX];
+    constexpr int TG = 64 * MW * WNC, TMB = 32 * MW, TNC = 32 * WNC, NTHR = G * TG;
+    constexpr int LDRA = KbTile<TMB>::LDR, LDRB = KbTile<TNC>::LDR, GU4 = KbTile<TMB>::U4 + KbTile<TNC>::U4;
+    constexpr int NA = TMB * 8 / TG;          // 4-vectors of A per thread per chunk
+    constexpr int NB = TNC * 8 / TG;          // u32x4 of the encoded weight per thread per chunk
+    static_assert(G * GU4 * 4 >= G * TMB * TNC, "the cross-group sum fits the operand images");
+    __shared__ u32x4 lds4[G * GU4];           // per K-group: kb-major images of its A and W chunk (gemm_tile.h)
+    __shared__ __attribute__((aligned(16))) float sS[CG_KMAX], tS[CG_KMAX];
     __shared__ int cSeg[CG_KMAX / KC], cTap[CG_KMAX / KC], cK0[CG_KMAX / KC];   // chunk -> (segment, tap, channel)
+    float *lds = (float *)lds4;
     const int tid = threadIdx.x, g = tid / TG, gt = tid % TG;
     const int lane = tid & 63, gw = gt >> 6, l31 = lane & 31, lh = lane >> 5;
     const int wm = gw / WNC, wn = gw % WNC;
-    float *As = lds + g * KC * (LDA + LDC), *Bs = As + KC * LDA;
+    u32x4 *Ab = lds4 + g * GU4, *Bb = Ab + KbTile<TMB>::U4;
     const int R = L.B * L.Lout;
     const int row0 = bx * TMB, n0 = by * TNC;
     PROBE_DECL;
@@ -294,12 +298,16 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     acc_zero<1, 1>(acc);
     // TWO register sets: the chunk staged in iteration `it` was requested two iterations earlier, so a load has two
     // MFMA phases (not one) to come back from L2 / MALL / HBM before the LDS store needs it
-    v4f ra0[NA], rw0[NB], ra1[NA], rw1[NB];
+    v4f ra0[NA], ra1[NA];
+    u32x4 rw0[NB], rw1[NB];
     bool ok0[NA], ok1[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) { ra0[i] = zero4(); ra1[i] = zero4(); ok0[i] = false; ok1[i] = false; }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) { rw0[i] = zero4(); rw1[i] = zero4(); }
+    for (int i = 0; i < NB; ++i) { rw0[i] = u32x4{0u, 0u, 0u, 0u}; rw1[i] = u32x4{0u, 0u, 0u, 0u}; }
+    // weight image item f = gt + TG * i of a chunk: column f % TNC, (plane, k-block) row f / TNC -- 16-byte pieces, lane-linear
+    // in global memory and in LDS (pre-encoded by cg_pack_kernel: no VALU on this operand)
+    const u32x4 *wsrc = L.Wenc + n0 + (gt % TNC) + (int64_t)(gt / TNC) * L.Cout;
     // (macros, not lambdas: the by-reference closure of a lambda called from several places is not always scalarised
     // by hipcc and drags every captured variable into scratch)
     // the chunk (hence the segment) is uniform within a K-group, i.e. within every wave: scalar selects
@@ -318,25 +326,18 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                                \
             RA[i] = cg_load_raw(L, x, C, Ls, ty ? 0 : 1, tap, k0 + 4 * kq, bb[i], ll[i], rv[i], OK[i]);               \
         _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                                \
-            RW[i] = ldg4(L.Wp + (int64_t)(n0 + rb + RSTEP * i) * L.Ktot + c_ * KC + 4 * kq);                          \
+            RW[i] = ldgu4(wsrc + ((int64_t)c_ * 8 + i * (TG / TNC)) * L.Cout);                                        \
     }
 #define CGK_FWD_STAGE(c_, RA, RW, OK)                                                                                 \
     {                                                                                                                 \
-        const float *sp = sS + (c_) * KC + 4 * kq, *tp = tS + (c_) * KC + 4 * kq;                                     \
-        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                              \
-            const int r = rb + RSTEP * i;                                                                             \
-            float e_[4];                                                                                              \
-            enc4<MM_ENC_A>(cg_act(sp[0], RA[i].x, tp[0], OK[i]), cg_act(sp[1], RA[i].y, tp[1], OK[i]),                      \
-                     cg_act(sp[2], RA[i].z, tp[2], OK[i]), cg_act(sp[3], RA[i].w, tp[3], OK[i]), e_);                 \
-            As[(4 * kq + 0) * LDA + r] = e_[0]; As[(4 * kq + 1) * LDA + r] = e_[1];                                   \
-            As[(4 * kq + 2) * LDA + r] = e_[2]; As[(4 * kq + 3) * LDA + r] = e_[3];                                   \
-        }                                                                                                             \
+        const v4f sp = *(const v4f *)(sS + (c_) * KC + 4 * kq), tp = *(const v4f *)(tS + (c_) * KC + 4 * kq);         \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                                \
+            kb_store4<MM_ENC_A, LDRA>(Ab, rb + RSTEP * i, kq, cg_act(sp.x, RA[i].x, tp.x, OK[i]),                      \
+                                      cg_act(sp.y, RA[i].y, tp.y, OK[i]), cg_act(sp.z, RA[i].z, tp.z, OK[i]),         \
+                                      cg_act(sp.w, RA[i].w, tp.w, OK[i]));                                            \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                              \
-            const int n = rb + RSTEP * i;                                                                             \
-            float e_[4];                                                                                              \
-            enc4<MM_ENC_W>(RW[i].x, RW[i].y, RW[i].z, RW[i].w, e_);                                                         \
-            Bs[(4 * kq + 0) * LDC + n] = e_[0]; Bs[(4 * kq + 1) * LDC + n] = e_[1];                                   \
-            Bs[(4 * kq + 2) * LDC + n] = e_[2]; Bs[(4 * kq + 3) * LDC + n] = e_[3];                                   \
+            const int f = gt + TG * i;                                                                                \
+            Bb[(f / TNC) * LDRB + (f % TNC)] = RW[i];                                                                 \
         }                                                                                                             \
     }
 #define CGK_FWD_ITER(it_, RA, RW, OK)                                                                                 \
@@ -346,7 +347,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         if (act) CGK_FWD_STAGE(c, RA, RW, OK);                                                                \
         if constexpr (TG != 64) __syncthreads(); else __builtin_amdgcn_wave_barrier();                                \
         if (c + 2 * G < nchunk) CGK_FWD_LOAD(c + 2 * G, RA, RW, OK);                                         \
-        if (act) mma_chunk<MM, 1, 1, LDA, LDC>(As, Bs, wm * 32, wn * 32, acc);                                    \
+        if (act) mma_chunk_kb<MM, 1, 1, LDRA, LDRB>(Ab, Bb, wm * 32, wn * 32, acc);                               \
         if constexpr (TG != 64) __syncthreads(); else __builtin_amdgcn_wave_barrier();                                \
     }
     // A K-group of ONE wave (TG == 64: the 32 x 32 tile in use) owns its LDS buffers alone and the LDS serves a wave's
@@ -542,7 +543,31 @@ struct CgPackAll {
     // latency-bound chains (the packing runs ahead of both, on its own stream)
     double *z0, *z1;
     int nz;
+    // forward operand images (gemm_tile.h "kb-major"): layer l's packed matrix split-encoded in MFMA operand order,
+    // [Ktot/32][plane][4][N] u32x4 at enc + pre[l] floats -- the forward K loops stage their weights with plain 16-byte copies
+    float *enc;
+    int mmf;                            // operand mode of the forward GEMMs (MM_*)
 };
+
+template <int MM>
+__device__ __forceinline__ void cg_pack_image_item(const CgPack &p, const float *__restrict__ src, int nrow_real, int64_t m,
+                                                   u32x4 *__restrict__ img)
+{
+    const int n = (int)(m % p.N), r = (int)(m / p.N), kb = r & 3, c = r >> 2;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        x[j] = 0.f;
+        if (n < nrow_real) {
+            const int64_t o = cg_torch_index(p, n, c * KC + 8 * kb + j);
+            if (o >= 0) x[j] = src[o];
+        }
+    }
+    u32x4 hi, lo;
+    enc8<MM>(x, hi, lo);
+    img[((int64_t)c * 8 + kb) * p.N + n] = hi;
+    img[((int64_t)c * 8 + 4 + kb) * p.N + n] = lo;
+}
 
 __global__ void cg_pack_kernel(CgPackAll t)
 {
@@ -558,6 +583,20 @@ __global__ void cg_pack_kernel(CgPackAll t)
         if (j < t.nz) {
             if (t.z0) t.z0[j] = 0.0;
             if (t.z1) t.z1[j] = 0.0;
+            return;
+        }
+        j -= t.nz;
+        if (j < t.pre[CN_NLAYER] / 8 && t.enc) {        // one (chunk, k-block, column) item of a forward image
+            int l = 0;
+#pragma unroll
+            for (int q = 1; q < CN_NLAYER; ++q)
+                if (8 * j >= t.pre[q]) l = q;
+            const int64_t m = j - t.pre[l] / 8;
+            u32x4 *img = (u32x4 *)(t.enc + t.pre[l]);
+            if (t.mmf == MM_F32) cg_pack_image_item<MM_F32>(t.p[l], t.src[l], t.nrow_real[l], m, img);
+            else if (t.mmf == MM_F16X3) cg_pack_image_item<MM_F16X3>(t.p[l], t.src[l], t.nrow_real[l], m, img);
+            else if (t.mmf == MM_BF16X3) cg_pack_image_item<MM_BF16X3>(t.p[l], t.src[l], t.nrow_real[l], m, img);
+            else cg_pack_image_item<MM_BF16X1>(t.p[l], t.src[l], t.nrow_real[l], m, img);
         }
         return;
     }
@@ -1234,7 +1273,7 @@ extern "C" int fcn_convnet_sizes(const fcn_cn_desc *d, int64_t *out6)
     const int64_t pmax = 4 * cn_partial_elems(d, P);   // (launch parity) x (chain / off-chain step): a step's reduce runs
                                                        // beside the next launch's weight gradients
     out6[0] = O.y[P.nl];      // floats: y (and dz) of all layers
-    out6[1] = O.wp[P.nl];     // floats: packed weights
+    out6[1] = 2 * O.wp[P.nl]; // floats: packed weights (N, Ktot) of all layers, then their split-encoded forward images
     out6[2] = O.bn[P.nl];     // floats: bn scale/shift/mean/rstd
     out6[3] = (int64_t)FCN_CG_REP * O.st[P.nl];     // doubles: stat (and bstat), FCN_CG_REP replica blocks each
     out6[4] = O.coef[P.nl];   // floats: coef
@@ -1247,7 +1286,7 @@ static void cn_fill_layer(const fcn_cn_desc *d, const fcn_cn_params *p, const Cn
 {
     L.nseg = P.nseg[l]; L.KT = P.KT[l]; L.stride = P.stride[l]; L.pad = P.pad[l];
     L.Lin = P.Lin[l]; L.Lout = P.Lout[l]; L.B = d->B; L.Cout = P.N[l]; L.Ktot = P.Ktot[l]; L.Cs = P.Cs[l];
-    L.Wp = ws->wp + O.wp[l]; L.bias = nullptr; L.nbias = 0; L.y = ws->y + O.y[l]; L.stat = nullptr; L.flags = ws->flags;
+    L.Wp = ws->wp + O.wp[l]; L.Wenc = (const u32x4 *)(ws->wp + O.wp[P.nl] + O.wp[l]); L.bias = nullptr; L.nbias = 0; L.y = ws->y + O.y[l]; L.stat = nullptr; L.flags = ws->flags;
     L.eps = d->eps; L.momentum = d->momentum; L.rep_stride = O.st[P.nl];
     for (int s = 0; s < CG_NSEG; ++s) {
         CgSeg &S = L.seg[s];
@@ -1293,8 +1332,11 @@ static int cn_pack(const fcn_cn_desc *d, const fcn_cn_params *p, const CnPlan &P
     }
     t.oh = one_hot; t.oh64 = ws->oh64; t.B = d->B; t.nvec = d->nvec;
     t.z0 = d->training ? ws->stat : nullptr; t.z1 = d->training ? ws->bstat : nullptr; t.nz = FCN_CG_REP * O.st[P.nl];
+    t.enc = ws->wp + O.wp[P.nl];            // second half of the weight arena (fcn_convnet_sizes)
+    t.mmf = FCN_MM_OF(d->precision, true);
     hipLaunchKernelGGL(cg_pack_kernel,
-                       dim3((unsigned)((t.pre[CN_NLAYER] + (int64_t)d->B * OH_PAD + t.nz + 255) / 256)), dim3(256), 0, st, t);
+                       dim3((unsigned)((t.pre[CN_NLAYER] + (int64_t)d->B * OH_PAD + t.nz + t.pre[CN_NLAYER] / 8 + 255) / 256)),
+                       dim3(256), 0, st, t);
     FCN_CHECK_LAUNCH();
     return 0;
 }
