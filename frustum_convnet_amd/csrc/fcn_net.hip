@@ -19,6 +19,12 @@
 #include "gemm_tile.h"
 
 #define CG_T 256
+// TIMING EXPERIMENTS ONLY (tuning builds, results are wrong when set): FCN_XF bits in the forward K-group kernel -- 1: activation
+// loads for a group's first chunk only, 2: weight loads first chunk only, 4: LDS staging first chunk only, 8: no MFMAs,
+// 16: no epilogue (cross-group sum, stores, statistics), 32: no BN prologue (scale 1 / shift 0), 64: no statistics atomics
+#ifndef FCN_XF
+#define FCN_XF 0
+#endif
 // replicas of the FCN's BatchNorm sum slots (fcn_common.h: same-address fp64 atomics are served one at a time).  Every
 // consumer workgroup of this latency-bound chain sums them in its prologue, so fewer than the PointNet kernels' 8.
 #ifndef FCN_CG_REP
@@ -323,8 +329,10 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         const int sgi = (SG), tap = (TAP), k0 = (K0);                                                                 \
         const float *x = SEL4(sgi, x0, x1, x2, x3);                                                                   \
         const int C = SEL4(sgi, C0, C1, C2, C3), ty = SEL4(sgi, T0, T1, T2, T3), Ls = SEL4(sgi, Q0, Q1, Q2, Q3);      \
+        if (!((FCN_XF & 1) && c_ >= 2 * G))                                                                           \
         _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                                \
             RA[i] = cg_load_raw(L, x, C, Ls, ty ? 0 : 1, tap, k0 + 4 * kq, bb[i], ll[i], rv[i], OK[i]);               \
+        if (!((FCN_XF & 2) && c_ >= 2 * G))                                                                           \
         _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                                \
             RW[i] = ldgu4(wsrc + ((int64_t)c_ * 8 + i * (TG / TNC)) * L.Cout);                                        \
     }
@@ -344,10 +352,10 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     {                                                                                                                 \
         const int c = (it_) * G + g;                                                                                  \
         const bool act = c < nchunk;                                                                                  \
-        if (act) CGK_FWD_STAGE(c, RA, RW, OK);                                                                \
+        if (act && !((FCN_XF & 4) && c >= G)) CGK_FWD_STAGE(c, RA, RW, OK);                                   \
         if constexpr (TG != 64) __syncthreads(); else __builtin_amdgcn_wave_barrier();                                \
         if (c + 2 * G < nchunk) CGK_FWD_LOAD(c + 2 * G, RA, RW, OK);                                         \
-        if (act) mma_chunk_kb<MM, 1, 1, LDRA, LDRB>(Ab, Bb, wm * 32, wn * 32, acc);                               \
+        if (act && !(FCN_XF & 8)) mma_chunk_kb<MM, 1, 1, LDRA, LDRB>(Ab, Bb, wm * 32, wn * 32, acc);              \
         if constexpr (TG != 64) __syncthreads(); else __builtin_amdgcn_wave_barrier();                                \
     }
     // A K-group of ONE wave (TG == 64: the 32 x 32 tile in use) owns its LDS buffers alone and the LDS serves a wave's
@@ -375,7 +383,8 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         cg_locate(L, tid * KC, sg, tap, k0, so);
         cSeg[tid] = sg; cTap[tid] = tap; cK0[tid] = k0;
     }
-    cg_fill_bn(L, sS, tS, tid, NTHR, bx == 0 && by == 0);
+    if (FCN_XF & 32) { for (int i = tid; i < L.Ktot; i += NTHR) { sS[i] = 1.f; tS[i] = 0.f; } }
+    else cg_fill_bn(L, sS, tS, tid, NTHR, bx == 0 && by == 0);
     __syncthreads();                            // sS / tS and the chunk table ready
     PROBE_STAMP();                                      // 2: prologue done
     for (int it = 0; it < nit; it += 2) {
@@ -383,6 +392,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         if (it + 1 < nit) CGK_FWD_ITER(it + 1, ra1, rw1, ok1);
     }
     PROBE_STAMP();                                      // 3: K loop done (wave 0)
+    if (FCN_XF & 16) { if (acc[0][0][0] == 123.456f) L.y[0] = 0.f; return; }
     // ---- sum the G group accumulators through LDS, then one epilogue pass over the tile
     if constexpr (TG == 64) __syncthreads();            // every group is done with its operand buffers (reused below)
     float *red = lds;                                   // [G][TMB][TNC]
@@ -439,7 +449,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         double a = 0.0;
 #pragma unroll
         for (int r = 0; r < NTHR / 64; ++r) a += (double)st[(r * TNC + c) * 2 + w];
-        atomic_add_f64(&L.stat[(int64_t)(blockIdx.x % FCN_CG_REP) * L.rep_stride + w * L.Cs + (n0 + c) % L.Cs], a);
+        if (!(FCN_XF & 64) || a == 123.456) atomic_add_f64(&L.stat[(int64_t)(blockIdx.x % FCN_CG_REP) * L.rep_stride + w * L.Cs + (n0 + c) % L.Cs], a);
     }
     PROBE_STAMP();                                      // 6: statistics added
     PROBE_FLUSH(((unsigned long long)L.Ktot << 32) | ((unsigned long long)L.Cout << 16) | (unsigned long long)(L.Lout & 0xffff));

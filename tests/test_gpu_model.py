@@ -55,11 +55,14 @@ def test_train_eval_parity(case):
         nmax = float(np.max(g["grad_norms"]))
         for nm, ref in zip(g["grad_names"], g["grad_norms"]):
             got = float(named[str(nm)].grad.double().norm())
-            worst = max(worst, abs(got - ref) / max(ref, 1e-3))
-            # 5e-3: measured fp32 noise floor of these norms -- two CPU fp32 evaluations of the same graph (reference
-            # modules vs oracle/det_ref.py) differ from the fp64 value by up to 3.5e-3 on the conv1/BN tensors
-            assert abs(got - ref) <= 5e-3 * max(ref, 1e-3) + 2e-5 * nmax, (nm, got, ref)
-        print(case, "worst relative grad-norm diff %.3e" % worst)
+            bar = 3e-4 * max(ref, 1e-3) + 2e-5 * nmax
+            worst = max(worst, abs(got - ref) / bar)
+            # the reference's fp32 norms themselves sit up to 3.5e-3 from the fp64 value on the conv1/BN tensors (two CPU fp32
+            # evaluations of the same graph differ by that much), but the HIP path lands much closer to the reference's
+            # numbers: measured on MI355X 1.2e-4 relative at worst (car B=32) -- the bar is set from that,
+            # plus an absolute term for tensors whose gradient is ~0
+            assert abs(got - ref) <= bar, (nm, got, ref)
+        print(case, "worst grad-norm difference: %.2f of its bar (3e-4 relative + 2e-5 of the largest norm)" % worst)
         for k in g.files:
             if k.startswith("grad::"):
                 gr = named[k[6:]].grad.detach().cpu().numpy()
@@ -221,15 +224,17 @@ def test_fused_convnet_matches_module_path(case):
         d_f = float((res[True][3][k].double().cpu() - gref).abs().max())
         d_m = float((res[False][3][k].double().cpu() - gref).abs().max())
         worst = max(worst, (d_f / max(sc, 1e-12), k))
-        # the hand-written path must be within 5e-3 of the tensor max of the fp64 value, or at least no worse than
-        # twice the error of the vendor-library (MIOpen) fp32 path on the same tensor
-        assert d_f <= max(5e-3 * sc + 2e-6 * gscale, 2.0 * d_m), (k, d_f, d_m, sc)
+        # the hand-written path must be within 3e-3 of the tensor max of the fp64 value (measured worst on MI355X: 1.4e-3,
+        # a deconvolution's BN bias of the people fixture), or at least no worse than twice the error of the vendor-library
+        # (MIOpen) fp32 path on the same tensor
+        assert d_f <= max(3e-3 * sc + 2e-6 * gscale, 2.0 * d_m), (k, d_f, d_m, sc)
     print(case, "worst fused-path gradient error vs fp64: %.2e of max (%s)" % worst)
 
 
 def test_gradients_vs_fp64_oracle():
     """Every parameter gradient of the full HIP step against the fp64 evaluation of the oracle (the fp32 noise floor of
-    some of these tensors is ~3e-3 of their max, so fp64 is the referee): elementwise 5e-3 of each tensor's max."""
+    some of these tensors is ~3e-3 of their max, so fp64 is the referee): elementwise 8e-5 of each tensor's max -- twice the
+    worst value measured on MI355X (3.8e-5)."""
     from oracle import det_ref
     g = load_golden("car_b4_n512")
     data_np = golden_inputs(g)
@@ -252,7 +257,7 @@ def test_gradients_vs_fp64_oracle():
         d = float((p.grad.double().cpu() - ref).abs().max())
         sc = float(ref.abs().max())
         worst = max(worst, d / max(sc, 1e-9))
-        assert d <= 1e-2 * sc + 2e-6 * gscale, (k, d, sc)
+        assert d <= 8e-5 * sc + 2e-6 * gscale, (k, d, sc)
     print("worst elementwise grad error vs fp64 oracle: %.2e of tensor max" % worst)
 
 
