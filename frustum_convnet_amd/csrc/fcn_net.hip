@@ -60,6 +60,7 @@ struct CgSeg {
     int C;                     // channels seen by the GEMM (type 1: OH_PAD)
     int Lsrc;                  // rows per frustum in the source buffer (type 1: 1 row per frustum, every position reads it)
     int type, nvec;
+    int st16;                  // x is one of the y arenas: stored as bf16 in the bf16 throughput mode (gemm_tile.h: St)
     // The producer's BN is FINALISED BY ITS CONSUMERS: every forward workgroup derives scale/shift from the batch sums
     // in its prologue (a few hundred fp64 operations) instead of waiting for a separate one-workgroup launch between
     // every two layers of a latency-bound chain.  Workgroup (0,0) of the consumer flagged `writer` also publishes
@@ -83,6 +84,7 @@ struct CgLayer {
     const float *bias;         // (nbias) or nullptr
     int nbias;
     float *y;                  // (B*Lout, Cout) pre-BN output
+    int y16;                   // y is stored as bf16 (bf16 throughput mode, every layer but the heads' fp32 logits)
     double *stat;              // sum[Cs], sumsq[Cs] (replica 0) or nullptr
     float eps, momentum;
     int rep_stride;            // doubles between the replica blocks of every stat pointer of this layer (the whole arena)
@@ -184,13 +186,18 @@ __device__ __forceinline__ void cg_locate(const CgLayer &L, int kk, int &sg, int
 // ReLU and the ok-mask are applied when the registers go to LDS one iteration later -- so the load stays in flight
 // across the MFMA phase (a "load or zero" select makes hipcc wait for the load right away).
 // A one-hot segment is a (B, OH_PAD) buffer: one row per frustum (Lsrc = 1), every position reads it (linmul = 0).
+template <int MM>
 __device__ __forceinline__ v4f cg_load_raw(const CgLayer &L, const float *x, int C, int Lsrc, int linmul, int tap,
-                                           int kc, int b, int l, bool rvalid, bool &ok)
+                                           int kc, int b, int l, bool rvalid, bool &ok, int s16 = 0)
 {
     const int lin = l * L.stride + tap - L.pad;
     ok = rvalid && lin >= 0 && lin < L.Lin;
     const int lc = min(max(lin, 0), L.Lin - 1) * linmul;
-    return ldg4(x + ((int64_t)b * Lsrc + lc) * C + kc);
+    const int64_t e = ((int64_t)b * Lsrc + lc) * C + kc;
+    if constexpr (St<MM>::half) {
+        if (s16) return lds4e<MM>(x, e);             // a layer output (bf16 arena); pooled features / one-hot stay fp32
+    }
+    return ldg4(x + e);
 }
 
 // 1 / sqrt(x) in fp64 from the fp32 rsqrt + three Newton steps (full double accuracy, x > 0 and within float range -- a
@@ -288,6 +295,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     const int C0 = opaque_s(L.seg[0].C), C1 = opaque_s(L.seg[1].C), C2 = opaque_s(L.seg[2].C), C3 = opaque_s(L.seg[3].C);
     const int T0 = opaque_s(L.seg[0].type), T1 = opaque_s(L.seg[1].type), T2 = opaque_s(L.seg[2].type), T3 = opaque_s(L.seg[3].type);
     const int Q0 = opaque_s(L.seg[0].Lsrc), Q1 = opaque_s(L.seg[1].Lsrc), Q2 = opaque_s(L.seg[2].Lsrc), Q3 = opaque_s(L.seg[3].Lsrc);
+    const int H0 = opaque_s(L.seg[0].st16), H1 = opaque_s(L.seg[1].st16), H2 = opaque_s(L.seg[2].st16), H3 = opaque_s(L.seg[3].st16);
     int bb[NA], ll[NA];
     bool rv[NA];
 #pragma unroll
@@ -329,9 +337,10 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         const int sgi = (SG), tap = (TAP), k0 = (K0);                                                                 \
         const float *x = SEL4(sgi, x0, x1, x2, x3);                                                                   \
         const int C = SEL4(sgi, C0, C1, C2, C3), ty = SEL4(sgi, T0, T1, T2, T3), Ls = SEL4(sgi, Q0, Q1, Q2, Q3);      \
+        const int h16 = SEL4(sgi, H0, H1, H2, H3);                                                                    \
         if (!((FCN_XF & 1) && c_ >= 2 * G))                                                                           \
         _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                                \
-            RA[i] = cg_load_raw(L, x, C, Ls, ty ? 0 : 1, tap, k0 + 4 * kq, bb[i], ll[i], rv[i], OK[i]);               \
+            RA[i] = cg_load_raw<MM>(L, x, C, Ls, ty ? 0 : 1, tap, k0 + 4 * kq, bb[i], ll[i], rv[i], OK[i], h16);      \
         if (!((FCN_XF & 2) && c_ >= 2 * G))                                                                           \
         _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                                \
             RW[i] = ldgu4(wsrc + ((int64_t)c_ * 8 + i * (TG / TNC)) * L.Cout);                                        \
@@ -415,7 +424,12 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         }
         const int row = row0 + er;
         if (row < R) {
-            sts4(L.y + (int64_t)row * L.Cout + col, v);
+            if (St<MM>::half && L.y16) {
+                sts4e<MM>(L.y, (int64_t)row * L.Cout + col, v);
+                v = st_round4<MM>(v);                      // the sums are over the values as stored
+            } else {
+                sts4(L.y + (int64_t)row * L.Cout + col, v);
+            }
             cs1 += v;
             cs2 += v * v;
             // fp16 operand parts overflow at |x| >= 65504 (inf - inf = NaN in the products, which the next layer's ReLU would
@@ -637,6 +651,7 @@ struct CgDgSeg {               // one differentiated input segment of the layer
     const float *ysrc, *bnsrc; // producer's pre-BN output and published BN (scale,shift,mean,rstd); null: plain input
     float *out;                // producer's dz (Rsrc x C) or the input gradient
     int accumulate;            // add to what `out` already holds (a second consumer)
+    int out16;                 // `out` is a dz arena: bf16 in the bf16 throughput mode (a feature map's gradient stays fp32)
     double *bstat_src;         // non-null on the LAST consumer: sum dz, sum dz*xhat of the producer
     int tx, ncb;               // row tiles (32 rows each) and 64-channel column blocks; tile t -> (t / ncb, t % ncb)
     int blk0;                  // first workgroup of this segment (a multiple of 8)
@@ -656,6 +671,7 @@ struct CgReduce {
 struct CgBwdStep {
     CgLayer lay;               // the layer being differentiated
     const float *dz;           // its incoming dz (R x Cout)
+    int dz16;                  // dz (and lay.y) are bf16 arenas (bf16 throughput mode; the heads' dlogits are fp32)
     CgBnBwd cb;                // its BN backward (bstat null: no BN)
     int ndg;
     CgDgSeg dg[CG_NSEG];       // read on the device through the kernarg segment only (cg_bwd_step_body), never indexed
@@ -688,8 +704,11 @@ struct CgBwdStep {
 template <int MM>
 __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &cb, const float *dzc, const float *yc,
                                               int sgi, int segoff, const float *ysrc, const float *bnsrc, float *outp,
-                                              int accumulate, double *bstat_src, int bx, int by, bool pub, float *smem)
+                                              int accumulate, double *bstat_src, int bx, int by, bool pub, float *smem,
+                                              int dz16, int out16)
 {
+    // (bf16 throughput mode: dz16 -- this layer's dz / y are bf16 arenas (not the heads' fp32 dlogits); out16 -- `outp` is a
+    // layer's dz arena (not a pooled feature map's fp32 gradient); the producer's y behind `ysrc` always is one)
     constexpr int G = CGB_G, KH = CGB_KH, TMB = 32, LDA = CGB_LDA, NTHR = G * 64;
     constexpr int NA = TMB * (KH / 4) / 64, NB = KH * 16 / 64;      // 4-vectors of dy (2) and W (4) per lane per chunk
     constexpr int ASZ = CGB_ASZ, NCH = CG_KBWD / KH;
@@ -748,8 +767,13 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
             ok[i] = rv[i] && t_ >= 0 && ((L.stride == 2) ? ((t_ & 1) == 0) : true) && lq < L.Lout;                    \
             const int lo = min(max(lq, 0), L.Lout - 1);                                                               \
             const int64_t o = ((int64_t)bb[i] * L.Lout + lo) * L.Cout + nb + 4 * kq;                                  \
-            rz[i] = ldg4(dzc + o);                         /* unconditional (clamped row), masked at store time */    \
-            ry[i] = ldg4((hasbn ? yc : dzc) + o);                                                                     \
+            if (St<MM>::half && dz16) {                                                                               \
+                rz[i] = lds4e<MM>(dzc, o);                                                                            \
+                ry[i] = lds4e<MM>(hasbn ? yc : dzc, o);                                                               \
+            } else {                                                                                                  \
+                rz[i] = ldg4(dzc + o);                     /* unconditional (clamped row), masked at store time */    \
+                ry[i] = ldg4((hasbn ? yc : dzc) + o);                                                                 \
+            }                                                                                                         \
         }                                                                                                             \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {       /* rows 2*pr, 2*pr+1 of one column quad (a k pair) */  \
             const int f = lane + 64 * (i >> 1);                                                                       \
@@ -846,13 +870,19 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
         const int64_t o = (int64_t)row * C + col;
         v4f xh = zero4();
         if (bnsrc) {
-            const v4f yv = ldg4(ysrc + o);
+            const v4f yv = lds4e<MM>(ysrc, o);
             gsum.x = fmaf(ps.x, yv.x, pt.x) > 0.f ? gsum.x : 0.f; gsum.y = fmaf(ps.y, yv.y, pt.y) > 0.f ? gsum.y : 0.f;
             gsum.z = fmaf(ps.z, yv.z, pt.z) > 0.f ? gsum.z : 0.f; gsum.w = fmaf(ps.w, yv.w, pt.w) > 0.f ? gsum.w : 0.f;
             xh = (yv - pm) * pr;
         }
-        if (accumulate) gsum += ldg4(outp + o);
-        sts4(outp + o, gsum);
+        if (St<MM>::half && out16) {
+            if (accumulate) gsum += lds4e<MM>(outp, o);
+            sts4e<MM>(outp, o, gsum);
+            gsum = st_round4<MM>(gsum);                    // the sums are over the values as stored
+        } else {
+            if (accumulate) gsum += ldg4(outp + o);
+            sts4(outp + o, gsum);
+        }
         cs1 += gsum;
         cs2 += gsum * xh;
     }
@@ -912,6 +942,7 @@ __device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float
     const int SC = SEL4(sg, opaque_s(L.seg[0].C), opaque_s(L.seg[1].C), opaque_s(L.seg[2].C), opaque_s(L.seg[3].C));
     const int Sty = SEL4(sg, opaque_s(L.seg[0].type), opaque_s(L.seg[1].type), opaque_s(L.seg[2].type), opaque_s(L.seg[3].type));
     const int SLs = SEL4(sg, opaque_s(L.seg[0].Lsrc), opaque_s(L.seg[1].Lsrc), opaque_s(L.seg[2].Lsrc), opaque_s(L.seg[3].Lsrc));
+    const int S16 = SEL4(sg, opaque_s(L.seg[0].st16), opaque_s(L.seg[1].st16), opaque_s(L.seg[2].st16), opaque_s(L.seg[3].st16));
     // dy slice: 8 column quads x 8 row pairs (rows 2*pa, 2*pa + 1: a k pair); A slice: 16 column quads x 4 row pairs, twice
     const int cqa = lane & 7, pa = lane >> 3;
     const int cqb = lane & 15, pb = lane >> 4;
@@ -956,16 +987,21 @@ __device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                               \
             const int row = min(r0_ + 2 * pa + i, rend - 1);    /* clamped: unconditional loads, masked at store */   \
             const int64_t o = (int64_t)row * L.Cout + n0 + 4 * cqa;                                                   \
-            rz[i] = ldg4(a.dz + o);                                                                                   \
-            ry[i] = ldg4((hasbn ? L.y : a.dz) + o);                                                                   \
+            if (St<MM>::half && a.dz16) {                                                                             \
+                rz[i] = lds4e<MM>(a.dz, o);                                                                           \
+                ry[i] = lds4e<MM>(hasbn ? L.y : a.dz, o);                                                             \
+            } else {                                                                                                  \
+                rz[i] = ldg4(a.dz + o);                                                                               \
+                ry[i] = ldg4((hasbn ? L.y : a.dz) + o);                                                               \
+            }                                                                                                         \
         }                                                                                                             \
         _Pragma("unroll") for (int p2 = 0; p2 < 2; ++p2) {                                                            \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
                 const bool in = r0_ + 2 * (pb + 4 * p2) + i < rend;                                                   \
                 const bool wrap = i == 1 && wl[p2] + 1 >= L.Lout;                                                     \
                 const int b_ = wrap ? wb[p2] + 1 : wb[p2], l_ = wrap ? 0 : wl[p2] + i;                                \
-                rx[2 * p2 + i] = cg_load_raw(L, Sx, xC, xLs, xlm, tap, k0 + 4 * cqb, in ? b_ : bend, in ? l_ : lend,  \
-                                             true, ok[2 * p2 + i]);                                                   \
+                rx[2 * p2 + i] = cg_load_raw<MM>(L, Sx, xC, xLs, xlm, tap, k0 + 4 * cqb, in ? b_ : bend,              \
+                                                 in ? l_ : lend, true, ok[2 * p2 + i], S16);                          \
             }                                                                                                         \
             wl[p2] += NS * KH;                                                                                        \
             while (wl[p2] >= L.Lout) { wl[p2] -= L.Lout; wb[p2] += 1; }                                               \
@@ -1126,7 +1162,7 @@ __device__ __forceinline__ void cg_bwd_step_body(const CgBwdStep &a, const int b
     const int t = cg_xcd_tile(bid - g->blk0, g->tx * ncb);
     if (t < 0) return;
     cg_dgrad_body<MM>(a.lay, a.cb, a.dz, a.lay.y, g->sg, g->segoff, g->ysrc, g->bnsrc, g->out, g->accumulate,
-                      g->bstat_src, t / ncb, t % ncb, bid == 0, smem);
+                      g->bstat_src, t / ncb, t % ncb, bid == 0, smem, a.dz16, g->out16);
 }
 
 template <int MM>
@@ -1296,18 +1332,18 @@ static void cn_fill_layer(const fcn_cn_desc *d, const fcn_cn_params *p, const Cn
 {
     L.nseg = P.nseg[l]; L.KT = P.KT[l]; L.stride = P.stride[l]; L.pad = P.pad[l];
     L.Lin = P.Lin[l]; L.Lout = P.Lout[l]; L.B = d->B; L.Cout = P.N[l]; L.Ktot = P.Ktot[l]; L.Cs = P.Cs[l];
-    L.Wp = ws->wp + O.wp[l]; L.Wenc = (const u32x4 *)(ws->wp + O.wp[P.nl] + O.wp[l]); L.bias = nullptr; L.nbias = 0; L.y = ws->y + O.y[l]; L.stat = nullptr; L.flags = ws->flags;
+    L.Wp = ws->wp + O.wp[l]; L.Wenc = (const u32x4 *)(ws->wp + O.wp[P.nl] + O.wp[l]); L.bias = nullptr; L.nbias = 0; L.y = ws->y + O.y[l]; L.y16 = 1; L.stat = nullptr; L.flags = ws->flags;
     L.eps = d->eps; L.momentum = d->momentum; L.rep_stride = O.st[P.nl];
     for (int s = 0; s < CG_NSEG; ++s) {
         CgSeg &S = L.seg[s];
-        S.x = nullptr; S.bn = nullptr; S.C = P.C[l][s]; S.Lsrc = P.Lin[l]; S.type = 0; S.nvec = 0;
+        S.x = nullptr; S.bn = nullptr; S.C = P.C[l][s]; S.Lsrc = P.Lin[l]; S.type = 0; S.nvec = 0; S.st16 = 0;
         S.stat = nullptr; S.gamma = S.beta = nullptr; S.rmean = S.rvar = nullptr; S.nbt = nullptr; S.M = 1.0; S.writer = 0;
         if (s >= P.nseg[l]) continue;
         const int src = P.src[l][s];
         if (src == -9) { S.type = 1; S.x = ws->oh64; S.nvec = d->nvec; S.Lsrc = 1; }
         else if (src < 0) { S.x = feats[-src - 1]; S.Lsrc = d->L[-src - 1]; }
         else {
-            S.x = ws->y + O.y[src]; S.bn = ws->bn + O.bn[src];
+            S.x = ws->y + O.y[src]; S.bn = ws->bn + O.bn[src]; S.st16 = 1;
             S.Lsrc = P.Lout[src] * (P.dk[src] > 0 ? P.dk[src] : 1);     // a deconv's buffer is (B, L*k, 256)
             S.stat = d->training ? ws->stat + O.st[src] : nullptr;
             S.gamma = p->gamma[src]; S.beta = p->beta[src]; S.rmean = p->running_mean[src]; S.rvar = p->running_var[src];
@@ -1426,7 +1462,7 @@ extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p
                 waited[-src - 1] = true;
             }
         }
-        if (l == P.heads) { L.y = logits; L.bias = p->bias; L.nbias = P.nrow_real[l]; }
+        if (l == P.heads) { L.y = logits; L.y16 = 0; L.bias = p->bias; L.nbias = P.nrow_real[l]; }
         else if (tr) L.stat = ws->stat + O.st[l];
         return 0;
     };
@@ -1520,12 +1556,12 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
     };
     // data-gradient + weight-gradient roles of layer l (l < 0: none); returns the workgroups in front of the reduce role
     auto make_step = [&](int l, float *pbuf, CgBwdStep &a, CgReduce &own, int &own_blocks) -> int {
-        a.ndg = 0; a.w_ns = 0; a.w_ny = 1; a.rows = 2 * KC; a.partial = nullptr; a.dz = nullptr;
+        a.ndg = 0; a.w_ns = 0; a.w_ny = 1; a.rows = 2 * KC; a.partial = nullptr; a.dz = nullptr; a.dz16 = 0;
         a.cb.bstat = nullptr; a.cb.rep_stride = O.st[P.nl]; a.cb.gamma = nullptr; a.cb.bn = nullptr; a.cb.M = 1.0; a.cb.dgamma = nullptr; a.cb.dbeta = nullptr;
         CgDgSeg *dgs[CG_NSEG] = {&a.dg[0], &a.dg[1], &a.dg[2], &a.dg[3]};
         for (int s = 0; s < CG_NSEG; ++s) {
             dgs[s]->sg = 0; dgs[s]->segoff = 0; dgs[s]->ysrc = dgs[s]->bnsrc = nullptr; dgs[s]->out = nullptr;
-            dgs[s]->accumulate = 0; dgs[s]->bstat_src = nullptr; dgs[s]->tx = 1; dgs[s]->ncb = 1; dgs[s]->blk0 = 0;
+            dgs[s]->accumulate = 0; dgs[s]->out16 = 0; dgs[s]->bstat_src = nullptr; dgs[s]->tx = 1; dgs[s]->ncb = 1; dgs[s]->blk0 = 0;
         }
         blank_reduce(own);
         own_blocks = 0;
@@ -1538,6 +1574,7 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
         cn_fill_layer(d, p, P, O, ws, feats, one_hot, l, a.lay);
         const int R = d->B * P.Lout[l];
         a.dz = (l == P.heads) ? dlogits : ws->dz + O.y[l];
+        a.dz16 = (l == P.heads) ? 0 : 1;
         if (l == P.heads) {
             a.lay.y = nullptr;
         } else {
@@ -1552,12 +1589,12 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
                 CgDgSeg &g = *dgs[a.ndg];
                 g.sg = s; g.segoff = segoff;
                 if (src >= 0) {
-                    g.ysrc = ws->y + O.y[src]; g.bnsrc = ws->bn + O.bn[src]; g.out = ws->dz + O.y[src];
+                    g.ysrc = ws->y + O.y[src]; g.bnsrc = ws->bn + O.bn[src]; g.out = ws->dz + O.y[src]; g.out16 = 1;
                     g.accumulate = seen[src] > 0 ? 1 : 0;
                     seen[src] += 1;
                     g.bstat_src = (seen[src] == pending[src]) ? ws->bstat + O.st[src] : nullptr;
                 } else {
-                    g.out = dfeats[-src - 1];
+                    g.out = dfeats[-src - 1]; g.out16 = 0;
                 }
                 const int Rs = d->B * a.lay.seg[s].Lsrc;
                 g.tx = (Rs + 31) / 32;

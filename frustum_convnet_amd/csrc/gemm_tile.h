@@ -207,6 +207,64 @@ __device__ __forceinline__ void mma_chunk(const float *As, const float *Bs, int 
 }
 
 // ------------------------------------------------------------------------------------------------
+// STORAGE type of the big intermediate tensors (PointNet y2 / y3 / dy3 / dz2, the FCN's y / dz arenas).  fp32 in the split
+// and f32 operand modes; in the bf16 throughput mode (FCN_PREC_BF16, BASELINE config 2) they are stored as bf16 -- half the
+// HBM bytes of the step's dominant streams -- while accumulators, BatchNorm sums, pooled features, logits and every
+// parameter gradient stay fp32.  The buffers keep their float-typed pointers and element counts (the caller sizes them for
+// fp32; bf16 uses the first half): all index arithmetic is in ELEMENTS and these helpers scale it.
+#ifndef FCN_BF16_STORE
+#define FCN_BF16_STORE 1       // 0 (tuning / A-B builds): bf16 operands only, fp32 storage as in rounds 1-2
+#endif
+template <int MM>
+struct St {
+    static constexpr bool half = (MM == MM_BF16X1) && FCN_BF16_STORE;
+    static constexpr int bytes = half ? 2 : 4;
+};
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef const bf16x4 __attribute__((address_space(1))) *gbf4p;
+template <int MM>
+__device__ __forceinline__ v4f lds4e(const float *base, int64_t e)            // 4 consecutive stored elements -> fp32
+{
+    if constexpr (St<MM>::half) {
+        const bf16x4 h = *(gbf4p)((const __bf16 *)base + e);
+        return __builtin_convertvector(h, v4f);
+    } else {
+        return ldg4(base + e);
+    }
+}
+template <int MM>
+__device__ __forceinline__ void sts4e(float *base, int64_t e, v4f v)
+{
+    if constexpr (St<MM>::half) *(bf16x4 *)((__bf16 *)base + e) = __builtin_convertvector(v, bf16x4);
+    else sts4(base + e, v);
+}
+template <int MM>
+__device__ __forceinline__ float lds1e(const float *base, int64_t e)
+{
+    if constexpr (St<MM>::half) return (float)((const __bf16 *)base)[e];
+    else return base[e];
+}
+template <int MM>
+__device__ __forceinline__ void sts1e(float *base, int64_t e, float v)
+{
+    if constexpr (St<MM>::half) ((__bf16 *)base)[e] = (__bf16)v;
+    else base[e] = v;
+}
+// what a stored value reads back as (BatchNorm sums are taken over the STORED values, so the statistics match the data)
+template <int MM>
+__device__ __forceinline__ float st_round(float v)
+{
+    if constexpr (St<MM>::half) return (float)(__bf16)v;
+    else return v;
+}
+template <int MM>
+__device__ __forceinline__ v4f st_round4(v4f v)
+{
+    if constexpr (St<MM>::half) return __builtin_convertvector(__builtin_convertvector(v, bf16x4), v4f);
+    else return v;
+}
+
+// ------------------------------------------------------------------------------------------------
 // "kb-major" operand images (PointNet forward / data-gradient GEMMs).  One u32x4 is EXACTLY what a lane feeds a 32x32x16 MFMA:
 // the four packed dwords of 8 reduction-adjacent values of one row / column.  A 32-deep chunk of a T-row operand tile is two
 // planes (hi parts, lo parts) of [4 k-blocks][LDR] u32x4, LDR = T + 2:

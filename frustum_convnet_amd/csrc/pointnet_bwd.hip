@@ -76,6 +76,7 @@ extern "C" int fcn_pn_probe_read(unsigned long long *host_out, int max_records, 
 // One wave = one window x 64 channels (lane = channel); a workgroup covers PWB consecutive windows, stages
 // its dfeat tile through LDS (dfeat is (B,C,L): 64-B runs along L), routes the gradient to the max rows and
 // reduces dbeta3 / dgamma3 over its windows before one fp64 atomic pair per channel.
+template <int S16>
 __global__ __launch_bounds__(GT) void poolbwd_kernel(
     const float *__restrict__ dfeat, const int32_t *__restrict__ amax, const float *__restrict__ y3,
     const float *__restrict__ bn3, float *__restrict__ gmax, double *__restrict__ bstat, int rep_stride,
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(GT) void poolbwd_kernel(
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
         if (l0 + wave + 4 * q >= L) am[q] = -1;
-        yy[q] = y3[((int64_t)b * cap + max(am[q], 0)) * C3 + c];
+        yy[q] = lds1e<(S16 ? MM_BF16X1 : MM_F32)>(y3, ((int64_t)b * cap + max(am[q], 0)) * C3 + c);
     }
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
@@ -245,12 +246,12 @@ void dgrad_kernel(DgradArgs a)
         const int nq_ = (cc) * KC;                                                                                    \
         if (!((FCN_XB & 1) && (cc) > 0))                                                                              \
         _Pragma("unroll") for (int i = 0; i < NA4; ++i) {                                                             \
-            ry[i] = ldg4(a.ycur + arow[i] + nq_);                                                                     \
+            ry[i] = lds4e<MM>(a.ycur, arow[i] + nq_);                                                                 \
             if constexpr (LAYER == 3) {                                                                               \
                 rm[i] = ldg4i(a.amax + wbase[i] + nq_);                                                               \
                 rz[i] = ldg4(a.gmax + wbase[i] + nq_);                                                                \
             } else {                                                                                                  \
-                rz[i] = ldg4(a.dzcur + arow[i] + nq_);                                                                \
+                rz[i] = lds4e<MM>(a.dzcur, arow[i] + nq_);                                                            \
             }                                                                                                         \
         }                                                                                                             \
         if (!((FCN_XB & 2) && (cc) > 0))                                                                              \
@@ -293,7 +294,7 @@ void dgrad_kernel(DgradArgs a)
             if constexpr (LAYER == 3) {
                 if (ok && byi == 0 && !(FCN_XB & 128)) {
                     const v4f d0 = {dv[0], dv[1], dv[2], dv[3]};
-                    sts4(a.dybuf + (grow0 + r) * CRED + nb, d0);
+                    sts4e<MM>(a.dybuf, (grow0 + r) * CRED + nb, d0);
                 }
             }
         }
@@ -340,7 +341,7 @@ void dgrad_kernel(DgradArgs a)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int row = min(wm * 32 * MT + mt * 32 + acc_row(reg, lh), nvalid - 1);      // clamped, unconditional
-                    yv[mt][reg] = a.yprev[(grow0 + row) * CPREV + col];
+                    yv[mt][reg] = lds1e<MM>(a.yprev, (grow0 + row) * CPREV + col);
                 }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -349,8 +350,8 @@ void dgrad_kernel(DgradArgs a)
                     const int row = wm * 32 * MT + mt * 32 + acc_row(reg, lh);
                     if (row < nvalid) {
                         const float y = yv[mt][reg];
-                        const float dz = (fmaf(ps, y, pt) > 0.f) ? acc[mt][nt][reg] : 0.f;
-                        if (!(FCN_XB & 32)) a.dzprev[(grow0 + row) * CPREV + col] = dz;
+                        const float dz = st_round<MM>((fmaf(ps, y, pt) > 0.f) ? acc[mt][nt][reg] : 0.f);       // as stored
+                        if (!(FCN_XB & 32)) sts1e<MM>(a.dzprev, (grow0 + row) * CPREV + col, dz);
                         st[nt][0] += dz;
                         st[nt][1] = fmaf(dz, (y - pm) * pr, st[nt][1]);
                     }
@@ -416,6 +417,14 @@ struct WgradArgs {
     float *partial;         // (nsplit, COUT, CIN)
     int L, cap, COUT, CIN, tps;
 };
+
+// four stored elements (fp32, or bf16 in the bf16 throughput mode) as a float4
+template <int MM>
+__device__ __forceinline__ float4 ld4f(const float *base, int64_t e)
+{
+    const v4f v = lds4e<MM>(base, e);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 
 // dW[n][k] = sum_rows dy[row][n] * a_prev[row][k]; workgroup tile (64*MT) x (64*NT).  Split s reduces the
 // rows of live tiles [s*tpb, (s+1)*tpb) and writes one partial; wgrad_reduce sums the live partials in a fixed
@@ -509,17 +518,17 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
             const int rr = min(WG_AROW(i), lastr);
             const int o = (g0 + rr) * COUT + n0 + 4 * acq;
             if constexpr (LAYER == 3) {
-                ra[i] = *(const float4 *)(a.dy + o);
+                ra[i] = ld4f<MM>(a.dy, o);
             } else {
-                ra[i] = *(const float4 *)(a.dz + o);
-                ra2[i] = *(const float4 *)(a.ycur + o);
+                ra[i] = ld4f<MM>(a.dz, o);
+                ra2[i] = ld4f<MM>(a.ycur, o);
                 rwt[i] = a.ent[g0 + rr].w;
             }
         }
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {
             const int rr = min(WG_BROW(i), lastr);
-            if constexpr (LAYER == 3) rb4[i] = *(const float4 *)(a.yprev + (g0 + rr) * CIN + k0 + 4 * bcq);
+            if constexpr (LAYER == 3) rb4[i] = ld4f<MM>(a.yprev, (g0 + rr) * CIN + k0 + 4 * bcq);
             else rb4[i] = a.ent[g0 + rr];
         }
     };
@@ -776,8 +785,12 @@ extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, co
 
     hipError_t e = hipSuccess;          // ws->bstat was zeroed by the pool kernel of this scale's forward
 
-    hipLaunchKernelGGL(poolbwd_kernel, dim3((L + PWB - 1) / PWB, C3 / 64, B), dim3(GT), 0, st, dfeat, ws->amax,
-                       ws->y3, bn3, ws->gmax, bs3, brs, L, cap, C3, C3 + d->nvec, d->nlc);
+    if (FCN_BF16_STORE && d->precision == FCN_PREC_BF16)       // y3 stored as bf16 (gemm_tile.h: St)
+        hipLaunchKernelGGL(poolbwd_kernel<1>, dim3((L + PWB - 1) / PWB, C3 / 64, B), dim3(GT), 0, st, dfeat, ws->amax,
+                           ws->y3, bn3, ws->gmax, bs3, brs, L, cap, C3, C3 + d->nvec, d->nlc);
+    else
+        hipLaunchKernelGGL(poolbwd_kernel<0>, dim3((L + PWB - 1) / PWB, C3 / 64, B), dim3(GT), 0, st, dfeat, ws->amax,
+                           ws->y3, bn3, ws->gmax, bs3, brs, L, cap, C3, C3 + d->nvec, d->nlc);
     FCN_CHECK_LAUNCH();
     DgradArgs g;
     g.ent = (const float4 *)ws->ent; g.woff = ws->woff; g.tiles = ws->tiles; g.ewin = ws->ewin; g.L = L; g.cap = cap; g.tps = tps;

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
                 // unconditional, from a clamped row (a "load or zero" select makes the compiler wait for the load at
                 // once); rows past nvalid are zeroed when the registers go to LDS.  32-bit element offsets
                 // (launch_fwd_gemm checks B * cap * CIN < 2^31).
-                ra[i] = ldg4(a.aprev + ((int)grow0 + min(r, nvalid - 1)) * CIN + c * KC + 4 * kq);
+                ra[i] = lds4e<MM>(a.aprev, ((int)grow0 + min(r, nvalid - 1)) * CIN + c * KC + 4 * kq);
             }
         }
         if (!((FCN_X & 2) && c > 0))
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
                 const int col = n0 + wn * 32 * NT + nt * 32 + l31;
                 const float v = acc[mt][nt][reg];
                 if constexpr (MM == MM_F16X3) bad |= !(fabsf(v) < 3.0e38f);
-                if (row < nvalid) a.y[(grow0 + row) * COUT + col] = v;
+                if (row < nvalid) sts1e<MM>(a.y, (grow0 + row) * COUT + col, v);
             }
 #else
     float *patch = (float *)lds4 + wave * EP_FLOATS;          // (the operand buffers are free after the last barrier)
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
                 const int idx = lane + 64 * q, row = rbase + (idx >> 3);
                 const v4f v = ep_get(patch, lane, q);
                 if constexpr (MM == MM_F16X3) bad |= !(fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w) < 3.0e38f);
-                if (row < nvalid && !(FCN_X & 32)) sts4(a.y + (grow0 + row) * COUT + cbase + 4 * (idx & 7), v);
+                if (row < nvalid && !(FCN_X & 32)) sts4e<MM>(a.y, (grow0 + row) * COUT + cbase + 4 * (idx & 7), v);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const float w = wS[wm * 32 * MT + mt * 32 + acc_row(reg, lh)];
-                    const float v = acc[mt][nt][reg];
+                    const float v = st_round<MM>(acc[mt][nt][reg]);       // (the sums are over the values as stored)
                     s1 = fmaf(w, v, s1);
                     s2 = fmaf(w * v, v, s2);
                 }
@@ -503,6 +503,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
 // a workgroup covers 16 consecutive windows so the (B, C, L) output goes out as 64-B runs through LDS.
 #define PW 4            // windows per workgroup: ONE PER WAVE (the row walk of a window is a serial latency chain)
 
+template <int S16>
 __global__ __launch_bounds__(GT) void pool_kernel(
     const float *__restrict__ y3, const float *__restrict__ bn3, const int32_t *__restrict__ woff,
     const int32_t *__restrict__ cnt, const float *__restrict__ one_hot, float *__restrict__ feat,
@@ -524,21 +525,22 @@ __global__ __launch_bounds__(GT) void pool_kernel(
         int arg = -1;
         if (l < L && cnt[(int64_t)b * L + l] > 0) {
             const int o0 = wo[l], o1 = wo[l + 1];
-            const float *yp = y3 + ((int64_t)b * cap + o0) * C3 + c;
+            constexpr int SM = S16 ? MM_BF16X1 : MM_F32;         // storage of y3: bf16 in the bf16 throughput mode
+            const int64_t yo = ((int64_t)b * cap + o0) * C3 + c;
             int r = o0;
             // 8 independent row loads in flight; compared in row order (first maximum wins, like torch.max)
-            for (; r + 8 <= o1; r += 8, yp += 8 * (int64_t)C3) {
+            for (; r + 8 <= o1; r += 8) {
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = yp[j * (int64_t)C3];
+                for (int j = 0; j < 8; ++j) v[j] = lds1e<SM>(y3, yo + (int64_t)(r - o0 + j) * C3);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float u = fmaf(s, v[j], t);
                     if (u > best) { best = u; arg = r + j; }
                 }
             }
-            for (; r < o1; ++r, yp += C3) {
-                const float v = fmaf(s, *yp, t);
+            for (; r < o1; ++r) {
+                const float v = fmaf(s, lds1e<SM>(y3, yo + (int64_t)(r - o0) * C3), t);
                 if (v > best) { best = v; arg = r; }
             }
         }
@@ -567,7 +569,7 @@ __global__ __launch_bounds__(GT) void pool_kernel(
 // 58 us for 74 MB -- while most waves had finished long before.  The partial (max, arg-max) pairs meet in LDS; ties go to
 // the earlier row, like torch.max.
 typedef float v2f __attribute__((ext_vector_type(2)));
-template <int VEC, int WPW>
+template <int VEC, int WPW, int S16>
 __global__ __launch_bounds__(GT) void pool_nlc_kernel(
     const float *__restrict__ y3, const float *__restrict__ bn3, const int32_t *__restrict__ woff,
     const int32_t *__restrict__ cnt, float *__restrict__ feat, int32_t *__restrict__ amax, int L, int cap, int C3,
@@ -591,21 +593,27 @@ __global__ __launch_bounds__(GT) void pool_nlc_kernel(
     if (live && cnt[(int64_t)b * L + l] > 0) {
         const int32_t *wo = woff + (int64_t)b * (L + 1);
         const int o0 = wo[l], o1 = wo[l + 1];
-        const float *ybase = y3 + (int64_t)b * cap * C3 + c;
+        constexpr int SM = S16 ? MM_BF16X1 : MM_F32;             // storage of y3: bf16 in the bf16 throughput mode
+        const int64_t ybase = (int64_t)b * cap * C3 + c;
         // batches part, part + WPW, ...: rows past the window's end are loaded from its last row (unconditional loads) and
         // skipped in the comparison; rows are compared in row order, the first maximum wins
         for (int r = o0 + part * UN; r < o1; r += WPW * UN) {
             float v[UN][VEC];
 #pragma unroll
             for (int j = 0; j < UN; ++j) {
-                const float *q = ybase + (int64_t)min(r + j, o1 - 1) * C3;
+                const int64_t q = ybase + (int64_t)min(r + j, o1 - 1) * C3;
                 if constexpr (VEC == 2) {
-                    const v2f x = *(const v2f __attribute__((address_space(1))) *)q;
-                    v[j][0] = x.x; v[j][1] = x.y;
+                    if constexpr (S16) {
+                        const bf16x2 x = *(const bf16x2 __attribute__((address_space(1))) *)((const __bf16 *)y3 + q);
+                        v[j][0] = (float)x[0]; v[j][1] = (float)x[1];
+                    } else {
+                        const v2f x = *(const v2f __attribute__((address_space(1))) *)(y3 + q);
+                        v[j][0] = x.x; v[j][1] = x.y;
+                    }
                 } else {
 #pragma unroll
                     for (int h = 0; h < VEC / 4; ++h) {
-                        const v4f x = ldg4(q + 4 * h);
+                        const v4f x = lds4e<SM>(y3, q + 4 * h);
                         v[j][4 * h] = x.x; v[j][4 * h + 1] = x.y; v[j][4 * h + 2] = x.z; v[j][4 * h + 3] = x.w;
                     }
                 }
@@ -724,22 +732,27 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
     FCN_CHECK_LAUNCH();
 
     const int nz = FCN_STAT_REP * (2 * C3 + 2 * C2 + 4 * C1);
+    const bool s16 = FCN_BF16_STORE && d->precision == FCN_PREC_BF16;       // y2 / y3 stored as bf16 (gemm_tile.h: St)
     if (d->nlc && (C3 == 128 || C3 == 256 || C3 == 512)) {
         int32_t *am = tr ? ws->amax : nullptr;
         double *zp = tr ? ws->bstat : nullptr;
         // waves per window by the window capacity (nsample): 4 from 128 rows up, else 1 (measured: two waves per window at
         // nsample 64 are SLOWER than one -- 83 -> 96 us for the scale -- the exchange costs more than the shorter walk saves)
-#define FCN_POOL_LAUNCH(VEC_)                                                                                         \
-        if (K >= 128) hipLaunchKernelGGL((pool_nlc_kernel<VEC_, 4>), dim3(L, 1, B), dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, feat, am, L, cap, C3, zp, nz); \
-        else hipLaunchKernelGGL((pool_nlc_kernel<VEC_, 1>), dim3((L + PW - 1) / PW, 1, B), dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, feat, am, L, cap, C3, zp, nz);
+#define FCN_POOL_LAUNCH2(VEC_, S16_)                                                                                  \
+        if (K >= 128) hipLaunchKernelGGL((pool_nlc_kernel<VEC_, 4, S16_>), dim3(L, 1, B), dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, feat, am, L, cap, C3, zp, nz); \
+        else hipLaunchKernelGGL((pool_nlc_kernel<VEC_, 1, S16_>), dim3((L + PW - 1) / PW, 1, B), dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, feat, am, L, cap, C3, zp, nz);
+#define FCN_POOL_LAUNCH(VEC_) if (s16) { FCN_POOL_LAUNCH2(VEC_, 1) } else { FCN_POOL_LAUNCH2(VEC_, 0) }
         if (C3 == 128) { FCN_POOL_LAUNCH(2) }
         else if (C3 == 256) { FCN_POOL_LAUNCH(4) }
         else { FCN_POOL_LAUNCH(8) }
 #undef FCN_POOL_LAUNCH
+#undef FCN_POOL_LAUNCH2
     } else {
         dim3 pgrid((L + PW - 1) / PW, C3 / 64, B);
-        hipLaunchKernelGGL(pool_kernel, pgrid, dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, one_hot, feat,
-                           tr ? ws->amax : nullptr, L, cap, C3, d->nvec, d->nlc, tr ? ws->bstat : nullptr, nz);
+        if (s16) hipLaunchKernelGGL(pool_kernel<1>, pgrid, dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, one_hot, feat,
+                                    tr ? ws->amax : nullptr, L, cap, C3, d->nvec, d->nlc, tr ? ws->bstat : nullptr, nz);
+        else hipLaunchKernelGGL(pool_kernel<0>, pgrid, dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, one_hot, feat,
+                                tr ? ws->amax : nullptr, L, cap, C3, d->nvec, d->nlc, tr ? ws->bstat : nullptr, nz);
     }
     FCN_CHECK_LAUNCH();
     return 0;

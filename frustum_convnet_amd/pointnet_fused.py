@@ -56,6 +56,15 @@ class Workspace:
                       p(self.coef), p(self.partial), self.nsplit, p(self.gmom), p(self.wenc), p(self.flags))
 
 
+    @staticmethod
+    def stored(t, precision_code):
+        """fp32 view of one of the big intermediates (y2, y3, dy3, dz2) as the kernels of `precision_code` stored it: fp32, or --
+        in the bf16 throughput mode (FCN_PREC_BF16 = 2) -- bf16 in the first half of the same buffer."""
+        if precision_code != _precision.CODES["bf16"]:
+            return t
+        return t.view(-1).view(torch.bfloat16)[:t.numel()].view(t.shape).float()
+
+
 class WorkspacePool:
     def __init__(self):
         self.free = {}
@@ -310,7 +319,8 @@ def dense_from_entries(pool, dist, nsample, training, eps, momentum, pc, ref, bu
     ne = cnt.clamp(min=1).long()
     k = torch.arange(K, device=pc.device).view(1, 1, K)
     rows = ws.woff[:, :L].long().unsqueeze(2) + torch.where(k < ne.unsqueeze(2), k, torch.zeros_like(k))
-    y = torch.gather(ws.y3, 1, rows.view(B, L * K, 1).expand(-1, -1, C3)).view(B, L, K, C3)
+    y3 = ws.stored(ws.y3, desc.precision)
+    y = torch.gather(y3, 1, rows.view(B, L * K, 1).expand(-1, -1, C3)).view(B, L, K, C3)
     a = torch.relu(y * s3 + t3) * (cnt > 0).view(B, L, 1, 1).float()
     out = a.permute(0, 3, 1, 2).contiguous()
     pool.release(ws)
