@@ -6,7 +6,7 @@ run() { if [ $1 = prod ]; then unset FCN_LIB_NAME; else export FCN_LIB_NAME=libf
 for i in 1 2; do
   for lib in prod $VARIANTS; do
     run $lib
-    timeout 90 python bench.py --no-cpu-baseline --no-roofline --no-configs --min-time 1.5 > $O/abm_${lib}_$i.json 2> $O/abm_${lib}_$i.err
+    timeout 90 python bench.py --no-cpu-baseline --no-roofline --no-configs --min-time 1.5 $BENCH_ARGS > $O/abm_${lib}_$i.json 2> $O/abm_${lib}_$i.err
     echo "$lib $i: $(python -c "import json,sys; d=json.loads(open('$O/abm_${lib}_$i.json').read().strip().split(chr(10))[-1]); print(d['value'], d['ms_per_step'])" 2>&1 | tail -1)"
   done
 done
