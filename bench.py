@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the short windows of the other configurations")
     ap.add_argument("--cpu-baseline-batch", type=int, default=32)
-    ap.add_argument("--precision", choices=("split", "f32", "bf16"), default=None,
+    ap.add_argument("--precision", choices=("split", "f32", "bf16", "bf16ops"), default=None,
                     help="MFMA operand mode of the GEMM kernels (default: FCN_PRECISION or 'split')")
     return ap.parse_args()
 
@@ -178,7 +178,8 @@ def kernel_table(model, state, data, optim, prec, reps=5):
             for ws in lst:
                 if ws.key[2] == Lw and ws.key[3] == net.nsample:
                     E[(Lw, net.nsample)] = int(ws.woff[:, -1].sum().item())
-    peak_mm = {"split": PEAK_16BIT_MFMA_TFLOPS / 3.0, "f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_16BIT_MFMA_TFLOPS}[prec]
+    peak_mm = {"split": PEAK_16BIT_MFMA_TFLOPS / 3.0, "f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_16BIT_MFMA_TFLOPS,
+               "bf16ops": PEAK_16BIT_MFMA_TFLOPS}[prec]
     rows = []
     ff = fcn_flops(B, Ls, nvec=model.feat_net.num_vec, c1=model.conv_net.WIDTHS[0],
                    nout=2 + model.reg_out.weight.shape[0])
@@ -441,7 +442,7 @@ def workload_name(cfg_name, batch, npoint, Ls, optim=True, extra=""):
 
 # the other BASELINE.json configurations (4: people, 5: refine; 2's bf16 throughput mode) and SURVEY f-4's SUN-RGBD variant,
 # each timed in a short window of the same kind after the headline line's measurement (N = 1 only)
-OTHER_CONFIGS = (("people", "split"), ("refine", "split"), ("sunrgbd", "split"), ("car", "bf16"))
+OTHER_CONFIGS = (("people", "split"), ("refine", "split"), ("sunrgbd", "split"), ("car", "bf16"), ("car", "bf16ops"))
 
 
 def other_configs(a, dev, min_time=0.35):
@@ -449,7 +450,7 @@ def other_configs(a, dev, min_time=0.35):
     for cfg_name, prec in OTHER_CONFIGS:
         try:
             m = measure(a, cfg_name, prec, 20, 10, min_time, dev, 0, 1)
-            out.append({"cfg": cfg_name, "precision": prec, "dtype": "bf16" if prec == "bf16" else "f32",
+            out.append({"cfg": cfg_name, "precision": prec, "dtype": "bf16" if prec.startswith("bf16") else "f32",
                         "workload": workload_name(cfg_name, m["batch"], m["npoint"], m["Ls"], m["optim"]),
                         "value": round(m["batch"] / (m["ms_per_step"] / 1e3), 2), "unit": "frustums/s",
                         "ms_per_step": round(m["ms_per_step"], 4), "timed_steps": m["nstep"],
@@ -498,9 +499,11 @@ def main():
         "unit": "frustums/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "rounds": rounds,
         "timed_steps": nstep, "timed_seconds": round(wall, 4),
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": {"split": "f32", "f32": "f32", "bf16": "bf16"}[prec],
+        "vs_baseline": None, "dtype": {"split": "f32", "f32": "f32", "bf16": "bf16", "bf16ops": "bf16"}[prec],
         "mfma_operands": {"split": "fp16x3 (forward) / bf16x3 (backward) split of fp32 operands, fp32 accumulate: fp32-class",
-                          "f32": "fp32 (v_mfma_f32_32x32x2_f32)", "bf16": "bf16 single term, fp32 accumulate"}[prec],
+                          "f32": "fp32 (v_mfma_f32_32x32x2_f32)",
+                          "bf16": "bf16 single term, fp32 accumulate; y2/y3/dy3/dz2 and the FCN y/dz arenas stored as bf16",
+                          "bf16ops": "bf16 single term, fp32 accumulate, fp32 storage"}[prec],
         "data": "synthetic",
         "config": {"workload": "%s KITTI-%s, batch=%d/GPU, Npoint=%d, L=(%s), train fwd+bwd%s%s" % (
                        CFGS[a.cfg][0], a.cfg, a.batch, npoint, ",".join(str(v) for v in Ls),
@@ -524,7 +527,7 @@ def main():
                           flops_executed_per_step=top["flops_executed"],
                           frac_of_fp32_mfma_peak=top["frac_of_fp32_mfma_peak"],
                           peak_note="16-bit dense MFMA peak 2500 TFLOP/s / 3 instructions per fp32-class product" if prec == "split"
-                          else ("dense bf16 MFMA peak" if prec == "bf16" else "fp32 MFMA peak"))
+                          else ("dense bf16 MFMA peak" if prec.startswith("bf16") else "fp32 MFMA peak"))
             else:
                 rl.update(achieved=top["achieved_tbps"], peak=PEAK_HBM_TBPS, unit="TB/s")
             tr, why = pmc_traffic("entry", top["entry"].split("[")[0])

@@ -1431,7 +1431,7 @@ extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p
     CnOffsets O;
     cn_offsets(d, P, O);
     const int tr = d->training ? 1 : 0;
-    if (d->precision < 0 || d->precision > FCN_PREC_BF16) return FCN_E_BADARG;
+    if (d->precision < 0 || d->precision > FCN_PREC_BF16_OPS) return FCN_E_BADARG;
     const int mmf = FCN_MM_OF(d->precision, true);
     if (!d->prepacked) FCN_TRY(cn_pack(d, p, P, O, ws, one_hot, st));      // (also zeroes ws->stat / ws->bstat)
     // launches in dependency order; block{j}_conv1 and block{j-1}_deconv (j >= 3) are pairs of independent layers reading
@@ -1533,7 +1533,7 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
     // block{nlev-k}_merge), k = 1..nlev-2; events[nlev-1]: everything final (dfeats[0], all dW).
     const bool cont = stream2 != nullptr && events != nullptr;
     hipStream_t st = (hipStream_t)stream;
-    if (d->precision < 0 || d->precision > FCN_PREC_BF16) return FCN_E_BADARG;
+    if (d->precision < 0 || d->precision > FCN_PREC_BF16_OPS) return FCN_E_BADARG;
     const int mmb = FCN_MM_OF(d->precision, false);
     CnPlan P;
     FCN_TRY(cn_make_plan(d, P));

@@ -46,7 +46,8 @@ __device__ __forceinline__ v4f zero4() { v4f z = {0.f, 0.f, 0.f, 0.f}; return z;
 //   MM_F16X3  forward GEMMs: fp16 parts, 22 significand bits kept, error ~2^-21 per product (operands are O(1)
 //             activations after BN+ReLU and weights; |x| must stay below 65504 -- an overflow shows up as inf/NaN);
 //   MM_BF16X3 backward GEMMs: bf16 parts (fp32 exponent range -- gradients span many decades), error ~2^-17 per product;
-//   MM_BF16X1 throughput mode (BASELINE config 2 "bf16"): the hi product only;
+//   MM_BF16X1 bf16 operands, the hi product only (FCN_PREC_BF16_OPS); MM_BF16S the same with bf16 storage of the big
+//             intermediates -- BASELINE config 2's "bf16" throughput mode (FCN_PREC_BF16);
 //   MM_F32    exact fp32 MFMA (bitwise an fmaf chain), kept as the reference mode for A/B runs.
 // Measured on the CPU emulation of the whole net (tools/split_emulation.py): logits |err| vs fp64 9e-6 (f32) / 1.3e-5
 // (f16x3) / 3e-4 (bf16x3: misses the 1e-4 bar, hence fp16 forwards) / 0.13 (bf16x1); parameter gradients with a bf16x3
@@ -55,7 +56,10 @@ __device__ __forceinline__ v4f zero4() { v4f z = {0.f, 0.f, 0.f, 0.f}; return z;
 #define MM_F16X3 1
 #define MM_BF16X3 2
 #define MM_BF16X1 3
+#define MM_BF16S 4          // MM_BF16X1 operands + the big intermediate tensors STORED as bf16 (St below)
 
+template <int MM>
+inline constexpr bool mm_x1 = (MM == MM_BF16X1 || MM == MM_BF16S);        // one bf16 MFMA per product
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int acc_row_c(int reg, int lh) { return (reg & 3) + 8 * (reg >> 2) + 4 * lh; }
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -169,7 +173,7 @@ __device__ __forceinline__ void mma_chunk(const float *As, const float *Bs, int 
         // 8*lh + {1,3,5,7} (lo pairs) of the step, each a conflict-free ds_read_b32 (32 consecutive dwords per half-wave)
         const uint32_t *ap = (const uint32_t *)As + (8 * lh) * LDA + arow0 + l31;
         const uint32_t *bp = (const uint32_t *)Bs + (8 * lh) * LDB + bcol0 + l31;
-        constexpr bool X3 = (MM != MM_BF16X1);
+        constexpr bool X3 = !mm_x1<MM>;
 #pragma unroll
         for (int ks = 0; ks < KCH; ks += 16) {
             u32x4 ah[MT], al[MT], bh[NT], bl[NT];
@@ -208,16 +212,14 @@ __device__ __forceinline__ void mma_chunk(const float *As, const float *Bs, int 
 
 // ------------------------------------------------------------------------------------------------
 // STORAGE type of the big intermediate tensors (PointNet y2 / y3 / dy3 / dz2, the FCN's y / dz arenas).  fp32 in the split
-// and f32 operand modes; in the bf16 throughput mode (FCN_PREC_BF16, BASELINE config 2) they are stored as bf16 -- half the
+// and f32 operand modes (and in FCN_PREC_BF16_OPS); in the bf16 throughput mode (FCN_PREC_BF16, BASELINE config 2: MM_BF16S)
+// they are stored as bf16 -- half the
 // HBM bytes of the step's dominant streams -- while accumulators, BatchNorm sums, pooled features, logits and every
 // parameter gradient stay fp32.  The buffers keep their float-typed pointers and element counts (the caller sizes them for
 // fp32; bf16 uses the first half): all index arithmetic is in ELEMENTS and these helpers scale it.
-#ifndef FCN_BF16_STORE
-#define FCN_BF16_STORE 1       // 0 (tuning / A-B builds): bf16 operands only, fp32 storage as in rounds 1-2
-#endif
 template <int MM>
 struct St {
-    static constexpr bool half = (MM == MM_BF16X1) && FCN_BF16_STORE;
+    static constexpr bool half = (MM == MM_BF16S);
     static constexpr int bytes = half ? 2 : 4;
 };
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -319,7 +321,7 @@ __device__ __forceinline__ void kb_store4(u32x4 *img, int r, int kq, float x0, f
         enc2<MM>(x2, x3, h1, l1);
         const v2f_kb h = {h0, h1}, l = {l0, l1};
         *(v2f_kb *)((float *)(img + kb * LDR + r) + 2 * half) = h;
-        if constexpr (MM != MM_BF16X1) *(v2f_kb *)((float *)(img + (4 + kb) * LDR + r) + 2 * half) = l;
+        if constexpr (!mm_x1<MM>) *(v2f_kb *)((float *)(img + (4 + kb) * LDR + r) + 2 * half) = l;
     }
 }
 
@@ -349,7 +351,7 @@ __device__ __forceinline__ void mma_chunk_kb(const u32x4 *A, const u32x4 *B, int
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[jn], acc[i][jn], 0, 0, 0);
         }
     } else {
-        constexpr bool X3 = (MM != MM_BF16X1);
+        constexpr bool X3 = !mm_x1<MM>;
         const u32x4 *ap = A + lh * LDRA + arow0 + l31;
         const u32x4 *bp = B + lh * LDRB + bcol0 + l31;
 #pragma unroll
@@ -401,13 +403,15 @@ __device__ __forceinline__ v4f ep_get(const float *patch, int lane, int q)
 
 // host-side dispatch of a precision mode (fcn_pn_desc / fcn_cn_desc .precision) to the operand mode of a forward or a
 // backward GEMM: f(std::integral_constant<int, MM>) -> int
-#define FCN_MM_OF(prec, fwd) ((prec) == FCN_PREC_F32 ? MM_F32 : ((prec) == FCN_PREC_BF16 ? MM_BF16X1 : ((fwd) ? MM_F16X3 : MM_BF16X3)))
+#define FCN_MM_OF(prec, fwd)                                                                     \
+    ((prec) == FCN_PREC_F32 ? MM_F32 : ((prec) == FCN_PREC_BF16 ? MM_BF16S : ((prec) == FCN_PREC_BF16_OPS ? MM_BF16X1 : ((fwd) ? MM_F16X3 : MM_BF16X3))))
 #define FCN_MM_SWITCH(mm_, CALL)                                     \
     switch (mm_) {                                                   \
         case MM_F32: { constexpr int MM = MM_F32; CALL; } break;     \
         case MM_F16X3: { constexpr int MM = MM_F16X3; CALL; } break; \
         case MM_BF16X3: { constexpr int MM = MM_BF16X3; CALL; } break; \
-        default: { constexpr int MM = MM_BF16X1; CALL; } break;      \
+        case MM_BF16X1: { constexpr int MM = MM_BF16X1; CALL; } break; \
+        default: { constexpr int MM = MM_BF16S; CALL; } break;       \
     }
 
 // XCD-aware tile order (cdna guide T1).  Workgroup ids are dealt to the 8 XCDs round-robin and every XCD has its own 4 MB

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(GT) void poolbwd_kernel(
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
         if (l0 + wave + 4 * q >= L) am[q] = -1;
-        yy[q] = lds1e<(S16 ? MM_BF16X1 : MM_F32)>(y3, ((int64_t)b * cap + max(am[q], 0)) * C3 + c);
+        yy[q] = lds1e<(S16 ? MM_BF16S : MM_F32)>(y3, ((int64_t)b * cap + max(am[q], 0)) * C3 + c);
     }
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
@@ -767,7 +767,7 @@ extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, co
 {
     if (!d || !p || !ws || !dfeat || !dW || !dgamma || !dbeta) return FCN_E_BADARG;
     if (!d->training || !ws->wenc) return FCN_E_BADARG;
-    if (d->precision < 0 || d->precision > FCN_PREC_BF16) return FCN_E_BADARG;
+    if (d->precision < 0 || d->precision > FCN_PREC_BF16_OPS) return FCN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     const bool two = stream2 != nullptr && events != nullptr;
     hipStream_t sw = two ? (hipStream_t)stream2 : st;
@@ -785,7 +785,7 @@ extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, co
 
     hipError_t e = hipSuccess;          // ws->bstat was zeroed by the pool kernel of this scale's forward
 
-    if (FCN_BF16_STORE && d->precision == FCN_PREC_BF16)       // y3 stored as bf16 (gemm_tile.h: St)
+    if (d->precision == FCN_PREC_BF16)       // y3 stored as bf16 (gemm_tile.h: St)
         hipLaunchKernelGGL(poolbwd_kernel<1>, dim3((L + PWB - 1) / PWB, C3 / 64, B), dim3(GT), 0, st, dfeat, ws->amax,
                            ws->y3, bn3, ws->gmax, bs3, brs, L, cap, C3, C3 + d->nvec, d->nlc);
     else

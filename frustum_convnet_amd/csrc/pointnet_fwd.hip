@@ -169,7 +169,7 @@ extern "C" int fcn_pn_pack_weights(const fcn_pn_desc *d, const fcn_pn_params *p,
 {
     if (!d || !p || !ws || !ws->wenc || !p->W[1] || !p->W[2]) return FCN_E_BADARG;
     if (d->C1 % 64 || d->C2 % 64 || d->C3 % 64) return FCN_E_BADARG;
-    if (d->precision < 0 || d->precision > FCN_PREC_BF16 || ((uintptr_t)ws->wenc & 15)) return FCN_E_BADARG;
+    if (d->precision < 0 || d->precision > FCN_PREC_BF16_OPS || ((uintptr_t)ws->wenc & 15)) return FCN_E_BADARG;
     PackArgs a;
     a.W2 = p->W[1]; a.W3 = p->W[2]; a.wenc = ws->wenc; a.C1 = d->C1; a.C2 = d->C2; a.C3 = d->C3; a.precision = d->precision;
     const int items = 2 * (d->C2 * d->C1 + d->C3 * d->C2) / 8;
@@ -201,7 +201,7 @@ extern "C" int fcn_pn_pack_weights_all(int nscale, const fcn_pn_desc *const *d, 
         const int q = s < nscale ? s : 0;
         if (!d[q] || !p[q] || !ws[q] || !ws[q]->wenc || !p[q]->W[1] || !p[q]->W[2]) return FCN_E_BADARG;
         if (d[q]->C1 % 64 || d[q]->C2 % 64 || d[q]->C3 % 64) return FCN_E_BADARG;
-        if (d[q]->precision < 0 || d[q]->precision > FCN_PREC_BF16 || ((uintptr_t)ws[q]->wenc & 15)) return FCN_E_BADARG;
+        if (d[q]->precision < 0 || d[q]->precision > FCN_PREC_BF16_OPS || ((uintptr_t)ws[q]->wenc & 15)) return FCN_E_BADARG;
         PackArgs &S = a.s[s];
         S.W2 = p[q]->W[1]; S.W3 = p[q]->W[2]; S.wenc = ws[q]->wenc; S.C1 = d[q]->C1; S.C2 = d[q]->C2; S.C3 = d[q]->C3;
         S.precision = d[q]->precision;
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(GT) void pool_kernel(
         int arg = -1;
         if (l < L && cnt[(int64_t)b * L + l] > 0) {
             const int o0 = wo[l], o1 = wo[l + 1];
-            constexpr int SM = S16 ? MM_BF16X1 : MM_F32;         // storage of y3: bf16 in the bf16 throughput mode
+            constexpr int SM = S16 ? MM_BF16S : MM_F32;         // storage of y3: bf16 in the bf16 throughput mode
             const int64_t yo = ((int64_t)b * cap + o0) * C3 + c;
             int r = o0;
             // 8 independent row loads in flight; compared in row order (first maximum wins, like torch.max)
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(GT) void pool_nlc_kernel(
     if (live && cnt[(int64_t)b * L + l] > 0) {
         const int32_t *wo = woff + (int64_t)b * (L + 1);
         const int o0 = wo[l], o1 = wo[l + 1];
-        constexpr int SM = S16 ? MM_BF16X1 : MM_F32;             // storage of y3: bf16 in the bf16 throughput mode
+        constexpr int SM = S16 ? MM_BF16S : MM_F32;             // storage of y3: bf16 in the bf16 throughput mode
         const int64_t ybase = (int64_t)b * cap * C3 + c;
         // batches part, part + WPW, ...: rows past the window's end are loaded from its last row (unconditional loads) and
         // skipped in the comparison; rows are compared in row order, the first maximum wins
@@ -680,7 +680,7 @@ static int launch_fwd_gemm(const FwdArgs &a, int B, int precision, hipStream_t s
 {
     if (a.CIN % 64 || a.COUT % 64 || a.CIN > MAXC) return FCN_E_BADARG;
     if ((int64_t)B * a.cap * (a.CIN > a.COUT ? a.CIN : a.COUT) >= (int64_t)1 << 31) return FCN_E_LIMIT;      // 32-bit offsets
-    if (precision < 0 || precision > FCN_PREC_BF16) return FCN_E_BADARG;
+    if (precision < 0 || precision > FCN_PREC_BF16_OPS) return FCN_E_BADARG;
     FCN_MM_SWITCH(FCN_MM_OF(precision, true), return (launch_fwd_gemm_mm<MM, MODE>(a, B, st)));
     return FCN_E_BADARG;
 }
@@ -732,7 +732,7 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
     FCN_CHECK_LAUNCH();
 
     const int nz = FCN_STAT_REP * (2 * C3 + 2 * C2 + 4 * C1);
-    const bool s16 = FCN_BF16_STORE && d->precision == FCN_PREC_BF16;       // y2 / y3 stored as bf16 (gemm_tile.h: St)
+    const bool s16 = d->precision == FCN_PREC_BF16;       // y2 / y3 stored as bf16 (gemm_tile.h: St)
     if (d->nlc && (C3 == 128 || C3 == 256 || C3 == 512)) {
         int32_t *am = tr ? ws->amax : nullptr;
         double *zp = tr ? ws->bstat : nullptr;

@@ -60,7 +60,7 @@ class Workspace:
     def stored(t, precision_code):
         """fp32 view of one of the big intermediates (y2, y3, dy3, dz2) as the kernels of `precision_code` stored it: fp32, or --
         in the bf16 throughput mode (FCN_PREC_BF16 = 2) -- bf16 in the first half of the same buffer."""
-        if precision_code != _precision.CODES["bf16"]:
+        if precision_code != _precision.CODES["bf16"]:        # ("bf16ops" keeps fp32 storage)
             return t
         return t.view(-1).view(torch.bfloat16)[:t.numel()].view(t.shape).float()
 

@@ -52,11 +52,17 @@ extern "C" {
  *                   results (logits within 1e-4 of the fp32 reference) at 5.3x the fp32 matrix rate of gfx950.  Forward
  *                   operands (activations after BN+ReLU, weights) must stay below 65504 in magnitude.
  *   FCN_PREC_F32    exact fp32 MFMA (v_mfma_f32_32x32x2_f32): the reference mode for A/B comparisons.
- *   FCN_PREC_BF16   throughput mode of BASELINE config 2: single bf16 MFMA per product, fp32 accumulate (logits within
- *                   a few 1e-2 relative of the fp32 reference; grouping indices unaffected). */
+ *   FCN_PREC_BF16   throughput mode of BASELINE config 2 (bf16 activations + GEMM inputs): single bf16 MFMA per product, fp32
+ *                   accumulate, and the big intermediate tensors (PointNet y2 / y3 / dy3 / dz2, the FCN's y / dz arenas) STORED as
+ *                   bf16 in the first half of their (fp32-sized) buffers; BatchNorm sums, pooled features, logits and all
+ *                   parameter gradients stay fp32 (logits within a few 1e-2 relative of the fp32 reference; grouping indices
+ *                   unaffected).
+ *   FCN_PREC_BF16_OPS  the same operands with fp32 storage (rounds 1-2's bf16 mode): on MI355X the step is latency-, not
+ *                   HBM-bound, and the narrower accesses of bf16 storage make it SLOWER than this variant. */
 #define FCN_PREC_SPLIT 0
 #define FCN_PREC_F32   1
 #define FCN_PREC_BF16  2
+#define FCN_PREC_BF16_OPS 3
 
 /* Version / build probe: returns 950 (the only arch this library is built for). */
 int fcn_arch(void);

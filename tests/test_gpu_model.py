@@ -270,6 +270,27 @@ BF16_BAR = {"car_b4_n512": 3e-2, "car_b4_n512_uniform": 3.5e-2, "people_b2_n512"
             "car_b32_n1024": 3e-2}
 
 
+@pytest.mark.parametrize("case", ["car_b4_n512", "refine_b4_n512"])
+def test_bf16ops_mode_logits(case):
+    """FCN_PREC_BF16_OPS: bf16 operands, fp32 storage (rounds 1-2's bf16 mode, the faster variant on MI355X): same bar."""
+    from frustum_convnet_amd import precision
+    g = load_golden(case)
+    data = synth.to_torch(golden_inputs(g), "cuda")
+    m = _model(g)
+    m.train()
+    with precision.precision("bf16ops"):
+        losses, _ = m(data)
+        losses["total_loss"].backward()
+    cls, reg = m.last_logits
+    sel = torch.as_tensor(g["logit_samples"]).cuda()
+    got = np.concatenate([cls[sel].detach().cpu().numpy().ravel(), reg[sel].detach().cpu().numpy().ravel()])
+    ref = np.concatenate([g["cls_train"].ravel(), g["reg_train"].ravel()])
+    rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+    print(case, "bf16ops mode: relative L2 error of the logits %.3e (bar %.1e)" % (rel, BF16_BAR[case]))
+    assert rel < BF16_BAR[case]
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
 @pytest.mark.parametrize("case", sorted(BF16_BAR))
 def test_bf16_mode_logits(case):
     from frustum_convnet_amd import precision
