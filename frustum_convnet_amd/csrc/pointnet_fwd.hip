@@ -19,6 +19,9 @@
 #ifndef FCN_WIDE_TILES
 #define FCN_WIDE_TILES 0
 #endif
+#ifndef FCN_C3_BIG
+#define FCN_C3_BIG 1          // 128 x 128 tiles for the widest conv3 too (isolated on MI355X: 48.7 -> 44.1 us; 0: 64 x 128)
+#endif
 #ifndef FCN_FWD_EPI_DIRECT
 #define FCN_FWD_EPI_DIRECT 0
 #endif
@@ -664,7 +667,7 @@ static int launch_fwd_gemm_mm(const FwdArgs &a, int B, hipStream_t st)
     const unsigned nt = (unsigned)(B * a.tps);
     if (FCN_WIDE_TILES && a.COUT % 256 == 0) {
         hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 2, 4>), dim3(pad8(nt * (a.COUT / 256))), dim3(512), 0, st, a);
-    } else if (MODE == 1 && a.COUT >= 512 && a.COUT % 128 == 0) {      // the widest conv3: 64 x 128 tiles
+    } else if (!FCN_C3_BIG && MODE == 1 && a.COUT >= 512 && a.COUT % 128 == 0) {      // the widest conv3: 64 x 128 tiles
         hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 2, 2, 1>), dim3(pad8(2 * nt * (a.COUT / 128))), dim3(256), 0, st, a);
     } else if (a.COUT % 128 == 0) {
         hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 2, 2>), dim3(pad8(nt * (a.COUT / 128))), dim3(256), 0, st, a);
