@@ -12,7 +12,7 @@ echo "== bench car (full, default invocation)"; timeout 600 python bench.py > $O
 for c in people refine sunrgbd; do
   echo "== bench $c"; timeout 600 python bench.py --cfg $c --steps 100 --warmup 20 --no-cpu-baseline --no-configs > $O/${T}_bench_$c.json 2> $O/${T}_bench_$c.err; echo "rc=$?"; tail -1 $O/${T}_bench_$c.json | cut -c1-200
 done
-for p in f32 bf16; do
+for p in f32 bf16 bf16ops; do
   echo "== bench car $p"; timeout 600 python bench.py --precision $p --steps 200 --warmup 30 --no-cpu-baseline --no-configs > $O/${T}_bench_car_$p.json 2> $O/${T}_bench_car_$p.err; echo "rc=$?"; tail -1 $O/${T}_bench_car_$p.json | cut -c1-200
 done
 echo "== phase stamps"; timeout 300 python tools/phase_stamps.py > $O/${T}_phase_stamps.txt 2>&1; tail -9 $O/${T}_phase_stamps.txt
