@@ -388,7 +388,11 @@ __device__ __forceinline__ void mma_chunk_kb(const u32x4 *A, const u32x4 *B, int
 // Epilogue transposition patch of one wave: a 32 x 32 accumulator tile (lane = column, registers = rows) goes through a
 // wave-private 32 x EP_LD float patch and comes back row-major, 4 consecutive columns per lane (idx = lane + 64 q: row idx >> 3,
 // column quad idx & 7) -- so outputs leave as 16-byte stores (a quarter of the store instructions of one dword per lane).
-#define EP_LD 36
+// EP_LD = 32 (no padding) is the conflict-free choice for BOTH directions: the writes are 32 consecutive dwords of one row per
+// half-wave, and the 16-lane groups of a ds_read_b128 ({0-3,12-15,20-27}, ...) touch four rows at column quads {0-3,4-7,4-7,0-3}
+// -- 16-dword runs at 0, LD+16, 2LD+16, 3LD, which tile the 64 banks exactly when LD = 32 (with LD = 36 the second run wrapped
+// onto the first: SQ_LDS_BANK_CONFLICT 9-16 % of the forward GEMMs' LDS cycles).
+#define EP_LD 32
 #define EP_FLOATS (32 * EP_LD)
 __device__ __forceinline__ void ep_put(float *patch, const f32x16 &acc, int l31, int lh)
 {
