@@ -773,16 +773,42 @@ extern "C" int fcn_pn_backward(const fcn_pn_desc *d, const fcn_pn_params *p, con
 
 // Same with the weight gradients (wgrad + reduce of conv3 and conv2) on a second stream beside the data-gradient
 // chain poolbwd -> dgrad3 -> dgrad2 -> l1_finalize.  events: 3 caller-owned hipEvent_t (fork, fork, join).
+static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dfeat, const fcn_pn_ws *ws,
+                            float *dW[3], float *dgamma[3], float *dbeta[3], void *stream, void *stream2, void *stream3,
+                            void *const *events);
+
 extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dfeat,
                                 const fcn_pn_ws *ws, float *dW[3], float *dgamma[3], float *dbeta[3],
                                 void *stream, void *stream2, void *const *events)
+{
+    return pn_backward_impl(d, p, dfeat, ws, dW, dgamma, dbeta, stream, stream2, nullptr, events);
+}
+
+// Three streams: after dgrad3 (which leaves dy3, dz2 and the BN2-backward sums final) the chain splits three ways -- dgrad2 +
+// l1_finalize on `stream`, conv3's weight gradient (+ reduce) on `stream2`, conv2's on `stream3` -- instead of two: on the
+// widest scale the second stream's wgrad3 -> reduce -> wgrad2 -> reduce (121 us) was longer than the main chain's rest (67 us)
+// and set the scale's backward (232 us isolated).  Needs ws->partial sized for BOTH weight gradients at once
+// (nsplit * (C3*C2 + C2*C1) floats: conv2's partials follow conv3's) and 4 events (fork, unused, join 2, join 3).
+extern "C" int fcn_pn_backward3(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dfeat,
+                                const fcn_pn_ws *ws, float *dW[3], float *dgamma[3], float *dbeta[3],
+                                void *stream, void *stream2, void *stream3, void *const *events)
+{
+    if (!stream2 || !stream3 || !events) return FCN_E_BADARG;
+    return pn_backward_impl(d, p, dfeat, ws, dW, dgamma, dbeta, stream, stream2, stream3, events);
+}
+
+static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dfeat, const fcn_pn_ws *ws,
+                            float *dW[3], float *dgamma[3], float *dbeta[3], void *stream, void *stream2, void *stream3,
+                            void *const *events)
 {
     if (!d || !p || !ws || !dfeat || !dW || !dgamma || !dbeta) return FCN_E_BADARG;
     if (!d->training || !ws->wenc) return FCN_E_BADARG;
     if (d->precision < 0 || d->precision > FCN_PREC_BF16_OPS) return FCN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     const bool two = stream2 != nullptr && events != nullptr;
+    const bool three = two && stream3 != nullptr;
     hipStream_t sw = two ? (hipStream_t)stream2 : st;
+    hipStream_t sw2 = three ? (hipStream_t)stream3 : sw;        // stream of conv2's weight gradient
     const int B = d->B, L = d->L, K = d->K, C1 = d->C1, C2 = d->C2, C3 = d->C3;
     if (C1 % 64 || C2 % 64 || C3 % 64 || C1 > MAXC || C2 > MAXC || C3 > MAXC) return FCN_E_BADARG;
     const int cap = L * K;
@@ -824,19 +850,31 @@ extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, co
         if (e != hipSuccess) return (int)e;
         e = hipStreamWaitEvent(sw, (hipEvent_t)events[0], 0);
         if (e != hipSuccess) return (int)e;
+        if (three) {
+            e = hipStreamWaitEvent(sw2, (hipEvent_t)events[0], 0);
+            if (e != hipSuccess) return (int)e;
+        }
     }
     FCN_TRY(launch_wgrad<3>(w, B, ws->nsplit, d->precision, sw, dW[2]));
+    if (three) {
+        e = hipEventRecord((hipEvent_t)events[3], sw);
+        if (e != hipSuccess) return (int)e;
+    }
 
-    if (two) {     // dz2 and its BN-backward sums were final at events[0]: conv2's weight gradient follows conv3's on the side stream
-        e = hipEventRecord((hipEvent_t)events[1], st);
-        if (e != hipSuccess) return (int)e;
-        e = hipStreamWaitEvent(sw, (hipEvent_t)events[1], 0);
-        if (e != hipSuccess) return (int)e;
+    if (two) {     // dz2 and its BN-backward sums were final at events[0]: conv2's weight gradient follows conv3's on the side
+                   // stream (two streams) or runs beside it on the third
+        if (!three) {
+            e = hipEventRecord((hipEvent_t)events[1], st);
+            if (e != hipSuccess) return (int)e;
+            e = hipStreamWaitEvent(sw, (hipEvent_t)events[1], 0);
+            if (e != hipSuccess) return (int)e;
+        }
         w.dy = nullptr; w.dz = ws->dz2; w.ycur = ws->y2; w.yprev = nullptr; w.bn_prev = bn1;
         w.cb.bstat = bs2; w.cb.gamma = p->gamma[1]; w.cb.bn = bn2;
         w.W1 = p->W[0]; w.COUT = C2; w.CIN = C1;
-        FCN_TRY(launch_wgrad<2>(w, B, ws->nsplit, d->precision, sw, dW[1]));
-        e = hipEventRecord((hipEvent_t)events[2], sw);
+        if (three) w.partial = ws->partial + (int64_t)ws->nsplit * C3 * C2;      // its own partials: the two run at once
+        FCN_TRY(launch_wgrad<2>(w, B, ws->nsplit, d->precision, sw2, dW[1]));
+        e = hipEventRecord((hipEvent_t)events[2], sw2);
         if (e != hipSuccess) return (int)e;
     }
     g.ycur = ws->y2; g.amax = nullptr; g.gmax = nullptr; g.dzcur = ws->dz2;
@@ -859,6 +897,10 @@ extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, co
     if (two) {
         e = hipStreamWaitEvent(st, (hipEvent_t)events[2], 0);
         if (e != hipSuccess) return (int)e;
+        if (three) {
+            e = hipStreamWaitEvent(st, (hipEvent_t)events[3], 0);
+            if (e != hipSuccess) return (int)e;
+        }
     }
     return 0;
 }

@@ -49,7 +49,7 @@ class Workspace:
             self.dz2 = torch.empty((B, cap, C2), dtype=f32, device=dev)
             self.bstat = torch.zeros((rep * (2 * C3 + 2 * C2 + 4 * C1),), dtype=f64, device=dev)
             self.coef = torch.empty((5 * (C3 + C2),), dtype=f32, device=dev)
-            self.partial = torch.empty((self.nsplit * max(C3 * C2, C2 * C1),), dtype=f32, device=dev)
+            self.partial = torch.empty((self.nsplit * (C3 * C2 + C2 * C1),), dtype=f32, device=dev)     # both weight gradients at once
         p = lambda t: None if t is None else t.data_ptr()
         self.c = PnWs(p(self.woff), p(self.ent), p(self.ewin), p(self.tiles), p(self.y2), p(self.y3), p(self.amax),
                       p(self.stat), p(self.bn), p(self.gmax), p(self.dy3), p(self.dz2), p(self.bstat),
@@ -85,11 +85,12 @@ class WorkspacePool:
         if key not in self.side:
             with torch.cuda.device(device):
                 st = torch.cuda.Stream(device=device)
-                evs = [torch.cuda.Event(enable_timing=False) for _ in range(3)]
+                st3 = torch.cuda.Stream(device=device)
+                evs = [torch.cuda.Event(enable_timing=False) for _ in range(4)]
                 for ev in evs:
                     ev.record()
-                arr = (ctypes.c_void_p * 3)(*[ev.cuda_event for ev in evs])
-            self.side[key] = (st, evs, arr)
+                arr = (ctypes.c_void_p * 4)(*[ev.cuda_event for ev in evs])
+            self.side[key] = (st, evs, arr, st3)
         return self.side[key]
 
     def acquire(self, *key, device, need_grad):
@@ -230,16 +231,25 @@ class _PointNetPooled(torch.autograd.Function):
         db = [pick(3 * i + 2, bs[i]) for i in range(3)]
         params = _params_struct(Wc, gs, bs, [None] * 3, [None] * 3, [None] * 3)
         arr = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
+        three = False
         if ctx.pool.side_wgrad:
-            side, _evs, evarr = ctx.pool.side_stream(dev)
+            side, _evs, evarr, side3 = ctx.pool.side_stream(dev)
             s2 = ctypes.c_void_p(side.cuda_stream)
+            # three-way split (conv2's weight gradient on a stream of its own): FCN_PN_SIDE3=0 keeps the two-stream form
+            three = os.environ.get("FCN_PN_SIDE3", "1") != "0" and hasattr(L, "fcn_pn_backward3")
         else:
             s2, evarr = None, None
         with torch.cuda.device(dev):
-            _native.check(L.fcn_pn_backward2(ctypes.byref(desc), ctypes.byref(params), dfeat.data_ptr(),
-                                             ctypes.byref(ws.c), arr(dW), arr(dg), arr(db),
-                                             _native.current_stream(dev), s2, evarr),
-                          "fcn_pn_backward2")
+            if three:
+                _native.check(L.fcn_pn_backward3(ctypes.byref(desc), ctypes.byref(params), dfeat.data_ptr(),
+                                                 ctypes.byref(ws.c), arr(dW), arr(dg), arr(db),
+                                                 _native.current_stream(dev), s2, ctypes.c_void_p(side3.cuda_stream), evarr),
+                              "fcn_pn_backward3")
+            else:
+                _native.check(L.fcn_pn_backward2(ctypes.byref(desc), ctypes.byref(params), dfeat.data_ptr(),
+                                                 ctypes.byref(ws.c), arr(dW), arr(dg), arr(db),
+                                                 _native.current_stream(dev), s2, evarr),
+                              "fcn_pn_backward2")
         ctx.pool.release(ws)
         ctx.ws = None
         ctx.live = False

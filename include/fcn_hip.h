@@ -127,7 +127,7 @@ typedef struct fcn_pn_ws {
     float   *dz2;                /* (B, cap, C2)                                             */
     double  *bstat;              /* fcn_stat_replicas() * (2*C3 + 2*C2 + 4*C1) doubles       */
     float   *coef;               /* 5*(C3+C2) floats                                         */
-    float   *partial;            /* wgrad partials: nsplit * max(C3*C2, C2*C1) floats        */
+    float   *partial;            /* wgrad partials: nsplit * max(C3*C2, C2*C1) floats (fcn_pn_backward3: nsplit * (C3*C2 + C2*C1)) */
     int32_t  nsplit;             /* capacity of `partial` in splits: >= B*ceil(cap/128) (one per row tile) */
     double  *gmom;               /* (B,12) doubles, fcn_pn_group_compact only (may be NULL otherwise): per-frustum input moments +
                                     an arrival counter; zero it, and tiles[0..3], ONCE at allocation (the call leaves
@@ -186,6 +186,13 @@ int fcn_pn_backward(const fcn_pn_desc *d, const fcn_pn_params *p, const float *d
 int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dfeat,
                      const fcn_pn_ws *ws, float *dW[3], float *dgamma[3], float *dbeta[3],
                      void *stream, void *stream2, void *const *events);
+
+/* Three-way split: after the first data-gradient GEMM the chain continues on `stream` (dgrad of conv2, layer-1 finalisation),
+ * conv3's weight gradient runs on stream2 and conv2's on stream3.  ws.partial must hold BOTH weight gradients' partials at once:
+ * nsplit * (C3*C2 + C2*C1) floats.  events = 4 caller-owned hipEvent_t. */
+int fcn_pn_backward3(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dfeat,
+                     const fcn_pn_ws *ws, float *dW[3], float *dgamma[3], float *dbeta[3],
+                     void *stream, void *stream2, void *stream3, void *const *events);
 
 /* Launches ONLY the conv GEMM of `layer` (2 or 3) on the state a previous fcn_pn_compact/fcn_pn_forward left in
  * ws: the unit the roofline figure in bench.py is measured on.  with_stats != 0 keeps the BN-statistics epilogue. */
