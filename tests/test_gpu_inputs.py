@@ -158,6 +158,15 @@ def test_refine_builder_matches_reference_batch():
     out2 = b.build(inputs.refine_records_from_fixture(g), draws=(g["draw_choice"], g["draw_coin"] * 0, g["draw_normal"] * 0),
                    with_labels=False)
     assert "cls_label" not in out2 and out2["center_ref1"].shape == out["center_ref1"].shape
+    #  from_rgb_detection records carry the 2-D detector's score: it travels as 'rgb_prob' (B,1), as
+    # provider_sample_refine.py:228-238 returns it; records without one default to 1 (test_net_det.py:203-205)
+    recs = inputs.refine_records_from_fixture(g)
+    for i, r in enumerate(recs):
+        r["prob"] = 0.25 + 0.1 * i
+    out3 = b.build(recs, draws=(g["draw_choice"], g["draw_coin"] * 0, g["draw_normal"] * 0), with_labels=False)
+    assert np.allclose(out3["rgb_prob"].cpu().numpy().ravel(), [0.25 + 0.1 * i for i in range(len(recs))])
+    assert np.allclose(out2["rgb_prob"].cpu().numpy(), 1.0) and out2["rgb_prob"].shape == (len(recs), 1)
+    assert "rgb_prob" not in out
     # the built batch feeds the model (variable L incl. L4 = 3)
     from frustum_convnet_amd import det_base
     from frustum_convnet_amd.config import cfg

@@ -319,3 +319,18 @@ def test_optimizer_state_interchanges_with_torch_adam():
     bad["state"][0], bad["state"][3] = bad["state"][3], bad["state"][0]
     with pytest.raises(ValueError, match="shape"):
         st2.load_state_dict(bad)
+
+
+def test_refine_builder_refuses_the_non_rtc_geometry():
+    """the refine loader's kernel implements cfg.DATA.RTC = True (every shipped refine cfg); with RTC False the
+    reference builds its windows on the un-rotated predicted box (provider_sample_refine.py:225-262) -- refuse, do not
+    silently produce the other geometry."""
+    import pytest
+    from frustum_convnet_amd import config, inputs
+    cfg = config.reset_cfg()
+    cfg.DATA.RTC = False
+    with pytest.raises(NotImplementedError, match="RTC"):
+        inputs.RefineInputBuilder(512, strides=(0.1, 0.2, 0.4, 0.8))
+    config.reset_cfg()
+    inputs.RefineInputBuilder(512, strides=(0.1, 0.2, 0.4, 0.8))      # the default (RTC True) constructs
+
