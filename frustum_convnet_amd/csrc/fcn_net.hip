@@ -25,6 +25,12 @@
 #ifndef FCN_XF
 #define FCN_XF 0
 #endif
+// FCN_XG: the same for the backward roles -- 1: dz / y loads of a data-gradient tile for a group's first chunk only, 2: weight loads
+// first chunk only, 4: staging first chunk only, 8: no MFMAs, 16: no data-gradient epilogue; 256 / 512 / 1024: the same as 1+2 / 4 /
+// 8 in the weight-gradient role (CGB_NO_WGRAD / CGB_NO_REDUCE / CGB_NO_DGRAD drop whole roles)
+#ifndef FCN_XG
+#define FCN_XG 0
+#endif
 // replicas of the FCN's BatchNorm sum slots (fcn_common.h: same-address fp64 atomics are served one at a time).  Every
 // consumer workgroup of this latency-bound chain sums them in its prologue, so fewer than the PointNet kernels' 8.
 #ifndef FCN_CG_REP
@@ -759,6 +765,7 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
 #define CGK_DGRAD_LOAD_AT(TAP, NBASE)                                                                                 \
     {                                                                                                                 \
         const int tap = (TAP), nb = (NBASE);                                                                          \
+        if (!((FCN_XG & 1) && xg_later))                                                                              \
         _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                              \
             /* the output position source row li meets through tap t: (li + pad - t) / stride when it divides; */   \
             /* stride is 1 or 2 (cn_make_plan rejects anything else): shift / mask instead of a division */          \
@@ -775,12 +782,14 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
                 ry[i] = ldg4((hasbn ? yc : dzc) + o);                                                                 \
             }                                                                                                         \
         }                                                                                                             \
+        if (!((FCN_XG & 2) && xg_later))                                                                              \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {       /* rows 2*pr, 2*pr+1 of one column quad (a k pair) */  \
             const int f = lane + 64 * (i >> 1);                                                                       \
             const int nn = 2 * (f >> 4) + (i & 1), cq = f & 15;                                                       \
             rw[i] = ldg4(L.Wp + (int64_t)(nb + nn) * L.Ktot + segoff + tap * C + c0 + 4 * cq);                        \
         }                                                                                                             \
     }
+    bool xg_later = false;
     // first chunk requested BEFORE the coefficient prologue (it depends on neither the BN-backward sums nor the LDS tables):
     // its memory latency overlaps the prologue's
     {
@@ -799,6 +808,8 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
     for (int it = 0; it < nit; ++it) {
         const int c = it * G + g;
         if (c >= nchunk) break;                 // wave-uniform: no barrier inside the loop
+        xg_later = true;
+        if (!((FCN_XG & 4) && it > 0))
         {
             const int chb = __builtin_amdgcn_readfirstlane(cCh[c]) + 4 * kq;     // BN channel of this thread's first column
 #pragma unroll
@@ -827,9 +838,10 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
         }
         __builtin_amdgcn_wave_barrier();        // (compiler only) the stores above before the operand reads of every lane
         if (c + G < nchunk) CGK_DGRAD_LOAD(c + G);
-        mma_chunk<MM, 1, 2, LDA, LDN, KH>(As, Bs, 0, 0, acc);
+        if (!(FCN_XG & 8)) mma_chunk<MM, 1, 2, LDA, LDN, KH>(As, Bs, 0, 0, acc);
         __builtin_amdgcn_wave_barrier();        // ... and those reads before the next chunk's stores
     }
+    if (FCN_XG & 16) { if (acc[0][0][0] == 123.456f) outp[0] = 0.f; return; }
     // sum of the 8 group accumulators through LDS in two rounds (8 x 32 x 64 floats do not fit): groups 4..7 park theirs,
     // groups 0..3 add them to their own and park the sums for the epilogue pass
     constexpr int GE = G / 2;
@@ -1013,6 +1025,7 @@ __device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float
         const int c = NS * it + st;
         if (c >= nch) break;                    // wave-uniform: no barrier inside the loop
         const int r0 = rbeg + c * KH;
+        if (!((FCN_XG & 512) && it > 0))
         {
             v4f dv2[2];
             {
@@ -1054,8 +1067,8 @@ __device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float
             }
         }
         __builtin_amdgcn_wave_barrier();        // (compiler only) the stores above before the operand reads of every lane
-        if (c + NS < nch) CG_WGRAD_LOAD(r0 + NS * KH);
-        mma_chunk<MM, 1, 2, LDW, LDN, KH>(As, Bs, 0, 0, acc);
+        if (c + NS < nch && !(FCN_XG & 256)) CG_WGRAD_LOAD(r0 + NS * KH);
+        if (!(FCN_XG & 1024)) mma_chunk<MM, 1, 2, LDW, LDN, KH>(As, Bs, 0, 0, acc);
         __builtin_amdgcn_wave_barrier();        // ... and those reads before the next chunk's stores
     }
     // streams 2, 3 park their accumulators, streams 0, 1 add them to their own; stream 1 parks the sum, stream 0 adds it and
