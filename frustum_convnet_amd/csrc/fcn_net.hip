@@ -1222,7 +1222,13 @@ static int conv_len(int L, int k, int s, int p) { return (L + 2 * p - k) / s + 1
 // rows per wgrad split (multiple of 32): ~768 workgroups, >= 256 rows each
 static int pick_wrows(int R, int out_tiles)
 {
-    const int target = 768, minrows = 256;      // swept on MI355X: fewer, fatter splits beat more partial traffic
+#ifndef FCN_WG_TARGET
+#define FCN_WG_TARGET 512      // (768 / 384 / 1024 re-swept in round 3: 1.387 / 1.384 / 1.393 ms per step against 1.380)
+#endif
+#ifndef FCN_WG_MINROWS
+#define FCN_WG_MINROWS 256
+#endif
+    const int target = FCN_WG_TARGET, minrows = FCN_WG_MINROWS;      // swept on MI355X: fewer, fatter splits beat more partial traffic
     int ns = target / (out_tiles > 0 ? out_tiles : 1);
     if (ns > (R + minrows - 1) / minrows) ns = (R + minrows - 1) / minrows;
     if (ns < 1) ns = 1;
