@@ -733,13 +733,13 @@ static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, int precision, hipS
 {
     const bool m2 = (a.COUT % 128 == 0), n2 = (a.CIN % 128 == 0);
     const int oy = a.COUT / (m2 ? 128 : 64), oz = a.CIN / (n2 ? 128 : 64);
-    // 384 workgroup slots per launch (256 for the 128 x 128 tile of layer 2), swept on MI355X over 256 / 384 / 768 / 1536:
+    // FCN_WG_SLOTS workgroup slots per launch (two thirds for the 128 x 128 tile of layer 2), swept on MI355X over 256 / 384 / 768 / 1536:
     // every split writes a full (COUT, CIN) partial that the reduce reads back (at 768 slots 150 MB written + read per
     // step), and fewer, longer splits amortise the per-workgroup prologue -- 768 -> 384 took 14 us off the PointNet backward.
     // Each split takes ceil(live_tiles / nsplit) row tiles (computed on the device, where the live count is known), so
     // splits stay balanced whatever the occupancy of the frustums.
 #ifndef FCN_WG_SLOTS
-#define FCN_WG_SLOTS 384
+#define FCN_WG_SLOTS 256      // (re-swept in round 3 with the replicated sum slots: 384 -> 1.3587, 256 -> 1.3548, 512 -> 1.3630 ms per step)
 #endif
     const int slots = (LAYER == 2 && m2 && n2) ? (FCN_WG_SLOTS * 2) / 3 : FCN_WG_SLOTS;
     if ((int64_t)B * a.cap * (a.COUT > a.CIN ? a.COUT : a.CIN) >= (int64_t)1 << 31) return FCN_E_LIMIT;   // 32-bit offsets
