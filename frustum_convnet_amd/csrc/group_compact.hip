@@ -21,6 +21,7 @@
 // Outputs are identical to fcn_query_depth_point_f32 + fcn_pn_compact (+ bn1_finalize): cnt, woff, ent, ewin, tiles exactly,
 // moments up to fp64 summation order (tests/test_gpu_group_compact.py).
 #include "fcn_common.h"
+#include "pn_pack.h"
 
 #define GC_T 256
 #define GC_WAVES (GC_T / 64)
@@ -46,6 +47,7 @@ struct GcScale {
 
 struct GcArgs {
     GcScale s[GC_MAX_SCALES];
+    PackArgs pk[GC_MAX_SCALES];    // conv2 / conv3 weights of every scale -> ws.wenc (packed by the first launch, on the side)
     const float *pc;           // (B,3,N)
     int B, N, training, use_lds;
     float eps, momentum;
@@ -72,6 +74,14 @@ __global__ __launch_bounds__(GC_T) void gc_hits_kernel(GcArgs a)
     const int b = blockIdx.y;
     const GcScale S = gc_pick(a, (int)blockIdx.z);
     const int L = S.L, K = S.K, N = a.N;
+    {   // this scale's weight images, an item or two per thread spread over all (slice, frustum) workgroups of the scale -- the
+        // stores are not read before fcn_pn_forward's GEMMs, launches later
+        PackArgs P = a.pk[0];
+#pragma unroll
+        for (int q = 1; q < GC_MAX_SCALES; ++q)
+            if ((int)blockIdx.z == q) P = a.pk[q];
+        if (P.wenc) pn_pack_range(P, ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * GC_T + tid, (int)(gridDim.x * gridDim.y) * GC_T);
+    }
     if ((int)blockIdx.x * GC_WPB >= L) return;
     float *zs = (float *)smem;
     const float *pz = a.pc + (int64_t)b * 3 * N + 2 * (int64_t)N;
@@ -314,6 +324,10 @@ extern "C" int fcn_pn_group_compact(int nscale, const fcn_pn_desc *const *d, con
         S.W1 = p[q]->W[0]; S.gamma = p[q]->gamma[0]; S.beta = p[q]->beta[0]; S.rmean = p[q]->running_mean[0];
         S.rvar = p[q]->running_var[0]; S.nbt = p[q]->num_batches_tracked[0];
         S.bn1 = ws[q]->bn + fcn_bn_off(0, D->C1, D->C2);
+        PackArgs &K = a.pk[s];
+        K.W2 = p[q]->W[1]; K.W3 = p[q]->W[2]; K.wenc = (s < nscale) ? ws[q]->wenc : nullptr;
+        K.C1 = D->C1; K.C2 = D->C2; K.C3 = D->C3; K.precision = D->precision;
+        if (!K.W2 || !K.W3 || ((uintptr_t)ws[q]->wenc & 15) || D->precision < 0 || D->precision > FCN_PREC_BF16_OPS) return FCN_E_BADARG;
         if (!D->training && (!S.rmean || !S.rvar)) return FCN_E_BADARG;
         const size_t need = (size_t)(2 * D->L + 1) * sizeof(int) + (size_t)3 * D->L * sizeof(float);
         if (need > lds) lds = need;
@@ -324,8 +338,8 @@ extern "C" int fcn_pn_group_compact(int nscale, const fcn_pn_desc *const *d, con
     a.use_lds = (a.N <= GC_LDS_MAX_PTS) ? 1 : 0;
     if (lds > 64 * 1024) return FCN_E_LIMIT;
     hipStream_t st = (hipStream_t)stream;
-    // split-encoded conv2 / conv3 weights of every scale (read by the GEMMs of fcn_pn_forward / fcn_pn_backward)
-    FCN_TRY(fcn_pn_pack_weights_all(nscale, d, p, ws, stream));
+    // (the split-encoded conv2 / conv3 weights of every scale -- read by the GEMMs of fcn_pn_forward / fcn_pn_backward -- are
+    // packed by gc_hits_kernel on the side)
     hipLaunchKernelGGL(gc_hits_kernel, dim3(maxslice, a.B, nscale), dim3(GC_T), a.use_lds ? (size_t)a.N * sizeof(float) : 0, st, a);
     FCN_CHECK_LAUNCH();
     hipLaunchKernelGGL(gc_entries_kernel, dim3(a.B, nscale), dim3(GE_T), lds, st, a);
