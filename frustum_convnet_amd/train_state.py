@@ -47,6 +47,9 @@ def lr_for_epoch(epoch, base_lr, lr_steps, gamma, min_lr=0.0):
     return max(lr, min_lr) if min_lr > 0 else lr
 
 
+STEP_SPAN = 2048        # elements per workgroup of adam_kernel (ADAM_T * ADAM_V * 4, csrc/optim.hip)
+
+
 class FlatTrainState:
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, world=1, group=None,
                  optimizer="adam", momentum=0.9):
@@ -67,8 +70,14 @@ class FlatTrainState:
                 raise RuntimeError("FlatTrainState: fp32 parameters only")
         # every tensor starts on a 16-byte boundary (float4 access in the kernels, heads adjacency is preserved
         # because the head tensors' sizes are handled as one block below)
-        offs, off = [], 0
-        for n, p in named:
+        # ... and the first tensor after the PointNet scales starts on a multiple of the optimiser kernel's workgroup span
+        # (STEP_SPAN elements): the [pointnet] bucket's workgroups and the [fcn+heads] bucket's then tile the buffer exactly like
+        # the workgroups of ONE launch over the whole buffer, so both forms share their per-workgroup step counters
+        offs, off, cut_at = [], 0, None
+        for k, (n, p) in enumerate(named):
+            if k > 0 and named[k - 1][0].startswith("feat_net.") and not n.startswith("feat_net."):
+                off = (off + STEP_SPAN - 1) // STEP_SPAN * STEP_SPAN
+                cut_at = off
             offs.append(off)
             off += p.numel()
             if not (n in ("cls_out.weight", "cls_out.bias")):
@@ -91,10 +100,7 @@ class FlatTrainState:
         self.world, self.group = int(world), group
         # buckets in the order the backward completes them: everything after the PointNet scales (named feat_net.*,
         # first in the buffer), then the PointNet scales
-        cut = 0
-        for n, o, p in zip(self.names, offs, params):
-            if n.startswith("feat_net."):
-                cut = max(cut, (o + p.numel() + 3) // 4 * 4)
+        cut = cut_at or 0
         self.buckets = [("fcn+heads", cut, total), ("pointnet", 0, cut)] if 0 < cut < total else [("all", 0, total)]
         self._pending = []
         if optimizer == "sgd":          # lr, momentum, weight_decay, grad_scale; the momentum buffer lives in exp_avg
@@ -103,12 +109,12 @@ class FlatTrainState:
         else:
             self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, 1.0 / self.world], device=dev,
                                       dtype=torch.float32)
-        # one step counter per workgroup of the optimiser kernel (all equal); every bucket's launch has its own range of
-        # slots; step_count is slot 0
-        self._slot_off = [0]
-        for _, lo, hi in self.buckets:
-            self._slot_off.append(self._slot_off[-1] + max(int(_native.lib().fcn_adam_step_slots(ctypes.c_int64(hi - lo))), 1))
-        self._step_slots = torch.zeros(self._slot_off[-1], device=dev, dtype=torch.int64)
+        # one step counter per workgroup of the optimiser kernel (all equal), indexed by the workgroup's position in the WHOLE
+        # buffer: a bucket's launch uses the slots from lo / STEP_SPAN on; step_count is slot 0
+        nslots = max(int(_native.lib().fcn_adam_step_slots(ctypes.c_int64(total))), 1)
+        assert all(lo % STEP_SPAN == 0 for _, lo, _ in self.buckets)
+        self._slot_off = [lo // STEP_SPAN for _, lo, _ in self.buckets]
+        self._step_slots = torch.zeros(nslots, device=dev, dtype=torch.int64)
         self.step_count = self._step_slots[0:1]
         self.device = dev
 
@@ -141,6 +147,10 @@ class FlatTrainState:
     def adam_step_bucket(self, i):
         """The optimiser step of bucket i alone (its gradients must be final -- and reduced for world > 1 -- on the current
         stream).  Every bucket must be stepped exactly once per training step, in any order, on any streams."""
+        _, lo, hi = self.buckets[i]
+        self._step_range(lo, hi, self._slot_off[i], i)
+
+    def _step_range(self, lo, hi, slot0, what):
         m = self._model()
         if m is not None and getattr(m, "backward_pending", None) is not None and m.backward_pending():
             raise RuntimeError("FlatTrainState: the model holds a half-finished split backward (forward with split_backward = "
@@ -148,7 +158,6 @@ class FlatTrainState:
         if self.device.type != "cuda":
             raise RuntimeError("frustum_convnet_amd: the optimiser step is a HIP kernel (MI355X only); "
                                "there is no CPU fallback")
-        _, lo, hi = self.buckets[i]
         L = _native.lib()
         off = 4 * lo                                     # bytes; bucket boundaries are 16-byte aligned
         if self.optimizer == "sgd":
@@ -157,21 +166,21 @@ class FlatTrainState:
                                                  self.exp_avg.data_ptr() + off, ctypes.c_int64(hi - lo),
                                                  self.hyper.data_ptr(), _native.current_stream(self.device)),
                               "fcn_sgd_step_f32")
-            if i == 0:
+            if lo == 0:
                 self._step_slots[0:1] += 1          # (bookkeeping only: SGD has no bias correction)
             return
         with torch.cuda.device(self.device):
             _native.check(L.fcn_adam_step_f32(self.flat.data_ptr() + off, self.grad.data_ptr() + off,
                                               self.exp_avg.data_ptr() + off, self.exp_avg_sq.data_ptr() + off,
                                               ctypes.c_int64(hi - lo), self.hyper.data_ptr(),
-                                              self._step_slots.data_ptr() + 8 * self._slot_off[i],
+                                              self._step_slots.data_ptr() + 8 * slot0,
                                               _native.current_stream(self.device)),
                           "fcn_adam_step_f32")
 
     def adam_step(self):
-        """The optimiser step of every bucket on the current stream."""
-        for i in range(len(self.buckets)):
-            self.adam_step_bucket(i)
+        """The optimiser step of every bucket on the current stream: ONE launch over the whole buffer (the buckets exist for
+        the gradient exchange; stepping them separately -- adam_step_bucket -- advances the same counters)."""
+        self._step_range(0, self.numel, 0, "all")
 
     def step(self, zero_grad=False):
         """all-reduce + Adam.  The HIP backward kernels OVERWRITE every gradient they own, so no zero_grad is needed
