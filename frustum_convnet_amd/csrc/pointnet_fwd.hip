@@ -511,9 +511,22 @@ __global__ __launch_bounds__(GT) void pool_kernel(
 // 58 us for 74 MB -- while most waves had finished long before.  The partial (max, arg-max) pairs meet in LDS; ties go to
 // the earlier row, like torch.max.
 typedef float v2f __attribute__((ext_vector_type(2)));
+// BN3 as its consumer sees it: every pooling workgroup derives scale / shift of all C3 channels from the (replicated) batch sums in
+// its prologue -- the one-workgroup bn_finalize launch between conv3 and the pooling is gone from every scale's chain --, and
+// workgroup (0,0,0) publishes scale, shift, mean, rstd for the backward and updates the running statistics.
+struct PoolBn {
+    const double *stat;        // replica 0 of sum[C3], sumsq[C3] (training), or nullptr: running statistics
+    int rep_stride;
+    const float *gamma, *beta;
+    float *rmean, *rvar;
+    int64_t *nbt;
+    float *bn;                 // 4 x C3 published
+    double M;
+    float eps, momentum;
+};
 template <int VEC, int WPW, int S16>
 __global__ __launch_bounds__(GT) void pool_nlc_kernel(
-    const float *__restrict__ y3, const float *__restrict__ bn3, const int32_t *__restrict__ woff,
+    const float *__restrict__ y3, PoolBn q, const int32_t *__restrict__ woff,
     const int32_t *__restrict__ cnt, float *__restrict__ feat, int32_t *__restrict__ amax, int L, int cap, int C3,
     double *__restrict__ zero_ptr, int zero_n)
 {
@@ -521,6 +534,7 @@ __global__ __launch_bounds__(GT) void pool_nlc_kernel(
     constexpr int WIN = PW / WPW;                 // windows per workgroup
     __shared__ float bS[WPW > 1 ? GT * VEC : 1];
     __shared__ int aS[WPW > 1 ? GT * VEC : 1];
+    __shared__ float scS[MAXC], shS[MAXC];
     // the BN-backward sum buffer of this scale is zeroed by the last forward kernel: no memset node heading the backward
     if (zero_ptr && blockIdx.z == 0)
         for (int i = blockIdx.x * GT + threadIdx.x; i < zero_n; i += gridDim.x * GT) zero_ptr[i] = 0.0;
@@ -528,10 +542,39 @@ __global__ __launch_bounds__(GT) void pool_nlc_kernel(
     const int b = blockIdx.z, l = blockIdx.x * WIN + wave / WPW, part = wave % WPW;
     const bool live = l < L;
     const int c = lane * VEC;
+    {
+        const bool pub = blockIdx.x == 0 && blockIdx.z == 0;
+        for (int ch = tid; ch < C3; ch += GT) {
+            double mean, var;
+            if (q.stat) {
+                const double invM = 1.0 / q.M;
+                mean = fcn_rep_sum(q.stat + ch, q.rep_stride) * invM;
+                var = fcn_rep_sum(q.stat + C3 + ch, q.rep_stride) * invM - mean * mean;
+                if (var < 0.0) var = 0.0;
+            } else {
+                mean = q.rmean[ch];
+                var = q.rvar[ch];
+            }
+            const double rstd = fcn_rsqrt64(var + (double)q.eps);
+            const double sc = (double)q.gamma[ch] * rstd;
+            const float fs = (float)sc, ft = (float)((double)q.beta[ch] - mean * sc);
+            scS[ch] = fs;
+            shS[ch] = ft;
+            if (pub) {
+                q.bn[ch] = fs; q.bn[C3 + ch] = ft; q.bn[2 * C3 + ch] = (float)mean; q.bn[3 * C3 + ch] = (float)rstd;
+                if (q.stat && q.rmean) {
+                    q.rmean[ch] = (float)((1.0 - q.momentum) * q.rmean[ch] + q.momentum * mean);
+                    q.rvar[ch] = (float)((1.0 - q.momentum) * q.rvar[ch] + q.momentum * var * (q.M / (q.M - 1.0)));
+                    if (ch == 0 && q.nbt) q.nbt[0] += 1;
+                }
+            }
+        }
+        __syncthreads();
+    }
     float s[VEC], t[VEC], best[VEC];
     int arg[VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) { s[v] = bn3[c + v]; t[v] = bn3[C3 + c + v]; best[v] = 0.f; arg[v] = -1; }
+    for (int v = 0; v < VEC; ++v) { s[v] = scS[c + v]; t[v] = shS[c + v]; best[v] = 0.f; arg[v] = -1; }
     if (live && cnt[(int64_t)b * L + l] > 0) {
         const int32_t *wo = woff + (int64_t)b * (L + 1);
         const int o0 = wo[l], o1 = wo[l + 1];
@@ -668,21 +711,28 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
     a.rmean_in = p->running_mean[1]; a.rvar_in = p->running_var[1]; a.nbt_in = p->num_batches_tracked[1]; a.bn_pub = bn2;
     FCN_TRY(launch_fwd_gemm<1>(a, B, d->precision, st));
 
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C3 + 63) / 64), dim3(64), 0, st, st3, 2 * C2 + 2 * C3, p->gamma[2], p->beta[2],
-                       p->running_mean[2], p->running_var[2], p->num_batches_tracked[2], C3, tr, d->eps,
-                       d->momentum, M, bn3);
-    FCN_CHECK_LAUNCH();
+    const bool nlc_pool = d->nlc && (C3 == 128 || C3 == 256 || C3 == 512);
+    if (!nlc_pool) {        // (the position-major pooling kernels finalise BN3 themselves)
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C3 + 63) / 64), dim3(64), 0, st, st3, 2 * C2 + 2 * C3, p->gamma[2], p->beta[2],
+                           p->running_mean[2], p->running_var[2], p->num_batches_tracked[2], C3, tr, d->eps,
+                           d->momentum, M, bn3);
+        FCN_CHECK_LAUNCH();
+    }
 
     const int nz = FCN_STAT_REP * (2 * C3 + 2 * C2 + 4 * C1);
     const bool s16 = d->precision == FCN_PREC_BF16;       // y2 / y3 stored as bf16 (gemm_tile.h: St)
-    if (d->nlc && (C3 == 128 || C3 == 256 || C3 == 512)) {
+    if (nlc_pool) {
+        PoolBn pb;
+        pb.stat = tr ? st3 : nullptr; pb.rep_stride = 2 * C2 + 2 * C3; pb.gamma = p->gamma[2]; pb.beta = p->beta[2];
+        pb.rmean = p->running_mean[2]; pb.rvar = p->running_var[2]; pb.nbt = p->num_batches_tracked[2]; pb.bn = bn3;
+        pb.M = M; pb.eps = d->eps; pb.momentum = d->momentum;
         int32_t *am = tr ? ws->amax : nullptr;
         double *zp = tr ? ws->bstat : nullptr;
         // waves per window by the window capacity (nsample): 4 from 128 rows up, else 1 (measured: two waves per window at
         // nsample 64 are SLOWER than one -- 83 -> 96 us for the scale -- the exchange costs more than the shorter walk saves)
 #define FCN_POOL_LAUNCH2(VEC_, S16_)                                                                                  \
-        if (K >= 128) hipLaunchKernelGGL((pool_nlc_kernel<VEC_, 4, S16_>), dim3(L, 1, B), dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, feat, am, L, cap, C3, zp, nz); \
-        else hipLaunchKernelGGL((pool_nlc_kernel<VEC_, 1, S16_>), dim3((L + PW - 1) / PW, 1, B), dim3(GT), 0, st, ws->y3, bn3, ws->woff, cnt, feat, am, L, cap, C3, zp, nz);
+        if (K >= 128) hipLaunchKernelGGL((pool_nlc_kernel<VEC_, 4, S16_>), dim3(L, 1, B), dim3(GT), 0, st, ws->y3, pb, ws->woff, cnt, feat, am, L, cap, C3, zp, nz); \
+        else hipLaunchKernelGGL((pool_nlc_kernel<VEC_, 1, S16_>), dim3((L + PW - 1) / PW, 1, B), dim3(GT), 0, st, ws->y3, pb, ws->woff, cnt, feat, am, L, cap, C3, zp, nz);
 #define FCN_POOL_LAUNCH(VEC_) if (s16) { FCN_POOL_LAUNCH2(VEC_, 1) } else { FCN_POOL_LAUNCH2(VEC_, 0) }
         if (C3 == 128) { FCN_POOL_LAUNCH(2) }
         else if (C3 == 256) { FCN_POOL_LAUNCH(4) }
