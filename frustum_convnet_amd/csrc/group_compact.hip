@@ -25,7 +25,9 @@
 
 #define GC_T 256
 #define GC_WAVES (GC_T / 64)
+#ifndef GC_WPB
 #define GC_WPB 16                  // windows per workgroup in phase A (4 per wave)
+#endif
 #define GC_MAX_SCALES 8
 #define GC_LDS_MAX_PTS 8192        // z row staged in LDS up to this many points
 #define GC_MOM 12                  // doubles per frustum in gmom: 10 moment sums (+ 2 spare)
