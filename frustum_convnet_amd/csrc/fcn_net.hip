@@ -579,31 +579,59 @@ struct CgPackAll {
     int mmf;                            // operand mode of the forward GEMMs (MM_*)
 };
 
-template <int MM>
-__device__ __forceinline__ void cg_pack_image_item(const CgPack &p, const float *__restrict__ src, int nrow_real, int64_t m,
-                                                   u32x4 *__restrict__ img)
+// One thread = 8 reduction-adjacent elements (kk0 .. kk0 + 7, kk0 % 8 == 0) of one packed row n: they lie in ONE (segment, tap)
+// run of the torch weight (segment widths are multiples of 8), so ONE index computation + a constant source stride serves all
+// eight; the thread writes them to the packed fp32 matrix (the backward's operand) AND as one item of the forward image.
+// (Round 2 computed the torch index per ELEMENT with 64-bit divisions: 47 us on the side stream beside the CU-bound PointNet
+// forward.)
+__device__ __forceinline__ void cg_pack_src8(const CgPack &p, const float *__restrict__ src, int nrow_real, int n, int kk0,
+                                              float (&x)[8])
 {
-    const int n = (int)(m % p.N), r = (int)(m / p.N), kb = r & 3, c = r >> 2;
-    float x[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        x[j] = 0.f;
-        if (n < nrow_real) {
-            const int64_t o = cg_torch_index(p, n, c * KC + 8 * kb + j);
-            if (o >= 0) x[j] = src[o];
-        }
+    for (int j = 0; j < 8; ++j) x[j] = 0.f;
+    if (n >= nrow_real) return;
+    if (p.deconv_k > 0) {               // row n = j*Cout + co, kk = ci  ->  W[ci][co][j]: source stride Cout * k per kk
+        const int jj = n / p.cout_t, co = n % p.cout_t;
+        const int64_t o0 = ((int64_t)kk0 * p.cout_t + co) * p.deconv_k + jj, st = (int64_t)p.cout_t * p.deconv_k;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = src[o0 + j * st];
+        return;
     }
-    u32x4 hi, lo;
-    enc8<MM>(x, hi, lo);
-    img[((int64_t)c * 8 + kb) * p.N + n] = hi;
-    img[((int64_t)c * 8 + 4 + kb) * p.N + n] = lo;
+    int sg = 0, kk = kk0;
+#pragma unroll
+    for (int s = 0; s < CG_NSEG; ++s)
+        if (s < p.nseg && sg == s && kk >= p.KT * p.C[s]) { kk -= p.KT * p.C[s]; sg = s + 1; }
+    const int C = SEL4(sg, p.C[0], p.C[1], p.C[2], p.C[3]), choff = SEL4(sg, p.choff[0], p.choff[1], p.choff[2], p.choff[3]);
+    const int ty = SEL4(sg, p.type[0], p.type[1], p.type[2], p.type[3]);
+    const int tap = kk / C, k0 = kk % C;
+    const int64_t o0 = ((int64_t)n * p.cin_tot + choff + k0) * p.KT + tap;      // + KT per channel
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (ty != 1 || k0 + j < p.nvec) x[j] = src[o0 + (int64_t)j * p.KT];        // (padding columns of the virtual one-hot segment)
+}
+
+template <int MM>
+__device__ __forceinline__ void cg_pack_store8(const CgPack &p, int n, int kk0, const float (&x)[8], float *__restrict__ dst,
+                                                u32x4 *__restrict__ img)
+{
+    const v4f a = {x[0], x[1], x[2], x[3]}, b = {x[4], x[5], x[6], x[7]};
+    sts4(dst + (int64_t)n * p.Ktot + kk0, a);
+    sts4(dst + (int64_t)n * p.Ktot + kk0 + 4, b);
+    if (img) {
+        const int c = kk0 >> 5, kb = (kk0 >> 3) & 3;
+        u32x4 hi, lo;
+        enc8<MM>(x, hi, lo);
+        img[((int64_t)c * 8 + kb) * p.N + n] = hi;
+        img[((int64_t)c * 8 + 4 + kb) * p.N + n] = lo;
+    }
 }
 
 __global__ void cg_pack_kernel(CgPackAll t)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= t.pre[CN_NLAYER]) {
-        int64_t j = i - t.pre[CN_NLAYER];
+    const int64_t ngrp = t.pre[CN_NLAYER] / 8;
+    if (i >= ngrp) {
+        int64_t j = i - ngrp;
         if (j < (int64_t)t.B * OH_PAD) {
             const int b = (int)(j / OH_PAD), v = (int)(j % OH_PAD);
             t.oh64[j] = (v < t.nvec) ? t.oh[(int64_t)b * t.nvec + v] : 0.f;
@@ -613,35 +641,23 @@ __global__ void cg_pack_kernel(CgPackAll t)
         if (j < t.nz) {
             if (t.z0) t.z0[j] = 0.0;
             if (t.z1) t.z1[j] = 0.0;
-            return;
-        }
-        j -= t.nz;
-        if (j < t.pre[CN_NLAYER] / 8 && t.enc) {        // one (chunk, k-block, column) item of a forward image
-            int l = 0;
-#pragma unroll
-            for (int q = 1; q < CN_NLAYER; ++q)
-                if (8 * j >= t.pre[q]) l = q;
-            const int64_t m = j - t.pre[l] / 8;
-            u32x4 *img = (u32x4 *)(t.enc + t.pre[l]);
-            if (t.mmf == MM_F32) cg_pack_image_item<MM_F32>(t.p[l], t.src[l], t.nrow_real[l], m, img);
-            else if (t.mmf == MM_F16X3) cg_pack_image_item<MM_F16X3>(t.p[l], t.src[l], t.nrow_real[l], m, img);
-            else if (t.mmf == MM_BF16X3) cg_pack_image_item<MM_BF16X3>(t.p[l], t.src[l], t.nrow_real[l], m, img);
-            else cg_pack_image_item<MM_BF16X1>(t.p[l], t.src[l], t.nrow_real[l], m, img);
         }
         return;
     }
     int l = 0;
 #pragma unroll
     for (int q = 1; q < CN_NLAYER; ++q)
-        if (i >= t.pre[q]) l = q;
-    const int64_t e = i - t.pre[l];
-    const int n = (int)(e / t.p[l].Ktot), kk = (int)(e % t.p[l].Ktot);
-    float v = 0.f;
-    if (n < t.nrow_real[l]) {
-        const int64_t o = cg_torch_index(t.p[l], n, kk);
-        if (o >= 0) v = t.src[l][o];
-    }
-    t.dst[l][e] = v;
+        if (8 * i >= t.pre[q]) l = q;
+    const int m = (int)(i - t.pre[l] / 8);                  // group index inside the layer (N * Ktot / 8 < 2^31)
+    const int gpr = t.p[l].Ktot >> 3;                       // groups per packed row
+    const int n = m / gpr, kk0 = (m - n * gpr) << 3;
+    float x[8];
+    cg_pack_src8(t.p[l], t.src[l], t.nrow_real[l], n, kk0, x);
+    u32x4 *img = t.enc ? (u32x4 *)(t.enc + t.pre[l]) : nullptr;
+    if (t.mmf == MM_F32) cg_pack_store8<MM_F32>(t.p[l], n, kk0, x, t.dst[l], img);
+    else if (t.mmf == MM_F16X3) cg_pack_store8<MM_F16X3>(t.p[l], n, kk0, x, t.dst[l], img);
+    else if (t.mmf == MM_BF16X3) cg_pack_store8<MM_BF16X3>(t.p[l], n, kk0, x, t.dst[l], img);
+    else cg_pack_store8<MM_BF16X1>(t.p[l], n, kk0, x, t.dst[l], img);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1400,7 +1416,7 @@ static int cn_pack(const fcn_cn_desc *d, const fcn_cn_params *p, const CnPlan &P
     t.enc = ws->wp + O.wp[P.nl];            // second half of the weight arena (fcn_convnet_sizes)
     t.mmf = FCN_MM_OF(d->precision, true);
     hipLaunchKernelGGL(cg_pack_kernel,
-                       dim3((unsigned)((t.pre[CN_NLAYER] + (int64_t)d->B * OH_PAD + t.nz + t.pre[CN_NLAYER] / 8 + 255) / 256)),
+                       dim3((unsigned)((t.pre[CN_NLAYER] / 8 + (int64_t)d->B * OH_PAD + t.nz + 255) / 256)),
                        dim3(256), 0, st, t);
     FCN_CHECK_LAUNCH();
     return 0;
