@@ -60,6 +60,27 @@ __device__ __forceinline__ double fcn_rep_sum(const double *p, int stride)
 }
 __device__ __forceinline__ int fcn_rep_id() { return (int)(blockIdx.x % FCN_STAT_REP); }
 
+// Max-pool keys (pooling folded into conv3's epilogue, pointnet_fwd.hip).  BatchNorm + ReLU is monotone in the conv output y
+// with the sign of gamma (rstd > 0), so the row that wins max_r relu(bn(y_r)) is the row with the largest sgn(gamma) * y_r, known
+// before the batch statistics are: a 64-bit key orders (value, then EARLIER row) under an unsigned max.  0 = "no row".
+//   high word: the fp32 bits of sgn(gamma) * y mapped to an order-preserving unsigned; low word: ~row.
+__device__ __forceinline__ float fcn_pool_orient(float v, float gamma) { return gamma > 0.f ? v : (gamma < 0.f ? -v : 0.f); }
+__device__ __forceinline__ unsigned long long fcn_pool_key(float oriented, int row)
+{
+    const unsigned b = __float_as_uint(oriented);
+    const unsigned o = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return ((unsigned long long)o << 32) | (unsigned long long)(0xffffffffu - (unsigned)row);
+}
+// -> y of the winning row (as conv3 stored it) and the row, from the key's two words (kept as 32-bit values: ROCm 7.2's
+// instruction selection crashes on the 64-bit shift / compare form of this function)
+__device__ __forceinline__ float fcn_pool_key_value(unsigned hi, unsigned lo, float gamma, int &row)
+{
+    const unsigned b = (hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi;
+    row = (int)(0xffffffffu - lo);
+    const float s = __uint_as_float(b);
+    return gamma < 0.f ? -s : s;
+}
+
 // Coefficients of a BatchNorm backward, derived by every CONSUMER workgroup from the batch sums (a few fp64 products per
 // channel) instead of by a one-workgroup launch between two layers of a latency-bound chain:
 //   dy = c0 * (dz - (c3 + xhat * c4)),  xhat = (y - c1) * c2

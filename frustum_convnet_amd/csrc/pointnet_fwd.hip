@@ -157,6 +157,9 @@ extern "C" int fcn_pn_pack_weights_all(int nscale, const fcn_pn_desc *const *d, 
 }
 
 // ------------------------------------------------------------------------------------------------
+#ifndef FCN_POOL_FUSED
+#define FCN_POOL_FUSED 1     // 0 (tuning builds): conv3 writes y3 only and pool_nlc_kernel re-reads it
+#endif
 struct FwdArgs {
     const float4 *ent;     // (B,cap) rows (ux,uy,uz,w)
     const int32_t *woff;   // (B,L+1)
@@ -181,6 +184,11 @@ struct FwdArgs {
     float *bn_pub;              // 4 x CIN
     double M;
     float eps, momentum;
+    // POOL (conv3 with the max-pool folded into its epilogue): window of each row, the keys (B, L, COUT) -- zero between
+    // launches --, gamma of the BN behind this conv (its sign orients the max)
+    const int32_t *ewin;
+    unsigned long long *pkey;
+    const float *gamma_out;
 };
 
 __device__ __forceinline__ void fwd_bn_in(const FwdArgs &a, int i, bool pub, float &fs, float &ft)
@@ -215,7 +223,13 @@ __device__ __forceinline__ void fwd_bn_in(const FwdArgs &a, int i, bool pub, flo
 // staged A tile between 256 output columns, halving the BN+ReLU staging work per output element.
 // MT = 1: 64-row tiles, two workgroups per listed 128-row tile (scale 4's conv3: 1140 big tiles are 1.5 waves of the 768
 // resident slots -- two rounds; 2280 half tiles on 1024 slots are 2.2 half rounds).
-template <int MM, int MODE, int NT, int WN, int MT = 2>
+//
+// POOL = 1: the window max of relu(bn(y)) is taken HERE, over the accumulators, as (value, row) keys (fcn_pool_key): lanes own
+// columns and walk their rows in order, a segment per window; the segments of a workgroup meet in an LDS table [window slot]
+// [column] (ds_max_u64), and the table leaves as one 8-byte store per (window, column) when the window lies inside the tile, one
+// device-scope atomic max when it continues in a neighbouring tile (two windows per tile at most).  pool_keys_kernel turns the
+// keys into features once the batch statistics are complete -- the pooling pass that re-read all of y3 is gone.
+template <int MM, int MODE, int NT, int WN, int MT = 2, int POOL = 0>
 __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 1 ? 4 : 3, 4))) void fwd_gemm_kernel(FwdArgs a)
 {
     constexpr int NTHR = 128 * WN;
@@ -232,6 +246,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
     __shared__ __attribute__((aligned(16))) float tS[MAXC];
     __shared__ __attribute__((aligned(16))) float sS[MODE == 0 ? 3 * MAXC : MAXC];   // MODE 0: alpha[CIN][3]
     __shared__ float wS[TM];
+    __shared__ int winS[POOL ? TM : 1];
     u32x4 *Ab = lds4, *Bb = lds4 + KbTile<TM>::U4;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -302,6 +317,9 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
         }
     }
     if (tid < TM) wS[tid] = (tid < nvalid) ? a.ent[grow0 + tid].w : 0.f;
+    if constexpr (POOL) {
+        if (tid < TM) winS[tid] = (tid < nvalid) ? a.ewin[grow0 + tid] : -1;
+    }
     float ux = 0.f, uy = 0.f, uz = 0.f;
     const int r0 = tid % TM;
     const bool r0valid = r0 < nvalid;
@@ -362,6 +380,8 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
     // ---- epilogue: y out as 16-byte stores through the wave's transposition patch, per-channel weighted statistics
     if (FCN_X & 16) { if (acc[0][0][0] == 123.456f) a.y[0] = 0.f; return; }
     bool bad = false;
+    // (eval mode with the pooling in this epilogue: nothing reads y afterwards -- the keys carry the pooled values)
+    const bool store_y = !POOL || a.stat != nullptr;
 #if FCN_FWD_EPI_DIRECT      // (tuning builds: one dword per lane straight from the accumulator layout -- the round-2 epilogue)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -373,7 +393,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
                 const int col = n0 + wn * 32 * NT + nt * 32 + l31;
                 const float v = acc[mt][nt][reg];
                 if constexpr (MM == MM_F16X3) bad |= !(fabsf(v) < 3.0e38f);
-                if (row < nvalid) sts1e<MM>(a.y, (grow0 + row) * COUT + col, v);
+                if (row < nvalid && store_y) sts1e<MM>(a.y, (grow0 + row) * COUT + col, v);
             }
 #else
     float *patch = (float *)lds4 + wave * EP_FLOATS;          // (the operand buffers are free after the last barrier)
@@ -389,7 +409,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
                 const int idx = lane + 64 * q, row = rbase + (idx >> 3);
                 const v4f v = ep_get(patch, lane, q);
                 if constexpr (MM == MM_F16X3) bad |= !(fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w) < 3.0e38f);
-                if (row < nvalid && !(FCN_X & 32)) sts4e<MM>(a.y, (grow0 + row) * COUT + cbase + 4 * (idx & 7), v);
+                if (row < nvalid && store_y && !(FCN_X & 32)) sts4e<MM>(a.y, (grow0 + row) * COUT + cbase + 4 * (idx & 7), v);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -398,6 +418,60 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
         // fp16 operand parts overflow at |x| >= 65504 (inf - inf = NaN in the products, which a later ReLU would turn into a
         // silent zero): a non-finite output raises the sticky flag of the workspace
         if (a.flags && __ballot(bad) != 0ull && lane == 0) atomicOr(a.flags, FCN_FLAG_NONFINITE);
+    }
+    if constexpr (POOL) {
+        constexpr int NSLOT = LDSU4 * 2 / TN;                 // window slots of the LDS table (windows past it: direct atomics)
+        unsigned long long *tab = (unsigned long long *)lds4;
+        unsigned long long *pk = a.pkey + (int64_t)b * a.L * COUT + n0;
+        __syncthreads();                                      // every wave is done with its patch (the table aliases them)
+        for (int i = tid; i < NSLOT * TN / 2; i += NTHR) lds4[i] = u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();
+        const int win0 = winS[0];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = wn * 32 * NT + nt * 32 + l31;
+            const float g = a.gamma_out[n0 + col];
+            // a lane's segment = its rows of one window: (oriented value, row) of the best so far, a strict > keeps the earlier row;
+            // the 64-bit key is only built when the segment ends
+            int cur = -1, brow = 0;
+            float bval = 0.f;
+            auto flush = [&]() __attribute__((always_inline)) {
+                if (cur < 0) return;
+                const int slot = cur - win0;
+                const unsigned long long best = fcn_pool_key(bval, row0 + brow);
+                // (different scopes also keep the compiler from merging the two into one FLAT atomic on a selected address)
+                if (slot < NSLOT) __hip_atomic_fetch_max(&tab[slot * TN + col], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else __hip_atomic_fetch_max(&pk[(int64_t)cur * COUT + col], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {          // (rows ascend with mt, reg: windows are runs of rows)
+                    const int row = wm * 32 * MT + mt * 32 + acc_row(reg, lh);
+                    const int w = winS[row];
+                    const float v = fcn_pool_orient(st_round<MM>(acc[mt][nt][reg]), g);
+                    if (w != cur) {
+                        flush();
+                        cur = w;
+                        bval = v;
+                        brow = row;
+                    } else if (v > bval) {
+                        bval = v;
+                        brow = row;
+                    }
+                }
+            flush();
+        }
+        __syncthreads();
+        const int ns = min(winS[nvalid - 1] - win0 + 1, NSLOT);
+        const int32_t *wo = a.woff + (int64_t)b * (a.L + 1);
+        for (int i = tid; i < ns * TN; i += NTHR) {
+            const int l = win0 + i / TN, col = i % TN;
+            const unsigned long long key = tab[i];
+            // a window inside this tile has no rows anywhere else: plain store (the keys are zero between launches)
+            if (wo[l] >= row0 && wo[l + 1] <= row0 + nvalid) pk[(int64_t)l * COUT + col] = key;
+            else __hip_atomic_fetch_max(&pk[(int64_t)l * COUT + col], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (a.stat) {
         __syncthreads();                                      // every wave is done with its patch (red aliases them)
@@ -640,21 +714,86 @@ __global__ __launch_bounds__(GT) void pool_nlc_kernel(
     }
 }
 
+// Pooling from the keys conv3's epilogue left (fwd_gemm_kernel, POOL): feat (B, L, C3) = relu(bn3(y of the winning row)), amax =
+// that row (-1: nothing positive, no gradient), and the keys go back to zero for the next launch.  A thread owns two adjacent
+// channels (16-byte key loads) and derives their BN3 scale / shift itself from the batch sums; the threads of workgroup (0, 0)
+// that sit on the first window publish scale, shift, mean, rstd and update the running statistics.  WPB windows per workgroup.
+__global__ __launch_bounds__(GT) void pool_keys_kernel(unsigned long long *__restrict__ pkey, PoolBn q,
+                                                       const int32_t *__restrict__ cnt, float *__restrict__ feat,
+                                                       int32_t *__restrict__ amax, int L, int C3, int WPB,
+                                                       double *__restrict__ zero_ptr, int zero_n)
+{
+    if (zero_ptr && blockIdx.y == 0)
+        for (int i = blockIdx.x * GT + threadIdx.x; i < zero_n; i += gridDim.x * GT) zero_ptr[i] = 0.0;
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int c = (2 * tid) % C3, sub = (2 * tid) / C3, nsub = 2 * GT / C3;       // C3 <= 2 * GT
+    float g[2], s[2], t[2];
+    const bool pub = blockIdx.x == 0 && blockIdx.y == 0 && sub == 0;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int ch = c + e;
+        double mean, var;
+        if (q.stat) {
+            const double invM = 1.0 / q.M;
+            mean = fcn_rep_sum(q.stat + ch, q.rep_stride) * invM;
+            var = fcn_rep_sum(q.stat + C3 + ch, q.rep_stride) * invM - mean * mean;
+            if (var < 0.0) var = 0.0;
+        } else {
+            mean = q.rmean[ch];
+            var = q.rvar[ch];
+        }
+        const double rstd = fcn_rsqrt64(var + (double)q.eps);
+        g[e] = q.gamma[ch];
+        const double sc = (double)g[e] * rstd;
+        s[e] = (float)sc;
+        t[e] = (float)((double)q.beta[ch] - mean * sc);
+        if (pub) {
+            q.bn[ch] = s[e]; q.bn[C3 + ch] = t[e]; q.bn[2 * C3 + ch] = (float)mean; q.bn[3 * C3 + ch] = (float)rstd;
+            if (q.stat && q.rmean) {
+                q.rmean[ch] = (float)((1.0 - q.momentum) * q.rmean[ch] + q.momentum * mean);
+                q.rvar[ch] = (float)((1.0 - q.momentum) * q.rvar[ch] + q.momentum * var * (q.M / (q.M - 1.0)));
+                if (ch == 0 && q.nbt) q.nbt[0] += 1;
+            }
+        }
+    }
+    const int l_end = min(L, ((int)blockIdx.x + 1) * WPB);
+    for (int l = blockIdx.x * WPB + sub; l < l_end; l += nsub) {
+        const int64_t o = ((int64_t)b * L + l) * C3 + c;
+        const u32x4 kk = *(const u32x4 *)(pkey + o);               // (two keys as one 16-byte access)
+        *(u32x4 *)(pkey + o) = u32x4{0u, 0u, 0u, 0u};
+        const unsigned hi[2] = {kk.y, kk.w}, lo[2] = {kk.x, kk.z};
+        const bool live = cnt[(int64_t)b * L + l] > 0;           // (an empty window holds one stand-in row: no feature, no gradient)
+        float fo[2];
+        int ao[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            int row;
+            const float y = fcn_pool_key_value(hi[e], lo[e], g[e], row);
+            const float u = fmaf(s[e], y, t[e]);
+            const bool pos = live && (hi[e] | lo[e]) != 0u && u > 0.f;
+            fo[e] = pos ? u : 0.f;
+            ao[e] = pos ? row : -1;
+        }
+        *(v2f *)(feat + o) = v2f{fo[0], fo[1]};
+        if (amax) { amax[o] = ao[0]; amax[o + 1] = ao[1]; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 static inline unsigned pad8(unsigned n) { return (n + 7u) / 8u * 8u; }
 
-template <int MM, int MODE>
+template <int MM, int MODE, int POOL>
 static int launch_fwd_gemm_mm(const FwdArgs &a, int B, hipStream_t st)
 {
     const unsigned nt = (unsigned)(B * a.tps);
     if (FCN_WIDE_TILES && a.COUT % 256 == 0) {
-        hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 2, 4>), dim3(pad8(nt * (a.COUT / 256))), dim3(512), 0, st, a);
+        hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 2, 4, 2, POOL>), dim3(pad8(nt * (a.COUT / 256))), dim3(512), 0, st, a);
     } else if (!FCN_C3_BIG && MODE == 1 && a.COUT >= 512 && a.COUT % 128 == 0) {      // the widest conv3: 64 x 128 tiles
-        hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 2, 2, 1>), dim3(pad8(2 * nt * (a.COUT / 128))), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 2, 2, 1, POOL>), dim3(pad8(2 * nt * (a.COUT / 128))), dim3(256), 0, st, a);
     } else if (a.COUT % 128 == 0) {
-        hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 2, 2>), dim3(pad8(nt * (a.COUT / 128))), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 2, 2, 2, POOL>), dim3(pad8(nt * (a.COUT / 128))), dim3(256), 0, st, a);
     } else {
-        hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 1, 2>), dim3(pad8(nt * (a.COUT / 64))), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((fwd_gemm_kernel<MM, MODE, 1, 2, 2, POOL>), dim3(pad8(nt * (a.COUT / 64))), dim3(256), 0, st, a);
     }
     FCN_CHECK_LAUNCH();
     return 0;
@@ -666,7 +805,14 @@ static int launch_fwd_gemm(const FwdArgs &a, int B, int precision, hipStream_t s
     if (a.CIN % 64 || a.COUT % 64 || a.CIN > MAXC) return FCN_E_BADARG;
     if ((int64_t)B * a.cap * (a.CIN > a.COUT ? a.CIN : a.COUT) >= (int64_t)1 << 31) return FCN_E_LIMIT;      // 32-bit offsets
     if (precision < 0 || precision > FCN_PREC_BF16_OPS) return FCN_E_BADARG;
-    FCN_MM_SWITCH(FCN_MM_OF(precision, true), return (launch_fwd_gemm_mm<MM, MODE>(a, B, st)));
+    if constexpr (MODE == 1) {
+        if (a.pkey) {
+            if (!a.ewin || !a.gamma_out) return FCN_E_BADARG;
+            FCN_MM_SWITCH(FCN_MM_OF(precision, true), return (launch_fwd_gemm_mm<MM, MODE, 1>(a, B, st)));
+            return FCN_E_BADARG;
+        }
+    }
+    FCN_MM_SWITCH(FCN_MM_OF(precision, true), return (launch_fwd_gemm_mm<MM, MODE, 0>(a, B, st)));
     return FCN_E_BADARG;
 }
 
@@ -702,6 +848,7 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
     a.stat = tr ? st2 : nullptr; a.CIN = C1; a.COUT = C2;
     a.stat_in = nullptr; a.gamma_in = a.beta_in = nullptr; a.rmean_in = a.rvar_in = nullptr; a.nbt_in = nullptr; a.bn_pub = nullptr;
     a.M = M; a.eps = d->eps; a.momentum = d->momentum; a.rep_stride = 2 * C2 + 2 * C3;
+    a.ewin = nullptr; a.pkey = nullptr; a.gamma_out = nullptr;
     FCN_TRY(launch_fwd_gemm<0>(a, B, d->precision, st));
 
     // BN2 is finalised by conv3's workgroups (no launch in between)
@@ -709,10 +856,13 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
     a.stat = tr ? st3 : nullptr; a.CIN = C2; a.COUT = C3;
     a.stat_in = tr ? st2 : nullptr; a.gamma_in = p->gamma[1]; a.beta_in = p->beta[1];
     a.rmean_in = p->running_mean[1]; a.rvar_in = p->running_var[1]; a.nbt_in = p->num_batches_tracked[1]; a.bn_pub = bn2;
+    // position-major features + a key buffer in the workspace: the max-pool rides in conv3's epilogue (pool_keys_kernel finishes it)
+    const bool key_pool = FCN_POOL_FUSED && d->nlc && ws->pkey && ws->ewin && C3 % 2 == 0 && C3 <= 2 * GT && (2 * GT) % C3 == 0;
+    if (key_pool) { a.ewin = ws->ewin; a.pkey = (unsigned long long *)ws->pkey; a.gamma_out = p->gamma[2]; }
     FCN_TRY(launch_fwd_gemm<1>(a, B, d->precision, st));
 
     const bool nlc_pool = d->nlc && (C3 == 128 || C3 == 256 || C3 == 512);
-    if (!nlc_pool) {        // (the position-major pooling kernels finalise BN3 themselves)
+    if (!nlc_pool && !key_pool) {        // (the position-major pooling kernels finalise BN3 themselves)
         hipLaunchKernelGGL(bn_finalize_kernel, dim3((C3 + 63) / 64), dim3(64), 0, st, st3, 2 * C2 + 2 * C3, p->gamma[2], p->beta[2],
                            p->running_mean[2], p->running_var[2], p->num_batches_tracked[2], C3, tr, d->eps,
                            d->momentum, M, bn3);
@@ -721,7 +871,17 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
 
     const int nz = FCN_STAT_REP * (2 * C3 + 2 * C2 + 4 * C1);
     const bool s16 = d->precision == FCN_PREC_BF16;       // y2 / y3 stored as bf16 (gemm_tile.h: St)
-    if (nlc_pool) {
+    if (key_pool) {
+        PoolBn pb;
+        pb.stat = tr ? st3 : nullptr; pb.rep_stride = 2 * C2 + 2 * C3; pb.gamma = p->gamma[2]; pb.beta = p->beta[2];
+        pb.rmean = p->running_mean[2]; pb.rvar = p->running_var[2]; pb.nbt = p->num_batches_tracked[2]; pb.bn = bn3;
+        pb.M = M; pb.eps = d->eps; pb.momentum = d->momentum;
+        const int nsub = 2 * GT / C3;                       // windows a workgroup covers at once
+        int wpb = nsub;
+        while ((int64_t)B * ((L + wpb - 1) / wpb) > 1024 && wpb < 8 * nsub) wpb += nsub;       // ~ two workgroups per CU at least
+        hipLaunchKernelGGL(pool_keys_kernel, dim3((L + wpb - 1) / wpb, B), dim3(GT), 0, st, (unsigned long long *)ws->pkey, pb, cnt,
+                           feat, tr ? ws->amax : nullptr, L, C3, wpb, tr ? ws->bstat : nullptr, nz);
+    } else if (nlc_pool) {
         PoolBn pb;
         pb.stat = tr ? st3 : nullptr; pb.rep_stride = 2 * C2 + 2 * C3; pb.gamma = p->gamma[2]; pb.beta = p->beta[2];
         pb.rmean = p->running_mean[2]; pb.rvar = p->running_var[2]; pb.nbt = p->num_batches_tracked[2]; pb.bn = bn3;
@@ -768,6 +928,7 @@ extern "C" int fcn_pn_conv_fwd(const fcn_pn_desc *d, const fcn_pn_params *p, con
     a.M = 1.0; a.eps = d->eps; a.momentum = d->momentum;       // the BN in front is read finished from ws->bn
     a.rep_stride = 2 * C2 + 2 * C3;
     a.flags = ws->flags;
+    a.ewin = nullptr; a.pkey = nullptr; a.gamma_out = nullptr;
     if (layer == 2) {
         a.aprev = nullptr; a.bn_in = ws->bn + fcn_bn_off(0, C1, C2); a.W1 = p->W[0]; a.Wenc = (const u32x4 *)(ws->wenc + pn_wenc_off(0, C1, C2, C3)); a.y = ws->y2;
         a.stat = with_stats ? st2 : nullptr; a.CIN = C1; a.COUT = C2;

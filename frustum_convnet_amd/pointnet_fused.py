@@ -39,6 +39,8 @@ class Workspace:
         self.cnt = torch.empty((B, L), dtype=i32, device=dev)           # window hit counts of the fused grouping
         self.wenc = torch.empty((2 * (C2 * C1 + C3 * C2),), dtype=f32, device=dev)      # split-encoded conv2 / conv3 weights
         self.flags = flags if flags is not None else torch.zeros((1,), dtype=i32, device=dev)      # sticky FCN_FLAG_* bits
+        # max-pool keys of conv3's epilogue, zero between launches (FCN_POOL_KEYS=0: no key buffer -- the pooling pass re-reads y3)
+        self.pkey = torch.zeros((B, L, C3), dtype=torch.int64, device=dev) if os.environ.get("FCN_POOL_KEYS", "1") != "0" else None
         self.amax = self.gmax = self.dy3 = self.dz2 = self.bstat = self.coef = self.partial = None
         self.nsplit = 0
         if need_grad:
@@ -53,7 +55,7 @@ class Workspace:
         p = lambda t: None if t is None else t.data_ptr()
         self.c = PnWs(p(self.woff), p(self.ent), p(self.ewin), p(self.tiles), p(self.y2), p(self.y3), p(self.amax),
                       p(self.stat), p(self.bn), p(self.gmax), p(self.dy3), p(self.dz2), p(self.bstat),
-                      p(self.coef), p(self.partial), self.nsplit, p(self.gmom), p(self.wenc), p(self.flags))
+                      p(self.coef), p(self.partial), self.nsplit, p(self.gmom), p(self.wenc), p(self.flags), p(self.pkey))
 
 
     @staticmethod

@@ -136,6 +136,9 @@ typedef struct fcn_pn_ws {
                                     operand order (forward + data-gradient images), rewritten by every forward
                                     (fcn_pn_pack_weights[_all]) and read by the forward and backward GEMMs                    */
     int32_t *flags;              /* 1 int32 of sticky FCN_FLAG_* bits, or NULL: zero it once, read it whenever convenient    */
+    uint64_t *pkey;              /* (B, L, C3) max-pool keys, 16-byte aligned, or NULL: zero it ONCE at allocation (fcn_pn_forward
+                                    leaves it zero).  With it (and nlc = 1) the max-pool is taken in conv3's epilogue instead of
+                                    by a pass that re-reads y3 (and in eval mode y3 is not written at all)                     */
 } fcn_pn_ws;
 
 /* Sticky numeric flags (fcn_pn_ws.flags, fcn_cn_ws.flags): the kernels only ever OR bits in.

@@ -407,6 +407,16 @@ inline unsigned atomicAdd(unsigned *p, unsigned v) { return emu_fetch_add(p, v);
 inline int atomicAdd(int *p, int v) { return emu_fetch_add(p, v); }
 inline float atomicAdd(float *p, float v) { return emu_fetch_add(p, v); }
 inline int atomicOr(int *p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v)
+{
+    unsigned long long o = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+    while (o < v && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+    return o;
+}
+#define __hip_atomic_fetch_max(p, v, order, scope) atomicMax((p), (v))
+#define __HIP_MEMORY_SCOPE_WORKGROUP 1
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 inline unsigned long long wall_clock64() { return 0ull; }
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 template <class T>

@@ -19,3 +19,62 @@ def test_stages(case):
 def test_uniform_variant_full_windows():
     res = gsc.run_stages(2, 512, 2.0, 8, (64, 64, 128), 2.0, variant="uniform")
     assert not gsc.check(res)
+
+
+# (the last case: ~100 one- and two-row windows per 128-row tile -- more than the epilogue's LDS table has window slots)
+@pytest.mark.parametrize("case", gsc.CASES[1:] + [(2, 128, 0.25, 16, (64, 64, 128), 0.3)],
+                         ids=lambda c: "B%d_N%d_s%s_K%d_C%d" % (c[0], c[1], c[2], c[3], c[4][2]))
+@pytest.mark.parametrize("training", [True, False], ids=["train", "eval"])
+def test_key_pool_matches_row_pool(case, training):
+    """The max-pool taken in conv3's epilogue (keys + pool_keys_kernel) against the pooling pass over the stored y3: features
+    bit for bit; the arg-max rows too, except where two rows of a window reach the same relu(bn(y)) (a rounding tie -- either
+    row is 'the first maximum' of a different but equally valid evaluation order; the value at both must agree exactly).
+    One gamma of conv3's BatchNorm is negative and one is zero: the keys orient the maximum by the sign of gamma."""
+    import os
+    from frustum_convnet_amd import pointnet_fused as pf
+    from frustum_convnet_amd.precision import CODES
+
+    B, N, stride, K, mlp, dist = case
+    dev = torch.device("cuda:0")
+    pc, ref, sd, one_hot = gsc.make_case(B, N, stride, K, mlp, dist)
+    sd["m.conv3.1.weight"][1] = -0.7
+    sd["m.conv3.1.weight"][2] = 0.0
+    out = {}
+    for keys in ("1", "0"):
+        os.environ["FCN_POOL_KEYS"] = keys
+        sdg = {k: v.clone().to(dev) for k, v in sd.items()}
+        plist = []
+        for j in (1, 2, 3):
+            plist += [sdg["m.conv%d.0.weight" % j], sdg["m.conv%d.1.weight" % j], sdg["m.conv%d.1.bias" % j]]
+        bufs = ([sdg["m.conv%d.1.running_mean" % j] for j in (1, 2, 3)], [sdg["m.conv%d.1.running_var" % j] for j in (1, 2, 3)],
+                [sdg["m.conv%d.1.num_batches_tracked" % j] for j in (1, 2, 3)])
+        pool = pf.WorkspacePool()
+        cfgt = (float(dist), int(K), training, 1e-5, 0.1, True, True)          # (.., need_grad, nlc)
+        for rep in range(2):                # twice on the same workspace: the keys are back at zero after a forward
+            feat, idx, cnt, ws, desc, keep = pf._forward_impl(pool, cfgt, pc.to(dev), ref.to(dev), None, bufs, plist, True)
+            if rep == 0:
+                pool.release(ws)
+        assert (ws.pkey is not None) == (keys == "1")
+        if ws.pkey is not None:
+            assert int((ws.pkey != 0).sum()) == 0
+        y3 = pf.Workspace.stored(ws.y3, CODES["split"]).detach().cpu().clone()
+        for b in range(B):                  # (rows past a frustum's live entries are never written)
+            y3[b, int(ws.woff[b, -1]):] = 0
+        out[keys] = (feat.detach().cpu(), ws.amax.detach().cpu(), ws.bn.detach().cpu(), y3, bufs[0][2].detach().cpu())
+    del os.environ["FCN_POOL_KEYS"]
+    fk, ak, bnk, y3k, rmk = out["1"]
+    fr, ar, bnr, y3r, rmr = out["0"]
+    assert torch.equal(bnk, bnr) and torch.equal(rmk, rmr)
+    assert not training or torch.equal(y3k, y3r)          # (eval mode with keys: y3 is not written at all)
+    assert torch.equal(fk, fr)
+    if not training:                    # (no arg-max in eval mode)
+        return
+    assert torch.equal(ak < 0, ar < 0)
+    diff = (ak != ar).nonzero()
+    C3 = mlp[2]
+    s, t = bnk[4 * (mlp[0] + mlp[1]):][:C3], bnk[4 * (mlp[0] + mlp[1]):][C3:2 * C3]
+    for b, l, c in diff.tolist():
+        zk = torch.relu(torch.addcmul(t[c], s[c], y3k[b, ak[b, l, c], c]))
+        zr = torch.relu(torch.addcmul(t[c], s[c], y3k[b, ar[b, l, c], c]))
+        assert float(zk) == float(zr), (b, l, c, float(zk), float(zr))
+    assert len(diff) <= max(4, ak.numel() // 10000), len(diff)
