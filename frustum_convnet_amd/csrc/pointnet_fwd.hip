@@ -246,7 +246,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
     __shared__ __attribute__((aligned(16))) float tS[MAXC];
     __shared__ __attribute__((aligned(16))) float sS[MODE == 0 ? 3 * MAXC : MAXC];   // MODE 0: alpha[CIN][3]
     __shared__ float wS[TM];
-    __shared__ int winS[POOL ? TM : 1];
+    __shared__ int winS[POOL ? TM : 1], insS[POOL ? 64 : 1];
     u32x4 *Ab = lds4, *Bb = lds4 + KbTile<TM>::U4;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -317,8 +317,18 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
         }
     }
     if (tid < TM) wS[tid] = (tid < nvalid) ? a.ent[grow0 + tid].w : 0.f;
+    // POOL: window of each row, and -- kept in registers until the epilogue -- whether that window lies inside this tile (its
+    // row range from woff: two dependent loads that have the whole K loop to arrive)
+    int pw = -1, plo = 0, phi = 0;
     if constexpr (POOL) {
-        if (tid < TM) winS[tid] = (tid < nvalid) ? a.ewin[grow0 + tid] : -1;
+        if (tid < TM) {
+            if (tid < nvalid) {
+                pw = a.ewin[grow0 + tid];
+                plo = a.woff[(int64_t)b * (a.L + 1) + pw];
+                phi = a.woff[(int64_t)b * (a.L + 1) + pw + 1];
+            }
+            winS[tid] = pw;
+        }
     }
     float ux = 0.f, uy = 0.f, uz = 0.f;
     const int r0 = tid % TM;
@@ -333,9 +343,8 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
     acc_zero<MT, NT>(acc);
     const int nchunk = CIN / KC;
 
-    for (int c = 0; c < nchunk; ++c) {
-        // ---- registers -> LDS (kb-major images), applying the input BN + ReLU
-        if ((FCN_X & 4) && c > 0) goto staged;
+    // ---- registers -> LDS (kb-major images of chunk c at Aq / Bq), applying the input BN + ReLU
+    auto stage_chunk = [&](int c, u32x4 *Aq, u32x4 *Bq) __attribute__((always_inline)) {
         if constexpr (MODE == 1) {
 #pragma unroll
             for (int i = 0; i < NA4; ++i) {
@@ -345,7 +354,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
                 const v4f s4 = *(const v4f *)(sS + c * KC + 4 * kq), t4 = *(const v4f *)(tS + c * KC + 4 * kq);
                 const float z0 = ok ? fmaxf(fmaf(s4.x, ra[i].x, t4.x), 0.f) : 0.f, z1 = ok ? fmaxf(fmaf(s4.y, ra[i].y, t4.y), 0.f) : 0.f;
                 const float z2 = ok ? fmaxf(fmaf(s4.z, ra[i].z, t4.z), 0.f) : 0.f, z3 = ok ? fmaxf(fmaf(s4.w, ra[i].w, t4.w), 0.f) : 0.f;
-                kb_store4<MM_ENC_A, LDRA>(Ab, r, kq, z0, z1, z2, z3);
+                kb_store4<MM_ENC_A, LDRA>(Aq, r, kq, z0, z1, z2, z3);
             }
         } else {
             const int part = tid / TM;
@@ -361,16 +370,19 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
                 }
                 u32x4 hi, lo;
                 enc8<MM_ENC_A>(z, hi, lo);
-                Ab[kb * LDRA + r0] = hi;
-                Ab[(4 + kb) * LDRA + r0] = lo;
+                Aq[kb * LDRA + r0] = hi;
+                Aq[(4 + kb) * LDRA + r0] = lo;
             }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int f = tid + NTHR * i;
-            Bb[(f / TN) * LDRB + (f % TN)] = rw[i];       // (plane, k-block) row f / TN of the image
+            Bq[(f / TN) * LDRB + (f % TN)] = rw[i];       // (plane, k-block) row f / TN of the image
         }
-    staged:
+    };
+
+    for (int c = 0; c < nchunk; ++c) {
+        if (!((FCN_X & 4) && c > 0)) stage_chunk(c, Ab, Bb);
         __syncthreads();
         if (c + 1 < nchunk) load_chunk(c + 1);
         if (!(FCN_X & 8)) mma_chunk_kb<MM, MT, NT, LDRA, LDRB>(Ab, Bb, wm * 32 * MT, wn * 32 * NT, acc);
@@ -420,28 +432,33 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
         if (a.flags && __ballot(bad) != 0ull && lane == 0) atomicOr(a.flags, FCN_FLAG_NONFINITE);
     }
     if constexpr (POOL) {
-        constexpr int NSLOT = LDSU4 * 2 / TN;                 // window slots of the LDS table (windows past it: direct atomics)
+        constexpr int NSLOT = (LDSU4 * 2 / TN) < 64 ? (LDSU4 * 2 / TN) : 64;      // window slots of the LDS table (windows past it: direct atomics)
         unsigned long long *tab = (unsigned long long *)lds4;
         unsigned long long *pk = a.pkey + (int64_t)b * a.L * COUT + n0;
-        __syncthreads();                                      // every wave is done with its patch (the table aliases them)
-        for (int i = tid; i < NSLOT * TN / 2; i += NTHR) lds4[i] = u32x4{0u, 0u, 0u, 0u};
-        __syncthreads();
         const int win0 = winS[0];
+        const int ns = min(winS[nvalid - 1] - win0 + 1, NSLOT);
+        __syncthreads();                                      // every wave is done with its patch (the table aliases them)
+        for (int i = tid; i < ns * TN / 2; i += NTHR) lds4[i] = u32x4{0u, 0u, 0u, 0u};
+        if (pw >= 0 && pw - win0 < NSLOT) insS[pw - win0] = (plo >= row0 && phi <= row0 + nvalid) ? 1 : 0;
+        __syncthreads();
+        {
+            // a lane's segment = its rows of one window, all NT columns of the lane at once: (oriented value, row) of the best so
+            // far, a strict > keeps the earlier row; the 64-bit keys are only built when the segment ends
+            float g[NT], bval[NT];
+            int brow[NT], cur = -1;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int col = wn * 32 * NT + nt * 32 + l31;
-            const float g = a.gamma_out[n0 + col];
-            // a lane's segment = its rows of one window: (oriented value, row) of the best so far, a strict > keeps the earlier row;
-            // the 64-bit key is only built when the segment ends
-            int cur = -1, brow = 0;
-            float bval = 0.f;
+            for (int nt = 0; nt < NT; ++nt) { g[nt] = a.gamma_out[n0 + wn * 32 * NT + nt * 32 + l31]; bval[nt] = 0.f; brow[nt] = 0; }
             auto flush = [&]() __attribute__((always_inline)) {
                 if (cur < 0) return;
                 const int slot = cur - win0;
-                const unsigned long long best = fcn_pool_key(bval, row0 + brow);
-                // (different scopes also keep the compiler from merging the two into one FLAT atomic on a selected address)
-                if (slot < NSLOT) __hip_atomic_fetch_max(&tab[slot * TN + col], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                else __hip_atomic_fetch_max(&pk[(int64_t)cur * COUT + col], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int col = wn * 32 * NT + nt * 32 + l31;
+                    const unsigned long long best = fcn_pool_key(bval[nt], row0 + brow[nt]);
+                    // (different scopes also keep the compiler from merging the two into one FLAT atomic on a selected address)
+                    if (slot < NSLOT) __hip_atomic_fetch_max(&tab[slot * TN + col], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else __hip_atomic_fetch_max(&pk[(int64_t)cur * COUT + col], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             };
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -449,28 +466,30 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
                 for (int reg = 0; reg < 16; ++reg) {          // (rows ascend with mt, reg: windows are runs of rows)
                     const int row = wm * 32 * MT + mt * 32 + acc_row(reg, lh);
                     const int w = winS[row];
-                    const float v = fcn_pool_orient(st_round<MM>(acc[mt][nt][reg]), g);
-                    if (w != cur) {
+                    const bool fresh = w != cur;
+                    if (fresh) {
                         flush();
                         cur = w;
-                        bval = v;
-                        brow = row;
-                    } else if (v > bval) {
-                        bval = v;
-                        brow = row;
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float v = fcn_pool_orient(st_round<MM>(acc[mt][nt][reg]), g[nt]);
+                        if (fresh || v > bval[nt]) {
+                            bval[nt] = v;
+                            brow[nt] = row;
+                        }
                     }
                 }
             flush();
         }
         __syncthreads();
-        const int ns = min(winS[nvalid - 1] - win0 + 1, NSLOT);
-        const int32_t *wo = a.woff + (int64_t)b * (a.L + 1);
         for (int i = tid; i < ns * TN; i += NTHR) {
-            const int l = win0 + i / TN, col = i % TN;
+            const int slot = i / TN, col = i % TN;
             const unsigned long long key = tab[i];
+            unsigned long long *dst = &pk[(int64_t)(win0 + slot) * COUT + col];
             // a window inside this tile has no rows anywhere else: plain store (the keys are zero between launches)
-            if (wo[l] >= row0 && wo[l + 1] <= row0 + nvalid) pk[(int64_t)l * COUT + col] = key;
-            else __hip_atomic_fetch_max(&pk[(int64_t)l * COUT + col], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (insS[slot]) *dst = key;
+            else __hip_atomic_fetch_max(dst, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (a.stat) {
@@ -729,30 +748,43 @@ __global__ __launch_bounds__(GT) void pool_keys_kernel(unsigned long long *__res
     const int c = (2 * tid) % C3, sub = (2 * tid) / C3, nsub = 2 * GT / C3;       // C3 <= 2 * GT
     float g[2], s[2], t[2];
     const bool pub = blockIdx.x == 0 && blockIdx.y == 0 && sub == 0;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int ch = c + e;
-        double mean, var;
+    {
+        // the two channels' sums as 16-byte loads, every replica requested before the first is used (one memory round trip)
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        d2 mean, var;
         if (q.stat) {
+            d2 s1[FCN_STAT_REP], s2[FCN_STAT_REP];
+#pragma unroll
+            for (int r = 0; r < FCN_STAT_REP; ++r) {
+                s1[r] = *(const d2 *)(q.stat + (int64_t)r * q.rep_stride + c);
+                s2[r] = *(const d2 *)(q.stat + (int64_t)r * q.rep_stride + C3 + c);
+            }
+            d2 a1 = s1[0], a2 = s2[0];
+#pragma unroll
+            for (int r = 1; r < FCN_STAT_REP; ++r) { a1 += s1[r]; a2 += s2[r]; }       // replica order, like fcn_rep_sum
             const double invM = 1.0 / q.M;
-            mean = fcn_rep_sum(q.stat + ch, q.rep_stride) * invM;
-            var = fcn_rep_sum(q.stat + C3 + ch, q.rep_stride) * invM - mean * mean;
-            if (var < 0.0) var = 0.0;
+            mean = a1 * invM;
+            var = a2 * invM - mean * mean;
         } else {
-            mean = q.rmean[ch];
-            var = q.rvar[ch];
+            mean = d2{(double)q.rmean[c], (double)q.rmean[c + 1]};
+            var = d2{(double)q.rvar[c], (double)q.rvar[c + 1]};
         }
-        const double rstd = fcn_rsqrt64(var + (double)q.eps);
-        g[e] = q.gamma[ch];
-        const double sc = (double)g[e] * rstd;
-        s[e] = (float)sc;
-        t[e] = (float)((double)q.beta[ch] - mean * sc);
-        if (pub) {
-            q.bn[ch] = s[e]; q.bn[C3 + ch] = t[e]; q.bn[2 * C3 + ch] = (float)mean; q.bn[3 * C3 + ch] = (float)rstd;
-            if (q.stat && q.rmean) {
-                q.rmean[ch] = (float)((1.0 - q.momentum) * q.rmean[ch] + q.momentum * mean);
-                q.rvar[ch] = (float)((1.0 - q.momentum) * q.rvar[ch] + q.momentum * var * (q.M / (q.M - 1.0)));
-                if (ch == 0 && q.nbt) q.nbt[0] += 1;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int ch = c + e;
+            const double mu = mean[e], vr = var[e] < 0.0 ? 0.0 : var[e];
+            const double rstd = fcn_rsqrt64(vr + (double)q.eps);
+            g[e] = q.gamma[ch];
+            const double sc = (double)g[e] * rstd;
+            s[e] = (float)sc;
+            t[e] = (float)((double)q.beta[ch] - mu * sc);
+            if (pub) {
+                q.bn[ch] = s[e]; q.bn[C3 + ch] = t[e]; q.bn[2 * C3 + ch] = (float)mu; q.bn[3 * C3 + ch] = (float)rstd;
+                if (q.stat && q.rmean) {
+                    q.rmean[ch] = (float)((1.0 - q.momentum) * q.rmean[ch] + q.momentum * mu);
+                    q.rvar[ch] = (float)((1.0 - q.momentum) * q.rvar[ch] + q.momentum * vr * (q.M / (q.M - 1.0)));
+                    if (ch == 0 && q.nbt) q.nbt[0] += 1;
+                }
             }
         }
     }

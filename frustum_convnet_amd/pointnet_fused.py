@@ -39,8 +39,12 @@ class Workspace:
         self.cnt = torch.empty((B, L), dtype=i32, device=dev)           # window hit counts of the fused grouping
         self.wenc = torch.empty((2 * (C2 * C1 + C3 * C2),), dtype=f32, device=dev)      # split-encoded conv2 / conv3 weights
         self.flags = flags if flags is not None else torch.zeros((1,), dtype=i32, device=dev)      # sticky FCN_FLAG_* bits
-        # max-pool keys of conv3's epilogue, zero between launches (FCN_POOL_KEYS=0: no key buffer -- the pooling pass re-reads y3)
-        self.pkey = torch.zeros((B, L, C3), dtype=torch.int64, device=dev) if os.environ.get("FCN_POOL_KEYS", "1") != "0" else None
+        # max-pool keys of conv3's epilogue (fcn_pn_ws.pkey, zero between launches).  Measured on one MI355X:
+        # +6 % for the eval-mode forward (y3 is neither written nor re-read), but -0.5...-1.5 % for the training step -- so by
+        # default only workspaces that no backward will read get the key buffer; FCN_POOL_KEYS=1 / 0 forces it on / off.
+        mode = os.environ.get("FCN_POOL_KEYS")
+        use_keys = mode == "1" or (mode not in ("0", "1") and not need_grad)
+        self.pkey = torch.zeros((B, L, C3), dtype=torch.int64, device=dev) if use_keys else None
         self.amax = self.gmax = self.dy3 = self.dz2 = self.bstat = self.coef = self.partial = None
         self.nsplit = 0
         if need_grad:
