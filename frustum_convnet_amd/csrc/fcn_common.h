@@ -58,6 +58,16 @@ __device__ __forceinline__ double fcn_rep_sum(const double *p, int stride)
     for (int r = 1; r < FCN_STAT_REP; ++r) v += p[(int64_t)r * stride];
     return v;
 }
+// Consumer-side BatchNorm finalisation reads 2 x REP sums per channel in every workgroup's prologue.  The forward GEMM requests them
+// FIRST -- ahead of the dependent round trips of the tile lookup, with a compiler fence (FCN_LOAD_FENCE) that keeps them there --
+// so their latency runs beside that chain instead of after it: tools/pn_probe.py fwd measured the prologue at 22-40 % of a conv3
+// workgroup's cycles before and 9-15 % after (workgroup cycles -17...-27 %; forward of a scale alone -2.4 us; the whole step: within
+// noise).  The same move in the data-gradient GEMMs (up to 76 loads per thread in front of the lookup) measured 1.5 % SLOWER over
+// the step and is not in the tree.  FCN_EARLY_STATS=0 (tuning builds) keeps the loads at the point of use.
+#ifndef FCN_EARLY_STATS
+#define FCN_EARLY_STATS 1
+#endif
+#define FCN_LOAD_FENCE() asm volatile("" ::: "memory")
 __device__ __forceinline__ int fcn_rep_id() { return (int)(blockIdx.x % FCN_STAT_REP); }
 
 // Max-pool keys (pooling folded into conv3's epilogue, pointnet_fwd.hip).  BatchNorm + ReLU is monotone in the conv output y

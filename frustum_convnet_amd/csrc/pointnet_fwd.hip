@@ -157,6 +157,41 @@ extern "C" int fcn_pn_pack_weights_all(int nscale, const fcn_pn_desc *const *d, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Intra-kernel cycle accounting of the forward GEMM for TUNING BUILDS ONLY (-DFCN_PROBE, tools/pn_probe.py fwd; never compiled
+// into the product): wave 0 of every workgroup sums the shader-clock cycles it spends in each phase of the K loop.
+#ifdef FCN_PROBE
+#define PNF_MAX 32768
+__device__ unsigned long long g_pnf_probe[PNF_MAX * 8];
+__device__ unsigned int g_pnf_probe_n;
+#define PNF_DECL unsigned long long pa_[6] = {0, 0, 0, 0, 0, 0}; unsigned long long pt_ = clock64(), pt0_ = pt_
+#define PNF_ADD(i) do { const unsigned long long n_ = clock64(); pa_[i] += n_ - pt_; pt_ = n_; } while (0)
+#define PNF_FLUSH(tag)                                                                                   \
+    do {                                                                                                 \
+        if (threadIdx.x == 0) {                                                                          \
+            const unsigned int s_ = atomicAdd(&g_pnf_probe_n, 1u);                                       \
+            if (s_ < PNF_MAX) {                                                                          \
+                g_pnf_probe[s_ * 8] = (unsigned long long)(tag);                                         \
+                g_pnf_probe[s_ * 8 + 1] = clock64() - pt0_;                                              \
+                for (int q_ = 0; q_ < 6; ++q_) g_pnf_probe[s_ * 8 + 2 + q_] = pa_[q_];                   \
+            }                                                                                            \
+        }                                                                                                \
+    } while (0)
+extern "C" int fcn_pn_probe_read_fwd(unsigned long long *host_out, int max_records, int reset)
+{
+    unsigned int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_pnf_probe_n), sizeof(n)) != hipSuccess) return -1;
+    if ((int)n > max_records) n = max_records;
+    if (n > PNF_MAX) n = PNF_MAX;
+    if (n && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pnf_probe), (size_t)n * 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned int z = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_pnf_probe_n), &z, sizeof(z)); }
+    return (int)n;
+}
+#else
+#define PNF_DECL
+#define PNF_ADD(i)
+#define PNF_FLUSH(tag)
+#endif
+
 #ifndef FCN_POOL_FUSED
 #define FCN_POOL_FUSED 1     // 0 (tuning builds): conv3 writes y3 only and pool_nlc_kernel re-reads it
 #endif
@@ -191,14 +226,20 @@ struct FwdArgs {
     const float *gamma_out;
 };
 
-__device__ __forceinline__ void fwd_bn_in(const FwdArgs &a, int i, bool pub, float &fs, float &ft)
+// (s1, s2: the channel's batch sums when the caller fetched them already -- `have` --, else they are read here)
+__device__ __forceinline__ void fwd_bn_in(const FwdArgs &a, int i, bool pub, float &fs, float &ft, bool have = false, double s1 = 0.0,
+                                          double s2 = 0.0)
 {
     const int C = a.CIN;
     double mean, var;
     if (a.stat_in) {
         const double invM = 1.0 / a.M;
-        mean = fcn_rep_sum(a.stat_in + i, a.rep_stride) * invM;
-        var = fcn_rep_sum(a.stat_in + C + i, a.rep_stride) * invM - mean * mean;
+        if (!have) {
+            s1 = fcn_rep_sum(a.stat_in + i, a.rep_stride);
+            s2 = fcn_rep_sum(a.stat_in + C + i, a.rep_stride);
+        }
+        mean = s1 * invM;
+        var = s2 * invM - mean * mean;
         if (var < 0.0) var = 0.0;
     } else {
         mean = a.rmean_in[i];
@@ -263,6 +304,21 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
             }
         }
     }
+    // MODE 1, training: the batch sums of this thread's input channel are requested FIRST -- 2 x FCN_STAT_REP loads whose latency
+    // then runs beside the three dependent round trips of the tile lookup below instead of after them (tools/pn_probe.py fwd: the
+    // prologue was 22 % of a conv3 workgroup's cycles on the widest scale and 40 % on the narrow ones)
+    double q1[FCN_STAT_REP], q2[FCN_STAT_REP];
+    const bool early = FCN_EARLY_STATS && MODE == 1 && a.gamma_in && a.stat_in && tid < a.CIN;
+    if constexpr (MODE == 1) {
+        if (early) {
+#pragma unroll
+            for (int r = 0; r < FCN_STAT_REP; ++r) {
+                q1[r] = a.stat_in[(int64_t)r * a.rep_stride + tid];
+                q2[r] = a.stat_in[(int64_t)r * a.rep_stride + a.CIN + tid];
+            }
+        }
+        FCN_LOAD_FENCE();         // (without it the loads are sunk below the early returns of the tile lookup, to where their values are used)
+    }
     const int xt = fcn_xcd_tile(blockIdx.x, SUB * a.tiles[0] * ny);
     if (xt < 0) return;
     const int bxi = xt / ny, byi = xt % ny;
@@ -277,6 +333,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
     const int n0 = byi * TN;
     const int CIN = a.CIN, COUT = a.COUT;
 
+    PNF_DECL;
     u32x4 rw[NB];
     v4f ra[MODE == 1 ? NA4 : 1];
     const u32x4 *wsrc = a.Wenc + n0 + (tid % TN) + (int64_t)(tid / TN) * COUT;      // item f = tid + NTHR*i: column f % TN, (plane, k-block) f / TN
@@ -302,7 +359,14 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
     for (int i = tid; i < CIN; i += NTHR) {
         float s, t;
         if (MODE == 1 && a.gamma_in) {
-            fwd_bn_in(a, i, false, s, t);
+            if (early && i == tid) {
+                double s1 = q1[0], s2 = q2[0];
+#pragma unroll
+                for (int r = 1; r < FCN_STAT_REP; ++r) { s1 += q1[r]; s2 += q2[r]; }      // replica order, like fcn_rep_sum
+                fwd_bn_in(a, i, false, s, t, true, s1, s2);
+            } else {
+                fwd_bn_in(a, i, false, s, t);
+            }
         } else {
             s = a.bn_in[i];
             t = a.bn_in[CIN + i];
@@ -381,12 +445,18 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
         }
     };
 
+    PNF_ADD(0);                                   // 0: prologue (BN of the input, row weights, first loads issued)
     for (int c = 0; c < nchunk; ++c) {
         if (!((FCN_X & 4) && c > 0)) stage_chunk(c, Ab, Bb);
+        PNF_ADD(2);                               // 2: wait for the loads + operand transform + LDS stores
         __syncthreads();
+        PNF_ADD(3);                               // 3: barriers
         if (c + 1 < nchunk) load_chunk(c + 1);
+        PNF_ADD(1);                               // 1: issue of the global loads
         if (!(FCN_X & 8)) mma_chunk_kb<MM, MT, NT, LDRA, LDRB>(Ab, Bb, wm * 32 * MT, wn * 32 * NT, acc);
+        PNF_ADD(4);                               // 4: LDS operand reads + MFMAs
         __syncthreads();
+        PNF_ADD(3);
     }
 
     // ---- epilogue: y out as 16-byte stores through the wave's transposition patch, per-channel weighted statistics
@@ -426,6 +496,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
             __builtin_amdgcn_wave_barrier();
         }
 #endif
+    PNF_ADD(5);                                   // 5: y stores (the rest up to the total: pooling keys, statistics)
     if constexpr (MM == MM_F16X3) {
         // fp16 operand parts overflow at |x| >= 65504 (inf - inf = NaN in the products, which a later ReLU would turn into a
         // silent zero): a non-finite output raises the sticky flag of the workspace
@@ -531,6 +602,8 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
             }
         }
     }
+    PNF_FLUSH(((unsigned long long)(MODE + 2) << 48) | ((unsigned long long)CIN << 32) | ((unsigned long long)COUT << 16) |
+              (unsigned long long)nvalid);
 }
 
 // ------------------------------------------------------------------------------------------------

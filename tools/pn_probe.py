@@ -11,7 +11,8 @@ import torch
 import bench
 from frustum_convnet_amd import _native
 
-cfg = sys.argv[1] if len(sys.argv) > 1 else "car"
+fwd = "fwd" in sys.argv[1:]            # python tools/pn_probe.py [cfg] fwd: the forward GEMMs (conv2 / conv3) instead
+cfg = ([a for a in sys.argv[1:] if a != "fwd"] + ["car"])[0]
 serial = os.environ.get("FCN_SERIAL", "0") == "1"
 dev = torch.device("cuda", 0)
 model = bench.build_model(dev, cfg)
@@ -20,6 +21,28 @@ L = _native.lib()
 L.fcn_pn_probe_read.restype = ctypes.c_int
 L.fcn_pn_probe_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
 buf = np.zeros((32768, 8), dtype=np.uint64)
+if fwd:
+    L.fcn_pn_probe_read_fwd.restype = ctypes.c_int
+    L.fcn_pn_probe_read_fwd.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    for it in range(3):
+        L.fcn_pn_probe_read_fwd(buf.ctypes.data, 32768, 1)
+        losses, _ = model(data)
+        torch.cuda.synchronize()
+        n = L.fcn_pn_probe_read_fwd(buf.ctypes.data, 32768, 1)
+    rec = buf[:n].astype(np.int64)
+    print("records", n, "(forward GEMMs, scales %s)" % ("serialised" if serial else "concurrent"))
+    names = ["prologue", "load issue", "wait+transform+lds st", "barriers", "lds rd + mfma", "y stores"]
+    tags = rec[:, 0] >> 16
+    for t in sorted(set(tags)):
+        r = rec[tags == t]
+        full = r[(r[:, 0] & 0xffff) >= 64]                     # full tiles (64 or 128 rows)
+        tot = full[:, 1].astype(np.float64)
+        ph = full[:, 2:8].astype(np.float64)
+        print("conv%d K=%4d N=%4d  wg %5d (full %5d)  cycles/wg %8.0f (max %8.0f) = %.1f us @2.4GHz | " % (
+            t >> 32, (t >> 16) & 0xffff, t & 0xffff, len(r), len(full), tot.mean(), tot.max(), tot.mean() / 2400.0) +
+              "  ".join("%s %4.1f%%" % (nm, 100 * ph[:, i].mean() / tot.mean()) for i, nm in enumerate(names)) +
+              "  rest %4.1f%%" % (100 * (1 - ph.sum(1).mean() / tot.mean())))
+    sys.exit(0)
 for it in range(3):
     losses, _ = model(data)
     torch.cuda.synchronize()
