@@ -445,6 +445,45 @@ def workload_name(cfg_name, batch, npoint, Ls, optim=True, extra=""):
 OTHER_CONFIGS = (("people", "split"), ("refine", "split"), ("sunrgbd", "split"), ("car", "bf16"), ("car", "bf16ops"))
 
 
+def measure_inference(cfg_name, batch, dev, min_time=0.35, prec="split"):
+    """Eval-mode forward through decode (no labels, no grad) of one configuration, captured into a hipGraph and replayed: the
+    inference path of train/test_net_det.py:140-190.  -> dict(value frustums/s, ms_per_forward, ...)."""
+    from frustum_convnet_amd import precision as fprec
+    fprec.set_precision(prec)
+    model = build_model(dev, cfg_name).eval()
+    data = make_data(cfg_name, batch, CFGS[cfg_name][3], 1234, dev)
+    data = {k: v for k, v in data.items() if k in ("point_cloud", "one_hot", "rot_angle", "ref_center", "rgb_prob") or k.startswith("center_ref")}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        for _ in range(3):
+            model(data)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(g):
+        model(data)
+    for _ in range(20):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        g.replay()
+    torch.cuda.synchronize()
+    n = max(50, int(np.ceil(min_time / ((time.perf_counter() - t0) / 50))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        g.replay()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    return {"cfg": cfg_name, "precision": prec, "mode": "inference", "dtype": "bf16" if prec.startswith("bf16") else "f32",
+            "workload": "%s KITTI-%s, batch=%d/GPU, Npoint=%d, L=(%s), eval forward + decode (no labels)" % (
+                CFGS[cfg_name][0], cfg_name, batch, CFGS[cfg_name][3],
+                ",".join(str(data["center_ref%d" % i].shape[2]) for i in range(1, 6) if ("center_ref%d" % i) in data)),
+            "value": round(batch * n / wall, 2), "unit": "frustums/s", "ms_per_step": round(wall * 1e3 / n, 4),
+            "timed_steps": n, "timed_seconds": round(wall, 4)}
+
+
 def other_configs(a, dev, min_time=0.35):
     out = []
     for cfg_name, prec in OTHER_CONFIGS:
@@ -460,6 +499,12 @@ def other_configs(a, dev, min_time=0.35):
             out.append({"cfg": cfg_name, "precision": prec, "error": "%s: %s" % (type(e).__name__, e)})
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
+    try:
+        out.append(measure_inference("car", a.batch, dev, min_time))
+    except Exception as e:  # noqa
+        out.append({"cfg": "car", "mode": "inference", "error": "%s: %s" % (type(e).__name__, e)})
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
     return out
 
 

@@ -114,6 +114,40 @@ def test_eval_outputs_are_independent_of_the_rest_of_the_batch():
 
 
 @pytest.mark.parametrize("cfg_name", ["car", "sunrgbd"])
+def test_inference_with_pool_keys_equals_pooling_pass_full_size(cfg_name):
+    """The inference path takes the max-pool in conv3's epilogue (keys, y3 never written); FCN_POOL_KEYS=0 keeps the pooling pass
+    over the stored y3.  Same model, same full-size batch: the logits must agree BIT FOR BIT (the pooled features are the same
+    fp32 expression of the same winning row), and so must the training-mode forward with the keys forced on."""
+    import os
+    data = _full_batch(cfg_name=cfg_name)
+    keys = [k for k in data if k in ("point_cloud", "one_hot") or k.startswith("center_ref")]
+    out = {}
+    try:
+        for mode in ("default", "0", "1"):
+            if mode == "default":
+                os.environ.pop("FCN_POOL_KEYS", None)
+            else:
+                os.environ["FCN_POOL_KEYS"] = mode
+            m = _model(cfg_name=cfg_name)
+            m.eval()
+            with torch.no_grad():
+                m({k: data[k] for k in keys})
+                ev = [t.clone() for t in m.last_logits]
+            uses_keys = [w.pkey is not None for n in m.feat_net.nets for lst in n._pool.free.values() for w in lst]
+            assert uses_keys and all(u == (mode != "0") for u in uses_keys), (mode, uses_keys)
+            m.train()
+            with torch.no_grad():
+                m(data)
+                tr = [t.clone() for t in m.last_logits]
+            out[mode] = ev + tr
+    finally:
+        os.environ.pop("FCN_POOL_KEYS", None)
+    for mode in ("default", "1"):
+        for a, b in zip(out[mode], out["0"]):
+            assert torch.equal(a, b), mode
+
+
+@pytest.mark.parametrize("cfg_name", ["car", "sunrgbd"])
 def test_train_statistics_are_the_only_coupling_between_frustums(cfg_name):
     """Training-mode BatchNorm couples the frustums ONLY through the batch statistics: duplicating the whole batch
     (2B frustums) leaves mean / biased variance unchanged, hence the logits of the first copy (1e-4)."""
