@@ -295,7 +295,7 @@ void dgrad_kernel(DgradArgs a)
             }
             kb_store4<MM_ENC_A, LDRA>(Ab, r, kq, dv[0], dv[1], dv[2], dv[3]);
             if constexpr (LAYER == 3) {
-                if (ok && byi == 0 && !(FCN_XB & 128)) {
+                if (ok && byi == 0 && a.dybuf && !(FCN_XB & 128)) {
                     const v4f d0 = {dv[0], dv[1], dv[2], dv[3]};
                     sts4e<MM>(a.dybuf, (grow0 + r) * CRED + nb, d0);
                 }
@@ -410,10 +410,13 @@ struct WgradArgs {
     const float4 *ent;
     const int32_t *woff;
     const int32_t *tiles;   // live-tile list
-    const float *dy;        // LAYER 3: dy3 (B,cap,C3)
+    const float *dy;        // LAYER 3: dy3 (B,cap,C3) as the data-gradient GEMM stored it, or nullptr: REBUILT here (RC)
     const float *dz;        // LAYER 2: dz2 (B,cap,C2)
-    const float *ycur;      // LAYER 2: y2 (for xhat2)
-    FcnBnBwd cb;            // LAYER 2: BN2 backward, finalised by every workgroup
+    const float *ycur;      // LAYER 2: y2 (for xhat2); LAYER 3 RC: y3
+    FcnBnBwd cb;            // LAYER 2: BN2 backward (LAYER 3 RC: BN3 backward), finalised by every workgroup
+    const int32_t *ewin;    // LAYER 3 RC: window of each row, and the arg-max / routed-gradient maps (B,L,C3) of the max-pool
+    const int32_t *amax;
+    const float *gmax;
     const float *yprev;     // LAYER 3: y2 -> a2
     const float *bn_prev;   // scale, shift of the previous layer's BN
     const float *W1;        // LAYER 2
@@ -432,9 +435,14 @@ __device__ __forceinline__ float4 ld4f(const float *base, int64_t e)
 // dW[n][k] = sum_rows dy[row][n] * a_prev[row][k]; workgroup tile (64*MT) x (64*NT).  Split s reduces the
 // rows of live tiles [s*tpb, (s+1)*tpb) and writes one partial; wgrad_reduce sums the live partials in a fixed
 // order (deterministic, no float atomics).
-template <int MM, int LAYER, int MT, int NT>
-__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ? 3 : 2, 4))) void wgrad_kernel(WgradArgs a)
+// RC (LAYER 3): dy3 is not read from memory but REBUILT while staging, the way the data-gradient GEMM builds it -- from y3, the
+// row's multiplicity, the max-pool's arg-max / routed-gradient maps at the row's window and the BN3-backward coefficients -- so
+// that nothing has to write (B, cap, C3) floats for this kernel to read back: the same fp32 expression, bit-identical dW3.
+// The window ids of a chunk's rows are fetched one chunk ahead (the map addresses depend on them).
+template <int MM, int LAYER, int MT, int NT, int RC = 0>
+__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu((LAYER == 3 && !RC) ? 3 : 2, 4))) void wgrad_kernel(WgradArgs a)
 {
+    constexpr bool XF = LAYER == 2 || RC;               // the A operand is transformed by a BatchNorm backward while staging
     constexpr int LDA = 64 * MT + 4, LDB = 64 * NT + 4;
     __shared__ __attribute__((aligned(16))) float As[KC * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[KC * LDB];
@@ -443,6 +451,7 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
     // "load or zero" branches behind it made the compiler wait for every load at once -- tools/pn_probe.py: 45-60 % of the
     // kernel's cycles between them, 13-19 % in the MFMA phase
     __shared__ int tG0[WG_TMAX], tLeft[WG_TMAX];
+    __shared__ int tBL[RC ? WG_TMAX : 1], tR0[RC ? WG_TMAX : 1];      // RC: b * L and the tile's first row within its frustum
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -460,6 +469,7 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
         const int b = code / a.tps, t = code % a.tps;
         tG0[i] = b * a.cap + t * 128;
         tLeft[i] = a.woff[(int64_t)b * (a.L + 1) + a.L] - t * 128;
+        if constexpr (RC) { tBL[i] = b * a.L; tR0[i] = t * 128; }
     }
     __syncthreads();
 
@@ -472,7 +482,7 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
 #define WG_BROW(i) (2 * brr + ((i) & 1) + 2 * BRT * ((i) >> 1))
     float cf[5][4];
     float bs[4], bt[4], bal[4][3];
-    if constexpr (LAYER == 2) {
+    if constexpr (XF) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float c5[5];
@@ -498,6 +508,8 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
     acc_zero<MT, NT>(acc);
     float4 ra[2 * MT], ra2[2 * MT], rb4[2 * NT];
     float rwt[2 * MT];
+    v4i rm[RC ? 2 * MT : 1];                   // RC: arg-max rows of the row's window at this thread's four channels
+    int rwin[RC ? 2 * MT : 1], rwin_n[RC ? 2 * MT : 1];      // RC: windows of the chunk being loaded / of the next one
 
     // chunk q -> (global row of its first row, number of valid rows left in its tile from there)
     // (32-bit element offsets throughout: launch_wgrad checks B * cap * max(COUT, CIN) < 2^31 -- the 64-bit multiplies of
@@ -508,6 +520,18 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
         left = tLeft[q >> 2] - r0;                             // may be <= 0 for the tail chunks of a tile
     };
 
+    // RC: window ids of chunk q's rows -> rwin_n (same clamping as the data loads)
+    auto load_win = [&](int q) __attribute__((always_inline)) {
+        if constexpr (RC) {
+            int g0, left;
+            chunk_rows(q, g0, left);
+            const int lastr = max(left, 1) - 1;
+            if (left <= 0) g0 = tG0[q >> 2];
+#pragma unroll
+            for (int i = 0; i < 2 * MT; ++i) rwin_n[i] = a.ewin[g0 + min(WG_AROW(i), lastr)];
+        }
+    };
+
     auto load_chunk = [&](int q) __attribute__((always_inline)) {
         int g0, left;
         chunk_rows(q, g0, left);
@@ -516,17 +540,33 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
         // tile's first row, which is live.
         const int lastr = max(left, 1) - 1;
         if (left <= 0) g0 = tG0[q >> 2];
+        int bl = 0;
+        if constexpr (RC) {
+            bl = tBL[q >> 2];
+#pragma unroll
+            for (int i = 0; i < 2 * MT; ++i) rwin[i] = rwin_n[i];        // (requested one chunk ago)
+        }
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
             const int rr = min(WG_AROW(i), lastr);
             const int o = (g0 + rr) * COUT + n0 + 4 * acq;
-            if constexpr (LAYER == 3) {
+            if constexpr (RC) {
+                const int om = (bl + rwin[i]) * COUT + n0 + 4 * acq;
+                ra2[i] = ld4f<MM>(a.ycur, o);
+                rm[i] = ldg4i(a.amax + om);
+                const v4f g4 = ldg4(a.gmax + om);
+                ra[i] = make_float4(g4.x, g4.y, g4.z, g4.w);
+                rwt[i] = a.ent[g0 + rr].w;
+            } else if constexpr (LAYER == 3) {
                 ra[i] = ld4f<MM>(a.dy, o);
             } else {
                 ra[i] = ld4f<MM>(a.dz, o);
                 ra2[i] = ld4f<MM>(a.ycur, o);
                 rwt[i] = a.ent[g0 + rr].w;
             }
+        }
+        if constexpr (RC) {
+            if (q + 1 < nq) load_win(q + 1);
         }
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {
@@ -537,6 +577,7 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
     };
 
     PNP_ADD(0);                                   // 0: prologue
+    load_win(0);
     load_chunk(0);
     for (int q = 0; q < nq; ++q) {
         PNP_ADD(1);                               // 1: chunk lookup + issue of the global loads
@@ -550,8 +591,14 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(LAYER == 3 ?
             const bool ok = rr < left;
             const v4f rv = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
             v4f v = ok ? rv : zero4();
-            if constexpr (LAYER == 2) {
-                const float dzv[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+            if constexpr (XF) {
+                float dzv[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+                if constexpr (RC) {          // the routed gradient counts at the window's arg-max row only
+                    const int rloc = tR0[q >> 2] + (q & 3) * KC + rr;
+                    const int mv[4] = {rm[i].x, rm[i].y, rm[i].z, rm[i].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dzv[j] = (mv[j] == rloc) ? dzv[j] : 0.f;
+                }
                 const float yv[4] = {ra2[i].x, ra2[i].y, ra2[i].z, ra2[i].w};
                 float o[4];
 #pragma unroll
@@ -719,13 +766,13 @@ static int launch_dgrad(const DgradArgs &a, int B, int precision, hipStream_t st
     return 0;
 }
 
-template <int MM, int LAYER>
+template <int MM, int LAYER, int RC = 0>
 static void launch_wgrad_mm(const WgradArgs &a, dim3 grid, bool m2, bool n2, hipStream_t st)
 {
-    if (m2 && n2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 2, 2>), grid, dim3(GT), 0, st, a);
-    else if (m2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 2, 1>), grid, dim3(GT), 0, st, a);
-    else if (n2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 1, 2>), grid, dim3(GT), 0, st, a);
-    else hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 1, 1>), grid, dim3(GT), 0, st, a);
+    if (m2 && n2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 2, 2, RC>), grid, dim3(GT), 0, st, a);
+    else if (m2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 2, 1, RC>), grid, dim3(GT), 0, st, a);
+    else if (n2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 1, 2, RC>), grid, dim3(GT), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 1, 1, RC>), grid, dim3(GT), 0, st, a);
 }
 
 template <int LAYER>
@@ -749,7 +796,12 @@ static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, int precision, hipS
     if (nsplit > B * a.tps) nsplit = B * a.tps;
     if (nsplit > nsplit_cap) nsplit = nsplit_cap;
     dim3 grid(nsplit, oy, oz);
-    FCN_MM_SWITCH(FCN_MM_OF(precision, false), (launch_wgrad_mm<MM, LAYER>(a, grid, m2, n2, st)));
+    if (LAYER == 3 && !a.dy) {             // dy3 rebuilt by the kernel (RC)
+        if (!a.ycur || !a.ewin || !a.amax || !a.gmax || !a.cb.bstat) return FCN_E_BADARG;
+        FCN_MM_SWITCH(FCN_MM_OF(precision, false), (launch_wgrad_mm<MM, LAYER, LAYER == 3 ? 1 : 0>(a, grid, m2, n2, st)));
+    } else {
+        FCN_MM_SWITCH(FCN_MM_OF(precision, false), (launch_wgrad_mm<MM, LAYER>(a, grid, m2, n2, st)));
+    }
     FCN_CHECK_LAUNCH();
     const int64_t ne = (int64_t)a.COUT * a.CIN;
     if (((uintptr_t)out & 15) != 0) return FCN_E_BADARG;        // the reduce writes 16-byte vectors (include/fcn_hip.h)
@@ -844,6 +896,11 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
     w.partial = ws->partial;
     w.dy = ws->dy3; w.dz = nullptr; w.ycur = nullptr; w.yprev = ws->y2; w.bn_prev = bn2;
     w.cb.bstat = nullptr; w.cb.rep_stride = brs; w.cb.gamma = nullptr; w.cb.bn = nullptr; w.cb.invM = 1.0 / M; w.cb.dgamma = nullptr; w.cb.dbeta = nullptr;
+    w.ewin = nullptr; w.amax = nullptr; w.gmax = nullptr;
+    if (!ws->dy3) {        // no dy3 buffer: conv3's weight-gradient GEMM rebuilds dy3 from what the data-gradient GEMM reads
+        w.ycur = ws->y3; w.cb.bstat = bs3; w.cb.gamma = p->gamma[2]; w.cb.bn = bn3;
+        w.ewin = ws->ewin; w.amax = ws->amax; w.gmax = ws->gmax;
+    }
     w.W1 = nullptr; w.COUT = C3; w.CIN = C2;
     if (two) {     // dy3 is final: conv3's weight gradient can run beside the rest of the chain
         e = hipEventRecord((hipEvent_t)events[0], st);

@@ -123,7 +123,9 @@ typedef struct fcn_pn_ws {
     float   *bn;                 /* 4*(C1+C2+C3) floats: per layer scale, shift, mean, rstd  */
     /* backward only */
     float   *gmax;               /* (B, L, C3)  dfeat routed to the max rows                 */
-    float   *dy3;                /* (B, cap, C3)                                             */
+    float   *dy3;                /* (B, cap, C3), or NULL: dy3 is not materialised -- conv3's weight-gradient GEMM rebuilds
+                                    it from y3, ewin, amax, gmax and the BN3-backward sums while staging (bit-identical dW3;
+                                    measured 0.7 % slower over the step, saves B*cap*C3 floats) */
     float   *dz2;                /* (B, cap, C2)                                             */
     double  *bstat;              /* fcn_stat_replicas() * (2*C3 + 2*C2 + 4*C1) doubles       */
     float   *coef;               /* 5*(C3+C2) floats                                         */

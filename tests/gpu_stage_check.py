@@ -176,7 +176,8 @@ def run_stages(B, N, stride, K, mlp, dist, seed=5, variant="car", verbose=True, 
     assert rc == 0, rc
     if not emu:
         torch.cuda.synchronize()
-    rec("dy3", live(ws.dy3), r["dy3"])
+    if ws.dy3 is not None:          # (FCN_STORE_DY3=0: conv3's weight-gradient GEMM rebuilds dy3 and nothing stores it)
+        rec("dy3", live(ws.dy3), r["dy3"])
     zmask2 = (f["y2"] * f["s"][1] + f["t"][1] > 0).float()
     rec("dz2", live(ws.dz2), r["G2"] * zmask2)
     for j in (3, 2, 1):

@@ -78,3 +78,50 @@ def test_key_pool_matches_row_pool(case, training):
         zr = torch.relu(torch.addcmul(t[c], s[c], y3k[b, ar[b, l, c], c]))
         assert float(zk) == float(zr), (b, l, c, float(zk), float(zr))
     assert len(diff) <= max(4, ak.numel() // 10000), len(diff)
+
+
+@pytest.mark.parametrize("case", [gsc.CASES[1], gsc.CASES[4], gsc.CASES[5]], ids=lambda c: "B%d_N%d_s%s_K%d_C%d" % (c[0], c[1], c[2], c[3], c[4][2]))
+def test_rebuilt_dy3_gives_bit_identical_gradients(case):
+    """FCN_STORE_DY3=0: dy3 is never materialised -- conv3's weight-gradient GEMM rebuilds it while staging from what the
+    data-gradient GEMM reads (y3, arg-max / routed-gradient maps, BN3-backward sums); the default keeps the buffer and the
+    read-back.  Same fp32 expression on the same inputs: every gradient of the scale must agree BIT FOR BIT."""
+    import ctypes
+    import os
+    import numpy as np
+    from frustum_convnet_amd import _native, pointnet_fused as pf, synth
+
+    B, N, stride, K, mlp, dist = case
+    dev = torch.device("cuda:0")
+    pc, ref, sd, one_hot = gsc.make_case(B, N, stride, K, mlp, dist)
+    L = ref.shape[2]
+    dfeat = torch.from_numpy(synth.normalish(3, 1, (B, mlp[2] + 3, L)).astype(np.float32)).to(dev).contiguous()
+    out = {}
+    try:
+        for mode in ("0", "1"):
+            os.environ["FCN_STORE_DY3"] = mode
+            sdg = {k: v.clone().to(dev) for k, v in sd.items()}
+            plist = []
+            for j in (1, 2, 3):
+                plist += [sdg["m.conv%d.0.weight" % j], sdg["m.conv%d.1.weight" % j], sdg["m.conv%d.1.bias" % j]]
+            bufs = ([sdg["m.conv%d.1.running_mean" % j] for j in (1, 2, 3)], [sdg["m.conv%d.1.running_var" % j] for j in (1, 2, 3)],
+                    [sdg["m.conv%d.1.num_batches_tracked" % j] for j in (1, 2, 3)])
+            pool = pf.WorkspacePool()
+            feat, idx, cnt, ws, desc, keep = pf._forward_impl(pool, (float(dist), int(K), True, 1e-5, 0.1), pc.to(dev), ref.to(dev),
+                                                              one_hot.to(dev), bufs, plist, True)
+            assert (ws.dy3 is not None) == (mode == "1")
+            Wc, gs, bs = keep[0], keep[1], keep[2]
+            dW = [torch.empty_like(w) for w in Wc]
+            dg = [torch.empty_like(g) for g in gs]
+            db = [torch.empty_like(b) for b in bs]
+            params = pf._params_struct(Wc, gs, bs, [None] * 3, [None] * 3, [None] * 3)
+            arr = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
+            rc = _native.lib().fcn_pn_backward(ctypes.byref(desc), ctypes.byref(params), dfeat.data_ptr(), ctypes.byref(ws.c),
+                                               arr(dW), arr(dg), arr(db), _native.current_stream(dev))
+            assert rc == 0, rc
+            torch.cuda.synchronize()
+            out[mode] = [t.detach().cpu() for t in dW + dg + db]
+    finally:
+        os.environ.pop("FCN_STORE_DY3", None)
+    for a, b in zip(out["0"], out["1"]):
+        assert torch.equal(a, b)
+    assert float(out["0"][2].abs().max()) > 0
