@@ -107,7 +107,7 @@ def make_data(cfg_name, batch, npoint, seed, device):
 # ------------------------------------------------------------------------------------------------
 # Live per-entry-point timing: HIP events recorded on the launch stream right around each C-ABI call of an EAGER step.
 # Every launch of a call is enqueued back to back on that stream, so the interval is the GPU time of the call's kernels.
-TIMED = ("fcn_pn_group_compact", "fcn_pn_forward", "fcn_convnet_pack", "fcn_convnet_forward2", "fcn_det_loss_tail_rows2",
+TIMED = ("fcn_pn_group_compact2", "fcn_pn_forward", "fcn_convnet_pack", "fcn_convnet_forward2", "fcn_det_loss_tail_rows2",
          "fcn_det_iou_metrics", "fcn_convnet_backward", "fcn_pn_backward2", "fcn_adam_step_f32")
 
 
@@ -153,6 +153,7 @@ def kernel_table(model, state, data, optim, prec, reps=5):
     B = data["point_cloud"].shape[0]
     Ls = [data["center_ref%d" % i].shape[2] for i in range(1, 6) if ("center_ref%d" % i) in data]
     agg = {}
+    model.feat_net.drop_prefetch()                       # (a front the last replayed step prefetched: this table times the whole front)
     for rep in range(reps + 1):
         with CallTimer(lib) as ct:
             losses, _ = model(data)
@@ -203,7 +204,7 @@ def kernel_table(model, state, data, optim, prec, reps=5):
             flops = 2.0 * ff
         elif key == "fcn_adam_step_f32":
             nbytes = 7.0 * 4.0 * nparam
-        elif key == "fcn_pn_group_compact":
+        elif key == "fcn_pn_group_compact2":
             # algorithmic bytes of the fused front: z row + centres in, entry rows (16 B + 4 B window id) + offsets + counts out
             nbytes = sum(B * (4.0 * N + 12.0 * Lw) + 20.0 * E.get((Lw, net.nsample), 0) + B * 8.0 * Lw
                          for net, Lw in zip(nets, Ls))
@@ -311,6 +312,7 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
     batch = batch or a.batch
     npoint = npoint or CFGS[cfg_name][3]
     model = build_model(dev, cfg_name)
+    model.defer_metrics_join = os.environ.get("FCN_IOU_JOIN", "late") != "early"     # joined by model.backward()
     if world > 1:
         fdist.broadcast_state(model, 0)
     # reference optimiser: Adam(lr 1e-3, weight_decay 1e-4), train/train_net_det.py:321-339.  Parameters, gradients and
@@ -322,8 +324,16 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
     overlap = world > 1 and not a.no_overlap and not a.eager
     model.split_backward = overlap
 
+    prefetch = os.environ.get("FCN_PREFETCH", "1") != "0" and world == 1 and optim
+    steps_per_graph = 1
+
     def fwd_bwd():
         losses, _ = model(data)
+        if prefetch:
+            # the next step's batch (the same resident synthetic batch): its batch-only front -- grouping, entry rows, tile lists,
+            # input moments -- runs on a side branch beside this step's backward, as a loader prefetches; the work stays INSIDE the
+            # timed step, only off its critical path.  Double-buffered workspaces: captured steps alternate between two graphs.
+            model.prefetch(data)
         model.backward(losses["total_loss"])          # == loss.backward(), seeded with a cached unit gradient
         return losses["total_loss"]
 
@@ -356,24 +366,36 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
                     pending = model.take_split()
                     from frustum_convnet_amd.loss_fused import unit_grad
                     loss.backward(gradient=unit_grad(loss.device))
+                    model._iou_metrics.join()        # (deferred join: the side branch must end inside this capture)
                 with torch.cuda.graph(gB, pool=gA.pool(), capture_error_mode=mode):
                     pending.backward()
                 graphs = (gA, gB)
             else:
+                # with the prefetch a step consumes the front its predecessor prepared in the OTHER workspace set: the captured
+                # graph holds TWO steps (even / odd) -- one replay = two whole steps, which also halves the graph-to-graph gap
+                # per step.  `step()` below replays it on every second call.
+                glist = []
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode=mode):
-                    loss = fwd_bwd()
-                    if world == 1 and optim:
-                        state.adam_step()
-                graphs = (g,)
+                    for _ in range(2 if prefetch else 1):
+                        loss = fwd_bwd()
+                        if world == 1 and optim:
+                            state.adam_step()
+                glist.append(g)
+                steps_per_graph = 2 if prefetch else 1
+                graphs = (tuple(glist),)
         except Exception as e:  # noqa
             if rank == 0:
                 print("[bench] hipGraph capture failed (%s: %s); falling back to eager launches" %
                       (type(e).__name__, e), file=sys.stderr)
             graphs = None
             overlap = False
+            steps_per_graph = 1
             model.split_backward = False
+            model._split = model._pending_split = None          # (a capture that died between take_split() and phase 2)
             torch.cuda.synchronize()
+
+    parity = [0]
 
     def step():
         if graphs is None:
@@ -390,18 +412,21 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
             if optim:
                 state.adam_step()
         else:
-            graphs[0].replay()
+            if parity[0] % steps_per_graph == 0:
+                graphs[0][0].replay()
+            parity[0] += 1
             if world > 1:
                 state.allreduce()
                 if optim:
                     state.adam_step()
 
-    for _ in range(warmup):
+    even = lambda n: n + (n % steps_per_graph)          # a replay holds steps_per_graph whole steps: counts are multiples of it
+    for _ in range(even(warmup)):
         step()
     torch.cuda.synchronize()
     # length of one K-step window -> number of rounds for a timed region of at least min_time seconds
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(even(steps)):
         step()
     torch.cuda.synchronize()
     probe = time.perf_counter() - t0
@@ -415,7 +440,7 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    for _ in range(rounds * steps):
+    for _ in range(even(rounds * steps)):
         step()
     e1.record()
     torch.cuda.synchronize()
@@ -427,11 +452,12 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
     if world > 1:
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
     wall = float(tt.item())
-    nstep = rounds * steps
+    nstep = even(rounds * steps)
     Ls = [data["center_ref%d" % i].shape[2] for i in range(1, 6) if ("center_ref%d" % i) in data]
     return {"model": model, "state": state, "data": data, "graphs": graphs, "overlap": overlap, "optim": optim,
             "rounds": rounds, "nstep": nstep, "wall": wall, "ms_per_step": wall * 1e3 / nstep,
             "gpu_event_ms_per_step": e0.elapsed_time(e1) / nstep, "final_loss": float(loss.item()),
+            "steps_per_graph": steps_per_graph, "prefetch": prefetch,
             "batch": batch, "npoint": npoint, "Ls": Ls}
 
 
@@ -556,7 +582,9 @@ def main():
                        ("+RCCL grad all-reduce (%s)" % ("2 buckets overlapped with the PointNet backward" if overlap else
                                                         "one call after the backward")) if world > 1 else ""),
                    "global_batch": a.batch * world, "parallelism": "dp%d" % world,
-                   "launch": ("hipGraph replay x%d" % len(graphs)) if graphs is not None else "eager"},
+                   "launch": (("hipGraph replay x%d" % len(graphs)) + (", %d steps per replay" % m["steps_per_graph"] if m["steps_per_graph"] > 1 else "")
+                              if graphs is not None else "eager") +
+                             (", next batch's grouping front prefetched beside the backward (double-buffered workspaces)" if m["prefetch"] else "")},
         "gpu_event_ms_per_step": round(gpu_event_ms, 4),
         "final_loss": round(final_loss, 5),
     }

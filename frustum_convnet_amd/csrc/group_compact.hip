@@ -53,6 +53,9 @@ struct GcArgs {
     const float *pc;           // (B,3,N)
     int B, N, training, use_lds;
     float eps, momentum;
+    int fold;                  // 1: the entries launch also folds BN1 (scale / shift, running statistics) from the input moments;
+                               // 0: data-only front (fcn_pn_group_compact2 phase 1) -- gc_fold_kernel does it later, after the
+                               // optimiser step the weights depend on
 };
 
 #define GE_T 1024
@@ -66,6 +69,44 @@ __device__ __forceinline__ GcScale gc_pick(const GcArgs &a, int z)
     for (int q = 1; q < GC_MAX_SCALES; ++q)
         if (z == q) S = a.s[q];
     return S;
+}
+
+
+// BN1 scale / shift (+ running statistics) of one scale from its 10 input moments `mo` (sum w, sum w*u [3], sum w*u*u^T [6]): conv1
+// is linear in u, so mean = W1 mu, var = W1^T Cov W1 (fp64).  Called by the last workgroup of gc_entries_kernel (fused front) or by
+// gc_fold_kernel (phased front: the moments depend on the batch only, the fold on the weights of THIS step).
+__device__ __forceinline__ void gc_fold_bn1(const GcArgs &a, const GcScale &S, const double *mo, int tid, int nthr)
+{
+    const double M = (double)a.B * (double)S.L * (double)S.K;
+    for (int c = tid; c < S.C1; c += nthr) {
+        double mean, var;
+        if (a.training) {
+            // (one fp64 division, no software sqrt: this workgroup is the tail of the front every scale waits for)
+            const double iM = 1.0 / M;
+            const double mx = mo[1] * iM, my = mo[2] * iM, mz = mo[3] * iM;
+            const double cxx = mo[4] * iM - mx * mx, cxy = mo[5] * iM - mx * my, cxz = mo[6] * iM - mx * mz;
+            const double cyy = mo[7] * iM - my * my, cyz = mo[8] * iM - my * mz, czz = mo[9] * iM - mz * mz;
+            const double w0 = S.W1[3 * c], w1 = S.W1[3 * c + 1], w2 = S.W1[3 * c + 2];
+            mean = w0 * mx + w1 * my + w2 * mz;
+            var = w0 * (cxx * w0 + cxy * w1 + cxz * w2) + w1 * (cxy * w0 + cyy * w1 + cyz * w2) +
+                  w2 * (cxz * w0 + cyz * w1 + czz * w2);
+            if (var < 0.0) var = 0.0;
+            if (S.rmean) {
+                S.rmean[c] = (float)((1.0 - a.momentum) * S.rmean[c] + a.momentum * mean);
+                S.rvar[c] = (float)((1.0 - a.momentum) * S.rvar[c] + a.momentum * var * (M / (M - 1.0)));
+                if (c == 0 && S.nbt) S.nbt[0] += 1;
+            }
+        } else {
+            mean = S.rmean[c];
+            var = S.rvar[c];
+        }
+        const double rstd = fcn_rsqrt64(var + (double)a.eps);
+        const double sc = (double)S.gamma[c] * rstd;
+        S.bn1[c] = (float)sc;
+        S.bn1[S.C1 + c] = (float)((double)S.beta[c] - mean * sc);
+        S.bn1[2 * S.C1 + c] = (float)mean;
+        S.bn1[3 * S.C1 + c] = (float)rstd;
+    }
 }
 
 // ---- launch 1: hit lists (query_depth_point_cuda_kernel.cu:40-64: fabsf(z2 - z1) < dis_z in fp32, ascending k, first K)
@@ -232,38 +273,7 @@ __global__ __launch_bounds__(GE_T) void gc_entries_kernel(GcArgs a)
     for (int i = 10 + tid; i < 16 + FCN_STAT_REP * (2 * S.C2 + 2 * S.C3); i += GE_T) S.stat[i] = 0.0;      // every replica block
     __syncthreads();
     // BN1 scale / shift from the moments (conv1 is linear in u): what bn1_finalize_kernel computes
-    {
-        const double M = (double)a.B * (double)L * (double)K;
-        for (int c = tid; c < S.C1; c += GE_T) {
-            double mean, var;
-            if (a.training) {
-                // (one fp64 division, no software sqrt: this workgroup is the tail of the front every scale waits for)
-                const double iM = 1.0 / M;
-                const double mx = red[0][1] * iM, my = red[0][2] * iM, mz = red[0][3] * iM;
-                const double cxx = red[0][4] * iM - mx * mx, cxy = red[0][5] * iM - mx * my, cxz = red[0][6] * iM - mx * mz;
-                const double cyy = red[0][7] * iM - my * my, cyz = red[0][8] * iM - my * mz, czz = red[0][9] * iM - mz * mz;
-                const double w0 = S.W1[3 * c], w1 = S.W1[3 * c + 1], w2 = S.W1[3 * c + 2];
-                mean = w0 * mx + w1 * my + w2 * mz;
-                var = w0 * (cxx * w0 + cxy * w1 + cxz * w2) + w1 * (cxy * w0 + cyy * w1 + cyz * w2) +
-                      w2 * (cxz * w0 + cyz * w1 + czz * w2);
-                if (var < 0.0) var = 0.0;
-                if (S.rmean) {
-                    S.rmean[c] = (float)((1.0 - a.momentum) * S.rmean[c] + a.momentum * mean);
-                    S.rvar[c] = (float)((1.0 - a.momentum) * S.rvar[c] + a.momentum * var * (M / (M - 1.0)));
-                    if (c == 0 && S.nbt) S.nbt[0] += 1;
-                }
-            } else {
-                mean = S.rmean[c];
-                var = S.rvar[c];
-            }
-            const double rstd = fcn_rsqrt64(var + (double)a.eps);
-            const double sc = (double)S.gamma[c] * rstd;
-            S.bn1[c] = (float)sc;
-            S.bn1[S.C1 + c] = (float)((double)S.beta[c] - mean * sc);
-            S.bn1[2 * S.C1 + c] = (float)mean;
-            S.bn1[3 * S.C1 + c] = (float)rstd;
-        }
-    }
+    if (a.fold) gc_fold_bn1(a, S, &red[0][0], tid, GE_T);
     // live-tile list: tiles[0] = count, tiles[4+i] = b*tps + t (frustum-major, as tile_list_kernel)
     {
         const int tps = (int)((cap + 127) / 128);
@@ -297,10 +307,50 @@ __global__ __launch_bounds__(GE_T) void gc_entries_kernel(GcArgs a)
     }
 }
 
+
+// ---- phased front, phase 2: everything of the front that depends on the WEIGHTS (they change with every optimiser step) -- the
+// split-encoded conv2 / conv3 images of every scale and the BN1 fold -- in one light launch behind the optimiser step; phase 1
+// (hit lists, entry rows, moments, tile lists: functions of the batch alone) may have run long before, beside the previous step
+#define GF_T 256
+__global__ __launch_bounds__(GF_T) void gc_fold_kernel(GcArgs a)
+{
+    __shared__ double mo[10];
+    const int tid = threadIdx.x;
+    const GcScale S = gc_pick(a, (int)blockIdx.y);
+    {   // ONE image item (8 reduction-adjacent values of a weight row or column -> both planes) per thread: the grid covers the
+        // widest scale's item count, a narrower scale's surplus workgroups leave at once.  (16 workgroups per scale looping over
+        // the items took 14 us -- a dozen dependent memory round trips per thread -- on the chain behind the optimiser step.)
+        PackArgs P = a.pk[0];
+#pragma unroll
+        for (int q = 1; q < GC_MAX_SCALES; ++q)
+            if ((int)blockIdx.y == q) P = a.pk[q];
+        if (P.wenc) pn_pack_range(P, (int)blockIdx.x * GF_T + tid, (int)gridDim.x * GF_T);
+    }
+    if (blockIdx.x != 0) return;
+    if (tid < 10) mo[tid] = S.stat[FCN_STAT_MOM + tid];
+    __syncthreads();
+    gc_fold_bn1(a, S, mo, tid, GF_T);
+}
+
+extern "C" int fcn_pn_group_compact2(int nscale, const fcn_pn_desc *const *d, const fcn_pn_params *const *p, const float *pc,
+                                     const float *const *ref, const float *dis_z, const fcn_pn_ws *const *ws,
+                                     int32_t *const *cnt, int phase, void *stream);
+
 extern "C" int fcn_pn_group_compact(int nscale, const fcn_pn_desc *const *d, const fcn_pn_params *const *p, const float *pc,
                                     const float *const *ref, const float *dis_z, const fcn_pn_ws *const *ws,
                                     int32_t *const *cnt, void *stream)
 {
+    return fcn_pn_group_compact2(nscale, d, p, pc, ref, dis_z, ws, cnt, 3, stream);
+}
+
+// phase 1: the batch-only part (hit lists, entries, moments, tile lists, zeroed BN sums) -- a loader may run it for the NEXT batch
+// beside the current step; phase 2: the weight-dependent part (weight images + BN1 fold), one light launch; 3: both, fused (the
+// two launches of fcn_pn_group_compact).  Phases 1 + 2 leave the workspaces exactly as phase 3 does.
+extern "C" int fcn_pn_group_compact2(int nscale, const fcn_pn_desc *const *d, const fcn_pn_params *const *p, const float *pc,
+                                     const float *const *ref, const float *dis_z, const fcn_pn_ws *const *ws,
+                                     int32_t *const *cnt, int phase, void *stream)
+{
+    if (phase < 1 || phase > 3) return FCN_E_BADARG;
     if (nscale < 1 || nscale > GC_MAX_SCALES || !d || !p || !pc || !ref || !dis_z || !ws || !cnt) return FCN_E_BADARG;
     GcArgs a;
     size_t lds = 0;
@@ -327,7 +377,7 @@ extern "C" int fcn_pn_group_compact(int nscale, const fcn_pn_desc *const *d, con
         S.rvar = p[q]->running_var[0]; S.nbt = p[q]->num_batches_tracked[0];
         S.bn1 = ws[q]->bn + fcn_bn_off(0, D->C1, D->C2);
         PackArgs &K = a.pk[s];
-        K.W2 = p[q]->W[1]; K.W3 = p[q]->W[2]; K.wenc = (s < nscale) ? ws[q]->wenc : nullptr;
+        K.W2 = p[q]->W[1]; K.W3 = p[q]->W[2]; K.wenc = (s < nscale && phase != 1) ? ws[q]->wenc : nullptr;
         K.C1 = D->C1; K.C2 = D->C2; K.C3 = D->C3; K.precision = D->precision;
         if (!K.W2 || !K.W3 || ((uintptr_t)ws[q]->wenc & 15) || D->precision < 0 || D->precision > FCN_PREC_BF16_OPS) return FCN_E_BADARG;
         if (!D->training && (!S.rmean || !S.rvar)) return FCN_E_BADARG;
@@ -338,8 +388,19 @@ extern "C" int fcn_pn_group_compact(int nscale, const fcn_pn_desc *const *d, con
     }
     a.pc = pc; a.B = d[0]->B; a.N = d[0]->N; a.training = d[0]->training ? 1 : 0; a.eps = d[0]->eps; a.momentum = d[0]->momentum;
     a.use_lds = (a.N <= GC_LDS_MAX_PTS) ? 1 : 0;
+    a.fold = (phase == 3) ? 1 : 0;
     if (lds > 64 * 1024) return FCN_E_LIMIT;
     hipStream_t st = (hipStream_t)stream;
+    if (phase == 2) {
+        int items = 1;              // image items of the widest scale: 2 * (C2*C1 + C3*C2) / 8 (49 k for 256-256-512)
+        for (int s = 0; s < nscale; ++s) {
+            const int n = 2 * (d[s]->C2 * d[s]->C1 + d[s]->C3 * d[s]->C2) / 8;
+            if (n > items) items = n;
+        }
+        hipLaunchKernelGGL(gc_fold_kernel, dim3((items + GF_T - 1) / GF_T, nscale), dim3(GF_T), 0, st, a);
+        FCN_CHECK_LAUNCH();
+        return 0;
+    }
     // (the split-encoded conv2 / conv3 weights of every scale -- read by the GEMMs of fcn_pn_forward / fcn_pn_backward -- are
     // packed by gc_hits_kernel on the side)
     hipLaunchKernelGGL(gc_hits_kernel, dim3(maxslice, a.B, nscale), dim3(GC_T), a.use_lds ? (size_t)a.N * sizeof(float) : 0, st, a);

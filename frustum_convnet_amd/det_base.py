@@ -129,6 +129,7 @@ class PointNetFeat(nn.Module):
         self.concurrent_scales = True
         self.fused_front = os.environ.get("FCN_FUSED_FRONT", "1") != "0"
         self._stream_cache = {}
+        self._prefetched = None     # (key, prepared handles, event or None) of prefetch(): the next batch's front, phase 1
         # the widest scale is the long pole of the backward: its weight-gradient GEMMs run on a second stream beside
         # its data-gradient chain (bit k of FCN_PN_SIDE = scale k+1; default scale 4 only)
         # Stream topology switches (FCN_TOPO bit mask, default 0 = what measured fastest on ROCm 7.2 / MI355X):
@@ -150,6 +151,59 @@ class PointNetFeat(nn.Module):
     def nets(self):
         return tuple(getattr(self, "pointnet%d" % (i + 1)) for i in range(self.num_scales))
 
+    @staticmethod
+    def _front_key(point_cloud, sample_pc, one_hot_vec, nlc, training):
+        ts = [point_cloud] + list(sample_pc) + ([] if one_hot_vec is None else [one_hot_vec])
+        return (tuple((t.data_ptr(), tuple(t.shape), t._version) for t in ts), bool(nlc), bool(training),
+                torch.is_grad_enabled())
+
+    def prefetch(self, point_cloud, sample_pc, one_hot_vec=None, nlc=False):
+        """Phase 1 of the fused front (grouping, entry rows, tile lists, input moments: functions of the batch alone) for the
+        batch the NEXT forward() will see, on a side stream forked from the current one -- as a data loader prefetches
+        (datasets/provider_sample.py:291-327 run by DataLoader workers ahead of train/train_net_det.py:114).  The next forward
+        then starts with the light weight-dependent launch (phase 2) instead of the whole front.  The tensors must be passed
+        to that forward unmodified (same storage, no in-place write in between); anything else discards the prefetch.
+        join_prefetch() makes the current stream wait for the branch (PointNetDet.backward does: inside a captured step
+        the branch has to end in the same capture)."""
+        if not (self.fused_front and self.concurrent_scales and point_cloud.is_cuda):
+            return False
+        self.drop_prefetch()
+        from .pointnet_fused import group_compact
+        dev = point_cloud.device
+        nets = self.nets
+        cur = torch.cuda.current_stream(dev)
+        key = "pf" + str(dev)
+        if key not in self._stream_cache:
+            self._stream_cache[key] = (torch.cuda.Stream(device=dev), torch.cuda.Event(enable_timing=False),
+                                       torch.cuda.Event(enable_timing=False))
+        side, ev_in, ev_out = self._stream_cache[key]
+        prepared = [nets[s].prepare_pooled(point_cloud, sample_pc[s], one_hot_vec, nlc) for s in range(self.num_scales)]
+        ev_in.record(cur)
+        side.wait_event(ev_in)
+        with torch.cuda.stream(side):
+            group_compact(prepared, point_cloud, phase=1)
+            ev_out.record(side)
+        for t in [point_cloud] + list(sample_pc):
+            t.record_stream(side)
+        self._prefetched = [self._front_key(point_cloud, sample_pc, one_hot_vec, nlc, self.training), prepared, (dev, ev_out)]
+        return True
+
+    def join_prefetch(self):
+        """The current stream waits for the prefetch branch (no-op without one)."""
+        if self._prefetched is not None and self._prefetched[2] is not None:
+            dev, ev = self._prefetched[2]
+            torch.cuda.current_stream(dev).wait_event(ev)
+            self._prefetched[2] = None
+
+    def drop_prefetch(self):
+        """Forgets a prefetched front nobody consumed (its workspaces go back to the pools)."""
+        if self._prefetched is None:
+            return
+        self.join_prefetch()
+        for net, h in zip(self.nets, self._prefetched[1]):
+            net._pool.release(h["ws"])
+        self._prefetched = None
+
     def forward(self, point_cloud, sample_pc, feat=None, one_hot_vec=None, nlc=False, join=True):
         """join=False (fused FCN path): the caller's stream is NOT made to wait for the scales; self.done_events holds one
         event per scale for the consumer to wait on (fcn_convnet_forward2 does, map by map)."""
@@ -159,6 +213,7 @@ class PointNetFeat(nn.Module):
         ns = self.num_scales
         self.done_events = None
         if not (self.concurrent_scales and point_cloud.is_cuda) or os.environ.get("FCN_SERIAL", "0") == "1":
+            self.drop_prefetch()
             return tuple(net.forward_pooled(point_cloud, ref, one_hot_vec, nlc) for net, ref in zip(nets, sample_pc))
         # The scales are independent until the FCN: all but the last run on HIP streams forked from the current one and
         # the widest (the last scale, the long pole) on the current stream itself, captured as parallel branches of the step's
@@ -175,10 +230,20 @@ class PointNetFeat(nn.Module):
         # fused front: grouping + compaction + BN1 of all four scales in ONE launch on the caller's stream, in front of the
         # fork (fcn_pn_group_compact); fused_front = False keeps the API-form grouping per scale (int64 idx, 5 nodes each)
         prepared = None
+        if self._prefetched is not None and self._prefetched[0] != self._front_key(point_cloud, sample_pc, one_hot_vec, nlc,
+                                                                                 self.training):
+            self.drop_prefetch()
         if self.fused_front:
             from .pointnet_fused import group_compact, launch_prepared
-            prepared = [nets[s].prepare_pooled(point_cloud, sample_pc[s], one_hot_vec, nlc) for s in range(ns)]
-            group_compact(prepared, point_cloud)
+            if self._prefetched is not None:
+                # the batch-only part ran ahead (prefetch): only the weight-dependent launch is left on the chain
+                self.join_prefetch()
+                prepared = self._prefetched[1]
+                self._prefetched = None
+                group_compact(prepared, point_cloud, phase=2)
+            else:
+                prepared = [nets[s].prepare_pooled(point_cloud, sample_pc[s], one_hot_vec, nlc) for s in range(ns)]
+                group_compact(prepared, point_cloud)
         fork.record(cur)
         handles = [None] * ns
         s4_forked = bool(self.topo & 1)
@@ -283,6 +348,7 @@ class _PendingPointNetBackward:
         if any(l.grad is None for l in self.leaves):
             raise RuntimeError("phase 2 of the split backward before phase 1: differentiate the loss first")
         torch.autograd.backward(list(self.feats), [l.grad for l in self.leaves])
+        self.model._join_side()
         if self.model._pending_split is self:
             self.model._pending_split = None
         self.feats = self.leaves = None
@@ -343,6 +409,11 @@ class PointNetDet(nn.Module):
         self._cn_pool = CnPool()
         from .loss_fused import IouMetrics
         self._iou_metrics = IouMetrics()
+        # defer_metrics_join: the IoU-metrics branch (side stream) is joined by backward() / backward_split() / the pending
+        # phase-2 object instead of right behind the loss tail, so that the first backward launch does not wait for it (nothing
+        # in the backward reads it).  OPT-IN: a training loop that sets it promises to differentiate through one of those three
+        # (a plain loss.backward() would leave the branch unjoined until the next forward) and to read the metrics after it.
+        self.defer_metrics_join = False
         self.last_logits = None
         self.last_logits64 = None
         self.last_num_fg = None
@@ -404,6 +475,25 @@ class PointNetDet(nn.Module):
                                      "split precision, |x| >= 65504, or a genuine overflow); rerun with precision 'f32' or 'bf16'")
         return f
 
+    def prefetch(self, data_dicts):
+        """Starts the batch-only part of the NEXT forward's front (sliding-frustum grouping, entry rows, tile lists, input
+        moments of all scales) on a side stream, beside whatever the current stream does next -- call it between
+        `model(data)` and `model.backward(loss)` with the batch the next `model(...)` call will get (the same tensors,
+        unmodified), as a DataLoader worker prepares the next batch while the step runs (train/train_net_det.py:114).
+        backward() / backward_split() join the branch; the next forward then begins with one light launch (weight images +
+        BN1 fold) instead of the front.  Returns False when the prefetch does not apply (CPU tensors, module path)."""
+        pc = data_dicts.get('point_cloud')
+        if pc is None or not pc.is_cuda or not self.fused_fcn or data_dicts.get('one_hot') is None:
+            return False
+        refs = [data_dicts.get('center_ref%d' % i) for i in range(1, self.num_scales + 1)]
+        xyz = pc[:, :3, :].contiguous()
+        self._pf_xyz = ((pc.data_ptr(), tuple(pc.shape), pc._version), xyz)
+        return self.feat_net.prefetch(xyz, refs, data_dicts.get('one_hot'), nlc=True)
+
+    def _join_side(self):
+        self._iou_metrics.join()
+        self.feat_net.join_prefetch()
+
     def backward(self, loss):
         """loss.backward() seeded with a cached unit gradient (loss_fused.unit_grad): two tiny kernels (ones fill, multiply by
         one) less between the loss tail and the first backward GEMM.  Same gradients."""
@@ -411,6 +501,7 @@ class PointNetDet(nn.Module):
         if self._split is not None:
             return self.backward_split(loss)
         loss.backward(gradient=unit_grad(loss.device))
+        self._join_side()
 
     def take_split(self):
         """Hands over phase 2 of a split backward (the PointNet scales' part of the graph) as an object with .backward();
@@ -438,6 +529,7 @@ class PointNetDet(nn.Module):
         if between is not None:
             between()
         pending.backward()
+        self._join_side()
 
     def _slice_output(self, output):
         nb, ns = self.num_bins, self.num_size_cluster
@@ -468,10 +560,16 @@ class PointNetDet(nn.Module):
         refs = [data_dicts.get('center_ref%d' % i) for i in range(1, self.num_scales + 1)]
 
         batch_size = point_cloud.shape[0]
-        xyz = point_cloud[:, :3, :].contiguous()
+        pf = getattr(self, "_pf_xyz", None)
+        self._pf_xyz = None
+        if pf is not None and pf[0] == (point_cloud.data_ptr(), tuple(point_cloud.shape), point_cloud._version):
+            xyz = pf[1]                  # the coordinate slice prefetch() already handed to the front
+        else:
+            xyz = point_cloud[:, :3, :].contiguous()
         mean_size_array = self._mean_size.to(device=point_cloud.device, dtype=point_cloud.dtype)
 
         logits64 = None
+        self._iou_metrics.join()          # (a deferred join nobody made: the branch must not outlive its step)
         if self.backward_pending():
             # (a plain loss.backward() after a split forward differentiates only the loss tail, heads and ConvFeatNet)
             self._split = self._pending_split = None
@@ -550,7 +648,8 @@ class PointNetDet(nn.Module):
                     logits64, batch_size, num_out, cls_label, refs[1], center_label, heading_label, size_label,
                     size_class_label, mean_size_array, self.num_bins, self.num_size_cluster, wts,
                     self._loss_scratch[1])
-                self._iou_metrics.join()
+                if not (self.defer_metrics_join and self.training and torch.is_grad_enabled()):
+                    self._iou_metrics.join()
                 iou2, iou3, iout = ious[0], ious[1], ious[2]
             else:
                 losses, (a_cls, a_head, a_size), nfg = det_loss_tail(

@@ -169,9 +169,11 @@ def _forward_impl(pool, cfgt, pc, ref, one_hot, bufs, plist, need_grad):
     return _run_forward(h, cnt, idx)
 
 
-def group_compact(handles, pc):
-    """ONE launch for the grouping + compaction + BN1 finalisation of every prepared scale (fcn_pn_group_compact): the
-    int64 idx of the API form is never materialised.  Marks the descriptors `grouped`."""
+def group_compact(handles, pc, phase=3):
+    """The fused front of every prepared scale (fcn_pn_group_compact2): grouping + compaction + tile lists + input moments
+    (phase 1: functions of the batch alone -- PointNetFeat.prefetch runs it for the NEXT batch beside the current step) and
+    weight images + BN1 fold (phase 2: functions of this step's weights); phase 3 = both, two launches.  The int64 idx of the API
+    form is never materialised.  Marks the descriptors `grouped` once the weight-dependent part has run."""
     L = _native.lib()
     n = len(handles)
     dev = pc.device
@@ -183,10 +185,11 @@ def group_compact(handles, pc):
     cnts = arr([h["ws"].cnt.data_ptr() for h in handles])
     dz = (ctypes.c_float * n)(*[h["dist"] for h in handles])
     with torch.cuda.device(dev):
-        _native.check(L.fcn_pn_group_compact(n, descs, params, pc.data_ptr(), refs, dz, wss, cnts,
-                                             _native.current_stream(dev)), "fcn_pn_group_compact")
-    for h in handles:
-        h["desc"].grouped = 1
+        _native.check(L.fcn_pn_group_compact2(n, descs, params, pc.data_ptr(), refs, dz, wss, cnts, int(phase),
+                                              _native.current_stream(dev)), "fcn_pn_group_compact2")
+    if phase != 1:
+        for h in handles:
+            h["desc"].grouped = 1
 
 
 def _empty_idx(dev):

@@ -170,6 +170,19 @@ int fcn_pn_group_compact(int nscale, const fcn_pn_desc *const *d, const fcn_pn_p
                          const float *const *ref, const float *dis_z, const fcn_pn_ws *const *ws, int32_t *const *cnt,
                          void *stream);
 
+/* The same front in two PHASES, so that a loader can prepare the NEXT batch while the current step still runs (the reference's
+ * DataLoader workers prefetch batches the same way, datasets/provider_sample.py:291-327 behind train/train_net_det.py:114):
+ *   phase 1  everything that depends on the batch alone -- hit lists, entry rows, window offsets, tile lists, input moments,
+ *            zeroed BN sums -- into workspaces no launch in flight uses (two launches; p[s] must be valid but its weights are not read);
+ *   phase 2  everything that depends on the WEIGHTS of the step that consumes the batch -- the split-encoded conv2 / conv3 images and
+ *            the BN1 fold (scale / shift, running statistics) from the moments phase 1 left in ws[s]->stat -- one light launch,
+ *            to be issued after the optimiser step, in front of fcn_pn_forward (descriptors with grouped = 1);
+ *   phase 3  both at once = fcn_pn_group_compact.
+ * Phases 1 + 2 leave every workspace bit-identical to phase 3 (tests/test_gpu_group_compact.py). */
+int fcn_pn_group_compact2(int nscale, const fcn_pn_desc *const *d, const fcn_pn_params *const *p, const float *pc,
+                          const float *const *ref, const float *dis_z, const fcn_pn_ws *const *ws, int32_t *const *cnt,
+                          int phase, void *stream);
+
 /* Split-encodes the conv2 / conv3 weights of one scale into ws->wenc (one small launch).  fcn_pn_forward does it itself on
  * descriptors with grouped == 0; fcn_pn_group_compact does it for all its scales (fcn_pn_pack_weights_all, one launch). */
 int fcn_pn_pack_weights(const fcn_pn_desc *d, const fcn_pn_params *p, const fcn_pn_ws *ws, void *stream);

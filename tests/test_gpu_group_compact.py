@@ -111,3 +111,83 @@ def test_fused_front_model_matches_unfused():
     for k in outs[0][2]:
         if "running" in k or k.endswith("num_batches_tracked"):
             assert torch.allclose(outs[0][2][k].float(), outs[1][2][k].float(), rtol=1e-4, atol=1e-6), k
+
+
+@pytest.mark.parametrize("B,N,strides", [(4, 512, (0.25, 0.5, 1.0, 2.0)), (32, 1024, (0.25, 0.5, 1.0, 2.0))])
+def test_phased_front_is_bit_identical_to_the_fused_front(B, N, strides):
+    """fcn_pn_group_compact2: phase 1 (batch-only part) + phase 2 (weight images + BN1 fold) leave every workspace buffer, the
+    BN1 block and the running statistics bit-identical to the fused phase 3 -- also when the weights CHANGE between the two
+    phases (the prefetch case: phase 1 runs before the optimiser step, phase 2 after it)."""
+    from frustum_convnet_amd import pointnet_fused as pf
+    data = synth.make_batch(B, N, strides=strides, seed=91, variant="car", tilt=(0.01, 0.05))
+    pc = torch.from_numpy(data["point_cloud"]).cuda()
+    pools = [pf.WorkspacePool() for _ in range(4)]
+    fused, phased, params = [], [], []
+    for s in range(4):
+        ref = torch.from_numpy(data["center_ref%d" % (s + 1)]).cuda()
+        cfgt = (float(strides[s]), NS[s], True, 1e-5, 0.1, False, True)
+        pa, ba = _params(MLP[s], 20 + s)
+        pb, bb = _params(MLP[s], 20 + s)
+        fused.append(pf._acquire(pools[s], cfgt, pc, ref, None, ba, pa, False))
+        phased.append(pf._acquire(pools[s], cfgt, pc, ref, None, bb, pb, False))
+        params.append((pa, ba, pb, bb))
+    pf.group_compact(phased, pc, phase=1)
+    torch.cuda.synchronize()
+    assert all(h["desc"].grouped == 0 for h in phased)
+    for pa, ba, pb, bb in params:           # "the optimiser step": the same in-place update of both parameter sets
+        for ta, tb in zip(pa, pb):
+            ta.mul_(1.25).add_(0.01)
+            tb.mul_(1.25).add_(0.01)
+    pf.group_compact(phased, pc, phase=2)
+    pf.group_compact(fused, pc)
+    torch.cuda.synchronize()
+    assert all(h["desc"].grouped == 1 for h in phased)
+    for s in range(4):
+        wf, wp = fused[s]["ws"], phased[s]["ws"]
+        for name in ("cnt", "woff", "tiles", "stat", "bn", "wenc", "gmom"):
+            a, b = getattr(wf, name), getattr(wp, name)
+            if name == "bn":
+                a, b = a[:4 * MLP[s][0]], b[:4 * MLP[s][0]]
+            assert torch.equal(a, b), (s, name)
+        for b_ in range(B):
+            n = int(wf.woff[b_, -1])
+            assert torch.equal(wf.ent[b_, :n], wp.ent[b_, :n]) and torch.equal(wf.ewin[b_, :n], wp.ewin[b_, :n]), (s, b_)
+        pa, ba, pb, bb = params[s]
+        assert torch.equal(ba[0][0], bb[0][0]) and torch.equal(ba[1][0], bb[1][0]) and int(ba[2][0]) == int(bb[2][0]) == 1, s
+        ff = pf._run_forward(fused[s], wf.cnt, pf._empty_idx(pc.device))[0]
+        fp = pf._run_forward(phased[s], wp.cnt, pf._empty_idx(pc.device))[0]
+        torch.cuda.synchronize()
+        assert torch.equal(ff, fp), s
+
+
+def test_prefetched_front_gives_the_same_training_steps():
+    """PointNetDet.prefetch(): three optimiser steps with the next batch's front prefetched beside the backward are bit-identical
+    (logits, losses, parameters, running statistics) to three steps without it; a prefetch for a batch the next forward does not
+    get is dropped."""
+    from test_gpu_model import _model
+    from helpers import load_golden, golden_inputs
+    from frustum_convnet_amd.train_state import FlatTrainState
+    g = load_golden("car_b4_n512")
+    data = synth.to_torch(golden_inputs(g), "cuda")
+    other = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data.items()}
+    runs = []
+    for pre in (False, True):
+        m = _model(g)
+        m.train()
+        m.defer_metrics_join = pre
+        st = FlatTrainState(m, lr=1e-3, weight_decay=1e-4)
+        logs = []
+        for step in range(3):
+            losses, _ = m(data)
+            if pre:
+                assert m.prefetch(other if step == 1 else data)       # step 1 prefetches a batch nobody will pass: dropped
+            m.backward(losses["total_loss"])
+            st.adam_step()
+            logs.append((torch.cat([t.flatten() for t in m.last_logits]).detach().clone(), losses["total_loss"].detach().clone()))
+        m.feat_net.drop_prefetch()
+        torch.cuda.synchronize()
+        runs.append((logs, {k: v.clone() for k, v in m.state_dict().items()}))
+    for (la, ta), (lb, tb) in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(la, lb) and torch.equal(ta, tb)
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
