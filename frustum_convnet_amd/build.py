@@ -19,6 +19,18 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno
 OBJ = os.path.join(CSRC, "_obj")
 
 
+def source_hash(extra_flags=()):
+    """sha256 over the kernel sources, headers and compile flags (hex, 16 characters): what libfcn_hip.so reports through
+    fcn_build_hash() -- the library ships prebuilt to the GPU box, so smoke() and bench.py compare the two."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read() + b"\0")
+    h.update(" ".join(FLAGS + list(extra_flags)).encode())
+    return h.hexdigest()[:16]
+
+
 def _deps_mtime():
     return max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS + [os.path.abspath(__file__)])
 
@@ -57,6 +69,12 @@ def build(force=False, verbose=True, lib=None, extra_flags=()):
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
+    # the hash of what was compiled, linked in as a one-function host object
+    hsrc, hobj = os.path.join(objdir, "build_hash.cpp"), os.path.join(objdir, "build_hash.o")
+    with open(hsrc, "w") as f:
+        f.write('extern "C" const char *fcn_build_hash(void) { return "%s"; }\n' % source_hash(extra_flags))
+    subprocess.check_call([os.environ.get("CXX", "g++"), "-O1", "-fPIC", "-c", hsrc, "-o", hobj])
+    objs.append(hobj)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib]
     if verbose:
         print("[fcn build]", " ".join(cmd), flush=True)

@@ -21,7 +21,8 @@
 #define CG_T 256
 // TIMING EXPERIMENTS ONLY (tuning builds, results are wrong when set): FCN_XF bits in the forward K-group kernel -- 1: activation
 // loads for a group's first chunk only, 2: weight loads first chunk only, 4: LDS staging first chunk only, 8: no MFMAs,
-// 16: no epilogue (cross-group sum, stores, statistics), 32: no BN prologue (scale 1 / shift 0), 64: no statistics atomics
+// 16: no epilogue (cross-group sum, stores, statistics), 32: no BN prologue (scale 1 / shift 0), 64: no statistics atomics,
+// 128: return at entry (bare launches), 256: return behind the prologue
 #ifndef FCN_XF
 #define FCN_XF 0
 #endif
@@ -52,6 +53,9 @@ __device__ __forceinline__ double cg_rep_sum(const double *p, int stride)
 #endif
 #ifndef FCN_FT_WNC
 #define FCN_FT_WNC 1
+#endif
+#ifndef FCN_FT_NTW
+#define FCN_FT_NTW 1           // 32-column blocks per wave (a layer whose width is no multiple of the tile falls back to 1)
 #endif
 #define FCN_FT_THREADS (FCN_FT_G * 64 * FCN_FT_MW * FCN_FT_WNC)
 #define LDN 68                 // row-major LDS leading dim of a 64-wide tile (float4 aligned)
@@ -273,18 +277,20 @@ __device__ __forceinline__ float cg_act(float s, float x, float t, bool ok) { re
 // gives 4-16 resident waves per tile to hide the gather / staging latency, and nothing but the result goes back to HBM.
 // In use: <1,4,1> (32 x 32 tile, 4 waves) -- 560 workgroups per layer; <1,4> (32 x 64) and <2,4> (64 x 64) measured
 // 5 % slower over the forward (280 tiles for 256 CUs at every level of the pyramid).
-template <int MM, int MW, int G, int WNC = 2>      // WNC waves across N per K-group: tile (32*MW) x (32*WNC)
-__device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, const int by)
+template <int MM, int MW, int G, int WNC = 2, int NTW = 1>      // WNC waves across N per K-group, NTW 32-column blocks per wave:
+__device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, const int by)      // tile (32*MW) x (32*WNC*NTW)
 {
-    constexpr int TG = 64 * MW * WNC, TMB = 32 * MW, TNC = 32 * WNC, NTHR = G * TG;
+    constexpr int TG = 64 * MW * WNC, TMB = 32 * MW, TNC = 32 * WNC * NTW, NTHR = G * TG;
     constexpr int LDRA = KbTile<TMB>::LDR, LDRB = KbTile<TNC>::LDR, GU4 = KbTile<TMB>::U4 + KbTile<TNC>::U4;
     constexpr int NA = TMB * 8 / TG;          // 4-vectors of A per thread per chunk
     constexpr int NB = TNC * 8 / TG;          // u32x4 of the encoded weight per thread per chunk
     static_assert(G * GU4 * 4 >= G * TMB * TNC, "the cross-group sum fits the operand images");
+    static_assert(2 * TNC <= NTHR && (TMB * 8) % TG == 0 && (TNC * 8) % TG == 0, "epilogue / staging lane mapping");
     __shared__ u32x4 lds4[G * GU4];           // per K-group: kb-major images of its A and W chunk (gemm_tile.h)
     __shared__ __attribute__((aligned(16))) float sS[CG_KMAX], tS[CG_KMAX];
     __shared__ int cSeg[CG_KMAX / KC], cTap[CG_KMAX / KC], cK0[CG_KMAX / KC];   // chunk -> (segment, tap, channel)
     float *lds = (float *)lds4;
+    if (FCN_XF & 128) return;                           // (timing builds: the bare launch -- dispatch + kernel boundary)
     const int tid = threadIdx.x, g = tid / TG, gt = tid % TG;
     const int lane = tid & 63, gw = gt >> 6, l31 = lane & 31, lh = lane >> 5;
     const int wm = gw / WNC, wn = gw % WNC;
@@ -314,8 +320,8 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         bb[i] = q_;
         ll[i] = r_;
     }
-    f32x16 acc[1][1];
-    acc_zero<1, 1>(acc);
+    f32x16 acc[1][NTW];
+    acc_zero<1, NTW>(acc);
     // TWO register sets: the chunk staged in iteration `it` was requested two iterations earlier, so a load has two
     // MFMA phases (not one) to come back from L2 / MALL / HBM before the LDS store needs it
     v4f ra0[NA], ra1[NA];
@@ -327,7 +333,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     for (int i = 0; i < NB; ++i) { rw0[i] = u32x4{0u, 0u, 0u, 0u}; rw1[i] = u32x4{0u, 0u, 0u, 0u}; }
     // weight image item f = gt + TG * i of a chunk: column f % TNC, (plane, k-block) row f / TNC -- 16-byte pieces, lane-linear
     // in global memory and in LDS (pre-encoded by cg_pack_kernel: no VALU on this operand)
-    const u32x4 *wsrc = L.Wenc + n0 + (gt % TNC) + (int64_t)(gt / TNC) * L.Cout;
+    const u32x4 *wsrc = L.Wenc + n0;
     // (macros, not lambdas: the by-reference closure of a lambda called from several places is not always scalarised
     // by hipcc and drags every captured variable into scratch)
     // the chunk (hence the segment) is uniform within a K-group, i.e. within every wave: scalar selects
@@ -348,8 +354,10 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                                \
             RA[i] = cg_load_raw<MM>(L, x, C, Ls, ty ? 0 : 1, tap, k0 + 4 * kq, bb[i], ll[i], rv[i], OK[i], h16);      \
         if (!((FCN_XF & 2) && c_ >= 2 * G))                                                                           \
-        _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                                \
-            RW[i] = ldgu4(wsrc + ((int64_t)c_ * 8 + i * (TG / TNC)) * L.Cout);                                        \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                              \
+            const int f = gt + TG * i;                                                                                \
+            RW[i] = ldgu4(wsrc + ((int64_t)c_ * 8 + f / TNC) * L.Cout + (f % TNC));                                   \
+        }                                                                                                             \
     }
 #define CGK_FWD_STAGE(c_, RA, RW, OK)                                                                                 \
     {                                                                                                                 \
@@ -370,7 +378,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         if (act && !((FCN_XF & 4) && c >= G)) CGK_FWD_STAGE(c, RA, RW, OK);                                   \
         if constexpr (TG != 64) __syncthreads(); else __builtin_amdgcn_wave_barrier();                                \
         if (c + 2 * G < nchunk) CGK_FWD_LOAD(c + 2 * G, RA, RW, OK);                                         \
-        if (act && !(FCN_XF & 8)) mma_chunk_kb<MM, 1, 1, LDRA, LDRB>(Ab, Bb, wm * 32, wn * 32, acc);              \
+        if (act && !(FCN_XF & 8)) mma_chunk_kb<MM, 1, NTW, LDRA, LDRB>(Ab, Bb, wm * 32, wn * 32 * NTW, acc);      \
         if constexpr (TG != 64) __syncthreads(); else __builtin_amdgcn_wave_barrier();                                \
     }
     // A K-group of ONE wave (TG == 64: the 32 x 32 tile in use) owns its LDS buffers alone and the LDS serves a wave's
@@ -401,6 +409,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     if (FCN_XF & 32) { for (int i = tid; i < L.Ktot; i += NTHR) { sS[i] = 1.f; tS[i] = 0.f; } }
     else cg_fill_bn(L, sS, tS, tid, NTHR, bx == 0 && by == 0);
     __syncthreads();                            // sS / tS and the chunk table ready
+    if (FCN_XF & 256) { if (sS[0] == 123.456f) L.y[0] = 0.f; return; }      // (timing builds: launch + prologue only)
     PROBE_STAMP();                                      // 2: prologue done
     for (int it = 0; it < nit; it += 2) {
         CGK_FWD_ITER(it, ra0, rw0, ok0);
@@ -412,8 +421,10 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     if constexpr (TG == 64) __syncthreads();            // every group is done with its operand buffers (reused below)
     float *red = lds;                                   // [G][TMB][TNC]
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg)
-        red[(g * TMB + wm * 32 + acc_row(reg, lh)) * TNC + wn * 32 + l31] = acc[0][0][reg];
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            red[(g * TMB + wm * 32 + acc_row(reg, lh)) * TNC + (wn * NTW + j) * 32 + l31] = acc[0][j][reg];
     __syncthreads();
     PROBE_STAMP();                                      // 4: all groups done, partials in LDS
     constexpr int NQ = TNC / 4;                         // column quads of the tile
@@ -475,13 +486,13 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     PROBE_FLUSH(((unsigned long long)L.Ktot << 32) | ((unsigned long long)L.Cout << 16) | (unsigned long long)(L.Lout & 0xffff));
 }
 
-template <int MM, int MW, int G, int WNC = 2>
+template <int MM, int MW, int G, int WNC = 2, int NTW = 1>
 __global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_kernel(CgLayer L)
 {
-    const int nby = L.Cout / (32 * WNC), nbx = (L.B * L.Lout + 32 * MW - 1) / (32 * MW);
+    const int nby = L.Cout / (32 * WNC * NTW), nbx = (L.B * L.Lout + 32 * MW - 1) / (32 * MW);
     const int t = cg_xcd_tile(blockIdx.x, nbx * nby);          // column tiles fastest: a row tile's operand rows stay in one L2
     if (t < 0) return;
-    cgk_fwd_body<MM, MW, G, WNC>(L, t / nby, t % nby);
+    cgk_fwd_body<MM, MW, G, WNC, NTW>(L, t / nby, t % nby);
 }
 
 // Two INDEPENDENT layers in one launch (a deconvolution next to the stride-2 conv that reads the same merge output):
@@ -492,17 +503,17 @@ struct CgLayerPair {
     int na;                    // workgroups of A (a multiple of 8); the rest belong to B
 };
 
-template <int MM, int MW, int G, int WNC>
+template <int MM, int MW, int G, int WNC, int NTW = 1>
 __global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_pair_kernel(CgLayerPair p)
 {
     const int bid = blockIdx.x;
     const bool isA = bid < p.na;
     const CgLayer &L = isA ? p.A : p.B;
-    const int nby = L.Cout / (32 * WNC), nbx = (L.B * L.Lout + 32 * MW - 1) / (32 * MW);
+    const int nby = L.Cout / (32 * WNC * NTW), nbx = (L.B * L.Lout + 32 * MW - 1) / (32 * MW);
     const int t = cg_xcd_tile(isA ? bid : bid - p.na, nbx * nby);
     if (t < 0) return;
-    if (isA) cgk_fwd_body<MM, MW, G, WNC>(p.A, t / nby, t % nby);
-    else cgk_fwd_body<MM, MW, G, WNC>(p.B, t / nby, t % nby);
+    if (isA) cgk_fwd_body<MM, MW, G, WNC, NTW>(p.A, t / nby, t % nby);
+    else cgk_fwd_body<MM, MW, G, WNC, NTW>(p.B, t / nby, t % nby);
 }
 
 // BN-backward coefficients of one channel from the batch sums (sum dz, sum dz*xhat): gamma*rstd, mean, rstd, dbeta/M,
@@ -1513,19 +1524,33 @@ extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p
             FCN_TRY(prep(l, pp.A));
             FCN_TRY(prep(l2, pp.B));
             const int R2 = d->B * P.Lout[l2];
-            constexpr int TR = 32 * FCN_FT_MW, TC = 32 * FCN_FT_WNC;
-            pp.na = cg_pad8(((R + TR - 1) / TR) * (P.N[l] / TC));
-            const int nb = cg_pad8(((R2 + TR - 1) / TR) * (P.N[l2] / TC));
-            FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_pair_kernel<MM, FCN_FT_MW, FCN_FT_G, FCN_FT_WNC>), dim3(pp.na + nb),
-                                                  dim3(FCN_FT_THREADS), 0, st, pp));
+            constexpr int TR = 32 * FCN_FT_MW, TCW = 32 * FCN_FT_WNC * FCN_FT_NTW;
+            if (FCN_FT_NTW > 1 && P.N[l] % TCW == 0 && P.N[l2] % TCW == 0) {
+                pp.na = cg_pad8(((R + TR - 1) / TR) * (P.N[l] / TCW));
+                const int nb = cg_pad8(((R2 + TR - 1) / TR) * (P.N[l2] / TCW));
+                FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_pair_kernel<MM, FCN_FT_MW, FCN_FT_G, FCN_FT_WNC, FCN_FT_NTW>), dim3(pp.na + nb),
+                                                      dim3(FCN_FT_THREADS), 0, st, pp));
+            } else {
+                constexpr int TC = 32 * FCN_FT_WNC;
+                pp.na = cg_pad8(((R + TR - 1) / TR) * (P.N[l] / TC));
+                const int nb = cg_pad8(((R2 + TR - 1) / TR) * (P.N[l2] / TC));
+                FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_pair_kernel<MM, FCN_FT_MW, FCN_FT_G, FCN_FT_WNC, 1>), dim3(pp.na + nb),
+                                                      dim3(FCN_FT_THREADS), 0, st, pp));
+            }
             FCN_CHECK_LAUNCH();
             ++q;
         } else {
             CgLayer L;
             FCN_TRY(prep(l, L));
-            constexpr int TR = 32 * FCN_FT_MW, TC = 32 * FCN_FT_WNC;
-            FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_kernel<MM, FCN_FT_MW, FCN_FT_G, FCN_FT_WNC>),
-                                                  dim3(cg_pad8(((R + TR - 1) / TR) * (P.N[l] / TC))), dim3(FCN_FT_THREADS), 0, st, L));
+            constexpr int TR = 32 * FCN_FT_MW, TCW = 32 * FCN_FT_WNC * FCN_FT_NTW;
+            if (FCN_FT_NTW > 1 && P.N[l] % TCW == 0) {
+                FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_kernel<MM, FCN_FT_MW, FCN_FT_G, FCN_FT_WNC, FCN_FT_NTW>),
+                                                      dim3(cg_pad8(((R + TR - 1) / TR) * (P.N[l] / TCW))), dim3(FCN_FT_THREADS), 0, st, L));
+            } else {
+                constexpr int TC = 32 * FCN_FT_WNC;
+                FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_kernel<MM, FCN_FT_MW, FCN_FT_G, FCN_FT_WNC, 1>),
+                                                      dim3(cg_pad8(((R + TR - 1) / TR) * (P.N[l] / TC))), dim3(FCN_FT_THREADS), 0, st, L));
+            }
             FCN_CHECK_LAUNCH();
         }
     }

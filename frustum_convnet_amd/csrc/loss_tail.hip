@@ -432,6 +432,7 @@ extern "C" int fcn_det_loss_tail(const float *cls_raw, const float *reg_raw, con
         return FCN_E_BADARG;
     if (num_heading_bin != LT_NB || (num_size_cluster != 3 && num_size_cluster != 10)) return FCN_E_LIMIT;
     if (B <= 0 || L2 <= 0) return FCN_E_BADARG;
+    if ((uintptr_t)cls_label & 15) return FCN_E_BADARG;          // the label count reads two int64 per 16-byte load
     LossArgs a;
     a.cls_raw = cls_raw; a.reg_raw = reg_raw; a.cls_label = cls_label; a.ref2 = center_ref2;
     a.box_center = box3d_center; a.box_heading = box3d_heading; a.box_size = box3d_size; a.size_class = size_class;
@@ -477,6 +478,8 @@ extern "C" int fcn_det_loss_tail_rows2(const float *logits, const int64_t *cls_l
         return FCN_E_BADARG;
     if (num_heading_bin != LT_NB || (num_size_cluster != 3 && num_size_cluster != 10)) return FCN_E_LIMIT;
     if (B <= 0 || L2 <= 0) return FCN_E_BADARG;
+    // 16-byte vector accesses: two int64 labels per load, the logits rows as float4 loads, the gradient rows as float4 stores
+    if (((uintptr_t)cls_label & 15) || ((uintptr_t)logits & 15) || ((uintptr_t)dlogits & 15)) return FCN_E_BADARG;
     LossArgs a;
     a.cls_raw = logits; a.reg_raw = nullptr; a.cls_label = cls_label; a.ref2 = center_ref2;
     a.box_center = box3d_center; a.box_heading = box3d_heading; a.box_size = box3d_size; a.size_class = size_class;

@@ -204,9 +204,11 @@ class PointNetFeat(nn.Module):
             net._pool.release(h["ws"])
         self._prefetched = None
 
-    def forward(self, point_cloud, sample_pc, feat=None, one_hot_vec=None, nlc=False, join=True):
+    def forward(self, point_cloud, sample_pc, feat=None, one_hot_vec=None, nlc=False, join=True, after_front=None):
         """join=False (fused FCN path): the caller's stream is NOT made to wait for the scales; self.done_events holds one
-        event per scale for the consumer to wait on (fcn_convnet_forward2 does, map by map)."""
+        event per scale for the consumer to wait on (fcn_convnet_forward2 does, map by map).  after_front: called on the
+        caller's stream right behind the front's launches, before the scales fork (PointNetDet starts the FCN's weight packing
+        there: forked in front of the front, its 1650 workgroups delayed the front's light launches)."""
         if one_hot_vec is not None:
             assert self.num_vec == one_hot_vec.shape[1]
         nets = self.nets
@@ -214,6 +216,8 @@ class PointNetFeat(nn.Module):
         self.done_events = None
         if not (self.concurrent_scales and point_cloud.is_cuda) or os.environ.get("FCN_SERIAL", "0") == "1":
             self.drop_prefetch()
+            if after_front is not None:
+                after_front()
             return tuple(net.forward_pooled(point_cloud, ref, one_hot_vec, nlc) for net, ref in zip(nets, sample_pc))
         # The scales are independent until the FCN: all but the last run on HIP streams forked from the current one and
         # the widest (the last scale, the long pole) on the current stream itself, captured as parallel branches of the step's
@@ -244,14 +248,21 @@ class PointNetFeat(nn.Module):
             else:
                 prepared = [nets[s].prepare_pooled(point_cloud, sample_pc[s], one_hot_vec, nlc) for s in range(ns)]
                 group_compact(prepared, point_cloud)
+        if after_front is not None:
+            after_front()
         fork.record(cur)
         handles = [None] * ns
         s4_forked = bool(self.topo & 1)
-        sts = [streams[i] for i in range(ns - 1)] + [streams[ns - 1] if s4_forked else cur]
+        # FCN_SCALE_STREAMS="0,0,2" (tuning): which forked stream each of the first ns-1 scales runs on (default: one each)
+        smap = [int(v) for v in os.environ.get("FCN_SCALE_STREAMS", "").split(",") if v != ""]
+        smap = smap if len(smap) == ns - 1 else list(range(ns - 1))
+        sts = [streams[smap[i]] for i in range(ns - 1)] + [streams[ns - 1] if s4_forked else cur]
         heavy_first = (ns - 1,) + tuple(range(ns - 2, 1, -1)) + (0, 1)          # 4 scales: (3, 2, 0, 1)
+        waited = set()
         for s in (((ns - 1,) + tuple(range(ns - 1))) if s4_forked else heavy_first):
             st = sts[s]
-            if st is not cur:
+            if st is not cur and id(st) not in waited:
+                waited.add(id(st))
                 st.wait_event(fork)
             with torch.cuda.stream(st):
                 if prepared is not None:
@@ -461,7 +472,7 @@ class PointNetDet(nn.Module):
             return torch.zeros(1, dtype=torch.int32, device=device if device is not None else self.reg_out.weight.device)
         out = ts[0].clone()
         for t in ts[1:]:
-            out |= t
+            out |= t.to(out.device)       # (pools used on several devices: combine on the first one)
         return out
 
     def check_numerics(self):
@@ -584,11 +595,27 @@ class PointNetDet(nn.Module):
                                       "model.fused_fcn = False explicitly to run the nn.Conv1d modules instead")
         if self.fused_fcn:
             from .fcn_fused import convnet_fused, convnet_prepack
-            # the FCN's weight re-packing depends on the weights only: start it beside the PointNet scales
-            pre = convnet_prepack(self._cn_pool, self.conv_net, self.cls_out, self.reg_out, batch_size,
-                                  [r.shape[2] for r in refs], one_hot_vec, point_cloud.device)
+            # the FCN's weight re-packing depends on the weights only: it runs on a side stream beside the PointNet scales.
+            # FCN_PACK_ORDER: "first" (default) forks it in front of the grouping front; "behind" behind the front's launches;
+            # "beside" forks it in front of them but captures its launch behind theirs
+            pre_box = []
+            order = os.environ.get("FCN_PACK_ORDER", "first")
+            dev = point_cloud.device
+            ev0 = None
+            if order == "beside":
+                ev0 = self._zero_cache.get("pack_ev" + str(dev))
+                if ev0 is None:
+                    ev0 = self._zero_cache["pack_ev" + str(dev)] = torch.cuda.Event(enable_timing=False)
+                ev0.record(torch.cuda.current_stream(dev))
+            start_pack = lambda: pre_box.append(convnet_prepack(self._cn_pool, self.conv_net, self.cls_out, self.reg_out,
+                                                                batch_size, [r.shape[2] for r in refs], one_hot_vec, dev,
+                                                                after=ev0))
+            if order == "first":
+                start_pack()
             # no join after the scales: the FCN waits for each pooled map right before the first layer that reads it
-            feats = self.feat_net(xyz, refs, None, one_hot_vec, nlc=True, join=False)
+            feats = self.feat_net(xyz, refs, None, one_hot_vec, nlc=True, join=False,
+                                  after_front=None if order == "first" else start_pack)
+            pre = pre_box[0]
             if self.split_backward and self.training and torch.is_grad_enabled():
                 # two-phase backward (backward_split): the FCN sees detached leaves, so loss.backward() stops at the pooled
                 # feature maps and the PointNet scales are differentiated by a second call

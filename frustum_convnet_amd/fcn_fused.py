@@ -287,16 +287,20 @@ def _gather(conv_net, cls_out, reg_out):
     return pt, bufs, bn0
 
 
-def convnet_prepack(pool, conv_net, cls_out, reg_out, B, Ls, one_hot, device):
+def convnet_prepack(pool, conv_net, cls_out, reg_out, B, Ls, one_hot, device, after=None):
     """Starts the weight re-packing of the coming convnet_fused() call on the pool's side stream (forked from the current
-    stream) and returns the handle to pass as `pre`: 25 us that overlap the PointNet scales instead of heading the FCN."""
+    stream, or behind the event `after` recorded on it earlier) and returns the handle to pass as `pre`: 25 us that overlap
+    the PointNet scales instead of heading the FCN."""
     pt, bufs, bn0 = _gather(conv_net, cls_out, reg_out)
     training = conv_net.training
     need_grad = bool(training) and torch.is_grad_enabled() and any(t.requires_grad for t in pt)
     cfgt = (bool(training), float(bn0.eps), bn_momentum(bn0), need_grad)
     cur = torch.cuda.current_stream(device)
     side, ev = pool.pack_stream(device)
-    side.wait_stream(cur)
+    if after is not None:
+        side.wait_event(after)
+    else:
+        side.wait_stream(cur)
     with torch.cuda.stream(side):
         pre = _prepare(pool, cfgt, bufs, one_hot, B, list(Ls), device, pt)
         with torch.cuda.device(device):

@@ -153,8 +153,16 @@ class FlatTrainState:
     def _step_range(self, lo, hi, slot0, what):
         m = self._model()
         if m is not None and getattr(m, "backward_pending", None) is not None and m.backward_pending():
-            raise RuntimeError("FlatTrainState: the model holds a half-finished split backward (forward with split_backward = "
-                               "True, then only phase 1 differentiated): the PointNet gradients are the previous step's")
+            # a split backward is in flight.  Stepping the [FCN + heads] bucket between its two phases is the documented use of
+            # adam_step_bucket (backward_split(loss, between=...): those gradients are final after phase 1); anything that
+            # touches the PointNet range, or any step before phase 1 ran at all, would use the previous step's gradients.
+            cut = min(b[1] for b in self.buckets if b[0] != "pointnet") if len(self.buckets) > 1 else 0
+            pend = getattr(m, "_pending_split", None)                # take_split() handed phase 2 over; phase 1 has run once
+            phase1_done = (getattr(m, "_split", None) is None and pend is not None and pend.leaves is not None and
+                           all(l.grad is not None for l in pend.leaves))      # the cut leaves hold their gradients
+            if lo < cut or not phase1_done or len(self.buckets) == 1:
+                raise RuntimeError("FlatTrainState: the model holds a half-finished split backward (forward with split_backward "
+                                   "= True, phase 2 not differentiated yet): the PointNet gradients are the previous step's")
         if self.device.type != "cuda":
             raise RuntimeError("frustum_convnet_amd: the optimiser step is a HIP kernel (MI355X only); "
                                "there is no CPU fallback")
@@ -244,6 +252,12 @@ class FlatTrainState:
             st = sd["state"].get(key, sd["state"].get(str(key)))
             if st is not None:
                 for f in fields:
+                    if st.get(f) is None:
+                        # torch.optim.SGD keeps momentum_buffer = None until the first step (and with momentum 0): a zero
+                        # buffer below; an Adam entry without its moments is not a state this optimiser can resume from
+                        if self.optimizer == "sgd":
+                            continue
+                        raise ValueError("optimizer state entry %s (%s) has no '%s'" % (key, self.names[k], f))
                     if tuple(st[f].shape) != tuple(p.shape):
                         raise ValueError("optimizer state entry %s (%s): %s has shape %s, the parameter %s" % (
                             key, self.names[k], f, tuple(st[f].shape), tuple(p.shape)))
@@ -270,6 +284,8 @@ class FlatTrainState:
                     continue
                 self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
                 self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                if "step" not in st:
+                    raise ValueError("optimizer state entry of %s has no 'step'" % self.names[self.offsets.index(o)])
                 steps.add(int(float(st["step"])))
             if len(steps) > 1:
                 raise ValueError("per-parameter step counts differ (%s): the flat optimiser keeps one" % sorted(steps))

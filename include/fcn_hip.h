@@ -336,7 +336,9 @@ int fcn_sgd_step_f32(float *param, const float *grad, float *momentum_buf, int64
 
 /* Same with a persistent scratch buffer (fcn_det_loss_tail_scratch_floats(B, L2) floats, zeroed ONCE by the caller, then
  * owned by one stream at a time): no memset node in front of the launch, the workgroup partials are summed in a fixed
- * order (the 16 scalars are reproducible bit for bit), and `total` (1 float, may be NULL) receives a copy of out16[0]. */
+ * order (the 16 scalars are reproducible bit for bit), and `total` (1 float, may be NULL) receives a copy of out16[0].
+ * Alignment (all three loss-tail entry points): cls_label -- and, in the row-major forms, logits and dlogits -- must be 16-byte
+ * aligned (the kernel reads two labels / four logits per load and stores four gradient values at once); FCN_E_BADARG otherwise. */
 int fcn_det_loss_tail_scratch_floats(int B, int L2);
 int fcn_det_loss_tail_rows2(const float *logits, const int64_t *cls_label, const float *center_ref2,
                             const float *box3d_center, const float *box3d_heading, const float *box3d_size,
@@ -381,6 +383,12 @@ int fcn_rotate_nms_3d(const float *dets, const int32_t *valid, const int32_t *un
 
 /* Measurement aid: stores the device's constant-rate wall clock (100 MHz ticks) into *slot, in stream order. */
 int fcn_stamp(uint64_t *slot, void *stream);
+
+/* 16 hex characters: sha256 over the kernel sources, headers and compile flags this library was built from
+ * (frustum_convnet_amd/build.py source_hash()).  The library travels prebuilt; __graft_entry__.smoke() and bench.py compare
+ * it with the tree they run from, so a stale binary cannot pass for the committed sources. */
+const char *fcn_build_hash(void);
+
 
 /* ---------------------------------------------------------------------------------------------
  * On-device construction of one training batch from raw frustum records: replaces the

@@ -288,3 +288,69 @@ def test_two_graph_overlapped_step_equals_single_graph():
     assert int(s1.step_count) == 5 and int(s2.step_count) == 5
     assert torch.equal(s1.grad, s2.grad)
     assert torch.equal(s1.flat, s2.flat)
+
+
+def test_early_bucket_step_between_the_two_backward_phases():
+    """ The documented early step: adam_step_bucket(0) on the [FCN + heads] bucket inside backward_split's
+    between() -- its gradients are final after phase 1 -- then the PointNet bucket after phase 2: same parameters as one
+    adam_step() after the whole backward.  The PointNet bucket (or the whole buffer) between the phases is refused."""
+    from frustum_convnet_amd.train_state import FlatTrainState
+    g = load_golden("car_b4_n512")
+    data = synth.to_torch(golden_inputs(g), "cuda")
+    ma, mb = _model(g), _model(g)
+    for m in (ma, mb):
+        m.train()
+    mb.split_backward = True
+    sa, sb = FlatTrainState(ma, lr=1e-4, weight_decay=1e-4), FlatTrainState(mb, lr=1e-4, weight_decay=1e-4)
+    assert [n for n, _, _ in sb.buckets] == ["fcn+heads", "pointnet"]
+    refused = []
+
+    def between():
+        for bad in (lambda: sb.adam_step_bucket(1), sb.adam_step):
+            try:
+                bad()
+                refused.append(False)
+            except RuntimeError:
+                refused.append(True)
+        sb.adam_step_bucket(0)
+
+    for it in range(2):
+        la, _ = ma(data)
+        ma.backward(la["total_loss"])
+        sa.adam_step()
+        lb, _ = mb(data)
+        mb.backward_split(lb["total_loss"], between=between)
+        sb.adam_step_bucket(1)
+    torch.cuda.synchronize()
+    assert refused == [True] * 4
+    assert torch.equal(sa.flat, sb.flat) and int(sb._step_slots.min()) == 2
+    # before phase 1 has run at all, even the [FCN + heads] bucket is refused
+    lb, _ = mb(data)
+    pending = mb.take_split()
+    with pytest.raises(RuntimeError):
+        sb.adam_step_bucket(0)
+    lb["total_loss"].backward()
+    pending.backward()
+    sb.adam_step()
+
+
+def test_load_state_dict_accepts_torch_sgd_without_momentum_buffers():
+    """(ADVICE r3) torch.optim.SGD keeps momentum_buffer = None until its first step: such a checkpoint loads as zero buffers;
+    an Adam entry without its moments is refused with a ValueError (not a KeyError / AttributeError)."""
+    from frustum_convnet_amd.train_state import FlatTrainState
+    g = load_golden("car_b4_n512")
+    m = _model(g)
+    st = FlatTrainState(m, lr=1e-4, weight_decay=1e-4, optimizer="sgd", momentum=0.9)
+    st.exp_avg.fill_(3.0)
+    n = len(st.params)
+    sd = {"state": {i: {"momentum_buffer": None} for i in range(n)},
+          "param_groups": [{"lr": 1e-3, "momentum": 0.9, "dampening": 0, "weight_decay": 1e-4, "nesterov": False,
+                            "params": list(range(n))}]}
+    st.load_state_dict(sd)
+    assert float(st.exp_avg.abs().max()) == 0.0
+    m2 = _model(g)
+    st2 = FlatTrainState(m2, lr=1e-4, weight_decay=1e-4)
+    sd2 = st2.state_dict()
+    del sd2["state"][0]["exp_avg"]
+    with pytest.raises(ValueError):
+        st2.load_state_dict(sd2)
