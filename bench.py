@@ -230,6 +230,40 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def grouping_op_row(data, cfg_name, reps=20):
+    """The standalone operator of the path -- fcn_query_depth_point_f32, the drop-in for query_depth_point_cuda.forward
+    (ops/query_depth_point/query_depth_point_cuda_kernel.cu:16-65): the (B, L, K) int64 index + counts of every scale of the batch,
+    timed with HIP events on the launch stream.  Algorithmic bytes: z row + window centres in, idx + cnt out."""
+    from frustum_convnet_amd.query_depth_point import query_depth_point
+    from frustum_convnet_amd.det_base import PointNetFeat
+    from frustum_convnet_amd.det_base_sunrgbd import PointNetFeat as PointNetFeat5
+    pc = data["point_cloud"][:, :3, :].contiguous()
+    B, _, N = pc.shape
+    scales = (PointNetFeat5 if cfg_name == "sunrgbd" else PointNetFeat).SCALES
+    strides = CFGS[cfg_name][1]
+    refs = [data["center_ref%d" % (i + 1)] for i in range(len(scales))]
+
+    def run():
+        for (mlp, K), dz, ref in zip(scales, strides, refs):
+            query_depth_point(float(dz), int(K), pc, ref)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = sum(B * (4.0 * N + 4.0 * r.shape[2] + 8.0 * r.shape[2] * K + 4.0 * r.shape[2]) for (mlp, K), r in zip(scales, refs))
+    tb = nbytes / (ms * 1e-3) / 1e12
+    return {"entry": "fcn_query_depth_point_f32[%d scales, API form: int64 idx + cnt]" % len(scales), "calls_per_step": len(scales),
+            "ms_per_step": round(ms, 5), "bound": "hbm", "bytes_algorithmic": nbytes, "bytes_per_frustum": round(nbytes / B),
+            "achieved_tbps": round(tb, 4), "frac": round(tb / PEAK_HBM_TBPS, 4),
+            "note": "standalone operator (the model itself uses the fused front, fcn_pn_group_compact2, which never writes idx)"}
+
+
 def pmc_traffic(kind, entry=None):
     """HBM bytes from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, written by tools/pmc_summarize.py from
     tools/gpu_traffic.sh) -- only when they were measured on THESE kernel sources.  kind "step": the whole-step record;
@@ -454,7 +488,27 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
     wall = float(tt.item())
     nstep = even(rounds * steps)
     Ls = [data["center_ref%d" % i].shape[2] for i in range(1, 6) if ("center_ref%d" % i) in data]
-    return {"model": model, "state": state, "data": data, "graphs": graphs, "overlap": overlap, "optim": optim,
+    comm = None
+    if world > 1:
+        # what the exchange is made of, measured beside the timed region: ranks the communicator really has (an all-reduce of
+        # ones) and the time of each bucket's all-reduce alone (events on the current stream around a blocking call)
+        ones = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(ones)
+        comm = {"backend": torch.distributed.get_backend(), "ranks": int(round(float(ones.item()))), "buckets": []}
+        for name, lo, hi in state.buckets:
+            buf = torch.zeros(hi - lo, device=dev)
+            for _ in range(2):
+                torch.distributed.all_reduce(buf)
+            torch.cuda.synchronize()
+            b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            b0.record()
+            for _ in range(5):
+                torch.distributed.all_reduce(buf)
+            b1.record()
+            torch.cuda.synchronize()
+            comm["buckets"].append({"name": name, "mbytes": round(4e-6 * (hi - lo), 3), "allreduce_ms": round(b0.elapsed_time(b1) / 5, 4)})
+        torch.distributed.barrier()
+    return {"model": model, "state": state, "data": data, "graphs": graphs, "overlap": overlap, "optim": optim, "comm": comm,
             "rounds": rounds, "nstep": nstep, "wall": wall, "ms_per_step": wall * 1e3 / nstep,
             "gpu_event_ms_per_step": e0.elapsed_time(e1) / nstep, "final_loss": float(loss.item()),
             "steps_per_graph": steps_per_graph, "prefetch": prefetch,
@@ -468,7 +522,13 @@ def workload_name(cfg_name, batch, npoint, Ls, optim=True, extra=""):
 
 # the other BASELINE.json configurations (4: people, 5: refine; 2's bf16 throughput mode) and SURVEY f-4's SUN-RGBD variant,
 # each timed in a short window of the same kind after the headline line's measurement (N = 1 only)
-OTHER_CONFIGS = (("people", "split"), ("refine", "split"), ("sunrgbd", "split"), ("car", "bf16"), ("car", "bf16ops"))
+# (cfg, precision, Npoint or None = the yaml's): BASELINE.json configs[3] quotes the people config at Npoint = 512, its yaml
+# (cfgs/det_sample_people.yaml:28 of the reference) says 1024 -- both are run; car in the exact-fp32 MFMA mode sits beside the
+# split-precision headline
+OTHER_CONFIGS = (("car", "f32", None), ("people", "split", None), ("people", "split", 512), ("refine", "split", None),
+                 ("sunrgbd", "split", None), ("car", "bf16", None), ("car", "bf16ops", None))
+DTYPE_LABEL = {"split": "f32 (fp32 operands split into two 16-bit parts, 3 MFMAs per product, fp32 accumulate)", "f32": "f32",
+               "bf16": "bf16", "bf16ops": "bf16"}
 
 
 def measure_inference(cfg_name, batch, dev, min_time=0.35, prec="split"):
@@ -510,12 +570,12 @@ def measure_inference(cfg_name, batch, dev, min_time=0.35, prec="split"):
             "timed_steps": n, "timed_seconds": round(wall, 4)}
 
 
-def other_configs(a, dev, min_time=0.35):
+def other_configs(a, dev, min_time=0.3):
     out = []
-    for cfg_name, prec in OTHER_CONFIGS:
+    for cfg_name, prec, npt in OTHER_CONFIGS:
         try:
-            m = measure(a, cfg_name, prec, 20, 10, min_time, dev, 0, 1)
-            out.append({"cfg": cfg_name, "precision": prec, "dtype": "bf16" if prec.startswith("bf16") else "f32",
+            m = measure(a, cfg_name, prec, 20, 10, min_time, dev, 0, 1, npoint=npt)
+            out.append({"cfg": cfg_name, "precision": prec, "dtype": DTYPE_LABEL[prec],
                         "workload": workload_name(cfg_name, m["batch"], m["npoint"], m["Ls"], m["optim"]),
                         "value": round(m["batch"] / (m["ms_per_step"] / 1e3), 2), "unit": "frustums/s",
                         "ms_per_step": round(m["ms_per_step"], 4), "timed_steps": m["nstep"],
@@ -565,12 +625,13 @@ def main():
         return
     Ls = m["Ls"]
     out = {
-        "metric": "frustums/sec (train fwd+bwd) KITTI-car B=32 N=1024",
+        "metric": "frustums/sec (train fwd+bwd) %s B=%d N=%d" % (
+            {"car": "KITTI-car", "people": "KITTI-people", "refine": "KITTI-refine", "sunrgbd": "SUN-RGBD"}[a.cfg], a.batch, npoint),
         "value": round(a.batch * world / (ms_per_step / 1e3), 2),
         "unit": "frustums/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "rounds": rounds,
         "timed_steps": nstep, "timed_seconds": round(wall, 4),
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": {"split": "f32", "f32": "f32", "bf16": "bf16", "bf16ops": "bf16"}[prec],
+        "vs_baseline": None, "dtype": DTYPE_LABEL[prec],
         "mfma_operands": {"split": "fp16x3 (forward) / bf16x3 (backward) split of fp32 operands, fp32 accumulate: fp32-class",
                           "f32": "fp32 (v_mfma_f32_32x32x2_f32)",
                           "bf16": "bf16 single term, fp32 accumulate; y2/y3/dy3/dz2 and the FCN y/dz arenas stored as bf16",
@@ -588,6 +649,9 @@ def main():
         "gpu_event_ms_per_step": round(gpu_event_ms, 4),
         "final_loss": round(final_loss, 5),
     }
+    if m.get("comm"):
+        out["rccl_ranks"] = m["comm"]["ranks"]
+        out["comm"] = m["comm"]
     if world == 1 and not a.no_roofline:
         try:
             model.split_backward = False
@@ -614,6 +678,10 @@ def main():
                 rl["traffic_note"] = why
             rl["how"] = ("top-time C-ABI entry point of one step: HIP events on its launch stream around the call, eager "
                          "launches, mean of 5 steps; FLOPs = executed (entry-space rows, real channels)")
+            try:
+                rows.append(grouping_op_row(data, a.cfg))
+            except Exception as e:  # noqa
+                rows.append({"entry": "fcn_query_depth_point_f32", "error": "%s: %s" % (type(e).__name__, e)})
             rl["kernels"] = rows
             out["roofline"] = rl
         except Exception as e:  # noqa

@@ -10,6 +10,7 @@ Stand-ins injected before importing models/det_base.py (both unbuildable here, S
                                               feeds no_grad metrics only, det_base.py:480-503)
 
 Usage:  python tests/golden/make_golden.py           (rewrites the KITTI-model fixtures tests/golden/*.npz)
+        python tests/golden/make_golden.py full [people] [refine] [sunrgbd]   (B = 32 fixtures of those configurations)
         python tests/golden/make_golden.py sunrgbd   (writes sunrgbd_b4_n1024.npz from models/det_base_sunrgbd.py)
 """
 import hashlib
@@ -219,6 +220,18 @@ def main():
         # test a coin flip.
         run_case("sunrgbd_b4_n1024", 4, 1024, (0.1, 0.2, 0.4, 0.8, 1.6), "car", (0.01, 0.05), full_idx=False,
                  sunrgbd=True, seed=1329)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "full":       # full-size (B = 32) fixtures of the other three configurations (round 4)
+        ppl_ = (0.1, 0.2, 0.4, 0.8)
+        which = sys.argv[2:] or ["people", "refine", "sunrgbd"]
+        if "people" in which:
+            run_case("people_b32_n1024", 32, 1024, ppl_, "car", (0.01, 0.05), full_idx=False, logit_samples=(0, 17))
+        if "refine" in which:
+            run_case("refine_b32_n512", 32, 512, ppl_, "uniform", (0.0, 0.0), z_range=(-1.0, 1.0), full_idx=False,
+                     logit_samples=(0, 17))
+        if "sunrgbd" in which:
+            run_case("sunrgbd_b32_n2048", 32, 2048, (0.1, 0.2, 0.4, 0.8, 1.6), "car", (0.01, 0.05), full_idx=False,
+                     sunrgbd=True, seed=1329, logit_samples=(0, 17))
         return
     testpy_case()
     car = (0.25, 0.5, 1.0, 2.0)

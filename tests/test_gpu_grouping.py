@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import grouping
-from helpers import load_golden, golden_inputs, NSAMPLE
+from helpers import load_golden, golden_inputs, NSAMPLE, adversarial_grouping_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -93,3 +93,41 @@ def test_double_inputs_are_narrowed_like_the_reference_kernel():
     assert torch.equal(i64, i32) and torch.equal(c64, c32)
     e_idx, e_cnt = grouping.query_depth_point_numpy(0.2, 8, xyz1.float().cpu().numpy(), xyz2.float().cpu().numpy())
     assert np.array_equal(i64.cpu().numpy(), e_idx) and np.array_equal(c64.cpu().numpy(), e_cnt)
+
+
+def test_adversarial_inputs():
+    """ NaN / +-inf depths, dis_z in {0, < 0, inf}, nsample > n, >= 65 equal-depth hits straddling the nsample
+    cut and the 64-lane chunks, N just above the LDS staging limits: the API kernel (int64 idx + cnt) against both oracle
+    restatements, and the fused front's counts / entry lists against the compacted oracle index."""
+    import entry_ref
+    from frustum_convnet_amd import pointnet_fused as pf
+    for name, dis, ns, xyz1, xyz2 in adversarial_grouping_cases():
+        with np.errstate(invalid="ignore"):
+            e_idx, e_cnt = grouping.query_depth_point_c(dis, ns, xyz1, xyz2)
+            n_idx, n_cnt = grouping.query_depth_point_numpy(dis, ns, xyz1, xyz2)
+        assert np.array_equal(e_idx, n_idx) and np.array_equal(e_cnt, n_cnt), name
+        idx, cnt = _gpu(dis, ns, xyz1, xyz2)
+        assert np.array_equal(cnt, e_cnt) and np.array_equal(idx, e_idx), name
+        # the model's fused front on the same inputs (it never builds idx: compare the compacted form)
+        if ns > 1024 or not np.isfinite(xyz1).all() or not np.isfinite(xyz2).all():
+            continue        # (entry rows of non-finite points are NaN != NaN; K is bounded by the descriptor)
+        B, M = xyz2.shape[0], xyz2.shape[2]
+        pc, ref = torch.from_numpy(xyz1).cuda(), torch.from_numpy(xyz2).cuda()
+        C = (64, 64, 128)
+        g = torch.Generator().manual_seed(5)
+        plist = []
+        for i, (co, ci) in enumerate(((C[0], 3), (C[1], C[0]), (C[2], C[1]))):
+            plist += [(torch.randn(co, ci, generator=g) * 0.1).cuda(), torch.ones(co).cuda(), torch.zeros(co).cuda()]
+        bufs = ([torch.zeros(c).cuda() for c in C], [torch.ones(c).cuda() for c in C],
+                [torch.zeros((), dtype=torch.int64).cuda() for c in C])
+        pool = pf.WorkspacePool()
+        h = pf._acquire(pool, (float(dis), ns, True, 1e-5, 0.1, False, True), pc, ref, None, bufs, plist, False)
+        pf.group_compact([h], pc)
+        torch.cuda.synchronize()
+        c = entry_ref.compact(torch.from_numpy(e_idx), torch.from_numpy(e_cnt), torch.from_numpy(xyz1), torch.from_numpy(xyz2), ns)
+        ws = h["ws"]
+        assert torch.equal(ws.cnt.cpu(), torch.from_numpy(e_cnt)), name
+        assert torch.equal(ws.woff.cpu(), c["woff"]), name
+        for b in range(B):
+            n = int(c["nent"][b])
+            assert torch.equal(ws.ent.cpu()[b, :n], c["ent"][b, :n]) and torch.equal(ws.ewin.cpu()[b, :n], c["ewin"][b, :n]), (name, b)

@@ -31,8 +31,11 @@ def _model(g):
     return m.cuda()
 
 
+# (the *_b32_* fixtures are the FULL-SIZE batches of BASELINE.json's configurations -- tile edges and split counts depend on
+# the size -- captured from the reference by `make_golden.py full`: logits of two samples, all losses, every gradient norm)
 @pytest.mark.parametrize("case", ["car_b4_n512", "car_b4_n512_uniform", "people_b2_n512", "refine_b4_n512",
-                                  "car_b32_n1024", "sunrgbd_b4_n1024"])
+                                  "car_b32_n1024", "sunrgbd_b4_n1024", "people_b32_n1024", "refine_b32_n512",
+                                  "sunrgbd_b32_n2048"])
 def test_train_eval_parity(case):
     g = load_golden(case)
     data = synth.to_torch(golden_inputs(g), "cuda")
@@ -218,17 +221,26 @@ def test_fused_convnet_matches_module_path(case):
         assert torch.allclose(res[True][4][k].float(), v.float(), rtol=1e-4, atol=1e-5), k
     ref, _ = _fp64_oracle_grads(g, data_np)
     gscale = max(float(v.abs().max()) for v in ref.values())
-    worst = (0.0, "")
+    worst = (0.0, "", 0.0)
     for k, gref in ref.items():
         sc = float(gref.abs().max())
         d_f = float((res[True][3][k].double().cpu() - gref).abs().max())
         d_m = float((res[False][3][k].double().cpu() - gref).abs().max())
-        worst = max(worst, (d_f / max(sc, 1e-12), k))
+        # tensors whose fp64 gradient is ~0 (a BatchNorm bias in front of another BatchNorm: exact cancellation) have no
+        # meaningful RELATIVE error -- they are held to the absolute term below and reported in absolute units
+        if sc > 1e-6 * gscale:
+            worst = max(worst, (d_f / sc, k, d_f))
         # the hand-written path must be within 3e-3 of the tensor max of the fp64 value (measured worst on MI355X: 1.4e-3,
         # a deconvolution's BN bias of the people fixture), or at least no worse than twice the error of the vendor-library
         # (MIOpen) fp32 path on the same tensor
         assert d_f <= max(3e-3 * sc + 2e-6 * gscale, 2.0 * d_m), (k, d_f, d_m, sc)
-    print(case, "worst fused-path gradient error vs fp64: %.2e of max (%s)" % worst)
+    print(case, "worst fused-path gradient error vs fp64: %.2e of the tensor's max (%s, absolute %.2e; largest gradient %.2e)"
+          % (worst + (gscale,)))
+    tiny = [(float((res[True][3][k].double().cpu() - v).abs().max()), k) for k, v in ref.items()
+            if float(v.abs().max()) <= 1e-6 * gscale]
+    if tiny:
+        print(case, "near-zero reference tensors (max <= 1e-6 of the largest gradient): worst ABSOLUTE error %.2e (%s), bar %.2e"
+              % (max(tiny) + (2e-6 * gscale,)))
 
 
 def test_gradients_vs_fp64_oracle():

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import grouping
-from helpers import load_golden, golden_inputs, NSAMPLE
+from helpers import load_golden, golden_inputs, NSAMPLE, adversarial_grouping_cases
 
 
 def _expect_from_mask(mask, nsample):
@@ -71,3 +71,17 @@ def test_edge_cases():
     # zero-size inputs
     idx, cnt = grouping.query_depth_point_c(1.0, 4, np.zeros((2, 3, 0), np.float32), np.zeros((2, 3, 5), np.float32))
     assert idx.shape == (2, 5, 4) and not idx.any() and not cnt.any()
+
+
+def test_adversarial_inputs_both_restatements_and_the_mask_criterion_agree():
+    """NaN / inf depths, dis_z <= 0, nsample > n, equal-depth runs across the nsample cut, N above the staging limits: the C
+    restatement, the independent numpy formulation and test.py's mask criterion give the same idx / cnt (the GPU test
+    test_gpu_grouping.py::test_adversarial_inputs holds the HIP kernels to the same arrays)."""
+    for name, dis, ns, xyz1, xyz2 in adversarial_grouping_cases():
+        with np.errstate(invalid="ignore"):
+            mask = np.abs(xyz2[:, 2, :, None] - xyz1[:, 2, None, :]) < np.float32(dis)
+            e_idx, e_cnt = _expect_from_mask(mask, ns)
+            ic, cc = grouping.query_depth_point_c(dis, ns, xyz1, xyz2)
+            inp, cn = grouping.query_depth_point_numpy(dis, ns, xyz1, xyz2)
+        assert np.array_equal(ic, e_idx) and np.array_equal(cc, e_cnt), name
+        assert np.array_equal(inp, e_idx) and np.array_equal(cn, e_cnt), name
