@@ -90,8 +90,22 @@ def _capture_feats(model):
     return store, h
 
 
+def _oracle64_grads(model, data_np, strides):
+    """The fp64 referee: oracle/det_ref.py evaluated in double precision on the same weights and batch -> {name: grad}."""
+    from oracle import det_ref
+    sd = {k: (v.detach().clone().double() if v.dtype.is_floating_point else v.detach().clone())
+          for k, v in model.state_dict().items()}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    d64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in synth.to_torch(data_np).items()}
+    _, _, lo = det_ref.forward(sd, d64, tuple(strides), training=True)
+    lo["total_loss"].backward()
+    return {k: v.grad for k, v in sd.items() if v.dtype.is_floating_point and v.grad is not None}, float(lo["total_loss"])
+
+
 def run_case(name, batch, npoint, strides, variant, tilt, z_range=None, full_idx=True, logit_samples=None,
-             grads=True, seed=1234, sunrgbd=False):
+             grads=True, seed=1234, sunrgbd=False, oracle64=False):
     nscale = len(strides)
     if sunrgbd:     # models/det_base_sunrgbd.py with the SUN-RGBD class table (cfgs/det_sample_sunrgbd.yaml)
         from oracle.det_ref import MEAN_SIZE_SUNRGBD, NSAMPLE_SUNRGBD
@@ -126,6 +140,10 @@ def run_case(name, batch, npoint, strides, variant, tilt, z_range=None, full_idx
             assert idx.max() < 32768
             out["idx%d" % (s + 1)] = idx.astype(np.int16)
 
+    g64 = None
+    if oracle64:          # BEFORE the reference's forward updates the running statistics (train mode does not read them)
+        g64, loss64 = _oracle64_grads(model, data_np, strides)
+        out["loss64_total"] = np.array(loss64)
     # training-mode forward + backward through the reference modules
     model.train()
     store, h = _capture_feats(model)
@@ -151,6 +169,8 @@ def run_case(name, batch, npoint, strides, variant, tilt, z_range=None, full_idx
             gn.append(float(p.grad.double().norm()))
         out["grad_names"] = np.array([k for k, _ in model.named_parameters()])
         out["grad_norms"] = np.array(gn)
+        if g64 is not None:     # the same norms from the fp64 oracle: how far the reference's own fp32 arithmetic sits from them
+            out["grad_norms64"] = np.array([float(g64[k].norm()) for k, _ in model.named_parameters()])
         named = dict(model.named_parameters())
         for k in ("cls_out.weight", "cls_out.bias", "reg_out.weight", "reg_out.bias",
                   "feat_net.pointnet1.conv1.0.weight", "feat_net.pointnet1.conv1.1.weight",
@@ -164,6 +184,11 @@ def run_case(name, batch, npoint, strides, variant, tilt, z_range=None, full_idx
             if g.size > 40000:
                 g = g.reshape(g.shape[0], -1)[::8, ::4]
             out["grad::" + k] = g.copy()
+            if g64 is not None:
+                q = g64[k].numpy()
+                if q.size > 40000:
+                    q = q.reshape(q.shape[0], -1)[::8, ::4]
+                out["grad64::" + k] = q.copy()
     # running stats after one step
     sd = model.state_dict()
     rs_names, rs_vals = [], []
@@ -225,13 +250,13 @@ def main():
         ppl_ = (0.1, 0.2, 0.4, 0.8)
         which = sys.argv[2:] or ["people", "refine", "sunrgbd"]
         if "people" in which:
-            run_case("people_b32_n1024", 32, 1024, ppl_, "car", (0.01, 0.05), full_idx=False, logit_samples=(0, 17))
+            run_case("people_b32_n1024", 32, 1024, ppl_, "car", (0.01, 0.05), full_idx=False, logit_samples=(0, 17), oracle64=True)
         if "refine" in which:
             run_case("refine_b32_n512", 32, 512, ppl_, "uniform", (0.0, 0.0), z_range=(-1.0, 1.0), full_idx=False,
-                     logit_samples=(0, 17))
+                     logit_samples=(0, 17), oracle64=True)
         if "sunrgbd" in which:
             run_case("sunrgbd_b32_n2048", 32, 2048, (0.1, 0.2, 0.4, 0.8, 1.6), "car", (0.01, 0.05), full_idx=False,
-                     sunrgbd=True, seed=1329, logit_samples=(0, 17))
+                     sunrgbd=True, seed=1329, logit_samples=(0, 17), oracle64=True)
         return
     testpy_case()
     car = (0.25, 0.5, 1.0, 2.0)

@@ -56,9 +56,19 @@ def test_train_eval_parity(case):
         named = dict(m.named_parameters())
         worst = 0.0
         nmax = float(np.max(g["grad_norms"]))
-        for nm, ref in zip(g["grad_names"], g["grad_norms"]):
+        # full-size fixtures also carry the fp64 oracle's norms (make_golden.py full): at B = 32 the reference's OWN fp32 gradients
+        # sit up to 6.5e-3 of a tensor's max from the fp64 values (people, pointnet2.conv2), so the reference numbers get a bar
+        # widened by twice their own distance from fp64, and the fp64 values are the tight referee
+        n64 = g["grad_norms64"] if "grad_norms64" in g.files else None
+        worst64 = 0.0
+        for i, (nm, ref) in enumerate(zip(g["grad_names"], g["grad_norms"])):
             got = float(named[str(nm)].grad.double().norm())
             bar = 3e-4 * max(ref, 1e-3) + 2e-5 * nmax
+            if n64 is not None:
+                bar += 2.0 * abs(float(n64[i]) - ref)
+                bar64 = 3e-4 * max(float(n64[i]), 1e-3) + 2e-5 * nmax
+                worst64 = max(worst64, abs(got - float(n64[i])) / bar64)
+                assert abs(got - float(n64[i])) <= bar64, (nm, got, float(n64[i]), "fp64 referee")
             worst = max(worst, abs(got - ref) / bar)
             # the reference's fp32 norms themselves sit up to 3.5e-3 from the fp64 value on the conv1/BN tensors (two CPU fp32
             # evaluations of the same graph differ by that much), but the HIP path lands much closer to the reference's
@@ -66,13 +76,21 @@ def test_train_eval_parity(case):
             # plus an absolute term for tensors whose gradient is ~0
             assert abs(got - ref) <= bar, (nm, got, ref)
         print(case, "worst grad-norm difference: %.2f of its bar (3e-4 relative + 2e-5 of the largest norm)" % worst)
+        if n64 is not None:
+            print(case, "worst grad-norm difference vs the fp64 oracle: %.2f of its bar (3e-4 relative + 2e-5 of the largest)" % worst64)
         for k in g.files:
             if k.startswith("grad::"):
                 gr = named[k[6:]].grad.detach().cpu().numpy()
                 if gr.size > 40000:
                     gr = gr.reshape(gr.shape[0], -1)[::8, ::4]
                 ref = g[k]
-                assert np.abs(gr - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-7, k
+                extra = 0.0
+                if ("grad64::" + k[6:]) in g.files:
+                    r64 = g["grad64::" + k[6:]]
+                    extra = 2.0 * float(np.abs(ref - r64).max())
+                    e64 = float(np.abs(gr - r64).max()) / float(np.abs(r64).max())
+                    assert e64 <= 1e-4, (k, e64, "elementwise vs the fp64 oracle")       # (the 8e-5 bar of test_gradients_vs_fp64_oracle, rounded up)
+                assert np.abs(gr - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-7 + extra, k
     sd = m.state_dict()
     off = 0
     for nm, n in zip(g["rs_names"], g["rs_sizes"]):
