@@ -66,7 +66,10 @@ def test_train_eval_parity(case):
             bar = 3e-4 * max(ref, 1e-3) + 2e-5 * nmax
             if n64 is not None:
                 bar += 2.0 * abs(float(n64[i]) - ref)
-                bar64 = 3e-4 * max(float(n64[i]), 1e-3) + 2e-5 * nmax
+                # (conv1's weight gradient in front of BN1 is a difference of large sums: at B = 32 both fp32 evaluations -- the
+                # reference's and this one -- sit ~2e-3 from the fp64 value there; "no worse than twice the reference's own
+                # fp32 error" is the bar for such tensors, 3e-4 for the rest)
+                bar64 = max(3e-4 * max(float(n64[i]), 1e-3), 2.0 * abs(float(n64[i]) - ref)) + 2e-5 * nmax
                 worst64 = max(worst64, abs(got - float(n64[i])) / bar64)
                 assert abs(got - float(n64[i])) <= bar64, (nm, got, float(n64[i]), "fp64 referee")
             worst = max(worst, abs(got - ref) / bar)
@@ -89,7 +92,13 @@ def test_train_eval_parity(case):
                     r64 = g["grad64::" + k[6:]]
                     extra = 2.0 * float(np.abs(ref - r64).max())
                     e64 = float(np.abs(gr - r64).max()) / float(np.abs(r64).max())
-                    assert e64 <= 1e-4, (k, e64, "elementwise vs the fp64 oracle")       # (the 8e-5 bar of test_gradients_vs_fp64_oracle, rounded up)
+                    r32 = float(np.abs(ref - r64).max()) / float(np.abs(r64).max())     # the reference's own fp32 error
+                    print(case, "%-44s elementwise vs fp64: %.2e of max (the reference's fp32: %.2e)" % (k[6:], e64, r32))
+                    # 1e-4 of the tensor's max (the 8e-5 bar of test_gradients_vs_fp64_oracle, rounded up), or three times the
+                    # reference's own fp32 error on that tensor (measured worst on MI355X: 2.1x -- SUN-RGBD B = 32,
+                    # pointnet2.conv2.weight, a sum over 3e5 slots where the reference itself is 1.7e-3 from fp64; 0.04x - 1.3x
+                    # on the people / refine fixtures)
+                    assert e64 <= max(1e-4, 3.0 * r32), (k, e64, r32, "elementwise vs the fp64 oracle")
                 assert np.abs(gr - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-7 + extra, k
     sd = m.state_dict()
     off = 0
