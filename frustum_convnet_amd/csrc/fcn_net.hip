@@ -91,6 +91,8 @@ struct CgLayer {
     int Cout, Ktot, Cs;        // GEMM N, GEMM K = KT * sum(C), BN channels (col % Cs)
     const float *Wp;           // packed (Cout, Ktot)
     const u32x4 *Wenc;         // its forward image, split-encoded in MFMA operand order: [Ktot/32][plane][4][Cout] (cg_pack_kernel)
+    const u32x4 *Wgrd;         // its data-gradient image (reduction over the OUTPUT index n): [Cout/8][plane][Ktot] u32x4, element
+                               // (n8, plane, kk) = the packed hi / lo parts of Wp[8*n8 .. 8*n8+7][kk] in the backward operand mode
     const float *bias;         // (nbias) or nullptr
     int nbias;
     float *y;                  // (B*Lout, Cout) pre-BN output
@@ -588,6 +590,10 @@ struct CgPackAll {
     // [Ktot/32][plane][4][N] u32x4 at enc + pre[l] floats -- the forward K loops stage their weights with plain 16-byte copies
     float *enc;
     int mmf;                            // operand mode of the forward GEMMs (MM_*)
+    // data-gradient operand images (CgLayer.Wgrd) at grd + pre[l] floats, encoded in the backward operand mode mmb; written by a
+    // second range of threads of the same launch (one thread = the 8 n-adjacent values of one packed column)
+    float *grd;
+    int mmb;
 };
 
 // One thread = 8 reduction-adjacent elements (kk0 .. kk0 + 7, kk0 % 8 == 0) of one packed row n: they lie in ONE (segment, tap)
@@ -621,6 +627,45 @@ __device__ __forceinline__ void cg_pack_src8(const CgPack &p, const float *__res
         if (ty != 1 || k0 + j < p.nvec) x[j] = src[o0 + (int64_t)j * p.KT];        // (padding columns of the virtual one-hot segment)
 }
 
+// The 8 OUTPUT-adjacent values Wp[n0 .. n0+7][kk] (n0 % 8 == 0): one (segment, tap, channel) decomposition of kk serves all eight
+// rows, the torch weight is walked with the row stride (conv: cin_tot * KT per n; deconv: rows n = j*Cout + co -> stride k per co)
+__device__ __forceinline__ void cg_pack_src8n(const CgPack &p, const float *__restrict__ src, int nrow_real, int n0, int kk,
+                                               float (&x)[8])
+{
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = 0.f;
+    if (p.deconv_k > 0) {               // row n = jj*Cout + co, kk = ci  ->  W[ci][co][jj]
+        const int jj = n0 / p.cout_t, co = n0 % p.cout_t;          // (Cout = 256: the 8 rows share jj)
+        const int64_t o0 = ((int64_t)kk * p.cout_t + co) * p.deconv_k + jj;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (n0 + j < nrow_real) x[j] = src[o0 + (int64_t)j * p.deconv_k];
+        return;
+    }
+    int sg = 0, k2 = kk;
+#pragma unroll
+    for (int s = 0; s < CG_NSEG; ++s)
+        if (s < p.nseg && sg == s && k2 >= p.KT * p.C[s]) { k2 -= p.KT * p.C[s]; sg = s + 1; }
+    const int C = SEL4(sg, p.C[0], p.C[1], p.C[2], p.C[3]), choff = SEL4(sg, p.choff[0], p.choff[1], p.choff[2], p.choff[3]);
+    const int ty = SEL4(sg, p.type[0], p.type[1], p.type[2], p.type[3]);
+    const int tap = k2 / C, k0 = k2 % C;
+    if (ty == 1 && k0 >= p.nvec) return;                            // padding column of the virtual one-hot segment
+    const int64_t o0 = ((int64_t)n0 * p.cin_tot + choff + k0) * p.KT + tap, st = (int64_t)p.cin_tot * p.KT;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (n0 + j < nrow_real) x[j] = src[o0 + j * st];
+}
+
+template <int MM>
+__device__ __forceinline__ void cg_pack_store8n(const CgPack &p, int n0, int kk, const float (&x)[8], u32x4 *__restrict__ img)
+{
+    u32x4 hi, lo;
+    enc8<MM>(x, hi, lo);
+    const int n8 = n0 >> 3;
+    img[((int64_t)n8 * 2 + 0) * p.Ktot + kk] = hi;
+    img[((int64_t)n8 * 2 + 1) * p.Ktot + kk] = lo;
+}
+
 template <int MM>
 __device__ __forceinline__ void cg_pack_store8(const CgPack &p, int n, int kk0, const float (&x)[8], float *__restrict__ dst,
                                                 u32x4 *__restrict__ img)
@@ -639,8 +684,27 @@ __device__ __forceinline__ void cg_pack_store8(const CgPack &p, int n, int kk0, 
 
 __global__ void cg_pack_kernel(CgPackAll t)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t ngrp = t.pre[CN_NLAYER] / 8;
+    if (t.grd && i >= ngrp && i < 2 * ngrp) {           // the data-gradient images: group m of layer l = (n8, kk), kk fastest
+        i -= ngrp;
+        int l = 0;
+#pragma unroll
+        for (int q = 1; q < CN_NLAYER; ++q)
+            if (8 * i >= t.pre[q]) l = q;
+        const int m = (int)(i - t.pre[l] / 8);
+        const int Kt = t.p[l].Ktot;
+        const int n8 = m / Kt, kk = m - n8 * Kt;
+        float x[8];
+        cg_pack_src8n(t.p[l], t.src[l], t.nrow_real[l], 8 * n8, kk, x);
+        u32x4 *img = (u32x4 *)(t.grd + t.pre[l]);
+        if (t.mmb == MM_F32) cg_pack_store8n<MM_F32>(t.p[l], 8 * n8, kk, x, img);
+        else if (t.mmb == MM_BF16X3) cg_pack_store8n<MM_BF16X3>(t.p[l], 8 * n8, kk, x, img);
+        else if (t.mmb == MM_F16X3) cg_pack_store8n<MM_F16X3>(t.p[l], 8 * n8, kk, x, img);
+        else cg_pack_store8n<MM_BF16X1>(t.p[l], 8 * n8, kk, x, img);
+        return;
+    }
+    if (t.grd && i >= 2 * ngrp) i -= ngrp;
     if (i >= ngrp) {
         int64_t j = i - ngrp;
         if (j < (int64_t)t.B * OH_PAD) {
@@ -727,6 +791,69 @@ struct CgBwdStep {
 #define CG_KBWD 2048           // largest reduction length of a data-gradient GEMM (block5_deconv: 8 * 256 output columns)
 #define CGB_SMEM (CGB_LDS + 5 * CG_CMAX + 3 * (CG_KBWD / CGB_KH))
 
+// ------------------------------------------------------------------------------------------------
+// 16-deep kb-major chunk images of the backward data-gradient role (gemm_tile.h "kb-major", two k-blocks instead of four):
+// [plane][2 k-blocks][LDR] u32x4 -- a fragment is ONE ds_read_b128 per operand part (the k-major dword layout needed four
+// ds_read_b32), and the weight operand arrives PRE-ENCODED (CgLayer.Wgrd, cg_pack_kernel) as plain 16-byte copies.
+template <int T>
+struct Kb16 {
+    static constexpr int LDR = T + KB_PAD;
+    static constexpr int U4 = 4 * LDR;         // u32x4 per chunk (2 planes x 2 k-blocks)
+};
+template <int MM, int LDR>
+__device__ __forceinline__ void kb16_store4(u32x4 *img, int r, int kq, float x0, float x1, float x2, float x3)
+{
+    const int kb = kq >> 1, half = kq & 1;      // kq = 0..3: values 4*kq .. 4*kq+3 of the chunk
+    if constexpr (MM == MM_F32) {
+        const v4f v = {x0, x1, x2, x3};
+        *(v4f *)(img + (half * 2 + kb) * LDR + r) = v;
+    } else {
+        float h0, l0, h1, l1;
+        enc2<MM>(x0, x1, h0, l0);
+        enc2<MM>(x2, x3, h1, l1);
+        const v2f_kb h = {h0, h1}, l = {l0, l1};
+        *(v2f_kb *)((float *)(img + kb * LDR + r) + 2 * half) = h;
+        if constexpr (!mm_x1<MM>) *(v2f_kb *)((float *)(img + (2 + kb) * LDR + r) + 2 * half) = l;
+    }
+}
+template <int MM, int NT, int LDRA, int LDRB>
+__device__ __forceinline__ void mma_chunk_kb16(const u32x4 *A, const u32x4 *B, f32x16 (&acc)[1][NT])
+{
+    const int lane = threadIdx.x & 63;
+    const int l31 = lane & 31, lh = lane >> 5;
+    if constexpr (MM == MM_F32) {
+        const float *Af = (const float *)A, *Bf = (const float *)B;
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            const int k = kk + lh, kb = k >> 3, j = k & 7;
+            const float a = Af[(((j >> 2) * 2 + kb) * LDRA + l31) * 4 + (j & 3)];
+            float b[NT];
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn) b[jn] = Bf[(((j >> 2) * 2 + kb) * LDRB + jn * 32 + l31) * 4 + (j & 3)];
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn) acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[jn], acc[0][jn], 0, 0, 0);
+        }
+    } else {
+        constexpr bool X3 = !mm_x1<MM>;
+        const u32x4 ah = A[lh * LDRA + l31];
+        u32x4 al, bh[NT], bl[NT];
+        if constexpr (X3) al = A[(2 + lh) * LDRA + l31];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            bh[j] = B[lh * LDRB + j * 32 + l31];
+            if constexpr (X3) bl[j] = B[(2 + lh) * LDRB + j * 32 + l31];
+        }
+        if constexpr (X3) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[0][j] = mfma16<MM>(ah, bl[j], acc[0][j]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[0][j] = mfma16<MM>(al, bh[j], acc[0][j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[0][j] = mfma16<MM>(ah, bh[j], acc[0][j]);
+    }
+}
+
 // G[rs][k] = sum_tap sum_n dy[r_out(rs,tap)][n] * Wp[n][segoff + tap*C + k]; 32 source rows x 64 source channels by 8
 // K-groups, then the producer-side epilogue: ReLU mask from its pre-BN output, accumulate (second consumer),
 // BN-backward sums.
@@ -742,10 +869,14 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
 {
     // (bf16 throughput mode: dz16 -- this layer's dz / y are bf16 arenas (not the heads' fp32 dlogits); out16 -- `outp` is a
     // layer's dz arena (not a pooled feature map's fp32 gradient); the producer's y behind `ysrc` always is one)
-    constexpr int G = CGB_G, KH = CGB_KH, TMB = 32, LDA = CGB_LDA, NTHR = G * 64;
-    constexpr int NA = TMB * (KH / 4) / 64, NB = KH * 16 / 64;      // 4-vectors of dy (2) and W (4) per lane per chunk
+    constexpr int G = CGB_G, KH = CGB_KH, TMB = 32, NTHR = G * 64;
+    constexpr int LDRA = Kb16<TMB>::LDR, LDRB = Kb16<64>::LDR;
+    constexpr bool X3 = !mm_x1<MM>;
+    constexpr int NA = TMB * (KH / 4) / 64;             // 4-vectors of dy per lane per chunk (2)
+    constexpr int NB = (X3 || MM == MM_F32) ? 4 : 2;    // u32x4 of the encoded weight per lane per chunk: (plane, k-block) rows x 64 columns
     constexpr int ASZ = CGB_ASZ, NCH = CG_KBWD / KH;
-    static_assert(NTHR == CGB_T && NA == 2 && NB == 4 && (ASZ % 4) == 0 && KH * LDA <= ASZ, "dgrad lane mapping");
+    static_assert(NTHR == CGB_T && NA == 2 && KH == 16 && Kb16<TMB>::U4 * 4 <= ASZ && Kb16<64>::U4 * 4 <= CGB_WSZ - ASZ,
+                  "dgrad lane mapping / operand images fit the wave's LDS region");
     float *lds = smem;
     float *coefS = smem + CGB_LDS;
     int *cTap = (int *)(coefS + 5 * CG_CMAX), *cNb = cTap + NCH, *cCh = cNb + NCH;
@@ -754,7 +885,7 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
     const int SLsrc = SEL4(sgi, opaque_s(L.seg[0].Lsrc), opaque_s(L.seg[1].Lsrc), opaque_s(L.seg[2].Lsrc), opaque_s(L.seg[3].Lsrc));
     const int tid = threadIdx.x, g = tid >> 6;
     const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
-    float *As = lds + g * CGB_WSZ, *Bs = As + ASZ;
+    u32x4 *Ai = (u32x4 *)(lds + g * CGB_WSZ), *Bi = (u32x4 *)(lds + g * CGB_WSZ + ASZ);
     const int C = SC, Rs = L.B * SLsrc, Cs = L.Cs;
     const int row0 = bx * TMB, c0 = by * 64;
     const int kq = lane & 3, rb = lane >> 2;            // dy: 4 column quads x 16 rows per pass
@@ -776,7 +907,8 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
     }
     f32x16 acc[1][2];
     acc_zero<1, 2>(acc);
-    v4f rz[NA], ry[NA], rw[NB];
+    v4f rz[NA], ry[NA];
+    u32x4 rw[NB];
     const int ncn = L.Cout / KH, nchunk = L.KT * ncn, nit = (nchunk + G - 1) / G;
     // No integer division inside the reduction loop (each one is ~40 VALU instructions and the loop body is otherwise
     // ~100): the (tap, column base, BN channel base) of every chunk comes from a small LDS table.
@@ -784,6 +916,8 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
         const int tp = tid / ncn, nb = (tid % ncn) * KH;
         cTap[tid] = tp; cNb[tid] = nb; cCh[tid] = nb % Cs;
     }
+    // the weight operand: this tile's 64 columns of the layer's data-gradient image (CgLayer.Wgrd), one column per lane
+    const u32x4 *wg = L.Wgrd + segoff + c0 + lane;
 #define CGK_DGRAD_LOAD(cc)                                                                                            \
     {                                                                                                                 \
         const int c__ = (cc);                                                                                         \
@@ -810,11 +944,8 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
             }                                                                                                         \
         }                                                                                                             \
         if (!((FCN_XG & 2) && xg_later))                                                                              \
-        _Pragma("unroll") for (int i = 0; i < NB; ++i) {       /* rows 2*pr, 2*pr+1 of one column quad (a k pair) */  \
-            const int f = lane + 64 * (i >> 1);                                                                       \
-            const int nn = 2 * (f >> 4) + (i & 1), cq = f & 15;                                                       \
-            rw[i] = ldg4(L.Wp + (int64_t)(nb + nn) * L.Ktot + segoff + tap * C + c0 + 4 * cq);                        \
-        }                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i)          /* row i = (plane i >> 1, k-block i & 1): 16-byte copies */ \
+            rw[i] = ldgu4(wg + ((int64_t)((nb >> 3) + (i & 1)) * 2 + (i >> 1)) * L.Ktot + tap * C);                   \
     }
     bool xg_later = false;
     // first chunk requested BEFORE the coefficient prologue (it depends on neither the BN-backward sums nor the LDS tables):
@@ -849,23 +980,14 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
                     if (hasbn) d[j] = cg_dy(coefS, Cs, chb + j, d[j], yv[j]);
                     d[j] = ok[i] ? d[j] : 0.f;
                 }
-                float e_[4];
-                enc4<MM_ENC_A>(d[0], d[1], d[2], d[3], e_);
-                As[(4 * kq + 0) * LDA + r] = e_[0]; As[(4 * kq + 1) * LDA + r] = e_[1];
-                As[(4 * kq + 2) * LDA + r] = e_[2]; As[(4 * kq + 3) * LDA + r] = e_[3];
+                kb16_store4<MM_ENC_A, LDRA>(Ai, r, kq, d[0], d[1], d[2], d[3]);
             }
 #pragma unroll
-            for (int i = 0; i < NB; i += 2) {
-                const int f = lane + 64 * (i >> 1);
-                v4f hi, lo;
-                enc2x4<MM_ENC_W>(rw[i], rw[i + 1], hi, lo);
-                sts4(Bs + (2 * (f >> 4)) * LDN + 4 * (f & 15), hi);
-                sts4(Bs + (2 * (f >> 4) + 1) * LDN + 4 * (f & 15), lo);
-            }
+            for (int i = 0; i < NB; ++i) Bi[((i >> 1) * 2 + (i & 1)) * LDRB + lane] = rw[i];
         }
         __builtin_amdgcn_wave_barrier();        // (compiler only) the stores above before the operand reads of every lane
         if (c + G < nchunk) CGK_DGRAD_LOAD(c + G);
-        if (!(FCN_XG & 8)) mma_chunk<MM, 1, 2, LDA, LDN, KH>(As, Bs, 0, 0, acc);
+        if (!(FCN_XG & 8)) mma_chunk_kb16<MM, 2, LDRA, LDRB>(Ai, Bi, acc);
         __builtin_amdgcn_wave_barrier();        // ... and those reads before the next chunk's stores
     }
     if (FCN_XG & 16) { if (acc[0][0][0] == 123.456f) outp[0] = 0.f; return; }
@@ -1365,7 +1487,7 @@ extern "C" int fcn_convnet_sizes(const fcn_cn_desc *d, int64_t *out6)
     const int64_t pmax = 4 * cn_partial_elems(d, P);   // (launch parity) x (chain / off-chain step): a step's reduce runs
                                                        // beside the next launch's weight gradients
     out6[0] = O.y[P.nl];      // floats: y (and dz) of all layers
-    out6[1] = 2 * O.wp[P.nl]; // floats: packed weights (N, Ktot) of all layers, then their split-encoded forward images
+    out6[1] = 3 * O.wp[P.nl]; // floats: packed weights (N, Ktot) of all layers, their split-encoded forward images, their data-gradient images
     out6[2] = O.bn[P.nl];     // floats: bn scale/shift/mean/rstd
     out6[3] = (int64_t)FCN_CG_REP * O.st[P.nl];     // doubles: stat (and bstat), FCN_CG_REP replica blocks each
     out6[4] = O.coef[P.nl];   // floats: coef
@@ -1378,7 +1500,8 @@ static void cn_fill_layer(const fcn_cn_desc *d, const fcn_cn_params *p, const Cn
 {
     L.nseg = P.nseg[l]; L.KT = P.KT[l]; L.stride = P.stride[l]; L.pad = P.pad[l];
     L.Lin = P.Lin[l]; L.Lout = P.Lout[l]; L.B = d->B; L.Cout = P.N[l]; L.Ktot = P.Ktot[l]; L.Cs = P.Cs[l];
-    L.Wp = ws->wp + O.wp[l]; L.Wenc = (const u32x4 *)(ws->wp + O.wp[P.nl] + O.wp[l]); L.bias = nullptr; L.nbias = 0; L.y = ws->y + O.y[l]; L.y16 = 1; L.stat = nullptr; L.flags = ws->flags;
+    L.Wp = ws->wp + O.wp[l]; L.Wenc = (const u32x4 *)(ws->wp + O.wp[P.nl] + O.wp[l]);
+    L.Wgrd = (const u32x4 *)(ws->wp + 2 * O.wp[P.nl] + O.wp[l]); L.bias = nullptr; L.nbias = 0; L.y = ws->y + O.y[l]; L.y16 = 1; L.stat = nullptr; L.flags = ws->flags;
     L.eps = d->eps; L.momentum = d->momentum; L.rep_stride = O.st[P.nl];
     for (int s = 0; s < CG_NSEG; ++s) {
         CgSeg &S = L.seg[s];
@@ -1424,10 +1547,12 @@ static int cn_pack(const fcn_cn_desc *d, const fcn_cn_params *p, const CnPlan &P
     }
     t.oh = one_hot; t.oh64 = ws->oh64; t.B = d->B; t.nvec = d->nvec;
     t.z0 = d->training ? ws->stat : nullptr; t.z1 = d->training ? ws->bstat : nullptr; t.nz = FCN_CG_REP * O.st[P.nl];
-    t.enc = ws->wp + O.wp[P.nl];            // second half of the weight arena (fcn_convnet_sizes)
+    t.enc = ws->wp + O.wp[P.nl];            // second third of the weight arena (fcn_convnet_sizes)
     t.mmf = FCN_MM_OF(d->precision, true);
+    t.grd = d->training ? ws->wp + 2 * O.wp[P.nl] : nullptr;      // third third: only a backward reads it
+    t.mmb = FCN_MM_OF(d->precision, false);
     hipLaunchKernelGGL(cg_pack_kernel,
-                       dim3((unsigned)((t.pre[CN_NLAYER] / 8 + (int64_t)d->B * OH_PAD + t.nz + 255) / 256)),
+                       dim3((unsigned)(((t.grd ? 2 : 1) * (t.pre[CN_NLAYER] / 8) + (int64_t)d->B * OH_PAD + t.nz + 255) / 256)),
                        dim3(256), 0, st, t);
     FCN_CHECK_LAUNCH();
     return 0;
