@@ -171,9 +171,18 @@ struct DgradArgs {
 // almost empty); 1140 half tiles on 768 slots are 1.5.
 // Operands in the kb-major images of gemm_tile.h: dy rows built 8 reduction-adjacent channels at a time (one ds_write_b128
 // per part), the weight from its pre-encoded data-gradient image (plain 16-byte copies), fragments by ds_read_b128.
+// LDS bytes of a data-gradient workgroup: operand images + BN-backward coefficients + the tile rows' (ux,uy,uz,w)
+template <int MT, int NT, int WN>
+struct DgradLds {
+    static constexpr int TM = 64 * MT, TN = 32 * NT * WN;
+    static constexpr int U4 = KbTile<TM>::U4 + KbTile<TN>::U4;
+    static constexpr int BYTES = U4 * 16 + 5 * MAXC * 4 + TM * 16;
+};
+
+// The body takes its workgroup index and LDS explicitly: dgrad_kernel below is the plain launch, pn_mid_kernel runs it as one
+// ROLE beside the two weight-gradient GEMMs of the same scale (they all depend on the layer-3 data-gradient launch only).
 template <int MM, int LAYER, int MT, int NT, int WN>
-__global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT * NT <= 2 ? (LAYER == 2 ? FCN_DG2_OCC : 3) : 2, 4)))
-void dgrad_kernel(DgradArgs a)
+__device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, unsigned char *smem_)
 {
     constexpr int NTHR = 128 * WN;
     constexpr int TM = 64 * MT;               // rows of the tile
@@ -183,22 +192,22 @@ void dgrad_kernel(DgradArgs a)
     constexpr int NB = TN * 8 / NTHR;         // u32x4 of the encoded weight per thread per chunk
     constexpr int SUB = 128 / TM;             // workgroups per 128-row tile of the live-tile list
     constexpr int LDSU4 = KbTile<TM>::U4 + KbTile<TN>::U4;
-    __shared__ u32x4 lds4[LDSU4];
-    __shared__ __attribute__((aligned(16))) float coefS[5 * MAXC];
-    __shared__ __attribute__((aligned(16))) float4 uS[TM];      // (ux,uy,uz,w) of the tile rows
+    u32x4 *lds4 = (u32x4 *)smem_;
+    float *coefS = (float *)(smem_ + LDSU4 * 16);
+    float4 *uS = (float4 *)(smem_ + LDSU4 * 16 + 5 * MAXC * 4);      // (ux,uy,uz,w) of the tile rows
     u32x4 *Ab = lds4, *Bb = lds4 + KbTile<TM>::U4;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int ny = a.CPREV / TN;                  // XCD order, column tiles fastest (see fcn_xcd_tile)
-    if (blockIdx.x == 0 && a.cb.dgamma) {         // workgroup 0 always exists (the grid is padded): it exports dgamma / dbeta
+    if (bid == 0 && a.cb.dgamma) {                // workgroup 0 always exists (the grid is padded): it exports dgamma / dbeta
         for (int c = tid; c < a.CRED; c += NTHR) {
             a.cb.dgamma[c] = (float)fcn_rep_sum(a.cb.bstat + a.CRED + c, a.cb.rep_stride);
             a.cb.dbeta[c] = (float)fcn_rep_sum(a.cb.bstat + c, a.cb.rep_stride);
         }
     }
-    const int xt = fcn_xcd_tile(blockIdx.x, SUB * a.tiles[0] * ny);
+    const int xt = fcn_xcd_tile(bid, SUB * a.tiles[0] * ny);
     if (xt < 0) return;
     const int bxi = xt / ny, byi = xt % ny;
     const int lt = bxi / SUB, sub = bxi % SUB;
@@ -405,6 +414,14 @@ void dgrad_kernel(DgradArgs a)
               (unsigned long long)nvalid);
 }
 
+template <int MM, int LAYER, int MT, int NT, int WN>
+__global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT * NT <= 2 ? (LAYER == 2 ? FCN_DG2_OCC : 3) : 2, 4)))
+void dgrad_kernel(DgradArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[DgradLds<MT, NT, WN>::BYTES];
+    dgrad_body<MM, LAYER, MT, NT, WN>(a, (int)blockIdx.x, smem);
+}
+
 // ------------------------------------------------------------------------------------------------
 struct WgradArgs {
     const float4 *ent;
@@ -439,30 +456,37 @@ __device__ __forceinline__ float4 ld4f(const float *base, int64_t e)
 // row's multiplicity, the max-pool's arg-max / routed-gradient maps at the row's window and the BN3-backward coefficients -- so
 // that nothing has to write (B, cap, C3) floats for this kernel to read back: the same fp32 expression, bit-identical dW3.
 // The window ids of a chunk's rows are fetched one chunk ahead (the map addresses depend on them).
+template <int MT, int NT, int RC>
+struct WgradLds {
+    static constexpr int LDA = 64 * MT + 4, LDB = 64 * NT + 4;
+    static constexpr int BYTES = KC * (LDA + LDB) * 4 + (2 + (RC ? 2 : 0)) * WG_TMAX * 4;
+};
+
 template <int MM, int LAYER, int MT, int NT, int RC = 0>
-__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu((LAYER == 3 && !RC) ? 3 : 2, 4))) void wgrad_kernel(WgradArgs a)
+__device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, const int by_, const int bz_, const int gx_,
+                                           unsigned char *smem_)
 {
     constexpr bool XF = LAYER == 2 || RC;               // the A operand is transformed by a BatchNorm backward while staging
     constexpr int LDA = 64 * MT + 4, LDB = 64 * NT + 4;
-    __shared__ __attribute__((aligned(16))) float As[KC * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[KC * LDB];
+    float *As = (float *)smem_;
+    float *Bs = As + KC * LDA;
     // (first row, live rows) of the split's row tiles, looked up ONCE: per chunk, the walk tile list -> frustum -> live-row
     // count was two dependent memory round trips in front of every chunk's loads AND again in front of its staging, and the
     // "load or zero" branches behind it made the compiler wait for every load at once -- tools/pn_probe.py: 45-60 % of the
     // kernel's cycles between them, 13-19 % in the MFMA phase
-    __shared__ int tG0[WG_TMAX], tLeft[WG_TMAX];
-    __shared__ int tBL[RC ? WG_TMAX : 1], tR0[RC ? WG_TMAX : 1];      // RC: b * L and the tile's first row within its frustum
+    int *tG0 = (int *)(Bs + KC * LDB), *tLeft = tG0 + WG_TMAX;
+    int *tBL = tLeft + WG_TMAX, *tR0 = tBL + (RC ? WG_TMAX : 0);      // RC: b * L and the tile's first row within its frustum
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int ntile = a.tiles[0];
-    const int tpb = (ntile + (int)gridDim.x - 1) / (int)gridDim.x;   // live tiles per split, balanced on the device
-    const int t_beg = blockIdx.x * tpb;
+    const int tpb = (ntile + gx_ - 1) / gx_;            // live tiles per split, balanced on the device
+    const int t_beg = bx_ * tpb;
     if (t_beg >= ntile) return;
     const int t_end = min(ntile, t_beg + tpb);
     const int nq = (t_end - t_beg) * 4;                 // 32-row chunks to reduce
-    const int n0 = blockIdx.y * 64 * MT, k0 = blockIdx.z * 64 * NT;
+    const int n0 = by_ * 64 * MT, k0 = bz_ * 64 * NT;
     const int COUT = a.COUT, CIN = a.CIN;
     for (int i = tid; i < t_end - t_beg; i += GT) {     // (launch_wgrad keeps a split within WG_TMAX tiles)
         const int code = a.tiles[4 + t_beg + i];
@@ -655,7 +679,7 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu((LAYER == 3 
 #undef WG_AROW
 #undef WG_BROW
 
-    float *out = a.partial + (int64_t)blockIdx.x * COUT * CIN;
+    float *out = a.partial + (int64_t)bx_ * COUT * CIN;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -668,6 +692,46 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu((LAYER == 3 
             }
     PNP_FLUSH(((unsigned long long)(10 + LAYER) << 48) | ((unsigned long long)COUT << 32) | ((unsigned long long)CIN << 16) |
               (unsigned long long)64);
+}
+
+template <int MM, int LAYER, int MT, int NT, int RC = 0>
+__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu((LAYER == 3 && !RC) ? 3 : 2, 4))) void wgrad_kernel(WgradArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WgradLds<MT, NT, RC>::BYTES];
+    wgrad_body<MM, LAYER, MT, NT, RC>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The three GEMMs of a scale's backward that depend on the layer-3 data-gradient launch ONLY -- conv3's weight gradient (reads
+// dy3), conv2's data gradient and conv2's weight gradient (both read dz2 and the BN2-backward sums) -- as ROLES of one launch:
+// workgroups [0, n_g2) run dgrad<2> tiles, [n_g2, n_g2 + n_w3) the splits of wgrad<3>, the rest those of wgrad<2>.  On one stream
+// the three used to queue behind each other with their reduces in between (8 dependent launches per scale; the narrow scales'
+// chains are a string of 5-30 us kernels that ends the step's backward); here the chain is poolbwd -> dgrad<3> -> this launch ->
+// reduce, reduce, finalise.  The roles share the LDS (the largest of the three) and the register budget of the widest.
+struct PnMidArgs {
+    DgradArgs g2;
+    WgradArgs w3, w2;
+    int n_g2, n_w3;            // workgroups of the first two roles (n_g2 a multiple of 8: the XCD-aware tile order of the role)
+    int ns3, oy3, ns2, oy2;    // split counts and row-tile counts of the two weight-gradient grids (x = split, y, z)
+};
+template <int A, int B>
+struct CMax { static constexpr int V = A > B ? A : B; };
+
+template <int MM, int DNT, int W3M, int W3N, int W2M, int W2N>
+__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(2, 4))) void pn_mid_kernel(PnMidArgs m)
+{
+    constexpr int LB = CMax<CMax<DgradLds<1, DNT, 2>::BYTES, WgradLds<W3M, W3N, 0>::BYTES>::V, WgradLds<W2M, W2N, 0>::BYTES>::V;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LB];
+    const int bid = (int)blockIdx.x;
+    if (bid < m.n_g2) {
+        dgrad_body<MM, 2, 1, DNT, 2>(m.g2, bid, smem);
+    } else if (bid < m.n_g2 + m.n_w3) {
+        const int i = bid - m.n_g2, bx = i % m.ns3, r = i / m.ns3;
+        wgrad_body<MM, 3, W3M, W3N, 0>(m.w3, bx, r % m.oy3, r / m.oy3, m.ns3, smem);
+    } else {
+        const int i = bid - m.n_g2 - m.n_w3, bx = i % m.ns2, r = i / m.ns2;
+        wgrad_body<MM, 2, W2M, W2N, 0>(m.w2, bx, r % m.oy2, r / m.oy2, m.ns2, smem);
+    }
 }
 
 // out[i] = sum over the live splits in a fixed order (deterministic).  The 256-thread workgroup covers 256 / gr
@@ -775,11 +839,17 @@ static void launch_wgrad_mm(const WgradArgs &a, dim3 grid, bool m2, bool n2, hip
     else hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 1, 1, RC>), grid, dim3(GT), 0, st, a);
 }
 
+struct WgradPlan {
+    int nsplit, oy, oz;
+    bool m2, n2;
+};
+
+// split count and tile grid of a weight-gradient GEMM
 template <int LAYER>
-static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, int precision, hipStream_t st, float *out)
+static int plan_wgrad(const WgradArgs &a, int B, int nsplit_cap, WgradPlan &P)
 {
-    const bool m2 = (a.COUT % 128 == 0), n2 = (a.CIN % 128 == 0);
-    const int oy = a.COUT / (m2 ? 128 : 64), oz = a.CIN / (n2 ? 128 : 64);
+    P.m2 = (a.COUT % 128 == 0); P.n2 = (a.CIN % 128 == 0);
+    P.oy = a.COUT / (P.m2 ? 128 : 64); P.oz = a.CIN / (P.n2 ? 128 : 64);
     // FCN_WG_SLOTS workgroup slots per launch (two thirds for the 128 x 128 tile of layer 2), swept on MI355X over 256 / 384 / 768 / 1536:
     // every split writes a full (COUT, CIN) partial that the reduce reads back (at 768 slots 150 MB written + read per
     // step), and fewer, longer splits amortise the per-workgroup prologue -- 768 -> 384 took 14 us off the PointNet backward.
@@ -788,26 +858,70 @@ static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, int precision, hipS
 #ifndef FCN_WG_SLOTS
 #define FCN_WG_SLOTS 256      // (re-swept in round 3 with the replicated sum slots: 384 -> 1.3587, 256 -> 1.3548, 512 -> 1.3630 ms per step)
 #endif
-    const int slots = (LAYER == 2 && m2 && n2) ? (FCN_WG_SLOTS * 2) / 3 : FCN_WG_SLOTS;
+    const int slots = (LAYER == 2 && P.m2 && P.n2) ? (FCN_WG_SLOTS * 2) / 3 : FCN_WG_SLOTS;
     if ((int64_t)B * a.cap * (a.COUT > a.CIN ? a.COUT : a.CIN) >= (int64_t)1 << 31) return FCN_E_LIMIT;   // 32-bit offsets
-    int nsplit = slots / (oy * oz);
+    int nsplit = slots / (P.oy * P.oz);
     if (nsplit < (B * a.tps + WG_TMAX - 1) / WG_TMAX) nsplit = (B * a.tps + WG_TMAX - 1) / WG_TMAX;      // tiles per split <= WG_TMAX
     if (nsplit < 1) nsplit = 1;
     if (nsplit > B * a.tps) nsplit = B * a.tps;
     if (nsplit > nsplit_cap) nsplit = nsplit_cap;
-    dim3 grid(nsplit, oy, oz);
-    if (LAYER == 3 && !a.dy) {             // dy3 rebuilt by the kernel (RC)
-        if (!a.ycur || !a.ewin || !a.amax || !a.gmax || !a.cb.bstat) return FCN_E_BADARG;
-        FCN_MM_SWITCH(FCN_MM_OF(precision, false), (launch_wgrad_mm<MM, LAYER, LAYER == 3 ? 1 : 0>(a, grid, m2, n2, st)));
-    } else {
-        FCN_MM_SWITCH(FCN_MM_OF(precision, false), (launch_wgrad_mm<MM, LAYER>(a, grid, m2, n2, st)));
-    }
-    FCN_CHECK_LAUNCH();
+    P.nsplit = nsplit;
+    return 0;
+}
+
+// the fixed-order sum of the split partials into the torch weight layout
+static int launch_wgrad_reduce(const WgradArgs &a, const WgradPlan &P, hipStream_t st, float *out)
+{
     const int64_t ne = (int64_t)a.COUT * a.CIN;
     if (((uintptr_t)out & 15) != 0) return FCN_E_BADARG;        // the reduce writes 16-byte vectors (include/fcn_hip.h)
+    const int nsplit = P.nsplit;
     const int gr = nsplit >= 128 ? 16 : (nsplit >= 64 ? 8 : (nsplit >= 32 ? 4 : (nsplit >= 16 ? 2 : 1)));
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(ne / (4 * (WR_T / gr)))), dim3(WR_T), 0, st, a.partial, a.tiles,
                        nsplit, gr, ne, out);
+    FCN_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int LAYER>
+static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, int precision, hipStream_t st, float *out)
+{
+    WgradPlan P;
+    FCN_TRY(plan_wgrad<LAYER>(a, B, nsplit_cap, P));
+    dim3 grid(P.nsplit, P.oy, P.oz);
+    if (LAYER == 3 && !a.dy) {             // dy3 rebuilt by the kernel (RC)
+        if (!a.ycur || !a.ewin || !a.amax || !a.gmax || !a.cb.bstat) return FCN_E_BADARG;
+        FCN_MM_SWITCH(FCN_MM_OF(precision, false), (launch_wgrad_mm<MM, LAYER, LAYER == 3 ? 1 : 0>(a, grid, P.m2, P.n2, st)));
+    } else {
+        FCN_MM_SWITCH(FCN_MM_OF(precision, false), (launch_wgrad_mm<MM, LAYER>(a, grid, P.m2, P.n2, st)));
+    }
+    FCN_CHECK_LAUNCH();
+    return launch_wgrad_reduce(a, P, st, out);
+}
+
+// conv2's data gradient + both weight gradients of a scale in ONE launch (pn_mid_kernel).  Supported tile plans: the all-64 one
+// (C1 = C2 = 64, C3 = 128: the narrow scales) and the all-128 one (every width a multiple of 128); -1: not supported, run them apart.
+static int launch_mid(const DgradArgs &g2, const WgradArgs &w3, const WgradArgs &w2, const WgradPlan &P3, const WgradPlan &P2,
+                      int B, int precision, hipStream_t st)
+{
+    if (g2.CRED % 64 || g2.CPREV % 64 || g2.CRED > MAXC) return FCN_E_BADARG;
+    if ((int64_t)B * g2.cap * (g2.CRED > g2.CPREV ? g2.CRED : g2.CPREV) >= (int64_t)1 << 31) return FCN_E_LIMIT;
+    const bool d2 = g2.CPREV % 128 == 0;
+    PnMidArgs m;
+    m.g2 = g2; m.w3 = w3; m.w2 = w2;
+    const unsigned nt = (unsigned)(B * g2.tps);
+    m.n_g2 = (int)((2 * nt * (g2.CPREV / (d2 ? 128 : 64)) + 7) / 8 * 8);
+    m.ns3 = P3.nsplit; m.oy3 = P3.oy; m.n_w3 = P3.nsplit * P3.oy * P3.oz;
+    m.ns2 = P2.nsplit; m.oy2 = P2.oy;
+    const unsigned grid = (unsigned)(m.n_g2 + m.n_w3 + P2.nsplit * P2.oy * P2.oz);
+    const bool all128 = d2 && P3.m2 && P3.n2 && P2.m2 && P2.n2;
+    const bool all64 = !d2 && P3.m2 && !P3.n2 && !P2.m2 && !P2.n2;
+    if (all128) {
+        FCN_MM_SWITCH(FCN_MM_OF(precision, false), hipLaunchKernelGGL((pn_mid_kernel<MM, 2, 2, 2, 2, 2>), dim3(grid), dim3(GT), 0, st, m));
+    } else if (all64) {
+        FCN_MM_SWITCH(FCN_MM_OF(precision, false), hipLaunchKernelGGL((pn_mid_kernel<MM, 1, 2, 1, 1, 1>), dim3(grid), dim3(GT), 0, st, m));
+    } else {
+        return -1;
+    }
     FCN_CHECK_LAUNCH();
     return 0;
 }
@@ -902,6 +1016,34 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
         w.ewin = ws->ewin; w.amax = ws->amax; w.gmax = ws->gmax;
     }
     w.W1 = nullptr; w.COUT = C3; w.CIN = C2;
+    if (!two && ws->partial_both && ws->dy3) {
+        // ONE stream: conv2's data gradient and both weight gradients ride in one launch (they depend on dgrad<3> only), then the
+        // two reduces and the layer-1 finalisation -- 6 launches per scale instead of 8, none of them waiting for a sibling
+        DgradArgs g2 = g;
+        g2.ycur = ws->y2; g2.amax = nullptr; g2.gmax = nullptr; g2.dzcur = ws->dz2;
+        g2.Wenc = (const u32x4 *)(ws->wenc + (int64_t)C2 * C1 + (int64_t)C3 * C2);               // G2 (pn_wenc_off(2))
+        g2.cb.bstat = bs2; g2.cb.gamma = p->gamma[1]; g2.cb.bn = bn2; g2.cb.dgamma = dgamma[1]; g2.cb.dbeta = dbeta[1];
+        g2.dybuf = nullptr; g2.yprev = nullptr; g2.bn_prev = bn1; g2.W1 = p->W[0]; g2.dzprev = nullptr; g2.bstat_prev = bsQ;
+        g2.CRED = C2; g2.CPREV = C1;
+        WgradArgs w2 = w;
+        w2.dy = nullptr; w2.dz = ws->dz2; w2.ycur = ws->y2; w2.yprev = nullptr; w2.bn_prev = bn1;
+        w2.cb.bstat = bs2; w2.cb.gamma = p->gamma[1]; w2.cb.bn = bn2;
+        w2.W1 = p->W[0]; w2.COUT = C2; w2.CIN = C1;
+        w2.partial = ws->partial + (int64_t)ws->nsplit * C3 * C2;      // its own partials: the two weight gradients run at once
+        WgradPlan P3, P2;
+        FCN_TRY(plan_wgrad<3>(w, B, ws->nsplit, P3));
+        FCN_TRY(plan_wgrad<2>(w2, B, ws->nsplit, P2));
+        const int rc = launch_mid(g2, w, w2, P3, P2, B, d->precision, st);
+        if (rc > 0) return rc;
+        if (rc == 0) {
+            FCN_TRY(launch_wgrad_reduce(w, P3, st, dW[2]));
+            FCN_TRY(launch_wgrad_reduce(w2, P2, st, dW[1]));
+            hipLaunchKernelGGL(l1_finalize_kernel, dim3((C1 + 63) / 64), dim3(64), 0, st, bsQ, brs, ws->stat + FCN_STAT_MOM,
+                               p->W[0], p->gamma[0], bn1, C1, M, dW[0], dgamma[0], dbeta[0]);
+            FCN_CHECK_LAUNCH();
+            return 0;
+        }                               // (rc < 0: a tile plan the merged launch has no instance for -- the launches below)
+    }
     if (two) {     // dy3 is final: conv3's weight gradient can run beside the rest of the chain
         e = hipEventRecord((hipEvent_t)events[0], st);
         if (e != hipSuccess) return (int)e;

@@ -271,7 +271,11 @@ class PointNetFeat(nn.Module):
                     handles[s] = nets[s].launch_pooled(point_cloud, sample_pc[s], one_hot_vec, nlc)
         outs = [None] * ns
         done = self._done_events(dev)
-        for s in range(ns):
+        # (FCN_ATTACH_ORDER="1,0,2,3", tuning: the order the autograd nodes are created in -- the backward runs them in reverse,
+        # and ROCm's graph executor assigns its four internal streams to branches in capture order)
+        aord = [int(v) for v in os.environ.get("FCN_ATTACH_ORDER", "").split(",") if v != ""]
+        aord = aord if sorted(aord) == list(range(ns)) else list(range(ns))
+        for s in aord:
             with torch.cuda.stream(sts[s]):
                 outs[s] = nets[s].attach_pooled(handles[s])
                 done[s].record(sts[s])

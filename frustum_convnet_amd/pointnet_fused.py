@@ -63,7 +63,14 @@ class Workspace:
         p = lambda t: None if t is None else t.data_ptr()
         self.c = PnWs(p(self.woff), p(self.ent), p(self.ewin), p(self.tiles), p(self.y2), p(self.y3), p(self.amax),
                       p(self.stat), p(self.bn), p(self.gmax), p(self.dy3), p(self.dz2), p(self.bstat),
-                      p(self.coef), p(self.partial), self.nsplit, p(self.gmom), p(self.wenc), p(self.flags), p(self.pkey))
+                      p(self.coef), p(self.partial), self.nsplit, p(self.gmom), p(self.wenc), p(self.flags), p(self.pkey),
+                      # `partial` above holds both weight gradients' split partials, so the one-stream backward COULD run conv2's data
+                      # gradient and the two weight-gradient GEMMs as roles of one launch (pn_mid_kernel: 6 launches per scale instead
+                      # of 8, bit-identical gradients).  Measured on MI355X (round 4, three alternating pairs): 1.279 vs 1.279-1.289 ms
+                      # per step -- the merged launch lasts as long as the three it replaces one after the other (55-122 us against
+                      # 48-107: the roles share one register / LDS budget and the machine is already full of the other scales'
+                      # kernels) -- so it is an option (FCN_PN_MID=1), off by default
+                      1 if (need_grad and os.environ.get("FCN_PN_MID", "0") == "1") else 0)
 
 
     @staticmethod

@@ -125,3 +125,51 @@ def test_rebuilt_dy3_gives_bit_identical_gradients(case):
     for a, b in zip(out["0"], out["1"]):
         assert torch.equal(a, b)
     assert float(out["0"][2].abs().max()) > 0
+
+
+@pytest.mark.parametrize("case", [(3, 200, 2.5, 32, (64, 64, 128), 0.7), (4, 512, 1.0, 64, (128, 128, 256), 1.0),
+                                  (4, 512, 2.0, 128, (256, 256, 512), 2.0)], ids=lambda c: "C%d-K%d" % (c[4][2], c[3]))
+def test_merged_mid_launch_gives_bit_identical_gradients(case):
+    """One-stream backward of a scale: conv2's data gradient and both weight-gradient GEMMs as roles of ONE launch
+    (pn_mid_kernel, fcn_pn_ws.partial_both = 1) against the three launches one after the other (partial_both = 0).  The same
+    kernels bodies on the same inputs, fixed-order reduces: every gradient of the scale agrees BIT FOR BIT."""
+    import ctypes
+    import os
+    import numpy as np
+    from frustum_convnet_amd import _native, pointnet_fused as pf, synth
+
+    B, N, stride, K, mlp, dist = case
+    dev = torch.device("cuda:0")
+    pc, ref, sd, one_hot = gsc.make_case(B, N, stride, K, mlp, dist)
+    L = ref.shape[2]
+    dfeat = torch.from_numpy(synth.normalish(3, 1, (B, mlp[2] + 3, L)).astype(np.float32)).to(dev).contiguous()
+    out = {}
+    try:
+        for mode in ("0", "1"):
+            os.environ["FCN_PN_MID"] = mode
+            sdg = {k: v.clone().to(dev) for k, v in sd.items()}
+            plist = []
+            for j in (1, 2, 3):
+                plist += [sdg["m.conv%d.0.weight" % j], sdg["m.conv%d.1.weight" % j], sdg["m.conv%d.1.bias" % j]]
+            bufs = ([sdg["m.conv%d.1.running_mean" % j] for j in (1, 2, 3)], [sdg["m.conv%d.1.running_var" % j] for j in (1, 2, 3)],
+                    [sdg["m.conv%d.1.num_batches_tracked" % j] for j in (1, 2, 3)])
+            pool = pf.WorkspacePool()
+            feat, idx, cnt, ws, desc, keep = pf._forward_impl(pool, (float(dist), int(K), True, 1e-5, 0.1), pc.to(dev), ref.to(dev),
+                                                              one_hot.to(dev), bufs, plist, True)
+            assert int(ws.c.partial_both) == int(mode)
+            Wc, gs, bs = keep[0], keep[1], keep[2]
+            dW = [torch.empty_like(w) for w in Wc]
+            dg = [torch.empty_like(g) for g in gs]
+            db = [torch.empty_like(b) for b in bs]
+            params = pf._params_struct(Wc, gs, bs, [None] * 3, [None] * 3, [None] * 3)
+            arr = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
+            rc = _native.lib().fcn_pn_backward(ctypes.byref(desc), ctypes.byref(params), dfeat.data_ptr(), ctypes.byref(ws.c),
+                                               arr(dW), arr(dg), arr(db), _native.current_stream(dev))
+            assert rc == 0, rc
+            torch.cuda.synchronize()
+            out[mode] = [t.detach().cpu() for t in dW + dg + db]
+    finally:
+        os.environ.pop("FCN_PN_MID", None)
+    for a, b in zip(out["0"], out["1"]):
+        assert torch.isfinite(a).all() and float(a.abs().max()) > 0
+        assert torch.equal(a, b)
