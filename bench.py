@@ -361,9 +361,14 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
     prefetch = os.environ.get("FCN_PREFETCH", "1") != "0" and world == 1 and optim
     steps_per_graph = 1
 
+    pf_point = os.environ.get("FCN_PF_POINT", "fcn_fwd")
+    spg = max(2, 2 * (int(os.environ.get("FCN_STEPS_PER_GRAPH", "2")) // 2))      # whole steps per captured graph (even)
+
     def fwd_bwd():
+        if prefetch and pf_point == "fcn_fwd":
+            model.next_batch = data                   # forward() starts the prefetch beside the ConvFeatNet forward
         losses, _ = model(data)
-        if prefetch:
+        if prefetch and pf_point != "fcn_fwd":
             # the next step's batch (the same resident synthetic batch): its batch-only front -- grouping, entry rows, tile lists,
             # input moments -- runs on a side branch beside this step's backward, as a loader prefetches; the work stays INSIDE the
             # timed step, only off its critical path.  Double-buffered workspaces: captured steps alternate between two graphs.
@@ -411,12 +416,12 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
                 glist = []
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode=mode):
-                    for _ in range(2 if prefetch else 1):
+                    for _ in range(spg if prefetch else 1):
                         loss = fwd_bwd()
                         if world == 1 and optim:
                             state.adam_step()
                 glist.append(g)
-                steps_per_graph = 2 if prefetch else 1
+                steps_per_graph = spg if prefetch else 1
                 graphs = (tuple(glist),)
         except Exception as e:  # noqa
             if rank == 0:
@@ -454,7 +459,7 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
                 if optim:
                     state.adam_step()
 
-    even = lambda n: n + (n % steps_per_graph)          # a replay holds steps_per_graph whole steps: counts are multiples of it
+    even = lambda n: ((n + steps_per_graph - 1) // steps_per_graph) * steps_per_graph       # a replay holds whole steps
     for _ in range(even(warmup)):
         step()
     torch.cuda.synchronize()

@@ -626,6 +626,13 @@ class PointNetDet(nn.Module):
                 leaves = tuple(f.detach().requires_grad_(True) for f in feats)
                 self._split = (feats, leaves)
                 feats = leaves
+            nxt = getattr(self, "next_batch", None)
+            if nxt is not None and self.training and torch.is_grad_enabled():
+                # the caller announced the NEXT batch (model.next_batch = data_dicts): start its batch-only front here, on a side
+                # branch beside the latency-bound ConvFeatNet forward whose launches leave most CUs idle (instead of a
+                # model.prefetch() call between forward and backward, which lands beside the first backward launches)
+                self.next_batch = None
+                self.prefetch(nxt)
             logits64 = convnet_fused(self._cn_pool, self.conv_net, self.cls_out, self.reg_out, feats, one_hot_vec, pre,
                                      self.feat_net.done_events)
             lv = logits64.view(batch_size, refs[1].shape[2], logits64.shape[1])
