@@ -18,7 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 # kernel name prefix -> C-ABI entry point whose call launches it (include/fcn_hip.h)
-ENTRY = (("gc_hits_kernel", "fcn_pn_group_compact"), ("gc_entries_kernel", "fcn_pn_group_compact"),
+ENTRY = (("gc_hits_kernel", "fcn_pn_group_compact2"), ("gc_entries_kernel", "fcn_pn_group_compact2"),
+         ("gc_fold_kernel", "fcn_pn_group_compact2"), ("pn_mid_kernel", "fcn_pn_backward2"),
          ("fwd_gemm_kernel", "fcn_pn_forward"), ("pool_nlc_kernel", "fcn_pn_forward"), ("pool_kernel", "fcn_pn_forward"),
          ("bn_finalize", "fcn_pn_forward"), ("poolbwd", "fcn_pn_backward2"), ("dgrad_kernel", "fcn_pn_backward2"),
          ("wgrad_kernel", "fcn_pn_backward2"), ("wgrad_reduce", "fcn_pn_backward2"), ("l1_finalize", "fcn_pn_backward2"),
