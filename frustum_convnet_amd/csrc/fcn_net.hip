@@ -19,6 +19,19 @@
 #include "gemm_tile.h"
 
 #define CG_T 256
+// EXPERIMENT (tuning builds, -DFCN_BWD_PERSIST=1 / 2): the backward launches as PERSISTENT grids of at most FCN_BWD_SLOTS workgroups
+// that pull work items (the block indices of the plain launch) from eight per-XCD head counters -- item b belongs to XCD b % 8, as
+// in the plain launch, so the XCD-aware tile order of every role is kept; workgroup w pulls for XCD w % 8.  The next ticket is
+// requested while the current item runs.  Counters: g_cgq[launch][xcd * 16], zeroed by cg_pack_kernel once per step.
+// 1: the item body inlined into the dequeue loop; 2: the item body as a real (noinline) call with LDS-resident descriptors.
+#ifndef FCN_BWD_PERSIST
+#define FCN_BWD_PERSIST 0
+#endif
+#ifndef FCN_BWD_SLOTS
+#define FCN_BWD_SLOTS 512
+#endif
+#define CGQ_LAUNCHES 24
+__device__ unsigned int g_cgq[CGQ_LAUNCHES * 8 * 16];
 // TIMING EXPERIMENTS ONLY (tuning builds, results are wrong when set): FCN_XF bits in the forward K-group kernel -- 1: activation
 // loads for a group's first chunk only, 2: weight loads first chunk only, 4: LDS staging first chunk only, 8: no MFMAs,
 // 16: no epilogue (cross-group sum, stores, statistics), 32: no BN prologue (scale 1 / shift 0), 64: no statistics atomics,
@@ -170,9 +183,29 @@ static inline int cg_pad8(int n) { return ((n + 7) / 8) * 8; }
 // Pins a wave-uniform value in an SGPR.  Without it LLVM rewrites "select between fields of the by-value kernel
 // struct" into "load from a dynamically selected field address", which needs the struct in memory: the whole kernarg
 // struct gets memcpy'd to scratch and every later field access becomes a scratch load.
+#if FCN_BWD_PERSIST == 2
+// (descriptors read from LDS arrive in VGPRs: make them wave-uniform scalars first)
+template <class T>
+__device__ __forceinline__ T cg_uniform(T v)
+{
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(T, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+    } else {
+        static_assert(sizeof(T) == 8, "4- or 8-byte descriptor fields");
+        const long long x = __builtin_bit_cast(long long, v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(x & 0xffffffffll));
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(x >> 32));
+        return __builtin_bit_cast(T, (long long)(((unsigned long long)hi << 32) | lo));
+    }
+}
+#else
+template <class T>
+__device__ __forceinline__ T cg_uniform(T v) { return v; }
+#endif
 template <class T>
 __device__ __forceinline__ T opaque_s(T v)
 {
+    v = cg_uniform(v);
     asm volatile("" : "+s"(v));
     return v;
 }
@@ -685,6 +718,9 @@ __device__ __forceinline__ void cg_pack_store8(const CgPack &p, int n, int kk0, 
 __global__ void cg_pack_kernel(CgPackAll t)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+#if FCN_BWD_PERSIST
+    if (i < CGQ_LAUNCHES * 8 * 16) g_cgq[i] = 0u;        // work-queue heads of the persistent backward launches (experiment)
+#endif
     const int64_t ngrp = t.pre[CN_NLAYER] / 8;
     if (t.grd && i >= ngrp && i < 2 * ngrp) {           // the data-gradient images: group m of layer l = (n8, kk), kk fastest
         i -= ngrp;
@@ -1317,9 +1353,13 @@ __device__ __forceinline__ void cg_bwd_step_body(const CgBwdStep &a, const int b
     // The role's segment descriptor is one of four: selecting it field by field from the by-value struct costs 4 x 14 pinned
     // SGPRs, and indexing the struct dynamically makes LLVM copy the whole kernarg struct to scratch.  It IS an array in the
     // kernarg segment, though: a scalar load at a wave-uniform offset from the kernarg pointer fetches exactly one.
+#if FCN_BWD_PERSIST == 2
+    const CgDgSeg *g = &a.dg[role];            // (the descriptor lives in LDS in this experiment: dynamic indexing is plain address arithmetic)
+#else
     typedef __attribute__((address_space(4))) const char *kchar_p;
     typedef __attribute__((address_space(4))) const CgDgSeg *kdg_p;
     const kdg_p g = (kdg_p)((kchar_p)__builtin_amdgcn_kernarg_segment_ptr() + koff + offsetof(CgBwdStep, dg)) + role;
+#endif
     const int ncb = g->ncb;
     const int t = cg_xcd_tile(bid - g->blk0, g->tx * ncb);
     if (t < 0) return;
@@ -1349,6 +1389,63 @@ __global__ __launch_bounds__(CGB_T, 4) void cg_bwd_pair_kernel(CgBwdPair p)
     if (bid < p.na) cg_bwd_step_body<MM>(p.A, bid, smem, (int)offsetof(CgBwdPair, A));
     else cg_bwd_step_body<MM>(p.B, bid - p.na, smem, (int)offsetof(CgBwdPair, B));
 }
+
+#if FCN_BWD_PERSIST
+typedef __attribute__((address_space(3))) float *cg_lds_p;
+typedef __attribute__((address_space(3))) const CgBwdStep *cg_lds_step_p;
+// one work item as a REAL call: the body keeps its own register allocation (inlined into the dequeue loop it spills at the 128-VGPR
+// budget of 4 waves per SIMD).  Descriptors and operand buffers arrive as address_space(3) pointers: a callee that only sees
+// generic pointers would use flat instructions.
+template <int MM>
+__device__ __attribute__((noinline)) void cg_bwd_item(cg_lds_step_p a3, const int koff, const int bid, cg_lds_p smem3)
+{
+    cg_bwd_step_body<MM>(*(const CgBwdStep *)a3, bid, (float *)smem3, koff);
+}
+
+#ifndef FCN_BWD_OCC
+#define FCN_BWD_OCC 4          // waves per SIMD the persistent kernel is compiled for (2: 256 VGPRs, one workgroup per CU)
+#endif
+template <int MM>
+__global__ __launch_bounds__(CGB_T, FCN_BWD_OCC) void cg_bwd_persist_kernel(CgBwdPair p, int total, int qslot)
+{
+    __shared__ __attribute__((aligned(16))) float smem[CGB_SMEM];
+    __shared__ int item_s;
+#if FCN_BWD_PERSIST == 2
+    __shared__ __attribute__((aligned(16))) int desc[2][(sizeof(CgBwdStep) + 3) / 4];
+    {
+        typedef __attribute__((address_space(4))) const char *kchar_p;
+        typedef __attribute__((address_space(4))) const int *kint_p;
+        const kint_p ka = (kint_p)((kchar_p)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(CgBwdPair, A));
+        const kint_p kb = (kint_p)((kchar_p)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(CgBwdPair, B));
+        for (int i = threadIdx.x; i < (int)(sizeof(CgBwdStep) / 4); i += CGB_T) { desc[0][i] = ka[i]; desc[1][i] = kb[i]; }
+    }
+#endif
+    const int xcd = (int)blockIdx.x & 7;
+    unsigned int *head = g_cgq + (qslot * 8 + xcd) * 16;
+    const int per = (total + 7 - xcd) >> 3;             // items of this XCD: xcd, xcd + 8, ...
+    int nxt = 0;
+    if (threadIdx.x == 0) nxt = (int)atomicAdd(head, 1u);
+    for (int guard = 0; guard < (1 << 20); ++guard) {
+        if (threadIdx.x == 0) {
+            item_s = nxt;
+            nxt = (int)atomicAdd(head, 1u);             // the next ticket: in flight while this item runs
+        }
+        __syncthreads();
+        const int k = item_s;
+        __syncthreads();
+        if (k >= per) return;
+        const int bid = __builtin_amdgcn_readfirstlane(8 * k + xcd);
+#if FCN_BWD_PERSIST == 2
+        if (bid < p.na) cg_bwd_item<MM>((cg_lds_step_p)&desc[0][0], (int)offsetof(CgBwdPair, A), bid, (cg_lds_p)smem);
+        else cg_bwd_item<MM>((cg_lds_step_p)&desc[1][0], (int)offsetof(CgBwdPair, B), bid - p.na, (cg_lds_p)smem);
+#else
+        if (bid < p.na) cg_bwd_step_body<MM>(p.A, bid, smem, (int)offsetof(CgBwdPair, A));
+        else cg_bwd_step_body<MM>(p.B, bid - p.na, smem, (int)offsetof(CgBwdPair, B));
+#endif
+        __syncthreads();
+    }
+}
+#endif
 
 // ================================================================================================
 // Host side: the topology of ConvFeatNet(128, nvec) + heads for n = 4 (models/det_base.py:163-224) or n = 5 pyramid levels
@@ -1848,8 +1945,17 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
         }
         pp.na = nA;
         if (nA + nB > 0) {
+#if FCN_BWD_PERSIST
+            {
+                if (nB == 0) pp.B = pp.A;               // (a valid descriptor in the unused slot)
+                const int total = nA + nB;
+                const int grid = total < FCN_BWD_SLOTS ? ((total + 7) / 8) * 8 : FCN_BWD_SLOTS;
+                FCN_MM_SWITCH(mmb, hipLaunchKernelGGL(cg_bwd_persist_kernel<MM>, dim3(grid), dim3(CGB_T), 0, st, pp, total, k));
+            }
+#else
             if (nB > 0) { FCN_MM_SWITCH(mmb, hipLaunchKernelGGL(cg_bwd_pair_kernel<MM>, dim3(nA + nB), dim3(CGB_T), 0, st, pp)); }
             else { FCN_MM_SWITCH(mmb, hipLaunchKernelGGL(cg_bwd_step_kernel<MM>, dim3(nA), dim3(CGB_T), 0, st, pp.A)); }
+#endif
             FCN_CHECK_LAUNCH();
         }
         pendA = ownA; pendA_blocks = ownA_blocks;
