@@ -378,6 +378,7 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
 
     use_graph = not a.eager
     graphs = None
+    split_scales = None
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -398,7 +399,11 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
                 # N > 1: two graphs cut where the FCN gradients are final.  Replay A (forward, loss, FCN backward) -> start
                 # the all-reduce of the [FCN + heads] bucket on RCCL's stream -> replay B (PointNet backward) beside it ->
                 # all-reduce the PointNet bucket -> join -> Adam.
-                gA, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                # ... and the PointNet backward itself in two: the wide scales first (their ~1 MB of gradients start their all-reduce
+                # while the narrow scales run), then the narrow ones (~0.1 MB: all that is left exposed behind the backward)
+                gA, gB, gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                ns = model.feat_net.num_scales
+                wide, narrow = list(range(ns // 2, ns)), list(range(ns // 2))
                 with torch.cuda.graph(gA, capture_error_mode=mode):
                     losses, _ = model(data)
                     loss = losses["total_loss"]
@@ -407,8 +412,11 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
                     loss.backward(gradient=unit_grad(loss.device))
                     model._iou_metrics.join()        # (deferred join: the side branch must end inside this capture)
                 with torch.cuda.graph(gB, pool=gA.pool(), capture_error_mode=mode):
-                    pending.backward()
-                graphs = (gA, gB)
+                    pending.backward(scales=wide)
+                with torch.cuda.graph(gC, pool=gA.pool(), capture_error_mode=mode):
+                    pending.backward(scales=narrow)
+                graphs = (gA, gB, gC)
+                split_scales = (wide, narrow)
             else:
                 # with the prefetch a step consumes the front its predecessor prepared in the OTHER workspace set: the captured
                 # graph holds TWO steps (even / odd) -- one replay = two whole steps, which also halves the graph-to-graph gap
@@ -442,11 +450,13 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
             state.allreduce()
             if optim:
                 state.adam_step()
-        elif len(graphs) == 2:
+        elif len(graphs) == 3:
             graphs[0].replay()
             state.allreduce_bucket_async(0)          # [FCN + heads]: final after graph A
             graphs[1].replay()
-            state.allreduce_bucket_async(1)          # [PointNet]
+            state.allreduce_scales_async(split_scales[0])      # the wide PointNet scales: final after graph B
+            graphs[2].replay()
+            state.allreduce_scales_async(split_scales[1])      # the narrow ones
             state.wait_allreduce()
             if optim:
                 state.adam_step()
@@ -500,7 +510,12 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
         ones = torch.ones(1, device=dev)
         torch.distributed.all_reduce(ones)
         comm = {"backend": torch.distributed.get_backend(), "ranks": int(round(float(ones.item()))), "buckets": []}
-        for name, lo, hi in state.buckets:
+        pieces = list(state.buckets)
+        if split_scales is not None:        # the pieces the overlapped step really exchanges
+            sr = state.scale_ranges
+            pieces = [state.buckets[0]] + [("pointnet scales %s" % "+".join(str(k + 1) for k in ks), sr[ks[0]][0], sr[ks[-1]][1])
+                                           for ks in split_scales]
+        for name, lo, hi in pieces:
             buf = torch.zeros(hi - lo, device=dev)
             for _ in range(2):
                 torch.distributed.all_reduce(buf)
@@ -645,7 +660,7 @@ def main():
         "config": {"workload": "%s KITTI-%s, batch=%d/GPU, Npoint=%d, L=(%s), train fwd+bwd%s%s" % (
                        CFGS[a.cfg][0], a.cfg, a.batch, npoint, ",".join(str(v) for v in Ls),
                        "" if a.no_optim else "+Adam",
-                       ("+RCCL grad all-reduce (%s)" % ("2 buckets overlapped with the PointNet backward" if overlap else
+                       ("+RCCL grad all-reduce (%s)" % ("3 pieces overlapped with the backward: [FCN + heads] beside the PointNet backward, the wide scales beside the narrow ones" if overlap else
                                                         "one call after the backward")) if world > 1 else ""),
                    "global_batch": a.batch * world, "parallelism": "dp%d" % world,
                    "launch": (("hipGraph replay x%d" % len(graphs)) + (", %d steps per replay" % m["steps_per_graph"] if m["steps_per_graph"] > 1 else "")

@@ -359,10 +359,23 @@ class _PendingPointNetBackward:
     def __init__(self, model, feats, leaves):
         self.model, self.feats, self.leaves = model, feats, leaves
 
-    def backward(self):
+    def backward(self, scales=None):
+        """scales: None = every scale not differentiated yet; or an iterable of 0-based scale indices -- the step loop may
+        differentiate the wide scales first and start the all-reduce of their gradients (FlatTrainState.allreduce_scales_async)
+        while the narrow ones run.  The object is finished when every scale has been differentiated."""
         if any(l.grad is None for l in self.leaves):
             raise RuntimeError("phase 2 of the split backward before phase 1: differentiate the loss first")
-        torch.autograd.backward(list(self.feats), [l.grad for l in self.leaves])
+        if not hasattr(self, "_todo"):
+            self._todo = set(range(len(self.feats)))
+        ks = sorted(self._todo if scales is None else set(scales))
+        if not set(ks) <= self._todo:
+            raise RuntimeError("scales %s were differentiated already (left: %s)" % (sorted(set(ks) - self._todo), sorted(self._todo)))
+        if ks:
+            # (widest first, as the one-call form does: autograd runs the nodes in reverse creation order within a call)
+            torch.autograd.backward([self.feats[k] for k in ks], [self.leaves[k].grad for k in ks])
+        self._todo -= set(ks)
+        if self._todo:
+            return
         self.model._join_side()
         if self.model._pending_split is self:
             self.model._pending_split = None

@@ -102,6 +102,15 @@ class FlatTrainState:
         # first in the buffer), then the PointNet scales
         cut = cut_at or 0
         self.buckets = [("fcn+heads", cut, total), ("pointnet", 0, cut)] if 0 < cut < total else [("all", 0, total)]
+        # the PointNet bucket scale by scale (feat_net.pointnet<k>.*: contiguous, in scale order): the wide scales finish their
+        # backward first, so a step loop that differentiates them first (take_split().backward(scales=...)) can start THEIR
+        # all-reduce while the narrow scales still run -- only the narrow scales' ~0.1 MB is then exposed behind the backward
+        self.scale_ranges = {}
+        for n, p, o in zip(self.names, params, offs):
+            if n.startswith("feat_net.pointnet"):
+                k = int(n[len("feat_net.pointnet"):].split(".")[0]) - 1
+                lo, hi = self.scale_ranges.get(k, (o, o))
+                self.scale_ranges[k] = (min(lo, o), max(hi, (o + p.numel() + 3) // 4 * 4))
         self._pending = []
         if optimizer == "sgd":          # lr, momentum, weight_decay, grad_scale; the momentum buffer lives in exp_avg
             self.hyper = torch.tensor([lr, momentum, weight_decay, 1.0 / self.world, 0.0, 1.0 / self.world], device=dev,
@@ -137,6 +146,17 @@ class FlatTrainState:
         if self.world > 1:
             _, lo, hi = self.buckets[i]
             self._pending.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def allreduce_scales_async(self, scales):
+        """Starts the summing all-reduce of the gradients of the PointNet scales `scales` (0-based, a contiguous run of scales: one
+        call over [first.lo, last.hi)) -- a sub-range of the [pointnet] bucket; every scale must be reduced exactly once per step,
+        either through here or through its bucket.  world 1: no-op."""
+        ks = sorted(scales)
+        assert ks == list(range(ks[0], ks[-1] + 1)) and all(k in self.scale_ranges for k in ks), ks
+        lo, hi = self.scale_ranges[ks[0]][0], self.scale_ranges[ks[-1]][1]
+        if self.world > 1:
+            self._pending.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return lo, hi
 
     def wait_allreduce(self):
         """The current stream waits for every bucket started with allreduce_bucket_async (no host block on CUDA/HIP)."""

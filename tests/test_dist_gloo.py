@@ -63,6 +63,23 @@ def _worker(rank, world, port, q):
     dist.all_gather(allg, local)
     mean = sum(allg) / world
     q.put((rank, "bucketed", bool(torch.allclose(st.grad * float(st.hyper[5]), mean, rtol=1e-6, atol=1e-7))))
+    # three pieces -- [FCN + heads], the wide PointNet scales, the narrow ones (bench.py's overlapped step) -- give the same: the
+    # scale ranges tile the [pointnet] bucket
+    sr = st.scale_ranges
+    tiles = sorted(sr.values())
+    q.put((rank, "scale_ranges", bool(sorted(sr) == [0, 1, 2, 3] and tiles[0][0] == 0 and tiles[-1][1] <= cut and
+                                      all(a[1] <= b[0] for a, b in zip(tiles, tiles[1:])) and
+                                      all(sr[k][0] <= o < sr[k][1] for n, o in zip(st.names, st.offsets)
+                                          for k in range(4) if n.startswith("feat_net.pointnet%d." % (k + 1))))))
+    st.grad.copy_(local)
+    st.allreduce_bucket_async(0)
+    st.allreduce_scales_async([2, 3])
+    st.allreduce_scales_async([0, 1])
+    st.wait_allreduce()
+    used = torch.zeros(st.numel, dtype=torch.bool)
+    for p_, o_ in zip(st.params, st.offsets):
+        used[o_:o_ + p_.numel()] = True                # (alignment pad slots between the pieces belong to no parameter)
+    q.put((rank, "pieces", bool(torch.allclose((st.grad * float(st.hyper[5]))[used], mean[used], rtol=1e-6, atol=1e-7))))
     # single-call path gives the same
     st.grad.copy_(local)
     st.allreduce()
@@ -93,9 +110,9 @@ def test_world2_gloo():
     for p in procs:
         p.join(180)
         assert p.exitcode == 0
-    got = [q.get(timeout=5) for _ in range(world * 5)]
+    got = [q.get(timeout=5) for _ in range(world * 7)]
     bad = [g for g in got if not g[2]]
-    assert len(got) == 10 and not bad, bad
+    assert len(got) == 14 and {g[1] for g in got} >= {"scale_ranges", "pieces", "bucketed", "single"} and not bad, bad
 
 
 def test_shard_batch_matches_dataparallel_scatter():

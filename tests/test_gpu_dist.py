@@ -54,31 +54,42 @@ def _worker_graphs_one_gpu(rank, world, port, q):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     dist.barrier()
-    gA, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    # bench.py's overlapped step (round 4): three graphs -- [forward, loss, FCN backward], [wide PointNet scales], [narrow ones] --
+    # with the matching piece of the gradient exchanged behind each
+    gA, gB, gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
     with torch.cuda.graph(gA, capture_error_mode="thread_local"):
         lo, _ = m(data)
         pending = m.take_split()
         lo["total_loss"].backward(gradient=unit_grad(lo["total_loss"].device))
     with torch.cuda.graph(gB, pool=gA.pool(), capture_error_mode="thread_local"):
-        pending.backward()
+        pending.backward(scales=[2, 3])
+    with torch.cuda.graph(gC, pool=gA.pool(), capture_error_mode="thread_local"):
+        pending.backward(scales=[0, 1])
     assert [n for n, _, _ in st.buckets] == ["fcn+heads", "pointnet"]
+    sr = st.scale_ranges
+    spans = [(st.buckets[0][1], st.buckets[0][2]), (sr[2][0], sr[3][1]), (sr[0][0], sr[1][1])]
     ok_grad = True
     for it in range(3):
+        locs = []
         gA.replay()
         torch.cuda.synchronize()
-        local0 = st.grad[st.buckets[0][1]:st.buckets[0][2]].clone()           # [FCN + heads]: final after graph A
+        locs.append(st.grad[spans[0][0]:spans[0][1]].clone())                # [FCN + heads]: final after graph A
         st.allreduce_bucket_async(0)
         gB.replay()
         torch.cuda.synchronize()
-        local1 = st.grad[st.buckets[1][1]:st.buckets[1][2]].clone()           # [PointNet]: final after graph B
-        st.allreduce_bucket_async(1)
+        locs.append(st.grad[spans[1][0]:spans[1][1]].clone())                # the wide scales: final after graph B
+        st.allreduce_scales_async([2, 3])
+        gC.replay()
+        torch.cuda.synchronize()
+        locs.append(st.grad[spans[2][0]:spans[2][1]].clone())                # the narrow scales: final after graph C
+        st.allreduce_scales_async([0, 1])
         st.wait_allreduce()
         torch.cuda.synchronize()
-        for bi, loc in ((0, local0), (1, local1)):
+        for (a, b), loc in zip(spans, locs):
             both = [torch.zeros_like(loc) for _ in range(world)]
             dist.all_gather(both, loc)
             mean = sum(both) / world
-            got = st.grad[st.buckets[bi][1]:st.buckets[bi][2]] * float(st.hyper[5])
+            got = st.grad[a:b] * float(st.hyper[5])
             ok_grad = ok_grad and bool(torch.allclose(got, mean, rtol=1e-5, atol=1e-8))
             ok_grad = ok_grad and bool((both[0] != both[1]).any())            # the ranks really saw different frustums
         st.adam_step()

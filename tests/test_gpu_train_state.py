@@ -266,22 +266,31 @@ def test_two_graph_overlapped_step_equals_single_graph():
         s1.adam_step()
     m2, s2 = make(True)
     warm(m2)
-    gA, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    # (round 4: the PointNet backward itself is cut in two -- wide scales, then narrow scales -- so that the wide scales' gradients
+    # can be exchanged while the narrow ones are computed: three graphs)
+    gA, gB, gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
     with torch.cuda.graph(gA):
         lo2, _ = m2(data)
         pending = m2.take_split()
         lo2["total_loss"].backward(gradient=unit_grad(lo2["total_loss"].device))
         assert m2.backward_pending()
     with torch.cuda.graph(gB, pool=gA.pool()):
-        pending.backward()
+        pending.backward(scales=[2, 3])
+        assert m2.backward_pending()
+        with pytest.raises(RuntimeError):
+            pending.backward(scales=[3])              # a scale is differentiated once
+    with torch.cuda.graph(gC, pool=gA.pool()):
+        pending.backward(scales=[0, 1])
     assert not m2.backward_pending()
-    assert [n for n, _, _ in s2.buckets] == ["fcn+heads", "pointnet"]
+    assert [n for n, _, _ in s2.buckets] == ["fcn+heads", "pointnet"] and sorted(s2.scale_ranges) == [0, 1, 2, 3]
     for _ in range(5):
         g1.replay()
         gA.replay()
         s2.allreduce_bucket_async(0)
         gB.replay()
-        s2.allreduce_bucket_async(1)
+        s2.allreduce_scales_async([2, 3])
+        gC.replay()
+        s2.allreduce_scales_async([0, 1])
         s2.wait_allreduce()
         s2.adam_step()
     torch.cuda.synchronize()
