@@ -10,7 +10,9 @@
 #include "fcn_common.h"
 
 #define QDP_THREADS 256
+#ifndef QDP_WPB
 #define QDP_WPB 16                 // windows per workgroup (4 waves x 4 windows)
+#endif
 #define QDP_LDS_MAX_PTS 16384      // z staged in LDS up to this many points (64 KiB), else read through L1/L2
 
 __global__ __launch_bounds__(QDP_THREADS) void qdp_kernel(

@@ -172,9 +172,9 @@ def test_full_size_gradients_in_the_exact_fp32_mode(case):
         e32 = float(np.abs(r32 - r64).max()) / float(np.abs(r64).max())
         worst = max(worst, (e64 / max(1e-4, 3.0 * e32), k[8:]))
         print(case, "f32 mode %-44s elementwise vs fp64: %.2e of max (the reference's fp32: %.2e)" % (k[8:], e64, e32))
-        # (layer-1 tensors -- conv1 weight, BN1 gamma / beta -- come out of the Q sums of conv2's data-gradient epilogue, not out of a
-        # weight-gradient GEMM; in THIS operand mode they measured 4.4e-3 ... 7.1e-3 of max on the people fixture, ten times the
-        # split mode's distance on the same tensors (4.1e-4).  Open question, EXPERIMENTS.md round 4; held to 1e-2 here.)
+        # (v_mfma_f32_32x32x2_f32 is an fmaf CHAIN: on the scale with the most rows -- people, scale 1 -- its gradients come out of a
+        # few thousand sequential fp32 accumulations per element and sit 4.4e-3 ... 7.1e-3 of max from fp64 (norms 3-7e-4), ten
+        # times the split mode's distance there; the other scales are at the reference's distance.  EXPERIMENTS.md round 4.)
         bar = 1e-2 if ".conv1." in k else max(1e-4, 3.0 * e32)
         assert e64 <= bar, (k, e64, e32)
     print(case, "exact-fp32 mode, worst sampled gradient vs fp64: %.2f of its bar (%s)" % worst)
