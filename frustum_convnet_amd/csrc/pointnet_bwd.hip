@@ -1003,6 +1003,9 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
     g.cb.bstat = bs3; g.cb.rep_stride = brs; g.cb.gamma = p->gamma[2]; g.cb.bn = bn3; g.cb.invM = 1.0 / M; g.cb.dgamma = dgamma[2]; g.cb.dbeta = dbeta[2];
     g.dybuf = ws->dy3; g.yprev = ws->y2; g.bn_prev = bn2; g.W1 = nullptr; g.dzprev = ws->dz2; g.bstat_prev = bs2;
     g.CRED = C3; g.CPREV = C2;
+#if FCN_XB & 512       // (timing build: the cost of a2 . G instead of dy3 . W3 -- reduction over C2, the A operand read from y2)
+    g.ycur = ws->y2; g.CRED = C2;
+#endif
     FCN_TRY(launch_dgrad<3>(g, B, d->precision, st));
 
     WgradArgs w;
@@ -1016,6 +1019,9 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
         w.ewin = ws->ewin; w.amax = ws->amax; w.gmax = ws->gmax;
     }
     w.W1 = nullptr; w.COUT = C3; w.CIN = C2;
+#if FCN_XB & 256       // (timing build: the cost of the Gram matrix a2^T a2 instead of dy3^T a2)
+    w.dy = ws->y2; w.COUT = C2;
+#endif
     if (!two && ws->partial_both && ws->dy3) {
         // ONE stream: conv2's data gradient and both weight gradients ride in one launch (they depend on dgrad<3> only), then the
         // two reduces and the layer-1 finalisation -- 6 launches per scale instead of 8, none of them waiting for a sibling
