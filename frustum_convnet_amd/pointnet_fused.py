@@ -15,6 +15,21 @@ from .query_depth_point import query_depth_point
 from . import precision as _precision
 
 
+def _mid_launch(B, L, K, C3):
+    """Merged middle launch of a scale's backward (fcn_pn_ws.partial_both)?  It pays where the scale's chain is LATENCY-bound: two
+    launches less on a chain of small kernels.  Measured on MI355X (round 4, one-box A/Bs): car -0.4 ... -0.9 % per step with it on
+    the two narrow scales (C3 = 128, 8 960 slots per frustum; ROCm's graph executor queues one of them behind the widest scale's
+    data-gradient branch, so it runs at the tail of the phase, alone: 100 -> 89 us), refine -1.5 ... -3 % (L = 20 ... 3: every chain
+    is launch latency); people +0.6 % SLOWER (its narrow scales hold 22 400 slots per frustum: the merged launch's roles share one
+    register / LDS budget and last as long as the three they replace), SUN-RGBD +/-0; on a 128-wide scale nothing, for the widest
+    scale instead of its second stream +5 %.  FCN_PN_MID: auto (default: C3 <= 128 and at most 300 k slots) | 1 (every one-stream
+    scale) | 0; FCN_PN_MID_L=140,280: by window count (tuning)."""
+    mode = os.environ.get("FCN_PN_MID", "auto")
+    if str(L) in os.environ.get("FCN_PN_MID_L", "").split(","):
+        return True
+    return mode == "1" or (mode == "auto" and C3 <= 128 and B * L * K <= 300000)
+
+
 class Workspace:
     """Caller-owned scratch of one scale (fcn_pn_ws).  Persistent across steps, recycled through the
     owning module's free list so that two forwards in flight (before their backwards) never share one."""
@@ -64,14 +79,10 @@ class Workspace:
         self.c = PnWs(p(self.woff), p(self.ent), p(self.ewin), p(self.tiles), p(self.y2), p(self.y3), p(self.amax),
                       p(self.stat), p(self.bn), p(self.gmax), p(self.dy3), p(self.dz2), p(self.bstat),
                       p(self.coef), p(self.partial), self.nsplit, p(self.gmom), p(self.wenc), p(self.flags), p(self.pkey),
-                      # `partial` above holds both weight gradients' split partials, so the one-stream backward COULD run conv2's data
-                      # gradient and the two weight-gradient GEMMs as roles of one launch (pn_mid_kernel: 6 launches per scale instead
-                      # of 8, bit-identical gradients).  Measured on MI355X (round 4, three alternating pairs): 1.279 vs 1.279-1.289 ms
-                      # per step -- the merged launch lasts as long as the three it replaces one after the other (55-122 us against
-                      # 48-107: the roles share one register / LDS budget and the machine is already full of the other scales'
-                      # kernels) -- so it is an option (FCN_PN_MID=1), off by default
-                      1 if (need_grad and os.environ.get("FCN_PN_MID", "0") == "1") else 0)
-
+                      # `partial` above holds both weight gradients' split partials, so a one-stream backward can run conv2's data
+                      # gradient and the two weight-gradient GEMMs as roles of ONE launch (pn_mid_kernel: 6 launches per scale instead
+                      # of 8, bit-identical gradients) -- _mid_launch() below says where that pays
+                      1 if (need_grad and _mid_launch(B, L, K, C3)) else 0)
 
     @staticmethod
     def stored(t, precision_code):
