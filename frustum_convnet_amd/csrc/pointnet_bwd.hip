@@ -882,8 +882,10 @@ static int launch_wgrad_reduce(const WgradArgs &a, const WgradPlan &P, hipStream
     return 0;
 }
 
+// rewait: an event the stream waits for AGAIN between the GEMM and its reduce (fcn_pn_backward3: a redundant edge that steers ROCm's
+// graph executor -- see pn_backward_impl)
 template <int LAYER>
-static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, int precision, hipStream_t st, float *out)
+static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, int precision, hipStream_t st, float *out, hipEvent_t rewait = nullptr)
 {
     WgradPlan P;
     FCN_TRY(plan_wgrad<LAYER>(a, B, nsplit_cap, P));
@@ -895,6 +897,10 @@ static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, int precision, hipS
         FCN_MM_SWITCH(FCN_MM_OF(precision, false), (launch_wgrad_mm<MM, LAYER>(a, grid, P.m2, P.n2, st)));
     }
     FCN_CHECK_LAUNCH();
+    if (rewait) {
+        const hipError_t e = hipStreamWaitEvent(st, rewait, 0);
+        if (e != hipSuccess) return (int)e;
+    }
     return launch_wgrad_reduce(a, P, st, out);
 }
 
@@ -1060,10 +1066,37 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
             if (e != hipSuccess) return (int)e;
         }
     }
-    FCN_TRY(launch_wgrad<3>(w, B, ws->nsplit, d->precision, sw, dW[2]));
+    // three streams: ROCm 7.2's graph executor gives child i of a node on its internal stream p the stream (p + i) % 4, counting every
+    // edge out of the node.  dgrad<3>'s edges in capture order: conv3's weight-gradient GEMM (0: stays on p), its reduce through a SECOND
+    // wait for events[0] (1: redundant, the node is already placed), conv2's data gradient (2) and conv2's weight gradient (3) -- so the
+    // two branches land on the streams of the third and fourth captured scale (the narrow ones), not on the second's (tools/graph_dot.py)
+    FCN_TRY(launch_wgrad<3>(w, B, ws->nsplit, d->precision, sw, dW[2], three ? (hipEvent_t)events[0] : nullptr));
     if (three) {
         e = hipEventRecord((hipEvent_t)events[3], sw);
         if (e != hipSuccess) return (int)e;
+        // conv2's data gradient + the layer-1 finalisation FIRST (edge 2), conv2's weight gradient after them (edge 3)
+        DgradArgs g2 = g;
+        g2.ycur = ws->y2; g2.amax = nullptr; g2.gmax = nullptr; g2.dzcur = ws->dz2;
+        g2.Wenc = (const u32x4 *)(ws->wenc + (int64_t)C2 * C1 + (int64_t)C3 * C2);
+        g2.cb.bstat = bs2; g2.cb.gamma = p->gamma[1]; g2.cb.bn = bn2; g2.cb.dgamma = dgamma[1]; g2.cb.dbeta = dbeta[1];
+        g2.dybuf = nullptr; g2.yprev = nullptr; g2.bn_prev = bn1; g2.W1 = p->W[0]; g2.dzprev = nullptr; g2.bstat_prev = bsQ;
+        g2.CRED = C2; g2.CPREV = C1;
+        FCN_TRY(launch_dgrad<2>(g2, B, d->precision, st));
+        hipLaunchKernelGGL(l1_finalize_kernel, dim3((C1 + 63) / 64), dim3(64), 0, st, bsQ, brs, ws->stat + FCN_STAT_MOM,
+                           p->W[0], p->gamma[0], bn1, C1, M, dW[0], dgamma[0], dbeta[0]);
+        FCN_CHECK_LAUNCH();
+        w.dy = nullptr; w.dz = ws->dz2; w.ycur = ws->y2; w.yprev = nullptr; w.bn_prev = bn1;
+        w.cb.bstat = bs2; w.cb.gamma = p->gamma[1]; w.cb.bn = bn2;
+        w.W1 = p->W[0]; w.COUT = C2; w.CIN = C1;
+        w.partial = ws->partial + (int64_t)ws->nsplit * C3 * C2;      // its own partials: the two weight gradients run at once
+        FCN_TRY(launch_wgrad<2>(w, B, ws->nsplit, d->precision, sw2, dW[1]));
+        e = hipEventRecord((hipEvent_t)events[2], sw2);
+        if (e != hipSuccess) return (int)e;
+        e = hipStreamWaitEvent(st, (hipEvent_t)events[2], 0);
+        if (e != hipSuccess) return (int)e;
+        e = hipStreamWaitEvent(st, (hipEvent_t)events[3], 0);
+        if (e != hipSuccess) return (int)e;
+        return 0;
     }
 
     if (two) {     // dz2 and its BN-backward sums were final at events[0]: conv2's weight gradient follows conv3's on the side

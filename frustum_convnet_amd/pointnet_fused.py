@@ -266,9 +266,10 @@ class _PointNetPooled(torch.autograd.Function):
         if ctx.pool.side_wgrad:
             side, _evs, evarr, side3 = ctx.pool.side_stream(dev)
             s2 = ctypes.c_void_p(side.cuda_stream)
-            # three-way split (conv2's weight gradient on a stream of its own, fcn_pn_backward3): measured SLOWER on MI355X
-            # (1.451 vs 1.393 ms per step: the PointNet backward is bound by total CU time, more concurrent kernels only
-            # interfere) -- FCN_PN_SIDE3=1 turns it on for experiments
+            # three-way split (conv2's weight gradient on a stream of its own, fcn_pn_backward3; its capture order puts the two
+            # extra branches on the narrow scales' executor streams): the widest scale's chain 335 -> 269 us, but both narrow scales
+            # then wait for those branches and run alone at the tail -- step +4 % slower on MI355X (EXPERIMENTS.md round 4).
+            # FCN_PN_SIDE3=1 turns it on for experiments
             three = os.environ.get("FCN_PN_SIDE3", "0") == "1" and hasattr(L, "fcn_pn_backward3")
         else:
             s2, evarr = None, None
