@@ -19,19 +19,6 @@
 #include "gemm_tile.h"
 
 #define CG_T 256
-// EXPERIMENT (tuning builds, -DFCN_BWD_PERSIST=1 / 2): the backward launches as PERSISTENT grids of at most FCN_BWD_SLOTS workgroups
-// that pull work items (the block indices of the plain launch) from eight per-XCD head counters -- item b belongs to XCD b % 8, as
-// in the plain launch, so the XCD-aware tile order of every role is kept; workgroup w pulls for XCD w % 8.  The next ticket is
-// requested while the current item runs.  Counters: g_cgq[launch][xcd * 16], zeroed by cg_pack_kernel once per step.
-// 1: the item body inlined into the dequeue loop; 2: the item body as a real (noinline) call with LDS-resident descriptors.
-#ifndef FCN_BWD_PERSIST
-#define FCN_BWD_PERSIST 0
-#endif
-#ifndef FCN_BWD_SLOTS
-#define FCN_BWD_SLOTS 512
-#endif
-#define CGQ_LAUNCHES 24
-__device__ unsigned int g_cgq[CGQ_LAUNCHES * 8 * 16];
 // TIMING EXPERIMENTS ONLY (tuning builds, results are wrong when set): FCN_XF bits in the forward K-group kernel -- 1: activation
 // loads for a group's first chunk only, 2: weight loads first chunk only, 4: LDS staging first chunk only, 8: no MFMAs,
 // 16: no epilogue (cross-group sum, stores, statistics), 32: no BN prologue (scale 1 / shift 0), 64: no statistics atomics,
@@ -152,6 +139,16 @@ extern "C" int fcn_probe_read(unsigned long long *host_out, int max_records, int
 #define PROBE_STAMP()
 #define PROBE_FLUSH(tag)
 #endif
+// (-DFCN_PROBE=3: the stamps of the BACKWARD roles instead -- tag bit 60: data-gradient tile, bit 61: weight-gradient workgroup)
+#if defined(FCN_PROBE) && FCN_PROBE == 3
+#define BPROBE_DECL unsigned long long pb_[8]; int pbn_ = 0
+#define BPROBE_STAMP() do { if (pbn_ < 7) pb_[pbn_++] = wall_clock64(); } while (0)
+#define BPROBE_FLUSH(tag) PROBE_FLUSH(tag)
+#else
+#define BPROBE_DECL
+#define BPROBE_STAMP()
+#define BPROBE_FLUSH(tag)
+#endif
 
 // n / d and n % d for 0 <= n < 2^23 through a float reciprocal and one correction step (~10 instructions): hipcc's general
 // 32-bit division is ~40 and every workgroup of a 25-launch latency-bound chain paid a dozen of them before its first load.
@@ -162,7 +159,8 @@ __device__ __forceinline__ void cg_divmod(int n, int d, float inv, int &q, int &
     if (r < 0) { q -= 1; r += d; }
     else if (r >= d) { q += 1; r -= d; }
 }
-__device__ __forceinline__ float cg_inv(int d) { return 1.0f / (float)d; }
+// (v_rcp_f32, 1 ulp: cg_divmod's correction step absorbs it -- the IEEE division was ~10 instructions in every prologue)
+__device__ __forceinline__ float cg_inv(int d) { return __builtin_amdgcn_rcpf((float)d); }
 
 // XCD-aware tile order (cdna guide T1).  Workgroup ids are dealt to the 8 XCDs round-robin and every XCD has its own 4 MB
 // L2; with the natural order the tiles that share operand rows land on eight different L2s and each of them pulls the
@@ -183,46 +181,52 @@ static inline int cg_pad8(int n) { return ((n + 7) / 8) * 8; }
 // Pins a wave-uniform value in an SGPR.  Without it LLVM rewrites "select between fields of the by-value kernel
 // struct" into "load from a dynamically selected field address", which needs the struct in memory: the whole kernarg
 // struct gets memcpy'd to scratch and every later field access becomes a scratch load.
-#if FCN_BWD_PERSIST == 2
-// (descriptors read from LDS arrive in VGPRs: make them wave-uniform scalars first)
-template <class T>
-__device__ __forceinline__ T cg_uniform(T v)
-{
-    if constexpr (sizeof(T) == 4) {
-        return __builtin_bit_cast(T, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
-    } else {
-        static_assert(sizeof(T) == 8, "4- or 8-byte descriptor fields");
-        const long long x = __builtin_bit_cast(long long, v);
-        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(x & 0xffffffffll));
-        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(x >> 32));
-        return __builtin_bit_cast(T, (long long)(((unsigned long long)hi << 32) | lo));
-    }
-}
-#else
-template <class T>
-__device__ __forceinline__ T cg_uniform(T v) { return v; }
-#endif
 template <class T>
 __device__ __forceinline__ T opaque_s(T v)
 {
-    v = cg_uniform(v);
     asm volatile("" : "+s"(v));
     return v;
 }
+// Several values read THROUGH A POINTER pinned at once: every asm volatile is a scheduling barrier, so a row of opaque_s() calls on
+// pointer loads becomes load, wait, load, wait, ... -- one scalar-cache round trip per field.  Plain loads into locals first (the
+// compiler issues them back to back), then ONE asm that takes them all.
+#define CG_PIN_1(a) "+s"(a)
+#define CG_PIN_2(a, ...) "+s"(a), CG_PIN_1(__VA_ARGS__)
+#define CG_PIN_3(a, ...) "+s"(a), CG_PIN_2(__VA_ARGS__)
+#define CG_PIN_4(a, ...) "+s"(a), CG_PIN_3(__VA_ARGS__)
+#define CG_PIN_5(a, ...) "+s"(a), CG_PIN_4(__VA_ARGS__)
+#define CG_PIN_6(a, ...) "+s"(a), CG_PIN_5(__VA_ARGS__)
+#define CG_PIN_7(a, ...) "+s"(a), CG_PIN_6(__VA_ARGS__)
+#define CG_PIN_8(a, ...) "+s"(a), CG_PIN_7(__VA_ARGS__)
+#define CG_PIN_9(a, ...) "+s"(a), CG_PIN_8(__VA_ARGS__)
+#define CG_PIN_10(a, ...) "+s"(a), CG_PIN_9(__VA_ARGS__)
+#define CG_PIN_11(a, ...) "+s"(a), CG_PIN_10(__VA_ARGS__)
+#define CG_PIN_12(a, ...) "+s"(a), CG_PIN_11(__VA_ARGS__)
+#define CG_PIN_13(a, ...) "+s"(a), CG_PIN_12(__VA_ARGS__)
+#define CG_PIN_14(a, ...) "+s"(a), CG_PIN_13(__VA_ARGS__)
+#define CG_PIN_15(a, ...) "+s"(a), CG_PIN_14(__VA_ARGS__)
+#define CG_PIN_16(a, ...) "+s"(a), CG_PIN_15(__VA_ARGS__)
+#define CG_PIN_17(a, ...) "+s"(a), CG_PIN_16(__VA_ARGS__)
+#define CG_PIN_18(a, ...) "+s"(a), CG_PIN_17(__VA_ARGS__)
+#define CG_PIN(N, ...) asm volatile("" : CG_PIN_##N(__VA_ARGS__))
 
-// (segment, tap, channel) of packed column kk.  Only STATIC indices into L.seg: a dynamically indexed by-value
-// kernel struct is copied to scratch and every access becomes a scratch/vector load in the middle of the prefetch.
-__device__ __forceinline__ void cg_locate(const CgLayer &L, int kk, int &sg, int &tap, int &k0, int &segoff)
+// (segment, tap, channel) of packed column kk from fields the caller holds in SGPRs.  Only STATIC selects: a dynamically indexed
+// by-value kernel struct is copied to scratch and every access becomes a scratch / vector load in the middle of the prefetch.
+struct CgGeo {
+    int nseg, KT, stride, pad, Lin;
+};
+__device__ __forceinline__ void cg_locate_s(const CgGeo &G, int C0, int C1, int C2, int C3, int kk, int &sg, int &tap, int &k0,
+                                            int &segoff)
 {
     sg = 0; segoff = 0;
 #pragma unroll
     for (int s = 0; s < CG_NSEG; ++s) {
-        if (s < L.nseg) {
-            const int span = L.KT * L.seg[s].C;
+        if (s < G.nseg) {
+            const int span = G.KT * SEL4(s, C0, C1, C2, C3);
             if (sg == s && kk >= span) { kk -= span; segoff += span; sg = s + 1; }
         }
     }
-    const int C = SEL4(sg, opaque_s(L.seg[0].C), opaque_s(L.seg[1].C), opaque_s(L.seg[2].C), opaque_s(L.seg[3].C));
+    const int C = SEL4(sg, C0, C1, C2, C3);
     cg_divmod(kk, C, cg_inv(C), tap, k0);               // kk < CG_KMAX
 }
 
@@ -232,13 +236,15 @@ __device__ __forceinline__ void cg_locate(const CgLayer &L, int kk, int &sg, int
 // across the MFMA phase (a "load or zero" select makes hipcc wait for the load right away).
 // A one-hot segment is a (B, OH_PAD) buffer: one row per frustum (Lsrc = 1), every position reads it (linmul = 0).
 template <int MM>
-__device__ __forceinline__ v4f cg_load_raw(const CgLayer &L, const float *x, int C, int Lsrc, int linmul, int tap,
+__device__ __forceinline__ v4f cg_load_raw(const CgGeo &L, const float *x, int C, int Lsrc, int linmul, int tap,
                                            int kc, int b, int l, bool rvalid, bool &ok, int s16 = 0)
 {
     const int lin = l * L.stride + tap - L.pad;
     ok = rvalid && lin >= 0 && lin < L.Lin;
     const int lc = min(max(lin, 0), L.Lin - 1) * linmul;
-    const int64_t e = ((int64_t)b * Lsrc + lc) * C + kc;
+    // 32-bit element offset (cn_make_plan checks B * L * C < 2^31 for every arena): an unsigned offset off a wave-uniform base
+    // is the SGPR-base + VGPR-offset form of global_load -- no 64-bit multiply / add per load
+    const unsigned e = (unsigned)((b * Lsrc + lc) * C + kc);
     if constexpr (St<MM>::half) {
         if (s16) return lds4e<MM>(x, e);             // a layer output (bf16 arena); pooled features / one-hot stay fp32
     }
@@ -260,13 +266,29 @@ __device__ __forceinline__ double cg_rsqrt64(double x)
 
 // per-column (kk) scale/shift of the virtual A matrix: BN of the producer, or (1,0) for inputs that are already
 // activations (pooled features, one-hot: both >= 0, so the ReLU applied uniformly is the identity on them)
-__device__ __forceinline__ void cg_fill_bn(const CgLayer &L, float *sS, float *tS, int tid, int nthr, bool pub)
+// The layer descriptor read THROUGH THE KERNARG POINTER from a given program point on: fields read through the by-value kernel
+// parameter are all fetched in the kernel's entry block (the compiler hoists kernel-argument loads there), in as many serialized
+// batches as the SGPR budget forces -- each batch a scalar-cache round trip plus v_writelane spills -- in front of the first global
+// load of every workgroup, although the BatchNorm fold and the epilogue need theirs much later.  The asm makes the pointer opaque:
+// loads through it cannot move above it, so they are issued behind the operand loads already in flight.
+typedef __attribute__((address_space(4))) const CgLayer *cg_klayer_p;
+__device__ __forceinline__ cg_klayer_p cg_kernarg_layer(int koff)
 {
+    typedef __attribute__((address_space(4))) const char *kchar_p;
+    cg_klayer_p p = (cg_klayer_p)((kchar_p)__builtin_amdgcn_kernarg_segment_ptr() + koff);
+    asm volatile("" : "+s"(p) : : "memory");
+    return p;
+}
+
+template <class LP>            // LP: const CgLayer * (by-value parameter) or cg_klayer_p
+__device__ __forceinline__ void cg_fill_bn(LP Lp, float *sS, float *tS, int tid, int nthr, bool pub)
+{
+    const auto &L = *Lp;
     int off = 0;
 #pragma unroll
     for (int s = 0; s < CG_NSEG; ++s) {
         if (s < L.nseg) {
-            const CgSeg &S = L.seg[s];
+            const auto &S = L.seg[s];
             const int C = S.C, span = L.KT * C;
             if (S.gamma) {
                 const bool batch = S.stat != nullptr;
@@ -313,7 +335,7 @@ __device__ __forceinline__ float cg_act(float s, float x, float t, bool ok) { re
 // In use: <1,4,1> (32 x 32 tile, 4 waves) -- 560 workgroups per layer; <1,4> (32 x 64) and <2,4> (64 x 64) measured
 // 5 % slower over the forward (280 tiles for 256 CUs at every level of the pyramid).
 template <int MM, int MW, int G, int WNC = 2, int NTW = 1>      // WNC waves across N per K-group, NTW 32-column blocks per wave:
-__device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, const int by)      // tile (32*MW) x (32*WNC*NTW)
+__device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, const int by, const int koff)      // tile (32*MW) x (32*WNC*NTW); koff: offset of L in the kernarg segment
 {
     constexpr int TG = 64 * MW * WNC, TMB = 32 * MW, TNC = 32 * WNC * NTW, NTHR = G * TG;
     constexpr int LDRA = KbTile<TMB>::LDR, LDRB = KbTile<TNC>::LDR, GU4 = KbTile<TMB>::U4 + KbTile<TNC>::U4;
@@ -330,19 +352,31 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     const int lane = tid & 63, gw = gt >> 6, l31 = lane & 31, lh = lane >> 5;
     const int wm = gw / WNC, wn = gw % WNC;
     u32x4 *Ab = lds4 + g * GU4, *Bb = Ab + KbTile<TMB>::U4;
-    const int R = L.B * L.Lout;
-    const int row0 = bx * TMB, n0 = by * TNC;
     PROBE_DECL;
     PROBE_STAMP();                                      // 0: entry
+    // EVERY kernel-argument field the code in front of the first loads reads, fetched as ONE batch of scalar loads and pinned:
+    // left to the compiler they are re-fetched from the kernarg segment at each use, one s_load + s_waitcnt round trip after the
+    // other (15 of them between here and the first global load, ~1 us of the 2.5 us every workgroup of every layer spent there)
+    const int LB = opaque_s(L.B), LLout = opaque_s(L.Lout), LKtot = opaque_s(L.Ktot), LCout = opaque_s(L.Cout);
+    CgGeo geo;
+    geo.nseg = opaque_s(L.nseg); geo.KT = opaque_s(L.KT); geo.stride = opaque_s(L.stride); geo.pad = opaque_s(L.pad);
+    geo.Lin = opaque_s(L.Lin);
+    const u32x4 *LWenc = opaque_s(L.Wenc);
+    const int R = LB * LLout;
+    const int row0 = bx * TMB, n0 = by * TNC;
     const int kq = gt & 7, rb = gt >> 3;      // rb: 0..31 (MW=2) or 0..15 (MW=1)
     constexpr int RSTEP = TG / 8;
-    const int nchunk = L.Ktot / KC, nit = (nchunk + G - 1) / G;
+    const int nchunk = LKtot / KC, nit = (nchunk + G - 1) / G;
     // segment fields as scalars (static indices)
     const float *x0 = opaque_s(L.seg[0].x), *x1 = opaque_s(L.seg[1].x), *x2 = opaque_s(L.seg[2].x), *x3 = opaque_s(L.seg[3].x);
     const int C0 = opaque_s(L.seg[0].C), C1 = opaque_s(L.seg[1].C), C2 = opaque_s(L.seg[2].C), C3 = opaque_s(L.seg[3].C);
     const int T0 = opaque_s(L.seg[0].type), T1 = opaque_s(L.seg[1].type), T2 = opaque_s(L.seg[2].type), T3 = opaque_s(L.seg[3].type);
     const int Q0 = opaque_s(L.seg[0].Lsrc), Q1 = opaque_s(L.seg[1].Lsrc), Q2 = opaque_s(L.seg[2].Lsrc), Q3 = opaque_s(L.seg[3].Lsrc);
     const int H0 = opaque_s(L.seg[0].st16), H1 = opaque_s(L.seg[1].st16), H2 = opaque_s(L.seg[2].st16), H3 = opaque_s(L.seg[3].st16);
+#if defined(FCN_PROBE) && FCN_PROBE == 2      // (finer stamps of the issue phase: the kernel arguments have arrived ...)
+    if (H0 + H1 + H2 + H3 + C0 + Q0 + T0 == -12345) return;
+    PROBE_STAMP();
+#endif
     int bb[NA], ll[NA];
     bool rv[NA];
 #pragma unroll
@@ -350,11 +384,15 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         const int gr = row0 + rb + RSTEP * i;
         rv[i] = gr < R;
         int q_ = 0, r_ = 0;
-        if (R < (1 << 23)) cg_divmod(rv[i] ? gr : 0, L.Lout, cg_inv(L.Lout), q_, r_);
-        else { q_ = (rv[i] ? gr : 0) / L.Lout; r_ = (rv[i] ? gr : 0) % L.Lout; }
+        if (R < (1 << 23)) cg_divmod(rv[i] ? gr : 0, LLout, cg_inv(LLout), q_, r_);
+        else { q_ = (rv[i] ? gr : 0) / LLout; r_ = (rv[i] ? gr : 0) % LLout; }
         bb[i] = q_;
         ll[i] = r_;
     }
+#if defined(FCN_PROBE) && FCN_PROBE == 2      // (... the row -> (frustum, position) divisions are done)
+    if (bb[0] + ll[0] == -12345) return;
+    PROBE_STAMP();
+#endif
     f32x16 acc[1][NTW];
     acc_zero<1, NTW>(acc);
     // TWO register sets: the chunk staged in iteration `it` was requested two iterations earlier, so a load has two
@@ -368,7 +406,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     for (int i = 0; i < NB; ++i) { rw0[i] = u32x4{0u, 0u, 0u, 0u}; rw1[i] = u32x4{0u, 0u, 0u, 0u}; }
     // weight image item f = gt + TG * i of a chunk: column f % TNC, (plane, k-block) row f / TNC -- 16-byte pieces, lane-linear
     // in global memory and in LDS (pre-encoded by cg_pack_kernel: no VALU on this operand)
-    const u32x4 *wsrc = L.Wenc + n0;
+    const u32x4 *wsrc = LWenc + n0;
     // (macros, not lambdas: the by-reference closure of a lambda called from several places is not always scalarised
     // by hipcc and drags every captured variable into scratch)
     // the chunk (hence the segment) is uniform within a K-group, i.e. within every wave: scalar selects
@@ -387,11 +425,11 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         const int h16 = SEL4(sgi, H0, H1, H2, H3);                                                                    \
         if (!((FCN_XF & 1) && c_ >= 2 * G))                                                                           \
         _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                                \
-            RA[i] = cg_load_raw<MM>(L, x, C, Ls, ty ? 0 : 1, tap, k0 + 4 * kq, bb[i], ll[i], rv[i], OK[i], h16);      \
+            RA[i] = cg_load_raw<MM>(geo, x, C, Ls, ty ? 0 : 1, tap, k0 + 4 * kq, bb[i], ll[i], rv[i], OK[i], h16);    \
         if (!((FCN_XF & 2) && c_ >= 2 * G))                                                                           \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                              \
             const int f = gt + TG * i;                                                                                \
-            RW[i] = ldgu4(wsrc + ((int64_t)c_ * 8 + f / TNC) * L.Cout + (f % TNC));                                   \
+            RW[i] = ldgu4(wsrc + (unsigned)((c_ * 8 + f / TNC) * LCout + (f % TNC)));                                 \
         }                                                                                                             \
     }
 #define CGK_FWD_STAGE(c_, RA, RW, OK)                                                                                 \
@@ -428,30 +466,33 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     {
         int sg_, tap_, k0_, so_;
         const int ca = min(g, nchunk - 1), cb = min(g + G, nchunk - 1);
-        cg_locate(L, ca * KC, sg_, tap_, k0_, so_);
+        cg_locate_s(geo, C0, C1, C2, C3, ca * KC, sg_, tap_, k0_, so_);
         CGK_FWD_LOAD_AT(ca, __builtin_amdgcn_readfirstlane(sg_), __builtin_amdgcn_readfirstlane(tap_),
                         __builtin_amdgcn_readfirstlane(k0_), ra0, rw0, ok0);
-        cg_locate(L, cb * KC, sg_, tap_, k0_, so_);
+        cg_locate_s(geo, C0, C1, C2, C3, cb * KC, sg_, tap_, k0_, so_);
         CGK_FWD_LOAD_AT(cb, __builtin_amdgcn_readfirstlane(sg_), __builtin_amdgcn_readfirstlane(tap_),
                         __builtin_amdgcn_readfirstlane(k0_), ra1, rw1, ok1);
     }
     PROBE_STAMP();                                      // 1: first loads issued
     if (tid < nchunk) {
         int sg, tap, k0, so;
-        cg_locate(L, tid * KC, sg, tap, k0, so);
+        cg_locate_s(geo, C0, C1, C2, C3, tid * KC, sg, tap, k0, so);
         cSeg[tid] = sg; cTap[tid] = tap; cK0[tid] = k0;
     }
-    if (FCN_XF & 32) { for (int i = tid; i < L.Ktot; i += NTHR) { sS[i] = 1.f; tS[i] = 0.f; } }
-    else cg_fill_bn(L, sS, tS, tid, NTHR, bx == 0 && by == 0);
+    // (from here on the descriptor is read through the kernarg pointer: see cg_kernarg_layer)
+    const cg_klayer_p Lk = cg_kernarg_layer(koff);
+    if (FCN_XF & 32) { for (int i = tid; i < LKtot; i += NTHR) { sS[i] = 1.f; tS[i] = 0.f; } }
+    else cg_fill_bn(Lk, sS, tS, tid, NTHR, bx == 0 && by == 0);
     __syncthreads();                            // sS / tS and the chunk table ready
-    if (FCN_XF & 256) { if (sS[0] == 123.456f) L.y[0] = 0.f; return; }      // (timing builds: launch + prologue only)
+    if (FCN_XF & 256) { if (sS[0] == 123.456f) Lk->y[0] = 0.f; return; }      // (timing builds: launch + prologue only)
     PROBE_STAMP();                                      // 2: prologue done
     for (int it = 0; it < nit; it += 2) {
         CGK_FWD_ITER(it, ra0, rw0, ok0);
         if (it + 1 < nit) CGK_FWD_ITER(it + 1, ra1, rw1, ok1);
     }
     PROBE_STAMP();                                      // 3: K loop done (wave 0)
-    if (FCN_XF & 16) { if (acc[0][0][0] == 123.456f) L.y[0] = 0.f; return; }
+    if (FCN_XF & 16) { if (acc[0][0][0] == 123.456f) Lk->y[0] = 0.f; return; }
+    const cg_klayer_p Le = cg_kernarg_layer(koff);      // the epilogue's fields: fetched now, not in the entry block
     // ---- sum the G group accumulators through LDS, then one epilogue pass over the tile
     if constexpr (TG == 64) __syncthreads();            // every group is done with its operand buffers (reused below)
     float *red = lds;                                   // [G][TMB][TNC]
@@ -470,29 +511,29 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         v4f v = zero4();
 #pragma unroll
         for (int q = 0; q < G; ++q) v += *(const v4f *)(red + (q * TMB + er) * TNC + 4 * ecq);
-        if (L.bias) {
-            v.x += col + 0 < L.nbias ? L.bias[col + 0] : 0.f; v.y += col + 1 < L.nbias ? L.bias[col + 1] : 0.f;
-            v.z += col + 2 < L.nbias ? L.bias[col + 2] : 0.f; v.w += col + 3 < L.nbias ? L.bias[col + 3] : 0.f;
+        if (Le->bias) {
+            v.x += col + 0 < Le->nbias ? Le->bias[col + 0] : 0.f; v.y += col + 1 < Le->nbias ? Le->bias[col + 1] : 0.f;
+            v.z += col + 2 < Le->nbias ? Le->bias[col + 2] : 0.f; v.w += col + 3 < Le->nbias ? Le->bias[col + 3] : 0.f;
         }
         const int row = row0 + er;
         if (row < R) {
-            if (St<MM>::half && L.y16) {
-                sts4e<MM>(L.y, (int64_t)row * L.Cout + col, v);
+            if (St<MM>::half && Le->y16) {
+                sts4e<MM>(Le->y, (int64_t)row * Le->Cout + col, v);
                 v = st_round4<MM>(v);                      // the sums are over the values as stored
             } else {
-                sts4(L.y + (int64_t)row * L.Cout + col, v);
+                sts4(Le->y + (int64_t)row * Le->Cout + col, v);
             }
             cs1 += v;
             cs2 += v * v;
             // fp16 operand parts overflow at |x| >= 65504 (inf - inf = NaN in the products, which the next layer's ReLU would
             // turn into a silent zero): a non-finite output raises the sticky flag of the workspace
             if constexpr (MM == MM_F16X3) {
-                if (!(fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w) < 3.0e38f) && L.flags) atomicOr(L.flags, FCN_FLAG_NONFINITE);
+                if (!(fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w) < 3.0e38f) && Le->flags) atomicOr(Le->flags, FCN_FLAG_NONFINITE);
             }
         }
     }
     PROBE_STAMP();                                      // 5: outputs stored
-    if (!L.stat) { PROBE_FLUSH(((unsigned long long)L.Ktot << 32) | ((unsigned long long)L.Cout << 16) | (unsigned long long)(L.Lout & 0xffff)); return; }
+    if (!Le->stat) { PROBE_FLUSH(((unsigned long long)Le->Ktot << 32) | ((unsigned long long)Le->Cout << 16) | (unsigned long long)(Le->Lout & 0xffff)); return; }
     // rows of one wave: lanes NQ apart share a column quad -> xor-shuffle down to NQ lanes, then across waves via LDS
     float pv[8] = {cs1.x, cs1.y, cs1.z, cs1.w, cs2.x, cs2.y, cs2.z, cs2.w};
 #pragma unroll
@@ -515,10 +556,10 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         double a = 0.0;
 #pragma unroll
         for (int r = 0; r < NTHR / 64; ++r) a += (double)st[(r * TNC + c) * 2 + w];
-        if (!(FCN_XF & 64) || a == 123.456) atomic_add_f64(&L.stat[(int64_t)(blockIdx.x % FCN_CG_REP) * L.rep_stride + w * L.Cs + (n0 + c) % L.Cs], a);
+        if (!(FCN_XF & 64) || a == 123.456) atomic_add_f64(&Le->stat[(int64_t)(blockIdx.x % FCN_CG_REP) * Le->rep_stride + w * Le->Cs + (n0 + c) % Le->Cs], a);
     }
     PROBE_STAMP();                                      // 6: statistics added
-    PROBE_FLUSH(((unsigned long long)L.Ktot << 32) | ((unsigned long long)L.Cout << 16) | (unsigned long long)(L.Lout & 0xffff));
+    PROBE_FLUSH(((unsigned long long)Le->Ktot << 32) | ((unsigned long long)Le->Cout << 16) | (unsigned long long)(Le->Lout & 0xffff));
 }
 
 template <int MM, int MW, int G, int WNC = 2, int NTW = 1>
@@ -527,7 +568,9 @@ __global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_kernel(CgLayer L)
     const int nby = L.Cout / (32 * WNC * NTW), nbx = (L.B * L.Lout + 32 * MW - 1) / (32 * MW);
     const int t = cg_xcd_tile(blockIdx.x, nbx * nby);          // column tiles fastest: a row tile's operand rows stay in one L2
     if (t < 0) return;
-    cgk_fwd_body<MM, MW, G, WNC, NTW>(L, t / nby, t % nby);
+    int bx, by;
+    cg_divmod(t, nby, cg_inv(nby), bx, by);                    // (t < 2^23: a grid is at most a few thousand workgroups)
+    cgk_fwd_body<MM, MW, G, WNC, NTW>(L, bx, by, 0);
 }
 
 // Two INDEPENDENT layers in one launch (a deconvolution next to the stride-2 conv that reads the same merge output):
@@ -547,8 +590,10 @@ __global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_pair_kernel(CgLayer
     const int nby = L.Cout / (32 * WNC * NTW), nbx = (L.B * L.Lout + 32 * MW - 1) / (32 * MW);
     const int t = cg_xcd_tile(isA ? bid : bid - p.na, nbx * nby);
     if (t < 0) return;
-    if (isA) cgk_fwd_body<MM, MW, G, WNC, NTW>(p.A, t / nby, t % nby);
-    else cgk_fwd_body<MM, MW, G, WNC, NTW>(p.B, t / nby, t % nby);
+    int bx, by;
+    cg_divmod(t, nby, cg_inv(nby), bx, by);
+    if (isA) cgk_fwd_body<MM, MW, G, WNC, NTW>(p.A, bx, by, (int)offsetof(CgLayerPair, A));
+    else cgk_fwd_body<MM, MW, G, WNC, NTW>(p.B, bx, by, (int)offsetof(CgLayerPair, B));
 }
 
 // BN-backward coefficients of one channel from the batch sums (sum dz, sum dz*xhat): gamma*rstd, mean, rstd, dbeta/M,
@@ -562,7 +607,8 @@ struct CgBnBwd {
     float *dgamma, *dbeta;     // non-null on the launch that exports them
 };
 
-__device__ __forceinline__ void cg_bnbwd_coef(const CgBnBwd &q, int Cs, int c, float (&cf)[5], bool pub)
+template <class QT>            // QT: CgBnBwd by value or through the kernarg pointer (address_space(4))
+__device__ __forceinline__ void cg_bnbwd_coef(const QT &q, int Cs, int c, float (&cf)[5], bool pub)
 {
     const double db = cg_rep_sum(q.bstat + c, q.rep_stride), dg = cg_rep_sum(q.bstat + Cs + c, q.rep_stride);
     const float rstd = q.bn[3 * Cs + c];
@@ -591,7 +637,8 @@ struct CgPack {
     int nvec, cin_tot, deconv_k, cout_t;
 };
 
-__device__ __forceinline__ int64_t cg_torch_index(const CgPack &p, int n, int kk)
+template <class PT>
+__device__ __forceinline__ int64_t cg_torch_index(const PT &p, int n, int kk)
 {
     if (p.deconv_k > 0) {               // row n = j*Cout + co, kk = ci  ->  W[ci][co][j]
         const int j = n / p.cout_t, co = n % p.cout_t;
@@ -718,9 +765,6 @@ __device__ __forceinline__ void cg_pack_store8(const CgPack &p, int n, int kk0, 
 __global__ void cg_pack_kernel(CgPackAll t)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-#if FCN_BWD_PERSIST
-    if (i < CGQ_LAUNCHES * 8 * 16) g_cgq[i] = 0u;        // work-queue heads of the persistent backward launches (experiment)
-#endif
     const int64_t ngrp = t.pre[CN_NLAYER] / 8;
     if (t.grd && i >= ngrp && i < 2 * ngrp) {           // the data-gradient images: group m of layer l = (n8, kk), kk fastest
         i -= ngrp;
@@ -897,8 +941,8 @@ __device__ __forceinline__ void mma_chunk_kb16(const u32x4 *A, const u32x4 *B, f
 // write -> read -> write sequence of its K loop needs no barrier (cgk_fwd_body does the same).  The groups take 16-deep
 // chunks g, g + 8, ...: a wave stages the same number of operand values per step as a wave of the former two-wave groups
 // did with 32-deep chunks (32 x 16 of dy + 16 x 64 of W), and computes the whole 32 x 64 tile of its chunk.
-template <int MM>
-__device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &cb, const float *dzc, const float *yc,
+template <int MM, class LT, class CT>           // LT / CT: CgLayer / CgBnBwd, by value or through the kernarg pointer
+__device__ __forceinline__ void cg_dgrad_body(const LT &L, const CT &cb, const float *dzc, const float *yc,
                                               int sgi, int segoff, const float *ysrc, const float *bnsrc, float *outp,
                                               int accumulate, double *bstat_src, int bx, int by, bool pub, float *smem,
                                               int dz16, int out16)
@@ -916,17 +960,24 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
     float *lds = smem;
     float *coefS = smem + CGB_LDS;
     int *cTap = (int *)(coefS + 5 * CG_CMAX), *cNb = cTap + NCH, *cCh = cNb + NCH;
-    // sgi is workgroup-uniform: static-index selects, no dynamic struct indexing
-    const int SC = SEL4(sgi, opaque_s(L.seg[0].C), opaque_s(L.seg[1].C), opaque_s(L.seg[2].C), opaque_s(L.seg[3].C));
-    const int SLsrc = SEL4(sgi, opaque_s(L.seg[0].Lsrc), opaque_s(L.seg[1].Lsrc), opaque_s(L.seg[2].Lsrc), opaque_s(L.seg[3].Lsrc));
+    BPROBE_DECL;
+    BPROBE_STAMP();                             // 0: entry
+    // sgi is workgroup-uniform (a scalar loaded from the role descriptor)
+    // everything the code in front of the first loads reads, as ONE batch of scalar loads (L is read through the kernarg pointer:
+    // the wave-uniform segment index is address arithmetic)
+    int SC = L.seg[sgi].C, SLsrc = L.seg[sgi].Lsrc;
+    int LB = L.B, LLin = L.Lin, LLout = L.Lout, LCout = L.Cout, LKT = L.KT, LCs = L.Cs, Lpad = L.pad, Lstride = L.stride, LKtot = L.Ktot;
+    const u32x4 *LWgrd = L.Wgrd;
+    const double *cbstat = cb.bstat;
+    CG_PIN(13, SC, SLsrc, LB, LLin, LLout, LCout, LKT, LCs, Lpad, Lstride, LKtot, LWgrd, cbstat);
     const int tid = threadIdx.x, g = tid >> 6;
     const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
     u32x4 *Ai = (u32x4 *)(lds + g * CGB_WSZ), *Bi = (u32x4 *)(lds + g * CGB_WSZ + ASZ);
-    const int C = SC, Rs = L.B * SLsrc, Cs = L.Cs;
+    const int C = SC, Rs = LB * SLsrc, Cs = LCs;
     const int row0 = bx * TMB, c0 = by * 64;
     const int kq = lane & 3, rb = lane >> 2;            // dy: 4 column quads x 16 rows per pass
     constexpr int RSTEP = 16;
-    const bool hasbn = cb.bstat != nullptr;
+    const bool hasbn = cbstat != nullptr;
     int bb[NA], li[NA];
     bool rv[NA], ok[NA];
 #pragma unroll
@@ -938,22 +989,25 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
         else { q_ = (rv[i] ? gr : 0) / SLsrc; r_ = (rv[i] ? gr : 0) % SLsrc; }
         bb[i] = q_;
         li[i] = r_;
-        rv[i] = rv[i] && li[i] < L.Lin;
+        rv[i] = rv[i] && li[i] < LLin;
         ok[i] = false;
     }
     f32x16 acc[1][2];
     acc_zero<1, 2>(acc);
     v4f rz[NA], ry[NA];
     u32x4 rw[NB];
-    const int ncn = L.Cout / KH, nchunk = L.KT * ncn, nit = (nchunk + G - 1) / G;
+    const int ncn = LCout / KH, nchunk = LKT * ncn, nit = (nchunk + G - 1) / G;
     // No integer division inside the reduction loop (each one is ~40 VALU instructions and the loop body is otherwise
     // ~100): the (tap, column base, BN channel base) of every chunk comes from a small LDS table.
     if (tid < nchunk) {
-        const int tp = tid / ncn, nb = (tid % ncn) * KH;
-        cTap[tid] = tp; cNb[tid] = nb; cCh[tid] = nb % Cs;
+        int tp, cn, q_, ch;
+        cg_divmod(tid, ncn, cg_inv(ncn), tp, cn);         // (float-reciprocal divisions: three general ones were ~120 instructions)
+        const int nb = cn * KH;
+        cg_divmod(nb, Cs, cg_inv(Cs), q_, ch);
+        cTap[tid] = tp; cNb[tid] = nb; cCh[tid] = ch;
     }
     // the weight operand: this tile's 64 columns of the layer's data-gradient image (CgLayer.Wgrd), one column per lane
-    const u32x4 *wg = L.Wgrd + segoff + c0 + lane;
+    const u32x4 *wg = LWgrd + segoff + c0 + lane;
 #define CGK_DGRAD_LOAD(cc)                                                                                            \
     {                                                                                                                 \
         const int c__ = (cc);                                                                                         \
@@ -966,11 +1020,11 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
         _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                              \
             /* the output position source row li meets through tap t: (li + pad - t) / stride when it divides; */   \
             /* stride is 1 or 2 (cn_make_plan rejects anything else): shift / mask instead of a division */          \
-            const int t_ = li[i] + L.pad - tap;                                                                       \
-            const int lq = (L.stride == 2) ? (t_ >> 1) : t_;                                                          \
-            ok[i] = rv[i] && t_ >= 0 && ((L.stride == 2) ? ((t_ & 1) == 0) : true) && lq < L.Lout;                    \
-            const int lo = min(max(lq, 0), L.Lout - 1);                                                               \
-            const int64_t o = ((int64_t)bb[i] * L.Lout + lo) * L.Cout + nb + 4 * kq;                                  \
+            const int t_ = li[i] + Lpad - tap;                                                                       \
+            const int lq = (Lstride == 2) ? (t_ >> 1) : t_;                                                          \
+            ok[i] = rv[i] && t_ >= 0 && ((Lstride == 2) ? ((t_ & 1) == 0) : true) && lq < LLout;                    \
+            const int lo = min(max(lq, 0), LLout - 1);                                                               \
+            const unsigned o = (unsigned)((bb[i] * LLout + lo) * LCout + nb + 4 * kq);                              \
             if (St<MM>::half && dz16) {                                                                               \
                 rz[i] = lds4e<MM>(dzc, o);                                                                            \
                 ry[i] = lds4e<MM>(hasbn ? yc : dzc, o);                                                               \
@@ -981,15 +1035,18 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
         }                                                                                                             \
         if (!((FCN_XG & 2) && xg_later))                                                                              \
         _Pragma("unroll") for (int i = 0; i < NB; ++i)          /* row i = (plane i >> 1, k-block i & 1): 16-byte copies */ \
-            rw[i] = ldgu4(wg + ((int64_t)((nb >> 3) + (i & 1)) * 2 + (i >> 1)) * L.Ktot + tap * C);                   \
+            rw[i] = ldgu4(wg + (unsigned)((((nb >> 3) + (i & 1)) * 2 + (i >> 1)) * LKtot + tap * C));                \
     }
     bool xg_later = false;
     // first chunk requested BEFORE the coefficient prologue (it depends on neither the BN-backward sums nor the LDS tables):
     // its memory latency overlaps the prologue's
     {
         const int c1 = min(g, nchunk - 1);
-        CGK_DGRAD_LOAD_AT(__builtin_amdgcn_readfirstlane(c1 / ncn), __builtin_amdgcn_readfirstlane((c1 % ncn) * KH));
+        int tp1, cn1;
+        cg_divmod(c1, ncn, cg_inv(ncn), tp1, cn1);
+        CGK_DGRAD_LOAD_AT(__builtin_amdgcn_readfirstlane(tp1), __builtin_amdgcn_readfirstlane(cn1 * KH));
     }
+    BPROBE_STAMP();                             // 1: first loads issued
     if (hasbn) {
         for (int c = tid; c < Cs; c += NTHR) {
             float cf[5];
@@ -999,6 +1056,7 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
         }
     }
     __syncthreads();                            // chunk table and coefS ready
+    BPROBE_STAMP();                             // 2: prologue done
     for (int it = 0; it < nit; ++it) {
         const int c = it * G + g;
         if (c >= nchunk) break;                 // wave-uniform: no barrier inside the loop
@@ -1026,6 +1084,7 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
         if (!(FCN_XG & 8)) mma_chunk_kb16<MM, 2, LDRA, LDRB>(Ai, Bi, acc);
         __builtin_amdgcn_wave_barrier();        // ... and those reads before the next chunk's stores
     }
+    BPROBE_STAMP();                             // 3: K loop done (wave 0)
     if (FCN_XG & 16) { if (acc[0][0][0] == 123.456f) outp[0] = 0.f; return; }
     // sum of the 8 group accumulators through LDS in two rounds (8 x 32 x 64 floats do not fit): groups 4..7 park theirs,
     // groups 0..3 add them to their own and park the sums for the epilogue pass
@@ -1050,6 +1109,7 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
             }
     }
     __syncthreads();
+    BPROBE_STAMP();                             // 4: groups summed
     const int ecq = tid & 15;
     const int col = c0 + 4 * ecq;
     v4f ps = zero4(), pt = zero4(), pm = zero4(), pr = zero4();
@@ -1083,7 +1143,8 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
         cs1 += gsum;
         cs2 += gsum * xh;
     }
-    if (!bstat_src) return;
+    BPROBE_STAMP();                             // 5: outputs stored
+    if (!bstat_src) { BPROBE_FLUSH((1ull << 60) | ((unsigned long long)LKtot << 32) | ((unsigned long long)LCout << 16) | (unsigned long long)(C & 0xffff)); return; }
     float pv[8] = {cs1.x, cs1.y, cs1.z, cs1.w, cs2.x, cs2.y, cs2.z, cs2.w};
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -1107,6 +1168,8 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
         for (int r = 0; r < NTHR / 64; ++r) v += (double)st[(r * 64 + c) * 2 + w];
         atomic_add_f64(&bstat_src[(int64_t)(blockIdx.x % FCN_CG_REP) * cb.rep_stride + w * C + c0 + c], v);
     }
+    BPROBE_STAMP();                             // 6: statistics added
+    BPROBE_FLUSH((1ull << 60) | ((unsigned long long)LKtot << 32) | ((unsigned long long)LCout << 16) | (unsigned long long)(C & 0xffff));
 }
 
 // dWp[n][kk] = sum_r dy[r][n] * A[r][kk]; tile 64 (n) x 64 (kk); the workgroup owns rows [rbeg, rend) of one split.
@@ -1114,49 +1177,51 @@ __device__ __forceinline__ void cg_dgrad_body(const CgLayer &L, const CgBnBwd &c
 // 16 x 32 slice of dy and the 16 x 64 slice of A of its chunk into LDS buffers of its own and computes 32 (n) x 64 (kk) --
 // nothing is shared between waves, so the loop has no barrier (the A slice is staged by both waves of a stream: its
 // transform is one fma + max per value).  The stream accumulators are summed through LDS at the end.
-template <int MM>
-__device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float *smem)
+template <int MM, class AT>                     // AT: CgBwdStep, by value or through the kernarg pointer
+__device__ __forceinline__ void cg_wgrad_body(const AT &a, int wid, float *smem)
 {
     constexpr int KH = CGB_KH, NS = CGB_G / 2, LDW = CGB_LDW;
-    const CgLayer &L = a.lay;
+    const auto &L = a.lay;
+    BPROBE_DECL;
+    BPROBE_STAMP();                             // 0: entry
     const int tid = threadIdx.x, w = tid >> 6, st = w >> 1, wm = w & 1;
     const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
     float *As = smem + w * CGB_WSZ, *Bs = As + CGB_ASZ;
+    // the kernel-argument fields of the prologue as ONE batch of scalar loads (see cgk_fwd_body)
+    int w_ny = a.w_ny, w_ns = a.w_ns, a_rows = a.rows, adz16 = a.dz16;
+    int LB = L.B, LLout = L.Lout, LKtot = L.Ktot, LCs = L.Cs, LCout = L.Cout;
+    CgGeo geo;
+    geo.nseg = L.nseg; geo.KT = L.KT; geo.stride = L.stride; geo.pad = L.pad; geo.Lin = L.Lin;
+    int sC0 = L.seg[0].C, sC1 = L.seg[1].C, sC2 = L.seg[2].C, sC3 = L.seg[3].C;
+    CG_PIN(18, w_ny, w_ns, a_rows, adz16, LB, LLout, LKtot, LCs, LCout, geo.nseg, geo.KT, geo.stride, geo.pad, geo.Lin, sC0, sC1, sC2, sC3);
     // XCD order: the row split is the slow index, so the workgroups that reduce the same rows (all output tiles) share an L2
-    const int nyz = a.w_ny * (L.Ktot / 64);
-    const int wt = cg_xcd_tile(wid, a.w_ns * nyz);
+    const int nyz = w_ny * (LKtot / 64);
+    const int wt = cg_xcd_tile(wid, w_ns * nyz);
     if (wt < 0) return;
-    const int bx = wt / nyz, byz = wt % nyz, by = byz % a.w_ny, bz = byz / a.w_ny;
-    const int R = L.B * L.Lout, Cs = L.Cs;
-    const int rbeg = bx * a.rows, rend = min(R, rbeg + a.rows);
+    int bx, byz, by, bz;
+    cg_divmod(wt, nyz, cg_inv(nyz), bx, byz);                   // (wt < 2^23; float-reciprocal divisions)
+    cg_divmod(byz, w_ny, cg_inv(w_ny), bz, by);
+    const int R = LB * LLout, Cs = LCs;
+    const int rbeg = bx * a_rows, rend = min(R, rbeg + a_rows);
     const int n0 = by * 64 + wm * 32, kk0 = bz * 64;
     int sg, tap, k0, so;
-    cg_locate(L, kk0, sg, tap, k0, so);                   // kk0 is workgroup-uniform
+    cg_locate_s(geo, sC0, sC1, sC2, sC3, kk0, sg, tap, k0, so);         // kk0 is workgroup-uniform
     sg = __builtin_amdgcn_readfirstlane(sg);
-    const float *Sx = SEL4(sg, opaque_s(L.seg[0].x), opaque_s(L.seg[1].x), opaque_s(L.seg[2].x), opaque_s(L.seg[3].x));
-    const float *Sbn = SEL4(sg, opaque_s((const float *)L.seg[0].bn), opaque_s((const float *)L.seg[1].bn),
-                            opaque_s((const float *)L.seg[2].bn), opaque_s((const float *)L.seg[3].bn));
-    const int SC = SEL4(sg, opaque_s(L.seg[0].C), opaque_s(L.seg[1].C), opaque_s(L.seg[2].C), opaque_s(L.seg[3].C));
-    const int Sty = SEL4(sg, opaque_s(L.seg[0].type), opaque_s(L.seg[1].type), opaque_s(L.seg[2].type), opaque_s(L.seg[3].type));
-    const int SLs = SEL4(sg, opaque_s(L.seg[0].Lsrc), opaque_s(L.seg[1].Lsrc), opaque_s(L.seg[2].Lsrc), opaque_s(L.seg[3].Lsrc));
-    const int S16 = SEL4(sg, opaque_s(L.seg[0].st16), opaque_s(L.seg[1].st16), opaque_s(L.seg[2].st16), opaque_s(L.seg[3].st16));
+    // the segment's descriptor: `a` lives in the kernarg segment (cg_bwd_step_body reads it through the kernarg pointer), so a
+    // wave-uniform index is plain address arithmetic and the six fields come in ONE batch of scalar loads (selected field by field
+    // from four pinned copies they were 24 loads strung along a chain of branches)
+    const auto &S = L.seg[sg];
+    const float *Sx = S.x, *Sbn = (const float *)S.bn, *adz = a.dz, *Ly = (const float *)L.y;
+    const double *cbstat = a.cb.bstat;
+    int SC = S.C, Sty = S.type, SLs = S.Lsrc, S16 = S.st16;
+    CG_PIN(9, Sx, Sbn, adz, Ly, cbstat, SC, Sty, SLs, S16);
     // dy slice: 8 column quads x 8 row pairs (rows 2*pa, 2*pa + 1: a k pair); A slice: 16 column quads x 4 row pairs, twice
     const int cqa = lane & 7, pa = lane >> 3;
     const int cqb = lane & 15, pb = lane >> 4;
     // constants of the tile's 64 + 64 columns in LDS (registers are short: 4 waves per SIMD): BN-backward coefficients of dy
     // [5][64], BN scale / shift of the A operand [2][64]
-    const bool hasbn = a.cb.bstat != nullptr;
+    const bool hasbn = cbstat != nullptr;
     float *cfS = smem + CGB_LDS, *abS = cfS + 5 * 64;
-    if (tid < 64) {
-        float c5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-        if (hasbn) cg_bnbwd_coef(a.cb, Cs, (by * 64 + tid) % Cs, c5, false);
-#pragma unroll
-        for (int q = 0; q < 5; ++q) cfS[q * 64 + tid] = c5[q];
-    } else if (tid < 128) {
-        const int j = tid - 64;
-        abS[j] = Sbn ? Sbn[k0 + j] : 1.f;
-        abS[64 + j] = Sbn ? Sbn[SC + k0 + j] : 0.f;
-    }
     const float *cfp = cfS + wm * 32 + 4 * cqa, *abp = abS + 4 * cqb;
     f32x16 acc[1][2];
     acc_zero<1, 2>(acc);
@@ -1172,40 +1237,54 @@ __device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float
 #pragma unroll
     for (int p2 = 0; p2 < 2; ++p2) {
         const int r = rbeg + st * KH + 2 * (pb + 4 * p2);
-        if (fastdiv) cg_divmod(r, L.Lout, invL, wb[p2], wl[p2]);
-        else { wb[p2] = r / L.Lout; wl[p2] = r % L.Lout; }
+        if (fastdiv) cg_divmod(r, LLout, invL, wb[p2], wl[p2]);
+        else { wb[p2] = r / LLout; wl[p2] = r % LLout; }
     }
     int bend, lend;
-    if (fastdiv) cg_divmod(rend - 1, L.Lout, invL, bend, lend);
-    else { bend = (rend - 1) / L.Lout; lend = (rend - 1) % L.Lout; }
+    if (fastdiv) cg_divmod(rend - 1, LLout, invL, bend, lend);
+    else { bend = (rend - 1) / LLout; lend = (rend - 1) % LLout; }
 #define CG_WGRAD_LOAD(rr)                                                                                             \
     {                                                                                                                 \
         const int r0_ = (rr);                                                                                         \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                               \
             const int row = min(r0_ + 2 * pa + i, rend - 1);    /* clamped: unconditional loads, masked at store */   \
-            const int64_t o = (int64_t)row * L.Cout + n0 + 4 * cqa;                                                   \
-            if (St<MM>::half && a.dz16) {                                                                             \
-                rz[i] = lds4e<MM>(a.dz, o);                                                                           \
-                ry[i] = lds4e<MM>(hasbn ? L.y : a.dz, o);                                                             \
+            const unsigned o = (unsigned)(row * LCout + n0 + 4 * cqa);                                               \
+            if (St<MM>::half && adz16) {                                                                              \
+                rz[i] = lds4e<MM>(adz, o);                                                                            \
+                ry[i] = lds4e<MM>(hasbn ? Ly : adz, o);                                                               \
             } else {                                                                                                  \
-                rz[i] = ldg4(a.dz + o);                                                                               \
-                ry[i] = ldg4((hasbn ? L.y : a.dz) + o);                                                               \
+                rz[i] = ldg4(adz + o);                                                                                \
+                ry[i] = ldg4((hasbn ? Ly : adz) + o);                                                                 \
             }                                                                                                         \
         }                                                                                                             \
         _Pragma("unroll") for (int p2 = 0; p2 < 2; ++p2) {                                                            \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
                 const bool in = r0_ + 2 * (pb + 4 * p2) + i < rend;                                                   \
-                const bool wrap = i == 1 && wl[p2] + 1 >= L.Lout;                                                     \
+                const bool wrap = i == 1 && wl[p2] + 1 >= LLout;                                                     \
                 const int b_ = wrap ? wb[p2] + 1 : wb[p2], l_ = wrap ? 0 : wl[p2] + i;                                \
-                rx[2 * p2 + i] = cg_load_raw<MM>(L, Sx, xC, xLs, xlm, tap, k0 + 4 * cqb, in ? b_ : bend,              \
+                rx[2 * p2 + i] = cg_load_raw<MM>(geo, Sx, xC, xLs, xlm, tap, k0 + 4 * cqb, in ? b_ : bend,            \
                                                  in ? l_ : lend, true, ok[2 * p2 + i], S16);                          \
             }                                                                                                         \
             wl[p2] += NS * KH;                                                                                        \
-            while (wl[p2] >= L.Lout) { wl[p2] -= L.Lout; wb[p2] += 1; }                                               \
+            while (wl[p2] >= LLout) { wl[p2] -= LLout; wb[p2] += 1; }                                               \
         }                                                                                                             \
     }
+    // the first chunk is requested BEFORE the coefficient tables below are filled: they wait for the BatchNorm sums (a memory
+    // round trip of waves 0 and 1, which the workgroup's barrier then waits for) and the operand loads depend on neither
     if (st < nch) CG_WGRAD_LOAD(rbeg + st * KH);
+    BPROBE_STAMP();                             // 1: first loads issued
+    if (tid < 64) {
+        float c5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (hasbn) cg_bnbwd_coef(a.cb, Cs, (by * 64 + tid) % Cs, c5, false);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) cfS[q * 64 + tid] = c5[q];
+    } else if (tid < 128) {
+        const int j = tid - 64;
+        abS[j] = Sbn ? Sbn[k0 + j] : 1.f;
+        abS[64 + j] = Sbn ? Sbn[SC + k0 + j] : 0.f;
+    }
     __syncthreads();                            // cfS / abS ready
+    BPROBE_STAMP();                             // 2: prologue done
     for (int it = 0; it < nit; ++it) {
         const int c = NS * it + st;
         if (c >= nch) break;                    // wave-uniform: no barrier inside the loop
@@ -1256,6 +1335,7 @@ __device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float
         if (!(FCN_XG & 1024)) mma_chunk<MM, 1, 2, LDW, LDN, KH>(As, Bs, 0, 0, acc);
         __builtin_amdgcn_wave_barrier();        // ... and those reads before the next chunk's stores
     }
+    BPROBE_STAMP();                             // 3: K loop done (wave 0)
     // streams 2, 3 park their accumulators, streams 0, 1 add them to their own; stream 1 parks the sum, stream 0 adds it and
     // writes the split's partial
     float *red = smem + (((st & 1) * 2 + wm) * 32) * 64;    // [2 slots][2 halves][32][64]
@@ -1280,24 +1360,27 @@ __device__ __forceinline__ void cg_wgrad_body(const CgBwdStep &a, int wid, float
     __syncthreads();
     if (st == 0) {
         const float *r1 = smem + ((2 + wm) * 32) * 64;      // stream 1's slot
-        float *out = a.partial + (int64_t)bx * L.Cout * L.Ktot;
+        float *out = a.partial + (int64_t)bx * LCout * LKtot;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int rr = acc_row(reg, lh), cc = j * 32 + l31;
-                out[(int64_t)(n0 + rr) * L.Ktot + kk0 + cc] = acc[0][j][reg] + r1[rr * 64 + cc];
+                out[(int64_t)(n0 + rr) * LKtot + kk0 + cc] = acc[0][j][reg] + r1[rr * 64 + cc];
             }
     }
+    BPROBE_STAMP();                             // 4: partial written (wave 0: behind the last barrier)
+    BPROBE_FLUSH((2ull << 60) | ((unsigned long long)LKtot << 32) | ((unsigned long long)LCout << 16) | (unsigned long long)(LLout & 0xffff));
 }
 
 // dW (torch layout) = sum of the split partials (fixed order); padding columns/rows are dropped.  The workgroup covers
 // CGB_T / gr consecutive packed elements with gr split groups (gr = 1, 2, 4 or 8, chosen on the host from the split
 // count): big layers have few splits and many elements (one thread per element), small layers the opposite (a few
 // independent loads per thread, then a group sum through LDS).
-__device__ __forceinline__ void cg_reduce_body(const CgReduce &q, int rid, float *smem)
+template <class QT>
+__device__ __forceinline__ void cg_reduce_body(const QT &q, int rid, float *smem)
 {
-    const CgPack &p = q.pk;
+    const auto &p = q.pk;
     if (q.gr == 0) {                    // column sum of dlogits (R = p.N rows, row stride q.nsplit): dbias of the heads
         float t = 0.f;
         for (int r = threadIdx.x; r < p.N; r += CGB_T) t += q.partial[(int64_t)r * q.nsplit + rid];
@@ -1339,32 +1422,38 @@ __device__ __forceinline__ void cg_reduce_body(const CgReduce &q, int rid, float
 template <int MM>
 __device__ __forceinline__ void cg_bwd_step_body(const CgBwdStep &a, const int bid, float *smem, const int koff)
 {
+    // The role of this workgroup from ONE batch of scalar loads of the by-value parameter; everything else is read through the kernarg
+    // POINTER inside the role that needs it (cg_kernarg_layer explains: fields read through the by-value parameter are all fetched in
+    // the entry block -- here the union of what three roles read, a dozen serialized s_load / s_waitcnt / v_writelane batches in front
+    // of every one of the 800-2 800 workgroups of a launch).
+    const int r_blk0 = opaque_s(a.r_blk0), w_blk0 = opaque_s(a.w_blk0), ndg = opaque_s(a.ndg);
+    const int b1 = opaque_s(a.dg[1].blk0), b2 = opaque_s(a.dg[2].blk0), b3 = opaque_s(a.dg[3].blk0);
+    typedef __attribute__((address_space(4))) const char *kchar_p;
+    typedef __attribute__((address_space(4))) const CgBwdStep *kstep_p;
+    kstep_p ak = (kstep_p)((kchar_p)__builtin_amdgcn_kernarg_segment_ptr() + koff);
+    asm volatile("" : "+s"(ak) : : "memory");
 #ifndef CGB_NO_REDUCE
-    if (bid >= a.r_blk0) { cg_reduce_body(a.red, bid - a.r_blk0, smem); return; }
+    if (bid >= r_blk0) { cg_reduce_body(ak->red, bid - r_blk0, smem); return; }
 #endif
 #ifndef CGB_NO_WGRAD
-    if (bid >= a.w_blk0) { cg_wgrad_body<MM>(a, bid - a.w_blk0, smem); return; }
+    if (bid >= w_blk0) { cg_wgrad_body<MM>(*ak, bid - w_blk0, smem); return; }
 #endif
 #ifdef CGB_NO_DGRAD
     return;
 #endif
-    const int role = __builtin_amdgcn_readfirstlane(
-        (a.ndg > 3 && bid >= a.dg[3].blk0) ? 3 : ((a.ndg > 2 && bid >= a.dg[2].blk0) ? 2 : ((a.ndg > 1 && bid >= a.dg[1].blk0) ? 1 : 0)));
-    // The role's segment descriptor is one of four: selecting it field by field from the by-value struct costs 4 x 14 pinned
-    // SGPRs, and indexing the struct dynamically makes LLVM copy the whole kernarg struct to scratch.  It IS an array in the
-    // kernarg segment, though: a scalar load at a wave-uniform offset from the kernarg pointer fetches exactly one.
-#if FCN_BWD_PERSIST == 2
-    const CgDgSeg *g = &a.dg[role];            // (the descriptor lives in LDS in this experiment: dynamic indexing is plain address arithmetic)
-#else
-    typedef __attribute__((address_space(4))) const char *kchar_p;
-    typedef __attribute__((address_space(4))) const CgDgSeg *kdg_p;
-    const kdg_p g = (kdg_p)((kchar_p)__builtin_amdgcn_kernarg_segment_ptr() + koff + offsetof(CgBwdStep, dg)) + role;
-#endif
-    const int ncb = g->ncb;
-    const int t = cg_xcd_tile(bid - g->blk0, g->tx * ncb);
+    const int role = __builtin_amdgcn_readfirstlane((ndg > 3 && bid >= b3) ? 3 : ((ndg > 2 && bid >= b2) ? 2 : ((ndg > 1 && bid >= b1) ? 1 : 0)));
+    // The role's segment descriptor is one of four: a scalar load at a wave-uniform offset from the kernarg pointer fetches exactly
+    // one (selecting it field by field from the by-value struct costs 4 x 14 pinned SGPRs, and indexing the struct dynamically makes
+    // LLVM copy the whole kernarg struct to scratch).
+    const auto *g = &ak->dg[role];
+    int ncb = g->ncb, gtx = g->tx, gblk0 = g->blk0;
+    CG_PIN(3, ncb, gtx, gblk0);
+    const int t = cg_xcd_tile(bid - gblk0, gtx * ncb);
     if (t < 0) return;
-    cg_dgrad_body<MM>(a.lay, a.cb, a.dz, a.lay.y, g->sg, g->segoff, g->ysrc, g->bnsrc, g->out, g->accumulate,
-                      g->bstat_src, t / ncb, t % ncb, bid == 0, smem, a.dz16, g->out16);
+    int tbx, tby;
+    cg_divmod(t, ncb, cg_inv(ncb), tbx, tby);                  // (t < 2^23)
+    cg_dgrad_body<MM>(ak->lay, ak->cb, ak->dz, ak->lay.y, g->sg, g->segoff, g->ysrc, g->bnsrc, g->out, g->accumulate,
+                      g->bstat_src, tbx, tby, bid == 0, smem, ak->dz16, g->out16);
 }
 
 template <int MM>
@@ -1389,63 +1478,6 @@ __global__ __launch_bounds__(CGB_T, 4) void cg_bwd_pair_kernel(CgBwdPair p)
     if (bid < p.na) cg_bwd_step_body<MM>(p.A, bid, smem, (int)offsetof(CgBwdPair, A));
     else cg_bwd_step_body<MM>(p.B, bid - p.na, smem, (int)offsetof(CgBwdPair, B));
 }
-
-#if FCN_BWD_PERSIST
-typedef __attribute__((address_space(3))) float *cg_lds_p;
-typedef __attribute__((address_space(3))) const CgBwdStep *cg_lds_step_p;
-// one work item as a REAL call: the body keeps its own register allocation (inlined into the dequeue loop it spills at the 128-VGPR
-// budget of 4 waves per SIMD).  Descriptors and operand buffers arrive as address_space(3) pointers: a callee that only sees
-// generic pointers would use flat instructions.
-template <int MM>
-__device__ __attribute__((noinline)) void cg_bwd_item(cg_lds_step_p a3, const int koff, const int bid, cg_lds_p smem3)
-{
-    cg_bwd_step_body<MM>(*(const CgBwdStep *)a3, bid, (float *)smem3, koff);
-}
-
-#ifndef FCN_BWD_OCC
-#define FCN_BWD_OCC 4          // waves per SIMD the persistent kernel is compiled for (2: 256 VGPRs, one workgroup per CU)
-#endif
-template <int MM>
-__global__ __launch_bounds__(CGB_T, FCN_BWD_OCC) void cg_bwd_persist_kernel(CgBwdPair p, int total, int qslot)
-{
-    __shared__ __attribute__((aligned(16))) float smem[CGB_SMEM];
-    __shared__ int item_s;
-#if FCN_BWD_PERSIST == 2
-    __shared__ __attribute__((aligned(16))) int desc[2][(sizeof(CgBwdStep) + 3) / 4];
-    {
-        typedef __attribute__((address_space(4))) const char *kchar_p;
-        typedef __attribute__((address_space(4))) const int *kint_p;
-        const kint_p ka = (kint_p)((kchar_p)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(CgBwdPair, A));
-        const kint_p kb = (kint_p)((kchar_p)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(CgBwdPair, B));
-        for (int i = threadIdx.x; i < (int)(sizeof(CgBwdStep) / 4); i += CGB_T) { desc[0][i] = ka[i]; desc[1][i] = kb[i]; }
-    }
-#endif
-    const int xcd = (int)blockIdx.x & 7;
-    unsigned int *head = g_cgq + (qslot * 8 + xcd) * 16;
-    const int per = (total + 7 - xcd) >> 3;             // items of this XCD: xcd, xcd + 8, ...
-    int nxt = 0;
-    if (threadIdx.x == 0) nxt = (int)atomicAdd(head, 1u);
-    for (int guard = 0; guard < (1 << 20); ++guard) {
-        if (threadIdx.x == 0) {
-            item_s = nxt;
-            nxt = (int)atomicAdd(head, 1u);             // the next ticket: in flight while this item runs
-        }
-        __syncthreads();
-        const int k = item_s;
-        __syncthreads();
-        if (k >= per) return;
-        const int bid = __builtin_amdgcn_readfirstlane(8 * k + xcd);
-#if FCN_BWD_PERSIST == 2
-        if (bid < p.na) cg_bwd_item<MM>((cg_lds_step_p)&desc[0][0], (int)offsetof(CgBwdPair, A), bid, (cg_lds_p)smem);
-        else cg_bwd_item<MM>((cg_lds_step_p)&desc[1][0], (int)offsetof(CgBwdPair, B), bid - p.na, (cg_lds_p)smem);
-#else
-        if (bid < p.na) cg_bwd_step_body<MM>(p.A, bid, smem, (int)offsetof(CgBwdPair, A));
-        else cg_bwd_step_body<MM>(p.B, bid - p.na, smem, (int)offsetof(CgBwdPair, B));
-#endif
-        __syncthreads();
-    }
-}
-#endif
 
 // ================================================================================================
 // Host side: the topology of ConvFeatNet(128, nvec) + heads for n = 4 (models/det_base.py:163-224) or n = 5 pyramid levels
@@ -1945,17 +1977,8 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
         }
         pp.na = nA;
         if (nA + nB > 0) {
-#if FCN_BWD_PERSIST
-            {
-                if (nB == 0) pp.B = pp.A;               // (a valid descriptor in the unused slot)
-                const int total = nA + nB;
-                const int grid = total < FCN_BWD_SLOTS ? ((total + 7) / 8) * 8 : FCN_BWD_SLOTS;
-                FCN_MM_SWITCH(mmb, hipLaunchKernelGGL(cg_bwd_persist_kernel<MM>, dim3(grid), dim3(CGB_T), 0, st, pp, total, k));
-            }
-#else
             if (nB > 0) { FCN_MM_SWITCH(mmb, hipLaunchKernelGGL(cg_bwd_pair_kernel<MM>, dim3(nA + nB), dim3(CGB_T), 0, st, pp)); }
             else { FCN_MM_SWITCH(mmb, hipLaunchKernelGGL(cg_bwd_step_kernel<MM>, dim3(nA), dim3(CGB_T), 0, st, pp.A)); }
-#endif
             FCN_CHECK_LAUNCH();
         }
         pendA = ownA; pendA_blocks = ownA_blocks;

@@ -375,6 +375,7 @@ inline T emu_atomic_load(const T *p) { T t; __atomic_load(const_cast<T *>(p), &t
 #define __hip_atomic_load(p, order, scope) emu_atomic_load((p))
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))           // v_rcp_f32 (1 ulp on the GPU; only used where a correction step follows)
 // wave-synchronous LDS exchange: on the GPU the 64 lanes execute in lockstep and this builtin only pins the compiler's
 // order; here the lanes are coroutines, so it is a real wave-level barrier
 #define __builtin_amdgcn_wave_barrier() emu::group_barrier(emu::waves[emu::cur->wave])
