@@ -384,8 +384,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         const int gr = row0 + rb + RSTEP * i;
         rv[i] = gr < R;
         int q_ = 0, r_ = 0;
-        if (R < (1 << 23)) cg_divmod(rv[i] ? gr : 0, LLout, cg_inv(LLout), q_, r_);
-        else { q_ = (rv[i] ? gr : 0) / LLout; r_ = (rv[i] ? gr : 0) % LLout; }
+        cg_divmod(rv[i] ? gr : 0, LLout, cg_inv(LLout), q_, r_);           // (R < 2^23: cn_make_plan)
         bb[i] = q_;
         ll[i] = r_;
     }
@@ -985,8 +984,7 @@ __device__ __forceinline__ void cg_dgrad_body(const LT &L, const CT &cb, const f
         const int gr = row0 + rb + RSTEP * i;
         rv[i] = gr < Rs;
         int q_ = 0, r_ = 0;
-        if (Rs < (1 << 23)) cg_divmod(rv[i] ? gr : 0, SLsrc, cg_inv(SLsrc), q_, r_);
-        else { q_ = (rv[i] ? gr : 0) / SLsrc; r_ = (rv[i] ? gr : 0) % SLsrc; }
+        cg_divmod(rv[i] ? gr : 0, SLsrc, cg_inv(SLsrc), q_, r_);           // (Rs < 2^23: cn_make_plan)
         bb[i] = q_;
         li[i] = r_;
         rv[i] = rv[i] && li[i] < LLin;
@@ -1233,16 +1231,10 @@ __device__ __forceinline__ void cg_wgrad_body(const AT &a, int wid, float *smem)
     // out of the row index; the second row of a pair is the next position (or position 0 of the next frustum)
     int wb[2], wl[2];
     const float invL = cg_inv(L.Lout);
-    const bool fastdiv = R < (1 << 23);
 #pragma unroll
-    for (int p2 = 0; p2 < 2; ++p2) {
-        const int r = rbeg + st * KH + 2 * (pb + 4 * p2);
-        if (fastdiv) cg_divmod(r, LLout, invL, wb[p2], wl[p2]);
-        else { wb[p2] = r / LLout; wl[p2] = r % LLout; }
-    }
+    for (int p2 = 0; p2 < 2; ++p2) cg_divmod(rbeg + st * KH + 2 * (pb + 4 * p2), LLout, invL, wb[p2], wl[p2]);      // (R < 2^23: cn_make_plan)
     int bend, lend;
-    if (fastdiv) cg_divmod(rend - 1, LLout, invL, bend, lend);
-    else { bend = (rend - 1) / LLout; lend = (rend - 1) % LLout; }
+    cg_divmod(rend - 1, LLout, invL, bend, lend);
 #define CG_WGRAD_LOAD(rr)                                                                                             \
     {                                                                                                                 \
         const int r0_ = (rr);                                                                                         \
@@ -1316,6 +1308,13 @@ __device__ __forceinline__ void cg_wgrad_body(const AT &a, int wid, float *smem)
             sts4(As + (2 * pa + 1) * LDW + 4 * cqa, lo);
 #pragma unroll
             for (int p2 = 0; p2 < 2; ++p2) {
+                if (FCN_XG & 2048) {            // (timing build: the activation operand as plain 16-byte copies -- a pre-encoded image's cost)
+                    // (masked to small finite 16-bit halves: raw fp32 bits read as bf16 pairs would turn the weights into NaN)
+                    v4i m0 = __builtin_bit_cast(v4i, rx[2 * p2]) & 0x3f7f3f7f, m1 = __builtin_bit_cast(v4i, rx[2 * p2 + 1]) & 0x3f7f3f7f;
+                    sts4(Bs + (2 * (pb + 4 * p2)) * LDN + 4 * cqb, __builtin_bit_cast(v4f, m0));
+                    sts4(Bs + (2 * (pb + 4 * p2) + 1) * LDN + 4 * cqb, __builtin_bit_cast(v4f, m1));
+                    continue;
+                }
                 v4f av2[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -1582,6 +1581,11 @@ static int cn_make_plan(const fcn_cn_desc *d, CnPlan &P)
         P.cin_tot[l] = ct;
         // LDS tables of the kernels: per-column BN scale/shift, per-chunk descriptors, BN-backward coefficients
         if (P.Ktot[l] > CG_KMAX || P.KT[l] * P.N[l] > CG_KBWD || P.Cs[l] > CG_CMAX || P.KT[l] > 3 || P.stride[l] > 2) return FCN_E_LIMIT;
+        // the kernels address every arena with 32-bit element offsets and divide row indices through a float reciprocal
+        // (cg_divmod: exact below 2^23): rows of a layer, elements of its input / output / packed weights
+        const int64_t rows = (int64_t)d->B * (P.Lout[l] > P.Lin[l] ? P.Lout[l] : P.Lin[l]);
+        if (rows >= ((int64_t)1 << 23) || rows * (P.N[l] > cs ? P.N[l] : cs) >= ((int64_t)1 << 31) ||
+            (int64_t)P.N[l] * P.Ktot[l] >= ((int64_t)1 << 31)) return FCN_E_LIMIT;
     }
     return 0;
 }
