@@ -831,6 +831,8 @@ struct CgDgSeg {               // one differentiated input segment of the layer
     double *bstat_src;         // non-null on the LAST consumer: sum dz, sum dz*xhat of the producer
     int tx, ncb;               // row tiles (32 rows each) and 64-channel column blocks; tile t -> (t / ncb, t % ncb)
     int blk0;                  // first workgroup of this segment (a multiple of 8)
+    int wave_tiles;            // SHORT reductions (at most CGB_ROWS_MAXCH chunks: the heads, K = 64): a workgroup takes 8 tiles, one per
+                               // wave, each wave reducing all chunks of its tile -- no cross-wave sum, an eighth of the workgroups
 };
 
 struct CgReduce {
@@ -861,6 +863,9 @@ struct CgBwdStep {
 #define CGB_T 512
 #define CGB_G 8                // K-groups of a data-gradient tile: ONE wave each
 #define CGB_KH 16              // reduction chunk of a K-group (one 32x32x16 step)
+#ifndef CGB_ROWS_MAXCH
+#define CGB_ROWS_MAXCH 4       // data-gradient tiles with at most this many chunks run one per WAVE (CgDgSeg.wave_tiles)
+#endif
 #define CGB_LDA 34             // A leading dimension: 4 * LDA = 8 (mod 32) spreads a half-wave's ds_write_b32 over all banks
 // G waves x (A [KH][LDA or LDW] + B [KH][LDN]) + BN-backward coefficients + chunk tables
 #define CGB_LDW 36             // leading dimension of the weight-gradient role's dy operand (float4 stores: rows 16-B aligned)
@@ -940,11 +945,12 @@ __device__ __forceinline__ void mma_chunk_kb16(const u32x4 *A, const u32x4 *B, f
 // write -> read -> write sequence of its K loop needs no barrier (cgk_fwd_body does the same).  The groups take 16-deep
 // chunks g, g + 8, ...: a wave stages the same number of operand values per step as a wave of the former two-wave groups
 // did with 32-deep chunks (32 x 16 of dy + 16 x 64 of W), and computes the whole 32 x 64 tile of its chunk.
-template <int MM, class LT, class CT>           // LT / CT: CgLayer / CgBnBwd, by value or through the kernarg pointer
+// ROWS (CgDgSeg.wave_tiles): bx = the workgroup's first tile, by = the segment's tile count; wave g owns tile bx + g alone.
+template <int MM, bool ROWS, class LT, class CT>           // LT / CT: CgLayer / CgBnBwd, by value or through the kernarg pointer
 __device__ __forceinline__ void cg_dgrad_body(const LT &L, const CT &cb, const float *dzc, const float *yc,
                                               int sgi, int segoff, const float *ysrc, const float *bnsrc, float *outp,
                                               int accumulate, double *bstat_src, int bx, int by, bool pub, float *smem,
-                                              int dz16, int out16)
+                                              int dz16, int out16, int ncb = 1)
 {
     // (bf16 throughput mode: dz16 -- this layer's dz / y are bf16 arenas (not the heads' fp32 dlogits); out16 -- `outp` is a
     // layer's dz arena (not a pooled feature map's fp32 gradient); the producer's y behind `ysrc` always is one)
@@ -973,6 +979,14 @@ __device__ __forceinline__ void cg_dgrad_body(const LT &L, const CT &cb, const f
     const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
     u32x4 *Ai = (u32x4 *)(lds + g * CGB_WSZ), *Bi = (u32x4 *)(lds + g * CGB_WSZ + ASZ);
     const int C = SC, Rs = LB * SLsrc, Cs = LCs;
+    bool wave_live = true;
+    if constexpr (ROWS) {                               // this wave's own tile (the prologue's barrier is reached by every wave)
+        const int t = bx + g;
+        wave_live = t < by;
+        int tbx, tby;
+        cg_divmod(wave_live ? t : 0, ncb, cg_inv(ncb), tbx, tby);
+        bx = __builtin_amdgcn_readfirstlane(tbx); by = __builtin_amdgcn_readfirstlane(tby);
+    }
     const int row0 = bx * TMB, c0 = by * 64;
     const int kq = lane & 3, rb = lane >> 2;            // dy: 4 column quads x 16 rows per pass
     constexpr int RSTEP = 16;
@@ -994,7 +1008,7 @@ __device__ __forceinline__ void cg_dgrad_body(const LT &L, const CT &cb, const f
     acc_zero<1, 2>(acc);
     v4f rz[NA], ry[NA];
     u32x4 rw[NB];
-    const int ncn = LCout / KH, nchunk = LKT * ncn, nit = (nchunk + G - 1) / G;
+    const int ncn = LCout / KH, nchunk = LKT * ncn, nit = ROWS ? nchunk : (nchunk + G - 1) / G;
     // No integer division inside the reduction loop (each one is ~40 VALU instructions and the loop body is otherwise
     // ~100): the (tap, column base, BN channel base) of every chunk comes from a small LDS table.
     if (tid < nchunk) {
@@ -1039,7 +1053,7 @@ __device__ __forceinline__ void cg_dgrad_body(const LT &L, const CT &cb, const f
     // first chunk requested BEFORE the coefficient prologue (it depends on neither the BN-backward sums nor the LDS tables):
     // its memory latency overlaps the prologue's
     {
-        const int c1 = min(g, nchunk - 1);
+        const int c1 = ROWS ? 0 : min(g, nchunk - 1);
         int tp1, cn1;
         cg_divmod(c1, ncn, cg_inv(ncn), tp1, cn1);
         CGK_DGRAD_LOAD_AT(__builtin_amdgcn_readfirstlane(tp1), __builtin_amdgcn_readfirstlane(cn1 * KH));
@@ -1055,8 +1069,9 @@ __device__ __forceinline__ void cg_dgrad_body(const LT &L, const CT &cb, const f
     }
     __syncthreads();                            // chunk table and coefS ready
     BPROBE_STAMP();                             // 2: prologue done
+    if (ROWS && !wave_live) return;             // (no barrier behind this point in the one-tile-per-wave form)
     for (int it = 0; it < nit; ++it) {
-        const int c = it * G + g;
+        const int c = ROWS ? it : it * G + g;
         if (c >= nchunk) break;                 // wave-uniform: no barrier inside the loop
         xg_later = true;
         if (!((FCN_XG & 4) && it > 0))
@@ -1078,12 +1093,60 @@ __device__ __forceinline__ void cg_dgrad_body(const LT &L, const CT &cb, const f
             for (int i = 0; i < NB; ++i) Bi[((i >> 1) * 2 + (i & 1)) * LDRB + lane] = rw[i];
         }
         __builtin_amdgcn_wave_barrier();        // (compiler only) the stores above before the operand reads of every lane
-        if (c + G < nchunk) CGK_DGRAD_LOAD(c + G);
+        if (c + (ROWS ? 1 : G) < nchunk) CGK_DGRAD_LOAD(c + (ROWS ? 1 : G));
         if (!(FCN_XG & 8)) mma_chunk_kb16<MM, 2, LDRA, LDRB>(Ai, Bi, acc);
         __builtin_amdgcn_wave_barrier();        // ... and those reads before the next chunk's stores
     }
     BPROBE_STAMP();                             // 3: K loop done (wave 0)
     if (FCN_XG & 16) { if (acc[0][0][0] == 123.456f) outp[0] = 0.f; return; }
+    if constexpr (ROWS) {
+        // the wave's tile straight from the accumulators (MFMA layout: lane = column l31 (+ 32 j), registers = 16 rows): ReLU mask of
+        // the producer, store, BatchNorm-backward sums of the producer -- per column over the lane's rows, the two half-waves joined by
+        // one shuffle, then fp64 atomics (the same count per tile as the workgroup form)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = c0 + j * 32 + l31;
+            float ps = 0.f, pt = 0.f, pm = 0.f, pr = 0.f;
+            if (bnsrc) { ps = bnsrc[col]; pt = bnsrc[C + col]; pm = bnsrc[2 * C + col]; pr = bnsrc[3 * C + col]; }
+            float yv[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {        // (all loads first: see the PointNet data-gradient epilogue)
+                const int row = min(row0 + acc_row(reg, lh), Rs - 1);
+                yv[reg] = bnsrc ? lds1e<MM>(ysrc, (int64_t)row * C + col) : 0.f;
+            }
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = row0 + acc_row(reg, lh);
+                if (row < Rs) {
+                    float gs = acc[0][j][reg];
+                    float xh = 0.f;
+                    if (bnsrc) { gs = fmaf(ps, yv[reg], pt) > 0.f ? gs : 0.f; xh = (yv[reg] - pm) * pr; }
+                    const int64_t o = (int64_t)row * C + col;
+                    if (St<MM>::half && out16) {
+                        if (accumulate) gs += lds1e<MM>(outp, o);
+                        sts1e<MM>(outp, o, gs);
+                        gs = st_round<MM>(gs);             // the sums are over the values as stored
+                    } else {
+                        if (accumulate) gs += outp[o];
+                        outp[o] = gs;
+                    }
+                    s1 += gs;
+                    s2 = fmaf(gs, xh, s2);
+                }
+            }
+            if (bstat_src) {
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (lh == 0) {
+                    double *br = bstat_src + (int64_t)(blockIdx.x % FCN_CG_REP) * cb.rep_stride;
+                    atomic_add_f64(&br[col], (double)s1);
+                    atomic_add_f64(&br[C + col], (double)s2);
+                }
+            }
+        }
+        return;
+    }
     // sum of the 8 group accumulators through LDS in two rounds (8 x 32 x 64 floats do not fit): groups 4..7 park theirs,
     // groups 0..3 add them to their own and park the sums for the epilogue pass
     constexpr int GE = G / 2;
@@ -1445,14 +1508,22 @@ __device__ __forceinline__ void cg_bwd_step_body(const CgBwdStep &a, const int b
     // one (selecting it field by field from the by-value struct costs 4 x 14 pinned SGPRs, and indexing the struct dynamically makes
     // LLVM copy the whole kernarg struct to scratch).
     const auto *g = &ak->dg[role];
-    int ncb = g->ncb, gtx = g->tx, gblk0 = g->blk0;
-    CG_PIN(3, ncb, gtx, gblk0);
+    int ncb = g->ncb, gtx = g->tx, gblk0 = g->blk0, gwt = g->wave_tiles;
+    CG_PIN(4, ncb, gtx, gblk0, gwt);
+    if (gwt) {                          // short reduction: eight tiles per workgroup, one per wave
+        const int ntile = gtx * ncb;
+        const int t = cg_xcd_tile(bid - gblk0, (ntile + CGB_G - 1) / CGB_G);
+        if (t < 0) return;
+        cg_dgrad_body<MM, true>(ak->lay, ak->cb, ak->dz, ak->lay.y, g->sg, g->segoff, g->ysrc, g->bnsrc, g->out, g->accumulate,
+                                g->bstat_src, t * CGB_G, ntile, bid == 0, smem, ak->dz16, g->out16, ncb);
+        return;
+    }
     const int t = cg_xcd_tile(bid - gblk0, gtx * ncb);
     if (t < 0) return;
     int tbx, tby;
     cg_divmod(t, ncb, cg_inv(ncb), tbx, tby);                  // (t < 2^23)
-    cg_dgrad_body<MM>(ak->lay, ak->cb, ak->dz, ak->lay.y, g->sg, g->segoff, g->ysrc, g->bnsrc, g->out, g->accumulate,
-                      g->bstat_src, tbx, tby, bid == 0, smem, ak->dz16, g->out16);
+    cg_dgrad_body<MM, false>(ak->lay, ak->cb, ak->dz, ak->lay.y, g->sg, g->segoff, g->ysrc, g->bnsrc, g->out, g->accumulate,
+                             g->bstat_src, tbx, tby, bid == 0, smem, ak->dz16, g->out16);
 }
 
 template <int MM>
@@ -1880,6 +1951,7 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
         for (int s = 0; s < CG_NSEG; ++s) {
             dgs[s]->sg = 0; dgs[s]->segoff = 0; dgs[s]->ysrc = dgs[s]->bnsrc = nullptr; dgs[s]->out = nullptr;
             dgs[s]->accumulate = 0; dgs[s]->out16 = 0; dgs[s]->bstat_src = nullptr; dgs[s]->tx = 1; dgs[s]->ncb = 1; dgs[s]->blk0 = 0;
+            dgs[s]->wave_tiles = 0;
         }
         blank_reduce(own);
         own_blocks = 0;
@@ -1921,7 +1993,10 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
 #if (FCN_EXP & 8)       // timing experiment (tools build, wrong gradients): one data-gradient tile per segment only
                 g.tx = 1; g.ncb = 1;
 #endif
-                nblk += cg_pad8(g.tx * g.ncb);
+#ifndef FCN_NO_WAVE_TILES
+                g.wave_tiles = (P.KT[l] * (P.N[l] / CGB_KH) <= CGB_ROWS_MAXCH) ? 1 : 0;       // (chunks of the reduction: KT * Cout / 16)
+#endif
+                nblk += cg_pad8(g.wave_tiles ? (g.tx * g.ncb + CGB_G - 1) / CGB_G : g.tx * g.ncb);
                 a.ndg += 1;
             }
             segoff += P.KT[l] * P.C[l][s];

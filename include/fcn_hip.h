@@ -260,7 +260,8 @@ typedef struct fcn_cn_params {
 } fcn_cn_params;
 
 /* Workspace; element counts come from fcn_convnet_sizes (out6: y/dz floats, packed-weight floats, bn floats,
- * stat/bstat doubles, coef floats, wgrad-partial floats). */
+ * stat/bstat doubles, coef floats, wgrad-partial floats).  Size limits (FCN_E_LIMIT from every fcn_convnet_* entry): B * L1 < 2^23
+ * rows and every layer's B * L * C (and Cout * Ktot) < 2^31 elements -- the kernels address with 32-bit offsets. */
 typedef struct fcn_cn_ws {
     float  *y, *dz, *wp, *bn;
     double *stat, *bstat;
