@@ -140,7 +140,7 @@ extern "C" int fcn_probe_read(unsigned long long *host_out, int max_records, int
 #define PROBE_FLUSH(tag)
 #endif
 // (-DFCN_PROBE=3: the stamps of the BACKWARD roles instead -- tag bit 60: data-gradient tile, bit 61: weight-gradient workgroup)
-#if defined(FCN_PROBE) && FCN_PROBE == 3
+#if defined(FCN_PROBE) && FCN_PROBE >= 3
 #define BPROBE_DECL unsigned long long pb_[8]; int pbn_ = 0
 #define BPROBE_STAMP() do { if (pbn_ < 7) pb_[pbn_++] = wall_clock64(); } while (0)
 #define BPROBE_FLUSH(tag) PROBE_FLUSH(tag)
@@ -860,8 +860,13 @@ struct CgBwdStep {
     CgReduce red;
 };
 
-#define CGB_T 512
-#define CGB_G 8                // K-groups of a data-gradient tile: ONE wave each
+#ifndef CGB_G
+#define CGB_G 4                // K-groups of a data-gradient tile = waves of a backward workgroup, ONE wave each.  4 (256 threads, 38 KB
+                               // of LDS: four workgroups per CU) against the 8 of rounds 3-4 (512 threads, 64 KB: two per CU): the same 16
+                               // waves per CU in twice as many, half as long-lived workgroups -- step 1.216-1.226 -> 1.177-1.181 ms (-3.4 %) on
+                               // MI355X; 2: +10 % (the K loops get too long for the launches' tails)
+#endif
+#define CGB_T (64 * CGB_G)
 #define CGB_KH 16              // reduction chunk of a K-group (one 32x32x16 step)
 #ifndef CGB_ROWS_MAXCH
 #define CGB_ROWS_MAXCH 4       // data-gradient tiles with at most this many chunks run one per WAVE (CgDgSeg.wave_tiles)
@@ -1147,8 +1152,8 @@ __device__ __forceinline__ void cg_dgrad_body(const LT &L, const CT &cb, const f
         }
         return;
     }
-    // sum of the 8 group accumulators through LDS in two rounds (8 x 32 x 64 floats do not fit): groups 4..7 park theirs,
-    // groups 0..3 add them to their own and park the sums for the epilogue pass
+    // sum of the G group accumulators through LDS in two rounds (G x 32 x 64 floats do not fit at G = 8): the upper half park theirs,
+    // the lower half add them to their own and park the sums for the epilogue pass
     constexpr int GE = G / 2;
     float *red = lds;                                   // [GE][TMB][64]
     __syncthreads();                            // every group is done with its operand buffers
@@ -1234,7 +1239,7 @@ __device__ __forceinline__ void cg_dgrad_body(const LT &L, const CT &cb, const f
 }
 
 // dWp[n][kk] = sum_r dy[r][n] * A[r][kk]; tile 64 (n) x 64 (kk); the workgroup owns rows [rbeg, rend) of one split.
-// Its eight waves are four row-chunk STREAMS (16-row chunks s, s + 4, ...) x two halves of the n side: a wave stages the
+// Its waves are CGB_G / 2 row-chunk STREAMS (16-row chunks s, s + NS, ...) x two halves of the n side: a wave stages the
 // 16 x 32 slice of dy and the 16 x 64 slice of A of its chunk into LDS buffers of its own and computes 32 (n) x 64 (kk) --
 // nothing is shared between waves, so the loop has no barrier (the A slice is staged by both waves of a stream: its
 // transform is one fma + max per value).  The stream accumulators are summed through LDS at the end.
@@ -1402,14 +1407,17 @@ __device__ __forceinline__ void cg_wgrad_body(const AT &a, int wid, float *smem)
     // writes the split's partial
     float *red = smem + (((st & 1) * 2 + wm) * 32) * 64;    // [2 slots][2 halves][32][64]
     __syncthreads();                            // every wave is done with its operand buffers
-    if (st >= 2) {
+#if defined(FCN_PROBE) && FCN_PROBE == 4
+    BPROBE_STAMP();                             // (4: every wave has left its K loop)
+#endif
+    if (NS == 4 ? st >= 2 : st == 1) {          // (two streams, CGB_G = 4: stream 1 parks, stream 0 adds and writes)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) red[acc_row(reg, lh) * 64 + j * 32 + l31] = acc[0][j][reg];
     }
     __syncthreads();
-    if (st < 2) {
+    if (NS == 4 && st < 2) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1420,6 +1428,9 @@ __device__ __forceinline__ void cg_wgrad_body(const AT &a, int wid, float *smem)
             }
     }
     __syncthreads();
+#if defined(FCN_PROBE) && FCN_PROBE == 4
+    BPROBE_STAMP();                             // (5: the stream sums are in LDS)
+#endif
     if (st == 0) {
         const float *r1 = smem + ((2 + wm) * 32) * 64;      // stream 1's slot
         float *out = a.partial + (int64_t)bx * LCout * LKtot;
@@ -1428,7 +1439,7 @@ __device__ __forceinline__ void cg_wgrad_body(const AT &a, int wid, float *smem)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int rr = acc_row(reg, lh), cc = j * 32 + l31;
-                out[(int64_t)(n0 + rr) * LKtot + kk0 + cc] = acc[0][j][reg] + r1[rr * 64 + cc];
+                out[(int64_t)(n0 + rr) * LKtot + kk0 + cc] = NS == 1 ? acc[0][j][reg] : acc[0][j][reg] + r1[rr * 64 + cc];
             }
     }
     BPROBE_STAMP();                             // 4: partial written (wave 0: behind the last barrier)

@@ -29,7 +29,7 @@ rec = buf[:n]
 tags = rec[:, 0]
 role = (tags >> np.uint64(60)).astype(np.int64)
 print("records", n, "(the table holds 65536: later launches of the backward may be cut off)")
-NAMES = {1: ["issue", "prologue", "kloop", "join", "store", "stats"], 2: ["issue", "prologue", "kloop", "write"]}
+NAMES = {1: ["issue", "prologue", "kloop", "join", "store", "stats"], 2: ["issue", "prologue", "kloop", "write"] if os.environ.get("FCN_PROBE", "3") != "4" else ["issue", "prologue", "kloop", "wait-all", "lds-sum", "write"]}
 tot = {}
 for t in sorted(set(tags.tolist()), key=lambda t: rec[tags == t][:, 1].min()):
     r = rec[tags == np.uint64(t)].astype(np.int64)
