@@ -860,25 +860,33 @@ struct CgBwdStep {
     CgReduce red;
 };
 
-#ifndef CGB_G
-#define CGB_G 4                // K-groups of a data-gradient tile = waves of a backward workgroup, ONE wave each.  4 (256 threads, 38 KB
-                               // of LDS: four workgroups per CU) against the 8 of rounds 3-4 (512 threads, 64 KB: two per CU): the same 16
-                               // waves per CU in twice as many, half as long-lived workgroups -- step 1.216-1.226 -> 1.177-1.181 ms (-3.4 %) on
-                               // MI355X; 2: +10 % (the K loops get too long for the launches' tails)
-#endif
-#define CGB_T (64 * CGB_G)
+// K-groups of a data-gradient tile = waves of a backward workgroup (ONE wave each): a template parameter G of the backward kernels, 4
+// or 8, chosen per model by the host (cn_bwd_groups).  4 (256 threads, 38 KB of LDS: four workgroups per CU) against the 8 of rounds
+// 3-4 (512 threads, 64 KB: two per CU) is the same 16 waves per CU in twice as many, half as long-lived workgroups: car step
+// 1.216-1.226 -> 1.177-1.181 ms (-3.4 %), people -1.5 %; but where a launch does not fill the machine anyway (refine: 640 rows, SUN-RGBD:
+// 2 560) the longer K loops of four groups only stretch the chain -- refine 0.713 -> 0.750 ms with 4.  2: car +10 %.
+#define CGB_KH_ 16
+#define CGB_LDW_ 36
+#define CG_CMAX_ 512
+#define CG_KBWD_ 2048
+template <int G>
+struct CgB {
+    static constexpr int T = 64 * G;                                   // threads
+    static constexpr int LDS = G * (CGB_KH_ * CGB_LDW_ + CGB_KH_ * LDN);     // G waves x (A [KH][LDA or LDW] + B [KH][LDN])
+    static constexpr int SMEM = LDS + 5 * CG_CMAX_ + 3 * (CG_KBWD_ / CGB_KH_);      // + BN-backward coefficients + chunk tables
+};
 #define CGB_KH 16              // reduction chunk of a K-group (one 32x32x16 step)
+
 #ifndef CGB_ROWS_MAXCH
 #define CGB_ROWS_MAXCH 4       // data-gradient tiles with at most this many chunks run one per WAVE (CgDgSeg.wave_tiles)
 #endif
 #define CGB_LDA 34             // A leading dimension: 4 * LDA = 8 (mod 32) spreads a half-wave's ds_write_b32 over all banks
-// G waves x (A [KH][LDA or LDW] + B [KH][LDN]) + BN-backward coefficients + chunk tables
 #define CGB_LDW 36             // leading dimension of the weight-gradient role's dy operand (float4 stores: rows 16-B aligned)
 #define CGB_ASZ (CGB_KH * CGB_LDW)
 #define CGB_WSZ (CGB_ASZ + CGB_KH * LDN)     // one wave's operand buffers (both roles)
-#define CGB_LDS (CGB_G * CGB_WSZ)
 #define CG_KBWD 2048           // largest reduction length of a data-gradient GEMM (block5_deconv: 8 * 256 output columns)
-#define CGB_SMEM (CGB_LDS + 5 * CG_CMAX + 3 * (CG_KBWD / CGB_KH))
+static_assert(CGB_KH == CGB_KH_ && CGB_LDW == CGB_LDW_ && CG_CMAX == CG_CMAX_ && CG_KBWD == CG_KBWD_ &&
+              CgB<4>::LDS == 4 * CGB_WSZ, "CgB mirrors the backward's LDS layout constants");
 
 // ------------------------------------------------------------------------------------------------
 // 16-deep kb-major chunk images of the backward data-gradient role (gemm_tile.h "kb-major", two k-blocks instead of four):
@@ -951,7 +959,7 @@ __device__ __forceinline__ void mma_chunk_kb16(const u32x4 *A, const u32x4 *B, f
 // chunks g, g + 8, ...: a wave stages the same number of operand values per step as a wave of the former two-wave groups
 // did with 32-deep chunks (32 x 16 of dy + 16 x 64 of W), and computes the whole 32 x 64 tile of its chunk.
 // ROWS (CgDgSeg.wave_tiles): bx = the workgroup's first tile, by = the segment's tile count; wave g owns tile bx + g alone.
-template <int MM, bool ROWS, class LT, class CT>           // LT / CT: CgLayer / CgBnBwd, by value or through the kernarg pointer
+template <int MM, bool ROWS, int G, class LT, class CT>    // LT / CT: CgLayer / CgBnBwd, by value or through the kernarg pointer
 __device__ __forceinline__ void cg_dgrad_body(const LT &L, const CT &cb, const float *dzc, const float *yc,
                                               int sgi, int segoff, const float *ysrc, const float *bnsrc, float *outp,
                                               int accumulate, double *bstat_src, int bx, int by, bool pub, float *smem,
@@ -959,16 +967,16 @@ __device__ __forceinline__ void cg_dgrad_body(const LT &L, const CT &cb, const f
 {
     // (bf16 throughput mode: dz16 -- this layer's dz / y are bf16 arenas (not the heads' fp32 dlogits); out16 -- `outp` is a
     // layer's dz arena (not a pooled feature map's fp32 gradient); the producer's y behind `ysrc` always is one)
-    constexpr int G = CGB_G, KH = CGB_KH, TMB = 32, NTHR = G * 64;
+    constexpr int KH = CGB_KH, TMB = 32, NTHR = G * 64;
     constexpr int LDRA = Kb16<TMB>::LDR, LDRB = Kb16<64>::LDR;
     constexpr bool X3 = !mm_x1<MM>;
     constexpr int NA = TMB * (KH / 4) / 64;             // 4-vectors of dy per lane per chunk (2)
     constexpr int NB = (X3 || MM == MM_F32) ? 4 : 2;    // u32x4 of the encoded weight per lane per chunk: (plane, k-block) rows x 64 columns
     constexpr int ASZ = CGB_ASZ, NCH = CG_KBWD / KH;
-    static_assert(NTHR == CGB_T && NA == 2 && KH == 16 && Kb16<TMB>::U4 * 4 <= ASZ && Kb16<64>::U4 * 4 <= CGB_WSZ - ASZ,
+    static_assert(NTHR == CgB<G>::T && NA == 2 && KH == 16 && Kb16<TMB>::U4 * 4 <= ASZ && Kb16<64>::U4 * 4 <= CGB_WSZ - ASZ,
                   "dgrad lane mapping / operand images fit the wave's LDS region");
     float *lds = smem;
-    float *coefS = smem + CGB_LDS;
+    float *coefS = smem + CgB<G>::LDS;
     int *cTap = (int *)(coefS + 5 * CG_CMAX), *cNb = cTap + NCH, *cCh = cNb + NCH;
     BPROBE_DECL;
     BPROBE_STAMP();                             // 0: entry
@@ -1239,14 +1247,14 @@ __device__ __forceinline__ void cg_dgrad_body(const LT &L, const CT &cb, const f
 }
 
 // dWp[n][kk] = sum_r dy[r][n] * A[r][kk]; tile 64 (n) x 64 (kk); the workgroup owns rows [rbeg, rend) of one split.
-// Its waves are CGB_G / 2 row-chunk STREAMS (16-row chunks s, s + NS, ...) x two halves of the n side: a wave stages the
+// Its waves are G / 2 row-chunk STREAMS (16-row chunks s, s + NS, ...) x two halves of the n side: a wave stages the
 // 16 x 32 slice of dy and the 16 x 64 slice of A of its chunk into LDS buffers of its own and computes 32 (n) x 64 (kk) --
 // nothing is shared between waves, so the loop has no barrier (the A slice is staged by both waves of a stream: its
 // transform is one fma + max per value).  The stream accumulators are summed through LDS at the end.
-template <int MM, class AT>                     // AT: CgBwdStep, by value or through the kernarg pointer
+template <int MM, int G, class AT>              // AT: CgBwdStep, by value or through the kernarg pointer
 __device__ __forceinline__ void cg_wgrad_body(const AT &a, int wid, float *smem)
 {
-    constexpr int KH = CGB_KH, NS = CGB_G / 2, LDW = CGB_LDW;
+    constexpr int KH = CGB_KH, NS = G / 2, LDW = CGB_LDW;
     const auto &L = a.lay;
     BPROBE_DECL;
     BPROBE_STAMP();                             // 0: entry
@@ -1287,7 +1295,7 @@ __device__ __forceinline__ void cg_wgrad_body(const AT &a, int wid, float *smem)
     // constants of the tile's 64 + 64 columns in LDS (registers are short: 4 waves per SIMD): BN-backward coefficients of dy
     // [5][64], BN scale / shift of the A operand [2][64]
     const bool hasbn = cbstat != nullptr;
-    float *cfS = smem + CGB_LDS, *abS = cfS + 5 * 64;
+    float *cfS = smem + CgB<G>::LDS, *abS = cfS + 5 * 64;
     const float *cfp = cfS + wm * 32 + 4 * cqa, *abp = abS + 4 * cqb;
     f32x16 acc[1][2];
     acc_zero<1, 2>(acc);
@@ -1410,7 +1418,7 @@ __device__ __forceinline__ void cg_wgrad_body(const AT &a, int wid, float *smem)
 #if defined(FCN_PROBE) && FCN_PROBE == 4
     BPROBE_STAMP();                             // (4: every wave has left its K loop)
 #endif
-    if (NS == 4 ? st >= 2 : st == 1) {          // (two streams, CGB_G = 4: stream 1 parks, stream 0 adds and writes)
+    if (NS == 4 ? st >= 2 : st == 1) {          // (two streams, G = 4: stream 1 parks, stream 0 adds and writes)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1450,9 +1458,10 @@ __device__ __forceinline__ void cg_wgrad_body(const AT &a, int wid, float *smem)
 // CGB_T / gr consecutive packed elements with gr split groups (gr = 1, 2, 4 or 8, chosen on the host from the split
 // count): big layers have few splits and many elements (one thread per element), small layers the opposite (a few
 // independent loads per thread, then a group sum through LDS).
-template <class QT>
+template <int G, class QT>
 __device__ __forceinline__ void cg_reduce_body(const QT &q, int rid, float *smem)
 {
+    constexpr int CGB_T = CgB<G>::T;
     const auto &p = q.pk;
     if (q.gr == 0) {                    // column sum of dlogits (R = p.N rows, row stride q.nsplit): dbias of the heads
         float t = 0.f;
@@ -1492,7 +1501,7 @@ __device__ __forceinline__ void cg_reduce_body(const QT &q, int rid, float *smem
     q.dW[o] = t;
 }
 
-template <int MM>
+template <int MM, int G>
 __device__ __forceinline__ void cg_bwd_step_body(const CgBwdStep &a, const int bid, float *smem, const int koff)
 {
     // The role of this workgroup from ONE batch of scalar loads of the by-value parameter; everything else is read through the kernarg
@@ -1506,10 +1515,10 @@ __device__ __forceinline__ void cg_bwd_step_body(const CgBwdStep &a, const int b
     kstep_p ak = (kstep_p)((kchar_p)__builtin_amdgcn_kernarg_segment_ptr() + koff);
     asm volatile("" : "+s"(ak) : : "memory");
 #ifndef CGB_NO_REDUCE
-    if (bid >= r_blk0) { cg_reduce_body(ak->red, bid - r_blk0, smem); return; }
+    if (bid >= r_blk0) { cg_reduce_body<G>(ak->red, bid - r_blk0, smem); return; }
 #endif
 #ifndef CGB_NO_WGRAD
-    if (bid >= w_blk0) { cg_wgrad_body<MM>(*ak, bid - w_blk0, smem); return; }
+    if (bid >= w_blk0) { cg_wgrad_body<MM, G>(*ak, bid - w_blk0, smem); return; }
 #endif
 #ifdef CGB_NO_DGRAD
     return;
@@ -1523,25 +1532,25 @@ __device__ __forceinline__ void cg_bwd_step_body(const CgBwdStep &a, const int b
     CG_PIN(4, ncb, gtx, gblk0, gwt);
     if (gwt) {                          // short reduction: eight tiles per workgroup, one per wave
         const int ntile = gtx * ncb;
-        const int t = cg_xcd_tile(bid - gblk0, (ntile + CGB_G - 1) / CGB_G);
+        const int t = cg_xcd_tile(bid - gblk0, (ntile + G - 1) / G);
         if (t < 0) return;
-        cg_dgrad_body<MM, true>(ak->lay, ak->cb, ak->dz, ak->lay.y, g->sg, g->segoff, g->ysrc, g->bnsrc, g->out, g->accumulate,
-                                g->bstat_src, t * CGB_G, ntile, bid == 0, smem, ak->dz16, g->out16, ncb);
+        cg_dgrad_body<MM, true, G>(ak->lay, ak->cb, ak->dz, ak->lay.y, g->sg, g->segoff, g->ysrc, g->bnsrc, g->out, g->accumulate,
+                                g->bstat_src, t * G, ntile, bid == 0, smem, ak->dz16, g->out16, ncb);
         return;
     }
     const int t = cg_xcd_tile(bid - gblk0, gtx * ncb);
     if (t < 0) return;
     int tbx, tby;
     cg_divmod(t, ncb, cg_inv(ncb), tbx, tby);                  // (t < 2^23)
-    cg_dgrad_body<MM, false>(ak->lay, ak->cb, ak->dz, ak->lay.y, g->sg, g->segoff, g->ysrc, g->bnsrc, g->out, g->accumulate,
+    cg_dgrad_body<MM, false, G>(ak->lay, ak->cb, ak->dz, ak->lay.y, g->sg, g->segoff, g->ysrc, g->bnsrc, g->out, g->accumulate,
                              g->bstat_src, tbx, tby, bid == 0, smem, ak->dz16, g->out16);
 }
 
-template <int MM>
-__global__ __launch_bounds__(CGB_T, 4) void cg_bwd_step_kernel(CgBwdStep a)
+template <int MM, int G>
+__global__ __launch_bounds__(64 * G, 4) void cg_bwd_step_kernel(CgBwdStep a)
 {
-    __shared__ __attribute__((aligned(16))) float smem[CGB_SMEM];
-    cg_bwd_step_body<MM>(a, blockIdx.x, smem, 0);
+    __shared__ __attribute__((aligned(16))) float smem[CgB<G>::SMEM];
+    cg_bwd_step_body<MM, G>(a, blockIdx.x, smem, 0);
 }
 
 // A chain step and an OFF-CHAIN step (the backward of a deconvolution, which only hangs off the heads) in one launch:
@@ -1551,13 +1560,13 @@ struct CgBwdPair {
     int na;
 };
 
-template <int MM>
-__global__ __launch_bounds__(CGB_T, 4) void cg_bwd_pair_kernel(CgBwdPair p)
+template <int MM, int G>
+__global__ __launch_bounds__(64 * G, 4) void cg_bwd_pair_kernel(CgBwdPair p)
 {
-    __shared__ __attribute__((aligned(16))) float smem[CGB_SMEM];
+    __shared__ __attribute__((aligned(16))) float smem[CgB<G>::SMEM];
     const int bid = blockIdx.x;
-    if (bid < p.na) cg_bwd_step_body<MM>(p.A, bid, smem, (int)offsetof(CgBwdPair, A));
-    else cg_bwd_step_body<MM>(p.B, bid - p.na, smem, (int)offsetof(CgBwdPair, B));
+    if (bid < p.na) cg_bwd_step_body<MM, G>(p.A, bid, smem, (int)offsetof(CgBwdPair, A));
+    else cg_bwd_step_body<MM, G>(p.B, bid - p.na, smem, (int)offsetof(CgBwdPair, B));
 }
 
 // ================================================================================================
@@ -1577,6 +1586,13 @@ struct CnPlan {
 };
 
 static int conv_len(int L, int k, int s, int p) { return (L + 2 * p - k) / s + 1; }
+
+// waves per backward workgroup (template parameter G of cg_bwd_*_kernel; CgB explains): four where the launches fill the machine
+// (car: 8 960 rows at the first level, people: 22 400), eight where they do not (refine: 640, SUN-RGBD: 2 560)
+#ifndef FCN_BWD_G4_ROWS
+#define FCN_BWD_G4_ROWS 4096
+#endif
+static int cn_bwd_groups(const fcn_cn_desc *d) { return (int64_t)d->B * d->L[0] >= FCN_BWD_G4_ROWS ? 4 : 8; }
 
 // rows per wgrad split (multiple of 32): ~768 workgroups, >= 256 rows each
 static int pick_wrows(int R, int out_tiles)
@@ -1954,6 +1970,7 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
     auto blank_reduce = [&](CgReduce &r) {
         r.partial = nullptr; r.nsplit = 0; r.nrow_real = 0; r.dW = nullptr; r.gr = 1; cn_fill_pack(d, P, 0, r.pk);
     };
+    const int BG = cn_bwd_groups(d);           // waves per backward workgroup (4 or 8): one choice for the whole chain
     // data-gradient + weight-gradient roles of layer l (l < 0: none); returns the workgroups in front of the reduce role
     auto make_step = [&](int l, float *pbuf, CgBwdStep &a, CgReduce &own, int &own_blocks) -> int {
         a.ndg = 0; a.w_ns = 0; a.w_ny = 1; a.rows = 2 * KC; a.partial = nullptr; a.dz = nullptr; a.dz16 = 0;
@@ -2007,7 +2024,7 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
 #ifndef FCN_NO_WAVE_TILES
                 g.wave_tiles = (P.KT[l] * (P.N[l] / CGB_KH) <= CGB_ROWS_MAXCH) ? 1 : 0;       // (chunks of the reduction: KT * Cout / 16)
 #endif
-                nblk += cg_pad8(g.wave_tiles ? (g.tx * g.ncb + CGB_G - 1) / CGB_G : g.tx * g.ncb);
+                nblk += cg_pad8(g.wave_tiles ? (g.tx * g.ncb + BG - 1) / BG : g.tx * g.ncb);
                 a.ndg += 1;
             }
             segoff += P.KT[l] * P.C[l][s];
@@ -2023,7 +2040,7 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
         own.partial = a.partial; own.nsplit = a.w_ns; cn_fill_pack(d, P, l, own.pk); own.nrow_real = P.nrow_real[l];
         own.dW = dW[l];
         own.gr = a.w_ns >= 32 ? 8 : (a.w_ns >= 16 ? 4 : (a.w_ns >= 8 ? 2 : 1));
-        own_blocks = (int)(((int64_t)P.N[l] * P.Ktot[l]) / (CGB_T / own.gr));
+        own_blocks = (int)(((int64_t)P.N[l] * P.Ktot[l]) / (64 * BG / own.gr));
         return nblk;
     };
 
@@ -2067,8 +2084,13 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
         }
         pp.na = nA;
         if (nA + nB > 0) {
-            if (nB > 0) { FCN_MM_SWITCH(mmb, hipLaunchKernelGGL(cg_bwd_pair_kernel<MM>, dim3(nA + nB), dim3(CGB_T), 0, st, pp)); }
-            else { FCN_MM_SWITCH(mmb, hipLaunchKernelGGL(cg_bwd_step_kernel<MM>, dim3(nA), dim3(CGB_T), 0, st, pp.A)); }
+            if (BG == 4) {
+                if (nB > 0) { FCN_MM_SWITCH(mmb, hipLaunchKernelGGL((cg_bwd_pair_kernel<MM, 4>), dim3(nA + nB), dim3(256), 0, st, pp)); }
+                else { FCN_MM_SWITCH(mmb, hipLaunchKernelGGL((cg_bwd_step_kernel<MM, 4>), dim3(nA), dim3(256), 0, st, pp.A)); }
+            } else {
+                if (nB > 0) { FCN_MM_SWITCH(mmb, hipLaunchKernelGGL((cg_bwd_pair_kernel<MM, 8>), dim3(nA + nB), dim3(512), 0, st, pp)); }
+                else { FCN_MM_SWITCH(mmb, hipLaunchKernelGGL((cg_bwd_step_kernel<MM, 8>), dim3(nA), dim3(512), 0, st, pp.A)); }
+            }
             FCN_CHECK_LAUNCH();
         }
         pendA = ownA; pendA_blocks = ownA_blocks;
