@@ -1,4 +1,6 @@
-"""Intra-kernel phase times of the FCN forward kernels (tuning build libfcn_hip_probe.so, -DFCN_PROBE; not the product).
+"""Intra-kernel phase times of the FCN forward kernels (tuning build libfcn_hip_probe.so, -DFCN_PROBE=1; not the product; with
+-DFCN_PROBE=2 the issue phase is split further: the columns then read kernel arguments arrived / row divisions done / first loads
+issued / prologue / K loop / groups joined).
     FCN_LIB_NAME=libfcn_hip_probe.so python tools/fcn_probe.py [cfg]
 Per layer (Ktot, Cout, Lout): workgroups, and the mean / max over workgroups of the phase durations in us
 (entry -> loads issued -> prologue done -> K loop done -> groups joined -> stored -> statistics), plus the span first entry ->
