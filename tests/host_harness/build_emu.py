@@ -56,8 +56,11 @@ def build(force=False, extra=()):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT
     src = _stage_sources()
+    # -DFCN_BWD_G4_ROWS=1: the FCN backward's FOUR-wave workgroups (csrc/fcn_net.hip cn_bwd_groups) for every shape -- on the GPU the
+    # small test shapes run the eight-wave kernels and only the full-size fixtures the four-wave ones; here it is the other way round,
+    # so both instantiations see small, ragged shapes somewhere
     cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-g0", "-mf16c", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-w",
-           "-I", os.path.join(HERE, "hip_emu")] + list(extra) + [os.path.join(src, s) for s in SOURCES] + ["-o", OUT]
+           "-DFCN_BWD_G4_ROWS=1", "-I", os.path.join(HERE, "hip_emu")] + list(extra) + [os.path.join(src, s) for s in SOURCES] + ["-o", OUT]
     subprocess.check_call(cmd)
     return OUT
 
