@@ -162,6 +162,7 @@ struct DgradArgs {
     const float *W1;        // LAYER 2: (C1,3)
     float *dzprev;          // LAYER 3: dz2 out (B,cap,C2)
     double *bstat_prev;     // LAYER 3: dbeta2[C2], dgamma2[C2]; LAYER 2: Q[4][C1] -- replica 0 (stride cb.rep_stride)
+    float *prevpair;        // PRE: pair image (B,cap,CPREV) of the previous layer's ACTIVATION (a2 / a1), written by the epilogue
     int L, cap, CRED, CPREV, tps;
 };
 
@@ -179,9 +180,22 @@ struct DgradLds {
     static constexpr int BYTES = U4 * 16 + 5 * MAXC * 4 + TM * 16;
 };
 
+// PAIR IMAGES (PRE = 1): the operands of the weight-gradient GEMMs, encoded by their PRODUCERS.  The weight-gradient GEMMs reduce
+// over ROWS; their MFMA operands are dwords that pack the 16-bit parts of two reduction-adjacent rows (gemm_tile.h: enc2).  Built
+// by the consumer that is 250-350 VALU instructions per 24 MFMAs (BatchNorm backward / BatchNorm + ReLU / conv1 of 32 values per
+// lane and chunk, then the split), repeated by every output tile that shares the rows -- and those GEMMs end the widest scales'
+// backward chains.  But every value they encode passes through the registers of a data-gradient workgroup first: dy as the
+// staged A operand, the previous layer's activation as the ReLU mask of the epilogue.  So the data-gradient kernel writes them
+// ENCODED, once: a pair image has the shape of the fp32 tensor, (rows, C) dwords, row 2p = the packed HI parts of rows (2p, 2p+1)
+// per channel, row 2p + 1 their packed LO parts -- exactly the two k-major LDS rows of the consumer, which becomes a copy-to-LDS
+// GEMM (wgrad_body PRE).  Same enc2 on the same fp32 values: bit-identical gradients.  Rows past a frustum's live rows are
+// never written; the consumer masks whole pairs by their first row.
+// The A-staging of a PRE data-gradient workgroup gives each thread the two rows of a pair (rows 2p, 2p + 1 at the same four
+// channels) instead of rows 32 apart, so the pair is packed from the thread's own registers.
+//
 // The body takes its workgroup index and LDS explicitly: dgrad_kernel below is the plain launch, pn_mid_kernel runs it as one
 // ROLE beside the two weight-gradient GEMMs of the same scale (they all depend on the layer-3 data-gradient launch only).
-template <int MM, int LAYER, int MT, int NT, int WN>
+template <int MM, int LAYER, int MT, int NT, int WN, int PRE = 0>
 __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, unsigned char *smem_)
 {
     constexpr int NTHR = 128 * WN;
@@ -235,13 +249,16 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, un
     // arithmetic of int64
     int arow[NA4];        // element offset of this thread's piece (clamped row) in a (rows, CRED) buffer
     int wbase[NA4];       // LAYER 3: offset of the piece in its row's window of the (B, L, CRED) arg-max / routed-gradient maps
+    // piece i of a thread: 16 bytes at channel quad tid & 7 of row DG_ROW(i).  PRE: pieces (2j, 2j + 1) are the two rows of a pair
+    static_assert(!PRE || (NA4 % 2 == 0), "PRE: a thread stages whole row pairs");
+    const int kq_ = tid & 7;
+#define DG_ROW(i) (PRE ? (2 * ((tid >> 3) + (NTHR / 8) * ((i) >> 1)) + ((i) & 1)) : ((tid + NTHR * (i)) >> 3))
 #pragma unroll
     for (int i = 0; i < NA4; ++i) {
-        const int f = tid + NTHR * i;
-        const int rc = min(f >> 3, nvalid - 1);
-        arow[i] = ((int)grow0 + rc) * CRED + 4 * (f & 7);
+        const int rc = min(DG_ROW(i), nvalid - 1);
+        arow[i] = ((int)grow0 + rc) * CRED + 4 * kq_;
         wbase[i] = 0;
-        if constexpr (LAYER == 3) wbase[i] = (b * a.L + a.ewin[grow0 + rc]) * CRED + 4 * (f & 7);
+        if constexpr (LAYER == 3) wbase[i] = (b * a.L + a.ewin[grow0 + rc]) * CRED + 4 * kq_;
     }
     __syncthreads();
 
@@ -275,17 +292,8 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, un
     for (int c = 0; c < nchunk; ++c) {
         PNP_ADD(1);                               // 1: issue of the global loads (+ loop overhead)
         if ((FCN_XB & 4) && c > 0) goto staged;
-#pragma unroll
-        for (int i = 0; i < NA4; ++i) {
-            const int f = tid + NTHR * i;
-            const int r = f >> 3, kq = f & 7;
-            const bool ok = r < nvalid;
-            const float w = uS[r].w;
-            const int rloc = row0 + r;
-            const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
-            const float zv[4] = {rz[i].x, rz[i].y, rz[i].z, rz[i].w};
-            int mv[4] = {0, 0, 0, 0};
-            if constexpr (LAYER == 3) { mv[0] = rm[i].x; mv[1] = rm[i].y; mv[2] = rm[i].z; mv[3] = rm[i].w; }
+        {
+            const int kq = kq_;
             const int nb = c * KC + 4 * kq;
             float cfv[5][4];
 #pragma unroll
@@ -293,20 +301,46 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, un
                 const v4f c4 = *(const v4f *)(coefS + q * CRED + nb);
                 cfv[q][0] = c4.x; cfv[q][1] = c4.y; cfv[q][2] = c4.z; cfv[q][3] = c4.w;
             }
-            float dv[4];
+            float dvp[PRE ? 4 : 1];       // PRE: the even row of the pair, kept until its odd row is built
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float dz = zv[j];
-                if constexpr (LAYER == 3) dz = (mv[j] == rloc) ? zv[j] : 0.f;
-                const float xh = (yv[j] - cfv[1][j]) * cfv[2][j];
-                const float dy = cfv[0][j] * (dz - w * fmaf(xh, cfv[4][j], cfv[3][j]));
-                dv[j] = ok ? dy : 0.f;
-            }
-            kb_store4<MM_ENC_A, LDRA>(Ab, r, kq, dv[0], dv[1], dv[2], dv[3]);
-            if constexpr (LAYER == 3) {
-                if (ok && byi == 0 && a.dybuf && !(FCN_XB & 128)) {
-                    const v4f d0 = {dv[0], dv[1], dv[2], dv[3]};
-                    sts4e<MM>(a.dybuf, (grow0 + r) * CRED + nb, d0);
+            for (int i = 0; i < NA4; ++i) {
+                const int r = DG_ROW(i);
+                const bool ok = r < nvalid;
+                const float w = uS[r].w;
+                const int rloc = row0 + r;
+                const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
+                const float zv[4] = {rz[i].x, rz[i].y, rz[i].z, rz[i].w};
+                int mv[4] = {0, 0, 0, 0};
+                if constexpr (LAYER == 3) { mv[0] = rm[i].x; mv[1] = rm[i].y; mv[2] = rm[i].z; mv[3] = rm[i].w; }
+                float dv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float dz = zv[j];
+                    if constexpr (LAYER == 3) dz = (mv[j] == rloc) ? zv[j] : 0.f;
+                    const float xh = (yv[j] - cfv[1][j]) * cfv[2][j];
+                    const float dy = cfv[0][j] * (dz - w * fmaf(xh, cfv[4][j], cfv[3][j]));
+                    dv[j] = ok ? dy : 0.f;
+                }
+                kb_store4<MM_ENC_A, LDRA>(Ab, r, kq, dv[0], dv[1], dv[2], dv[3]);
+                if constexpr (PRE) {
+                    // the pair image of dy for the weight-gradient GEMM of this layer, written by the first column block: HI parts of
+                    // rows (r - 1, r) to row r - 1, LO parts to row r (rows past nvalid contribute zeros)
+                    if ((i & 1) == 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) dvp[j] = dv[j];
+                    } else if (byi == 0 && a.dybuf && r - 1 < nvalid && !(FCN_XB & 128)) {
+                        float h[4], l[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) enc2<MM>(dvp[j], dv[j], h[j], l[j]);
+                        const v4f h4 = {h[0], h[1], h[2], h[3]}, l4 = {l[0], l[1], l[2], l[3]};
+                        sts4(a.dybuf + (grow0 + r - 1) * CRED + nb, h4);
+                        sts4(a.dybuf + (grow0 + r) * CRED + nb, l4);
+                    }
+                } else if constexpr (LAYER == 3) {
+                    if (ok && byi == 0 && a.dybuf && !(FCN_XB & 128)) {
+                        const v4f d0 = {dv[0], dv[1], dv[2], dv[3]};
+                        sts4e<MM>(a.dybuf, (grow0 + r) * CRED + nb, d0);
+                    }
                 }
             }
         }
@@ -327,6 +361,7 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, un
         PNP_ADD(3);                               // (3: both barriers)
     }
 #undef DGRAD_LOAD
+#undef DG_ROW
 
     PNP_ADD(3);
     if (FCN_XB & 16) { if (acc[0][0][0] == 123.456f) a.bstat_prev[0] = 0.0; return; }
@@ -368,22 +403,63 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, un
                         st[nt][1] = fmaf(dz, (y - pm) * pr, st[nt][1]);
                     }
                 }
+            if constexpr (PRE) {
+                // the pair image of a2 = relu(bn2(y2)) for conv3's weight-gradient GEMM: accumulator registers (reg, reg + 1), reg
+                // even, are the rows of a pair (acc_row), and the activation is what the mask above evaluated anyway
+                if (a.prevpair) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int reg = 0; reg < 16; reg += 2) {
+                            const int row = wm * 32 * MT + mt * 32 + acc_row(reg, lh);
+                            if (row < nvalid) {
+                                const float a0 = fmaxf(fmaf(ps, yv[mt][reg], pt), 0.f);
+                                const float a1 = row + 1 < nvalid ? fmaxf(fmaf(ps, yv[mt][reg + 1], pt), 0.f) : 0.f;
+                                float h, l;
+                                enc2<MM>(a0, a1, h, l);
+                                a.prevpair[(grow0 + row) * CPREV + col] = h;
+                                a.prevpair[(grow0 + row + 1) * CPREV + col] = l;
+                            }
+                        }
+                }
+            }
         } else {
             const float al[3] = {ps * a.W1[3 * col], ps * a.W1[3 * col + 1], ps * a.W1[3 * col + 2]};
+            float a1v[PRE ? MT : 1][PRE ? 16 : 1];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int row = wm * 32 * MT + mt * 32 + acc_row(reg, lh);
+                    if constexpr (PRE) a1v[mt][reg] = 0.f;
                     if (row < nvalid) {
                         const float4 u = uS[row];
-                        const float dz = (l1_pre(al, pt, u.x, u.y, u.z) > 0.f) ? acc[mt][nt][reg] : 0.f;
+                        const float pre = l1_pre(al, pt, u.x, u.y, u.z);
+                        if constexpr (PRE) a1v[mt][reg] = fmaxf(pre, 0.f);
+                        const float dz = (pre > 0.f) ? acc[mt][nt][reg] : 0.f;
                         st[nt][0] += dz;
                         st[nt][1] = fmaf(dz, u.x, st[nt][1]);
                         st[nt][2] = fmaf(dz, u.y, st[nt][2]);
                         st[nt][3] = fmaf(dz, u.z, st[nt][3]);
                     }
                 }
+            if constexpr (PRE) {
+                // the pair image of a1 = relu(bn1(conv1(u))) for conv2's weight-gradient GEMM (same l1_pre as everywhere)
+                if (a.prevpair) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int reg = 0; reg < 16; reg += 2) {
+                            const int row = wm * 32 * MT + mt * 32 + acc_row(reg, lh);
+                            if (row < nvalid) {
+                                float h, l;
+                                enc2<MM>(a1v[mt][reg], a1v[mt][reg + 1], h, l);
+                                a.prevpair[(grow0 + row) * CPREV + col] = h;
+                                a.prevpair[(grow0 + row + 1) * CPREV + col] = l;
+                            }
+                        }
+                }
+            }
         }
 #pragma unroll
         for (int q = 0; q < NS; ++q) st[nt][q] += __shfl_xor(st[nt][q], 32, 64);
@@ -414,12 +490,12 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, un
               (unsigned long long)nvalid);
 }
 
-template <int MM, int LAYER, int MT, int NT, int WN>
+template <int MM, int LAYER, int MT, int NT, int WN, int PRE = 0>
 __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT * NT <= 2 ? (LAYER == 2 ? FCN_DG2_OCC : 3) : 2, 4)))
 void dgrad_kernel(DgradArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[DgradLds<MT, NT, WN>::BYTES];
-    dgrad_body<MM, LAYER, MT, NT, WN>(a, (int)blockIdx.x, smem);
+    dgrad_body<MM, LAYER, MT, NT, WN, PRE>(a, (int)blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -438,6 +514,7 @@ struct WgradArgs {
     const float *bn_prev;   // scale, shift of the previous layer's BN
     const float *W1;        // LAYER 2
     float *partial;         // (nsplit, COUT, CIN)
+    const float *bimg;      // PRE: pair image (B,cap,CIN) of the B operand (dy holds the pair image of the A operand, (B,cap,COUT))
     int L, cap, COUT, CIN, tps;
 };
 
@@ -462,11 +539,14 @@ struct WgradLds {
     static constexpr int BYTES = KC * (LDA + LDB) * 4 + (2 + (RC ? 2 : 0)) * WG_TMAX * 4;
 };
 
-template <int MM, int LAYER, int MT, int NT, int RC = 0>
+// PRE: both operands arrive as PAIR IMAGES (see dgrad_body) -- the staging is a masked 16-byte copy per piece, no arithmetic; the
+// layer only names the launch (both layers run the same code).
+template <int MM, int LAYER, int MT, int NT, int RC = 0, int PRE = 0>
 __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, const int by_, const int bz_, const int gx_,
                                            unsigned char *smem_)
 {
-    constexpr bool XF = LAYER == 2 || RC;               // the A operand is transformed by a BatchNorm backward while staging
+    static_assert(!(PRE && RC), "PRE reads dy from its pair image");
+    constexpr bool XF = !PRE && (LAYER == 2 || RC);     // the A operand is transformed by a BatchNorm backward while staging
     constexpr int LDA = 64 * MT + 4, LDB = 64 * NT + 4;
     float *As = (float *)smem_;
     float *Bs = As + KC * LDA;
@@ -515,15 +595,17 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
             for (int q = 0; q < 5; ++q) cf[q][j] = c5[q];
         }
     }
+    if constexpr (!PRE) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int k = k0 + 4 * bcq + j;
-        bs[j] = a.bn_prev[k];
-        bt[j] = a.bn_prev[CIN + k];
-        if constexpr (LAYER == 2) {
-            bal[j][0] = bs[j] * a.W1[3 * k];
-            bal[j][1] = bs[j] * a.W1[3 * k + 1];
-            bal[j][2] = bs[j] * a.W1[3 * k + 2];
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + 4 * bcq + j;
+            bs[j] = a.bn_prev[k];
+            bt[j] = a.bn_prev[CIN + k];
+            if constexpr (LAYER == 2) {
+                bal[j][0] = bs[j] * a.W1[3 * k];
+                bal[j][1] = bs[j] * a.W1[3 * k + 1];
+                bal[j][2] = bs[j] * a.W1[3 * k + 2];
+            }
         }
     }
 
@@ -531,6 +613,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
     f32x16 acc[MT][NT];
     acc_zero<MT, NT>(acc);
     float4 ra[2 * MT], ra2[2 * MT], rb4[2 * NT];
+    v4f pa[PRE ? 2 * MT : 1], pb[PRE ? 2 * NT : 1];      // PRE: the pieces of the two pair images, as loaded
     float rwt[2 * MT];
     v4i rm[RC ? 2 * MT : 1];                   // RC: arg-max rows of the row's window at this thread's four channels
     int rwin[RC ? 2 * MT : 1], rwin_n[RC ? 2 * MT : 1];      // RC: windows of the chunk being loaded / of the next one
@@ -562,7 +645,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
         // unconditional loads from a clamped row; rows past `left` are zeroed when the registers go to LDS.  A chunk without
         // a live row (the tail of a tile: cap need not be a multiple of 128, so its rows may lie past the buffer) reads the
         // tile's first row, which is live.
-        const int lastr = max(left, 1) - 1;
+        // (PRE: a pair's LO row lies one past its HI row -- also when the HI row is the last live one -- and is always there: the
+        // image has B * cap rows, cap even)
+        const int lastr = PRE ? ((max(left, 1) - 1) | 1) : max(left, 1) - 1;
         if (left <= 0) g0 = tG0[q >> 2];
         int bl = 0;
         if constexpr (RC) {
@@ -574,7 +659,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
         for (int i = 0; i < 2 * MT; ++i) {
             const int rr = min(WG_AROW(i), lastr);
             const int o = (g0 + rr) * COUT + n0 + 4 * acq;
-            if constexpr (RC) {
+            if constexpr (PRE) {
+                pa[i] = ldg4(a.dy + o);
+            } else if constexpr (RC) {
                 const int om = (bl + rwin[i]) * COUT + n0 + 4 * acq;
                 ra2[i] = ld4f<MM>(a.ycur, o);
                 rm[i] = ldg4i(a.amax + om);
@@ -595,7 +682,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {
             const int rr = min(WG_BROW(i), lastr);
-            if constexpr (LAYER == 3) rb4[i] = ld4f<MM>(a.yprev, (g0 + rr) * CIN + k0 + 4 * bcq);
+            if constexpr (PRE) {
+                pb[i] = ldg4(a.bimg + (g0 + rr) * CIN + k0 + 4 * bcq);
+            } else if constexpr (LAYER == 3) rb4[i] = ld4f<MM>(a.yprev, (g0 + rr) * CIN + k0 + 4 * bcq);
             else rb4[i] = a.ent[g0 + rr];
         }
     };
@@ -608,6 +697,20 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
         int g0_, left;
         chunk_rows(q, g0_, left);
         PNP_ADD(5);                               // 5: chunk lookup at the loop top (tile list -> live rows)
+        if constexpr (PRE) {
+            // copies; in the last chunks of a row tile a pair counts when its first row is live (`left` is workgroup-uniform)
+            if (left >= KC) {
+#pragma unroll
+                for (int i = 0; i < 2 * MT; ++i) sts4(As + WG_AROW(i) * LDA + 4 * acq, pa[i]);
+#pragma unroll
+                for (int i = 0; i < 2 * NT; ++i) sts4(Bs + WG_BROW(i) * LDB + 4 * bcq, pb[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2 * MT; ++i) sts4(As + WG_AROW(i) * LDA + 4 * acq, (WG_AROW(i) & ~1) < left ? pa[i] : zero4());
+#pragma unroll
+                for (int i = 0; i < 2 * NT; ++i) sts4(Bs + WG_BROW(i) * LDB + 4 * bcq, (WG_BROW(i) & ~1) < left ? pb[i] : zero4());
+            }
+        } else {
         v4f sa[2 * MT], sb[2 * NT];
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
@@ -666,6 +769,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
             sts4(Bs + WG_BROW(i) * LDB + 4 * bcq, hi);
             sts4(Bs + WG_BROW(i + 1) * LDB + 4 * bcq, lo);
         }
+        }
         PNP_ADD(2);                               // 2: wait for the loads + operand transform + LDS stores
         __syncthreads();
         PNP_ADD(3);                               // 3: barriers
@@ -694,11 +798,11 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
               (unsigned long long)64);
 }
 
-template <int MM, int LAYER, int MT, int NT, int RC = 0>
-__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu((LAYER == 3 && !RC) ? 3 : 2, 4))) void wgrad_kernel(WgradArgs a)
+template <int MM, int LAYER, int MT, int NT, int RC = 0, int PRE = 0>
+__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(((LAYER == 3 && !RC) || PRE) ? 3 : 2, 4))) void wgrad_kernel(WgradArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[WgradLds<MT, NT, RC>::BYTES];
-    wgrad_body<MM, LAYER, MT, NT, RC>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
+    wgrad_body<MM, LAYER, MT, NT, RC, PRE>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -804,7 +908,7 @@ __global__ void l1_finalize_kernel(const double *__restrict__ Qr, int rep_stride
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int LAYER>
+template <int LAYER, int PRE = 0>
 static int launch_dgrad(const DgradArgs &a, int B, int precision, hipStream_t st)
 {
     if (a.CRED % 64 || a.CPREV % 64 || a.CRED > MAXC) return FCN_E_BADARG;
@@ -821,22 +925,22 @@ static int launch_dgrad(const DgradArgs &a, int B, int precision, hipStream_t st
 #endif
     if (a.CPREV % 128 == 0) {          // 64 x 128 tiles, two workgroups per listed 128-row tile
         FCN_MM_SWITCH(FCN_MM_OF(precision, false),
-                      hipLaunchKernelGGL((dgrad_kernel<MM, LAYER, 1, 2, 2>), dim3((2 * nt * (a.CPREV / 128) + 7) / 8 * 8), dim3(256), 0, st, a));
+                      hipLaunchKernelGGL((dgrad_kernel<MM, LAYER, 1, 2, 2, PRE>), dim3((2 * nt * (a.CPREV / 128) + 7) / 8 * 8), dim3(256), 0, st, a));
     } else {                            // 64 x 64 tiles (the 64-channel layers of scales 1 and 2: few column tiles)
         FCN_MM_SWITCH(FCN_MM_OF(precision, false),
-                      hipLaunchKernelGGL((dgrad_kernel<MM, LAYER, 1, 1, 2>), dim3((2 * nt * (a.CPREV / 64) + 7) / 8 * 8), dim3(256), 0, st, a));
+                      hipLaunchKernelGGL((dgrad_kernel<MM, LAYER, 1, 1, 2, PRE>), dim3((2 * nt * (a.CPREV / 64) + 7) / 8 * 8), dim3(256), 0, st, a));
     }
     FCN_CHECK_LAUNCH();
     return 0;
 }
 
-template <int MM, int LAYER, int RC = 0>
+template <int MM, int LAYER, int RC = 0, int PRE = 0>
 static void launch_wgrad_mm(const WgradArgs &a, dim3 grid, bool m2, bool n2, hipStream_t st)
 {
-    if (m2 && n2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 2, 2, RC>), grid, dim3(GT), 0, st, a);
-    else if (m2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 2, 1, RC>), grid, dim3(GT), 0, st, a);
-    else if (n2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 1, 2, RC>), grid, dim3(GT), 0, st, a);
-    else hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 1, 1, RC>), grid, dim3(GT), 0, st, a);
+    if (m2 && n2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 2, 2, RC, PRE>), grid, dim3(GT), 0, st, a);
+    else if (m2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 2, 1, RC, PRE>), grid, dim3(GT), 0, st, a);
+    else if (n2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 1, 2, RC, PRE>), grid, dim3(GT), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 1, 1, RC, PRE>), grid, dim3(GT), 0, st, a);
 }
 
 struct WgradPlan {
@@ -890,7 +994,10 @@ static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, int precision, hipS
     WgradPlan P;
     FCN_TRY(plan_wgrad<LAYER>(a, B, nsplit_cap, P));
     dim3 grid(P.nsplit, P.oy, P.oz);
-    if (LAYER == 3 && !a.dy) {             // dy3 rebuilt by the kernel (RC)
+    if (a.bimg) {                          // both operands pre-encoded by the data-gradient kernels (PRE; one instance serves both layers)
+        if (!a.dy) return FCN_E_BADARG;
+        FCN_MM_SWITCH(FCN_MM_OF(precision, false), (launch_wgrad_mm<MM, 3, 0, 1>(a, grid, P.m2, P.n2, st)));
+    } else if (LAYER == 3 && !a.dy) {      // dy3 rebuilt by the kernel (RC)
         if (!a.ycur || !a.ewin || !a.amax || !a.gmax || !a.cb.bstat) return FCN_E_BADARG;
         FCN_MM_SWITCH(FCN_MM_OF(precision, false), (launch_wgrad_mm<MM, LAYER, LAYER == 3 ? 1 : 0>(a, grid, P.m2, P.n2, st)));
     } else {
@@ -969,6 +1076,64 @@ extern "C" int fcn_pn_backward3(const fcn_pn_desc *d, const fcn_pn_params *p, co
     return pn_backward_impl(d, p, dfeat, ws, dW, dgamma, dbeta, stream, stream2, stream3, events);
 }
 
+// The chain behind poolbwd with PRE-ENCODED weight-gradient operands (fcn_pn_ws.a2p / dy2p / a1p): dgrad<3> writes the pair images
+// of dy3 (first column block, while staging) and of a2 (epilogue); conv3's weight gradient is then a copy-to-LDS GEMM -- on `sw`
+// (two streams) beside dgrad<2>, which writes the images of dy2 and a1 for conv2's weight gradient BEHIND it on the main stream
+// (conv2's weight gradient used to follow conv3's on the side stream, rebuilding dy2 from dz2 / y2 and a1 from the entries: the
+// longest chain of the widest scale).  events: fork = events[0], join = events[2].
+static int pn_backward_pre(const fcn_pn_desc *d, const fcn_pn_params *p, const fcn_pn_ws *ws, DgradArgs g, float *dW[3],
+                           float *dgamma[3], float *dbeta[3], hipStream_t st, hipStream_t sw, void *const *events)
+{
+    const int B = d->B, L = d->L, K = d->K, C1 = d->C1, C2 = d->C2, C3 = d->C3;
+    const int cap = L * K;
+    if (cap % 2) return FCN_E_BADARG;                 // (row pairs never straddle two frustums)
+    const double M = (double)B * (double)L * (double)K;
+    const int tps = (cap + 127) / 128;
+    const float *bn1 = ws->bn + fcn_bn_off(0, C1, C2);
+    const float *bn2 = ws->bn + fcn_bn_off(1, C1, C2);
+    const int brs = 2 * C3 + 2 * C2 + 4 * C1;
+    double *bs3 = ws->bstat, *bs2 = bs3 + 2 * C3, *bsQ = bs2 + 2 * C2;
+    hipError_t e = hipSuccess;
+
+    g.prevpair = ws->a2p;
+    FCN_TRY((launch_dgrad<3, 1>(g, B, d->precision, st)));
+    if (sw) {
+        e = hipEventRecord((hipEvent_t)events[0], st);
+        if (e != hipSuccess) return (int)e;
+        e = hipStreamWaitEvent(sw, (hipEvent_t)events[0], 0);
+        if (e != hipSuccess) return (int)e;
+    }
+    WgradArgs w;
+    w.ent = (const float4 *)ws->ent; w.woff = ws->woff; w.tiles = ws->tiles; w.L = L; w.cap = cap; w.tps = tps;
+    w.dz = nullptr; w.ycur = nullptr; w.yprev = nullptr; w.bn_prev = nullptr; w.W1 = nullptr;
+    w.cb.bstat = nullptr; w.cb.rep_stride = brs; w.cb.gamma = nullptr; w.cb.bn = nullptr; w.cb.invM = 1.0 / M; w.cb.dgamma = nullptr; w.cb.dbeta = nullptr;
+    w.ewin = nullptr; w.amax = nullptr; w.gmax = nullptr;
+    w.partial = ws->partial; w.dy = ws->dy3; w.bimg = ws->a2p; w.COUT = C3; w.CIN = C2;
+    FCN_TRY(launch_wgrad<3>(w, B, ws->nsplit, d->precision, sw ? sw : st, dW[2]));
+    if (sw) {
+        e = hipEventRecord((hipEvent_t)events[2], sw);
+        if (e != hipSuccess) return (int)e;
+    }
+    DgradArgs g2 = g;
+    g2.ycur = ws->y2; g2.amax = nullptr; g2.gmax = nullptr; g2.dzcur = ws->dz2;
+    g2.Wenc = (const u32x4 *)(ws->wenc + (int64_t)C2 * C1 + (int64_t)C3 * C2);               // G2 (pn_wenc_off(2))
+    g2.cb.bstat = bs2; g2.cb.gamma = p->gamma[1]; g2.cb.bn = bn2; g2.cb.dgamma = dgamma[1]; g2.cb.dbeta = dbeta[1];
+    g2.dybuf = ws->dy2p; g2.yprev = nullptr; g2.bn_prev = bn1; g2.W1 = p->W[0]; g2.dzprev = nullptr; g2.bstat_prev = bsQ;
+    g2.CRED = C2; g2.CPREV = C1; g2.prevpair = ws->a1p;
+    FCN_TRY((launch_dgrad<2, 1>(g2, B, d->precision, st)));
+    hipLaunchKernelGGL(l1_finalize_kernel, dim3((C1 + 63) / 64), dim3(64), 0, st, bsQ, brs, ws->stat + FCN_STAT_MOM,
+                       p->W[0], p->gamma[0], bn1, C1, M, dW[0], dgamma[0], dbeta[0]);
+    FCN_CHECK_LAUNCH();
+    w.partial = ws->partial + (int64_t)ws->nsplit * C3 * C2;      // its own partials: the two weight gradients may run at once
+    w.dy = ws->dy2p; w.bimg = ws->a1p; w.COUT = C2; w.CIN = C1;
+    FCN_TRY(launch_wgrad<2>(w, B, ws->nsplit, d->precision, st, dW[1]));
+    if (sw) {
+        e = hipStreamWaitEvent(st, (hipEvent_t)events[2], 0);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
 static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dfeat, const fcn_pn_ws *ws,
                             float *dW[3], float *dgamma[3], float *dbeta[3], void *stream, void *stream2, void *stream3,
                             void *const *events)
@@ -1008,10 +1173,18 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
     g.Wenc = (const u32x4 *)(ws->wenc + 2 * (int64_t)C2 * C1 + (int64_t)C3 * C2);            // G3 (pn_wenc_off(3))
     g.cb.bstat = bs3; g.cb.rep_stride = brs; g.cb.gamma = p->gamma[2]; g.cb.bn = bn3; g.cb.invM = 1.0 / M; g.cb.dgamma = dgamma[2]; g.cb.dbeta = dbeta[2];
     g.dybuf = ws->dy3; g.yprev = ws->y2; g.bn_prev = bn2; g.W1 = nullptr; g.dzprev = ws->dz2; g.bstat_prev = bs2;
-    g.CRED = C3; g.CPREV = C2;
+    g.CRED = C3; g.CPREV = C2; g.prevpair = nullptr;
 #if FCN_XB & 512       // (timing build: the cost of a2 . G instead of dy3 . W3 -- reduction over C2, the A operand read from y2)
     g.ycur = ws->y2; g.CRED = C2;
 #endif
+    // PRE: the weight-gradient operands are written as pair images by the data-gradient kernels (see dgrad_body)
+    const bool pre = ws->a2p && ws->dy2p && ws->a1p;
+    if (pre) {
+        if (!ws->dy3 || ws->partial_both != 0) return FCN_E_BADARG;
+        return pn_backward_pre(d, p, ws, g, dW, dgamma, dbeta, st, two ? sw : nullptr, two ? events : nullptr);
+    }
+    if (ws->a2p || ws->dy2p || ws->a1p) return FCN_E_BADARG;
+    if (ws->partial_both != 0 && ws->partial_both != 1) return FCN_E_BADARG;
     FCN_TRY(launch_dgrad<3>(g, B, d->precision, st));
 
     WgradArgs w;
@@ -1019,7 +1192,7 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
     w.partial = ws->partial;
     w.dy = ws->dy3; w.dz = nullptr; w.ycur = nullptr; w.yprev = ws->y2; w.bn_prev = bn2;
     w.cb.bstat = nullptr; w.cb.rep_stride = brs; w.cb.gamma = nullptr; w.cb.bn = nullptr; w.cb.invM = 1.0 / M; w.cb.dgamma = nullptr; w.cb.dbeta = nullptr;
-    w.ewin = nullptr; w.amax = nullptr; w.gmax = nullptr;
+    w.ewin = nullptr; w.amax = nullptr; w.gmax = nullptr; w.bimg = nullptr;
     if (!ws->dy3) {        // no dy3 buffer: conv3's weight-gradient GEMM rebuilds dy3 from what the data-gradient GEMM reads
         w.ycur = ws->y3; w.cb.bstat = bs3; w.cb.gamma = p->gamma[2]; w.cb.bn = bn3;
         w.ewin = ws->ewin; w.amax = ws->amax; w.gmax = ws->gmax;
@@ -1036,7 +1209,7 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
         g2.Wenc = (const u32x4 *)(ws->wenc + (int64_t)C2 * C1 + (int64_t)C3 * C2);               // G2 (pn_wenc_off(2))
         g2.cb.bstat = bs2; g2.cb.gamma = p->gamma[1]; g2.cb.bn = bn2; g2.cb.dgamma = dgamma[1]; g2.cb.dbeta = dbeta[1];
         g2.dybuf = nullptr; g2.yprev = nullptr; g2.bn_prev = bn1; g2.W1 = p->W[0]; g2.dzprev = nullptr; g2.bstat_prev = bsQ;
-        g2.CRED = C2; g2.CPREV = C1;
+        g2.CRED = C2; g2.CPREV = C1; g2.prevpair = nullptr;
         WgradArgs w2 = w;
         w2.dy = nullptr; w2.dz = ws->dz2; w2.ycur = ws->y2; w2.yprev = nullptr; w2.bn_prev = bn1;
         w2.cb.bstat = bs2; w2.cb.gamma = p->gamma[1]; w2.cb.bn = bn2;
