@@ -515,6 +515,7 @@ struct WgradArgs {
     const float *W1;        // LAYER 2
     float *partial;         // (nsplit, COUT, CIN)
     const float *bimg;      // PRE: pair image (B,cap,CIN) of the B operand (dy holds the pair image of the A operand, (B,cap,COUT))
+    int pre_a;              // dy is a PAIR IMAGE (B,cap,COUT) although bimg is null: only the dy operand is pre-encoded
     int L, cap, COUT, CIN, tps;
 };
 
@@ -533,31 +534,43 @@ __device__ __forceinline__ float4 ld4f(const float *base, int64_t e)
 // row's multiplicity, the max-pool's arg-max / routed-gradient maps at the row's window and the BN3-backward coefficients -- so
 // that nothing has to write (B, cap, C3) floats for this kernel to read back: the same fp32 expression, bit-identical dW3.
 // The window ids of a chunk's rows are fetched one chunk ahead (the map addresses depend on them).
-template <int MT, int NT, int RC>
+// G > 1: K-GROUPS inside the workgroup.  A weight-gradient launch has a few hundred output tiles x splits for 256 CUs -- one
+// four-wave workgroup per CU, ONE wave per SIMD, and nothing to cover the stage -> barrier -> MFMA -> barrier sequence of a chunk
+// (2 600 cycles per chunk against 768 of MFMA work); more splits would fill the SIMDs but every split writes and re-reads a whole
+// (COUT, CIN) partial.  Instead a workgroup holds G groups of four waves: group g reduces the chunks g, g + G, ... of the split
+// through its OWN operand buffers and the G accumulator sets meet in LDS (fixed order) before ONE partial leaves -- the waves of
+// G splits without their partials.
+template <int MT, int NT, int RC, int G = 1>
 struct WgradLds {
     static constexpr int LDA = 64 * MT + 4, LDB = 64 * NT + 4;
-    static constexpr int BYTES = KC * (LDA + LDB) * 4 + (2 + (RC ? 2 : 0)) * WG_TMAX * 4;
+    static constexpr int GROUP = KC * (LDA + LDB) * 4;             // operand buffers of one K-group
+    static constexpr int BYTES = G * GROUP + (2 + (RC ? 2 : 0)) * WG_TMAX * 4;
+    static_assert(G == 1 || (G / 2) * GT * MT * NT * 16 * 4 <= G * GROUP, "the accumulator exchange fits the operand buffers");
 };
 
 // PRE: both operands arrive as PAIR IMAGES (see dgrad_body) -- the staging is a masked 16-byte copy per piece, no arithmetic; the
 // layer only names the launch (both layers run the same code).
-template <int MM, int LAYER, int MT, int NT, int RC = 0, int PRE = 0>
+template <int MM, int LAYER, int MT, int NT, int RC = 0, int PRE = 0, int G = 1>
 __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, const int by_, const int bz_, const int gx_,
                                            unsigned char *smem_)
 {
     static_assert(!(PRE && RC), "PRE reads dy from its pair image");
-    constexpr bool XF = !PRE && (LAYER == 2 || RC);     // the A operand is transformed by a BatchNorm backward while staging
+    static_assert(G == 1 || !RC, "K-groups: not with the rebuilt dy3 (its window prefetch runs one chunk ahead)");
+    constexpr bool PREA = (PRE & 1) != 0, PREB = (PRE & 2) != 0;      // which operands arrive as pair images (PREB only with PREA)
+    static_assert(PREA || !PREB, "the B image comes with the A image");
+    constexpr bool XF = !PREA && (LAYER == 2 || RC);    // the A operand is transformed by a BatchNorm backward while staging
     constexpr int LDA = 64 * MT + 4, LDB = 64 * NT + 4;
-    float *As = (float *)smem_;
+    const int grp = G == 1 ? 0 : (int)threadIdx.x / GT;             // K-group of this thread
+    float *As = (float *)(smem_ + grp * WgradLds<MT, NT, RC, G>::GROUP);
     float *Bs = As + KC * LDA;
     // (first row, live rows) of the split's row tiles, looked up ONCE: per chunk, the walk tile list -> frustum -> live-row
     // count was two dependent memory round trips in front of every chunk's loads AND again in front of its staging, and the
     // "load or zero" branches behind it made the compiler wait for every load at once -- tools/pn_probe.py: 45-60 % of the
     // kernel's cycles between them, 13-19 % in the MFMA phase
-    int *tG0 = (int *)(Bs + KC * LDB), *tLeft = tG0 + WG_TMAX;
+    int *tG0 = (int *)(smem_ + G * WgradLds<MT, NT, RC, G>::GROUP), *tLeft = tG0 + WG_TMAX;
     int *tBL = tLeft + WG_TMAX, *tR0 = tBL + (RC ? WG_TMAX : 0);      // RC: b * L and the tile's first row within its frustum
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = G == 1 ? (int)threadIdx.x : (int)threadIdx.x % GT, lane = tid & 63, wave = tid >> 6;      // (within the K-group)
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int ntile = a.tiles[0];
@@ -568,7 +581,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
     const int nq = (t_end - t_beg) * 4;                 // 32-row chunks to reduce
     const int n0 = by_ * 64 * MT, k0 = bz_ * 64 * NT;
     const int COUT = a.COUT, CIN = a.CIN;
-    for (int i = tid; i < t_end - t_beg; i += GT) {     // (launch_wgrad keeps a split within WG_TMAX tiles)
+    for (int i = threadIdx.x; i < t_end - t_beg; i += GT * G) {     // (launch_wgrad keeps a split within WG_TMAX tiles)
         const int code = a.tiles[4 + t_beg + i];
         const int b = code / a.tps, t = code % a.tps;
         tG0[i] = b * a.cap + t * 128;
@@ -595,7 +608,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
             for (int q = 0; q < 5; ++q) cf[q][j] = c5[q];
         }
     }
-    if constexpr (!PRE) {
+    if constexpr (!PREB) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = k0 + 4 * bcq + j;
@@ -613,7 +626,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
     f32x16 acc[MT][NT];
     acc_zero<MT, NT>(acc);
     float4 ra[2 * MT], ra2[2 * MT], rb4[2 * NT];
-    v4f pa[PRE ? 2 * MT : 1], pb[PRE ? 2 * NT : 1];      // PRE: the pieces of the two pair images, as loaded
+    v4f pa[PREA ? 2 * MT : 1], pb[PREB ? 2 * NT : 1];    // PRE: the pieces of the pair images, as loaded
     float rwt[2 * MT];
     v4i rm[RC ? 2 * MT : 1];                   // RC: arg-max rows of the row's window at this thread's four channels
     int rwin[RC ? 2 * MT : 1], rwin_n[RC ? 2 * MT : 1];      // RC: windows of the chunk being loaded / of the next one
@@ -647,7 +660,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
         // tile's first row, which is live.
         // (PRE: a pair's LO row lies one past its HI row -- also when the HI row is the last live one -- and is always there: the
         // image has B * cap rows, cap even)
-        const int lastr = PRE ? ((max(left, 1) - 1) | 1) : max(left, 1) - 1;
+        const int lastr = max(left, 1) - 1, lastp = lastr | 1;
         if (left <= 0) g0 = tG0[q >> 2];
         int bl = 0;
         if constexpr (RC) {
@@ -657,9 +670,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
         }
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
-            const int rr = min(WG_AROW(i), lastr);
+            const int rr = min(WG_AROW(i), PREA ? lastp : lastr);
             const int o = (g0 + rr) * COUT + n0 + 4 * acq;
-            if constexpr (PRE) {
+            if constexpr (PREA) {
                 pa[i] = ldg4(a.dy + o);
             } else if constexpr (RC) {
                 const int om = (bl + rwin[i]) * COUT + n0 + 4 * acq;
@@ -681,8 +694,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
         }
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {
-            const int rr = min(WG_BROW(i), lastr);
-            if constexpr (PRE) {
+            const int rr = min(WG_BROW(i), PREB ? lastp : lastr);
+            if constexpr (PREB) {
                 pb[i] = ldg4(a.bimg + (g0 + rr) * CIN + k0 + 4 * bcq);
             } else if constexpr (LAYER == 3) rb4[i] = ld4f<MM>(a.yprev, (g0 + rr) * CIN + k0 + 4 * bcq);
             else rb4[i] = a.ent[g0 + rr];
@@ -690,28 +703,40 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
     };
 
     PNP_ADD(0);                                   // 0: prologue
-    load_win(0);
-    load_chunk(0);
-    for (int q = 0; q < nq; ++q) {
+    // K-group grp takes the chunks grp, grp + G, ...; every group runs the same number of rounds (the barriers are the
+    // workgroup's), idle in the last one when its chunk does not exist
+    if (grp < nq) {
+        load_win(grp);
+        load_chunk(grp);
+    }
+    for (int q = grp; q - grp < nq; q += G) {
+        const bool act = G == 1 || q < nq;
         PNP_ADD(1);                               // 1: chunk lookup + issue of the global loads
-        int g0_, left;
-        chunk_rows(q, g0_, left);
+        int g0_ = 0, left = 0;
+        if (act) chunk_rows(q, g0_, left);
         PNP_ADD(5);                               // 5: chunk lookup at the loop top (tile list -> live rows)
-        if constexpr (PRE) {
-            // copies; in the last chunks of a row tile a pair counts when its first row is live (`left` is workgroup-uniform)
+        if (act) {
+        // PRE operands: copies; in the last chunks of a row tile a pair counts when its first row is live (`left` is workgroup-uniform)
+        if constexpr (PREA) {
             if (left >= KC) {
 #pragma unroll
                 for (int i = 0; i < 2 * MT; ++i) sts4(As + WG_AROW(i) * LDA + 4 * acq, pa[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2 * MT; ++i) sts4(As + WG_AROW(i) * LDA + 4 * acq, (WG_AROW(i) & ~1) < left ? pa[i] : zero4());
+            }
+        }
+        if constexpr (PREB) {
+            if (left >= KC) {
 #pragma unroll
                 for (int i = 0; i < 2 * NT; ++i) sts4(Bs + WG_BROW(i) * LDB + 4 * bcq, pb[i]);
             } else {
 #pragma unroll
-                for (int i = 0; i < 2 * MT; ++i) sts4(As + WG_AROW(i) * LDA + 4 * acq, (WG_AROW(i) & ~1) < left ? pa[i] : zero4());
-#pragma unroll
                 for (int i = 0; i < 2 * NT; ++i) sts4(Bs + WG_BROW(i) * LDB + 4 * bcq, (WG_BROW(i) & ~1) < left ? pb[i] : zero4());
             }
-        } else {
+        }
         v4f sa[2 * MT], sb[2 * NT];
+        if constexpr (!PREA) {
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
             const int rr = WG_AROW(i);
@@ -745,6 +770,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
             sts4(As + WG_AROW(i) * LDA + 4 * acq, hi);
             sts4(As + WG_AROW(i + 1) * LDA + 4 * acq, lo);
         }
+        }
+        if constexpr (!PREB) {
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {
             const int rr = WG_BROW(i);
@@ -770,12 +797,13 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
             sts4(Bs + WG_BROW(i + 1) * LDB + 4 * bcq, lo);
         }
         }
+        }
         PNP_ADD(2);                               // 2: wait for the loads + operand transform + LDS stores
         __syncthreads();
         PNP_ADD(3);                               // 3: barriers
-        if (q + 1 < nq) load_chunk(q + 1);
+        if (q + G < nq) load_chunk(q + G);
         PNP_ADD(1);
-        mma_chunk<MM, MT, NT, LDA, LDB>(As, Bs, wm * 32 * MT, wn * 32 * NT, acc);
+        if (act) mma_chunk<MM, MT, NT, LDA, LDB>(As, Bs, wm * 32 * MT, wn * 32 * NT, acc);
         PNP_ADD(4);                               // 4: LDS operand reads + MFMAs
         __syncthreads();
         PNP_ADD(3);
@@ -783,6 +811,36 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
 #undef WG_AROW
 #undef WG_BROW
 
+    if constexpr (G > 1) {
+        // the K-groups' accumulators meet in LDS, halving the live groups per round in a FIXED order ((0 + 2) + (1 + 3) for four):
+        // [register][thread] slots, so a wave's accesses are 64 consecutive dwords
+        float *red = (float *)smem_;
+        constexpr int NACC = MT * NT * 16;
+#pragma unroll
+        for (int half = G / 2; half >= 1; half /= 2) {
+            if (grp >= half && grp < 2 * half) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg)
+                            red[((grp - half) * NACC + (mt * NT + nt) * 16 + reg) * GT + tid] = acc[mt][nt][reg];
+            }
+            __syncthreads();
+            if (grp < half) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg)
+                            acc[mt][nt][reg] += red[(grp * NACC + (mt * NT + nt) * 16 + reg) * GT + tid];
+            }
+            if (half > 1) __syncthreads();
+        }
+        if (grp != 0) return;
+    }
     float *out = a.partial + (int64_t)bx_ * COUT * CIN;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -803,6 +861,14 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(((LAYER == 3
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[WgradLds<MT, NT, RC>::BYTES];
     wgrad_body<MM, LAYER, MT, NT, RC, PRE>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
+}
+
+// the same with G K-groups per workgroup (RC = 0): 256 * G threads, G * 34 KB of LDS
+template <int MM, int LAYER, int MT, int NT, int PRE, int G>
+__global__ __launch_bounds__(GT * G) void wgrad_kg_kernel(WgradArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WgradLds<MT, NT, 0, G>::BYTES];
+    wgrad_body<MM, LAYER, MT, NT, 0, PRE, G>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -934,9 +1000,29 @@ static int launch_dgrad(const DgradArgs &a, int B, int precision, hipStream_t st
     return 0;
 }
 
+// K-groups per weight-gradient workgroup of the plain launches (1: the four-wave kernels above).  FCN_WG_KG / FCN_WG_KG_PRE: tuning builds
+#ifndef FCN_WG_KG
+#define FCN_WG_KG 1
+#endif
+#ifndef FCN_WG_KG_PRE
+#define FCN_WG_KG_PRE 1
+#endif
+template <int MM, int LAYER, int PRE, int G>
+static void launch_wgrad_kg(const WgradArgs &a, dim3 grid, bool m2, bool n2, hipStream_t st)
+{
+    if (m2 && n2) hipLaunchKernelGGL((wgrad_kg_kernel<MM, LAYER, 2, 2, PRE, G>), grid, dim3(GT * G), 0, st, a);
+    else if (m2) hipLaunchKernelGGL((wgrad_kg_kernel<MM, LAYER, 2, 1, PRE, G>), grid, dim3(GT * G), 0, st, a);
+    else if (n2) hipLaunchKernelGGL((wgrad_kg_kernel<MM, LAYER, 1, 2, PRE, G>), grid, dim3(GT * G), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_kg_kernel<MM, LAYER, 1, 1, PRE, G>), grid, dim3(GT * G), 0, st, a);
+}
+
 template <int MM, int LAYER, int RC = 0, int PRE = 0>
 static void launch_wgrad_mm(const WgradArgs &a, dim3 grid, bool m2, bool n2, hipStream_t st)
 {
+    if constexpr (!RC && (PRE ? FCN_WG_KG_PRE : FCN_WG_KG) > 1) {
+        launch_wgrad_kg<MM, LAYER, PRE, (PRE ? FCN_WG_KG_PRE : FCN_WG_KG)>(a, grid, m2, n2, st);
+        return;
+    }
     if (m2 && n2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 2, 2, RC, PRE>), grid, dim3(GT), 0, st, a);
     else if (m2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 2, 1, RC, PRE>), grid, dim3(GT), 0, st, a);
     else if (n2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 1, 2, RC, PRE>), grid, dim3(GT), 0, st, a);
@@ -994,9 +1080,12 @@ static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, int precision, hipS
     WgradPlan P;
     FCN_TRY(plan_wgrad<LAYER>(a, B, nsplit_cap, P));
     dim3 grid(P.nsplit, P.oy, P.oz);
-    if (a.bimg) {                          // both operands pre-encoded by the data-gradient kernels (PRE; one instance serves both layers)
+    if (a.bimg) {                          // both operands pre-encoded by the data-gradient kernels (one instance serves both layers)
         if (!a.dy) return FCN_E_BADARG;
-        FCN_MM_SWITCH(FCN_MM_OF(precision, false), (launch_wgrad_mm<MM, 3, 0, 1>(a, grid, P.m2, P.n2, st)));
+        FCN_MM_SWITCH(FCN_MM_OF(precision, false), (launch_wgrad_mm<MM, 3, 0, 3>(a, grid, P.m2, P.n2, st)));
+    } else if (a.pre_a) {                  // dy as a pair image, the activation operand built while staging
+        if (!a.dy) return FCN_E_BADARG;
+        FCN_MM_SWITCH(FCN_MM_OF(precision, false), (launch_wgrad_mm<MM, LAYER, 0, 1>(a, grid, P.m2, P.n2, st)));
     } else if (LAYER == 3 && !a.dy) {      // dy3 rebuilt by the kernel (RC)
         if (!a.ycur || !a.ewin || !a.amax || !a.gmax || !a.cb.bstat) return FCN_E_BADARG;
         FCN_MM_SWITCH(FCN_MM_OF(precision, false), (launch_wgrad_mm<MM, LAYER, LAYER == 3 ? 1 : 0>(a, grid, P.m2, P.n2, st)));
@@ -1108,12 +1197,12 @@ static int pn_backward_pre(const fcn_pn_desc *d, const fcn_pn_params *p, const f
     w.dz = nullptr; w.ycur = nullptr; w.yprev = nullptr; w.bn_prev = nullptr; w.W1 = nullptr;
     w.cb.bstat = nullptr; w.cb.rep_stride = brs; w.cb.gamma = nullptr; w.cb.bn = nullptr; w.cb.invM = 1.0 / M; w.cb.dgamma = nullptr; w.cb.dbeta = nullptr;
     w.ewin = nullptr; w.amax = nullptr; w.gmax = nullptr;
-    w.partial = ws->partial; w.dy = ws->dy3; w.bimg = ws->a2p; w.COUT = C3; w.CIN = C2;
-    FCN_TRY(launch_wgrad<3>(w, B, ws->nsplit, d->precision, sw ? sw : st, dW[2]));
-    if (sw) {
-        e = hipEventRecord((hipEvent_t)events[2], sw);
-        if (e != hipSuccess) return (int)e;
-    }
+    w.partial = ws->partial; w.dy = ws->dy3; w.bimg = ws->a2p; w.pre_a = 1; w.COUT = C3; w.CIN = C2;
+    if (!ws->a2p) { w.yprev = ws->y2; w.bn_prev = bn2; }          // relu(bn2(y2)) built while staging, as without the images
+    // (the second wait for events[0], between the GEMM and its reduce, is a redundant edge out of dgrad<3> that uses up child index 1:
+    // ROCm's graph executor then gives dgrad<2> -- child 2 -- the internal stream of the THIRD captured scale, a narrow one, as
+    // the flow without the images does; as child 1 it lands on the second scale's stream and that scale's whole chain waits)
+    FCN_TRY(launch_wgrad<3>(w, B, ws->nsplit, d->precision, sw ? sw : st, dW[2], sw ? (hipEvent_t)events[0] : nullptr));
     DgradArgs g2 = g;
     g2.ycur = ws->y2; g2.amax = nullptr; g2.gmax = nullptr; g2.dzcur = ws->dz2;
     g2.Wenc = (const u32x4 *)(ws->wenc + (int64_t)C2 * C1 + (int64_t)C3 * C2);               // G2 (pn_wenc_off(2))
@@ -1124,10 +1213,21 @@ static int pn_backward_pre(const fcn_pn_desc *d, const fcn_pn_params *p, const f
     hipLaunchKernelGGL(l1_finalize_kernel, dim3((C1 + 63) / 64), dim3(64), 0, st, bsQ, brs, ws->stat + FCN_STAT_MOM,
                        p->W[0], p->gamma[0], bn1, C1, M, dW[0], dgamma[0], dbeta[0]);
     FCN_CHECK_LAUNCH();
-    w.partial = ws->partial + (int64_t)ws->nsplit * C3 * C2;      // its own partials: the two weight gradients may run at once
-    w.dy = ws->dy2p; w.bimg = ws->a1p; w.COUT = C2; w.CIN = C1;
-    FCN_TRY(launch_wgrad<2>(w, B, ws->nsplit, d->precision, st, dW[1]));
+    // conv2's weight gradient follows conv3's on the side stream once dgrad<2> has written its operands: the main stream ends with
+    // the layer-1 finalisation, as it does without the pair images (whatever the graph executor queues behind it waits no longer)
     if (sw) {
+        e = hipEventRecord((hipEvent_t)events[1], st);
+        if (e != hipSuccess) return (int)e;
+        e = hipStreamWaitEvent(sw, (hipEvent_t)events[1], 0);
+        if (e != hipSuccess) return (int)e;
+    }
+    w.partial = ws->partial + (int64_t)ws->nsplit * C3 * C2;      // its own partials
+    w.dy = ws->dy2p; w.bimg = ws->a1p; w.COUT = C2; w.CIN = C1;
+    if (!ws->a1p) { w.yprev = nullptr; w.bn_prev = bn1; w.W1 = p->W[0]; }      // relu(bn1(conv1(u))) built while staging
+    FCN_TRY(launch_wgrad<2>(w, B, ws->nsplit, d->precision, sw ? sw : st, dW[1]));
+    if (sw) {
+        e = hipEventRecord((hipEvent_t)events[2], sw);
+        if (e != hipSuccess) return (int)e;
         e = hipStreamWaitEvent(st, (hipEvent_t)events[2], 0);
         if (e != hipSuccess) return (int)e;
     }
@@ -1178,12 +1278,12 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
     g.ycur = ws->y2; g.CRED = C2;
 #endif
     // PRE: the weight-gradient operands are written as pair images by the data-gradient kernels (see dgrad_body)
-    const bool pre = ws->a2p && ws->dy2p && ws->a1p;
+    const bool pre = ws->dy2p != nullptr;
     if (pre) {
-        if (!ws->dy3 || ws->partial_both != 0) return FCN_E_BADARG;
+        if (!ws->dy3 || ws->partial_both != 0 || (ws->a2p != nullptr) != (ws->a1p != nullptr)) return FCN_E_BADARG;
         return pn_backward_pre(d, p, ws, g, dW, dgamma, dbeta, st, two ? sw : nullptr, two ? events : nullptr);
     }
-    if (ws->a2p || ws->dy2p || ws->a1p) return FCN_E_BADARG;
+    if (ws->a2p || ws->a1p) return FCN_E_BADARG;
     if (ws->partial_both != 0 && ws->partial_both != 1) return FCN_E_BADARG;
     FCN_TRY(launch_dgrad<3>(g, B, d->precision, st));
 
@@ -1192,7 +1292,7 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
     w.partial = ws->partial;
     w.dy = ws->dy3; w.dz = nullptr; w.ycur = nullptr; w.yprev = ws->y2; w.bn_prev = bn2;
     w.cb.bstat = nullptr; w.cb.rep_stride = brs; w.cb.gamma = nullptr; w.cb.bn = nullptr; w.cb.invM = 1.0 / M; w.cb.dgamma = nullptr; w.cb.dbeta = nullptr;
-    w.ewin = nullptr; w.amax = nullptr; w.gmax = nullptr; w.bimg = nullptr;
+    w.ewin = nullptr; w.amax = nullptr; w.gmax = nullptr; w.bimg = nullptr; w.pre_a = 0;
     if (!ws->dy3) {        // no dy3 buffer: conv3's weight-gradient GEMM rebuilds dy3 from what the data-gradient GEMM reads
         w.ycur = ws->y3; w.cb.bstat = bs3; w.cb.gamma = p->gamma[2]; w.cb.bn = bn3;
         w.ewin = ws->ewin; w.amax = ws->amax; w.gmax = ws->gmax;

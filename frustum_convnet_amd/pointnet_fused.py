@@ -31,9 +31,9 @@ def _mid_launch(B, L, K, C3):
 
 
 def _pre_encode():
-    """FCN_PN_PRE=0 keeps the weight-gradient GEMMs that build their operands themselves (the A/B reference of
-    tests/test_gpu_pointnet.py::test_preencoded_wgrad_operands_give_bit_identical_gradients)."""
-    return os.environ.get("FCN_PN_PRE", "1") != "0"
+    """Which weight-gradient operands the data-gradient kernels pre-encode (fcn_pn_ws.dy2p / a2p / a1p): FCN_PN_PRE = 0 none (the
+    weight-gradient GEMMs build their operands themselves), 1 the dy operands, 3 the activation operands too."""
+    return int(os.environ.get("FCN_PN_PRE", "1"))
 
 
 class Workspace:
@@ -87,9 +87,10 @@ class Workspace:
         # middle launch (whose weight-gradient roles run BESIDE conv2's data gradient and cannot read what it writes).
         self.a2p = self.dy2p = self.a1p = None
         if need_grad and not mid and self.dy3 is not None and cap % 2 == 0 and _pre_encode():
-            self.a2p = torch.empty((B, cap, C2), dtype=f32, device=dev)
             self.dy2p = torch.empty((B, cap, C2), dtype=f32, device=dev)
-            self.a1p = torch.empty((B, cap, C1), dtype=f32, device=dev)
+            if _pre_encode() & 2:
+                self.a2p = torch.empty((B, cap, C2), dtype=f32, device=dev)
+                self.a1p = torch.empty((B, cap, C1), dtype=f32, device=dev)
         p = lambda t: None if t is None else t.data_ptr()
         self.c = PnWs(p(self.woff), p(self.ent), p(self.ewin), p(self.tiles), p(self.y2), p(self.y3), p(self.amax),
                       p(self.stat), p(self.bn), p(self.gmax), p(self.dy3), p(self.dz2), p(self.bstat),
@@ -124,7 +125,7 @@ class Workspace:
 
     def dy3_values(self, precision_code):
         """dy3 as fp32, whichever form the backward left in the buffer (fp32 rows, or the pair image when a2p is set)."""
-        if self.a2p is not None:
+        if self.dy2p is not None:
             return self.pair_image_values(self.dy3, precision_code)
         return self.stored(self.dy3, precision_code)
 

@@ -228,15 +228,16 @@ def _scale_backward(case, env, two_streams=False):
                                   (4, 512, 2.0, 128, (256, 256, 512), 2.0), (2, 130, 0.5, 64, (128, 128, 256), 0.4)],
                          ids=lambda c: "B%d_N%d_C%d-K%d" % (c[0], c[1], c[4][2], c[3]))
 @pytest.mark.parametrize("two_streams", [False, True], ids=["one_stream", "two_streams"])
-def test_preencoded_wgrad_operands_give_bit_identical_gradients(case, two_streams):
+@pytest.mark.parametrize("mode", ["1", "3"], ids=["dy", "dy+act"])
+def test_preencoded_wgrad_operands_give_bit_identical_gradients(case, two_streams, mode):
     """fcn_pn_ws.a2p / dy2p / a1p: the data-gradient kernels write the operands of the weight-gradient GEMMs as PAIR IMAGES (dy3 and
     dy2 while they stage them, relu(bn2(y2)) and relu(bn1(conv1(u))) from the ReLU masks of their epilogues) and the weight-gradient
     GEMMs copy them to LDS -- against the GEMMs that derive their operands themselves (FCN_PN_PRE=0).  The same split encoding of the
     same fp32 values, the same split / reduce order: every gradient of the scale agrees BIT FOR BIT (ragged last tiles, odd live-row
     counts included)."""
     ref, ws0 = _scale_backward(case, {"FCN_PN_PRE": "0", "FCN_PN_MID": "0"}, two_streams)
-    got, ws1 = _scale_backward(case, {"FCN_PN_PRE": "1", "FCN_PN_MID": "0"}, two_streams)
-    assert ws0.a2p is None and ws1.a2p is not None
+    got, ws1 = _scale_backward(case, {"FCN_PN_PRE": mode, "FCN_PN_MID": "0"}, two_streams)
+    assert ws0.dy2p is None and ws1.dy2p is not None and (ws1.a2p is not None) == (mode == "3")
     for a, b in zip(ref, got):
         assert torch.isfinite(a).all() and float(a.abs().max()) > 0
         assert torch.equal(a, b)
