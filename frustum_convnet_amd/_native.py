@@ -51,7 +51,7 @@ class PnWs(ctypes.Structure):
     _fields_ = [("woff", c_fp), ("ent", c_fp), ("ewin", c_fp), ("tiles", c_fp), ("y2", c_fp), ("y3", c_fp), ("amax", c_fp),
                 ("stat", c_fp), ("bn", c_fp), ("gmax", c_fp), ("dy3", c_fp), ("dz2", c_fp), ("bstat", c_fp),
                 ("coef", c_fp), ("partial", c_fp), ("nsplit", ctypes.c_int32), ("gmom", c_fp), ("wenc", c_fp), ("flags", c_fp), ("pkey", c_fp),
-                ("partial_both", ctypes.c_int32), ("a2p", c_fp), ("dy2p", c_fp), ("a1p", c_fp)]
+                ("partial_both", ctypes.c_int32)]
 
 
 class InpDesc(ctypes.Structure):

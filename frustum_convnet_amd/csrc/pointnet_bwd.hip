@@ -162,7 +162,6 @@ struct DgradArgs {
     const float *W1;        // LAYER 2: (C1,3)
     float *dzprev;          // LAYER 3: dz2 out (B,cap,C2)
     double *bstat_prev;     // LAYER 3: dbeta2[C2], dgamma2[C2]; LAYER 2: Q[4][C1] -- replica 0 (stride cb.rep_stride)
-    float *prevpair;        // PRE: pair image (B,cap,CPREV) of the previous layer's ACTIVATION (a2 / a1), written by the epilogue
     int L, cap, CRED, CPREV, tps;
 };
 
@@ -180,22 +179,9 @@ struct DgradLds {
     static constexpr int BYTES = U4 * 16 + 5 * MAXC * 4 + TM * 16;
 };
 
-// PAIR IMAGES (PRE = 1): the operands of the weight-gradient GEMMs, encoded by their PRODUCERS.  The weight-gradient GEMMs reduce
-// over ROWS; their MFMA operands are dwords that pack the 16-bit parts of two reduction-adjacent rows (gemm_tile.h: enc2).  Built
-// by the consumer that is 250-350 VALU instructions per 24 MFMAs (BatchNorm backward / BatchNorm + ReLU / conv1 of 32 values per
-// lane and chunk, then the split), repeated by every output tile that shares the rows -- and those GEMMs end the widest scales'
-// backward chains.  But every value they encode passes through the registers of a data-gradient workgroup first: dy as the
-// staged A operand, the previous layer's activation as the ReLU mask of the epilogue.  So the data-gradient kernel writes them
-// ENCODED, once: a pair image has the shape of the fp32 tensor, (rows, C) dwords, row 2p = the packed HI parts of rows (2p, 2p+1)
-// per channel, row 2p + 1 their packed LO parts -- exactly the two k-major LDS rows of the consumer, which becomes a copy-to-LDS
-// GEMM (wgrad_body PRE).  Same enc2 on the same fp32 values: bit-identical gradients.  Rows past a frustum's live rows are
-// never written; the consumer masks whole pairs by their first row.
-// The A-staging of a PRE data-gradient workgroup gives each thread the two rows of a pair (rows 2p, 2p + 1 at the same four
-// channels) instead of rows 32 apart, so the pair is packed from the thread's own registers.
-//
 // The body takes its workgroup index and LDS explicitly: dgrad_kernel below is the plain launch, pn_mid_kernel runs it as one
 // ROLE beside the two weight-gradient GEMMs of the same scale (they all depend on the layer-3 data-gradient launch only).
-template <int MM, int LAYER, int MT, int NT, int WN, int PRE = 0>
+template <int MM, int LAYER, int MT, int NT, int WN>
 __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, unsigned char *smem_)
 {
     constexpr int NTHR = 128 * WN;
@@ -249,16 +235,13 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, un
     // arithmetic of int64
     int arow[NA4];        // element offset of this thread's piece (clamped row) in a (rows, CRED) buffer
     int wbase[NA4];       // LAYER 3: offset of the piece in its row's window of the (B, L, CRED) arg-max / routed-gradient maps
-    // piece i of a thread: 16 bytes at channel quad tid & 7 of row DG_ROW(i).  PRE: pieces (2j, 2j + 1) are the two rows of a pair
-    static_assert(!PRE || (NA4 % 2 == 0), "PRE: a thread stages whole row pairs");
-    const int kq_ = tid & 7;
-#define DG_ROW(i) (PRE ? (2 * ((tid >> 3) + (NTHR / 8) * ((i) >> 1)) + ((i) & 1)) : ((tid + NTHR * (i)) >> 3))
 #pragma unroll
     for (int i = 0; i < NA4; ++i) {
-        const int rc = min(DG_ROW(i), nvalid - 1);
-        arow[i] = ((int)grow0 + rc) * CRED + 4 * kq_;
+        const int f = tid + NTHR * i;
+        const int rc = min(f >> 3, nvalid - 1);
+        arow[i] = ((int)grow0 + rc) * CRED + 4 * (f & 7);
         wbase[i] = 0;
-        if constexpr (LAYER == 3) wbase[i] = (b * a.L + a.ewin[grow0 + rc]) * CRED + 4 * kq_;
+        if constexpr (LAYER == 3) wbase[i] = (b * a.L + a.ewin[grow0 + rc]) * CRED + 4 * (f & 7);
     }
     __syncthreads();
 
@@ -292,8 +275,17 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, un
     for (int c = 0; c < nchunk; ++c) {
         PNP_ADD(1);                               // 1: issue of the global loads (+ loop overhead)
         if ((FCN_XB & 4) && c > 0) goto staged;
-        {
-            const int kq = kq_;
+#pragma unroll
+        for (int i = 0; i < NA4; ++i) {
+            const int f = tid + NTHR * i;
+            const int r = f >> 3, kq = f & 7;
+            const bool ok = r < nvalid;
+            const float w = uS[r].w;
+            const int rloc = row0 + r;
+            const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
+            const float zv[4] = {rz[i].x, rz[i].y, rz[i].z, rz[i].w};
+            int mv[4] = {0, 0, 0, 0};
+            if constexpr (LAYER == 3) { mv[0] = rm[i].x; mv[1] = rm[i].y; mv[2] = rm[i].z; mv[3] = rm[i].w; }
             const int nb = c * KC + 4 * kq;
             float cfv[5][4];
 #pragma unroll
@@ -301,46 +293,20 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, un
                 const v4f c4 = *(const v4f *)(coefS + q * CRED + nb);
                 cfv[q][0] = c4.x; cfv[q][1] = c4.y; cfv[q][2] = c4.z; cfv[q][3] = c4.w;
             }
-            float dvp[PRE ? 4 : 1];       // PRE: the even row of the pair, kept until its odd row is built
+            float dv[4];
 #pragma unroll
-            for (int i = 0; i < NA4; ++i) {
-                const int r = DG_ROW(i);
-                const bool ok = r < nvalid;
-                const float w = uS[r].w;
-                const int rloc = row0 + r;
-                const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
-                const float zv[4] = {rz[i].x, rz[i].y, rz[i].z, rz[i].w};
-                int mv[4] = {0, 0, 0, 0};
-                if constexpr (LAYER == 3) { mv[0] = rm[i].x; mv[1] = rm[i].y; mv[2] = rm[i].z; mv[3] = rm[i].w; }
-                float dv[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float dz = zv[j];
-                    if constexpr (LAYER == 3) dz = (mv[j] == rloc) ? zv[j] : 0.f;
-                    const float xh = (yv[j] - cfv[1][j]) * cfv[2][j];
-                    const float dy = cfv[0][j] * (dz - w * fmaf(xh, cfv[4][j], cfv[3][j]));
-                    dv[j] = ok ? dy : 0.f;
-                }
-                kb_store4<MM_ENC_A, LDRA>(Ab, r, kq, dv[0], dv[1], dv[2], dv[3]);
-                if constexpr (PRE) {
-                    // the pair image of dy for the weight-gradient GEMM of this layer, written by the first column block: HI parts of
-                    // rows (r - 1, r) to row r - 1, LO parts to row r (rows past nvalid contribute zeros)
-                    if ((i & 1) == 0) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) dvp[j] = dv[j];
-                    } else if (byi == 0 && a.dybuf && r - 1 < nvalid && !(FCN_XB & 128)) {
-                        float h[4], l[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) enc2<MM>(dvp[j], dv[j], h[j], l[j]);
-                        const v4f h4 = {h[0], h[1], h[2], h[3]}, l4 = {l[0], l[1], l[2], l[3]};
-                        sts4(a.dybuf + (grow0 + r - 1) * CRED + nb, h4);
-                        sts4(a.dybuf + (grow0 + r) * CRED + nb, l4);
-                    }
-                } else if constexpr (LAYER == 3) {
-                    if (ok && byi == 0 && a.dybuf && !(FCN_XB & 128)) {
-                        const v4f d0 = {dv[0], dv[1], dv[2], dv[3]};
-                        sts4e<MM>(a.dybuf, (grow0 + r) * CRED + nb, d0);
-                    }
+            for (int j = 0; j < 4; ++j) {
+                float dz = zv[j];
+                if constexpr (LAYER == 3) dz = (mv[j] == rloc) ? zv[j] : 0.f;
+                const float xh = (yv[j] - cfv[1][j]) * cfv[2][j];
+                const float dy = cfv[0][j] * (dz - w * fmaf(xh, cfv[4][j], cfv[3][j]));
+                dv[j] = ok ? dy : 0.f;
+            }
+            kb_store4<MM_ENC_A, LDRA>(Ab, r, kq, dv[0], dv[1], dv[2], dv[3]);
+            if constexpr (LAYER == 3) {
+                if (ok && byi == 0 && a.dybuf && !(FCN_XB & 128)) {
+                    const v4f d0 = {dv[0], dv[1], dv[2], dv[3]};
+                    sts4e<MM>(a.dybuf, (grow0 + r) * CRED + nb, d0);
                 }
             }
         }
@@ -361,7 +327,6 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, un
         PNP_ADD(3);                               // (3: both barriers)
     }
 #undef DGRAD_LOAD
-#undef DG_ROW
 
     PNP_ADD(3);
     if (FCN_XB & 16) { if (acc[0][0][0] == 123.456f) a.bstat_prev[0] = 0.0; return; }
@@ -403,63 +368,22 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, un
                         st[nt][1] = fmaf(dz, (y - pm) * pr, st[nt][1]);
                     }
                 }
-            if constexpr (PRE) {
-                // the pair image of a2 = relu(bn2(y2)) for conv3's weight-gradient GEMM: accumulator registers (reg, reg + 1), reg
-                // even, are the rows of a pair (acc_row), and the activation is what the mask above evaluated anyway
-                if (a.prevpair) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int reg = 0; reg < 16; reg += 2) {
-                            const int row = wm * 32 * MT + mt * 32 + acc_row(reg, lh);
-                            if (row < nvalid) {
-                                const float a0 = fmaxf(fmaf(ps, yv[mt][reg], pt), 0.f);
-                                const float a1 = row + 1 < nvalid ? fmaxf(fmaf(ps, yv[mt][reg + 1], pt), 0.f) : 0.f;
-                                float h, l;
-                                enc2<MM>(a0, a1, h, l);
-                                a.prevpair[(grow0 + row) * CPREV + col] = h;
-                                a.prevpair[(grow0 + row + 1) * CPREV + col] = l;
-                            }
-                        }
-                }
-            }
         } else {
             const float al[3] = {ps * a.W1[3 * col], ps * a.W1[3 * col + 1], ps * a.W1[3 * col + 2]};
-            float a1v[PRE ? MT : 1][PRE ? 16 : 1];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int row = wm * 32 * MT + mt * 32 + acc_row(reg, lh);
-                    if constexpr (PRE) a1v[mt][reg] = 0.f;
                     if (row < nvalid) {
                         const float4 u = uS[row];
-                        const float pre = l1_pre(al, pt, u.x, u.y, u.z);
-                        if constexpr (PRE) a1v[mt][reg] = fmaxf(pre, 0.f);
-                        const float dz = (pre > 0.f) ? acc[mt][nt][reg] : 0.f;
+                        const float dz = (l1_pre(al, pt, u.x, u.y, u.z) > 0.f) ? acc[mt][nt][reg] : 0.f;
                         st[nt][0] += dz;
                         st[nt][1] = fmaf(dz, u.x, st[nt][1]);
                         st[nt][2] = fmaf(dz, u.y, st[nt][2]);
                         st[nt][3] = fmaf(dz, u.z, st[nt][3]);
                     }
                 }
-            if constexpr (PRE) {
-                // the pair image of a1 = relu(bn1(conv1(u))) for conv2's weight-gradient GEMM (same l1_pre as everywhere)
-                if (a.prevpair) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int reg = 0; reg < 16; reg += 2) {
-                            const int row = wm * 32 * MT + mt * 32 + acc_row(reg, lh);
-                            if (row < nvalid) {
-                                float h, l;
-                                enc2<MM>(a1v[mt][reg], a1v[mt][reg + 1], h, l);
-                                a.prevpair[(grow0 + row) * CPREV + col] = h;
-                                a.prevpair[(grow0 + row + 1) * CPREV + col] = l;
-                            }
-                        }
-                }
-            }
         }
 #pragma unroll
         for (int q = 0; q < NS; ++q) st[nt][q] += __shfl_xor(st[nt][q], 32, 64);
@@ -490,12 +414,12 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, un
               (unsigned long long)nvalid);
 }
 
-template <int MM, int LAYER, int MT, int NT, int WN, int PRE = 0>
+template <int MM, int LAYER, int MT, int NT, int WN>
 __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT * NT <= 2 ? (LAYER == 2 ? FCN_DG2_OCC : 3) : 2, 4)))
 void dgrad_kernel(DgradArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[DgradLds<MT, NT, WN>::BYTES];
-    dgrad_body<MM, LAYER, MT, NT, WN, PRE>(a, (int)blockIdx.x, smem);
+    dgrad_body<MM, LAYER, MT, NT, WN>(a, (int)blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -514,8 +438,6 @@ struct WgradArgs {
     const float *bn_prev;   // scale, shift of the previous layer's BN
     const float *W1;        // LAYER 2
     float *partial;         // (nsplit, COUT, CIN)
-    const float *bimg;      // PRE: pair image (B,cap,CIN) of the B operand (dy holds the pair image of the A operand, (B,cap,COUT))
-    int pre_a;              // dy is a PAIR IMAGE (B,cap,COUT) although bimg is null: only the dy operand is pre-encoded
     int L, cap, COUT, CIN, tps;
 };
 
@@ -534,43 +456,28 @@ __device__ __forceinline__ float4 ld4f(const float *base, int64_t e)
 // row's multiplicity, the max-pool's arg-max / routed-gradient maps at the row's window and the BN3-backward coefficients -- so
 // that nothing has to write (B, cap, C3) floats for this kernel to read back: the same fp32 expression, bit-identical dW3.
 // The window ids of a chunk's rows are fetched one chunk ahead (the map addresses depend on them).
-// G > 1: K-GROUPS inside the workgroup.  A weight-gradient launch has a few hundred output tiles x splits for 256 CUs -- one
-// four-wave workgroup per CU, ONE wave per SIMD, and nothing to cover the stage -> barrier -> MFMA -> barrier sequence of a chunk
-// (2 600 cycles per chunk against 768 of MFMA work); more splits would fill the SIMDs but every split writes and re-reads a whole
-// (COUT, CIN) partial.  Instead a workgroup holds G groups of four waves: group g reduces the chunks g, g + G, ... of the split
-// through its OWN operand buffers and the G accumulator sets meet in LDS (fixed order) before ONE partial leaves -- the waves of
-// G splits without their partials.
-template <int MT, int NT, int RC, int G = 1>
+template <int MT, int NT, int RC>
 struct WgradLds {
     static constexpr int LDA = 64 * MT + 4, LDB = 64 * NT + 4;
-    static constexpr int GROUP = KC * (LDA + LDB) * 4;             // operand buffers of one K-group
-    static constexpr int BYTES = G * GROUP + (2 + (RC ? 2 : 0)) * WG_TMAX * 4;
-    static_assert(G == 1 || (G / 2) * GT * MT * NT * 16 * 4 <= G * GROUP, "the accumulator exchange fits the operand buffers");
+    static constexpr int BYTES = KC * (LDA + LDB) * 4 + (2 + (RC ? 2 : 0)) * WG_TMAX * 4;
 };
 
-// PRE: both operands arrive as PAIR IMAGES (see dgrad_body) -- the staging is a masked 16-byte copy per piece, no arithmetic; the
-// layer only names the launch (both layers run the same code).
-template <int MM, int LAYER, int MT, int NT, int RC = 0, int PRE = 0, int G = 1>
+template <int MM, int LAYER, int MT, int NT, int RC = 0>
 __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, const int by_, const int bz_, const int gx_,
                                            unsigned char *smem_)
 {
-    static_assert(!(PRE && RC), "PRE reads dy from its pair image");
-    static_assert(G == 1 || !RC, "K-groups: not with the rebuilt dy3 (its window prefetch runs one chunk ahead)");
-    constexpr bool PREA = (PRE & 1) != 0, PREB = (PRE & 2) != 0;      // which operands arrive as pair images (PREB only with PREA)
-    static_assert(PREA || !PREB, "the B image comes with the A image");
-    constexpr bool XF = !PREA && (LAYER == 2 || RC);    // the A operand is transformed by a BatchNorm backward while staging
+    constexpr bool XF = LAYER == 2 || RC;               // the A operand is transformed by a BatchNorm backward while staging
     constexpr int LDA = 64 * MT + 4, LDB = 64 * NT + 4;
-    const int grp = G == 1 ? 0 : (int)threadIdx.x / GT;             // K-group of this thread
-    float *As = (float *)(smem_ + grp * WgradLds<MT, NT, RC, G>::GROUP);
+    float *As = (float *)smem_;
     float *Bs = As + KC * LDA;
     // (first row, live rows) of the split's row tiles, looked up ONCE: per chunk, the walk tile list -> frustum -> live-row
     // count was two dependent memory round trips in front of every chunk's loads AND again in front of its staging, and the
     // "load or zero" branches behind it made the compiler wait for every load at once -- tools/pn_probe.py: 45-60 % of the
     // kernel's cycles between them, 13-19 % in the MFMA phase
-    int *tG0 = (int *)(smem_ + G * WgradLds<MT, NT, RC, G>::GROUP), *tLeft = tG0 + WG_TMAX;
+    int *tG0 = (int *)(Bs + KC * LDB), *tLeft = tG0 + WG_TMAX;
     int *tBL = tLeft + WG_TMAX, *tR0 = tBL + (RC ? WG_TMAX : 0);      // RC: b * L and the tile's first row within its frustum
 
-    const int tid = G == 1 ? (int)threadIdx.x : (int)threadIdx.x % GT, lane = tid & 63, wave = tid >> 6;      // (within the K-group)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int ntile = a.tiles[0];
@@ -581,7 +488,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
     const int nq = (t_end - t_beg) * 4;                 // 32-row chunks to reduce
     const int n0 = by_ * 64 * MT, k0 = bz_ * 64 * NT;
     const int COUT = a.COUT, CIN = a.CIN;
-    for (int i = threadIdx.x; i < t_end - t_beg; i += GT * G) {     // (launch_wgrad keeps a split within WG_TMAX tiles)
+    for (int i = tid; i < t_end - t_beg; i += GT) {     // (launch_wgrad keeps a split within WG_TMAX tiles)
         const int code = a.tiles[4 + t_beg + i];
         const int b = code / a.tps, t = code % a.tps;
         tG0[i] = b * a.cap + t * 128;
@@ -608,17 +515,15 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
             for (int q = 0; q < 5; ++q) cf[q][j] = c5[q];
         }
     }
-    if constexpr (!PREB) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = k0 + 4 * bcq + j;
-            bs[j] = a.bn_prev[k];
-            bt[j] = a.bn_prev[CIN + k];
-            if constexpr (LAYER == 2) {
-                bal[j][0] = bs[j] * a.W1[3 * k];
-                bal[j][1] = bs[j] * a.W1[3 * k + 1];
-                bal[j][2] = bs[j] * a.W1[3 * k + 2];
-            }
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + 4 * bcq + j;
+        bs[j] = a.bn_prev[k];
+        bt[j] = a.bn_prev[CIN + k];
+        if constexpr (LAYER == 2) {
+            bal[j][0] = bs[j] * a.W1[3 * k];
+            bal[j][1] = bs[j] * a.W1[3 * k + 1];
+            bal[j][2] = bs[j] * a.W1[3 * k + 2];
         }
     }
 
@@ -626,7 +531,6 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
     f32x16 acc[MT][NT];
     acc_zero<MT, NT>(acc);
     float4 ra[2 * MT], ra2[2 * MT], rb4[2 * NT];
-    v4f pa[PREA ? 2 * MT : 1], pb[PREB ? 2 * NT : 1];    // PRE: the pieces of the pair images, as loaded
     float rwt[2 * MT];
     v4i rm[RC ? 2 * MT : 1];                   // RC: arg-max rows of the row's window at this thread's four channels
     int rwin[RC ? 2 * MT : 1], rwin_n[RC ? 2 * MT : 1];      // RC: windows of the chunk being loaded / of the next one
@@ -658,9 +562,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
         // unconditional loads from a clamped row; rows past `left` are zeroed when the registers go to LDS.  A chunk without
         // a live row (the tail of a tile: cap need not be a multiple of 128, so its rows may lie past the buffer) reads the
         // tile's first row, which is live.
-        // (PRE: a pair's LO row lies one past its HI row -- also when the HI row is the last live one -- and is always there: the
-        // image has B * cap rows, cap even)
-        const int lastr = max(left, 1) - 1, lastp = lastr | 1;
+        const int lastr = max(left, 1) - 1;
         if (left <= 0) g0 = tG0[q >> 2];
         int bl = 0;
         if constexpr (RC) {
@@ -670,11 +572,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
         }
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
-            const int rr = min(WG_AROW(i), PREA ? lastp : lastr);
+            const int rr = min(WG_AROW(i), lastr);
             const int o = (g0 + rr) * COUT + n0 + 4 * acq;
-            if constexpr (PREA) {
-                pa[i] = ldg4(a.dy + o);
-            } else if constexpr (RC) {
+            if constexpr (RC) {
                 const int om = (bl + rwin[i]) * COUT + n0 + 4 * acq;
                 ra2[i] = ld4f<MM>(a.ycur, o);
                 rm[i] = ldg4i(a.amax + om);
@@ -694,49 +594,21 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
         }
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {
-            const int rr = min(WG_BROW(i), PREB ? lastp : lastr);
-            if constexpr (PREB) {
-                pb[i] = ldg4(a.bimg + (g0 + rr) * CIN + k0 + 4 * bcq);
-            } else if constexpr (LAYER == 3) rb4[i] = ld4f<MM>(a.yprev, (g0 + rr) * CIN + k0 + 4 * bcq);
+            const int rr = min(WG_BROW(i), lastr);
+            if constexpr (LAYER == 3) rb4[i] = ld4f<MM>(a.yprev, (g0 + rr) * CIN + k0 + 4 * bcq);
             else rb4[i] = a.ent[g0 + rr];
         }
     };
 
     PNP_ADD(0);                                   // 0: prologue
-    // K-group grp takes the chunks grp, grp + G, ...; every group runs the same number of rounds (the barriers are the
-    // workgroup's), idle in the last one when its chunk does not exist
-    if (grp < nq) {
-        load_win(grp);
-        load_chunk(grp);
-    }
-    for (int q = grp; q - grp < nq; q += G) {
-        const bool act = G == 1 || q < nq;
+    load_win(0);
+    load_chunk(0);
+    for (int q = 0; q < nq; ++q) {
         PNP_ADD(1);                               // 1: chunk lookup + issue of the global loads
-        int g0_ = 0, left = 0;
-        if (act) chunk_rows(q, g0_, left);
+        int g0_, left;
+        chunk_rows(q, g0_, left);
         PNP_ADD(5);                               // 5: chunk lookup at the loop top (tile list -> live rows)
-        if (act) {
-        // PRE operands: copies; in the last chunks of a row tile a pair counts when its first row is live (`left` is workgroup-uniform)
-        if constexpr (PREA) {
-            if (left >= KC) {
-#pragma unroll
-                for (int i = 0; i < 2 * MT; ++i) sts4(As + WG_AROW(i) * LDA + 4 * acq, pa[i]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 2 * MT; ++i) sts4(As + WG_AROW(i) * LDA + 4 * acq, (WG_AROW(i) & ~1) < left ? pa[i] : zero4());
-            }
-        }
-        if constexpr (PREB) {
-            if (left >= KC) {
-#pragma unroll
-                for (int i = 0; i < 2 * NT; ++i) sts4(Bs + WG_BROW(i) * LDB + 4 * bcq, pb[i]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 2 * NT; ++i) sts4(Bs + WG_BROW(i) * LDB + 4 * bcq, (WG_BROW(i) & ~1) < left ? pb[i] : zero4());
-            }
-        }
         v4f sa[2 * MT], sb[2 * NT];
-        if constexpr (!PREA) {
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
             const int rr = WG_AROW(i);
@@ -770,8 +642,6 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
             sts4(As + WG_AROW(i) * LDA + 4 * acq, hi);
             sts4(As + WG_AROW(i + 1) * LDA + 4 * acq, lo);
         }
-        }
-        if constexpr (!PREB) {
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {
             const int rr = WG_BROW(i);
@@ -796,14 +666,12 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
             sts4(Bs + WG_BROW(i) * LDB + 4 * bcq, hi);
             sts4(Bs + WG_BROW(i + 1) * LDB + 4 * bcq, lo);
         }
-        }
-        }
         PNP_ADD(2);                               // 2: wait for the loads + operand transform + LDS stores
         __syncthreads();
         PNP_ADD(3);                               // 3: barriers
-        if (q + G < nq) load_chunk(q + G);
+        if (q + 1 < nq) load_chunk(q + 1);
         PNP_ADD(1);
-        if (act) mma_chunk<MM, MT, NT, LDA, LDB>(As, Bs, wm * 32 * MT, wn * 32 * NT, acc);
+        mma_chunk<MM, MT, NT, LDA, LDB>(As, Bs, wm * 32 * MT, wn * 32 * NT, acc);
         PNP_ADD(4);                               // 4: LDS operand reads + MFMAs
         __syncthreads();
         PNP_ADD(3);
@@ -811,36 +679,6 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
 #undef WG_AROW
 #undef WG_BROW
 
-    if constexpr (G > 1) {
-        // the K-groups' accumulators meet in LDS, halving the live groups per round in a FIXED order ((0 + 2) + (1 + 3) for four):
-        // [register][thread] slots, so a wave's accesses are 64 consecutive dwords
-        float *red = (float *)smem_;
-        constexpr int NACC = MT * NT * 16;
-#pragma unroll
-        for (int half = G / 2; half >= 1; half /= 2) {
-            if (grp >= half && grp < 2 * half) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                        for (int reg = 0; reg < 16; ++reg)
-                            red[((grp - half) * NACC + (mt * NT + nt) * 16 + reg) * GT + tid] = acc[mt][nt][reg];
-            }
-            __syncthreads();
-            if (grp < half) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                        for (int reg = 0; reg < 16; ++reg)
-                            acc[mt][nt][reg] += red[(grp * NACC + (mt * NT + nt) * 16 + reg) * GT + tid];
-            }
-            if (half > 1) __syncthreads();
-        }
-        if (grp != 0) return;
-    }
     float *out = a.partial + (int64_t)bx_ * COUT * CIN;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -856,19 +694,11 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
               (unsigned long long)64);
 }
 
-template <int MM, int LAYER, int MT, int NT, int RC = 0, int PRE = 0>
-__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(((LAYER == 3 && !RC) || PRE) ? 3 : 2, 4))) void wgrad_kernel(WgradArgs a)
+template <int MM, int LAYER, int MT, int NT, int RC = 0>
+__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu((LAYER == 3 && !RC) ? 3 : 2, 4))) void wgrad_kernel(WgradArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[WgradLds<MT, NT, RC>::BYTES];
-    wgrad_body<MM, LAYER, MT, NT, RC, PRE>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
-}
-
-// the same with G K-groups per workgroup (RC = 0): 256 * G threads, G * 34 KB of LDS
-template <int MM, int LAYER, int MT, int NT, int PRE, int G>
-__global__ __launch_bounds__(GT * G) void wgrad_kg_kernel(WgradArgs a)
-{
-    __shared__ __attribute__((aligned(16))) unsigned char smem[WgradLds<MT, NT, 0, G>::BYTES];
-    wgrad_body<MM, LAYER, MT, NT, 0, PRE, G>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
+    wgrad_body<MM, LAYER, MT, NT, RC>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -974,7 +804,7 @@ __global__ void l1_finalize_kernel(const double *__restrict__ Qr, int rep_stride
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int LAYER, int PRE = 0>
+template <int LAYER>
 static int launch_dgrad(const DgradArgs &a, int B, int precision, hipStream_t st)
 {
     if (a.CRED % 64 || a.CPREV % 64 || a.CRED > MAXC) return FCN_E_BADARG;
@@ -991,42 +821,22 @@ static int launch_dgrad(const DgradArgs &a, int B, int precision, hipStream_t st
 #endif
     if (a.CPREV % 128 == 0) {          // 64 x 128 tiles, two workgroups per listed 128-row tile
         FCN_MM_SWITCH(FCN_MM_OF(precision, false),
-                      hipLaunchKernelGGL((dgrad_kernel<MM, LAYER, 1, 2, 2, PRE>), dim3((2 * nt * (a.CPREV / 128) + 7) / 8 * 8), dim3(256), 0, st, a));
+                      hipLaunchKernelGGL((dgrad_kernel<MM, LAYER, 1, 2, 2>), dim3((2 * nt * (a.CPREV / 128) + 7) / 8 * 8), dim3(256), 0, st, a));
     } else {                            // 64 x 64 tiles (the 64-channel layers of scales 1 and 2: few column tiles)
         FCN_MM_SWITCH(FCN_MM_OF(precision, false),
-                      hipLaunchKernelGGL((dgrad_kernel<MM, LAYER, 1, 1, 2, PRE>), dim3((2 * nt * (a.CPREV / 64) + 7) / 8 * 8), dim3(256), 0, st, a));
+                      hipLaunchKernelGGL((dgrad_kernel<MM, LAYER, 1, 1, 2>), dim3((2 * nt * (a.CPREV / 64) + 7) / 8 * 8), dim3(256), 0, st, a));
     }
     FCN_CHECK_LAUNCH();
     return 0;
 }
 
-// K-groups per weight-gradient workgroup of the plain launches (1: the four-wave kernels above).  FCN_WG_KG / FCN_WG_KG_PRE: tuning builds
-#ifndef FCN_WG_KG
-#define FCN_WG_KG 1
-#endif
-#ifndef FCN_WG_KG_PRE
-#define FCN_WG_KG_PRE 1
-#endif
-template <int MM, int LAYER, int PRE, int G>
-static void launch_wgrad_kg(const WgradArgs &a, dim3 grid, bool m2, bool n2, hipStream_t st)
-{
-    if (m2 && n2) hipLaunchKernelGGL((wgrad_kg_kernel<MM, LAYER, 2, 2, PRE, G>), grid, dim3(GT * G), 0, st, a);
-    else if (m2) hipLaunchKernelGGL((wgrad_kg_kernel<MM, LAYER, 2, 1, PRE, G>), grid, dim3(GT * G), 0, st, a);
-    else if (n2) hipLaunchKernelGGL((wgrad_kg_kernel<MM, LAYER, 1, 2, PRE, G>), grid, dim3(GT * G), 0, st, a);
-    else hipLaunchKernelGGL((wgrad_kg_kernel<MM, LAYER, 1, 1, PRE, G>), grid, dim3(GT * G), 0, st, a);
-}
-
-template <int MM, int LAYER, int RC = 0, int PRE = 0>
+template <int MM, int LAYER, int RC = 0>
 static void launch_wgrad_mm(const WgradArgs &a, dim3 grid, bool m2, bool n2, hipStream_t st)
 {
-    if constexpr (!RC && (PRE ? FCN_WG_KG_PRE : FCN_WG_KG) > 1) {
-        launch_wgrad_kg<MM, LAYER, PRE, (PRE ? FCN_WG_KG_PRE : FCN_WG_KG)>(a, grid, m2, n2, st);
-        return;
-    }
-    if (m2 && n2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 2, 2, RC, PRE>), grid, dim3(GT), 0, st, a);
-    else if (m2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 2, 1, RC, PRE>), grid, dim3(GT), 0, st, a);
-    else if (n2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 1, 2, RC, PRE>), grid, dim3(GT), 0, st, a);
-    else hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 1, 1, RC, PRE>), grid, dim3(GT), 0, st, a);
+    if (m2 && n2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 2, 2, RC>), grid, dim3(GT), 0, st, a);
+    else if (m2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 2, 1, RC>), grid, dim3(GT), 0, st, a);
+    else if (n2) hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 1, 2, RC>), grid, dim3(GT), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<MM, LAYER, 1, 1, RC>), grid, dim3(GT), 0, st, a);
 }
 
 struct WgradPlan {
@@ -1080,13 +890,7 @@ static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, int precision, hipS
     WgradPlan P;
     FCN_TRY(plan_wgrad<LAYER>(a, B, nsplit_cap, P));
     dim3 grid(P.nsplit, P.oy, P.oz);
-    if (a.bimg) {                          // both operands pre-encoded by the data-gradient kernels (one instance serves both layers)
-        if (!a.dy) return FCN_E_BADARG;
-        FCN_MM_SWITCH(FCN_MM_OF(precision, false), (launch_wgrad_mm<MM, 3, 0, 3>(a, grid, P.m2, P.n2, st)));
-    } else if (a.pre_a) {                  // dy as a pair image, the activation operand built while staging
-        if (!a.dy) return FCN_E_BADARG;
-        FCN_MM_SWITCH(FCN_MM_OF(precision, false), (launch_wgrad_mm<MM, LAYER, 0, 1>(a, grid, P.m2, P.n2, st)));
-    } else if (LAYER == 3 && !a.dy) {      // dy3 rebuilt by the kernel (RC)
+    if (LAYER == 3 && !a.dy) {             // dy3 rebuilt by the kernel (RC)
         if (!a.ycur || !a.ewin || !a.amax || !a.gmax || !a.cb.bstat) return FCN_E_BADARG;
         FCN_MM_SWITCH(FCN_MM_OF(precision, false), (launch_wgrad_mm<MM, LAYER, LAYER == 3 ? 1 : 0>(a, grid, P.m2, P.n2, st)));
     } else {
@@ -1165,75 +969,6 @@ extern "C" int fcn_pn_backward3(const fcn_pn_desc *d, const fcn_pn_params *p, co
     return pn_backward_impl(d, p, dfeat, ws, dW, dgamma, dbeta, stream, stream2, stream3, events);
 }
 
-// The chain behind poolbwd with PRE-ENCODED weight-gradient operands (fcn_pn_ws.a2p / dy2p / a1p): dgrad<3> writes the pair images
-// of dy3 (first column block, while staging) and of a2 (epilogue); conv3's weight gradient is then a copy-to-LDS GEMM -- on `sw`
-// (two streams) beside dgrad<2>, which writes the images of dy2 and a1 for conv2's weight gradient BEHIND it on the main stream
-// (conv2's weight gradient used to follow conv3's on the side stream, rebuilding dy2 from dz2 / y2 and a1 from the entries: the
-// longest chain of the widest scale).  events: fork = events[0], join = events[2].
-static int pn_backward_pre(const fcn_pn_desc *d, const fcn_pn_params *p, const fcn_pn_ws *ws, DgradArgs g, float *dW[3],
-                           float *dgamma[3], float *dbeta[3], hipStream_t st, hipStream_t sw, void *const *events)
-{
-    const int B = d->B, L = d->L, K = d->K, C1 = d->C1, C2 = d->C2, C3 = d->C3;
-    const int cap = L * K;
-    if (cap % 2) return FCN_E_BADARG;                 // (row pairs never straddle two frustums)
-    const double M = (double)B * (double)L * (double)K;
-    const int tps = (cap + 127) / 128;
-    const float *bn1 = ws->bn + fcn_bn_off(0, C1, C2);
-    const float *bn2 = ws->bn + fcn_bn_off(1, C1, C2);
-    const int brs = 2 * C3 + 2 * C2 + 4 * C1;
-    double *bs3 = ws->bstat, *bs2 = bs3 + 2 * C3, *bsQ = bs2 + 2 * C2;
-    hipError_t e = hipSuccess;
-
-    g.prevpair = ws->a2p;
-    FCN_TRY((launch_dgrad<3, 1>(g, B, d->precision, st)));
-    if (sw) {
-        e = hipEventRecord((hipEvent_t)events[0], st);
-        if (e != hipSuccess) return (int)e;
-        e = hipStreamWaitEvent(sw, (hipEvent_t)events[0], 0);
-        if (e != hipSuccess) return (int)e;
-    }
-    WgradArgs w;
-    w.ent = (const float4 *)ws->ent; w.woff = ws->woff; w.tiles = ws->tiles; w.L = L; w.cap = cap; w.tps = tps;
-    w.dz = nullptr; w.ycur = nullptr; w.yprev = nullptr; w.bn_prev = nullptr; w.W1 = nullptr;
-    w.cb.bstat = nullptr; w.cb.rep_stride = brs; w.cb.gamma = nullptr; w.cb.bn = nullptr; w.cb.invM = 1.0 / M; w.cb.dgamma = nullptr; w.cb.dbeta = nullptr;
-    w.ewin = nullptr; w.amax = nullptr; w.gmax = nullptr;
-    w.partial = ws->partial; w.dy = ws->dy3; w.bimg = ws->a2p; w.pre_a = 1; w.COUT = C3; w.CIN = C2;
-    if (!ws->a2p) { w.yprev = ws->y2; w.bn_prev = bn2; }          // relu(bn2(y2)) built while staging, as without the images
-    // (the second wait for events[0], between the GEMM and its reduce, is a redundant edge out of dgrad<3> that uses up child index 1:
-    // ROCm's graph executor then gives dgrad<2> -- child 2 -- the internal stream of the THIRD captured scale, a narrow one, as
-    // the flow without the images does; as child 1 it lands on the second scale's stream and that scale's whole chain waits)
-    FCN_TRY(launch_wgrad<3>(w, B, ws->nsplit, d->precision, sw ? sw : st, dW[2], sw ? (hipEvent_t)events[0] : nullptr));
-    DgradArgs g2 = g;
-    g2.ycur = ws->y2; g2.amax = nullptr; g2.gmax = nullptr; g2.dzcur = ws->dz2;
-    g2.Wenc = (const u32x4 *)(ws->wenc + (int64_t)C2 * C1 + (int64_t)C3 * C2);               // G2 (pn_wenc_off(2))
-    g2.cb.bstat = bs2; g2.cb.gamma = p->gamma[1]; g2.cb.bn = bn2; g2.cb.dgamma = dgamma[1]; g2.cb.dbeta = dbeta[1];
-    g2.dybuf = ws->dy2p; g2.yprev = nullptr; g2.bn_prev = bn1; g2.W1 = p->W[0]; g2.dzprev = nullptr; g2.bstat_prev = bsQ;
-    g2.CRED = C2; g2.CPREV = C1; g2.prevpair = ws->a1p;
-    FCN_TRY((launch_dgrad<2, 1>(g2, B, d->precision, st)));
-    hipLaunchKernelGGL(l1_finalize_kernel, dim3((C1 + 63) / 64), dim3(64), 0, st, bsQ, brs, ws->stat + FCN_STAT_MOM,
-                       p->W[0], p->gamma[0], bn1, C1, M, dW[0], dgamma[0], dbeta[0]);
-    FCN_CHECK_LAUNCH();
-    // conv2's weight gradient follows conv3's on the side stream once dgrad<2> has written its operands: the main stream ends with
-    // the layer-1 finalisation, as it does without the pair images (whatever the graph executor queues behind it waits no longer)
-    if (sw) {
-        e = hipEventRecord((hipEvent_t)events[1], st);
-        if (e != hipSuccess) return (int)e;
-        e = hipStreamWaitEvent(sw, (hipEvent_t)events[1], 0);
-        if (e != hipSuccess) return (int)e;
-    }
-    w.partial = ws->partial + (int64_t)ws->nsplit * C3 * C2;      // its own partials
-    w.dy = ws->dy2p; w.bimg = ws->a1p; w.COUT = C2; w.CIN = C1;
-    if (!ws->a1p) { w.yprev = nullptr; w.bn_prev = bn1; w.W1 = p->W[0]; }      // relu(bn1(conv1(u))) built while staging
-    FCN_TRY(launch_wgrad<2>(w, B, ws->nsplit, d->precision, sw ? sw : st, dW[1]));
-    if (sw) {
-        e = hipEventRecord((hipEvent_t)events[2], sw);
-        if (e != hipSuccess) return (int)e;
-        e = hipStreamWaitEvent(st, (hipEvent_t)events[2], 0);
-        if (e != hipSuccess) return (int)e;
-    }
-    return 0;
-}
-
 static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dfeat, const fcn_pn_ws *ws,
                             float *dW[3], float *dgamma[3], float *dbeta[3], void *stream, void *stream2, void *stream3,
                             void *const *events)
@@ -1273,18 +1008,10 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
     g.Wenc = (const u32x4 *)(ws->wenc + 2 * (int64_t)C2 * C1 + (int64_t)C3 * C2);            // G3 (pn_wenc_off(3))
     g.cb.bstat = bs3; g.cb.rep_stride = brs; g.cb.gamma = p->gamma[2]; g.cb.bn = bn3; g.cb.invM = 1.0 / M; g.cb.dgamma = dgamma[2]; g.cb.dbeta = dbeta[2];
     g.dybuf = ws->dy3; g.yprev = ws->y2; g.bn_prev = bn2; g.W1 = nullptr; g.dzprev = ws->dz2; g.bstat_prev = bs2;
-    g.CRED = C3; g.CPREV = C2; g.prevpair = nullptr;
+    g.CRED = C3; g.CPREV = C2;
 #if FCN_XB & 512       // (timing build: the cost of a2 . G instead of dy3 . W3 -- reduction over C2, the A operand read from y2)
     g.ycur = ws->y2; g.CRED = C2;
 #endif
-    // PRE: the weight-gradient operands are written as pair images by the data-gradient kernels (see dgrad_body)
-    const bool pre = ws->dy2p != nullptr;
-    if (pre) {
-        if (!ws->dy3 || ws->partial_both != 0 || (ws->a2p != nullptr) != (ws->a1p != nullptr)) return FCN_E_BADARG;
-        return pn_backward_pre(d, p, ws, g, dW, dgamma, dbeta, st, two ? sw : nullptr, two ? events : nullptr);
-    }
-    if (ws->a2p || ws->a1p) return FCN_E_BADARG;
-    if (ws->partial_both != 0 && ws->partial_both != 1) return FCN_E_BADARG;
     FCN_TRY(launch_dgrad<3>(g, B, d->precision, st));
 
     WgradArgs w;
@@ -1292,7 +1019,7 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
     w.partial = ws->partial;
     w.dy = ws->dy3; w.dz = nullptr; w.ycur = nullptr; w.yprev = ws->y2; w.bn_prev = bn2;
     w.cb.bstat = nullptr; w.cb.rep_stride = brs; w.cb.gamma = nullptr; w.cb.bn = nullptr; w.cb.invM = 1.0 / M; w.cb.dgamma = nullptr; w.cb.dbeta = nullptr;
-    w.ewin = nullptr; w.amax = nullptr; w.gmax = nullptr; w.bimg = nullptr; w.pre_a = 0;
+    w.ewin = nullptr; w.amax = nullptr; w.gmax = nullptr;
     if (!ws->dy3) {        // no dy3 buffer: conv3's weight-gradient GEMM rebuilds dy3 from what the data-gradient GEMM reads
         w.ycur = ws->y3; w.cb.bstat = bs3; w.cb.gamma = p->gamma[2]; w.cb.bn = bn3;
         w.ewin = ws->ewin; w.amax = ws->amax; w.gmax = ws->gmax;
@@ -1309,7 +1036,7 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
         g2.Wenc = (const u32x4 *)(ws->wenc + (int64_t)C2 * C1 + (int64_t)C3 * C2);               // G2 (pn_wenc_off(2))
         g2.cb.bstat = bs2; g2.cb.gamma = p->gamma[1]; g2.cb.bn = bn2; g2.cb.dgamma = dgamma[1]; g2.cb.dbeta = dbeta[1];
         g2.dybuf = nullptr; g2.yprev = nullptr; g2.bn_prev = bn1; g2.W1 = p->W[0]; g2.dzprev = nullptr; g2.bstat_prev = bsQ;
-        g2.CRED = C2; g2.CPREV = C1; g2.prevpair = nullptr;
+        g2.CRED = C2; g2.CPREV = C1;
         WgradArgs w2 = w;
         w2.dy = nullptr; w2.dz = ws->dz2; w2.ycur = ws->y2; w2.yprev = nullptr; w2.bn_prev = bn1;
         w2.cb.bstat = bs2; w2.cb.gamma = p->gamma[1]; w2.cb.bn = bn2;

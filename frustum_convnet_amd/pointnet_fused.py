@@ -30,12 +30,6 @@ def _mid_launch(B, L, K, C3):
     return mode == "1" or (mode == "auto" and C3 <= 128 and B * L * K <= 300000)
 
 
-def _pre_encode():
-    """Which weight-gradient operands the data-gradient kernels pre-encode (fcn_pn_ws.dy2p / a2p / a1p): FCN_PN_PRE = 0 none (the
-    weight-gradient GEMMs build their operands themselves), 1 the dy operands, 3 the activation operands too."""
-    return int(os.environ.get("FCN_PN_PRE", "1"))
-
-
 class Workspace:
     """Caller-owned scratch of one scale (fcn_pn_ws).  Persistent across steps, recycled through the
     owning module's free list so that two forwards in flight (before their backwards) never share one."""
@@ -81,16 +75,6 @@ class Workspace:
             self.bstat = torch.zeros((rep * (2 * C3 + 2 * C2 + 4 * C1),), dtype=f64, device=dev)
             self.coef = torch.empty((5 * (C3 + C2),), dtype=f32, device=dev)
             self.partial = torch.empty((self.nsplit * (C3 * C2 + C2 * C1),), dtype=f32, device=dev)     # both weight gradients at once
-        mid = bool(need_grad and _mid_launch(B, L, K, C3))
-        # pre-encoded weight-gradient operands (fcn_pn_ws.a2p / dy2p / a1p: pair images written by the data-gradient kernels, the
-        # weight-gradient GEMMs become copy-to-LDS GEMMs; bit-identical gradients).  Wherever the scale's backward is not the merged
-        # middle launch (whose weight-gradient roles run BESIDE conv2's data gradient and cannot read what it writes).
-        self.a2p = self.dy2p = self.a1p = None
-        if need_grad and not mid and self.dy3 is not None and cap % 2 == 0 and _pre_encode():
-            self.dy2p = torch.empty((B, cap, C2), dtype=f32, device=dev)
-            if _pre_encode() & 2:
-                self.a2p = torch.empty((B, cap, C2), dtype=f32, device=dev)
-                self.a1p = torch.empty((B, cap, C1), dtype=f32, device=dev)
         p = lambda t: None if t is None else t.data_ptr()
         self.c = PnWs(p(self.woff), p(self.ent), p(self.ewin), p(self.tiles), p(self.y2), p(self.y3), p(self.amax),
                       p(self.stat), p(self.bn), p(self.gmax), p(self.dy3), p(self.dz2), p(self.bstat),
@@ -98,7 +82,7 @@ class Workspace:
                       # `partial` above holds both weight gradients' split partials, so a one-stream backward can run conv2's data
                       # gradient and the two weight-gradient GEMMs as roles of ONE launch (pn_mid_kernel: 6 launches per scale instead
                       # of 8, bit-identical gradients) -- _mid_launch() below says where that pays
-                      1 if mid else 0, p(self.a2p), p(self.dy2p), p(self.a1p))
+                      1 if (need_grad and _mid_launch(B, L, K, C3)) else 0)
 
     @staticmethod
     def stored(t, precision_code):
@@ -107,27 +91,6 @@ class Workspace:
         if precision_code != _precision.CODES["bf16"]:        # ("bf16ops" keeps fp32 storage)
             return t
         return t.view(-1).view(torch.bfloat16)[:t.numel()].view(t.shape).float()
-
-    @staticmethod
-    def pair_image_values(t, precision_code):
-        """fp32 values of a PAIR IMAGE (fcn_pn_ws.a2p / dy2p / a1p, and dy3 when those are set; include/fcn_hip.h): row 2p of the
-        (B, cap, C) buffer holds the packed 16-bit HI parts of rows (2p, 2p + 1), row 2p + 1 their LO parts, in the backward
-        operand mode of `precision_code` (bf16 parts; exact fp32 rows in the f32 mode).  For tests and debugging."""
-        if precision_code == _precision.CODES["f32"]:
-            return t
-        B, cap, C = t.shape
-        w = t.contiguous().view(torch.int32).view(B, cap // 2, 2, C)
-        hi, lo = w[:, :, 0], w[:, :, 1]
-        part = lambda d, sh: ((d >> sh) << 16).view(torch.float32) if sh else (d << 16).view(torch.float32)
-        even = part(hi, 0) + part(lo, 0)
-        odd = part(hi, 16) + part(lo, 16)
-        return torch.stack([even, odd], dim=2).view(B, cap, C)
-
-    def dy3_values(self, precision_code):
-        """dy3 as fp32, whichever form the backward left in the buffer (fp32 rows, or the pair image when a2p is set)."""
-        if self.dy2p is not None:
-            return self.pair_image_values(self.dy3, precision_code)
-        return self.stored(self.dy3, precision_code)
 
 
 class WorkspacePool:

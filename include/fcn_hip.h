@@ -143,18 +143,7 @@ typedef struct fcn_pn_ws {
                                     by a pass that re-reads y3 (and in eval mode y3 is not written at all)                     */
     int32_t  partial_both;       /* 1: `partial` holds nsplit * (C3*C2 + C2*C1) floats, so the one-stream backward (fcn_pn_backward,
                                     fcn_pn_backward2 with stream2 == NULL) may run conv2's data gradient and both weight gradients as
-                                    roles of ONE launch; 0: they run one after the other through nsplit * max(C3*C2, C2*C1) floats.
-                                    Strictly 0 or 1. */
-    /* PRE-ENCODED weight-gradient operands (dy2p non-NULL; needs dy3 non-NULL, partial_both == 0 and `partial` sized for both weight
-     * gradients: nsplit * (C3*C2 + C2*C1) floats).  The data-gradient kernels then write the dy operands of the weight-gradient
-     * GEMMs as PAIR IMAGES -- (rows, C) dwords, row 2p = the packed 16-bit HI parts of rows (2p, 2p+1), row 2p+1 their LO parts:
-     * dy3 holds the image of dy3 (instead of its fp32 rows), dy2p that of dy2 -- and the weight-gradient GEMMs copy them to LDS
-     * instead of re-deriving them from dz / y / the BatchNorm-backward sums.  With a2p and a1p (both or neither) the activation
-     * operands relu(bn2(y2)) and relu(bn1(conv1(u))) are images too (written by the data-gradient epilogues).  Bit-identical
-     * gradients in every combination.  The struct must be zero-initialised by callers that do not know these fields. */
-    float   *a2p;                /* (B, cap, C2) or NULL */
-    float   *dy2p;               /* (B, cap, C2) or NULL */
-    float   *a1p;                /* (B, cap, C1) or NULL */
+                                    roles of ONE launch; 0: they run one after the other through nsplit * max(C3*C2, C2*C1) floats */
 } fcn_pn_ws;
 
 /* Sticky numeric flags (fcn_pn_ws.flags, fcn_cn_ws.flags): the kernels only ever OR bits in.

@@ -177,12 +177,7 @@ def run_stages(B, N, stride, K, mlp, dist, seed=5, variant="car", verbose=True, 
     if not emu:
         torch.cuda.synchronize()
     if ws.dy3 is not None:          # (FCN_STORE_DY3=0: conv3's weight-gradient GEMM rebuilds dy3 and nothing stores it)
-        rec("dy3", live(ws.dy3_values(desc.precision)), r["dy3"])
-    if ws.dy2p is not None:         # the pair images of the other weight-gradient operands (pointnet_bwd.hip: dgrad_body PRE)
-        rec("dy2p", live(ws.pair_image_values(ws.dy2p, desc.precision)), r["dy2"])
-    if ws.a2p is not None:
-        rec("a2p", live(ws.pair_image_values(ws.a2p, desc.precision)), f["a2"])
-        rec("a1p", live(ws.pair_image_values(ws.a1p, desc.precision)), f["a1"])
+        rec("dy3", live(ws.dy3), r["dy3"])
     zmask2 = (f["y2"] * f["s"][1] + f["t"][1] > 0).float()
     rec("dz2", live(ws.dz2), r["G2"] * zmask2)
     for j in (3, 2, 1):
