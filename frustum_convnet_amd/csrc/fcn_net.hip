@@ -334,38 +334,24 @@ __device__ __forceinline__ float cg_act(float s, float x, float t, bool ok) { re
 // gives 4-16 resident waves per tile to hide the gather / staging latency, and nothing but the result goes back to HBM.
 // In use: <1,4,1> (32 x 32 tile, 4 waves) -- 560 workgroups per layer; <1,4> (32 x 64) and <2,4> (64 x 64) measured
 // 5 % slower over the forward (280 tiles for 256 CUs at every level of the pyramid).
-// T > 1: T TILES per workgroup, each reduced by G K-groups (T * G * MW * WNC waves per workgroup).  A launch of more tiles than the
-// machine holds workgroups (1 120 for block1 and the deconvolutions, 768 resident slots) runs in two rounds and its span is the
-// dispatch + issue + prologue of the second round, not its K loops (tools/fcn_probe.py: K loop 1.3-5.4 us of a 27-34 us launch):
-// half or a quarter as many workgroups, each with twice / four times the K loop per wave, fit one round.  The tiles of a
-// workgroup are neighbours in the tile order (the same rows, adjacent column blocks) and share the BatchNorm fold of the prologue.
-template <int MM, int MW, int G, int WNC = 2, int NTW = 1, int T = 1>      // WNC waves across N per K-group, NTW 32-column blocks per wave:
-__device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int tile0, const int nby, const int ntile, const int koff)      // tile (32*MW) x (32*WNC*NTW); koff: offset of L in the kernarg segment
+template <int MM, int MW, int G, int WNC = 2, int NTW = 1>      // WNC waves across N per K-group, NTW 32-column blocks per wave:
+__device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, const int by, const int koff)      // tile (32*MW) x (32*WNC*NTW); koff: offset of L in the kernarg segment
 {
-    constexpr int TG = 64 * MW * WNC, TMB = 32 * MW, TNC = 32 * WNC * NTW, NTHR = G * TG;      // NTHR: the threads of ONE tile
+    constexpr int TG = 64 * MW * WNC, TMB = 32 * MW, TNC = 32 * WNC * NTW, NTHR = G * TG;
     constexpr int LDRA = KbTile<TMB>::LDR, LDRB = KbTile<TNC>::LDR, GU4 = KbTile<TMB>::U4 + KbTile<TNC>::U4;
     constexpr int NA = TMB * 8 / TG;          // 4-vectors of A per thread per chunk
     constexpr int NB = TNC * 8 / TG;          // u32x4 of the encoded weight per thread per chunk
     static_assert(G * GU4 * 4 >= G * TMB * TNC, "the cross-group sum fits the operand images");
     static_assert(2 * TNC <= NTHR && (TMB * 8) % TG == 0 && (TNC * 8) % TG == 0, "epilogue / staging lane mapping");
-    __shared__ u32x4 lds4_[T * G * GU4];      // per tile and K-group: kb-major images of its A and W chunk (gemm_tile.h)
+    __shared__ u32x4 lds4[G * GU4];           // per K-group: kb-major images of its A and W chunk (gemm_tile.h)
     __shared__ __attribute__((aligned(16))) float sS[CG_KMAX], tS[CG_KMAX];
     __shared__ int cSeg[CG_KMAX / KC], cTap[CG_KMAX / KC], cK0[CG_KMAX / KC];   // chunk -> (segment, tap, channel)
-    if (FCN_XF & 128) return;                           // (timing builds: the bare launch -- dispatch + kernel boundary)
-    const int wtid = threadIdx.x, sub = T == 1 ? 0 : wtid / NTHR;           // sub: which tile of the workgroup
-    const int tid = T == 1 ? wtid : wtid % NTHR, g = tid / TG, gt = tid % TG;
-    u32x4 *lds4 = lds4_ + sub * (G * GU4);
     float *lds = (float *)lds4;
+    if (FCN_XF & 128) return;                           // (timing builds: the bare launch -- dispatch + kernel boundary)
+    const int tid = threadIdx.x, g = tid / TG, gt = tid % TG;
     const int lane = tid & 63, gw = gt >> 6, l31 = lane & 31, lh = lane >> 5;
     const int wm = gw / WNC, wn = gw % WNC;
     u32x4 *Ab = lds4 + g * GU4, *Bb = Ab + KbTile<TMB>::U4;
-    // this tile: column tiles fastest; a tile past the end (odd tile counts) works on rows past the matrix -- every load clamped, no store
-    int bx, by;
-    {
-        const int t_ = tile0 + sub;
-        cg_divmod(min(t_, ntile - 1), nby, cg_inv(nby), bx, by);       // (t < 2^23: a grid is at most a few thousand workgroups)
-        if (t_ >= ntile) { bx = 0x3fffff; by = 0; }
-    }
     PROBE_DECL;
     PROBE_STAMP();                                      // 0: entry
     // EVERY kernel-argument field the code in front of the first loads reads, fetched as ONE batch of scalar loads and pinned:
@@ -377,7 +363,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int tile0, 
     geo.Lin = opaque_s(L.Lin);
     const u32x4 *LWenc = opaque_s(L.Wenc);
     const int R = LB * LLout;
-    const int row0 = min(bx, 0x3fffff) * TMB, n0 = by * TNC;
+    const int row0 = bx * TMB, n0 = by * TNC;
     const int kq = gt & 7, rb = gt >> 3;      // rb: 0..31 (MW=2) or 0..15 (MW=1)
     constexpr int RSTEP = TG / 8;
     const int nchunk = LKtot / KC, nit = (nchunk + G - 1) / G;
@@ -487,15 +473,15 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int tile0, 
                         __builtin_amdgcn_readfirstlane(k0_), ra1, rw1, ok1);
     }
     PROBE_STAMP();                                      // 1: first loads issued
-    if (wtid < nchunk) {
+    if (tid < nchunk) {
         int sg, tap, k0, so;
-        cg_locate_s(geo, C0, C1, C2, C3, wtid * KC, sg, tap, k0, so);
-        cSeg[wtid] = sg; cTap[wtid] = tap; cK0[wtid] = k0;
+        cg_locate_s(geo, C0, C1, C2, C3, tid * KC, sg, tap, k0, so);
+        cSeg[tid] = sg; cTap[tid] = tap; cK0[tid] = k0;
     }
     // (from here on the descriptor is read through the kernarg pointer: see cg_kernarg_layer)
     const cg_klayer_p Lk = cg_kernarg_layer(koff);
-    if (FCN_XF & 32) { for (int i = wtid; i < LKtot; i += T * NTHR) { sS[i] = 1.f; tS[i] = 0.f; } }
-    else cg_fill_bn(Lk, sS, tS, wtid, T * NTHR, tile0 == 0);
+    if (FCN_XF & 32) { for (int i = tid; i < LKtot; i += NTHR) { sS[i] = 1.f; tS[i] = 0.f; } }
+    else cg_fill_bn(Lk, sS, tS, tid, NTHR, bx == 0 && by == 0);
     __syncthreads();                            // sS / tS and the chunk table ready
     if (FCN_XF & 256) { if (sS[0] == 123.456f) Lk->y[0] = 0.f; return; }      // (timing builds: launch + prologue only)
     PROBE_STAMP();                                      // 2: prologue done
@@ -575,13 +561,15 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int tile0, 
     PROBE_FLUSH(((unsigned long long)Le->Ktot << 32) | ((unsigned long long)Le->Cout << 16) | (unsigned long long)(Le->Lout & 0xffff));
 }
 
-template <int MM, int MW, int G, int WNC = 2, int NTW = 1, int T = 1>
-__global__ __launch_bounds__(T * G * 64 * MW * WNC) void cgk_fwd_kernel(CgLayer L)
+template <int MM, int MW, int G, int WNC = 2, int NTW = 1>
+__global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_kernel(CgLayer L)
 {
     const int nby = L.Cout / (32 * WNC * NTW), nbx = (L.B * L.Lout + 32 * MW - 1) / (32 * MW);
-    const int t = cg_xcd_tile(blockIdx.x, (nbx * nby + T - 1) / T);          // column tiles fastest: a row tile's operand rows stay in one L2
+    const int t = cg_xcd_tile(blockIdx.x, nbx * nby);          // column tiles fastest: a row tile's operand rows stay in one L2
     if (t < 0) return;
-    cgk_fwd_body<MM, MW, G, WNC, NTW, T>(L, t * T, nby, nbx * nby, 0);
+    int bx, by;
+    cg_divmod(t, nby, cg_inv(nby), bx, by);                    // (t < 2^23: a grid is at most a few thousand workgroups)
+    cgk_fwd_body<MM, MW, G, WNC, NTW>(L, bx, by, 0);
 }
 
 // Two INDEPENDENT layers in one launch (a deconvolution next to the stride-2 conv that reads the same merge output):
@@ -592,20 +580,19 @@ struct CgLayerPair {
     int na;                    // workgroups of A (a multiple of 8); the rest belong to B
 };
 
-// GT: waves per workgroup / (MW * WNC) = T * G for both layers; A runs one tile per workgroup (GT K-groups), B runs TB tiles
-// of GT / TB K-groups each
-template <int MM, int MW, int GT_, int WNC, int NTW = 1, int TB = 1>
-__global__ __launch_bounds__(GT_ * 64 * MW * WNC) void cgk_fwd_pair_kernel(CgLayerPair p)
+template <int MM, int MW, int G, int WNC, int NTW = 1>
+__global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_pair_kernel(CgLayerPair p)
 {
     const int bid = blockIdx.x;
     const bool isA = bid < p.na;
     const CgLayer &L = isA ? p.A : p.B;
     const int nby = L.Cout / (32 * WNC * NTW), nbx = (L.B * L.Lout + 32 * MW - 1) / (32 * MW);
-    const int tt = isA ? 1 : TB;
-    const int t = cg_xcd_tile(isA ? bid : bid - p.na, (nbx * nby + tt - 1) / tt);
+    const int t = cg_xcd_tile(isA ? bid : bid - p.na, nbx * nby);
     if (t < 0) return;
-    if (isA) cgk_fwd_body<MM, MW, GT_, WNC, NTW, 1>(p.A, t, nby, nbx * nby, (int)offsetof(CgLayerPair, A));
-    else cgk_fwd_body<MM, MW, GT_ / TB, WNC, NTW, TB>(p.B, t * TB, nby, nbx * nby, (int)offsetof(CgLayerPair, B));
+    int bx, by;
+    cg_divmod(t, nby, cg_inv(nby), bx, by);
+    if (isA) cgk_fwd_body<MM, MW, G, WNC, NTW>(p.A, bx, by, (int)offsetof(CgLayerPair, A));
+    else cgk_fwd_body<MM, MW, G, WNC, NTW>(p.B, bx, by, (int)offsetof(CgLayerPair, B));
 }
 
 // BN-backward coefficients of one channel from the batch sums (sum dz, sum dz*xhat): gamma*rstd, mean, rstd, dbeta/M,
@@ -1883,18 +1870,6 @@ extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p
     };
     // 32 x 32 tiles: 560 workgroups of 4 waves (2-3 resident per CU) instead of 280 of 8 (every level of the pyramid has
     // B*L*N/2048 = 280 tiles of 32 x 64 for 256 CUs); measured 369 -> 352 us over the forward
-    // Tiles per workgroup (cgk_fwd_body T): a layer of more than FCN_FT_TILES_1 tiles runs two per workgroup (two K-groups each),
-    // of more than FCN_FT_TILES_2 four (one wave per tile) -- always FCN_FT_G waves per workgroup
-#ifndef FCN_FT_TILES_1
-#define FCN_FT_TILES_1 768
-#endif
-#ifndef FCN_FT_TILES_2
-#define FCN_FT_TILES_2 (1 << 30)
-#endif
-    auto tiles_per_wg = [](int ntile) -> int {
-        if (FCN_FT_MW != 1 || FCN_FT_WNC != 1 || FCN_FT_G != 4) return 1;
-        return ntile > FCN_FT_TILES_2 ? 4 : (ntile > FCN_FT_TILES_1 ? 2 : 1);
-    };
     for (int q = 0; q < norder; ++q) {
         const int l = order[q];
         const int R = d->B * P.Lout[l];
@@ -1914,19 +1889,9 @@ extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p
             } else {
                 constexpr int TC = 32 * FCN_FT_WNC;
                 pp.na = cg_pad8(((R + TR - 1) / TR) * (P.N[l] / TC));
-                const int ntb = ((R2 + TR - 1) / TR) * (P.N[l2] / TC);
-                const int tb = tiles_per_wg(ntb);
-                const int nb = cg_pad8((ntb + tb - 1) / tb);
-                if (tb == 4) {
-                    FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_pair_kernel<MM, FCN_FT_MW, FCN_FT_G, FCN_FT_WNC, 1, 4>), dim3(pp.na + nb),
-                                                          dim3(FCN_FT_THREADS), 0, st, pp));
-                } else if (tb == 2) {
-                    FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_pair_kernel<MM, FCN_FT_MW, FCN_FT_G, FCN_FT_WNC, 1, 2>), dim3(pp.na + nb),
-                                                          dim3(FCN_FT_THREADS), 0, st, pp));
-                } else {
-                    FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_pair_kernel<MM, FCN_FT_MW, FCN_FT_G, FCN_FT_WNC, 1, 1>), dim3(pp.na + nb),
-                                                          dim3(FCN_FT_THREADS), 0, st, pp));
-                }
+                const int nb = cg_pad8(((R2 + TR - 1) / TR) * (P.N[l2] / TC));
+                FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_pair_kernel<MM, FCN_FT_MW, FCN_FT_G, FCN_FT_WNC, 1>), dim3(pp.na + nb),
+                                                      dim3(FCN_FT_THREADS), 0, st, pp));
             }
             FCN_CHECK_LAUNCH();
             ++q;
@@ -1939,16 +1904,8 @@ extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p
                                                       dim3(cg_pad8(((R + TR - 1) / TR) * (P.N[l] / TCW))), dim3(FCN_FT_THREADS), 0, st, L));
             } else {
                 constexpr int TC = 32 * FCN_FT_WNC;
-                const int nt1 = ((R + TR - 1) / TR) * (P.N[l] / TC);
-                const int t1 = tiles_per_wg(nt1);
-                const dim3 grid(cg_pad8((nt1 + t1 - 1) / t1));
-                if (t1 == 4) {
-                    FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_kernel<MM, FCN_FT_MW, FCN_FT_G / 4, FCN_FT_WNC, 1, 4>), grid, dim3(FCN_FT_THREADS), 0, st, L));
-                } else if (t1 == 2) {
-                    FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_kernel<MM, FCN_FT_MW, FCN_FT_G / 2, FCN_FT_WNC, 1, 2>), grid, dim3(FCN_FT_THREADS), 0, st, L));
-                } else {
-                    FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_kernel<MM, FCN_FT_MW, FCN_FT_G, FCN_FT_WNC, 1>), grid, dim3(FCN_FT_THREADS), 0, st, L));
-                }
+                FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_kernel<MM, FCN_FT_MW, FCN_FT_G, FCN_FT_WNC, 1>),
+                                                      dim3(cg_pad8(((R + TR - 1) / TR) * (P.N[l] / TC))), dim3(FCN_FT_THREADS), 0, st, L));
             }
             FCN_CHECK_LAUNCH();
         }
