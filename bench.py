@@ -440,6 +440,9 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
             steps_per_graph = 1
             model.split_backward = False
             model._split = model._pending_split = None          # (a capture that died between take_split() and phase 2)
+            model.feat_net.drop_prefetch()                      # (a front prefetched inside the dead capture never ran: dropped, not waited for)
+            model._pf_xyz = None
+            model.next_batch = None
             torch.cuda.synchronize()
 
     parity = [0]

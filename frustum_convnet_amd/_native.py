@@ -204,3 +204,25 @@ def ptr(t):
 def current_stream(device=None):
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_hip = None
+
+
+def capture_id(device=None):
+    """Id of the hipGraph capture the current stream of `device` is part of, 0 when it is not capturing (hipStreamGetCaptureInfo
+    on the HIP runtime torch loaded).  Used to keep state created during one capture from leaking into eager code or another
+    capture (PointNetFeat.prefetch)."""
+    global _hip
+    import torch
+    if not torch.cuda.is_available() or not torch.cuda.is_current_stream_capturing():
+        return 0
+    if _hip is None:
+        _hip = ctypes.CDLL("libamdhip64.so")
+        _hip.hipStreamGetCaptureInfo.restype = ctypes.c_int
+        _hip.hipStreamGetCaptureInfo.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_ulonglong)]
+    status, cid = ctypes.c_int(0), ctypes.c_ulonglong(0)
+    rc = _hip.hipStreamGetCaptureInfo(current_stream(device), ctypes.byref(status), ctypes.byref(cid))
+    if rc != 0 or status.value != 1:          # (hipStreamCaptureStatusActive == 1)
+        return -1                             # capturing, id unknown: never equal to a recorded id of another state
+    return int(cid.value) + 1

@@ -73,14 +73,18 @@ def build(force=False, verbose=True, lib=None, extra_flags=()):
     hsrc, hobj = os.path.join(objdir, "build_hash.cpp"), os.path.join(objdir, "build_hash.o")
     with open(hsrc, "w") as f:
         f.write('extern "C" const char *fcn_build_hash(void) { return "%s"; }\n' % source_hash(extra_flags))
-    subprocess.check_call([os.environ.get("CXX", "g++"), "-O1", "-fPIC", "-c", hsrc, "-o", hobj])
+    import shutil
+    cxx = os.environ.get("CXX") or shutil.which("g++") or shutil.which("c++")
+    if cxx:
+        subprocess.check_call([cxx, "-O1", "-fPIC", "-c", hsrc, "-o", hobj])
+    else:                                   # a ROCm box without a host compiler: hipcc compiles the one-line host object too
+        subprocess.check_call([hipcc, "-x", "c++", "-O1", "-fPIC", "-c", hsrc, "-o", hobj])
     objs.append(hobj)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib]
     if verbose:
         print("[fcn build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     if variant:
-        import shutil
         shutil.rmtree(objdir, ignore_errors=True)
     return lib
 

@@ -976,6 +976,7 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
     if (!d || !p || !ws || !dfeat || !dW || !dgamma || !dbeta) return FCN_E_BADARG;
     if (!d->training || !ws->wenc) return FCN_E_BADARG;
     if (d->precision < 0 || d->precision > FCN_PREC_BF16_OPS) return FCN_E_BADARG;
+    if (ws->partial_both != 0 && ws->partial_both != 1) return FCN_E_BADARG;      // (an uninitialised trailing field must not enable the merged launch)
     hipStream_t st = (hipStream_t)stream;
     const bool two = stream2 != nullptr && events != nullptr;
     const bool three = two && stream3 != nullptr;

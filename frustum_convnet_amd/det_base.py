@@ -30,6 +30,7 @@ from .common import Conv1d, Conv2d, DeConv1d, init_params, softmax_focal_loss_ig
 from .query_depth_point import QueryDepthPoint
 from .pointnet_fused import WorkspacePool, pointnet_pooled, launch_pooled, attach_pooled
 from . import box_ops
+from . import _native
 
 
 class PointNetModule(nn.Module):
@@ -93,6 +94,17 @@ class PointNetModule(nn.Module):
         feat, _, _ = attach_pooled(self._pool, handle)
         return feat
 
+    def front_signature(self, nlc=False):
+        """Everything a prepared handle (prepare_pooled) FREEZES besides the input tensors: the configuration tuple (training,
+        need_grad, BatchNorm eps / momentum, layout), the operand precision and where the parameters and BatchNorm buffers live.
+        A prefetched front is only consumed by a forward that would have prepared the same handle."""
+        from .pointnet_fused import _cfg_tuple
+        from . import precision as _precision
+        params, bufs = self._param_pack()
+        bn = self.conv1[1]
+        cfgt = _cfg_tuple(self.dist, self.nsample, self.training, bn.eps, bn_momentum(bn), params, nlc)
+        return (cfgt, _precision.code(), tuple(t.data_ptr() for t in params), tuple(t.data_ptr() for b in bufs for t in b))
+
     def forward(self, pc, feat, new_pc=None):
         """Reference-shaped output (B, C3, L, nsample), masked.  Inspection / parity API: it expands the
         fused path's per-entry activations back to the dense slots with device-side indexing and carries
@@ -129,7 +141,7 @@ class PointNetFeat(nn.Module):
         self.concurrent_scales = True
         self.fused_front = os.environ.get("FCN_FUSED_FRONT", "1") != "0"
         self._stream_cache = {}
-        self._prefetched = None     # (key, prepared handles, event or None) of prefetch(): the next batch's front, phase 1
+        self._prefetched = None     # prefetch(): the next batch's front, phase 1 (key, prepared handles, event, capture id)
         # the widest scale is the long pole of the backward: its weight-gradient GEMMs run on a second stream beside
         # its data-gradient chain (bit k of FCN_PN_SIDE = scale k+1; default scale 4 only)
         # Stream topology switches (FCN_TOPO bit mask, default 0 = what measured fastest on ROCm 7.2 / MI355X):
@@ -151,11 +163,12 @@ class PointNetFeat(nn.Module):
     def nets(self):
         return tuple(getattr(self, "pointnet%d" % (i + 1)) for i in range(self.num_scales))
 
-    @staticmethod
-    def _front_key(point_cloud, sample_pc, one_hot_vec, nlc, training):
+    def _front_key(self, point_cloud, sample_pc, one_hot_vec, nlc, training):
+        # the inputs as prefetch() saw them (storage, shape, version counter; a non-contiguous tensor is keyed as passed) and
+        # what the prepared handles froze: configuration, precision, parameter / buffer storage of every scale
         ts = [point_cloud] + list(sample_pc) + ([] if one_hot_vec is None else [one_hot_vec])
-        return (tuple((t.data_ptr(), tuple(t.shape), t._version) for t in ts), bool(nlc), bool(training),
-                torch.is_grad_enabled())
+        return (tuple((t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version) for t in ts), bool(nlc), bool(training),
+                torch.is_grad_enabled(), tuple(net.front_signature(nlc) for net in self.nets))
 
     def prefetch(self, point_cloud, sample_pc, one_hot_vec=None, nlc=False):
         """Phase 1 of the fused front (grouping, entry rows, tile lists, input moments: functions of the batch alone) for the
@@ -185,22 +198,33 @@ class PointNetFeat(nn.Module):
             ev_out.record(side)
         for t in [point_cloud] + list(sample_pc):
             t.record_stream(side)
-        self._prefetched = [self._front_key(point_cloud, sample_pc, one_hot_vec, nlc, self.training), prepared, (dev, ev_out)]
+        # cap: the hipGraph capture these launches belong to (0: none -- they really ran)
+        self._prefetched = {"key": self._front_key(point_cloud, sample_pc, one_hot_vec, nlc, self.training), "handles": prepared,
+                            "event": ev_out, "dev": dev, "cap": _native.capture_id(dev)}
         return True
 
+    def _prefetch_is_foreign(self):
+        """A prefetch made while a hipGraph was being captured exists only INSIDE that capture: its launches have not run (and
+        never will if the capture was aborted) and its event belongs to the capture.  Outside it -- an eager forward after the
+        capture, another capture -- the entry is discarded: neither consumed nor waited for.  (Under graph REPLAY the prefetched
+        front reads the input buffers the capture saw: refill BOTH steps' buffers before a replay.)"""
+        pf = self._prefetched
+        return pf is not None and pf["cap"] != _native.capture_id(pf["dev"])
+
     def join_prefetch(self):
-        """The current stream waits for the prefetch branch (no-op without one)."""
-        if self._prefetched is not None and self._prefetched[2] is not None:
-            dev, ev = self._prefetched[2]
-            torch.cuda.current_stream(dev).wait_event(ev)
-            self._prefetched[2] = None
+        """The current stream waits for the prefetch branch (no-op without one, or when the branch belongs to another capture)."""
+        pf = self._prefetched
+        if pf is not None and pf["event"] is not None:
+            if not self._prefetch_is_foreign():
+                torch.cuda.current_stream(pf["dev"]).wait_event(pf["event"])
+            pf["event"] = None
 
     def drop_prefetch(self):
         """Forgets a prefetched front nobody consumed (its workspaces go back to the pools)."""
         if self._prefetched is None:
             return
         self.join_prefetch()
-        for net, h in zip(self.nets, self._prefetched[1]):
+        for net, h in zip(self.nets, self._prefetched["handles"]):
             net._pool.release(h["ws"])
         self._prefetched = None
 
@@ -234,15 +258,16 @@ class PointNetFeat(nn.Module):
         # fused front: grouping + compaction + BN1 of all four scales in ONE launch on the caller's stream, in front of the
         # fork (fcn_pn_group_compact); fused_front = False keeps the API-form grouping per scale (int64 idx, 5 nodes each)
         prepared = None
-        if self._prefetched is not None and self._prefetched[0] != self._front_key(point_cloud, sample_pc, one_hot_vec, nlc,
-                                                                                 self.training):
+        if self._prefetched is not None and (self._prefetch_is_foreign() or
+                                             self._prefetched["key"] != self._front_key(point_cloud, sample_pc, one_hot_vec, nlc,
+                                                                                        self.training)):
             self.drop_prefetch()
         if self.fused_front:
             from .pointnet_fused import group_compact, launch_prepared
             if self._prefetched is not None:
                 # the batch-only part ran ahead (prefetch): only the weight-dependent launch is left on the chain
                 self.join_prefetch()
-                prepared = self._prefetched[1]
+                prepared = self._prefetched["handles"]
                 self._prefetched = None
                 group_compact(prepared, point_cloud, phase=2)
             else:

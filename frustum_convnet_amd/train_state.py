@@ -281,7 +281,13 @@ class FlatTrainState:
                     if tuple(st[f].shape) != tuple(p.shape):
                         raise ValueError("optimizer state entry %s (%s): %s has shape %s, the parameter %s" % (
                             key, self.names[k], f, tuple(st[f].shape), tuple(p.shape)))
+                if self.optimizer != "sgd" and "step" not in st:
+                    raise ValueError("optimizer state entry of %s has no 'step'" % self.names[k])
             entries.append(st)
+        # (everything is validated here, before the first copy: a rejected state_dict leaves this optimiser untouched)
+        steps = set(int(float(st["step"])) for st in entries if st is not None and "step" in st) if self.optimizer != "sgd" else set()
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ (%s): the flat optimiser keeps one" % sorted(steps))
         if self.optimizer == "sgd":
             with torch.no_grad():
                 for st, p, o in zip(entries, self.params, self.offsets):
@@ -294,7 +300,6 @@ class FlatTrainState:
                 self.hyper[0:3].copy_(torch.tensor([group["lr"], group["momentum"], group["weight_decay"]],
                                                    dtype=torch.float32))
             return
-        steps = set()
         with torch.no_grad():
             for st, p, o in zip(entries, self.params, self.offsets):
                 n = p.numel()
@@ -304,11 +309,6 @@ class FlatTrainState:
                     continue
                 self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
                 self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
-                if "step" not in st:
-                    raise ValueError("optimizer state entry of %s has no 'step'" % self.names[self.offsets.index(o)])
-                steps.add(int(float(st["step"])))
-            if len(steps) > 1:
-                raise ValueError("per-parameter step counts differ (%s): the flat optimiser keeps one" % sorted(steps))
             self._step_slots.fill_(steps.pop() if steps else 0)          # every workgroup's slot
             b1, b2 = group["betas"]
             self.hyper[0:5].copy_(torch.tensor([group["lr"], b1, b2, group["eps"], group["weight_decay"]],

@@ -143,7 +143,8 @@ typedef struct fcn_pn_ws {
                                     by a pass that re-reads y3 (and in eval mode y3 is not written at all)                     */
     int32_t  partial_both;       /* 1: `partial` holds nsplit * (C3*C2 + C2*C1) floats, so the one-stream backward (fcn_pn_backward,
                                     fcn_pn_backward2 with stream2 == NULL) may run conv2's data gradient and both weight gradients as
-                                    roles of ONE launch; 0: they run one after the other through nsplit * max(C3*C2, C2*C1) floats */
+                                    roles of ONE launch; 0: they run one after the other through nsplit * max(C3*C2, C2*C1) floats.
+                                    Strictly 0 or 1 (anything else: FCN_E_BADARG) -- zero-initialise the struct */
 } fcn_pn_ws;
 
 /* Sticky numeric flags (fcn_pn_ws.flags, fcn_cn_ws.flags): the kernels only ever OR bits in.

@@ -90,3 +90,61 @@ def test_smoke_entry_under_emulation():
             entry.smoke()
         finally:
             torch.cuda.is_available = saved
+
+
+def test_prefetch_made_inside_a_capture_is_never_consumed_outside_it(monkeypatch):
+    """a front prefetched while a hipGraph is being captured exists only inside that capture (its launches may never have
+    run).  An eager forward on the same tensors, or another capture, must discard it -- not run phase 2 on workspaces nobody
+    filled -- and must not wait for its event; the same capture consumes it.  Also: the key covers what the prepared handles
+    froze (precision, parameter storage), so a change between prefetch() and forward() drops the prefetch."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from emu_shim import emulated_gpu
+    from frustum_convnet_amd import _native, synth, precision
+    import bench
+    with emulated_gpu():
+        dev = torch.device("cuda", 0)
+        torch.manual_seed(3)
+        model = bench.build_model(dev, "car")
+        model.train()
+        data = synth.to_torch(synth.make_batch(2, 256, seed=11, variant="car", tilt=(0.01, 0.05)), dev)
+        fn = model.feat_net
+        cap = [0]
+        monkeypatch.setattr(_native, "capture_id", lambda device=None: cap[0])
+
+        def run():
+            losses, _ = model(data)
+            return float(losses["total_loss"])
+
+        ref = run()                                        # plain step (the running statistics move; the loss of the SAME weights is compared below)
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+
+        def fresh():
+            model.load_state_dict(sd)
+
+        fresh(); base = run()
+        # 1. prefetched inside capture 7, consumed by an eager forward: dropped, the full front runs -> same loss
+        fresh(); cap[0] = 7
+        assert model.prefetch(data) and fn._prefetched is not None and fn._prefetched["cap"] == 7
+        cap[0] = 0
+        assert fn._prefetch_is_foreign()
+        waited = []
+        ev = fn._prefetched["event"]
+        assert run() == base and fn._prefetched is None
+        # 2. ... by ANOTHER capture: dropped as well
+        fresh(); cap[0] = 7; model.prefetch(data); cap[0] = 8
+        assert fn._prefetch_is_foreign() and run() == base
+        # 3. the same capture consumes it (phase 2 only): identical result
+        fresh(); cap[0] = 9; model.prefetch(data)
+        assert not fn._prefetch_is_foreign()
+        assert run() == base and fn._prefetched is None
+        cap[0] = 0
+        # 4. a precision change between prefetch and forward: the handles froze the old code -> dropped, not consumed
+        fresh(); model.prefetch(data)
+        key = fn._prefetched["key"]
+        with precision.precision("f32"):
+            xyz = data["point_cloud"][:, :3, :].contiguous()
+            refs = [data["center_ref%d" % i] for i in range(1, 5)]
+            assert fn._front_key(model._pf_xyz[1], refs, data["one_hot"], True, True) != key
+        fn.drop_prefetch()
+        assert fn._prefetched is None

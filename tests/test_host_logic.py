@@ -325,6 +325,17 @@ def test_optimizer_state_interchanges_with_torch_adam():
     bad["state"][0], bad["state"][3] = bad["state"][3], bad["state"][0]
     with pytest.raises(ValueError, match="shape"):
         st2.load_state_dict(bad)
+    # a LATER entry without its 'step' (or with another step count) is refused BEFORE the first copy -- the moments
+    # of the earlier entries stay what they were
+    last = max(sd["state"].keys())
+    for broken in ({k: v for k, v in sd["state"][last].items() if k != "step"}, dict(sd["state"][last], step=torch.tensor(5.0))):
+        bad2 = {"state": dict(sd["state"]), "param_groups": sd["param_groups"], "names": sd["names"]}
+        bad2["state"][last] = broken
+        st3 = FlatTrainState(det_base.PointNetDet(3, num_vec=3, num_classes=2), lr=1e-3)
+        st3.exp_avg.fill_(0.25)
+        with pytest.raises(ValueError, match="step"):
+            st3.load_state_dict(bad2)
+        assert float(st3.exp_avg.min()) == 0.25 and float(st3.exp_avg.max()) == 0.25
 
 
 def test_refine_builder_refuses_the_non_rtc_geometry():
