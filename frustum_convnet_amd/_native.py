@@ -72,7 +72,7 @@ class InpRefineDesc(ctypes.Structure):
 
 
 EXPORTS = ("fcn_arch", "fcn_build_hash", "fcn_stat_replicas", "fcn_query_depth_point_f32", "fcn_pn_wgrad_rows", "fcn_pn_compact", "fcn_pn_group_compact", "fcn_pn_group_compact2",
-           "fcn_pn_pack_weights", "fcn_pn_pack_weights_all", "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_backward3", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_det_loss_tail_rows2", "fcn_det_iou_metrics",
+           "fcn_pn_pack_weights", "fcn_pn_pack_weights_all", "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_backward3", "fcn_pn_backward_dense", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_det_loss_tail_rows2", "fcn_det_iou_metrics",
            "fcn_det_loss_tail_scratch_floats", "fcn_adam_step_f32", "fcn_sgd_step_f32", "fcn_adam_step_slots", "fcn_prepare_inputs", "fcn_prepare_inputs_refine", "fcn_prepare_inputs_sunrgbd", "fcn_stamp",
            "fcn_convnet_sizes", "fcn_convnet_logits_ld", "fcn_convnet_pack", "fcn_convnet_forward", "fcn_convnet_forward2",
            "fcn_convnet_backward", "fcn_box3d_iou_pair_f32", "fcn_decode_detections", "fcn_rotate_nms_3d")
@@ -138,6 +138,10 @@ def lib():
         L.fcn_pn_backward3.restype = ctypes.c_int
         L.fcn_pn_backward3.argtypes = [ctypes.POINTER(PnDesc), ctypes.POINTER(PnParams), c_fp,
                                        ctypes.POINTER(PnWs), c_fp * 3, c_fp * 3, c_fp * 3, c_fp, c_fp, c_fp, ctypes.POINTER(c_fp)]
+    if hasattr(L, "fcn_pn_backward_dense"):
+        L.fcn_pn_backward_dense.restype = ctypes.c_int
+        L.fcn_pn_backward_dense.argtypes = [ctypes.POINTER(PnDesc), ctypes.POINTER(PnParams), c_fp,
+                                            ctypes.POINTER(PnWs), c_fp * 3, c_fp * 3, c_fp * 3, c_fp]
     L.fcn_pn_conv_fwd.restype = ctypes.c_int
     L.fcn_pn_conv_fwd.argtypes = [ctypes.POINTER(PnDesc), ctypes.POINTER(PnParams), ctypes.POINTER(PnWs),
                                   ctypes.c_int, ctypes.c_int, c_fp]

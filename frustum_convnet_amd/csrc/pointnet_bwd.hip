@@ -181,9 +181,14 @@ struct DgradLds {
 
 // The body takes its workgroup index and LDS explicitly: dgrad_kernel below is the plain launch, pn_mid_kernel runs it as one
 // ROLE beside the two weight-gradient GEMMs of the same scale (they all depend on the layer-3 data-gradient launch only).
-template <int MM, int LAYER, int MT, int NT, int WN>
+// DZ3 (LAYER 3 only): the upstream gradient of layer 3 arrives DENSE, per entry row -- dzcur = dz3 (B,cap,C3), already masked by
+// the ReLU -- instead of routed through the max-pool's arg-max / gradient maps: the backward of the reference's un-pooled module
+// return (PointNetModule.forward, models/det_base.py:62-103; fcn_pn_backward_dense).
+template <int MM, int LAYER, int MT, int NT, int WN, int DZ3 = 0>
 __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, unsigned char *smem_)
 {
+    static_assert(!DZ3 || LAYER == 3, "DZ3 is a form of the layer-3 data gradient");
+    constexpr bool MAPS = LAYER == 3 && !DZ3;     // dz of layer 3 from the pooled maps
     constexpr int NTHR = 128 * WN;
     constexpr int TM = 64 * MT;               // rows of the tile
     constexpr int TN = 32 * NT * WN;
@@ -241,7 +246,7 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, un
         const int rc = min(f >> 3, nvalid - 1);
         arow[i] = ((int)grow0 + rc) * CRED + 4 * (f & 7);
         wbase[i] = 0;
-        if constexpr (LAYER == 3) wbase[i] = (b * a.L + a.ewin[grow0 + rc]) * CRED + 4 * (f & 7);
+        if constexpr (MAPS) wbase[i] = (b * a.L + a.ewin[grow0 + rc]) * CRED + 4 * (f & 7);
     }
     __syncthreads();
 
@@ -259,7 +264,7 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, un
         if (!((FCN_XB & 1) && (cc) > 0))                                                                              \
         _Pragma("unroll") for (int i = 0; i < NA4; ++i) {                                                             \
             ry[i] = lds4e<MM>(a.ycur, arow[i] + nq_);                                                                 \
-            if constexpr (LAYER == 3) {                                                                               \
+            if constexpr (MAPS) {                                                                                     \
                 rm[i] = ldg4i(a.amax + wbase[i] + nq_);                                                               \
                 rz[i] = ldg4(a.gmax + wbase[i] + nq_);                                                                \
             } else {                                                                                                  \
@@ -285,7 +290,7 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, un
             const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
             const float zv[4] = {rz[i].x, rz[i].y, rz[i].z, rz[i].w};
             int mv[4] = {0, 0, 0, 0};
-            if constexpr (LAYER == 3) { mv[0] = rm[i].x; mv[1] = rm[i].y; mv[2] = rm[i].z; mv[3] = rm[i].w; }
+            if constexpr (MAPS) { mv[0] = rm[i].x; mv[1] = rm[i].y; mv[2] = rm[i].z; mv[3] = rm[i].w; }
             const int nb = c * KC + 4 * kq;
             float cfv[5][4];
 #pragma unroll
@@ -297,7 +302,7 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, un
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float dz = zv[j];
-                if constexpr (LAYER == 3) dz = (mv[j] == rloc) ? zv[j] : 0.f;
+                if constexpr (MAPS) dz = (mv[j] == rloc) ? zv[j] : 0.f;
                 const float xh = (yv[j] - cfv[1][j]) * cfv[2][j];
                 const float dy = cfv[0][j] * (dz - w * fmaf(xh, cfv[4][j], cfv[3][j]));
                 dv[j] = ok ? dy : 0.f;
@@ -414,12 +419,12 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, un
               (unsigned long long)nvalid);
 }
 
-template <int MM, int LAYER, int MT, int NT, int WN>
+template <int MM, int LAYER, int MT, int NT, int WN, int DZ3 = 0>
 __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT * NT <= 2 ? (LAYER == 2 ? FCN_DG2_OCC : 3) : 2, 4)))
 void dgrad_kernel(DgradArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[DgradLds<MT, NT, WN>::BYTES];
-    dgrad_body<MM, LAYER, MT, NT, WN>(a, (int)blockIdx.x, smem);
+    dgrad_body<MM, LAYER, MT, NT, WN, DZ3>(a, (int)blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -804,7 +809,7 @@ __global__ void l1_finalize_kernel(const double *__restrict__ Qr, int rep_stride
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int LAYER>
+template <int LAYER, int DZ3 = 0>
 static int launch_dgrad(const DgradArgs &a, int B, int precision, hipStream_t st)
 {
     if (a.CRED % 64 || a.CPREV % 64 || a.CRED > MAXC) return FCN_E_BADARG;
@@ -821,10 +826,10 @@ static int launch_dgrad(const DgradArgs &a, int B, int precision, hipStream_t st
 #endif
     if (a.CPREV % 128 == 0) {          // 64 x 128 tiles, two workgroups per listed 128-row tile
         FCN_MM_SWITCH(FCN_MM_OF(precision, false),
-                      hipLaunchKernelGGL((dgrad_kernel<MM, LAYER, 1, 2, 2>), dim3((2 * nt * (a.CPREV / 128) + 7) / 8 * 8), dim3(256), 0, st, a));
+                      hipLaunchKernelGGL((dgrad_kernel<MM, LAYER, 1, 2, 2, DZ3>), dim3((2 * nt * (a.CPREV / 128) + 7) / 8 * 8), dim3(256), 0, st, a));
     } else {                            // 64 x 64 tiles (the 64-channel layers of scales 1 and 2: few column tiles)
         FCN_MM_SWITCH(FCN_MM_OF(precision, false),
-                      hipLaunchKernelGGL((dgrad_kernel<MM, LAYER, 1, 1, 2>), dim3((2 * nt * (a.CPREV / 64) + 7) / 8 * 8), dim3(256), 0, st, a));
+                      hipLaunchKernelGGL((dgrad_kernel<MM, LAYER, 1, 1, 2, DZ3>), dim3((2 * nt * (a.CPREV / 64) + 7) / 8 * 8), dim3(256), 0, st, a));
     }
     FCN_CHECK_LAUNCH();
     return 0;
@@ -947,7 +952,18 @@ extern "C" int fcn_pn_backward(const fcn_pn_desc *d, const fcn_pn_params *p, con
 // chain poolbwd -> dgrad3 -> dgrad2 -> l1_finalize.  events: 3 caller-owned hipEvent_t (fork, fork, join).
 static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dfeat, const fcn_pn_ws *ws,
                             float *dW[3], float *dgamma[3], float *dbeta[3], void *stream, void *stream2, void *stream3,
-                            void *const *events);
+                            void *const *events, const float *dz3_dense = nullptr);
+
+// Backward of the UN-POOLED module output (PointNetModule.forward's (B, C3, L, K) return, models/det_base.py:62-103): dz3 (B,cap,C3)
+// is the gradient w.r.t. relu(bn3(y3)) of every ENTRY row -- the K slots of a window summed back onto its rows (the first hit
+// collects its K - ne + 1 duplicates), times the ReLU mask -- and ws->bstat replica 0 holds sum dz3 [C3], sum dz3 * xhat3 [C3]
+// (the other replicas zero), both prepared by the caller.  Everything behind that is the pooled backward's chain.
+extern "C" int fcn_pn_backward_dense(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dz3, const fcn_pn_ws *ws,
+                                     float *dW[3], float *dgamma[3], float *dbeta[3], void *stream)
+{
+    if (!dz3) return FCN_E_BADARG;
+    return pn_backward_impl(d, p, dz3, ws, dW, dgamma, dbeta, stream, nullptr, nullptr, nullptr, dz3);
+}
 
 extern "C" int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dfeat,
                                 const fcn_pn_ws *ws, float *dW[3], float *dgamma[3], float *dbeta[3],
@@ -971,7 +987,7 @@ extern "C" int fcn_pn_backward3(const fcn_pn_desc *d, const fcn_pn_params *p, co
 
 static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dfeat, const fcn_pn_ws *ws,
                             float *dW[3], float *dgamma[3], float *dbeta[3], void *stream, void *stream2, void *stream3,
-                            void *const *events)
+                            void *const *events, const float *dz3_dense)
 {
     if (!d || !p || !ws || !dfeat || !dW || !dgamma || !dbeta) return FCN_E_BADARG;
     if (!d->training || !ws->wenc) return FCN_E_BADARG;
@@ -996,7 +1012,9 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
 
     hipError_t e = hipSuccess;          // ws->bstat was zeroed by the pool kernel of this scale's forward
 
-    if (d->precision == FCN_PREC_BF16)       // y3 stored as bf16 (gemm_tile.h: St)
+    if (dz3_dense) {
+        if (!ws->dy3 || d->precision == FCN_PREC_BF16) return FCN_E_BADARG;      // (dz3 is fp32 rows; the dense form keeps dy3 materialised)
+    } else if (d->precision == FCN_PREC_BF16)       // y3 stored as bf16 (gemm_tile.h: St)
         hipLaunchKernelGGL(poolbwd_kernel<1>, dim3((L + PWB - 1) / PWB, C3 / 64, B), dim3(GT), 0, st, dfeat, ws->amax,
                            ws->y3, bn3, ws->gmax, bs3, brs, L, cap, C3, C3 + d->nvec, d->nlc);
     else
@@ -1013,7 +1031,12 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
 #if FCN_XB & 512       // (timing build: the cost of a2 . G instead of dy3 . W3 -- reduction over C2, the A operand read from y2)
     g.ycur = ws->y2; g.CRED = C2;
 #endif
-    FCN_TRY(launch_dgrad<3>(g, B, d->precision, st));
+    if (dz3_dense) {
+        g.dzcur = dz3_dense; g.amax = nullptr; g.gmax = nullptr;
+        FCN_TRY((launch_dgrad<3, 1>(g, B, d->precision, st)));
+    } else {
+        FCN_TRY(launch_dgrad<3>(g, B, d->precision, st));
+    }
 
     WgradArgs w;
     w.ent = (const float4 *)ws->ent; w.woff = ws->woff; w.tiles = ws->tiles; w.L = L; w.cap = cap; w.tps = tps;

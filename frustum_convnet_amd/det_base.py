@@ -106,17 +106,20 @@ class PointNetModule(nn.Module):
         return (cfgt, _precision.code(), tuple(t.data_ptr() for t in params), tuple(t.data_ptr() for b in bufs for t in b))
 
     def forward(self, pc, feat, new_pc=None):
-        """Reference-shaped output (B, C3, L, nsample), masked.  Inspection / parity API: it expands the
-        fused path's per-entry activations back to the dense slots with device-side indexing and carries
-        no autograd graph -- training goes through forward_pooled (PointNetFeat does that)."""
-        from .pointnet_fused import dense_from_entries
+        """Reference-shaped output (B, C3, L, nsample), masked (models/det_base.py:62-103), expanded from the fused path's per-entry
+        activations with device-side indexing.  With gradients enabled (training mode, a parameter that requires them) the
+        return carries its graph, as the reference's does: the backward sums the slots back onto the entry rows and runs the
+        HIP backward chain (pointnet_fused.dense_pointnet).  Training inside PointNetDet goes through forward_pooled, which never
+        materialises the K slots."""
+        from .pointnet_fused import dense_from_entries, dense_pointnet
         params, bufs = self._param_pack()
         bn = self.conv1[1]
-        if torch.is_grad_enabled() and (pc.requires_grad or any(p.requires_grad for p in params)):
-            # models/det_base.py:62-103 returns a tensor with a graph; this dense view has none -- refuse rather than hand a
-            # caller that trains through the module API silently-missing gradients
-            raise RuntimeError("PointNetModule.forward is an inspection API without autograd: call it under torch.no_grad() "
-                               "(training goes through forward_pooled / PointNetFeat, which are differentiable)")
+        if pc.requires_grad and torch.is_grad_enabled():
+            raise RuntimeError("PointNetModule.forward: no gradient w.r.t. the point cloud (the reference never asks for one either: "
+                               "its inputs do not require grad)")
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return dense_pointnet(self._pool, self.dist, self.nsample, True, bn.eps, bn_momentum(bn),
+                                  pc.contiguous(), new_pc.contiguous(), bufs, params)
         with torch.no_grad():
             return dense_from_entries(self._pool, self.dist, self.nsample, self.training, bn.eps,
                                       bn_momentum(bn),

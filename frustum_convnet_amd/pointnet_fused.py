@@ -349,23 +349,99 @@ def pointnet_pooled(pool, dist, nsample, training, eps, momentum, pc, ref, one_h
     return _PointNetPooled.apply(pool, cfgt, pc, ref, one_hot, bufs, gdst, None, *params)
 
 
-def dense_from_entries(pool, dist, nsample, training, eps, momentum, pc, ref, bufs, params):
-    """Reference-shaped (B, C3, L, K) masked activations of one scale (PointNetModule.forward's return,
-    models/det_base.py:103), expanded from the per-entry conv3 output of the HIP forward: slot k of window
-    l maps to row woff[l] + (k < ne ? k : 0).  Device-side indexing only; no autograd graph."""
-    if not pc.is_cuda:
-        raise RuntimeError("frustum_convnet_amd: MI355X only; no CPU fallback")
-    cfgt = (float(dist), int(nsample), bool(training), float(eps), float(momentum))
-    feat, idx, cnt, ws, desc, _ = _forward_impl(pool, cfgt, pc, ref, None, bufs, params, False)
+def _dense_view(ws, desc, cnt, dev):
+    """(rows (B, L*K) int64: the entry row behind every slot -- slot k of window l maps to row woff[l] + (k < ne ? k : 0) --,
+    a3 (B, cap, C3) = relu(bn3(y3)) of the entry rows, window mask (B, L)) of a finished forward."""
     B, L, K, C1, C2, C3 = desc.B, desc.L, desc.K, desc.C1, desc.C2, desc.C3
     off3 = 4 * (C1 + C2)
     s3, t3 = ws.bn[off3:off3 + C3], ws.bn[off3 + C3:off3 + 2 * C3]
     ne = cnt.clamp(min=1).long()
-    k = torch.arange(K, device=pc.device).view(1, 1, K)
+    k = torch.arange(K, device=dev).view(1, 1, K)
     rows = ws.woff[:, :L].long().unsqueeze(2) + torch.where(k < ne.unsqueeze(2), k, torch.zeros_like(k))
-    y3 = ws.stored(ws.y3, desc.precision)
-    y = torch.gather(y3, 1, rows.view(B, L * K, 1).expand(-1, -1, C3)).view(B, L, K, C3)
-    a = torch.relu(y * s3 + t3) * (cnt > 0).view(B, L, 1, 1).float()
+    a3 = torch.relu(ws.stored(ws.y3, desc.precision) * s3 + t3)
+    return rows.view(B, L * K), a3, (cnt > 0)
+
+
+def dense_from_entries(pool, dist, nsample, training, eps, momentum, pc, ref, bufs, params):
+    """Reference-shaped (B, C3, L, K) masked activations of one scale (PointNetModule.forward's return,
+    models/det_base.py:103), expanded from the per-entry conv3 output of the HIP forward.  Device-side indexing only; no
+    autograd graph (dense_pointnet() is the differentiable form)."""
+    if not pc.is_cuda:
+        raise RuntimeError("frustum_convnet_amd: MI355X only; no CPU fallback")
+    cfgt = (float(dist), int(nsample), bool(training), float(eps), float(momentum))
+    feat, idx, cnt, ws, desc, _ = _forward_impl(pool, cfgt, pc, ref, None, bufs, params, False)
+    B, L, K, C3 = desc.B, desc.L, desc.K, desc.C3
+    rows, a3, live = _dense_view(ws, desc, cnt, pc.device)
+    a = torch.gather(a3, 1, rows.unsqueeze(2).expand(-1, -1, C3)).view(B, L, K, C3) * live.view(B, L, 1, 1).float()
     out = a.permute(0, 3, 1, 2).contiguous()
     pool.release(ws)
     return out
+
+
+class _PointNetDense(torch.autograd.Function):
+    """PointNetModule.forward WITH its graph (models/det_base.py:62-103 returns a differentiable (B, C3, L, nsample) tensor): the
+    forward is the entry-space HIP forward expanded to the dense slots; the backward sums the K slots of every window back onto
+    its entry rows (the first hit collects its K - ne + 1 duplicates), applies the window and ReLU masks and hands the per-entry
+    gradient to the HIP backward chain (fcn_pn_backward_dense: BatchNorm backward with multiplicities, both weight-gradient
+    GEMMs, conv1 from its moments).  Differentiable w.r.t. the 9 parameter tensors."""
+
+    @staticmethod
+    def forward(ctx, pool, cfgt, pc, ref, bufs, *plist):
+        feat, idx, cnt, ws, desc, keep = _forward_impl(pool, cfgt, pc, ref, None, bufs, plist, True)
+        B, L, K, C3 = desc.B, desc.L, desc.K, desc.C3
+        rows, a3, live = _dense_view(ws, desc, cnt, pc.device)
+        a = torch.gather(a3, 1, rows.unsqueeze(2).expand(-1, -1, C3)).view(B, L, K, C3) * live.view(B, L, 1, 1).float()
+        ctx.pool, ctx.ws, ctx.desc, ctx.keep = pool, ws, desc, keep
+        ctx.rows, ctx.live = rows, live
+        ctx.pos = a3 > 0
+        ctx.shapes = tuple(t.shape for t in plist)
+        return a.permute(0, 3, 1, 2).contiguous()
+
+    @staticmethod
+    def backward(ctx, dout):
+        L_ = _native.lib()
+        ws, desc = ctx.ws, ctx.desc
+        if ws is None:
+            raise RuntimeError("the dense PointNet module's backward ran twice (its workspace is released after the first)")
+        Wc, gs, bs = ctx.keep[0], ctx.keep[1], ctx.keep[2]
+        B, L, K, C1, C2, C3 = desc.B, desc.L, desc.K, desc.C1, desc.C2, desc.C3
+        cap, dev = L * K, dout.device
+        # (B, C3, L, K) -> slots (B, L*K, C3), empty windows masked, summed onto the entry rows, ReLU mask
+        g = (dout.float() * ctx.live.view(B, 1, L, 1).float()).permute(0, 2, 3, 1).reshape(B, L * K, C3)
+        dz3 = torch.zeros((B, cap, C3), dtype=torch.float32, device=dev)
+        dz3.scatter_add_(1, ctx.rows.unsqueeze(2).expand(-1, -1, C3), g)
+        dz3 = torch.where(ctx.pos, dz3, torch.zeros_like(dz3)).contiguous()
+        # the BatchNorm-backward sums of layer 3 (fcn_pn_ws.bstat, replica 0; the forward left the buffer zeroed)
+        bn = ws.bn
+        off3 = 4 * (C1 + C2)
+        mean3, rstd3 = bn[off3 + 2 * C3:off3 + 3 * C3].double(), bn[off3 + 3 * C3:off3 + 4 * C3].double()
+        y3 = ws.stored(ws.y3, desc.precision)
+        d64 = dz3.double()
+        ws.bstat.zero_()
+        ws.bstat[:C3] = d64.sum(dim=(0, 1))
+        # (rows past a frustum's live entries hold whatever the allocator left: dz3 is zero there, the product must be too)
+        ws.bstat[C3:2 * C3] = torch.where(dz3 != 0, d64 * ((y3.double() - mean3) * rstd3), torch.zeros_like(d64)).sum(dim=(0, 1))
+        dW = [torch.empty_like(w) for w in Wc]
+        dg = [torch.empty_like(t) for t in gs]
+        db = [torch.empty_like(t) for t in bs]
+        params = _params_struct(Wc, gs, bs, [None] * 3, [None] * 3, [None] * 3)
+        arr = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
+        with torch.cuda.device(dev):
+            _native.check(L_.fcn_pn_backward_dense(ctypes.byref(desc), ctypes.byref(params), dz3.data_ptr(), ctypes.byref(ws.c),
+                                                   arr(dW), arr(dg), arr(db), _native.current_stream(dev)), "fcn_pn_backward_dense")
+        dz3.record_stream(torch.cuda.current_stream(dev))
+        ctx.pool.release(ws)
+        ctx.ws = None
+        outs = []
+        for i in range(3):
+            outs += [dW[i].view(ctx.shapes[3 * i]), dg[i], db[i]]
+        return (None, None, None, None, None) + tuple(outs)
+
+
+def dense_pointnet(pool, dist, nsample, training, eps, momentum, pc, ref, bufs, params):
+    """Differentiable PointNetModule.forward: (B, C3, L, K) masked activations carrying a graph to the 9 parameter tensors."""
+    _check_device(pc)
+    if os.environ.get("FCN_STORE_DY3", "1") == "0":
+        raise RuntimeError("the differentiable dense module API needs the dy3 buffer (unset FCN_STORE_DY3=0)")
+    cfgt = _cfg_tuple(dist, nsample, training, eps, momentum, params, False)
+    return _PointNetDense.apply(pool, cfgt, pc, ref, bufs, *params)

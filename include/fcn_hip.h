@@ -209,6 +209,14 @@ int fcn_pn_backward2(const fcn_pn_desc *d, const fcn_pn_params *p, const float *
                      const fcn_pn_ws *ws, float *dW[3], float *dgamma[3], float *dbeta[3],
                      void *stream, void *stream2, void *const *events);
 
+/* Backward of the UN-POOLED module output -- PointNetModule.forward's (B, C3, L, nsample) return, models/det_base.py:62-103, whose
+ * autograd the reference gets from torch.  dz3 (B, cap, C3) fp32: the gradient w.r.t. relu(bn3(y3)) of every ENTRY row (the K
+ * slots of a window summed back onto its rows -- the first hit collects its K - ne + 1 duplicates --, the (cnt > 0) mask and the
+ * ReLU mask applied); ws->bstat: replica 0 = sum dz3 [C3], sum dz3 * xhat3 [C3], everything else zero (the caller prepares both:
+ * frustum_convnet_amd/pointnet_fused.py does it with device-side indexing).  One stream; needs ws->dy3; not in FCN_PREC_BF16. */
+int fcn_pn_backward_dense(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dz3,
+                          const fcn_pn_ws *ws, float *dW[3], float *dgamma[3], float *dbeta[3], void *stream);
+
 /* Three-way split: after the first data-gradient GEMM the chain continues on `stream` (dgrad of conv2, layer-1 finalisation),
  * conv3's weight gradient runs on stream2 and conv2's on stream3.  ws.partial must hold BOTH weight gradients' partials at once:
  * nsplit * (C3*C2 + C2*C1) floats.  events = 4 caller-owned hipEvent_t. */
