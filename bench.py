@@ -355,10 +355,13 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
     state = FlatTrainState(model, lr=1e-3, weight_decay=1e-4, world=world)
     optim = not a.no_optim
     data = make_data(cfg_name, batch, npoint, 1234 + rank, dev)
-    overlap = world > 1 and not a.no_overlap and not a.eager
+    # FCN_BENCH_SPLIT_STEP=1: the N > 1 form of the step (three graphs, Adam at the head of the first, the all-reduce calls -- no-ops
+    # in a world of one) with ONE rank: what a rank's step costs on this box without its collectives, beside the N = 1 line
+    overlap = (world > 1 or os.environ.get("FCN_BENCH_SPLIT_STEP", "0") == "1") and not a.no_overlap and not a.eager
     model.split_backward = overlap
 
-    prefetch = os.environ.get("FCN_PREFETCH", "1") != "0" and world == 1 and optim
+    prefetch = os.environ.get("FCN_PREFETCH", "1") != "0" and optim and (world == 1 or (overlap and use_graph_requested(a)))
+    skip_comm = world > 1 and os.environ.get("FCN_SKIP_COMM", "0") == "1"      # rehearsal: the step without its collectives
     steps_per_graph = 1
 
     pf_point = os.environ.get("FCN_PF_POINT", "fcn_fwd")
@@ -396,26 +399,53 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
                 torch.cuda.synchronize()
             mode = "thread_local" if world > 1 else "global"   # RCCL's watchdog thread may query events meanwhile
             if overlap:
-                # N > 1: two graphs cut where the FCN gradients are final.  Replay A (forward, loss, FCN backward) -> start
-                # the all-reduce of the [FCN + heads] bucket on RCCL's stream -> replay B (PointNet backward) beside it ->
-                # all-reduce the PointNet bucket -> join -> Adam.
-                # ... and the PointNet backward itself in two: the wide scales first (their ~1 MB of gradients start their all-reduce
-                # while the narrow scales run), then the narrow ones (~0.1 MB: all that is left exposed behind the backward)
-                gA, gB, gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                # N > 1: the step is THREE graphs cut where gradients become final, so that each piece's all-reduce starts on the
+                # communication stream while the next graph runs: A = [Adam of the PREVIOUS step's (reduced) gradients, forward, loss,
+                # FCN + heads backward] -> all-reduce [FCN + heads] -> B = [PointNet backward of the wide scales] -> all-reduce them ->
+                # C = [the narrow scales] -> all-reduce them (~0.1 MB: all that is left exposed).  The optimiser step rides at the head
+                # of the next A (behind a stream-side wait for the three all-reduces), not as a launch of its own; with the prefetch the
+                # graphs exist twice (even / odd workspace set), as the two steps of the N = 1 graph do -- so a rank's step is the same
+                # work in the same order as the N = 1 step, plus two graph launches and the collectives.
+                from frustum_convnet_amd.loss_fused import unit_grad
                 ns = model.feat_net.num_scales
                 wide, narrow = list(range(ns // 2, ns)), list(range(ns // 2))
-                with torch.cuda.graph(gA, capture_error_mode=mode):
-                    losses, _ = model(data)
-                    loss = losses["total_loss"]
-                    pending = model.take_split()
-                    from frustum_convnet_amd.loss_fused import unit_grad
-                    loss.backward(gradient=unit_grad(loss.device))
-                    model._iou_metrics.join()        # (deferred join: the side branch must end inside this capture)
-                with torch.cuda.graph(gB, pool=gA.pool(), capture_error_mode=mode):
-                    pending.backward(scales=wide)
-                with torch.cuda.graph(gC, pool=gA.pool(), capture_error_mode=mode):
-                    pending.backward(scales=narrow)
-                graphs = (gA, gB, gC)
+                if os.environ.get("FCN_BENCH_PIECES", "3") == "2":      # (A/B: the PointNet backward as ONE graph, its 1.1 MB exchanged behind it)
+                    wide, narrow = list(range(ns)), []
+                nset = 2 if prefetch else 1
+                # (the eager warm-up ended with an optimiser step; the graphs' steps BEGIN with one: one more backward first, so
+                # that every gradient is applied exactly once)
+                with torch.cuda.stream(side):
+                    fwd_bwd()
+                    if not skip_comm:
+                        state.allreduce()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                glist, pool = [], None
+                for k in range(nset):
+                    gA, gB, gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gA, pool=pool, capture_error_mode=mode):
+                        # the front prefetched by the previous graph A of the cycle (for k = 0: by the step in front of the capture,
+                        # whose place the last graph A of the cycle takes in every replay) -- into the workspace set this step reads
+                        model.feat_net.adopt_prefetch()
+                        if optim:
+                            state.adam_step()
+                        if prefetch:
+                            model.next_batch = data
+                        losses, _ = model(data)
+                        loss = losses["total_loss"]
+                        pending = model.take_split()
+                        loss.backward(gradient=unit_grad(loss.device))
+                        model._join_side()               # (the IoU-metrics and prefetch branches end inside this capture)
+                    pool = gA.pool()
+                    with torch.cuda.graph(gB, pool=pool, capture_error_mode=mode):
+                        pending.backward(scales=wide)
+                    if narrow:
+                        with torch.cuda.graph(gC, pool=pool, capture_error_mode=mode):
+                            pending.backward(scales=narrow)
+                    else:
+                        gC = None
+                    glist.append((gA, gB, gC))
+                graphs = tuple(glist)
                 split_scales = (wide, narrow)
             else:
                 # with the prefetch a step consumes the front its predecessor prepared in the OTHER workspace set: the captured
@@ -424,6 +454,8 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
                 glist = []
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode=mode):
+                    # (the warm-up's last step prefetched this step's front, as the graph's last step does in every replay)
+                    model.feat_net.adopt_prefetch()
                     for _ in range(spg if prefetch else 1):
                         loss = fwd_bwd()
                         if world == 1 and optim:
@@ -453,16 +485,20 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
             state.allreduce()
             if optim:
                 state.adam_step()
-        elif len(graphs) == 3:
-            graphs[0].replay()
-            state.allreduce_bucket_async(0)          # [FCN + heads]: final after graph A
-            graphs[1].replay()
-            state.allreduce_scales_async(split_scales[0])      # the wide PointNet scales: final after graph B
-            graphs[2].replay()
-            state.allreduce_scales_async(split_scales[1])      # the narrow ones
-            state.wait_allreduce()
-            if optim:
-                state.adam_step()
+        elif overlap:
+            gA, gB, gC = graphs[parity[0] % len(graphs)]
+            parity[0] += 1
+            state.wait_allreduce()                   # the previous step's three pieces (a stream-side wait): graph A begins with Adam
+            gA.replay()
+            if not skip_comm:
+                state.allreduce_bucket_async(0)      # [FCN + heads]: final after graph A
+            gB.replay()
+            if not skip_comm:
+                state.allreduce_scales_async(split_scales[0])      # the wide PointNet scales: final after graph B
+            if gC is not None:
+                gC.replay()
+                if not skip_comm:
+                    state.allreduce_scales_async(split_scales[1])      # the narrow ones
         else:
             if parity[0] % steps_per_graph == 0:
                 graphs[0][0].replay()
@@ -472,6 +508,8 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
                 if optim:
                     state.adam_step()
 
+    if overlap and graphs is not None:
+        steps_per_graph = len(graphs)                # (whole even / odd cycles)
     even = lambda n: ((n + steps_per_graph - 1) // steps_per_graph) * steps_per_graph       # a replay holds whole steps
     for _ in range(even(warmup)):
         step()
@@ -494,6 +532,7 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
     e0.record()
     for _ in range(even(rounds * steps)):
         step()
+    state.wait_allreduce()                           # (N > 1: the last step's collectives belong to the timed region)
     e1.record()
     torch.cuda.synchronize()
     if world > 1:
@@ -512,12 +551,15 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
         # ones) and the time of each bucket's all-reduce alone (events on the current stream around a blocking call)
         ones = torch.ones(1, device=dev)
         torch.distributed.all_reduce(ones)
-        comm = {"backend": torch.distributed.get_backend(), "ranks": int(round(float(ones.item()))), "buckets": []}
+        comm = {"backend": torch.distributed.get_backend(), "ranks": int(round(float(ones.item()))), "buckets": [],
+                "skipped_in_timed_region": bool(skip_comm)}
+        if comm["ranks"] != world:
+            raise SystemExit("the process group has %d ranks, WORLD_SIZE says %d" % (comm["ranks"], world))
         pieces = list(state.buckets)
         if split_scales is not None:        # the pieces the overlapped step really exchanges
             sr = state.scale_ranges
             pieces = [state.buckets[0]] + [("pointnet scales %s" % "+".join(str(k + 1) for k in ks), sr[ks[0]][0], sr[ks[-1]][1])
-                                           for ks in split_scales]
+                                           for ks in split_scales if ks]
         for name, lo, hi in pieces:
             buf = torch.zeros(hi - lo, device=dev)
             for _ in range(2):
@@ -536,6 +578,10 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
             "gpu_event_ms_per_step": e0.elapsed_time(e1) / nstep, "final_loss": float(loss.item()),
             "steps_per_graph": steps_per_graph, "prefetch": prefetch,
             "batch": batch, "npoint": npoint, "Ls": Ls}
+
+
+def use_graph_requested(a):
+    return not a.eager
 
 
 def workload_name(cfg_name, batch, npoint, Ls, optim=True, extra=""):
@@ -663,17 +709,23 @@ def main():
         "config": {"workload": "%s KITTI-%s, batch=%d/GPU, Npoint=%d, L=(%s), train fwd+bwd%s%s" % (
                        CFGS[a.cfg][0], a.cfg, a.batch, npoint, ",".join(str(v) for v in Ls),
                        "" if a.no_optim else "+Adam",
-                       ("+RCCL grad all-reduce (%s)" % ("3 pieces overlapped with the backward: [FCN + heads] beside the PointNet backward, the wide scales beside the narrow ones" if overlap else
-                                                        "one call after the backward")) if world > 1 else ""),
+                       ("+%s grad all-reduce (%s)" % (
+                           {"nccl": "RCCL", "gloo": "gloo (CPU transport: a rehearsal of the code path, not of xGMI)"}.get(
+                               m["comm"]["backend"], m["comm"]["backend"]) + (", SKIPPED in the timed region" if m["comm"]["skipped_in_timed_region"] else ""),
+                           "3 pieces overlapped with the backward: [FCN + heads] beside the PointNet backward, the wide scales beside the narrow ones" if overlap else
+                           "one call after the backward")) if world > 1 else ""),
                    "global_batch": a.batch * world, "parallelism": "dp%d" % world,
-                   "launch": (("hipGraph replay x%d" % len(graphs)) + (", %d steps per replay" % m["steps_per_graph"] if m["steps_per_graph"] > 1 else "")
+                   "launch": ((("hipGraph replay x%d per step (Adam at the head of the first), %d workspace sets" % (3 if graphs[0][2] is not None else 2, len(graphs))) if overlap else
+                               ("hipGraph replay x%d" % len(graphs)) + (", %d steps per replay" % m["steps_per_graph"] if m["steps_per_graph"] > 1 else ""))
                               if graphs is not None else "eager") +
                              (", next batch's grouping front prefetched beside the backward (double-buffered workspaces)" if m["prefetch"] else "")},
         "gpu_event_ms_per_step": round(gpu_event_ms, 4),
         "final_loss": round(final_loss, 5),
     }
     if m.get("comm"):
-        out["rccl_ranks"] = m["comm"]["ranks"]
+        out["comm_ranks"] = m["comm"]["ranks"]
+        if m["comm"]["backend"] == "nccl":
+            out["rccl_ranks"] = m["comm"]["ranks"]   # (only a communicator that IS RCCL is reported under that name)
         out["comm"] = m["comm"]
     if world == 1 and not a.no_roofline:
         try:

@@ -214,6 +214,15 @@ class PointNetFeat(nn.Module):
         pf = self._prefetched
         return pf is not None and pf["cap"] != _native.capture_id(pf["dev"])
 
+    def adopt_prefetch(self):
+        """For a step that is SEVERAL graphs replayed in a fixed order: a prefetch made inside an earlier graph of the cycle is
+        handed to the capture now in progress.  The caller guarantees that every replay of this graph follows a replay of that one
+        on the same stream (so the branch has run; no event crosses the two captures)."""
+        pf = self._prefetched
+        if pf is not None:
+            pf["cap"] = _native.capture_id(pf["dev"])
+            pf["event"] = None
+
     def join_prefetch(self):
         """The current stream waits for the prefetch branch (no-op without one, or when the branch belongs to another capture)."""
         pf = self._prefetched

@@ -101,6 +101,98 @@ def _worker_graphs_one_gpu(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_cycle_one_gpu(rank, world, port, q):
+    """bench.py's round-5 form of the N > 1 step on one GPU over gloo: a prime backward, then the even / odd cycle of
+    [wait for the previous exchange; graph A = Adam + forward (prefetching the next front) + loss + FCN backward; exchange;
+    graph B = wide scales; exchange; graph C = narrow scales; exchange] -- against the plain eager loop
+    [forward, backward, all-reduce, Adam] on a second model: the same parameters, bit for bit, on both ranks."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from frustum_convnet_amd import dist as fdist, synth
+    from frustum_convnet_amd.train_state import FlatTrainState
+    from frustum_convnet_amd.loss_fused import unit_grad
+    from helpers import load_golden, golden_inputs
+    from test_gpu_model import _model
+    torch.cuda.set_device(0)
+    fdist.init_from_env(backend="gloo")
+    g = load_golden("car_b4_n512")
+    full = golden_inputs(g)
+    data = synth.to_torch({k: v[rank * 2:(rank + 1) * 2] for k, v in full.items()}, "cuda")
+    NSTEP = 4
+
+    def make():
+        m = _model(g)
+        m.train()
+        fdist.broadcast_state(m, 0)
+        return m, FlatTrainState(m, lr=1e-4, weight_decay=1e-4, world=world)
+
+    # reference: eager steps, one exchange after each backward
+    m0, st0 = make()
+    for it in range(NSTEP + 1):
+        lo, _ = m0(data)
+        m0.backward(lo["total_loss"])
+        st0.allreduce()
+        if it < NSTEP:
+            st0.adam_step()
+    torch.cuda.synchronize()
+    want = st0.flat.clone()
+    # the cycle
+    m, st = make()
+    m.split_backward = True
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                      # prime: one backward + exchange, no optimiser step
+        m.next_batch = data
+        lo, _ = m(data)
+        m.backward(lo["total_loss"])
+        st.allreduce()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    dist.barrier()
+    sets, pool = [], None
+    for k in range(2):
+        gA, gB, gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gA, pool=pool, capture_error_mode="thread_local"):
+            m.feat_net.adopt_prefetch()
+            st.adam_step()
+            m.next_batch = data
+            lo, _ = m(data)
+            pending = m.take_split()
+            lo["total_loss"].backward(gradient=unit_grad(lo["total_loss"].device))
+            m._join_side()
+        pool = gA.pool()
+        with torch.cuda.graph(gB, pool=pool, capture_error_mode="thread_local"):
+            pending.backward(scales=[2, 3])
+        with torch.cuda.graph(gC, pool=pool, capture_error_mode="thread_local"):
+            pending.backward(scales=[0, 1])
+        sets.append((gA, gB, gC))
+    for it in range(NSTEP):
+        gA, gB, gC = sets[it % 2]
+        st.wait_allreduce()
+        gA.replay()
+        st.allreduce_bucket_async(0)
+        gB.replay()
+        st.allreduce_scales_async([2, 3])
+        gC.replay()
+        st.allreduce_scales_async([0, 1])
+    st.wait_allreduce()
+    torch.cuda.synchronize()
+    flats = [torch.zeros_like(st.flat) for _ in range(world)]
+    dist.all_gather(flats, st.flat)
+    q.put((rank, bool(torch.equal(flats[0], flats[1])), bool(torch.equal(st.flat, want)),
+           float((st.flat - want).abs().max()), bool(torch.equal(st.grad, st0.grad))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_even_odd_cycle_with_adam_at_the_head_matches_eager_steps():
+    got = _run(_worker_cycle_one_gpu)
+    assert all(g[1] and g[2] and g[4] for g in got), got
+
+
 def _run(worker, world=2, timeout=600):
     import torch.multiprocessing as mp
     port = _free_port()
