@@ -71,7 +71,7 @@ class InpRefineDesc(ctypes.Structure):
                 ("stride", ctypes.c_double * 4), ("random_flip", ctypes.c_int32), ("random_shift", ctypes.c_int32)]
 
 
-EXPORTS = ("fcn_arch", "fcn_build_hash", "fcn_stat_replicas", "fcn_query_depth_point_f32", "fcn_pn_wgrad_rows", "fcn_pn_compact", "fcn_pn_group_compact", "fcn_pn_group_compact2",
+EXPORTS = ("fcn_arch", "fcn_build_hash", "fcn_stat_replicas", "fcn_query_depth_point_f32", "fcn_query_depth_point_multi_f32", "fcn_pn_wgrad_rows", "fcn_pn_compact", "fcn_pn_group_compact", "fcn_pn_group_compact2",
            "fcn_pn_pack_weights", "fcn_pn_pack_weights_all", "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_backward3", "fcn_pn_backward_dense", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_det_loss_tail_rows2", "fcn_det_iou_metrics",
            "fcn_det_loss_tail_scratch_floats", "fcn_adam_step_f32", "fcn_sgd_step_f32", "fcn_adam_step_slots", "fcn_prepare_inputs", "fcn_prepare_inputs_refine", "fcn_prepare_inputs_sunrgbd", "fcn_stamp",
            "fcn_convnet_sizes", "fcn_convnet_logits_ld", "fcn_convnet_pack", "fcn_convnet_forward", "fcn_convnet_forward2",
@@ -114,6 +114,10 @@ def lib():
     L.fcn_query_depth_point_f32.argtypes = [
         c_fp, ctypes.c_int64, ctypes.c_int64, c_fp, ctypes.c_int64, ctypes.c_int64,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp]
+    if hasattr(L, "fcn_query_depth_point_multi_f32"):
+        L.fcn_query_depth_point_multi_f32.restype = ctypes.c_int
+        L.fcn_query_depth_point_multi_f32.argtypes = [ctypes.c_int, c_fp, ctypes.c_int64, ctypes.c_int64, c_fp, c_fp, c_fp,
+                                                      ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]
     L.fcn_pn_compact.restype = ctypes.c_int
     L.fcn_pn_compact.argtypes = [ctypes.POINTER(PnDesc), c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(PnWs), c_fp]
     L.fcn_pn_group_compact.restype = ctypes.c_int

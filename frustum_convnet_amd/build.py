@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["grouping.hip", "group_compact.hip", "pointnet_fwd.hip", "pointnet_bwd.hip", "loss_tail.hip", "fcn_net.hip", "optim.hip", "inputs.hip", "box_iou.hip"]
-HEADERS = ["fcn_common.h", "gemm_tile.h", "pn_pack.h", "box_iou.h", os.path.join("..", "..", "include", "fcn_hip.h")]
+HEADERS = ["fcn_common.h", "fcn_tuning.h", "gemm_tile.h", "pn_pack.h", "box_iou.h", os.path.join("..", "..", "include", "fcn_hip.h")]
 LIB = os.path.join(HERE, "libfcn_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math",
          "-ffp-contract=off"]

@@ -16,22 +16,10 @@
 //   * backward: dgrad kernels gather dy rows through the inverse position map and write dz of the producer (ReLU
 //     mask + BN-backward sums in the epilogue), wgrad kernels reduce over rows in splits + a deterministic reduce
 //     that scatters straight into the torch weight layout.
+#define FCN_TUNING_FCN
 #include "gemm_tile.h"
 
 #define CG_T 256
-// TIMING EXPERIMENTS ONLY (tuning builds, results are wrong when set): FCN_XF bits in the forward K-group kernel -- 1: activation
-// loads for a group's first chunk only, 2: weight loads first chunk only, 4: LDS staging first chunk only, 8: no MFMAs,
-// 16: no epilogue (cross-group sum, stores, statistics), 32: no BN prologue (scale 1 / shift 0), 64: no statistics atomics,
-// 128: return at entry (bare launches), 256: return behind the prologue
-#ifndef FCN_XF
-#define FCN_XF 0
-#endif
-// FCN_XG: the same for the backward roles -- 1: dz / y loads of a data-gradient tile for a group's first chunk only, 2: weight loads
-// first chunk only, 4: staging first chunk only, 8: no MFMAs, 16: no data-gradient epilogue; 256 / 512 / 1024: the same as 1+2 / 4 /
-// 8 in the weight-gradient role (CGB_NO_WGRAD / CGB_NO_REDUCE / CGB_NO_DGRAD drop whole roles)
-#ifndef FCN_XG
-#define FCN_XG 0
-#endif
 // replicas of the FCN's BatchNorm sum slots (fcn_common.h: same-address fp64 atomics are served one at a time).  Every
 // consumer workgroup of this latency-bound chain sums them in its prologue, so fewer than the PointNet kernels' 8.
 #ifndef FCN_CG_REP
@@ -106,49 +94,6 @@ struct CgLayer {
 #define SEL3(i, a0, a1, a2) ((i) == 0 ? (a0) : ((i) == 1 ? (a1) : (a2)))
 #define SEL4(i, a0, a1, a2, a3) ((i) == 0 ? (a0) : ((i) == 1 ? (a1) : ((i) == 2 ? (a2) : (a3))))
 
-// Intra-kernel phase stamps for TUNING BUILDS ONLY (-DFCN_PROBE, tools/fcn_probe.py; never compiled into the product):
-// wave 0 of every workgroup records the 100 MHz device clock at phase boundaries into a global table.
-#ifdef FCN_PROBE
-#define FCN_PROBE_MAX 65536
-__device__ unsigned long long g_fcn_probe[FCN_PROBE_MAX * 8];
-__device__ unsigned int g_fcn_probe_n;
-#define PROBE_DECL unsigned long long pb_[8]; int pbn_ = 0
-#define PROBE_STAMP() do { if (pbn_ < 7) pb_[pbn_++] = wall_clock64(); } while (0)
-#define PROBE_FLUSH(tag)                                                                                 \
-    do {                                                                                                 \
-        if (threadIdx.x == 0) {                                                                          \
-            const unsigned int s_ = atomicAdd(&g_fcn_probe_n, 1u);                                       \
-            if (s_ < FCN_PROBE_MAX) {                                                                    \
-                g_fcn_probe[s_ * 8] = (unsigned long long)(tag);                                         \
-                for (int q_ = 0; q_ < 7; ++q_) g_fcn_probe[s_ * 8 + 1 + q_] = q_ < pbn_ ? pb_[q_] : 0ull; \
-            }                                                                                            \
-        }                                                                                                \
-    } while (0)
-extern "C" int fcn_probe_read(unsigned long long *host_out, int max_records, int reset)
-{
-    unsigned int n = 0;
-    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_fcn_probe_n), sizeof(n)) != hipSuccess) return -1;
-    if ((int)n > max_records) n = max_records;
-    if (n > FCN_PROBE_MAX) n = FCN_PROBE_MAX;
-    if (n && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fcn_probe), (size_t)n * 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    if (reset) { unsigned int z = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_fcn_probe_n), &z, sizeof(z)); }
-    return (int)n;
-}
-#else
-#define PROBE_DECL
-#define PROBE_STAMP()
-#define PROBE_FLUSH(tag)
-#endif
-// (-DFCN_PROBE=3: the stamps of the BACKWARD roles instead -- tag bit 60: data-gradient tile, bit 61: weight-gradient workgroup)
-#if defined(FCN_PROBE) && FCN_PROBE >= 3
-#define BPROBE_DECL unsigned long long pb_[8]; int pbn_ = 0
-#define BPROBE_STAMP() do { if (pbn_ < 7) pb_[pbn_++] = wall_clock64(); } while (0)
-#define BPROBE_FLUSH(tag) PROBE_FLUSH(tag)
-#else
-#define BPROBE_DECL
-#define BPROBE_STAMP()
-#define BPROBE_FLUSH(tag)
-#endif
 
 // n / d and n % d for 0 <= n < 2^23 through a float reciprocal and one correction step (~10 instructions): hipcc's general
 // 32-bit division is ~40 and every workgroup of a 25-launch latency-bound chain paid a dozen of them before its first load.

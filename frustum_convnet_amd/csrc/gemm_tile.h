@@ -10,6 +10,7 @@
 // is kept as the A/B reference mode, MM_BF16X1 as the throughput mode.
 #pragma once
 #include "fcn_common.h"
+#include "fcn_tuning.h"
 
 // Native 4-wide vectors for register staging.  HIP's float4 is a struct: copying an array element of it between
 // address spaces (global -> register array -> LDS) is lowered to memcpy through a PRIVATE (scratch) array that SROA
@@ -26,13 +27,6 @@ __device__ __forceinline__ v4i ldg4i(const int *p) { return *(gv4ip)p; }
 __device__ __forceinline__ void sts4(float *p, v4f v) { *(v4f *)p = v; }
 __device__ __forceinline__ v4f zero4() { v4f z = {0.f, 0.f, 0.f, 0.f}; return z; }
 
-// TIMING EXPERIMENTS ONLY (tools builds, never the product: results are wrong when set): FCN_EXP bit 0 stores the weight
-// operand without encoding, bit 1 the activation / gradient operand -- upper bounds for what pre-encoded operands could buy.
-#ifndef FCN_EXP
-#define FCN_EXP 0
-#endif
-#define MM_ENC_W ((FCN_EXP & 1) ? MM_F32 : MM)
-#define MM_ENC_A ((FCN_EXP & 2) ? MM_F32 : MM)
 
 #define GT 256          // threads per workgroup
 #define KC 32           // reduction chunk staged per iteration

@@ -78,6 +78,108 @@ extern "C" int fcn_query_depth_point_f32(const float *pts_z, int64_t pt_stride, 
     return 0;
 }
 
+// All scales of a batch in ONE launch: the scales share the point cloud (the z row is staged once per workgroup) and differ in
+// window centres, half height and nsample; workgroup x of a frustum takes 16 windows of the scale its index falls into.  The API
+// form of one PointNetFeat.forward is 4-5 calls of the operator; each of them is a 14 us affair for ~2 MB of output, most of it
+// launch latency.
+#define QDP_MAXS 8
+struct QdpMulti {
+    const float *ctr_z[QDP_MAXS];
+    int64_t ct_stride[QDP_MAXS], ct_bstride[QDP_MAXS];
+    int64_t *idx[QDP_MAXS];
+    int32_t *cnt[QDP_MAXS];
+    int m[QDP_MAXS], nsample[QDP_MAXS], blk0[QDP_MAXS + 1];      // blk0: first workgroup (x) of each scale
+    float dis_z[QDP_MAXS];
+    int nscale;
+};
+
+__global__ __launch_bounds__(QDP_THREADS) void qdp_multi_kernel(const float *__restrict__ pts_z, int64_t pt_stride, int64_t pt_bstride,
+                                                                int n, QdpMulti a, int use_lds)
+{
+    FCN_DYN_LDS(float, zs);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const float *pz = pts_z + (int64_t)b * pt_bstride;
+    if (use_lds) {
+        for (int i = tid; i < n; i += QDP_THREADS) zs[i] = pz[(int64_t)i * pt_stride];
+        __syncthreads();
+    }
+    // the scale of this workgroup: static indices only (a dynamically indexed kernel argument goes through scratch)
+    int s = 0;
+#pragma unroll
+    for (int q = 1; q < QDP_MAXS; ++q)
+        if (q < a.nscale && (int)blockIdx.x >= a.blk0[q]) s = q;
+    const float *ctr_z = a.ctr_z[0];
+    int64_t ct_stride = a.ct_stride[0], ct_bstride = a.ct_bstride[0];
+    int64_t *idx = a.idx[0];
+    int32_t *cnt = a.cnt[0];
+    int m = a.m[0], nsample = a.nsample[0], blk0 = a.blk0[0];
+    float dis_z = a.dis_z[0];
+#pragma unroll
+    for (int q = 1; q < QDP_MAXS; ++q)
+        if (s == q) {
+            ctr_z = a.ctr_z[q]; ct_stride = a.ct_stride[q]; ct_bstride = a.ct_bstride[q]; idx = a.idx[q]; cnt = a.cnt[q];
+            m = a.m[q]; nsample = a.nsample[q]; blk0 = a.blk0[q]; dis_z = a.dis_z[q];
+        }
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int q = 0; q < QDP_WPB / 4; ++q) {
+        const int mi = ((int)blockIdx.x - blk0) * QDP_WPB + q * 4 + wave;          // wave-uniform
+        if (mi >= m) break;
+        const float z2 = ctr_z[(int64_t)b * ct_bstride + (int64_t)mi * ct_stride];
+        int64_t *row = idx + ((int64_t)b * m + mi) * nsample;
+        int c = 0;
+        int first = 0;
+        for (int k0 = 0; k0 < n && c < nsample; k0 += 64) {         // (the same walk as qdp_kernel: .cu:40-64)
+            const int k = k0 + lane;
+            float z1 = 0.f;
+            if (k < n) z1 = use_lds ? zs[k] : pz[(int64_t)k * pt_stride];
+            const bool hit = (k < n) && (fabsf(z2 - z1) < dis_z);
+            const unsigned long long mask = __ballot(hit);
+            if (mask != 0ull) {
+                if (c == 0) first = k0 + (int)__ffsll((long long)mask) - 1;
+                const int pos = c + (int)__popcll(mask & lt_mask);
+                if (hit && pos < nsample) row[pos] = (int64_t)k;
+                c += (int)__popcll(mask);
+            }
+        }
+        const int taken = c < nsample ? c : nsample;
+        const int64_t pad = taken > 0 ? (int64_t)first : (int64_t)0;
+        for (int j = taken + lane; j < nsample; j += 64) row[j] = pad;
+        if (lane == 0) cnt[(int64_t)b * m + mi] = taken;
+    }
+}
+
+extern "C" int fcn_query_depth_point_multi_f32(int nscale, const float *pts_z, int64_t pt_stride, int64_t pt_bstride,
+                                               const float *const *ctr_z, const int64_t *ct_stride, const int64_t *ct_bstride,
+                                               int b, int n, const int32_t *m, const float *dis_z, const int32_t *nsample,
+                                               int64_t *const *idx, int32_t *const *cnt, void *stream)
+{
+    if (nscale < 1 || nscale > QDP_MAXS || b < 0 || n < 0) return FCN_E_BADARG;
+    if (!ctr_z || !ct_stride || !ct_bstride || !m || !dis_z || !nsample || !idx || !cnt) return FCN_E_BADARG;
+    if (b == 0) return 0;
+    if (!pts_z && n > 0) return FCN_E_BADARG;
+    if (b > 65535) return FCN_E_LIMIT;
+    QdpMulti a;
+    a.nscale = nscale;
+    int blk = 0;
+    for (int s = 0; s < QDP_MAXS; ++s) {
+        const int q = s < nscale ? s : 0;
+        if (m[q] < 0 || nsample[q] < 0 || (m[q] > 0 && (!ctr_z[q] || !idx[q] || !cnt[q]))) return FCN_E_BADARG;
+        a.ctr_z[s] = ctr_z[q]; a.ct_stride[s] = ct_stride[q]; a.ct_bstride[s] = ct_bstride[q]; a.idx[s] = idx[q]; a.cnt[s] = cnt[q];
+        a.m[s] = m[q]; a.nsample[s] = nsample[q]; a.dis_z[s] = dis_z[q];
+        a.blk0[s] = blk;
+        if (s < nscale) blk += (m[q] + QDP_WPB - 1) / QDP_WPB;
+    }
+    a.blk0[QDP_MAXS] = blk;
+    if (blk == 0) return 0;
+    const int use_lds = (n <= QDP_LDS_MAX_PTS) ? 1 : 0;
+    const size_t lds = use_lds ? (size_t)n * sizeof(float) : 0;
+    hipLaunchKernelGGL(qdp_multi_kernel, dim3(blk, b), dim3(QDP_THREADS), lds, (hipStream_t)stream, pts_z, pt_stride, pt_bstride, n, a,
+                       use_lds);
+    FCN_CHECK_LAUNCH();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Compaction: (idx, cnt) -> entry list.  Window l of frustum b contributes ne = max(cnt,1) rows
 // (its distinct hits; an empty window contributes point 0, which the reference also feeds through the

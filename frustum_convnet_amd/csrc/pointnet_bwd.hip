@@ -14,6 +14,7 @@
 //                    accumulates Q = sum dz1 * (1,u) -- enough for dW1/dgamma1/dbeta1 (conv1 is linear in u)
 //   wgrad<2>       : dW2 = dy2^T . relu(bn1(conv1(u)))
 //   l1_finalize    : dW1, dgamma1, dbeta1 from Q and the forward's input moments
+#define FCN_TUNING_PNP
 #include "gemm_tile.h"
 
 #define LDT 129                 // transposed (k-major) staging of a 128-row tile
@@ -23,12 +24,6 @@
 #define PWB 16                  // windows per poolbwd workgroup (4 per wave, their loads issued together)
 #ifndef FCN_WIDE_TILES
 #define FCN_WIDE_TILES 0
-#endif
-// TIMING EXPERIMENTS ONLY (tuning builds, results are wrong when set): FCN_XB bits in dgrad_kernel -- 1: A-side loads for the first
-// chunk only, 2: W loads first chunk only, 4: staging first chunk only, 8: no MFMAs, 16: no epilogue, 32: no dz stores, 64: no
-// statistics atomics, 128: no dy3 store
-#ifndef FCN_XB
-#define FCN_XB 0
 #endif
 #ifndef FCN_DG_WIDE
 #define FCN_DG_WIDE 0         // 1 (tuning builds): 64 x 256 data-gradient tiles where the previous layer has 256 channels
@@ -40,40 +35,6 @@
 extern "C" int fcn_pn_wgrad_rows(void) { return WG_ROWS; }
 extern "C" int fcn_stat_replicas(void) { return FCN_STAT_REP; }
 
-// Intra-kernel cycle accounting of the data-gradient GEMM for TUNING BUILDS ONLY (-DFCN_PROBE, tools/pn_probe.py; never
-// compiled into the product): wave 0 of every workgroup sums the shader-clock cycles it spends in each phase of the K loop.
-#ifdef FCN_PROBE
-#define PNP_MAX 32768
-__device__ unsigned long long g_pn_probe[PNP_MAX * 8];
-__device__ unsigned int g_pn_probe_n;
-#define PNP_DECL unsigned long long pa_[6] = {0, 0, 0, 0, 0, 0}; unsigned long long pt_ = clock64(), pt0_ = pt_
-#define PNP_ADD(i) do { const unsigned long long n_ = clock64(); pa_[i] += n_ - pt_; pt_ = n_; } while (0)
-#define PNP_FLUSH(tag)                                                                                   \
-    do {                                                                                                 \
-        if (threadIdx.x == 0) {                                                                          \
-            const unsigned int s_ = atomicAdd(&g_pn_probe_n, 1u);                                        \
-            if (s_ < PNP_MAX) {                                                                          \
-                g_pn_probe[s_ * 8] = (unsigned long long)(tag);                                          \
-                g_pn_probe[s_ * 8 + 1] = clock64() - pt0_;                                               \
-                for (int q_ = 0; q_ < 6; ++q_) g_pn_probe[s_ * 8 + 2 + q_] = pa_[q_];                    \
-            }                                                                                            \
-        }                                                                                                \
-    } while (0)
-extern "C" int fcn_pn_probe_read(unsigned long long *host_out, int max_records, int reset)
-{
-    unsigned int n = 0;
-    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_pn_probe_n), sizeof(n)) != hipSuccess) return -1;
-    if ((int)n > max_records) n = max_records;
-    if (n > PNP_MAX) n = PNP_MAX;
-    if (n && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pn_probe), (size_t)n * 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    if (reset) { unsigned int z = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_pn_probe_n), &z, sizeof(z)); }
-    return (int)n;
-}
-#else
-#define PNP_DECL
-#define PNP_ADD(i)
-#define PNP_FLUSH(tag)
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // One wave = one window x 64 channels (lane = channel); a workgroup covers PWB consecutive windows, stages

@@ -10,6 +10,7 @@
 // Training-mode BatchNorm needs whole-batch statistics between layers, hence one launch per layer;
 // everything elementwise (gather, centre, BN apply, ReLU, mask, max, concat) is fused into the
 // neighbouring GEMM's prologue/epilogue, so only the pre-BN conv outputs y2, y3 ever reach HBM.
+#define FCN_TUNING_PNF
 #include "gemm_tile.h"
 
 #define LDT 129            // LDS leading dimension of a 128-wide k-major tile
@@ -24,12 +25,6 @@
 #endif
 #ifndef FCN_FWD_EPI_DIRECT
 #define FCN_FWD_EPI_DIRECT 0
-#endif
-// TIMING EXPERIMENTS ONLY (tuning builds, results are wrong when set): FCN_X bits -- 1: A loaded for the first chunk only,
-// 2: W loaded for the first chunk only, 4: LDS staging for the first chunk only, 8: no MFMAs, 16: no output stores / statistics,
-// 32: no output stores (statistics kept), 64: no statistics atomics
-#ifndef FCN_X
-#define FCN_X 0
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -157,40 +152,6 @@ extern "C" int fcn_pn_pack_weights_all(int nscale, const fcn_pn_desc *const *d, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Intra-kernel cycle accounting of the forward GEMM for TUNING BUILDS ONLY (-DFCN_PROBE, tools/pn_probe.py fwd; never compiled
-// into the product): wave 0 of every workgroup sums the shader-clock cycles it spends in each phase of the K loop.
-#ifdef FCN_PROBE
-#define PNF_MAX 32768
-__device__ unsigned long long g_pnf_probe[PNF_MAX * 8];
-__device__ unsigned int g_pnf_probe_n;
-#define PNF_DECL unsigned long long pa_[6] = {0, 0, 0, 0, 0, 0}; unsigned long long pt_ = clock64(), pt0_ = pt_
-#define PNF_ADD(i) do { const unsigned long long n_ = clock64(); pa_[i] += n_ - pt_; pt_ = n_; } while (0)
-#define PNF_FLUSH(tag)                                                                                   \
-    do {                                                                                                 \
-        if (threadIdx.x == 0) {                                                                          \
-            const unsigned int s_ = atomicAdd(&g_pnf_probe_n, 1u);                                       \
-            if (s_ < PNF_MAX) {                                                                          \
-                g_pnf_probe[s_ * 8] = (unsigned long long)(tag);                                         \
-                g_pnf_probe[s_ * 8 + 1] = clock64() - pt0_;                                              \
-                for (int q_ = 0; q_ < 6; ++q_) g_pnf_probe[s_ * 8 + 2 + q_] = pa_[q_];                   \
-            }                                                                                            \
-        }                                                                                                \
-    } while (0)
-extern "C" int fcn_pn_probe_read_fwd(unsigned long long *host_out, int max_records, int reset)
-{
-    unsigned int n = 0;
-    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_pnf_probe_n), sizeof(n)) != hipSuccess) return -1;
-    if ((int)n > max_records) n = max_records;
-    if (n > PNF_MAX) n = PNF_MAX;
-    if (n && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pnf_probe), (size_t)n * 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    if (reset) { unsigned int z = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_pnf_probe_n), &z, sizeof(z)); }
-    return (int)n;
-}
-#else
-#define PNF_DECL
-#define PNF_ADD(i)
-#define PNF_FLUSH(tag)
-#endif
 
 #ifndef FCN_POOL_FUSED
 #define FCN_POOL_FUSED 1     // 0 (tuning builds): conv3 writes y3 only and pool_nlc_kernel re-reads it

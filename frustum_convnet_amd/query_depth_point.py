@@ -39,6 +39,35 @@ def query_depth_point(dis_z, nsample, xyz1, xyz2):
     return idx, cnt
 
 
+def query_depth_point_multi(dis_z, nsample, xyz1, xyz2_list, out=None):
+    """The operator for every scale of one batch in ONE launch (fcn_query_depth_point_multi_f32): dis_z / nsample / xyz2_list hold one
+    entry per scale ((B,3,M_s) window centres), xyz1 (B,3,N) is shared.  -> [(idx_s, cnt_s)], each exactly what
+    query_depth_point(dis_z[s], nsample[s], xyz1, xyz2_list[s]) returns.  out: the same list from an earlier call, written in place."""
+    import ctypes
+    ns = len(xyz2_list)
+    assert 1 <= ns <= 8 and len(dis_z) == ns and len(nsample) == ns
+    assert xyz1.is_cuda and xyz1.size(1) == 3 and xyz1.is_contiguous() and xyz1.dtype == torch.float32
+    b, _, n = xyz1.shape
+    for x2 in xyz2_list:
+        assert x2.is_cuda and x2.size(1) == 3 and x2.size(0) == b and x2.is_contiguous() and x2.dtype == torch.float32
+    ms = [int(x2.size(2)) for x2 in xyz2_list]
+    if out is None:
+        out = [(torch.empty((b, m, int(k)), dtype=torch.int64, device=xyz1.device), torch.empty((b, m), dtype=torch.int32, device=xyz1.device))
+               for m, k in zip(ms, nsample)]
+    ptrs = lambda vals: (ctypes.c_void_p * ns)(*vals)
+    i64 = lambda vals: (ctypes.c_int64 * ns)(*vals)
+    L = _native.lib()
+    with torch.cuda.device(xyz1.device):
+        rc = L.fcn_query_depth_point_multi_f32(
+            ns, xyz1.data_ptr() + 4 * 2 * n, 1, 3 * n,
+            ptrs([x2.data_ptr() + 4 * 2 * m for x2, m in zip(xyz2_list, ms)]), i64([1] * ns), i64([3 * m for m in ms]),
+            b, n, (ctypes.c_int32 * ns)(*ms), (ctypes.c_float * ns)(*[float(d) for d in dis_z]),
+            (ctypes.c_int32 * ns)(*[int(k) for k in nsample]),
+            ptrs([o[0].data_ptr() for o in out]), ptrs([o[1].data_ptr() for o in out]), _native.current_stream(xyz1.device))
+    _native.check(rc, "fcn_query_depth_point_multi_f32")
+    return out
+
+
 def query_depth_point_bn3(dis_z, nsample, xyz1_bn3, xyz2_bm3):
     """Same op on the kernel-native layout of the reference's pybind entry
     (query_depth_point_cuda.cpp:25-50): xyz1 (B,N,3), xyz2 (B,M,3)."""

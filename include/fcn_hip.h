@@ -80,6 +80,14 @@ int fcn_query_depth_point_f32(const float *pts_z, int64_t pt_stride, int64_t pt_
                               int b, int n, int m, float dis_z, int nsample,
                               int64_t *idx, int32_t *cnt, void *stream);
 
+/* The same operator for ALL scales of one batch in ONE launch (the scales of PointNetFeat.forward share the point cloud and differ
+ * in window centres, half height and nsample: models/det_base.py:126-157 calls query_depth_point once per scale).  Arrays of
+ * nscale <= 8 entries; outputs exactly those of nscale calls of fcn_query_depth_point_f32. */
+int fcn_query_depth_point_multi_f32(int nscale, const float *pts_z, int64_t pt_stride, int64_t pt_bstride,
+                                    const float *const *ctr_z, const int64_t *ct_stride, const int64_t *ct_bstride,
+                                    int b, int n, const int32_t *m, const float *dis_z, const int32_t *nsample,
+                                    int64_t *const *idx, int32_t *const *cnt, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * One PointNet scale (PointNetModule + max over K), "entry space" dataflow: every distinct
  * (window, point) pair is evaluated once and carries its multiplicity as a weight.

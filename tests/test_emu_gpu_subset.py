@@ -33,6 +33,7 @@ CASES = [
     ("test_gpu_grouping", "test_boundary_is_strict_and_fp32", ()),
     ("test_gpu_grouping", "test_kernel_native_layout_matches", ()),
     ("test_gpu_grouping", "test_double_inputs_are_narrowed_like_the_reference_kernel", ()),
+    ("test_gpu_grouping", "test_multi_scale_launch_equals_the_per_scale_operator", ()),
     ("test_gpu_box", "test_iou_pair_matches_golden", ()),
     ("test_gpu_box", "test_rotate_nms_matches_reference_keep_lists", ()),
     ("test_gpu_box", "test_decode_matches_oracle", (3, 64)),

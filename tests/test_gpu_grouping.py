@@ -131,3 +131,27 @@ def test_adversarial_inputs():
         for b in range(B):
             n = int(c["nent"][b])
             assert torch.equal(ws.ent.cpu()[b, :n], c["ent"][b, :n]) and torch.equal(ws.ewin.cpu()[b, :n], c["ewin"][b, :n]), (name, b)
+
+
+def test_multi_scale_launch_equals_the_per_scale_operator():
+    """fcn_query_depth_point_multi_f32: all scales of a batch in one launch -- idx / cnt bit for bit those of one call of the operator
+    per scale (car scales on the golden batch, a ragged one with nsample > n and an empty scale)."""
+    from frustum_convnet_amd.query_depth_point import query_depth_point, query_depth_point_multi
+    d = golden_inputs(load_golden("car_b4_n512"))
+    pc = torch.from_numpy(d["point_cloud"][:, :3].copy()).cuda().contiguous()
+    refs = [torch.from_numpy(d["center_ref%d" % i].copy()).cuda().contiguous() for i in (1, 2, 3, 4)]
+    dz, ks = [0.25, 0.5, 1.0, 2.0], [32, 64, 64, 128]
+    got = query_depth_point_multi(dz, ks, pc, refs)
+    for s in range(4):
+        idx, cnt = query_depth_point(dz[s], ks[s], pc, refs[s])
+        assert torch.equal(got[s][0], idx) and torch.equal(got[s][1], cnt)
+    again = query_depth_point_multi(dz, ks, pc, refs, out=got)           # in place
+    assert again is got
+    gen = torch.Generator().manual_seed(5)
+    pc2 = (torch.rand((3, 3, 70), generator=gen) * 4).cuda()
+    refs2 = [(torch.rand((3, 3, m), generator=gen) * 4).cuda() for m in (17, 1, 33)]
+    dz2, ks2 = [0.3, 5.0, 0.01], [100, 7, 16]
+    got2 = query_depth_point_multi(dz2, ks2, pc2, refs2)
+    for s in range(3):
+        idx, cnt = query_depth_point(dz2[s], ks2[s], pc2, refs2[s])
+        assert torch.equal(got2[s][0], idx) and torch.equal(got2[s][1], cnt)
