@@ -707,18 +707,23 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(2, 4))) void
 #define WR_T 256
 // (each thread owns FOUR consecutive elements: 16-byte loads -- a quarter of the load instructions of the dword version and
 // four times the bytes in flight per thread; 100 us of kernel time per step went through here at ~1.6 TB/s)
-__global__ __launch_bounds__(WR_T) void wgrad_reduce_kernel(const float *__restrict__ partial,
-                                                            const int32_t *__restrict__ tiles, int nsplit, int gr,
-                                                            int64_t nelem, float *__restrict__ out)
+struct ReduceJob {
+    const float *partial;
+    const int32_t *tiles;
+    float *out;
+    int64_t nelem;
+    int nsplit, gr, nblk;          // nblk: workgroups of this job
+};
+__device__ __forceinline__ void wgrad_reduce_body(const ReduceJob &j, const int rid, float *sh)
 {
-    __shared__ __attribute__((aligned(16))) float sh[WR_T * 4];
-    const int per = WR_T / gr;
+    const int gr = j.gr, per = WR_T / gr;
     const int x = threadIdx.x % per, y = threadIdx.x / per;
-    const int64_t i = ((int64_t)blockIdx.x * per + x) * 4;      // nelem is a multiple of 1024
-    const int ntile = tiles[0];
-    const int tpb = (ntile + nsplit - 1) / nsplit;
+    const int64_t i = ((int64_t)rid * per + x) * 4;      // nelem is a multiple of 1024
+    const int ntile = j.tiles[0];
+    const int tpb = (ntile + j.nsplit - 1) / j.nsplit;
     const int nsp = tpb > 0 ? (ntile + tpb - 1) / tpb : 0;
-    const float *p = partial + i;
+    const float *p = j.partial + i;
+    const int64_t nelem = j.nelem;
     v4f s0 = zero4(), s1 = zero4(), s2 = zero4(), s3 = zero4();
     int sp = y;
     for (; sp + 3 * gr < nsp; sp += 4 * gr) {
@@ -736,37 +741,69 @@ __global__ __launch_bounds__(WR_T) void wgrad_reduce_kernel(const float *__restr
         t = zero4();
         for (int q = 0; q < gr; ++q) t += *(const v4f *)(sh + 4 * (q * per + x));
     }
-    sts4(out + i, t);
+    sts4(j.out + i, t);
+}
+__global__ __launch_bounds__(WR_T) void wgrad_reduce_kernel(ReduceJob j)
+{
+    __shared__ __attribute__((aligned(16))) float sh[WR_T * 4];
+    wgrad_reduce_body(j, (int)blockIdx.x, sh);
 }
 
 // dW1, dgamma1, dbeta1 from Q = sum_e dz1 (1, u) and the forward's weighted moments of u.
-__global__ void l1_finalize_kernel(const double *__restrict__ Qr, int rep_stride, const double *__restrict__ mom,
-                                   const float *__restrict__ W1, const float *__restrict__ gamma,
-                                   const float *__restrict__ bn1, int C, double M,
-                                   float *__restrict__ dW1, float *__restrict__ dgamma, float *__restrict__ dbeta)
+struct L1Args {
+    const double *Qr;
+    int rep_stride;
+    const double *mom;
+    const float *W1, *gamma, *bn1;
+    int C;
+    double M;
+    float *dW1, *dgamma, *dbeta;
+};
+__device__ __forceinline__ void l1_finalize_body(const L1Args &a, const int c)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int C = a.C;
     if (c >= C) return;
+    const double *Qr = a.Qr, *mom = a.mom;
+    const int rep_stride = a.rep_stride;
     const double q0 = fcn_rep_sum(Qr + c, rep_stride);
     const double qu[3] = {fcn_rep_sum(Qr + C + c, rep_stride), fcn_rep_sum(Qr + 2 * C + c, rep_stride), fcn_rep_sum(Qr + 3 * C + c, rep_stride)};
-    const double w[3] = {W1[3 * c], W1[3 * c + 1], W1[3 * c + 2]};
-    const double mean = bn1[2 * C + c], rstd = bn1[3 * C + c];
+    const double w[3] = {a.W1[3 * c], a.W1[3 * c + 1], a.W1[3 * c + 2]};
+    const double mean = a.bn1[2 * C + c], rstd = a.bn1[3 * C + c];
     const double db = q0;
     const double dg = rstd * (w[0] * qu[0] + w[1] * qu[1] + w[2] * qu[2] - mean * q0);
-    const double iM = 1.0 / M;          // (one fp64 division instead of twelve: the last launch of the scale's backward chain)
+    const double iM = 1.0 / a.M;          // (one fp64 division instead of twelve: the last launch of the scale's backward chain)
     const double mu[3] = {mom[1] * iM, mom[2] * iM, mom[3] * iM};
     const double m2[3][3] = {{mom[4] * iM, mom[5] * iM, mom[6] * iM},
                              {mom[5] * iM, mom[7] * iM, mom[8] * iM},
                              {mom[6] * iM, mom[8] * iM, mom[9] * iM}};
-    const double kk = (double)gamma[c] * rstd;
+    const double kk = (double)a.gamma[c] * rstd;
     for (int j = 0; j < 3; ++j) {
         const double wm2 = w[0] * m2[0][j] + w[1] * m2[1][j] + w[2] * m2[2][j];
         // sum_e w x^ u_j = rstd * M * (W1_c . m2[:,j] - mean * mu_j);  sum_e w u_j = M mu_j
         const double v = kk * (qu[j] - db * mu[j] - dg * rstd * (wm2 - mean * mu[j]));
-        dW1[3 * c + j] = (float)v;
+        a.dW1[3 * c + j] = (float)v;
     }
-    dgamma[c] = (float)dg;
-    dbeta[c] = (float)db;
+    a.dgamma[c] = (float)dg;
+    a.dbeta[c] = (float)db;
+}
+__global__ void l1_finalize_kernel(L1Args a) { l1_finalize_body(a, (int)(blockIdx.x * blockDim.x + threadIdx.x)); }
+
+// The TAIL of a scale's backward in one launch: the fixed-order sums of both weight gradients' split partials and (optionally) the
+// layer-1 finalisation, as workgroup roles -- [0, r[0].nblk) reduce conv3's partials, the next r[1].nblk conv2's, the rest
+// finalise layer 1.  The reduces used to sit between the GEMMs of the chain (wgrad<3> -> reduce -> wgrad<2> -> reduce ->
+// finalise): three launches on the critical chain of every scale that nothing else waited for.
+struct PnTailArgs {
+    ReduceJob r[2];
+    L1Args l1;
+    int has_l1;
+};
+__global__ __launch_bounds__(WR_T) void pn_tail_kernel(PnTailArgs t)
+{
+    __shared__ __attribute__((aligned(16))) float sh[WR_T * 4];
+    const int bid = (int)blockIdx.x;
+    if (bid < t.r[0].nblk) wgrad_reduce_body(t.r[0], bid, sh);
+    else if (bid < t.r[0].nblk + t.r[1].nblk) wgrad_reduce_body(t.r[1], bid - t.r[0].nblk, sh);
+    else if (t.has_l1) l1_finalize_body(t.l1, (bid - t.r[0].nblk - t.r[1].nblk) * WR_T + (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -836,22 +873,61 @@ static int plan_wgrad(const WgradArgs &a, int B, int nsplit_cap, WgradPlan &P)
 }
 
 // the fixed-order sum of the split partials into the torch weight layout
-static int launch_wgrad_reduce(const WgradArgs &a, const WgradPlan &P, hipStream_t st, float *out)
+static int make_reduce_job(const WgradArgs &a, const WgradPlan &P, float *out, ReduceJob &j)
 {
     const int64_t ne = (int64_t)a.COUT * a.CIN;
     if (((uintptr_t)out & 15) != 0) return FCN_E_BADARG;        // the reduce writes 16-byte vectors (include/fcn_hip.h)
     const int nsplit = P.nsplit;
     const int gr = nsplit >= 128 ? 16 : (nsplit >= 64 ? 8 : (nsplit >= 32 ? 4 : (nsplit >= 16 ? 2 : 1)));
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(ne / (4 * (WR_T / gr)))), dim3(WR_T), 0, st, a.partial, a.tiles,
-                       nsplit, gr, ne, out);
+    j.partial = a.partial; j.tiles = a.tiles; j.out = out; j.nelem = ne; j.nsplit = nsplit; j.gr = gr;
+    j.nblk = (int)(ne / (4 * (WR_T / gr)));
+    return 0;
+}
+
+static int launch_wgrad_reduce(const WgradArgs &a, const WgradPlan &P, hipStream_t st, float *out)
+{
+    ReduceJob j;
+    FCN_TRY(make_reduce_job(a, P, out, j));
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)j.nblk), dim3(WR_T), 0, st, j);
+    FCN_CHECK_LAUNCH();
+    return 0;
+}
+
+static L1Args make_l1(const fcn_pn_desc *d, const fcn_pn_params *p, const fcn_pn_ws *ws, double *bsQ, int brs, const float *bn1, double M,
+                      float *dW0, float *dgamma0, float *dbeta0)
+{
+    L1Args a;
+    a.Qr = bsQ; a.rep_stride = brs; a.mom = ws->stat + FCN_STAT_MOM; a.W1 = p->W[0]; a.gamma = p->gamma[0]; a.bn1 = bn1; a.C = d->C1; a.M = M;
+    a.dW1 = dW0; a.dgamma = dgamma0; a.dbeta = dbeta0;
+    return a;
+}
+
+static int launch_l1(const L1Args &a, hipStream_t st)
+{
+    hipLaunchKernelGGL(l1_finalize_kernel, dim3((a.C + 63) / 64), dim3(64), 0, st, a);
+    FCN_CHECK_LAUNCH();
+    return 0;
+}
+
+// both reduces (+ the layer-1 finalisation) of a scale in one launch (pn_tail_kernel)
+static int launch_tail(const ReduceJob &r3, const ReduceJob &r2, const L1Args *l1, hipStream_t st)
+{
+    PnTailArgs t;
+    t.r[0] = r3; t.r[1] = r2;
+    t.has_l1 = l1 ? 1 : 0;
+    if (l1) t.l1 = *l1; else t.l1 = L1Args();
+    const unsigned nb = (unsigned)(r3.nblk + r2.nblk + (l1 ? (l1->C + WR_T - 1) / WR_T : 0));
+    hipLaunchKernelGGL(pn_tail_kernel, dim3(nb), dim3(WR_T), 0, st, t);
     FCN_CHECK_LAUNCH();
     return 0;
 }
 
 // rewait: an event the stream waits for AGAIN between the GEMM and its reduce (fcn_pn_backward3: a redundant edge that steers ROCm's
 // graph executor -- see pn_backward_impl)
+// defer: the reduce is not launched -- *defer receives its job (the caller runs it in a tail launch)
 template <int LAYER>
-static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, int precision, hipStream_t st, float *out, hipEvent_t rewait = nullptr)
+static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, int precision, hipStream_t st, float *out, hipEvent_t rewait = nullptr,
+                        ReduceJob *defer = nullptr)
 {
     WgradPlan P;
     FCN_TRY(plan_wgrad<LAYER>(a, B, nsplit_cap, P));
@@ -863,6 +939,7 @@ static int launch_wgrad(WgradArgs &a, int B, int nsplit_cap, int precision, hipS
         FCN_MM_SWITCH(FCN_MM_OF(precision, false), (launch_wgrad_mm<MM, LAYER>(a, grid, P.m2, P.n2, st)));
     }
     FCN_CHECK_LAUNCH();
+    if (defer) return make_reduce_job(a, P, out, *defer);
     if (rewait) {
         const hipError_t e = hipStreamWaitEvent(st, rewait, 0);
         if (e != hipSuccess) return (int)e;
@@ -953,7 +1030,7 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
     if (!d || !p || !ws || !dfeat || !dW || !dgamma || !dbeta) return FCN_E_BADARG;
     if (!d->training || !ws->wenc) return FCN_E_BADARG;
     if (d->precision < 0 || d->precision > FCN_PREC_BF16_OPS) return FCN_E_BADARG;
-    if (ws->partial_both != 0 && ws->partial_both != 1) return FCN_E_BADARG;      // (an uninitialised trailing field must not enable the merged launch)
+    if (ws->partial_both < 0 || ws->partial_both > 2) return FCN_E_BADARG;      // (an uninitialised trailing field must not enable the merged launches)
     hipStream_t st = (hipStream_t)stream;
     const bool two = stream2 != nullptr && events != nullptr;
     const bool three = two && stream3 != nullptr;
@@ -1013,7 +1090,11 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
 #if FCN_XB & 256       // (timing build: the cost of the Gram matrix a2^T a2 instead of dy3^T a2)
     w.dy = ws->y2; w.COUT = C2;
 #endif
-    if (!two && ws->partial_both && ws->dy3) {
+    // partial_both: `partial` holds both weight gradients' partials at once -- 1: the merged middle launch (one stream), 2: separate
+    // GEMMs; either way the two reduces (+ the layer-1 finalisation where it is on the same stream) run as ONE tail launch
+    const bool both = ws->partial_both != 0;
+    const L1Args l1a = make_l1(d, p, ws, bsQ, brs, bn1, M, dW[0], dgamma[0], dbeta[0]);
+    if (!two && ws->partial_both == 1 && ws->dy3) {
         // ONE stream: conv2's data gradient and both weight gradients ride in one launch (they depend on dgrad<3> only), then the
         // two reduces and the layer-1 finalisation -- 6 launches per scale instead of 8, none of them waiting for a sibling
         DgradArgs g2 = g;
@@ -1033,12 +1114,10 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
         const int rc = launch_mid(g2, w, w2, P3, P2, B, d->precision, st);
         if (rc > 0) return rc;
         if (rc == 0) {
-            FCN_TRY(launch_wgrad_reduce(w, P3, st, dW[2]));
-            FCN_TRY(launch_wgrad_reduce(w2, P2, st, dW[1]));
-            hipLaunchKernelGGL(l1_finalize_kernel, dim3((C1 + 63) / 64), dim3(64), 0, st, bsQ, brs, ws->stat + FCN_STAT_MOM,
-                               p->W[0], p->gamma[0], bn1, C1, M, dW[0], dgamma[0], dbeta[0]);
-            FCN_CHECK_LAUNCH();
-            return 0;
+            ReduceJob r3, r2;
+            FCN_TRY(make_reduce_job(w, P3, dW[2], r3));
+            FCN_TRY(make_reduce_job(w2, P2, dW[1], r2));
+            return launch_tail(r3, r2, &l1a, st);
         }                               // (rc < 0: a tile plan the merged launch has no instance for -- the launches below)
     }
     if (two) {     // dy3 is final: conv3's weight gradient can run beside the rest of the chain
@@ -1055,7 +1134,9 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
     // edge out of the node.  dgrad<3>'s edges in capture order: conv3's weight-gradient GEMM (0: stays on p), its reduce through a SECOND
     // wait for events[0] (1: redundant, the node is already placed), conv2's data gradient (2) and conv2's weight gradient (3) -- so the
     // two branches land on the streams of the third and fourth captured scale (the narrow ones), not on the second's (tools/graph_dot.py)
-    FCN_TRY(launch_wgrad<3>(w, B, ws->nsplit, d->precision, sw, dW[2], three ? (hipEvent_t)events[0] : nullptr));
+    ReduceJob r3, r2;
+    const bool tail = both && !three;         // the reduces deferred to one launch behind conv2's weight-gradient GEMM
+    FCN_TRY(launch_wgrad<3>(w, B, ws->nsplit, d->precision, sw, dW[2], three ? (hipEvent_t)events[0] : nullptr, tail ? &r3 : nullptr));
     if (three) {
         e = hipEventRecord((hipEvent_t)events[3], sw);
         if (e != hipSuccess) return (int)e;
@@ -1067,9 +1148,7 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
         g2.dybuf = nullptr; g2.yprev = nullptr; g2.bn_prev = bn1; g2.W1 = p->W[0]; g2.dzprev = nullptr; g2.bstat_prev = bsQ;
         g2.CRED = C2; g2.CPREV = C1;
         FCN_TRY(launch_dgrad<2>(g2, B, d->precision, st));
-        hipLaunchKernelGGL(l1_finalize_kernel, dim3((C1 + 63) / 64), dim3(64), 0, st, bsQ, brs, ws->stat + FCN_STAT_MOM,
-                           p->W[0], p->gamma[0], bn1, C1, M, dW[0], dgamma[0], dbeta[0]);
-        FCN_CHECK_LAUNCH();
+        FCN_TRY(launch_l1(l1a, st));
         w.dy = nullptr; w.dz = ws->dz2; w.ycur = ws->y2; w.yprev = nullptr; w.bn_prev = bn1;
         w.cb.bstat = bs2; w.cb.gamma = p->gamma[1]; w.cb.bn = bn2;
         w.W1 = p->W[0]; w.COUT = C2; w.CIN = C1;
@@ -1095,8 +1174,9 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
         w.dy = nullptr; w.dz = ws->dz2; w.ycur = ws->y2; w.yprev = nullptr; w.bn_prev = bn1;
         w.cb.bstat = bs2; w.cb.gamma = p->gamma[1]; w.cb.bn = bn2;
         w.W1 = p->W[0]; w.COUT = C2; w.CIN = C1;
-        if (three) w.partial = ws->partial + (int64_t)ws->nsplit * C3 * C2;      // its own partials: the two run at once
-        FCN_TRY(launch_wgrad<2>(w, B, ws->nsplit, d->precision, sw2, dW[1]));
+        if (three || tail) w.partial = ws->partial + (int64_t)ws->nsplit * C3 * C2;      // its own partials
+        FCN_TRY(launch_wgrad<2>(w, B, ws->nsplit, d->precision, sw2, dW[1], nullptr, tail ? &r2 : nullptr));
+        if (tail) FCN_TRY(launch_tail(r3, r2, nullptr, sw2));       // (the layer-1 finalisation ends the OTHER stream's chain)
         e = hipEventRecord((hipEvent_t)events[2], sw2);
         if (e != hipSuccess) return (int)e;
     }
@@ -1111,12 +1191,12 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
         w.dy = nullptr; w.dz = ws->dz2; w.ycur = ws->y2; w.yprev = nullptr; w.bn_prev = bn1;
         w.cb.bstat = bs2; w.cb.gamma = p->gamma[1]; w.cb.bn = bn2;
         w.W1 = p->W[0]; w.COUT = C2; w.CIN = C1;
-        FCN_TRY(launch_wgrad<2>(w, B, ws->nsplit, d->precision, st, dW[1]));
+        if (tail) w.partial = ws->partial + (int64_t)ws->nsplit * C3 * C2;
+        FCN_TRY(launch_wgrad<2>(w, B, ws->nsplit, d->precision, st, dW[1], nullptr, tail ? &r2 : nullptr));
+        if (tail) return launch_tail(r3, r2, &l1a, st);
     }
 
-    hipLaunchKernelGGL(l1_finalize_kernel, dim3((C1 + 63) / 64), dim3(64), 0, st, bsQ, brs, ws->stat + FCN_STAT_MOM,
-                       p->W[0], p->gamma[0], bn1, C1, M, dW[0], dgamma[0], dbeta[0]);
-    FCN_CHECK_LAUNCH();
+    FCN_TRY(launch_l1(l1a, st));
     if (two) {
         e = hipStreamWaitEvent(st, (hipEvent_t)events[2], 0);
         if (e != hipSuccess) return (int)e;

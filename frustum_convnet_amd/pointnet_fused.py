@@ -82,7 +82,7 @@ class Workspace:
                       # `partial` above holds both weight gradients' split partials, so a one-stream backward can run conv2's data
                       # gradient and the two weight-gradient GEMMs as roles of ONE launch (pn_mid_kernel: 6 launches per scale instead
                       # of 8, bit-identical gradients) -- _mid_launch() below says where that pays
-                      1 if (need_grad and _mid_launch(B, L, K, C3)) else 0)
+                      (1 if _mid_launch(B, L, K, C3) else (0 if os.environ.get("FCN_PN_TAIL", "1") == "0" else 2)) if need_grad else 0)
 
     @staticmethod
     def stored(t, precision_code):

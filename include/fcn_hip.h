@@ -149,10 +149,13 @@ typedef struct fcn_pn_ws {
     uint64_t *pkey;              /* (B, L, C3) max-pool keys, 16-byte aligned, or NULL: zero it ONCE at allocation (fcn_pn_forward
                                     leaves it zero).  With it (and nlc = 1) the max-pool is taken in conv3's epilogue instead of
                                     by a pass that re-reads y3 (and in eval mode y3 is not written at all)                     */
-    int32_t  partial_both;       /* 1: `partial` holds nsplit * (C3*C2 + C2*C1) floats, so the one-stream backward (fcn_pn_backward,
-                                    fcn_pn_backward2 with stream2 == NULL) may run conv2's data gradient and both weight gradients as
-                                    roles of ONE launch; 0: they run one after the other through nsplit * max(C3*C2, C2*C1) floats.
-                                    Strictly 0 or 1 (anything else: FCN_E_BADARG) -- zero-initialise the struct */
+    int32_t  partial_both;       /* 1 or 2: `partial` holds nsplit * (C3*C2 + C2*C1) floats -- both weight gradients' split partials at
+                                    once -- so their two fixed-order reduces (and the layer-1 finalisation) run as ONE launch at the
+                                    tail of the chain instead of between its GEMMs; with 1 the one-stream backward (fcn_pn_backward,
+                                    fcn_pn_backward2 with stream2 == NULL) also runs conv2's data gradient and both weight-gradient
+                                    GEMMs as roles of one launch.  0: `partial` holds nsplit * max(C3*C2, C2*C1) floats, GEMM and
+                                    reduce alternate.  Anything else: FCN_E_BADARG -- zero-initialise the struct.  Bit-identical
+                                    gradients in all three. */
 } fcn_pn_ws;
 
 /* Sticky numeric flags (fcn_pn_ws.flags, fcn_cn_ws.flags): the kernels only ever OR bits in.

@@ -75,6 +75,9 @@ CASES = [
     ("test_gpu_pointnet", "test_rebuilt_dy3_gives_bit_identical_gradients", ((4, 512, 2.0, 128, (256, 256, 512), 2.0),)),
     ("test_gpu_pointnet", "test_merged_mid_launch_gives_bit_identical_gradients", ((3, 200, 2.5, 32, (64, 64, 128), 0.7),)),
     ("test_gpu_pointnet", "test_merged_mid_launch_gives_bit_identical_gradients", ((4, 512, 1.0, 64, (128, 128, 256), 1.0),)),
+    ("test_gpu_pointnet", "test_tail_launch_gives_bit_identical_gradients", ((3, 200, 2.5, 32, (64, 64, 128), 0.7), False)),
+    ("test_gpu_pointnet", "test_tail_launch_gives_bit_identical_gradients", ((4, 512, 2.0, 128, (256, 256, 512), 2.0), True)),
+    ("test_gpu_pointnet", "test_tail_launch_gives_bit_identical_gradients", ((2, 130, 0.5, 64, (128, 128, 256), 0.4), False)),
     ("test_gpu_model", "test_train_eval_parity", ("car_b4_n512",)),
     ("test_gpu_model", "test_train_eval_parity", ("people_b2_n512",)),
     ("test_gpu_model", "test_train_eval_parity", ("refine_b4_n512",)),

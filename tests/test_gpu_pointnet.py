@@ -127,6 +127,71 @@ def test_rebuilt_dy3_gives_bit_identical_gradients(case):
     assert float(out["0"][2].abs().max()) > 0
 
 
+def _scale_backward(case, env, two_streams=False):
+    """Forward + backward of one scale through the C-ABI under the environment `env` -> (gradients on the CPU, workspace)."""
+    import ctypes
+    import os
+    import numpy as np
+    from frustum_convnet_amd import _native, pointnet_fused as pf, synth
+
+    B, N, stride, K, mlp, dist = case
+    dev = torch.device("cuda:0")
+    pc, ref, sd, one_hot = gsc.make_case(B, N, stride, K, mlp, dist)
+    L = ref.shape[2]
+    dfeat = torch.from_numpy(synth.normalish(3, 1, (B, mlp[2] + 3, L)).astype(np.float32)).to(dev).contiguous()
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        sdg = {k: v.clone().to(dev) for k, v in sd.items()}
+        plist = []
+        for j in (1, 2, 3):
+            plist += [sdg["m.conv%d.0.weight" % j], sdg["m.conv%d.1.weight" % j], sdg["m.conv%d.1.bias" % j]]
+        bufs = ([sdg["m.conv%d.1.running_mean" % j] for j in (1, 2, 3)], [sdg["m.conv%d.1.running_var" % j] for j in (1, 2, 3)],
+                [sdg["m.conv%d.1.num_batches_tracked" % j] for j in (1, 2, 3)])
+        pool = pf.WorkspacePool()
+        feat, idx, cnt, ws, desc, keep = pf._forward_impl(pool, (float(dist), int(K), True, 1e-5, 0.1), pc.to(dev), ref.to(dev),
+                                                          one_hot.to(dev), bufs, plist, True)
+        Wc, gs, bs = keep[0], keep[1], keep[2]
+        dW = [torch.empty_like(w) for w in Wc]
+        dg = [torch.empty_like(g) for g in gs]
+        db = [torch.empty_like(b) for b in bs]
+        params = pf._params_struct(Wc, gs, bs, [None] * 3, [None] * 3, [None] * 3)
+        arr = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
+        if two_streams:
+            side, _evs, evarr, _s3 = pool.side_stream(dev)
+            rc = _native.lib().fcn_pn_backward2(ctypes.byref(desc), ctypes.byref(params), dfeat.data_ptr(), ctypes.byref(ws.c),
+                                                arr(dW), arr(dg), arr(db), _native.current_stream(dev),
+                                                ctypes.c_void_p(side.cuda_stream), evarr)
+        else:
+            rc = _native.lib().fcn_pn_backward(ctypes.byref(desc), ctypes.byref(params), dfeat.data_ptr(), ctypes.byref(ws.c),
+                                               arr(dW), arr(dg), arr(db), _native.current_stream(dev))
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        return [t.detach().cpu() for t in dW + dg + db], ws
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("case", [(3, 200, 2.5, 32, (64, 64, 128), 0.7), (4, 512, 1.0, 64, (128, 128, 256), 1.0),
+                                  (4, 512, 2.0, 128, (256, 256, 512), 2.0), (2, 130, 0.5, 64, (128, 128, 256), 0.4)],
+                         ids=lambda c: "B%d_C%d-K%d" % (c[0], c[4][2], c[3]))
+@pytest.mark.parametrize("two_streams", [False, True], ids=["one_stream", "two_streams"])
+def test_tail_launch_gives_bit_identical_gradients(case, two_streams):
+    """fcn_pn_ws.partial_both = 2: both weight gradients' reduces (and, on one stream, the layer-1 finalisation) as roles of ONE launch
+    at the tail of the chain (pn_tail_kernel) against GEMM and reduce in alternation (partial_both = 0).  The same reduce on the
+    same partials: every gradient of the scale agrees BIT FOR BIT, on one stream and with the weight gradients on a second."""
+    ref, ws0 = _scale_backward(case, {"FCN_PN_TAIL": "0", "FCN_PN_MID": "0"}, two_streams)
+    got, ws1 = _scale_backward(case, {"FCN_PN_TAIL": "1", "FCN_PN_MID": "0"}, two_streams)
+    assert int(ws0.c.partial_both) == 0 and int(ws1.c.partial_both) == 2
+    for a, b in zip(ref, got):
+        assert torch.isfinite(a).all() and float(a.abs().max()) > 0
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("case", [(3, 200, 2.5, 32, (64, 64, 128), 0.7), (4, 512, 1.0, 64, (128, 128, 256), 1.0),
                                   (4, 512, 2.0, 128, (256, 256, 512), 2.0)], ids=lambda c: "C%d-K%d" % (c[4][2], c[3]))
 def test_merged_mid_launch_gives_bit_identical_gradients(case):
@@ -147,6 +212,7 @@ def test_merged_mid_launch_gives_bit_identical_gradients(case):
     try:
         for mode in ("0", "1"):
             os.environ["FCN_PN_MID"] = mode
+            os.environ["FCN_PN_TAIL"] = "0"
             sdg = {k: v.clone().to(dev) for k, v in sd.items()}
             plist = []
             for j in (1, 2, 3):
@@ -170,6 +236,7 @@ def test_merged_mid_launch_gives_bit_identical_gradients(case):
             out[mode] = [t.detach().cpu() for t in dW + dg + db]
     finally:
         os.environ.pop("FCN_PN_MID", None)
+        os.environ.pop("FCN_PN_TAIL", None)
     for a, b in zip(out["0"], out["1"]):
         assert torch.isfinite(a).all() and float(a.abs().max()) > 0
         assert torch.equal(a, b)
