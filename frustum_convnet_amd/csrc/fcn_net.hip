@@ -837,9 +837,13 @@ static_assert(CGB_KH == CGB_KH_ && CGB_LDW == CGB_LDW_ && CG_CMAX == CG_CMAX_ &&
 // 16-deep kb-major chunk images of the backward data-gradient role (gemm_tile.h "kb-major", two k-blocks instead of four):
 // [plane][2 k-blocks][LDR] u32x4 -- a fragment is ONE ds_read_b128 per operand part (the k-major dword layout needed four
 // ds_read_b32), and the weight operand arrives PRE-ENCODED (CgLayer.Wgrd, cg_pack_kernel) as plain 16-byte copies.
+// LDR: the staging of the dy operand is a ds_write_b64 per lane -- 16-lane groups of 4 rows x (2 k-blocks x 2 halves), 32 banks for
+// stores (MI355X_MICROARCH.md, LDS table): the two k-blocks of a group must sit 16 banks apart, 4 * LDR = 16 (mod 32).  With the
+// T + 2 of the 32-deep images (4 k-blocks, 8 banks apart) the k-blocks of a 32-row tile were 8 apart and every group wrote
+// 2-way: SQ_LDS_BANK_CONFLICT 10.5 / 11.7 % of the backward kernels' LDS cycles (profiles/r04_final_pmc_sq_summary.txt).
 template <int T>
 struct Kb16 {
-    static constexpr int LDR = T + KB_PAD;
+    static constexpr int LDR = T + (T % 8 == 0 ? 4 : KB_PAD);
     static constexpr int U4 = 4 * LDR;         // u32x4 per chunk (2 planes x 2 k-blocks)
 };
 template <int MM, int LDR>
