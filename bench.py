@@ -338,7 +338,7 @@ def cpu_baseline(batch, npoint, cfg_name):
             "variants": variants, "host_cpus": ncpu, "seconds_spent": round(spent(), 1)}
 
 
-def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=None, npoint=None):
+def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=None, npoint=None, force_optim=None):
     """Builds the model + flat train state for one configuration, captures the step into hipGraph(s), warms up and times
     rounds * steps replays inside ONE barrier + synchronize bracket.  Returns a dict with the timing and the live objects
     (model / state / data) the roofline table needs."""
@@ -355,7 +355,7 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
     # moments are flat buffers: the backward kernels write the gradients in place, the exchange is a bucketed all-reduce
     # and the step one streaming kernel (capturable: step counter and hyper-parameters live on the device).
     state = FlatTrainState(model, lr=1e-3, weight_decay=1e-4, world=world)
-    optim = not a.no_optim
+    optim = (not a.no_optim) if force_optim is None else bool(force_optim)
     data = make_data(cfg_name, batch, npoint, 1234 + rank, dev)
     # FCN_BENCH_SPLIT_STEP=1: the N > 1 form of the step (three graphs, Adam at the head of the first, the all-reduce calls -- no-ops
     # in a world of one) with ONE rank: what a rank's step costs on this box without its collectives, beside the N = 1 line
@@ -641,7 +641,7 @@ def measure_inference(cfg_name, batch, dev, min_time=0.35, prec="split"):
             "timed_steps": n, "timed_seconds": round(wall, 4)}
 
 
-def other_configs(a, dev, min_time=0.3):
+def other_configs(a, dev, min_time=0.3, car_flops=None):
     out = []
     for cfg_name, prec, npt in OTHER_CONFIGS:
         try:
@@ -651,6 +651,15 @@ def other_configs(a, dev, min_time=0.3):
                         "value": round(m["batch"] / (m["ms_per_step"] / 1e3), 2), "unit": "frustums/s",
                         "ms_per_step": round(m["ms_per_step"], 4), "timed_steps": m["nstep"],
                         "timed_seconds": round(m["wall"], 4), "final_loss": round(m["final_loss"], 5)})
+            if cfg_name == "car" and prec.startswith("bf16") and car_flops:
+                # BASELINE.json configs[1] ("1xMI355X bf16"): one bf16 MFMA per product -- executed FLOPs of the step (entry-space
+                # rows, real channels: the headline's table) against the dense bf16 MFMA peak
+                tf = car_flops / (m["ms_per_step"] * 1e-3) / 1e12
+                out[-1]["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": round(tf / PEAK_16BIT_MFMA_TFLOPS, 4), "flops_executed_per_step": car_flops,
+                                       "note": ("bf16 operands, fp32 storage: BASELINE config 2's bf16 line" if prec == "bf16ops" else
+                                                "bf16 operands AND bf16 storage of the big intermediates: slower than fp32 storage on MI355X "
+                                                "(8-byte loads, 2-byte stores; DESIGN.md section 6) -- kept as the literal reading of config 2")}
             del m
         except Exception as e:  # noqa
             out.append({"cfg": cfg_name, "precision": prec, "error": "%s: %s" % (type(e).__name__, e)})
@@ -695,6 +704,7 @@ def main():
     if rank != 0:
         return
     Ls = m["Ls"]
+    car_flops = None
     out = {
         "metric": "frustums/sec (train fwd+bwd) %s B=%d N=%d" % (
             {"car": "KITTI-car", "people": "KITTI-people", "refine": "KITTI-refine", "sunrgbd": "SUN-RGBD"}[a.cfg], a.batch, npoint),
@@ -761,6 +771,7 @@ def main():
                 rows.append({"entry": "fcn_query_depth_point_f32", "error": "%s: %s" % (type(e).__name__, e)})
             rl["kernels"] = rows
             out["roofline"] = rl
+            car_flops = float(sum(r.get("flops_executed", 0.0) for r in rows)) if a.cfg == "car" else None
         except Exception as e:  # noqa
             out["roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if world == 1:
@@ -780,7 +791,20 @@ def main():
         del model, state, data, graphs, m
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
-        out["configs"] = other_configs(a, dev)
+        # the optimiser-EXCLUSIVE figure SURVEY 8d defines the metric on (forward + loss + backward; `value` above also holds the
+        # Adam step, i.e. more work): the same graph-replay measurement without the optimiser launch, on this box
+        try:
+            mx = measure(a, a.cfg, prec, 20, 10, 0.5, dev, 0, 1, npoint=npoint, force_optim=False)
+            out["fwd_bwd_excl_optimizer"] = {"value": round(mx["batch"] / (mx["ms_per_step"] / 1e3), 2), "unit": "frustums/s",
+                                             "ms_per_step": round(mx["ms_per_step"], 4), "timed_steps": mx["nstep"],
+                                             "note": "forward + loss + backward of the same step, no optimiser launch (SURVEY 8d's timed "
+                                                     "region); `value` / `ms_per_step` of this line include the Adam step"}
+            del mx
+        except Exception as e:  # noqa
+            out["fwd_bwd_excl_optimizer"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        out["configs"] = other_configs(a, dev, car_flops=car_flops)
         fprec.set_precision(prec)
     if world == 1 and not a.no_cpu_baseline:
         try:
