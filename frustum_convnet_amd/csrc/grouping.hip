@@ -15,6 +15,58 @@
 #endif
 #define QDP_LDS_MAX_PTS 16384      // z staged in LDS up to this many points (64 KiB), else read through L1/L2
 
+typedef int64_t __attribute__((address_space(1))) *qdp_grow;
+typedef int32_t __attribute__((address_space(1))) *qdp_gcnt;
+
+// The walk of query_depth_point_cuda_kernel.cu:40-64 for the FOUR windows of a wave at once: a 64-point chunk of the z row is read
+// once and tested against the four centres (four ballots), so the loop overhead and the LDS read are shared and the four
+// compactions interleave.  Per window exactly the reference's sequence: hits in index order, the first `nsample` kept, the rest of the
+// row padded with the first hit (zeros for an empty window), cnt = min(hits, nsample).
+__device__ __forceinline__ void qdp_scan4(const float *zs, const float *pz, int64_t pt_stride, int use_lds, int n, int m, int mi0,
+                                          const float *cz, int64_t ct_stride, float dis_z, int nsample, int64_t *idx_b, int32_t *cnt_b,
+                                          int lane)
+{
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    float z2[4];
+    qdp_grow row[4];
+    int c[4], first[4];
+    bool live[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int mi = mi0 + 4 * q;                                // wave-uniform
+        live[q] = mi < m;
+        z2[q] = live[q] ? cz[(int64_t)mi * ct_stride] : 0.f;
+        row[q] = (qdp_grow)(idx_b + (int64_t)(live[q] ? mi : 0) * nsample);
+        c[q] = live[q] ? 0 : nsample;
+        first[q] = 0;
+    }
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        if (c[0] >= nsample && c[1] >= nsample && c[2] >= nsample && c[3] >= nsample) break;
+        const int k = k0 + lane;
+        float z1 = 0.f;
+        if (k < n) z1 = use_lds ? zs[k] : pz[(int64_t)k * pt_stride];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool hit = (k < n) && c[q] < nsample && (fabsf(z2[q] - z1) < dis_z);
+            const unsigned long long mask = __ballot(hit);
+            if (mask != 0ull) {
+                if (c[q] == 0) first[q] = k0 + (int)__ffsll((long long)mask) - 1;
+                const int pos = c[q] + (int)__popcll(mask & lt_mask);
+                if (hit && pos < nsample) row[q][pos] = (int64_t)k;
+                c[q] += (int)__popcll(mask);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (!live[q]) continue;
+        const int taken = c[q] < nsample ? c[q] : nsample;
+        const int64_t pad = taken > 0 ? (int64_t)first[q] : (int64_t)0;
+        for (int j = taken + lane; j < nsample; j += 64) row[q][j] = pad;
+        if (lane == 0) ((qdp_gcnt)cnt_b)[mi0 + 4 * q] = taken;
+    }
+}
+
 __global__ __launch_bounds__(QDP_THREADS) void qdp_kernel(
     const float *__restrict__ pts_z, int64_t pt_stride, int64_t pt_bstride,
     const float *__restrict__ ctr_z, int64_t ct_stride, int64_t ct_bstride,
@@ -30,32 +82,9 @@ __global__ __launch_bounds__(QDP_THREADS) void qdp_kernel(
         for (int i = tid; i < n; i += QDP_THREADS) zs[i] = pz[(int64_t)i * pt_stride];
         __syncthreads();
     }
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int q = 0; q < QDP_WPB / 4; ++q) {
-        const int mi = blockIdx.x * QDP_WPB + q * 4 + wave;          // wave-uniform
-        if (mi >= m) break;
-        const float z2 = ctr_z[(int64_t)b * ct_bstride + (int64_t)mi * ct_stride];
-        int64_t *row = idx + ((int64_t)b * m + mi) * nsample;
-        int c = 0;
-        int first = 0;
-        for (int k0 = 0; k0 < n && c < nsample; k0 += 64) {
-            const int k = k0 + lane;
-            float z1 = 0.f;
-            if (k < n) z1 = use_lds ? zs[k] : pz[(int64_t)k * pt_stride];
-            const bool hit = (k < n) && (fabsf(z2 - z1) < dis_z);
-            const unsigned long long mask = __ballot(hit);
-            if (mask != 0ull) {
-                if (c == 0) first = k0 + (int)__ffsll((long long)mask) - 1;
-                const int pos = c + (int)__popcll(mask & lt_mask);
-                if (hit && pos < nsample) row[pos] = (int64_t)k;
-                c += (int)__popcll(mask);
-            }
-        }
-        const int taken = c < nsample ? c : nsample;
-        const int64_t pad = taken > 0 ? (int64_t)first : (int64_t)0;
-        for (int j = taken + lane; j < nsample; j += 64) row[j] = pad;
-        if (lane == 0) cnt[(int64_t)b * m + mi] = taken;
-    }
+    static_assert(QDP_WPB == 16, "a wave takes four windows, a workgroup sixteen");
+    qdp_scan4(zs, pz, pt_stride, use_lds, n, m, blockIdx.x * QDP_WPB + wave, ctr_z + (int64_t)b * ct_bstride, ct_stride, dis_z, nsample,
+              idx + (int64_t)b * m * nsample, cnt + (int64_t)b * m, lane);
 }
 
 extern "C" int fcn_query_depth_point_f32(const float *pts_z, int64_t pt_stride, int64_t pt_bstride,
@@ -121,32 +150,8 @@ __global__ __launch_bounds__(QDP_THREADS) void qdp_multi_kernel(const float *__r
             ctr_z = a.ctr_z[q]; ct_stride = a.ct_stride[q]; ct_bstride = a.ct_bstride[q]; idx = a.idx[q]; cnt = a.cnt[q];
             m = a.m[q]; nsample = a.nsample[q]; blk0 = a.blk0[q]; dis_z = a.dis_z[q];
         }
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int q = 0; q < QDP_WPB / 4; ++q) {
-        const int mi = ((int)blockIdx.x - blk0) * QDP_WPB + q * 4 + wave;          // wave-uniform
-        if (mi >= m) break;
-        const float z2 = ctr_z[(int64_t)b * ct_bstride + (int64_t)mi * ct_stride];
-        int64_t *row = idx + ((int64_t)b * m + mi) * nsample;
-        int c = 0;
-        int first = 0;
-        for (int k0 = 0; k0 < n && c < nsample; k0 += 64) {         // (the same walk as qdp_kernel: .cu:40-64)
-            const int k = k0 + lane;
-            float z1 = 0.f;
-            if (k < n) z1 = use_lds ? zs[k] : pz[(int64_t)k * pt_stride];
-            const bool hit = (k < n) && (fabsf(z2 - z1) < dis_z);
-            const unsigned long long mask = __ballot(hit);
-            if (mask != 0ull) {
-                if (c == 0) first = k0 + (int)__ffsll((long long)mask) - 1;
-                const int pos = c + (int)__popcll(mask & lt_mask);
-                if (hit && pos < nsample) row[pos] = (int64_t)k;
-                c += (int)__popcll(mask);
-            }
-        }
-        const int taken = c < nsample ? c : nsample;
-        const int64_t pad = taken > 0 ? (int64_t)first : (int64_t)0;
-        for (int j = taken + lane; j < nsample; j += 64) row[j] = pad;
-        if (lane == 0) cnt[(int64_t)b * m + mi] = taken;
-    }
+    qdp_scan4(zs, pz, pt_stride, use_lds, n, m, ((int)blockIdx.x - blk0) * QDP_WPB + wave, ctr_z + (int64_t)b * ct_bstride, ct_stride, dis_z,
+              nsample, idx + (int64_t)b * m * nsample, cnt + (int64_t)b * m, lane);
 }
 
 extern "C" int fcn_query_depth_point_multi_f32(int nscale, const float *pts_z, int64_t pt_stride, int64_t pt_bstride,
