@@ -105,9 +105,18 @@ def test_train_eval_parity(case):
                     # 1.2e-3 of the tensor's max from fp64 at full size (SUN-RGBD pointnet5.conv3, where plain fp32 reaches 5e-6)
                     # while its NORM stays within the 3e-4 bar above.  Ceiling 2e-3; the exact-fp32 operand mode is held to the
                     # tight bar by test_full_size_gradients_in_the_exact_fp32_mode below.
-                    assert e64 <= max(1e-4, 3.0 * r32, 2e-3), (k, e64, r32, "elementwise vs the fp64 oracle")
-                # (full-size fixtures: the split mode's elementwise ceiling of 2e-3 on cancellation-heavy tensors, see above)
-                rel = 2e-3 if ("grad64::" + k[6:]) in g.files else 1e-3
+                    # Round 5: the ceiling is back at SURVEY App. B's 1e-3 on every BASELINE configuration (car, people, refine:
+                    # measured <= 5.3e-4 where the reference's own fp32 error is smaller than that); 2e-3 stays for exactly the two
+                    # SUN-RGBD tensors measured above 1e-3 (pointnet5.conv3.0.weight 1.16e-3: 3e5-slot sum through bf16 x 3 operands;
+                    # conv_net.block5_merge.1.weight 1.44e-3: a BatchNorm gamma gradient behind the 2048-deep data-gradient
+                    # reduction of block5_deconv) -- profiles/r05_n_fullsize_elementwise.txt lists every tensor
+                    cap = 2e-3 if (case.startswith("sunrgbd") and k[6:] in ("feat_net.pointnet5.conv3.0.weight",
+                                                                             "conv_net.block5_merge.1.weight")) else 1e-3
+                    assert e64 <= max(1e-4, 3.0 * r32, cap), (k, e64, r32, "elementwise vs the fp64 oracle")
+                rel = 1e-3
+                if ("grad64::" + k[6:]) in g.files and case.startswith("sunrgbd") and k[6:] in ("feat_net.pointnet5.conv3.0.weight",
+                                                                                                 "conv_net.block5_merge.1.weight"):
+                    rel = 2e-3
                 assert np.abs(gr - ref).max() <= rel * np.abs(ref).max() + 1e-7 + extra, k
     sd = m.state_dict()
     off = 0
