@@ -378,6 +378,19 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
     skip_comm = world > 1 and os.environ.get("FCN_SKIP_COMM", "0") == "1"      # rehearsal: the step without its collectives
     steps_per_graph = 1
 
+    # FCN_ADAM_LATE=1: only the PointNet bucket's optimiser step (13 % of the parameters) stays on the chain between the backward and
+    # the next forward; the [ConvFeatNet + heads] bucket's runs on the packing branch of that forward, in front of the weight packing
+    # -- the first thing that reads its result
+    late = os.environ.get("FCN_ADAM_LATE", "1") == "1" and world == 1 and optim and len(state.buckets) == 2
+    if late:
+        model._cn_pool.before_pack = lambda: state.adam_step_bucket(0)
+
+    def opt_step():
+        if late:
+            state.adam_step_bucket(1)
+        else:
+            state.adam_step()
+
     pf_point = os.environ.get("FCN_PF_POINT", "fcn_fwd")
     spg = max(2, 2 * (int(os.environ.get("FCN_STEPS_PER_GRAPH", "2")) // 2))      # whole steps per captured graph (even)
 
@@ -403,7 +416,7 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
             loss = fwd_bwd()
             state.allreduce()
             if optim:
-                state.adam_step()
+                opt_step()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     if use_graph:
@@ -473,7 +486,7 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
                     for _ in range(spg if prefetch else 1):
                         loss = fwd_bwd()
                         if world == 1 and optim:
-                            state.adam_step()
+                            opt_step()
                 glist.append(g)
                 steps_per_graph = spg if prefetch else 1
                 graphs = (tuple(glist),)
@@ -558,6 +571,10 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
     wall = float(tt.item())
     nstep = even(rounds * steps)
+    if late:                                          # the last step's [ConvFeatNet + heads] update, which the next forward would have run
+        model._cn_pool.before_pack = None
+        state.adam_step_bucket(0)
+        torch.cuda.synchronize()
     Ls = [data["center_ref%d" % i].shape[2] for i in range(1, 6) if ("center_ref%d" % i) in data]
     comm = None
     if world > 1:
@@ -590,7 +607,7 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
     return {"model": model, "state": state, "data": data, "graphs": graphs, "overlap": overlap, "optim": optim, "comm": comm,
             "rounds": rounds, "nstep": nstep, "wall": wall, "ms_per_step": wall * 1e3 / nstep,
             "gpu_event_ms_per_step": e0.elapsed_time(e1) / nstep, "final_loss": float(loss.item()),
-            "steps_per_graph": steps_per_graph, "prefetch": prefetch,
+            "steps_per_graph": steps_per_graph, "prefetch": prefetch, "late_adam": late,
             "batch": batch, "npoint": npoint, "Ls": Ls}
 
 
@@ -742,7 +759,8 @@ def main():
                    "launch": ((("hipGraph replay x%d per step (Adam at the head of the first), %d workspace sets" % (3 if graphs[0][2] is not None else 2, len(graphs))) if overlap else
                                ("hipGraph replay x%d" % len(graphs)) + (", %d steps per replay" % m["steps_per_graph"] if m["steps_per_graph"] > 1 else ""))
                               if graphs is not None else "eager") +
-                             (", next batch's grouping front prefetched beside the backward (double-buffered workspaces)" if m["prefetch"] else "")},
+                             (", next batch's grouping front prefetched beside the backward (double-buffered workspaces)" if m["prefetch"] else "") +
+                             (", the [ConvFeatNet + heads] bucket's Adam step on the next forward's weight-packing branch" if m.get("late_adam") else "")},
         "gpu_event_ms_per_step": round(gpu_event_ms, 4),
         "final_loss": round(final_loss, 5),
     }

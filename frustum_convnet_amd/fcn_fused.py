@@ -302,6 +302,11 @@ def convnet_prepack(pool, conv_net, cls_out, reg_out, B, Ls, one_hot, device, af
     else:
         side.wait_stream(cur)
     with torch.cuda.stream(side):
+        # a step loop may hang work in FRONT of the packing, on its stream (bench.py FCN_ADAM_LATE: the optimiser step of the
+        # [ConvFeatNet + heads] bucket, whose result nothing reads before this packing)
+        cb = getattr(pool, "before_pack", None)
+        if cb is not None:
+            cb()
         pre = _prepare(pool, cfgt, bufs, one_hot, B, list(Ls), device, pt)
         with torch.cuda.device(device):
             _native.check(_native.lib().fcn_convnet_pack(ctypes.byref(pre["desc"]), ctypes.byref(pre["params"]),
