@@ -54,11 +54,14 @@ class Workspace:
         self.cnt = torch.empty((B, L), dtype=i32, device=dev)           # window hit counts of the fused grouping
         self.wenc = torch.empty((2 * (C2 * C1 + C3 * C2),), dtype=f32, device=dev)      # split-encoded conv2 / conv3 weights
         self.flags = flags if flags is not None else torch.zeros((1,), dtype=i32, device=dev)      # sticky FCN_FLAG_* bits
-        # max-pool keys of conv3's epilogue (fcn_pn_ws.pkey, zero between launches).  Measured on one MI355X:
-        # +6 % for the eval-mode forward (y3 is neither written nor re-read), but -0.5...-1.5 % for the training step -- so by
-        # default only workspaces that no backward will read get the key buffer; FCN_POOL_KEYS=1 / 0 forces it on / off.
+        # max-pool keys of conv3's epilogue (fcn_pn_ws.pkey, zero between launches): the pooling pass that re-reads y3 is replaced by
+        # a pass over the (B, L, C3) keys.  Measured on MI355X: +6 % for the eval-mode forward (y3 is neither written nor
+        # re-read).  For the TRAINING step round 3 measured it 0.5...1.5 % slower; behind rounds 4-5's changes it is 0.5 % (car), 1 %
+        # (people), 2 % (SUN-RGBD) FASTER -- the PointNet forward phase ends 15 us earlier, the whole GPU suite passes with it -- and
+        # 0.75 % slower on the refine configuration (L = 20 ... 3: the key pass is one more small launch on a chain of small
+        # launches): keys by default from 65 536 window slots per scale up, FCN_POOL_KEYS=1 / 0 forces them on / off.
         mode = os.environ.get("FCN_POOL_KEYS")
-        use_keys = mode == "1" or (mode not in ("0", "1") and not need_grad)
+        use_keys = mode == "1" or (mode not in ("0", "1") and (not need_grad or B * L * K >= 65536))
         self.pkey = torch.zeros((B, L, C3), dtype=torch.int64, device=dev) if use_keys else None
         self.amax = self.gmax = self.dy3 = self.dz2 = self.bstat = self.coef = self.partial = None
         self.nsplit = 0
