@@ -26,6 +26,52 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
         if (rc__ != 0) return rc__;                \
     } while (0)
 
+// ---- single-instruction forms of staging arithmetic hipcc does not select on its own.  The operand path of the GEMMs (BatchNorm
+// + ReLU + split encode per element, row addresses per load) is VALU-issue-bound: 157 vector instructions per six MFMAs in the FCN
+// forward's K loop before these (tools/loophist.py on the ISA).  The host emulation of tests/ (no inline asm there: FCN_HOST_EMU)
+// compiles the plain C++ restatement beside each.
+// relu(y) where `keep` (+inf: the element counts) or 0 (it is padding): v_med3_f32 instead of v_max_f32 + v_cndmask.  A NaN comes
+// out as 0, as fmaxf(NaN, 0) does (the producer has raised the workspace's sticky flag for it).
+__device__ __forceinline__ float fcn_relu_keep(float y, float keep) { return __builtin_amdgcn_fmed3f(y, 0.f, keep); }
+__device__ __forceinline__ float fcn_keep(bool ok) { return ok ? __builtin_inff() : 0.f; }
+// a * b + c on the 24-bit integer multiplier (v_mad_u32_u24: full rate; the 32-bit multiplies hipcc emits for row addresses
+// -- v_mad_u64_u32 -- are quarter rate).  a, b < 2^24 and the true result < 2^32; b wave-uniform (one SGPR operand).
+__device__ __forceinline__ unsigned fcn_mad24(unsigned a, unsigned b, unsigned c)
+{
+#ifdef FCN_HOST_EMU
+    return a * b + c;
+#else
+    unsigned d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
+    return d;
+#endif
+}
+
+// a wave-uniform value as an opaque SGPR value (no code, not a scheduling barrier): hipcc cannot fold it back into a per-lane select
+__device__ __forceinline__ int fcn_opaque_sgpr(int v)
+{
+#ifndef FCN_HOST_EMU
+    asm("" : "+s"(v));
+#endif
+    return v;
+}
+
+// an LDS pointer as an opaque VGPR value (no code): two pointers that differ by a constant become two BASES for hipcc's
+// read-merging pass, which pairs only reads off one base (gemm_tile.h mma_chunk).  The pointer keeps its LDS address space (a
+// generic pointer behind an asm would be read with flat loads).
+#ifdef FCN_HOST_EMU
+typedef const uint32_t *fcn_lds_u32p;
+__device__ __forceinline__ fcn_lds_u32p fcn_opaque_lds(const uint32_t *p) { return p; }
+#else
+typedef const uint32_t __attribute__((address_space(3))) *fcn_lds_u32p;
+__device__ __forceinline__ fcn_lds_u32p fcn_opaque_lds(const uint32_t *p)
+{
+    fcn_lds_u32p q = (fcn_lds_u32p)p;
+    asm("" : "+v"(q));
+    return q;
+}
+#endif
+
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -186,14 +186,17 @@ __device__ __forceinline__ v4f cg_load_raw(const CgGeo &L, const float *x, int C
 {
     const int lin = l * L.stride + tap - L.pad;
     ok = rvalid && lin >= 0 && lin < L.Lin;
-    const int lc = min(max(lin, 0), L.Lin - 1) * linmul;
-    // 32-bit element offset (cn_make_plan checks B * L * C < 2^31 for every arena): an unsigned offset off a wave-uniform base
-    // is the SGPR-base + VGPR-offset form of global_load -- no 64-bit multiply / add per load
-    const unsigned e = (unsigned)((b * Lsrc + lc) * C + kc);
+    // linmul is wave-uniform: the upper clamp is a scalar, and pinned as one (hipcc otherwise turns it back into a per-lane select)
+    const int lc = min(max(lin, 0), fcn_opaque_sgpr((L.Lin - 1) * linmul));
     if constexpr (St<MM>::half) {
-        if (s16) return lds4e<MM>(x, e);             // a layer output (bf16 arena); pooled features / one-hot stay fp32
+        // a layer output (bf16 arena); pooled features / one-hot stay fp32
+        if (s16) return lds4e<MM>(x, (unsigned)((b * Lsrc + lc) * C + kc));
     }
-    return ldg4(x + e);
+    // 32-bit BYTE offset off the wave-uniform base (cn_make_plan checks B * L * C < 2^30 for every arena) -- the SGPR-base +
+    // VGPR-offset form of global_load -- from two full-rate 24-bit multiply-adds (rows < 2^23, C < 2^22): the 64-bit
+    // multiply-adds and the 64-bit shift-add hipcc emits for the element-index form were 6 quarter-rate-class instructions per load
+    const unsigned eb = fcn_mad24(fcn_mad24((unsigned)b, (unsigned)Lsrc, (unsigned)lc), (unsigned)(4 * C), (unsigned)(4 * kc));
+    return *(gv4fp)((const char *)x + eb);
 }
 
 // 1 / sqrt(x) in fp64 from the fp32 rsqrt + three Newton steps (full double accuracy, x > 0 and within float range -- a
@@ -271,6 +274,8 @@ __device__ __forceinline__ void cg_fill_bn(LP Lp, float *sS, float *tS, int tid,
 }
 
 __device__ __forceinline__ float cg_act(float s, float x, float t, bool ok) { return ok ? fmaxf(fmaf(s, x, t), 0.f) : 0.f; }
+// the same with the row's mask as fcn_keep(ok): one v_fma_f32 + one v_med3_f32 per element
+__device__ __forceinline__ float cg_actk(float s, float x, float t, float keep) { return fcn_relu_keep(fmaf(s, x, t), keep); }
 
 // ------------------------------------------------------------------------------------------------
 // K-group kernels: one workgroup of G groups of MW x WNC waves owns one (32*MW) x (32*WNC) output tile; group g reduces
@@ -350,13 +355,20 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     for (int i = 0; i < NB; ++i) { rw0[i] = u32x4{0u, 0u, 0u, 0u}; rw1[i] = u32x4{0u, 0u, 0u, 0u}; }
     // weight image item f = gt + TG * i of a chunk: column f % TNC, (plane, k-block) row f / TNC -- 16-byte pieces, lane-linear
     // in global memory and in LDS (pre-encoded by cg_pack_kernel: no VALU on this operand)
-    const u32x4 *wsrc = LWenc + n0;
+    // (byte offsets: 32-bit, the chunk's part of the address added to the SGPR base -- no vector address arithmetic per load)
+    unsigned woff[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int f = gt + TG * i;
+        woff[i] = (unsigned)((f / TNC) * LCout + (f % TNC)) * 16u;
+    }
+    const char *wsrc = (const char *)(LWenc + n0);
     // (macros, not lambdas: the by-reference closure of a lambda called from several places is not always scalarised
     // by hipcc and drags every captured variable into scratch)
     // the chunk (hence the segment) is uniform within a K-group, i.e. within every wave: scalar selects
 #define CGK_FWD_LOAD(cc, RA, RW, OK)                                                                                  \
     {                                                                                                                 \
-        const int c__ = (cc);                                                                                         \
+        const int c__ = __builtin_amdgcn_readfirstlane(cc);                                                           \
         CGK_FWD_LOAD_AT(c__, __builtin_amdgcn_readfirstlane(cSeg[c__]), __builtin_amdgcn_readfirstlane(cTap[c__]),    \
                         __builtin_amdgcn_readfirstlane(cK0[c__]), RA, RW, OK);                                        \
     }
@@ -371,18 +383,20 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                                \
             RA[i] = cg_load_raw<MM>(geo, x, C, Ls, ty ? 0 : 1, tap, k0 + 4 * kq, bb[i], ll[i], rv[i], OK[i], h16);    \
         if (!((FCN_XF & 2) && c_ >= 2 * G))                                                                           \
-        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                              \
-            const int f = gt + TG * i;                                                                                \
-            RW[i] = ldgu4(wsrc + (unsigned)((c_ * 8 + f / TNC) * LCout + (f % TNC)));                                 \
+        {                                                                                                             \
+            const char *wc_ = wsrc + (size_t)(unsigned)(c_ * 8 * LCout) * 16u;                                        \
+            _Pragma("unroll") for (int i = 0; i < NB; ++i) RW[i] = *(gu4p)(wc_ + woff[i]);                            \
         }                                                                                                             \
     }
 #define CGK_FWD_STAGE(c_, RA, RW, OK)                                                                                 \
     {                                                                                                                 \
         const v4f sp = *(const v4f *)(sS + (c_) * KC + 4 * kq), tp = *(const v4f *)(tS + (c_) * KC + 4 * kq);         \
-        _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                                \
-            kb_store4<MM_ENC_A, LDRA>(Ab, rb + RSTEP * i, kq, cg_act(sp.x, RA[i].x, tp.x, OK[i]),                      \
-                                      cg_act(sp.y, RA[i].y, tp.y, OK[i]), cg_act(sp.z, RA[i].z, tp.z, OK[i]),         \
-                                      cg_act(sp.w, RA[i].w, tp.w, OK[i]));                                            \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                              \
+            const float kp = fcn_keep(OK[i]);                                                                         \
+            kb_store4<MM_ENC_A, LDRA>(Ab, rb + RSTEP * i, kq, cg_actk(sp.x, RA[i].x, tp.x, kp),                        \
+                                      cg_actk(sp.y, RA[i].y, tp.y, kp), cg_actk(sp.z, RA[i].z, tp.z, kp),             \
+                                      cg_actk(sp.w, RA[i].w, tp.w, kp));                                              \
+        }                                                                                                             \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                              \
             const int f = gt + TG * i;                                                                                \
             Bb[(f / TNC) * LDRB + (f % TNC)] = RW[i];                                                                 \
@@ -411,10 +425,10 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         int sg_, tap_, k0_, so_;
         const int ca = min(g, nchunk - 1), cb = min(g + G, nchunk - 1);
         cg_locate_s(geo, C0, C1, C2, C3, ca * KC, sg_, tap_, k0_, so_);
-        CGK_FWD_LOAD_AT(ca, __builtin_amdgcn_readfirstlane(sg_), __builtin_amdgcn_readfirstlane(tap_),
+        CGK_FWD_LOAD_AT(__builtin_amdgcn_readfirstlane(ca), __builtin_amdgcn_readfirstlane(sg_), __builtin_amdgcn_readfirstlane(tap_),
                         __builtin_amdgcn_readfirstlane(k0_), ra0, rw0, ok0);
         cg_locate_s(geo, C0, C1, C2, C3, cb * KC, sg_, tap_, k0_, so_);
-        CGK_FWD_LOAD_AT(cb, __builtin_amdgcn_readfirstlane(sg_), __builtin_amdgcn_readfirstlane(tap_),
+        CGK_FWD_LOAD_AT(__builtin_amdgcn_readfirstlane(cb), __builtin_amdgcn_readfirstlane(sg_), __builtin_amdgcn_readfirstlane(tap_),
                         __builtin_amdgcn_readfirstlane(k0_), ra1, rw1, ok1);
     }
     PROBE_STAMP();                                      // 1: first loads issued
@@ -953,7 +967,7 @@ __device__ __forceinline__ void cg_dgrad_body(const LT &L, const CT &cb, const f
     const int kq = lane & 3, rb = lane >> 2;            // dy: 4 column quads x 16 rows per pass
     constexpr int RSTEP = 16;
     const bool hasbn = cbstat != nullptr;
-    int bb[NA], li[NA];
+    int bL[NA], li[NA];                                 // bL: first output row of the source row's frustum
     bool rv[NA], ok[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -961,7 +975,7 @@ __device__ __forceinline__ void cg_dgrad_body(const LT &L, const CT &cb, const f
         rv[i] = gr < Rs;
         int q_ = 0, r_ = 0;
         cg_divmod(rv[i] ? gr : 0, SLsrc, cg_inv(SLsrc), q_, r_);           // (Rs < 2^23: cn_make_plan)
-        bb[i] = q_;
+        bL[i] = q_ * LLout;
         li[i] = r_;
         rv[i] = rv[i] && li[i] < LLin;
         ok[i] = false;
@@ -998,13 +1012,14 @@ __device__ __forceinline__ void cg_dgrad_body(const LT &L, const CT &cb, const f
             const int lq = (Lstride == 2) ? (t_ >> 1) : t_;                                                          \
             ok[i] = rv[i] && t_ >= 0 && ((Lstride == 2) ? ((t_ & 1) == 0) : true) && lq < LLout;                    \
             const int lo = min(max(lq, 0), LLout - 1);                                                               \
-            const unsigned o = (unsigned)((bb[i] * LLout + lo) * LCout + nb + 4 * kq);                              \
+            /* 32-bit byte offset off the scalar base, one full-rate 24-bit multiply-add (see cg_load_raw) */         \
+            const unsigned ob = fcn_mad24((unsigned)(bL[i] + lo), (unsigned)(4 * LCout), (unsigned)(4 * (nb + 4 * kq))); \
             if (St<MM>::half && dz16) {                                                                               \
-                rz[i] = lds4e<MM>(dzc, o);                                                                            \
-                ry[i] = lds4e<MM>(hasbn ? yc : dzc, o);                                                               \
+                rz[i] = lds4e<MM>(dzc, ob >> 2);                                                                      \
+                ry[i] = lds4e<MM>(hasbn ? yc : dzc, ob >> 2);                                                         \
             } else {                                                                                                  \
-                rz[i] = ldg4(dzc + o);                     /* unconditional (clamped row), masked at store time */    \
-                ry[i] = ldg4((hasbn ? yc : dzc) + o);                                                                 \
+                rz[i] = *(gv4fp)((const char *)dzc + ob);  /* unconditional (clamped row), masked at store time */    \
+                ry[i] = *(gv4fp)((const char *)(hasbn ? yc : dzc) + ob);                                              \
             }                                                                                                         \
         }                                                                                                             \
         if (!((FCN_XG & 2) && xg_later))                                                                              \
@@ -1265,13 +1280,13 @@ __device__ __forceinline__ void cg_wgrad_body(const AT &a, int wid, float *smem)
         const int r0_ = (rr);                                                                                         \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                               \
             const int row = min(r0_ + 2 * pa + i, rend - 1);    /* clamped: unconditional loads, masked at store */   \
-            const unsigned o = (unsigned)(row * LCout + n0 + 4 * cqa);                                               \
+            const unsigned ob = fcn_mad24((unsigned)row, (unsigned)(4 * LCout), (unsigned)(4 * (n0 + 4 * cqa)));     \
             if (St<MM>::half && adz16) {                                                                              \
-                rz[i] = lds4e<MM>(adz, o);                                                                            \
-                ry[i] = lds4e<MM>(hasbn ? Ly : adz, o);                                                               \
-            } else {                                                                                                  \
-                rz[i] = ldg4(adz + o);                                                                                \
-                ry[i] = ldg4((hasbn ? Ly : adz) + o);                                                                 \
+                rz[i] = lds4e<MM>(adz, ob >> 2);                                                                      \
+                ry[i] = lds4e<MM>(hasbn ? Ly : adz, ob >> 2);                                                         \
+            } else {                 /* byte offset off the scalar base: see cg_load_raw */                           \
+                rz[i] = *(gv4fp)((const char *)adz + ob);                                                             \
+                ry[i] = *(gv4fp)((const char *)(hasbn ? Ly : adz) + ob);                                              \
             }                                                                                                         \
         }                                                                                                             \
         _Pragma("unroll") for (int p2 = 0; p2 < 2; ++p2) {                                                            \
@@ -1329,29 +1344,29 @@ __device__ __forceinline__ void cg_wgrad_body(const AT &a, int wid, float *smem)
             const v4f as = *(const v4f *)abp, at = *(const v4f *)(abp + 64);
             v4f hi, lo;
             enc2x4<MM_ENC_A>(dv2[0], dv2[1], hi, lo);
-            sts4(As + (2 * pa) * LDW + 4 * cqa, hi);
-            sts4(As + (2 * pa + 1) * LDW + 4 * cqa, lo);
+            sts4(As + mma_row_hi<KH>(pa) * LDW + 4 * cqa, hi);          // rows (2 pa, 2 pa + 1) = pair pa: gemm_tile.h "pair-plane" order
+            sts4(As + mma_row_lo<KH>(pa) * LDW + 4 * cqa, lo);
 #pragma unroll
             for (int p2 = 0; p2 < 2; ++p2) {
                 if (FCN_XG & 2048) {            // (timing build: the activation operand as plain 16-byte copies -- a pre-encoded image's cost)
                     // (masked to small finite 16-bit halves: raw fp32 bits read as bf16 pairs would turn the weights into NaN)
                     v4i m0 = __builtin_bit_cast(v4i, rx[2 * p2]) & 0x3f7f3f7f, m1 = __builtin_bit_cast(v4i, rx[2 * p2 + 1]) & 0x3f7f3f7f;
-                    sts4(Bs + (2 * (pb + 4 * p2)) * LDN + 4 * cqb, __builtin_bit_cast(v4f, m0));
-                    sts4(Bs + (2 * (pb + 4 * p2) + 1) * LDN + 4 * cqb, __builtin_bit_cast(v4f, m1));
+                    sts4(Bs + mma_row_hi<KH>(pb + 4 * p2) * LDN + 4 * cqb, __builtin_bit_cast(v4f, m0));
+                    sts4(Bs + mma_row_lo<KH>(pb + 4 * p2) * LDN + 4 * cqb, __builtin_bit_cast(v4f, m1));
                     continue;
                 }
                 v4f av2[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int q = 2 * p2 + i;
-                    const bool live = ok[q] && (r0 + 2 * (pb + 4 * p2) + i) < rend;
-                    v4f av = {cg_act(as.x, rx[q].x, at.x, live), cg_act(as.y, rx[q].y, at.y, live),
-                              cg_act(as.z, rx[q].z, at.z, live), cg_act(as.w, rx[q].w, at.w, live)};
+                    const float live = fcn_keep(ok[q] && (r0 + 2 * (pb + 4 * p2) + i) < rend);
+                    v4f av = {cg_actk(as.x, rx[q].x, at.x, live), cg_actk(as.y, rx[q].y, at.y, live),
+                              cg_actk(as.z, rx[q].z, at.z, live), cg_actk(as.w, rx[q].w, at.w, live)};
                     av2[i] = av;
                 }
                 enc2x4<MM_ENC_A>(av2[0], av2[1], hi, lo);
-                sts4(Bs + (2 * (pb + 4 * p2)) * LDN + 4 * cqb, hi);
-                sts4(Bs + (2 * (pb + 4 * p2) + 1) * LDN + 4 * cqb, lo);
+                sts4(Bs + mma_row_hi<KH>(pb + 4 * p2) * LDN + 4 * cqb, hi);
+                sts4(Bs + mma_row_lo<KH>(pb + 4 * p2) * LDN + 4 * cqb, lo);
             }
         }
         __builtin_amdgcn_wave_barrier();        // (compiler only) the stores above before the operand reads of every lane
@@ -1628,11 +1643,11 @@ static int cn_make_plan(const fcn_cn_desc *d, CnPlan &P)
         P.cin_tot[l] = ct;
         // LDS tables of the kernels: per-column BN scale/shift, per-chunk descriptors, BN-backward coefficients
         if (P.Ktot[l] > CG_KMAX || P.KT[l] * P.N[l] > CG_KBWD || P.Cs[l] > CG_CMAX || P.KT[l] > 3 || P.stride[l] > 2) return FCN_E_LIMIT;
-        // the kernels address every arena with 32-bit element offsets and divide row indices through a float reciprocal
+        // the kernels address every arena with 32-bit BYTE offsets and divide row indices through a float reciprocal
         // (cg_divmod: exact below 2^23): rows of a layer, elements of its input / output / packed weights
         const int64_t rows = (int64_t)d->B * (P.Lout[l] > P.Lin[l] ? P.Lout[l] : P.Lin[l]);
-        if (rows >= ((int64_t)1 << 23) || rows * (P.N[l] > cs ? P.N[l] : cs) >= ((int64_t)1 << 31) ||
-            (int64_t)P.N[l] * P.Ktot[l] >= ((int64_t)1 << 31)) return FCN_E_LIMIT;
+        if (rows >= ((int64_t)1 << 23) || rows * (P.N[l] > cs ? P.N[l] : cs) >= ((int64_t)1 << 30) ||
+            (int64_t)P.N[l] * P.Ktot[l] >= ((int64_t)1 << 30)) return FCN_E_LIMIT;
     }
     return 0;
 }

@@ -66,7 +66,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // values (k even, k + 1) of one row/column share two dwords: row k holds the packed HI parts {hi(x_k), hi(x_k+1)},
 // row k + 1 the packed LO parts -- exactly the register image of a 32x32x16 operand (lane (l&31, l>>5) holds
 // k = 8*(l>>5) .. +7 as four dwords), so the MFMA loop reads its operands with plain ds_read_b32 and no VALU.
-// enc2 turns such a pair into the two dwords to store (5 VALU per pair: v_cvt_pk, 2 unpack, v_pk_add, v_cvt_pk).
+// enc2 turns such a pair into the two dwords to store.  fp16 parts: THREE instructions per pair -- v_cvt_pk_f16_f32, then
+// v_fma_mixlo_f16 / v_fma_mixhi_f16, which read the fp16 hi part and the fp32 value, form x - hi in fp32 (exact) and round it to
+// fp16 into one half of the destination: the same bits as the unpack / subtract / convert sequence hipcc emits for the C++ form
+// (six instructions per pair).  bf16 parts: v_cvt_pk_bf16_f32, two masks, two subtractions, v_cvt_pk_bf16_f32.
 template <int MM>
 __device__ __forceinline__ void enc2(float x0, float x1, float &o0, float &o1)
 {
@@ -75,9 +78,18 @@ __device__ __forceinline__ void enc2(float x0, float x1, float &o0, float &o1)
     } else if constexpr (MM == MM_F16X3) {
         const f32x2 x = {x0, x1};
         const f16x2 h = __builtin_convertvector(x, f16x2);
+        o0 = __builtin_bit_cast(float, h);
+#ifdef FCN_HOST_EMU
         const f32x2 r = {x0 - (float)h[0], x1 - (float)h[1]};          // exact
         const f16x2 l = __builtin_convertvector(r, f16x2);
-        o0 = __builtin_bit_cast(float, h); o1 = __builtin_bit_cast(float, l);
+        o1 = __builtin_bit_cast(float, l);
+#else
+        const uint32_t hb = __builtin_bit_cast(uint32_t, h);
+        uint32_t lb;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hb), "v"(x0));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lb) : "v"(hb), "v"(x1));
+        o1 = __builtin_bit_cast(float, lb);
+#endif
     } else {
         const f32x2 x = {x0, x1};
         const bf16x2 h = __builtin_convertvector(x, bf16x2);
@@ -129,15 +141,26 @@ __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c)
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// One KCH-deep chunk (KC unless stated): As is [KCH][LDA] (m fastest), Bs is [KCH][LDB] (n fastest).
+// One KCH-deep chunk (KC unless stated) of the weight-gradient GEMMs, whose reduction runs over ROWS of row-major operands: As is
+// [KCH][LDA] (m fastest), Bs is [KCH][LDB] (n fastest), "pair-plane" order -- the two reduction-adjacent rows (2p, 2p + 1) of pair p
+// sit at LDS row p (split modes: the packed HI parts of the pair; MM_F32: row 2p) and at LDS row KCH/2 + p (the packed LO parts;
+// MM_F32: row 2p + 1).  mma_row_hi / mma_row_lo give the two LDS rows to the staging code.  The four dwords of one MFMA operand
+// part are then NEIGHBOURING LDS rows: hipcc merges neighbouring reads into ds_read2_b32 and its two results are the two
+// registers the operand wants next to each other (with the hi and lo row of a pair interleaved -- rows 2p, 2p + 1 -- every merged
+// read delivered one register each to two different operands: 50 v_mov_b32 per 24 MFMAs in the PointNet weight-gradient loop).
+template <int KCH>
+__device__ __forceinline__ constexpr int mma_row_hi(int pair) { return pair; }
+template <int KCH>
+__device__ __forceinline__ constexpr int mma_row_lo(int pair) { return KCH / 2 + pair; }
 template <int MM, int MT, int NT, int LDA, int LDB, int KCH = KC>
 __device__ __forceinline__ void mma_chunk(const float *As, const float *Bs, int arow0, int bcol0,
                                           f32x16 (&acc)[MT][NT]) {
     const int lane = threadIdx.x & 63;
     const int l31 = lane & 31, lh = lane >> 5;
     if constexpr (MM == MM_F32) {
-        const float *ap = As + lh * LDA + arow0 + l31;
-        const float *bp = Bs + lh * LDB + bcol0 + l31;
+        // k-step kk (even) multiplies rows kk + lh: LDS row kk/2 of plane lh
+        const float *ap = As + lh * (KCH / 2) * LDA + arow0 + l31;
+        const float *bp = Bs + lh * (KCH / 2) * LDB + bcol0 + l31;
         // operands of k-step kk+2 are fetched from LDS before the MFMAs of k-step kk issue, so the ds_read latency
         // hides behind 4 x 64 cycles of matrix work instead of stalling every step on lgkmcnt(0)
         float a[2][MT], b[2][NT];
@@ -150,9 +173,9 @@ __device__ __forceinline__ void mma_chunk(const float *As, const float *Bs, int 
             const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
             if (kk + 2 < KCH) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i) a[nxt][i] = ap[(kk + 2) * LDA + i * 32];
+                for (int i = 0; i < MT; ++i) a[nxt][i] = ap[((kk + 2) >> 1) * LDA + i * 32];
 #pragma unroll
-                for (int j = 0; j < NT; ++j) b[nxt][j] = bp[(kk + 2) * LDB + j * 32];
+                for (int j = 0; j < NT; ++j) b[nxt][j] = bp[((kk + 2) >> 1) * LDB + j * 32];
             }
             __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE this step's MFMAs (hipcc otherwise sinks it)
 #pragma unroll
@@ -163,10 +186,15 @@ __device__ __forceinline__ void mma_chunk(const float *As, const float *Bs, int 
             __builtin_amdgcn_sched_barrier(0);
         }
     } else {
-        // 32x32x16: lane (l31, lh) supplies k = 8*lh + 0..7 of row/column l31 -- LDS rows 8*lh + {0,2,4,6} (hi pairs) and
-        // 8*lh + {1,3,5,7} (lo pairs) of the step, each a conflict-free ds_read_b32 (32 consecutive dwords per half-wave)
-        const uint32_t *ap = (const uint32_t *)As + (8 * lh) * LDA + arow0 + l31;
-        const uint32_t *bp = (const uint32_t *)Bs + (8 * lh) * LDB + bcol0 + l31;
+        // 32x32x16: lane (l31, lh) supplies k = 8*lh + 0..7 of row/column l31 -- the pairs 4*lh + {0,1,2,3} of the step: four
+        // neighbouring LDS rows of the hi plane, four of the lo plane, each a conflict-free read of 32 consecutive dwords per half-wave
+        // (one opaque base per 32-column block: off a COMMON base hipcc pairs the reads of two blocks' same row -- 32 dwords apart,
+        // nearer than the next row -- and again every merged read feeds two operands)
+        fcn_lds_u32p ap[MT], bp[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) ap[i] = fcn_opaque_lds((const uint32_t *)As + (4 * lh) * LDA + arow0 + l31 + i * 32);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bp[j] = fcn_opaque_lds((const uint32_t *)Bs + (4 * lh) * LDB + bcol0 + l31 + j * 32);
         constexpr bool X3 = !mm_x1<MM>;
 #pragma unroll
         for (int ks = 0; ks < KCH; ks += 16) {
@@ -175,15 +203,15 @@ __device__ __forceinline__ void mma_chunk(const float *As, const float *Bs, int 
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    ah[i][q] = ap[(ks + 2 * q) * LDA + i * 32];
-                    if constexpr (X3) al[i][q] = ap[(ks + 2 * q + 1) * LDA + i * 32];
+                    ah[i][q] = ap[i][mma_row_hi<KCH>(ks / 2 + q) * LDA];
+                    if constexpr (X3) al[i][q] = ap[i][mma_row_lo<KCH>(ks / 2 + q) * LDA];
                 }
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    bh[j][q] = bp[(ks + 2 * q) * LDB + j * 32];
-                    if constexpr (X3) bl[j][q] = bp[(ks + 2 * q + 1) * LDB + j * 32];
+                    bh[j][q] = bp[j][mma_row_hi<KCH>(ks / 2 + q) * LDB];
+                    if constexpr (X3) bl[j][q] = bp[j][mma_row_lo<KCH>(ks / 2 + q) * LDB];
                 }
             // small cross terms first, then the hi.hi product; term-major so consecutive MFMAs hit different accumulators
             if constexpr (X3) {

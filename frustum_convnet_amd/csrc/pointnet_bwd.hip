@@ -539,9 +539,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
             const int rr = min(WG_AROW(i), lastr);
-            const int o = (g0 + rr) * COUT + n0 + 4 * acq;
+            const int o = (int)fcn_mad24((unsigned)(g0 + rr), (unsigned)COUT, (unsigned)(n0 + 4 * acq));      // (rows < 2^24: launch_wgrad)
             if constexpr (RC) {
-                const int om = (bl + rwin[i]) * COUT + n0 + 4 * acq;
+                const int om = (int)fcn_mad24((unsigned)(bl + rwin[i]), (unsigned)COUT, (unsigned)(n0 + 4 * acq));
                 ra2[i] = ld4f<MM>(a.ycur, o);
                 rm[i] = ldg4i(a.amax + om);
                 const v4f g4 = ldg4(a.gmax + om);
@@ -561,7 +561,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {
             const int rr = min(WG_BROW(i), lastr);
-            if constexpr (LAYER == 3) rb4[i] = ld4f<MM>(a.yprev, (g0 + rr) * CIN + k0 + 4 * bcq);
+            if constexpr (LAYER == 3) rb4[i] = ld4f<MM>(a.yprev, (int)fcn_mad24((unsigned)(g0 + rr), (unsigned)CIN, (unsigned)(k0 + 4 * bcq)));
             else rb4[i] = a.ent[g0 + rr];
         }
     };
@@ -604,33 +604,33 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
 #pragma unroll
         for (int i = 0; i < 2 * MT; i += 2) {
             v4f hi, lo;
-            enc2x4<MM_ENC_A>(sa[i], sa[i + 1], hi, lo);
-            sts4(As + WG_AROW(i) * LDA + 4 * acq, hi);
-            sts4(As + WG_AROW(i + 1) * LDA + 4 * acq, lo);
+            enc2x4<MM_ENC_A>(sa[i], sa[i + 1], hi, lo);               // rows (2p, 2p + 1) = pair p: gemm_tile.h "pair-plane" order
+            sts4(As + mma_row_hi<KC>(WG_AROW(i) >> 1) * LDA + 4 * acq, hi);
+            sts4(As + mma_row_lo<KC>(WG_AROW(i) >> 1) * LDA + 4 * acq, lo);
         }
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {
             const int rr = WG_BROW(i);
-            const bool ok = rr < left;
+            const float kp = fcn_keep(rr < left);         // ReLU + row mask as one v_med3_f32 per element
             float o[4];
             if constexpr (LAYER == 3) {
                 const float yv[4] = {rb4[i].x, rb4[i].y, rb4[i].z, rb4[i].w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = fmaxf(fmaf(bs[j], yv[j], bt[j]), 0.f);
+                for (int j = 0; j < 4; ++j) o[j] = fcn_relu_keep(fmaf(bs[j], yv[j], bt[j]), kp);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    o[j] = fmaxf(l1_pre(bal[j], bt[j], rb4[i].x, rb4[i].y, rb4[i].z), 0.f);
+                    o[j] = fcn_relu_keep(l1_pre(bal[j], bt[j], rb4[i].x, rb4[i].y, rb4[i].z), kp);
             }
             v4f ov = {o[0], o[1], o[2], o[3]};
-            sb[i] = ok ? ov : zero4();
+            sb[i] = ov;
         }
 #pragma unroll
         for (int i = 0; i < 2 * NT; i += 2) {
             v4f hi, lo;
             enc2x4<MM_ENC_A>(sb[i], sb[i + 1], hi, lo);
-            sts4(Bs + WG_BROW(i) * LDB + 4 * bcq, hi);
-            sts4(Bs + WG_BROW(i + 1) * LDB + 4 * bcq, lo);
+            sts4(Bs + mma_row_hi<KC>(WG_BROW(i) >> 1) * LDB + 4 * bcq, hi);
+            sts4(Bs + mma_row_lo<KC>(WG_BROW(i) >> 1) * LDB + 4 * bcq, lo);
         }
         PNP_ADD(2);                               // 2: wait for the loads + operand transform + LDS stores
         __syncthreads();
@@ -863,6 +863,7 @@ static int plan_wgrad(const WgradArgs &a, int B, int nsplit_cap, WgradPlan &P)
 #endif
     const int slots = (LAYER == 2 && P.m2 && P.n2) ? (FCN_WG_SLOTS * 2) / 3 : FCN_WG_SLOTS;
     if ((int64_t)B * a.cap * (a.COUT > a.CIN ? a.COUT : a.CIN) >= (int64_t)1 << 31) return FCN_E_LIMIT;   // 32-bit offsets
+    if ((int64_t)B * a.cap >= (int64_t)1 << 24) return FCN_E_LIMIT;                                        // 24-bit row multiplies
     int nsplit = slots / (P.oy * P.oz);
     if (nsplit < (B * a.tps + WG_TMAX - 1) / WG_TMAX) nsplit = (B * a.tps + WG_TMAX - 1) / WG_TMAX;      // tiles per split <= WG_TMAX
     if (nsplit < 1) nsplit = 1;

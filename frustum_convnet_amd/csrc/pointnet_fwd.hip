@@ -358,6 +358,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
     float ux = 0.f, uy = 0.f, uz = 0.f;
     const int r0 = tid % TM;
     const bool r0valid = r0 < nvalid;
+    const float r0keep = fcn_keep(r0valid);
     if (MODE == 0 && r0valid) {
         const float4 e = a.ent[grow0 + r0];
         ux = e.x; uy = e.y; uz = e.z;
@@ -375,10 +376,10 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
             for (int i = 0; i < NA4; ++i) {
                 const int f = tid + NTHR * i;
                 const int r = f >> 3, kq = f & 7;
-                const bool ok = r < nvalid;
+                const float kp = fcn_keep(r < nvalid);          // (loop-invariant) ReLU + row mask as ONE v_med3_f32 per element
                 const v4f s4 = *(const v4f *)(sS + c * KC + 4 * kq), t4 = *(const v4f *)(tS + c * KC + 4 * kq);
-                const float z0 = ok ? fmaxf(fmaf(s4.x, ra[i].x, t4.x), 0.f) : 0.f, z1 = ok ? fmaxf(fmaf(s4.y, ra[i].y, t4.y), 0.f) : 0.f;
-                const float z2 = ok ? fmaxf(fmaf(s4.z, ra[i].z, t4.z), 0.f) : 0.f, z3 = ok ? fmaxf(fmaf(s4.w, ra[i].w, t4.w), 0.f) : 0.f;
+                const float z0 = fcn_relu_keep(fmaf(s4.x, ra[i].x, t4.x), kp), z1 = fcn_relu_keep(fmaf(s4.y, ra[i].y, t4.y), kp);
+                const float z2 = fcn_relu_keep(fmaf(s4.z, ra[i].z, t4.z), kp), z3 = fcn_relu_keep(fmaf(s4.w, ra[i].w, t4.w), kp);
                 kb_store4<MM_ENC_A, LDRA>(Aq, r, kq, z0, z1, z2, z3);
             }
         } else {
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(MT == 
                 for (int j = 0; j < 8; ++j) {
                     const int kk = c * KC + 8 * kb + j;
                     const float zz = l1_pre(&sS[3 * kk], tS[kk], ux, uy, uz);
-                    z[j] = r0valid ? fmaxf(zz, 0.f) : 0.f;
+                    z[j] = fcn_relu_keep(zz, r0keep);
                 }
                 u32x4 hi, lo;
                 enc8<MM_ENC_A>(z, hi, lo);

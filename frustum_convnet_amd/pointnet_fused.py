@@ -163,7 +163,8 @@ def _acquire(pool, cfgt, pc, ref, one_hot, bufs, plist, need_grad):
     params = _params_struct(Wc, gs, bs, rmeans, rvars, nbts)
     oh = None if (one_hot is None or nlc) else one_hot.detach().contiguous().float()
     return {"ws": ws, "desc": desc, "params": params, "Wc": Wc, "gs": gs, "bs": bs, "oh": oh, "nlc": nlc, "nvec": nvec,
-            "ref": ref, "dist": float(dist), "dims": (B, Lw, C3), "dev": dev}
+            "ref": ref, "dist": float(dist), "dims": (B, Lw, C3), "dev": dev,
+            "bufs": bufs}       # (the C struct holds raw pointers to the running statistics: the handle keeps their tensors alive)
 
 
 def _run_forward(h, cnt, idx):

@@ -373,6 +373,14 @@ template <class T>
 inline T emu_atomic_load(const T *p) { T t; __atomic_load(const_cast<T *>(p), &t, __ATOMIC_SEQ_CST); return t; }
 #define __hip_atomic_store(p, v, order, scope) emu_atomic_store((p), (v))
 #define __hip_atomic_load(p, order, scope) emu_atomic_load((p))
+#define FCN_HOST_EMU 1                                  // the kernel sources compile their C++ restatement of inline-asm helpers
+// v_med3_f32 (IEEE mode): a NaN operand makes it min3 over the others' ordering (fminf drops the NaN)
+inline float emu_fmed3f(float a, float b, float c)
+{
+    if (a != a || b != b || c != c) return fminf(fminf(a, b), c);
+    return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));
+}
+#define __builtin_amdgcn_fmed3f(a, b, c) emu_fmed3f((a), (b), (c))
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))           // v_rcp_f32 (1 ulp on the GPU; only used where a correction step follows)

@@ -59,6 +59,7 @@ CASES = [
     ("test_gpu_group_compact", "test_group_compact_matches_oracle_and_unfused", (3, 700, (0.1, 0.2, 0.4, 0.8), "uniform")),
     ("test_gpu_group_compact", "test_group_compact_matches_oracle_and_unfused", (2, 130, (2.0, 2.0, 4.0, 8.0), "car")),
     ("test_gpu_group_compact", "test_phased_front_is_bit_identical_to_the_fused_front", (4, 512, (0.25, 0.5, 1.0, 2.0))),
+    ("test_gpu_group_compact", "test_forward_weight_images_hold_the_fp16_split_bit_for_bit", ()),
     # (B4_N512_s0.25_K32_C128 of gpu_stage_check.CASES is left to the hardware: with the emulation's accumulation order ONE
     # pre-ReLU activation of that draw lands on the other side of zero -- DESIGN.md section 5 on ReLU kinks)
     ("test_gpu_pointnet", "test_stages", ((2, 128, 3.5, 16, (64, 64, 128), 1.0),)),

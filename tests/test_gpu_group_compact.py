@@ -191,3 +191,46 @@ def test_prefetched_front_gives_the_same_training_steps():
         assert torch.equal(la, lb) and torch.equal(ta, tb)
     for k in runs[0][1]:
         assert torch.equal(runs[0][1][k], runs[1][1][k]), k
+
+
+def test_forward_weight_images_hold_the_fp16_split_bit_for_bit():
+    """The fp16 x 3 operand encode (gemm_tile.h enc2: v_cvt_pk_f16_f32 + v_fma_mixlo / v_fma_mixhi) is hi = rne16(x),
+    lo = rne16(x - hi) -- the arithmetic DESIGN.md states and the host emulation restates in C++: the conv2 / conv3 forward images
+    packed on the GPU (pn_pack.h layout: [Cin/32][plane][4 k-blocks][Cout] u32x4, dword q = the pair (8kb + 2q, 8kb + 2q + 1))
+    against numpy, bit for bit, on weights that cover fp16's normal, subnormal and overflow-free range, both signs, exact fp16
+    values (lo = 0) and values whose residual is itself subnormal."""
+    from frustum_convnet_amd import pointnet_fused as pf
+    B, N, strides = 4, 512, (0.25, 0.5, 1.0, 2.0)
+    data = synth.make_batch(B, N, strides=strides, seed=5, variant="car", tilt=(0.01, 0.05))
+    pc = torch.from_numpy(data["point_cloud"]).cuda()
+    pools = [pf.WorkspacePool() for _ in range(4)]
+    handles, weights = [], []
+    rng = np.random.default_rng(11)
+    for s in range(4):
+        ref = torch.from_numpy(data["center_ref%d" % (s + 1)]).cuda()
+        plist, bufs = _params(MLP[s], 40 + s)
+        for li in (1, 2):                       # conv2, conv3: magnitudes 2^-30 .. 2^15, a tenth of them exact fp16 numbers
+            W = plist[3 * li]
+            mag = np.exp2(rng.uniform(-30.0, 15.0, size=tuple(W.shape))).astype(np.float32)
+            x = (mag * rng.choice([-1.0, 1.0], size=mag.shape)).astype(np.float32)
+            exact = rng.random(mag.shape) < 0.1
+            x[exact] = x[exact].astype(np.float16).astype(np.float32)
+            x.flat[:4] = [0.0, -0.0, 65504.0, -6.0e-8]
+            W.copy_(torch.from_numpy(x))
+        weights.append([plist[3].cpu().numpy(), plist[6].cpu().numpy()])
+        cfgt = (float(strides[s]), NS[s], True, 1e-5, 0.1, False, True)
+        handles.append(pf._acquire(pools[s], cfgt, pc, ref, None, bufs, plist, False))
+    pf.group_compact(handles, pc)
+    torch.cuda.synchronize()
+    for s in range(4):
+        C1, C2, C3 = MLP[s]
+        raw = handles[s]["ws"].wenc.cpu().numpy().view(np.uint16)           # 2 halves per float
+        off = 0
+        for W, (COUT, CIN) in zip(weights[s], ((C2, C1), (C3, C2))):
+            img = raw[2 * off: 2 * (off + COUT * CIN)].reshape(CIN // 32, 2, 4, COUT, 8)      # [c][plane][kb][n][8 halves]
+            off += COUT * CIN
+            x = W.reshape(COUT, CIN // 32, 4, 8).transpose(1, 2, 0, 3)                         # [c][kb][n][j]
+            hi = x.astype(np.float16)
+            lo = (x - hi.astype(np.float32)).astype(np.float16)
+            assert np.array_equal(img[:, 0], hi.view(np.uint16)), (s, COUT, "hi")
+            assert np.array_equal(img[:, 1], lo.view(np.uint16)), (s, COUT, "lo")
