@@ -56,6 +56,16 @@ __device__ __forceinline__ int fcn_opaque_sgpr(int v)
     return v;
 }
 
+// a 32-bit per-lane value as an opaque VGPR value (no code) at the point of use: a loop-invariant byte offset is otherwise
+// zero-extended ONCE outside the loop and every load then adds a 64-bit VGPR pair to its base (v_lshl_add_u64) instead of taking
+// the SGPR-base + 32-bit-VGPR-offset addressing mode
+__device__ __forceinline__ unsigned fcn_opaque_v32(unsigned v)
+{
+#ifndef FCN_HOST_EMU
+    asm("" : "+v"(v));
+#endif
+    return v;
+}
 // an LDS pointer as an opaque VGPR value (no code): two pointers that differ by a constant become two BASES for hipcc's
 // read-merging pass, which pairs only reads off one base (gemm_tile.h mma_chunk).  The pointer keeps its LDS address space (a
 // generic pointer behind an asm would be read with flat loads).

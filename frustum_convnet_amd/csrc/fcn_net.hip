@@ -184,7 +184,7 @@ template <int MM>
 __device__ __forceinline__ v4f cg_load_raw(const CgGeo &L, const float *x, int C, int Lsrc, int linmul, int tap,
                                            int kc, int b, int l, bool rvalid, bool &ok, int s16 = 0)
 {
-    const int lin = l * L.stride + tap - L.pad;
+    const int lin = (int)fcn_mad24((unsigned)l, (unsigned)L.stride, (unsigned)(tap - L.pad));     // (l >= 0; wraps like the int form)
     ok = rvalid && lin >= 0 && lin < L.Lin;
     // linmul is wave-uniform: the upper clamp is a scalar, and pinned as one (hipcc otherwise turns it back into a per-lane select)
     const int lc = min(max(lin, 0), fcn_opaque_sgpr((L.Lin - 1) * linmul));
@@ -1054,17 +1054,27 @@ __device__ __forceinline__ void cg_dgrad_body(const LT &L, const CT &cb, const f
         if (!((FCN_XG & 4) && it > 0))
         {
             const int chb = __builtin_amdgcn_readfirstlane(cCh[c]) + 4 * kq;     // BN channel of this thread's first column
+            // the five coefficients of the thread's four channels as 16-byte LDS reads, ONE branch on hasbn per chunk (per element
+            // they were 40 ds_read_b32 and 8 branches in front of 6 MFMAs); the operation order is cg_dy's
+            v4f f0 = zero4(), f1 = zero4(), f2 = zero4(), f3 = zero4(), f4 = zero4();
+            if (hasbn) {
+                const float *cp = coefS + chb;          // (16-byte aligned: coefS, Cs and chb are multiples of 4 floats)
+                f0 = *(const v4f *)cp; f1 = *(const v4f *)(cp + Cs); f2 = *(const v4f *)(cp + 2 * Cs);
+                f3 = *(const v4f *)(cp + 3 * Cs); f4 = *(const v4f *)(cp + 4 * Cs);
+            }
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int r = rb + RSTEP * i;
-                float d[4] = {rz[i].x, rz[i].y, rz[i].z, rz[i].w};
-                const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (hasbn) d[j] = cg_dy(coefS, Cs, chb + j, d[j], yv[j]);
-                    d[j] = ok[i] ? d[j] : 0.f;
+                v4f d = rz[i];
+                if (hasbn) {
+                    const v4f xh = (ry[i] - f1) * f2;
+                    v4f m;
+                    m.x = fmaf(xh.x, f4.x, f3.x); m.y = fmaf(xh.y, f4.y, f3.y);
+                    m.z = fmaf(xh.z, f4.z, f3.z); m.w = fmaf(xh.w, f4.w, f3.w);
+                    d = f0 * (d - m);
                 }
-                kb16_store4<MM_ENC_A, LDRA>(Ai, r, kq, d[0], d[1], d[2], d[3]);
+                d = ok[i] ? d : zero4();
+                kb16_store4<MM_ENC_A, LDRA>(Ai, r, kq, d.x, d.y, d.z, d.w);
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) Bi[((i >> 1) * 2 + (i & 1)) * LDRB + lane] = rw[i];

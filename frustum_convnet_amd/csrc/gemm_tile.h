@@ -274,6 +274,25 @@ __device__ __forceinline__ void sts1e(float *base, int64_t e, float v)
     if constexpr (St<MM>::half) ((__bf16 *)base)[e] = (__bf16)v;
     else base[e] = v;
 }
+// The same through a WAVE-UNIFORM base pointer (kept in SGPRs: kernel arguments, tile coordinates) plus a 32-bit per-lane BYTE
+// offset -- the SGPR-base + VGPR-offset form of global_load: no 64-bit vector add per load (the element-index forms above cost a
+// v_lshl_add_u64 each; the PointNet data-gradient loop issued 16 of them per 12 MFMAs).  st_ptr advances a base by elements.
+template <int MM>
+__device__ __forceinline__ const float *st_ptr(const float *base, int64_t e)
+{
+    return (const float *)((const char *)base + e * St<MM>::bytes);
+}
+template <int MM>
+__device__ __forceinline__ v4f lds4b(const float *sbase, unsigned boff)
+{
+    boff = fcn_opaque_v32(boff);
+    if constexpr (St<MM>::half) {
+        const bf16x4 h = *(gbf4p)((const char *)sbase + boff);
+        return __builtin_convertvector(h, v4f);
+    } else {
+        return *(gv4fp)((const char *)sbase + boff);
+    }
+}
 // what a stored value reads back as (BatchNorm sums are taken over the STORED values, so the statistics match the data)
 template <int MM>
 __device__ __forceinline__ float st_round(float v)

@@ -199,16 +199,20 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, un
     // past nvalid are zeroed when the registers go to LDS
     // 32-bit element offsets (launch_dgrad checks B * cap * max(CRED, CPREV) < 2^31): half the registers and address
     // arithmetic of int64
-    int arow[NA4];        // element offset of this thread's piece (clamped row) in a (rows, CRED) buffer
-    int wbase[NA4];       // LAYER 3: offset of the piece in its row's window of the (B, L, CRED) arg-max / routed-gradient maps
+    // Addresses = a wave-uniform base (the tile's first row / the frustum's first window, advanced by the chunk: scalar arithmetic)
+    // + a loop-invariant 32-bit byte offset per lane: no vector address arithmetic in the loop (gemm_tile.h lds4b)
+    unsigned arowB[NA4];  // byte offset of this thread's piece (clamped row) from the tile's first row in a (rows, CRED) buffer
+    unsigned wbaseB[NA4]; // LAYER 3: byte offset of the piece in its row's window from the frustum's first window of the (B, L, CRED) maps
 #pragma unroll
     for (int i = 0; i < NA4; ++i) {
         const int f = tid + NTHR * i;
         const int rc = min(f >> 3, nvalid - 1);
-        arow[i] = ((int)grow0 + rc) * CRED + 4 * (f & 7);
-        wbase[i] = 0;
-        if constexpr (MAPS) wbase[i] = (b * a.L + a.ewin[grow0 + rc]) * CRED + 4 * (f & 7);
+        arowB[i] = (unsigned)(rc * CRED + 4 * (f & 7)) * St<MM>::bytes;
+        wbaseB[i] = 0;
+        if constexpr (MAPS) wbaseB[i] = (unsigned)(a.ewin[grow0 + rc] * CRED + 4 * (f & 7)) * 4u;
     }
+    const int64_t tile0 = grow0 * CRED;                     // elements in front of the tile's first row
+    const int64_t map0 = (int64_t)b * a.L * CRED;           // elements in front of the frustum's first window
     __syncthreads();
 
     f32x16 acc[MT][NT];
@@ -217,23 +221,35 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, un
     v4i rm[NA4];
     u32x4 rw[NB];
     const int nchunk = CRED / KC;
-    const u32x4 *wsrc = a.Wenc + k0 + (tid % TN) + (int64_t)(tid / TN) * CPREV;     // item f = tid + NTHR*i: column f % TN, (plane, k-block) f / TN
+    // weight image item f = tid + NTHR*i: column f % TN, (plane, k-block) f / TN
+    unsigned woffB[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) woffB[i] = (unsigned)((tid % TN) + (tid / TN + i * (NTHR / TN)) * CPREV) * 16u;
+    const u32x4 *wsrc = a.Wenc + k0;
 
 #define DGRAD_LOAD(cc)                                                                                                \
     {                                                                                                                 \
         const int nq_ = (cc) * KC;                                                                                    \
         if (!((FCN_XB & 1) && (cc) > 0))                                                                              \
-        _Pragma("unroll") for (int i = 0; i < NA4; ++i) {                                                             \
-            ry[i] = lds4e<MM>(a.ycur, arow[i] + nq_);                                                                 \
-            if constexpr (MAPS) {                                                                                     \
-                rm[i] = ldg4i(a.amax + wbase[i] + nq_);                                                               \
-                rz[i] = ldg4(a.gmax + wbase[i] + nq_);                                                                \
-            } else {                                                                                                  \
-                rz[i] = lds4e<MM>(a.dzcur, arow[i] + nq_);                                                            \
+        {                                                                                                             \
+            const float *yb_ = st_ptr<MM>(a.ycur, tile0 + nq_);                                                       \
+            const int *mb_ = MAPS ? a.amax + map0 + nq_ : nullptr;                                                    \
+            const float *gb_ = MAPS ? a.gmax + map0 + nq_ : st_ptr<MM>(a.dzcur, tile0 + nq_);                         \
+            _Pragma("unroll") for (int i = 0; i < NA4; ++i) {                                                         \
+                ry[i] = lds4b<MM>(yb_, arowB[i]);                                                                     \
+                if constexpr (MAPS) {                                                                                 \
+                    rm[i] = *(gv4ip)((const char *)mb_ + fcn_opaque_v32(wbaseB[i]));                                  \
+                    rz[i] = *(gv4fp)((const char *)gb_ + fcn_opaque_v32(wbaseB[i]));                                  \
+                } else {                                                                                              \
+                    rz[i] = lds4b<MM>(gb_, arowB[i]);                                                                 \
+                }                                                                                                     \
             }                                                                                                         \
         }                                                                                                             \
         if (!((FCN_XB & 2) && (cc) > 0))                                                                              \
-        _Pragma("unroll") for (int i = 0; i < NB; ++i) rw[i] = ldgu4(wsrc + ((int64_t)(cc) * 8 + i * (NTHR / TN)) * CPREV); \
+        {                                                                                                             \
+            const char *wb_ = (const char *)(wsrc + (int64_t)(cc) * 8 * CPREV);                                       \
+            _Pragma("unroll") for (int i = 0; i < NB; ++i) rw[i] = *(gu4p)(wb_ + fcn_opaque_v32(woffB[i]));           \
+        }                                                                                                             \
     }
 
     PNP_ADD(0);                                   // 0: prologue (tables, coefficients, first barrier)
@@ -265,8 +281,9 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, un
                 float dz = zv[j];
                 if constexpr (MAPS) dz = (mv[j] == rloc) ? zv[j] : 0.f;
                 const float xh = (yv[j] - cfv[1][j]) * cfv[2][j];
-                const float dy = cfv[0][j] * (dz - w * fmaf(xh, cfv[4][j], cfv[3][j]));
-                dv[j] = ok ? dy : 0.f;
+                // (rows past nvalid hold a live row's values again -- the loads are clamped -- and are not zeroed: a row of this
+                // operand reaches only its own output row, which the epilogue neither stores nor counts)
+                dv[j] = cfv[0][j] * (dz - w * fmaf(xh, cfv[4][j], cfv[3][j]));
             }
             kb_store4<MM_ENC_A, LDRA>(Ab, r, kq, dv[0], dv[1], dv[2], dv[3]);
             if constexpr (LAYER == 3) {
