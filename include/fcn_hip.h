@@ -210,7 +210,8 @@ int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, const int32_t *
                    const float *one_hot, const fcn_pn_ws *ws, float *feat, void *stream);
 
 /* Backward: dfeat (B, C3+nvec, L) -> dW[3], dgamma[3], dbeta[3] (overwritten, not accumulated).  dW[1] and dW[2] must be
- * 16-byte aligned (FCN_E_BADARG otherwise): the fixed-order sum of the split partials writes 16-byte vectors. */
+ * 16-byte aligned (FCN_E_BADARG otherwise): the fixed-order sum of the split partials writes 16-byte vectors.  Size limits
+ * (FCN_E_LIMIT): B * cap * max(C2, C3) < 2^31 elements (32-bit offsets) and B * cap < 2^24 entry rows (24-bit row multiplies). */
 int fcn_pn_backward(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dfeat,
                     const fcn_pn_ws *ws, float *dW[3], float *dgamma[3], float *dbeta[3], void *stream);
 
@@ -281,7 +282,7 @@ typedef struct fcn_cn_params {
 
 /* Workspace; element counts come from fcn_convnet_sizes (out6: y/dz floats, packed-weight floats, bn floats,
  * stat/bstat doubles, coef floats, wgrad-partial floats).  Size limits (FCN_E_LIMIT from every fcn_convnet_* entry): B * L1 < 2^23
- * rows and every layer's B * L * C (and Cout * Ktot) < 2^31 elements -- the kernels address with 32-bit offsets. */
+ * rows and every layer's B * L * C (and Cout * Ktot) < 2^30 elements -- the kernels address with 32-bit BYTE offsets. */
 typedef struct fcn_cn_ws {
     float  *y, *dz, *wp, *bn;
     double *stat, *bstat;
