@@ -26,7 +26,7 @@
 #define FCN_WIDE_TILES 0
 #endif
 #ifndef FCN_DG_WIDE
-#define FCN_DG_WIDE 0         // 1 (tuning builds): 64 x 256 data-gradient tiles where the previous layer has 256 channels
+#define FCN_DG_WIDE 1         // 64 x 256 data-gradient tiles (8 waves) where the previous layer has 256 channels; 0: 64 x 128 everywhere
 #endif
 #ifndef FCN_DG2_OCC
 #define FCN_DG2_OCC 3        // waves per SIMD the 64 x 128 data-gradient tile of layer 2 is compiled for (4: 128 VGPRs + 32 B scratch)
@@ -830,11 +830,12 @@ static int launch_dgrad(const DgradArgs &a, int B, int precision, hipStream_t st
     if (a.CRED % 64 || a.CPREV % 64 || a.CRED > MAXC) return FCN_E_BADARG;
     if ((int64_t)B * a.cap * (a.CRED > a.CPREV ? a.CRED : a.CPREV) >= (int64_t)1 << 31) return FCN_E_LIMIT;   // 32-bit offsets
     const unsigned nt = (unsigned)(B * a.tps);
-#if FCN_DG_WIDE     // 64 x 256 tiles (8 waves): the dy rows of a tile are built ONCE for all 256 columns -- measured equal (231.4 vs 230.2 us
-                    // for the widest scale's backward), so not compiled into the product
+#if FCN_DG_WIDE     // 64 x 256 tiles (8 waves): the dy rows of a tile are built ONCE for all 256 columns.  Rounds 3 / 4 measured it equal
+                    // (231.4 vs 230.2 us for the widest scale's backward) and left it out; behind round 5's staging diet -- the
+                    // operand transform is what is left of the loop's vector work -- it is 1.0-1.2 % of the step (EXPERIMENTS 5.6)
     if (a.CPREV % 256 == 0) {
         FCN_MM_SWITCH(FCN_MM_OF(precision, false),
-                      hipLaunchKernelGGL((dgrad_kernel<MM, LAYER, 1, 2, 4>), dim3((2 * nt * (a.CPREV / 256) + 7) / 8 * 8), dim3(512), 0, st, a));
+                      hipLaunchKernelGGL((dgrad_kernel<MM, LAYER, 1, 2, 4, DZ3>), dim3((2 * nt * (a.CPREV / 256) + 7) / 8 * 8), dim3(512), 0, st, a));
         FCN_CHECK_LAUNCH();
         return 0;
     }
