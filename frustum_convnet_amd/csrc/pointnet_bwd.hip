@@ -28,6 +28,9 @@
 #ifndef FCN_DG_WIDE
 #define FCN_DG_WIDE 1         // 64 x 256 data-gradient tiles (8 waves) where the previous layer has 256 channels; 0: 64 x 128 everywhere
 #endif
+#ifndef FCN_WG2_OCC
+#define FCN_WG2_OCC 2        // waves per SIMD the layer-2 (and rebuilt-dy3) weight-gradient kernels are compiled for
+#endif
 #ifndef FCN_DG2_OCC
 #define FCN_DG2_OCC 3        // waves per SIMD the 64 x 128 data-gradient tile of layer 2 is compiled for (4: 128 VGPRs + 32 B scratch)
 #endif
@@ -678,7 +681,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
 }
 
 template <int MM, int LAYER, int MT, int NT, int RC = 0>
-__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu((LAYER == 3 && !RC) ? 3 : 2, 4))) void wgrad_kernel(WgradArgs a)
+__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu((LAYER == 3 && !RC) ? 3 : FCN_WG2_OCC, 4))) void wgrad_kernel(WgradArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[WgradLds<MT, NT, RC>::BYTES];
     wgrad_body<MM, LAYER, MT, NT, RC>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
