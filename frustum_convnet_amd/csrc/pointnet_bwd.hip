@@ -28,6 +28,12 @@
 #ifndef FCN_DG_WIDE
 #define FCN_DG_WIDE 1         // 64 x 256 data-gradient tiles (8 waves) where the previous layer has 256 channels; 0: 64 x 128 everywhere
 #endif
+#ifndef FCN_WG_PITCH_PAD
+#define FCN_WG_PITCH_PAD 0   // extra dwords per LDS row of the weight-gradient operand tiles (4 = the pitch of rounds 2-4 for 64*T wide tiles)
+#endif
+#ifndef FCN_WG3_OCC
+#define FCN_WG3_OCC 3        // ... and the layer-3 one (stored dy3)
+#endif
 #ifndef FCN_WG2_OCC
 #define FCN_WG2_OCC 2        // waves per SIMD the layer-2 (and rebuilt-dy3) weight-gradient kernels are compiled for
 #endif
@@ -444,7 +450,11 @@ __device__ __forceinline__ float4 ld4f(const float *base, int64_t e)
 // The window ids of a chunk's rows are fetched one chunk ahead (the map addresses depend on them).
 template <int MT, int NT, int RC>
 struct WgradLds {
-    static constexpr int LDA = 64 * MT + 4, LDB = 64 * NT + 4;
+    // Row pitch of the k-major operand tiles: a MULTIPLE OF 64 dwords -- every row of the 32-deep chunk is then within the 8-bit,
+    // 64-dword-unit offsets of ds_read2st64_b32 from ONE base register per 32-column block (with the 64*MT + 4 pitch of rounds 2-4
+    // two rows were the most a ds_read2_b32 reached: 33 v_add_u32 per chunk rebuilt bases in a loop that is vector-issue-bound)
+    static constexpr int pitch(int T) { return (64 * T + 63) / 64 * 64 + (FCN_WG_PITCH_PAD); }
+    static constexpr int LDA = pitch(MT), LDB = pitch(NT);
     static constexpr int BYTES = KC * (LDA + LDB) * 4 + (2 + (RC ? 2 : 0)) * WG_TMAX * 4;
 };
 
@@ -453,7 +463,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
                                            unsigned char *smem_)
 {
     constexpr bool XF = LAYER == 2 || RC;               // the A operand is transformed by a BatchNorm backward while staging
-    constexpr int LDA = 64 * MT + 4, LDB = 64 * NT + 4;
+    constexpr int LDA = WgradLds<MT, NT, RC>::LDA, LDB = WgradLds<MT, NT, RC>::LDB;
     float *As = (float *)smem_;
     float *Bs = As + KC * LDA;
     // (first row, live rows) of the split's row tiles, looked up ONCE: per chunk, the walk tile list -> frustum -> live-row
@@ -681,7 +691,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
 }
 
 template <int MM, int LAYER, int MT, int NT, int RC = 0>
-__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu((LAYER == 3 && !RC) ? 3 : FCN_WG2_OCC, 4))) void wgrad_kernel(WgradArgs a)
+__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu((LAYER == 3 && !RC) ? FCN_WG3_OCC : FCN_WG2_OCC, 4))) void wgrad_kernel(WgradArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[WgradLds<MT, NT, RC>::BYTES];
     wgrad_body<MM, LAYER, MT, NT, RC>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, smem);
