@@ -441,6 +441,14 @@ __device__ __forceinline__ float4 ld4f(const float *base, int64_t e)
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+// ... the same through a wave-uniform base pointer + a 32-bit per-lane byte offset (gemm_tile.h lds4b)
+template <int MM>
+__device__ __forceinline__ float4 ld4fb(const float *sbase, unsigned boff)
+{
+    const v4f v = lds4b<MM>(sbase, boff);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // dW[n][k] = sum_rows dy[row][n] * a_prev[row][k]; workgroup tile (64*MT) x (64*NT).  Split s reduces the
 // rows of live tiles [s*tpb, (s+1)*tpb) and writes one partial; wgrad_reduce sums the live partials in a fixed
 // order (deterministic, no float atomics).
@@ -566,10 +574,17 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
 #pragma unroll
             for (int i = 0; i < 2 * MT; ++i) rwin[i] = rwin_n[i];        // (requested one chunk ago)
         }
+        // the chunk's first row is wave-uniform: its part of every address goes into SCALAR base pointers, the lanes add a 32-bit
+        // byte offset inside the chunk (no 64-bit vector arithmetic per load)
+        constexpr unsigned SB = St<MM>::bytes;
+        const int g0s = __builtin_amdgcn_readfirstlane(g0);
+        const float *abase = st_ptr<MM>(LAYER == 3 ? a.dy : a.dz, (int64_t)g0s * COUT);
+        const float *ybase = st_ptr<MM>(a.ycur, (int64_t)g0s * COUT);
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
             const int rr = min(WG_AROW(i), lastr);
-            const int o = (int)fcn_mad24((unsigned)(g0 + rr), (unsigned)COUT, (unsigned)(n0 + 4 * acq));      // (rows < 2^24: launch_wgrad)
+            const int o = RC ? (int)fcn_mad24((unsigned)(g0 + rr), (unsigned)COUT, (unsigned)(n0 + 4 * acq)) : 0;      // (rows < 2^24: launch_wgrad)
+            const unsigned ob = fcn_mad24((unsigned)rr, (unsigned)COUT * SB, (unsigned)(n0 + 4 * acq) * SB);
             if constexpr (RC) {
                 const int om = (int)fcn_mad24((unsigned)(bl + rwin[i]), (unsigned)COUT, (unsigned)(n0 + 4 * acq));
                 ra2[i] = ld4f<MM>(a.ycur, o);
@@ -578,20 +593,21 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
                 ra[i] = make_float4(g4.x, g4.y, g4.z, g4.w);
                 rwt[i] = a.ent[g0 + rr].w;
             } else if constexpr (LAYER == 3) {
-                ra[i] = ld4f<MM>(a.dy, o);
+                ra[i] = ld4fb<MM>(abase, ob);
             } else {
-                ra[i] = ld4f<MM>(a.dz, o);
-                ra2[i] = ld4f<MM>(a.ycur, o);
+                ra[i] = ld4fb<MM>(abase, ob);
+                ra2[i] = ld4fb<MM>(ybase, ob);
                 rwt[i] = a.ent[g0 + rr].w;
             }
         }
         if constexpr (RC) {
             if (q + 1 < nq) load_win(q + 1);
         }
+        const float *pbase = LAYER == 3 ? st_ptr<MM>(a.yprev, (int64_t)g0s * CIN) : nullptr;
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i) {
             const int rr = min(WG_BROW(i), lastr);
-            if constexpr (LAYER == 3) rb4[i] = ld4f<MM>(a.yprev, (int)fcn_mad24((unsigned)(g0 + rr), (unsigned)CIN, (unsigned)(k0 + 4 * bcq)));
+            if constexpr (LAYER == 3) rb4[i] = ld4fb<MM>(pbase, fcn_mad24((unsigned)rr, (unsigned)CIN * SB, (unsigned)(k0 + 4 * bcq) * SB));
             else rb4[i] = a.ent[g0 + rr];
         }
     };
