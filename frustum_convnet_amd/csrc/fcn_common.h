@@ -82,6 +82,16 @@ __device__ __forceinline__ fcn_lds_u32p fcn_opaque_lds(const uint32_t *p)
 }
 #endif
 
+// dy of a BatchNorm backward from (dz, y), the folded coefficients of fcn_bnbwd_coef and the entry's multiplicity w
+__device__ __forceinline__ float fcn_bn_dy(float c0, float c1, float c2, float c3, float dz, float y, float w)
+{
+    return fmaf(c0, dz, -(w * fmaf(c2, y - c1, c3)));
+}
+__device__ __forceinline__ float fcn_bn_dy1(float c0, float c1, float c2, float c3, float dz, float y)      // w = 1
+{
+    return fmaf(c0, dz, -fmaf(c2, y - c1, c3));
+}
+
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -148,9 +158,13 @@ __device__ __forceinline__ float fcn_pool_key_value(unsigned hi, unsigned lo, fl
 }
 
 // Coefficients of a BatchNorm backward, derived by every CONSUMER workgroup from the batch sums (a few fp64 products per
-// channel) instead of by a one-workgroup launch between two layers of a latency-bound chain:
-//   dy = c0 * (dz - (c3 + xhat * c4)),  xhat = (y - c1) * c2
-//   c0 = gamma * rstd, c1 = mean, c2 = rstd, c3 = sum(dz) / M, c4 = sum(dz * xhat) / M
+// channel) instead of by a one-workgroup launch between two layers of a latency-bound chain.  With xhat = (y - mean) * rstd,
+//   dy = gamma*rstd * (dz - w * (sum(dz)/M + xhat * sum(dz*xhat)/M))             (w = 1 outside the PointNet's entry space)
+// is evaluated per element in its FOLDED form -- a subtraction, two fused multiply-adds and (entry space) one product:
+//   dy = fma(c0, dz, -w * fma(c2, y - c1, c3))
+//   c0 = gamma * rstd, c1 = mean, c2 = c0 * rstd * sum(dz*xhat) / M, c3 = c0 * sum(dz) / M        (c4 unused, 0)
+// (the literal form costs six operations per element in the staging path of every backward GEMM, which is vector-issue-bound;
+// the folded one has the same terms of the same magnitudes -- no new cancellation -- and the per-channel products are formed in fp64)
 // bstat: sum dz [C], sum dz * xhat [C] (final when the consumer starts); bn: scale, shift, mean, rstd [C] of the forward.
 struct FcnBnBwd {
     const double *bstat;       // replica 0 of [sum dz [C], sum dz * xhat [C]]
@@ -165,9 +179,10 @@ __device__ __forceinline__ void fcn_bnbwd_coef(const FcnBnBwd &q, int C, int c, 
     const float rstd = q.bn[3 * C + c];
     cf[0] = q.gamma[c] * rstd;
     cf[1] = q.bn[2 * C + c];
-    cf[2] = rstd;
-    cf[3] = (float)(db * q.invM);
-    cf[4] = (float)(dg * q.invM);
+    const double c0 = (double)cf[0];
+    cf[2] = (float)(c0 * (double)rstd * (dg * q.invM));
+    cf[3] = (float)(c0 * (db * q.invM));
+    cf[4] = 0.f;
     if (pub && q.dgamma) { q.dgamma[c] = (float)dg; q.dbeta[c] = (float)db; }
 }
 

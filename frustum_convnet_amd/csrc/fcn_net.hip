@@ -572,10 +572,11 @@ __device__ __forceinline__ void cg_bnbwd_coef(const QT &q, int Cs, int c, float 
     const float rstd = q.bn[3 * Cs + c];
     cf[0] = q.gamma[c] * rstd;
     cf[1] = q.bn[2 * Cs + c];
-    cf[2] = rstd;
     const double invM = 1.0 / q.M;                      // (one division; the two per-channel quotients become products)
-    cf[3] = (float)(db * invM);
-    cf[4] = (float)(dg * invM);
+    const double c0 = (double)cf[0];                    // the folded form of fcn_common.h: dy = fma(c0, dz, -fma(c2, y - c1, c3))
+    cf[2] = (float)(c0 * (double)rstd * (dg * invM));
+    cf[3] = (float)(c0 * (db * invM));
+    cf[4] = 0.f;
     if (pub && q.dgamma) { q.dgamma[c] = (float)dg; q.dbeta[c] = (float)db; }
 }
 
@@ -584,8 +585,7 @@ __device__ __forceinline__ void cg_bnbwd_coef(const QT &q, int Cs, int c, float 
 // dy of a BN layer from raw (dz, y) and the LDS-staged coefficients: kk*(dz - dbeta/M - xhat*dgamma/M)
 __device__ __forceinline__ float cg_dy(const float *coefS, int Cs, int ch, float dz, float y)
 {
-    const float xh = (y - coefS[Cs + ch]) * coefS[2 * Cs + ch];
-    return coefS[ch] * (dz - fmaf(xh, coefS[4 * Cs + ch], coefS[3 * Cs + ch]));
+    return fcn_bn_dy1(coefS[ch], coefS[Cs + ch], coefS[2 * Cs + ch], coefS[3 * Cs + ch], dz, y);
 }
 
 // Weight packing descriptor of one layer: conv (Cout, Cin, KT) or deconv (Cin, Cout, k) <-> packed (N, Ktot).
@@ -1056,22 +1056,20 @@ __device__ __forceinline__ void cg_dgrad_body(const LT &L, const CT &cb, const f
             const int chb = __builtin_amdgcn_readfirstlane(cCh[c]) + 4 * kq;     // BN channel of this thread's first column
             // the five coefficients of the thread's four channels as 16-byte LDS reads, ONE branch on hasbn per chunk (per element
             // they were 40 ds_read_b32 and 8 branches in front of 6 MFMAs); the operation order is cg_dy's
-            v4f f0 = zero4(), f1 = zero4(), f2 = zero4(), f3 = zero4(), f4 = zero4();
+            v4f f0 = zero4(), f1 = zero4(), f2 = zero4(), f3 = zero4();
             if (hasbn) {
                 const float *cp = coefS + chb;          // (16-byte aligned: coefS, Cs and chb are multiples of 4 floats)
                 f0 = *(const v4f *)cp; f1 = *(const v4f *)(cp + Cs); f2 = *(const v4f *)(cp + 2 * Cs);
-                f3 = *(const v4f *)(cp + 3 * Cs); f4 = *(const v4f *)(cp + 4 * Cs);
+                f3 = *(const v4f *)(cp + 3 * Cs);
             }
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int r = rb + RSTEP * i;
                 v4f d = rz[i];
                 if (hasbn) {
-                    const v4f xh = (ry[i] - f1) * f2;
-                    v4f m;
-                    m.x = fmaf(xh.x, f4.x, f3.x); m.y = fmaf(xh.y, f4.y, f3.y);
-                    m.z = fmaf(xh.z, f4.z, f3.z); m.w = fmaf(xh.w, f4.w, f3.w);
-                    d = f0 * (d - m);
+                    const v4f y = ry[i];
+                    d.x = fcn_bn_dy1(f0.x, f1.x, f2.x, f3.x, d.x, y.x); d.y = fcn_bn_dy1(f0.y, f1.y, f2.y, f3.y, d.y, y.y);
+                    d.z = fcn_bn_dy1(f0.z, f1.z, f2.z, f3.z, d.z, y.z); d.w = fcn_bn_dy1(f0.w, f1.w, f2.w, f3.w, d.w, y.w);
                 }
                 d = ok[i] ? d : zero4();
                 kb16_store4<MM_ENC_A, LDRA>(Ai, r, kq, d.x, d.y, d.z, d.w);
@@ -1336,16 +1334,14 @@ __device__ __forceinline__ void cg_wgrad_body(const AT &a, int wid, float *smem)
             v4f dv2[2];
             {
                 const v4f f0 = *(const v4f *)cfp, f1 = *(const v4f *)(cfp + 64), f2 = *(const v4f *)(cfp + 128),
-                          f3 = *(const v4f *)(cfp + 192), f4 = *(const v4f *)(cfp + 256);
+                          f3 = *(const v4f *)(cfp + 192);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     v4f d = rz[i];
-                    if (hasbn) {                // elementwise, the same operation order as cg_dy
-                        const v4f xh = (ry[i] - f1) * f2;
-                        v4f m;
-                        m.x = fmaf(xh.x, f4.x, f3.x); m.y = fmaf(xh.y, f4.y, f3.y);
-                        m.z = fmaf(xh.z, f4.z, f3.z); m.w = fmaf(xh.w, f4.w, f3.w);
-                        d = f0 * (d - m);
+                    if (hasbn) {                // elementwise, the same operations as cg_dy
+                        const v4f y = ry[i];
+                        d.x = fcn_bn_dy1(f0.x, f1.x, f2.x, f3.x, d.x, y.x); d.y = fcn_bn_dy1(f0.y, f1.y, f2.y, f3.y, d.y, y.y);
+                        d.z = fcn_bn_dy1(f0.z, f1.z, f2.z, f3.z, d.z, y.z); d.w = fcn_bn_dy1(f0.w, f1.w, f2.w, f3.w, d.w, y.w);
                     }
                     const bool live = (r0 + 2 * pa + i) < rend;
                     dv2[i] = live ? d : zero4();

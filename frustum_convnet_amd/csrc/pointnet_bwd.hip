@@ -278,9 +278,9 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, un
             int mv[4] = {0, 0, 0, 0};
             if constexpr (MAPS) { mv[0] = rm[i].x; mv[1] = rm[i].y; mv[2] = rm[i].z; mv[3] = rm[i].w; }
             const int nb = c * KC + 4 * kq;
-            float cfv[5][4];
+            float cfv[4][4];
 #pragma unroll
-            for (int q = 0; q < 5; ++q) {
+            for (int q = 0; q < 4; ++q) {
                 const v4f c4 = *(const v4f *)(coefS + q * CRED + nb);
                 cfv[q][0] = c4.x; cfv[q][1] = c4.y; cfv[q][2] = c4.z; cfv[q][3] = c4.w;
             }
@@ -289,10 +289,9 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &a, const int bid, un
             for (int j = 0; j < 4; ++j) {
                 float dz = zv[j];
                 if constexpr (MAPS) dz = (mv[j] == rloc) ? zv[j] : 0.f;
-                const float xh = (yv[j] - cfv[1][j]) * cfv[2][j];
                 // (rows past nvalid hold a live row's values again -- the loads are clamped -- and are not zeroed: a row of this
                 // operand reaches only its own output row, which the epilogue neither stores nor counts)
-                dv[j] = cfv[0][j] * (dz - w * fmaf(xh, cfv[4][j], cfv[3][j]));
+                dv[j] = fcn_bn_dy(cfv[0][j], cfv[1][j], cfv[2][j], cfv[3][j], dz, yv[j], w);
             }
             kb_store4<MM_ENC_A, LDRA>(Ab, r, kq, dv[0], dv[1], dv[2], dv[3]);
             if constexpr (LAYER == 3) {
@@ -639,8 +638,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &a, const int bx_, co
                 float o[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float xh = (yv[j] - cf[1][j]) * cf[2][j];
-                    o[j] = cf[0][j] * (dzv[j] - rwt[i] * fmaf(xh, cf[4][j], cf[3][j]));
+                    o[j] = fcn_bn_dy(cf[0][j], cf[1][j], cf[2][j], cf[3][j], dzv[j], yv[j], rwt[i]);
                 }
                 v4f ov = {o[0], o[1], o[2], o[3]};
                 v = ok ? ov : zero4();
