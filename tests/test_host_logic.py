@@ -53,8 +53,8 @@ def test_bad_arguments_return_codes_without_gpu():
     assert lib.fcn_convnet_sizes(ctypes.byref(bad), ctypes.byref(sizes)) == 10001
     assert lib.fcn_convnet_sizes(None, None) == 10001
     assert lib.fcn_convnet_logits_ld(ctypes.byref(cd)) == 64
-    # the FCN kernels use 32-bit element offsets and float-reciprocal row divisions: a batch whose B * L reaches 2^23 rows
-    # (or whose arenas reach 2^31 elements) is refused with FCN_E_LIMIT instead of computing wrong addresses
+    # the FCN kernels use 32-bit offsets and float-reciprocal row divisions: a batch whose B * L reaches 2^23 rows
+    # (or whose arenas reach 2^30 elements: 32-bit byte offsets) is refused with FCN_E_LIMIT instead of computing wrong addresses
     ok_big = _native.CnDesc(4096, (ctypes.c_int32 * 5)(280, 140, 70, 35), 3, 39, 1, 1e-5, 0.1, 0)      # 1.1 M rows
     assert lib.fcn_convnet_sizes(ctypes.byref(ok_big), ctypes.byref(sizes)) == 0
     too_big = _native.CnDesc(32768, (ctypes.c_int32 * 5)(280, 140, 70, 35), 3, 39, 1, 1e-5, 0.1, 0)    # 9.2 M rows
