@@ -163,3 +163,7 @@ extern "C" int fcn_probe_read(unsigned long long *host_out, int max_records, int
 #define BPROBE_FLUSH(tag)
 #endif
 #endif
+
+#ifndef FCN_POOL_FUSED
+#define FCN_POOL_FUSED 1     // 0 (tuning builds): conv3 writes y3 only and pool_nlc_kernel re-reads it
+#endif

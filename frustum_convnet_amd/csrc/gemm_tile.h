@@ -29,6 +29,13 @@ __device__ __forceinline__ v4f zero4() { v4f z = {0.f, 0.f, 0.f, 0.f}; return z;
 
 
 #define GT 256          // threads per workgroup
+
+// Whether a scale's forward takes its max-pool from the keys of conv3's epilogue (pool_keys_kernel, pointnet_fwd.hip) -- asked by the
+// forward AND by the backward, whose first kernel then finds the winners' pre-BN values in the routed-gradient buffer
+static inline bool fcn_pn_key_pool(const fcn_pn_desc *d, const fcn_pn_ws *ws, int C3)
+{
+    return FCN_POOL_FUSED && d->nlc && ws->pkey && ws->ewin && C3 % 2 == 0 && C3 <= 2 * GT && (2 * GT) % C3 == 0;
+}
 #define KC 32           // reduction chunk staged per iteration
 
 // ------------------------------------------------------------------------------------------------

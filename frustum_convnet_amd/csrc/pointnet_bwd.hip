@@ -53,7 +53,7 @@ template <int S16>
 __global__ __launch_bounds__(GT) void poolbwd_kernel(
     const float *__restrict__ dfeat, const int32_t *__restrict__ amax, const float *__restrict__ y3,
     const float *__restrict__ bn3, float *__restrict__ gmax, double *__restrict__ bstat, int rep_stride,
-    int L, int cap, int C3, int CT, int nlc)
+    int L, int cap, int C3, int CT, int nlc, int ywin)           // ywin: gmax holds the winners' pre-BN values (pool_keys_kernel)
 {
     __shared__ float dS[64 * (PWB + 1)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -82,7 +82,8 @@ __global__ __launch_bounds__(GT) void poolbwd_kernel(
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
         if (l0 + wave + 4 * q >= L) am[q] = -1;
-        yy[q] = lds1e<(S16 ? MM_BF16S : MM_F32)>(y3, ((int64_t)b * cap + max(am[q], 0)) * C3 + c);
+        if (ywin) yy[q] = gmax[((int64_t)b * L + min(l0 + wave + 4 * q, L - 1)) * C3 + c];      // (read here, overwritten below by the same lane)
+        else yy[q] = lds1e<(S16 ? MM_BF16S : MM_F32)>(y3, ((int64_t)b * cap + max(am[q], 0)) * C3 + c);
     }
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
@@ -1100,10 +1101,10 @@ static int pn_backward_impl(const fcn_pn_desc *d, const fcn_pn_params *p, const 
         if (!ws->dy3 || d->precision == FCN_PREC_BF16) return FCN_E_BADARG;      // (dz3 is fp32 rows; the dense form keeps dy3 materialised)
     } else if (d->precision == FCN_PREC_BF16)       // y3 stored as bf16 (gemm_tile.h: St)
         hipLaunchKernelGGL(poolbwd_kernel<1>, dim3((L + PWB - 1) / PWB, C3 / 64, B), dim3(GT), 0, st, dfeat, ws->amax,
-                           ws->y3, bn3, ws->gmax, bs3, brs, L, cap, C3, C3 + d->nvec, d->nlc);
+                           ws->y3, bn3, ws->gmax, bs3, brs, L, cap, C3, C3 + d->nvec, d->nlc, (int)fcn_pn_key_pool(d, ws, C3));
     else
         hipLaunchKernelGGL(poolbwd_kernel<0>, dim3((L + PWB - 1) / PWB, C3 / 64, B), dim3(GT), 0, st, dfeat, ws->amax,
-                           ws->y3, bn3, ws->gmax, bs3, brs, L, cap, C3, C3 + d->nvec, d->nlc);
+                           ws->y3, bn3, ws->gmax, bs3, brs, L, cap, C3, C3 + d->nvec, d->nlc, (int)fcn_pn_key_pool(d, ws, C3));
     FCN_CHECK_LAUNCH();
     DgradArgs g;
     g.ent = (const float4 *)ws->ent; g.woff = ws->woff; g.tiles = ws->tiles; g.ewin = ws->ewin; g.L = L; g.cap = cap; g.tps = tps;

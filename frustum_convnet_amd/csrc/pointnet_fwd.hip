@@ -153,9 +153,6 @@ extern "C" int fcn_pn_pack_weights_all(int nscale, const fcn_pn_desc *const *d, 
 
 // ------------------------------------------------------------------------------------------------
 
-#ifndef FCN_POOL_FUSED
-#define FCN_POOL_FUSED 1     // 0 (tuning builds): conv3 writes y3 only and pool_nlc_kernel re-reads it
-#endif
 struct FwdArgs {
     const float4 *ent;     // (B,cap) rows (ux,uy,uz,w)
     const int32_t *woff;   // (B,L+1)
@@ -774,7 +771,7 @@ __global__ __launch_bounds__(GT) void pool_nlc_kernel(
 // that sit on the first window publish scale, shift, mean, rstd and update the running statistics.  WPB windows per workgroup.
 __global__ __launch_bounds__(GT) void pool_keys_kernel(unsigned long long *__restrict__ pkey, PoolBn q,
                                                        const int32_t *__restrict__ cnt, float *__restrict__ feat,
-                                                       int32_t *__restrict__ amax, int L, int C3, int WPB,
+                                                       int32_t *__restrict__ amax, float *__restrict__ ywin, int L, int C3, int WPB,
                                                        double *__restrict__ zero_ptr, int zero_n)
 {
     if (zero_ptr && blockIdx.y == 0)
@@ -830,7 +827,7 @@ __global__ __launch_bounds__(GT) void pool_keys_kernel(unsigned long long *__res
         *(u32x4 *)(pkey + o) = u32x4{0u, 0u, 0u, 0u};
         const unsigned hi[2] = {kk.y, kk.w}, lo[2] = {kk.x, kk.z};
         const bool live = cnt[(int64_t)b * L + l] > 0;           // (an empty window holds one stand-in row: no feature, no gradient)
-        float fo[2];
+        float fo[2], yo[2];
         int ao[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -840,9 +837,14 @@ __global__ __launch_bounds__(GT) void pool_keys_kernel(unsigned long long *__res
             const bool pos = live && (hi[e] | lo[e]) != 0u && u > 0.f;
             fo[e] = pos ? u : 0.f;
             ao[e] = pos ? row : -1;
+            yo[e] = y;
         }
         *(v2f *)(feat + o) = v2f{fo[0], fo[1]};
         if (amax) { amax[o] = ao[0]; amax[o + 1] = ao[1]; }
+        // the winners' pre-BN values, position-major, for the backward's BN3 sums (poolbwd_kernel reads them from the routed-gradient
+        // buffer it then overwrites, instead of gathering B*L*C3 single floats out of y3: one dependent round trip and ~36 MB of
+        // 64-byte sectors per launch on the widest scale)
+        if (ywin) *(v2f *)(ywin + o) = v2f{yo[0], yo[1]};
     }
 }
 
@@ -924,7 +926,7 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
     a.stat_in = tr ? st2 : nullptr; a.gamma_in = p->gamma[1]; a.beta_in = p->beta[1];
     a.rmean_in = p->running_mean[1]; a.rvar_in = p->running_var[1]; a.nbt_in = p->num_batches_tracked[1]; a.bn_pub = bn2;
     // position-major features + a key buffer in the workspace: the max-pool rides in conv3's epilogue (pool_keys_kernel finishes it)
-    const bool key_pool = FCN_POOL_FUSED && d->nlc && ws->pkey && ws->ewin && C3 % 2 == 0 && C3 <= 2 * GT && (2 * GT) % C3 == 0;
+    const bool key_pool = fcn_pn_key_pool(d, ws, C3);
     if (key_pool) { a.ewin = ws->ewin; a.pkey = (unsigned long long *)ws->pkey; a.gamma_out = p->gamma[2]; }
     FCN_TRY(launch_fwd_gemm<1>(a, B, d->precision, st));
 
@@ -947,7 +949,7 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
         int wpb = nsub;
         while ((int64_t)B * ((L + wpb - 1) / wpb) > 1024 && wpb < 8 * nsub) wpb += nsub;       // ~ two workgroups per CU at least
         hipLaunchKernelGGL(pool_keys_kernel, dim3((L + wpb - 1) / wpb, B), dim3(GT), 0, st, (unsigned long long *)ws->pkey, pb, cnt,
-                           feat, tr ? ws->amax : nullptr, L, C3, wpb, tr ? ws->bstat : nullptr, nz);
+                           feat, tr ? ws->amax : nullptr, tr ? ws->gmax : nullptr, L, C3, wpb, tr ? ws->bstat : nullptr, nz);
     } else if (nlc_pool) {
         PoolBn pb;
         pb.stat = tr ? st3 : nullptr; pb.rep_stride = 2 * C2 + 2 * C3; pb.gamma = p->gamma[2]; pb.beta = p->beta[2];
