@@ -366,12 +366,23 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
     # reference optimiser: Adam(lr 1e-3, weight_decay 1e-4), train/train_net_det.py:321-339.  Parameters, gradients and
     # moments are flat buffers: the backward kernels write the gradients in place, the exchange is a bucketed all-reduce
     # and the step one streaming kernel (capturable: step counter and hyper-parameters live on the device).
-    state = FlatTrainState(model, lr=1e-3, weight_decay=1e-4, world=world)
+    # FCN_BENCH_COMM=rccl1 (main() formed a ONE-rank RCCL group): the collectives of the N > 1 step are really issued -- communicator,
+    # communication stream, capture of the calls into the step's graph -- on a one-GPU box
+    one_rank_comm = world == 1 and torch.distributed.is_available() and torch.distributed.is_initialized()
+    state = FlatTrainState(model, lr=1e-3, weight_decay=1e-4, world=world, force_comm=one_rank_comm)
     optim = (not a.no_optim) if force_optim is None else bool(force_optim)
     data = make_data(cfg_name, batch, npoint, 1234 + rank, dev)
-    # FCN_BENCH_SPLIT_STEP=1: the N > 1 form of the step (three graphs, Adam at the head of the first, the all-reduce calls -- no-ops
-    # in a world of one) with ONE rank: what a rank's step costs on this box without its collectives, beside the N = 1 line
-    overlap = (world > 1 or os.environ.get("FCN_BENCH_SPLIT_STEP", "0") == "1") and not a.no_overlap and not a.eager
+    # FCN_BENCH_SPLIT_STEP=1: the N > 1 form of the step with ONE rank and no process group (the all-reduce calls are no-ops): what
+    # a rank's step costs on this box without its collectives, beside the N = 1 line
+    rehearse = one_rank_comm or os.environ.get("FCN_BENCH_SPLIT_STEP", "0") == "1"
+    overlap = (world > 1 or rehearse) and not a.no_overlap and not a.eager
+    # N > 1 step forms (FCN_BENCH_COMM_FORM): "captured" (default) = ONE graph of two whole steps, exactly the N = 1 step, with the
+    # all-reduce calls captured INTO it as forked branches (RCCL's stream joins the capture); "host" = round 5's three graphs per step
+    # with the collectives issued from the host between the replays
+    comm_form = os.environ.get("FCN_BENCH_COMM_FORM", "captured")
+    if comm_form not in ("captured", "host"):
+        raise SystemExit("FCN_BENCH_COMM_FORM must be 'captured' or 'host'")
+    captured_comm = overlap and comm_form == "captured"
     model.split_backward = overlap
 
     prefetch = os.environ.get("FCN_PREFETCH", "1") != "0" and (world == 1 or (overlap and use_graph_requested(a)))
@@ -381,13 +392,21 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
     # FCN_ADAM_LATE=1: only the PointNet bucket's optimiser step (13 % of the parameters) stays on the chain between the backward and
     # the next forward; the [ConvFeatNet + heads] bucket's runs on the packing branch of that forward, in front of the weight packing
     # -- the first thing that reads its result
-    late = os.environ.get("FCN_ADAM_LATE", "1") == "1" and world == 1 and optim and len(state.buckets) == 2
-    if late:
-        model._cn_pool.before_pack = lambda: state.adam_step_bucket(0)
+    late = (os.environ.get("FCN_ADAM_LATE", "1") == "1" and optim and len(state.buckets) == 2 and
+            ((world == 1 and not rehearse) or captured_comm))
+
+    def late_bucket0():
+        # (on the packing branch's stream) N > 1: the bucket's all-reduce -- started behind the previous step's FCN backward -- first
+        state.wait_allreduce(state.buckets[0][0])
+        state.adam_step_bucket(0)
 
     def opt_step():
         if late:
             state.adam_step_bucket(1)
+            # armed only now, BEHIND a backward: a forward that runs before any gradient exists must not step the bucket (ADVICE r5:
+            # armed from the start, the first warm-up forward applied an Adam step of zero gradients -- weight decay, counter + 1 --
+            # and the two buckets' step counters diverged for the rest of the run)
+            model._cn_pool.before_pack = late_bucket0
         else:
             state.adam_step()
 
@@ -424,8 +443,60 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
             if world > 1:
                 torch.distributed.barrier()          # no collective in flight while the step is being captured
                 torch.cuda.synchronize()
-            mode = "thread_local" if world > 1 else "global"   # RCCL's watchdog thread may query events meanwhile
-            if overlap:
+            mode = "thread_local" if (world > 1 or one_rank_comm) else "global"   # RCCL's watchdog thread may query events meanwhile
+            if captured_comm:
+                # N > 1, default: the step of the N = 1 graph -- same launches, same branches, two whole steps (even / odd workspace
+                # set) per graph -- plus the gradient exchange captured INTO it.  Per step:
+                #   head              wait [pointnet] all-reduce of the previous step -> Adam of that bucket -> weight fold -> scales ...
+                #   packing branch    wait [fcn+heads] all-reduce of the previous step -> Adam of that bucket -> weight packing
+                #   ... forward, loss, heads + ConvFeatNet backward (phase 1 of the split backward)
+                #   fork              all-reduce [fcn+heads] (12.2 MB) on RCCL's stream, beside the whole PointNet backward AND the
+                #                     next step's PointNet forward (its first reader is the next packing)
+                #   PointNet backward, every scale abreast as in the N = 1 step (phase 2)
+                #   fork              all-reduce [pointnet] (1.1 MB): the only exposed piece (the next head waits for it)
+                # and the capture ends by joining both.  No host call between the steps; a rank's step IS the N = 1 step.
+                from frustum_convnet_amd.loss_fused import unit_grad
+                # (the warm-up ended with an optimiser step; the graph's steps BEGIN with one: one more backward first -- its forward
+                # still runs the late [fcn+heads] update the last warm-up step left pending -- so that every gradient is applied once)
+                with torch.cuda.stream(side):
+                    fwd_bwd()
+                    if not skip_comm:
+                        state.allreduce()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                if state.comm and not skip_comm:
+                    _probe_captured_allreduce(dev, world, mode)
+
+                def cap_step():
+                    if optim:
+                        if late:
+                            state.wait_allreduce(state.buckets[1][0])
+                            state.adam_step_bucket(1)            # ([fcn+heads]: late_bucket0 on the packing branch of this forward)
+                        else:
+                            state.wait_allreduce()
+                            state.adam_step()
+                    if prefetch:
+                        model.next_batch = data
+                    losses, _ = model(data)
+                    lt = losses["total_loss"]
+                    pending = model.take_split()
+                    lt.backward(gradient=unit_grad(lt.device))
+                    if not skip_comm:
+                        state.allreduce_bucket_async(0)
+                    pending.backward()                           # (joins the IoU-metrics and prefetch branches)
+                    if not skip_comm:
+                        state.allreduce_bucket_async(1)
+                    return lt
+
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode=mode):
+                    model.feat_net.adopt_prefetch()
+                    for _ in range(spg if prefetch else 1):
+                        loss = cap_step()
+                    state.wait_allreduce()                       # RCCL's stream joins the capture: the next replay's head needs both
+                steps_per_graph = spg if prefetch else 1
+                graphs = ((g,),)
+            elif overlap:
                 # N > 1: the step is THREE graphs cut where gradients become final, so that each piece's all-reduce starts on the
                 # communication stream while the next graph runs: A = [Adam of the PREVIOUS step's (reduced) gradients, forward, loss,
                 # FCN + heads backward] -> all-reduce [FCN + heads] -> B = [PointNet backward of the wide scales] -> all-reduce them ->
@@ -496,6 +567,10 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
                       (type(e).__name__, e), file=sys.stderr)
             graphs = None
             overlap = False
+            captured_comm = False
+            late = False
+            model._cn_pool.before_pack = None
+            state._pending = {}
             steps_per_graph = 1
             model.split_backward = False
             model._split = model._pending_split = None          # (a capture that died between take_split() and phase 2)
@@ -512,6 +587,10 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
             state.allreduce()
             if optim:
                 state.adam_step()
+        elif captured_comm:
+            if parity[0] % steps_per_graph == 0:
+                graphs[0][0].replay()                # two whole steps, their collectives inside
+            parity[0] += 1
         elif overlap:
             gA, gB, gC = graphs[parity[0] % len(graphs)]
             parity[0] += 1
@@ -535,7 +614,7 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
                 if optim:
                     state.adam_step()
 
-    if overlap and graphs is not None:
+    if overlap and graphs is not None and not captured_comm:
         steps_per_graph = len(graphs)                # (whole even / odd cycles)
     even = lambda n: ((n + steps_per_graph - 1) // steps_per_graph) * steps_per_graph       # a replay holds whole steps
     for _ in range(even(warmup)):
@@ -571,13 +650,18 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
     wall = float(tt.item())
     nstep = even(rounds * steps)
-    if late:                                          # the last step's [ConvFeatNet + heads] update, which the next forward would have run
+    if captured_comm and graphs is not None and optim:    # the last captured step's gradients: its successor's head would have applied them
+        model._cn_pool.before_pack = None
+        state.adam_step()
+        torch.cuda.synchronize()
+    elif late and model._cn_pool.before_pack is not None:   # the last step's [ConvFeatNet + heads] update, which the next forward would have run
         model._cn_pool.before_pack = None
         state.adam_step_bucket(0)
         torch.cuda.synchronize()
+    model._cn_pool.before_pack = None
     Ls = [data["center_ref%d" % i].shape[2] for i in range(1, 6) if ("center_ref%d" % i) in data]
     comm = None
-    if world > 1:
+    if world > 1 or one_rank_comm:
         # what the exchange is made of, measured beside the timed region: ranks the communicator really has (an all-reduce of
         # ones) and the time of each bucket's all-reduce alone (events on the current stream around a blocking call)
         ones = torch.ones(1, device=dev)
@@ -587,6 +671,8 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
         if comm["ranks"] != world:
             raise SystemExit("the process group has %d ranks, WORLD_SIZE says %d" % (comm["ranks"], world))
         pieces = list(state.buckets)
+        comm["form"] = ("captured into the step's hipGraph" if captured_comm else
+                        "issued from the host between three graph replays per step" if overlap else "one call after the backward")
         if split_scales is not None:        # the pieces the overlapped step really exchanges
             sr = state.scale_ranges
             pieces = [state.buckets[0]] + [("pointnet scales %s" % "+".join(str(k + 1) for k in ks), sr[ks[0]][0], sr[ks[-1]][1])
@@ -604,15 +690,58 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
             torch.cuda.synchronize()
             comm["buckets"].append({"name": name, "mbytes": round(4e-6 * (hi - lo), 3), "allreduce_ms": round(b0.elapsed_time(b1) / 5, 4)})
         torch.distributed.barrier()
-    return {"model": model, "state": state, "data": data, "graphs": graphs, "overlap": overlap, "optim": optim, "comm": comm,
+    return {"captured_comm": captured_comm, "rehearse": rehearse, "model": model, "state": state, "data": data, "graphs": graphs, "overlap": overlap, "optim": optim, "comm": comm,
             "rounds": rounds, "nstep": nstep, "wall": wall, "ms_per_step": wall * 1e3 / nstep,
             "gpu_event_ms_per_step": e0.elapsed_time(e1) / nstep, "final_loss": float(loss.item()),
-            "steps_per_graph": steps_per_graph, "prefetch": prefetch, "late_adam": late,
+            "steps_per_graph": steps_per_graph, "prefetch": prefetch, "late_adam": bool(late),
             "batch": batch, "npoint": npoint, "Ls": Ls}
 
 
 def use_graph_requested(a):
     return not a.eager
+
+
+def _probe_captured_allreduce(dev, world, mode):
+    """Before the step's collectives are captured: ONE small all-reduce captured into a graph of its own, replayed twice and
+    checked (every replay sums `world` ones into a fresh copy).  A stack that cannot capture RCCL calls fails HERE, with a clear
+    exception that measure() turns into the eager fallback -- not in the middle of the step's capture."""
+    src = torch.ones(1024, device=dev)
+    buf = torch.zeros(1024, device=dev)
+    torch.distributed.all_reduce(buf)                       # (communicator warm-up outside the capture)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode=mode):
+        buf.copy_(src)
+        w = torch.distributed.all_reduce(buf, async_op=True)
+        w.wait()
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    got = float(buf[0].item())
+    if got != float(world) or float(buf.sum().item()) != 1024.0 * world:
+        raise RuntimeError("a captured all-reduce of ones over %d ranks replayed to %r" % (world, got))
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): re-executes itself under torch.distributed.run
+    with N ranks on this node (one per GPU, rendezvous on 127.0.0.1) and returns the launcher's exit code -- the rank-0 child prints
+    the JSON line.  Fails loudly (non-zero) when the box has fewer than N GPUs."""
+    import socket
+    import subprocess
+    one_dev = os.environ.get("FCN_BENCH_ONE_DEVICE", "0") == "1"
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < a.gpus and not one_dev:
+        print("bench.py: --gpus %d but this box has %d GPU(s): refusing to print a line for fewer ranks than asked for"
+              % (a.gpus, have), file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def workload_name(cfg_name, batch, npoint, Ls, optim=True, extra=""):
@@ -713,15 +842,27 @@ def main():
     # FCN_BENCH_BACKEND=gloo + FCN_BENCH_ONE_DEVICE=1: rehearsal of the N > 1 path with every rank on GPU 0 (a 1-GPU box
     # cannot form an RCCL communicator); the driver's multi-GPU runs leave both unset.
     one_dev = os.environ.get("FCN_BENCH_ONE_DEVICE", "0") == "1"
-    if one_dev:
-        torch.cuda.set_device(0)
-    rank, world, local = fdist.init_from_env(backend=os.environ.get("FCN_BENCH_BACKEND") or None)
-    if one_dev:
-        local = 0
-    if world != a.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the N ranks ourselves (`python bench.py --gpus 8` used to measure ONE GPU and print n_gpus 1)
+        sys.exit(self_launch(a))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%s: the line would not describe the run" % (a.gpus, os.environ.get("WORLD_SIZE")))
+    if torch.cuda.device_count() < a.gpus and not one_dev:
+        raise SystemExit("--gpus %d but this box has %d GPU(s)" % (a.gpus, torch.cuda.device_count()))
+    if one_dev:
+        torch.cuda.set_device(0)
+    # FCN_BENCH_COMM=rccl1 (N = 1 only): a ONE-rank RCCL group -- the N > 1 step with its collectives really issued, on one GPU
+    rccl1 = os.environ.get("FCN_BENCH_COMM", "") == "rccl1" and a.gpus == 1
+    rank, world, local = fdist.init_from_env(backend=("nccl" if rccl1 else os.environ.get("FCN_BENCH_BACKEND") or None),
+                                             single_rank_group=rccl1)
+    if one_dev:
+        local = 0
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -731,9 +872,35 @@ def main():
     gpu_event_ms = m["gpu_event_ms_per_step"]
 
     if rank != 0:
+        _shutdown_group()
         return
     Ls = m["Ls"]
     car_flops = None
+    captured_comm = m["captured_comm"]
+    comm_note = ""
+    if m.get("comm"):
+        cm = m["comm"]
+        comm_note = "+%s grad all-reduce%s (%s)" % (
+            {"nccl": "RCCL", "gloo": "gloo (CPU transport: a rehearsal of the code path, not of xGMI)"}.get(cm["backend"], cm["backend"]),
+            (" in a ONE-rank group (rehearsal of the N > 1 step on one GPU)" if world == 1 else "") +
+            (", SKIPPED in the timed region" if cm["skipped_in_timed_region"] else ""),
+            "2 pieces captured into the step's graph: [FCN + heads] beside the PointNet backward and the next PointNet forward, "
+            "[PointNet] behind the backward" if captured_comm else
+            "3 pieces issued between graph replays: [FCN + heads] beside the PointNet backward, the wide scales beside the narrow ones"
+            if overlap else "one call after the backward")
+    elif m["rehearse"]:
+        comm_note = " (the N > 1 step form with one rank, no process group: its collectives are no-ops)"
+    if graphs is None:
+        launch_note = "eager"
+    elif overlap and not captured_comm:
+        launch_note = "hipGraph replay x%d per step (Adam at the head of the first), %d workspace sets" % (
+            3 if graphs[0][2] is not None else 2, len(graphs))
+    else:
+        launch_note = "hipGraph replay x%d" % len(graphs) + (
+            ", %d steps per replay" % m["steps_per_graph"] if m["steps_per_graph"] > 1 else "") + (
+            ", the gradient all-reduces captured inside it (Adam of each bucket at the head of the next step)" if captured_comm else "")
+    launch_note += (", next batch's grouping front prefetched beside the backward (double-buffered workspaces)" if m["prefetch"] else "") + (
+        ", the [ConvFeatNet + heads] bucket's Adam step on the next forward's weight-packing branch" if m.get("late_adam") else "")
     out = {
         "metric": "frustums/sec (train fwd+bwd) %s B=%d N=%d" % (
             {"car": "KITTI-car", "people": "KITTI-people", "refine": "KITTI-refine", "sunrgbd": "SUN-RGBD"}[a.cfg], a.batch, npoint),
@@ -747,20 +914,9 @@ def main():
                           "bf16": "bf16 single term, fp32 accumulate; y2/y3/dy3/dz2 and the FCN y/dz arenas stored as bf16",
                           "bf16ops": "bf16 single term, fp32 accumulate, fp32 storage"}[prec],
         "data": "synthetic",
-        "config": {"workload": "%s KITTI-%s, batch=%d/GPU, Npoint=%d, L=(%s), train fwd+bwd%s%s" % (
-                       CFGS[a.cfg][0], a.cfg, a.batch, npoint, ",".join(str(v) for v in Ls),
-                       "" if a.no_optim else "+Adam",
-                       ("+%s grad all-reduce (%s)" % (
-                           {"nccl": "RCCL", "gloo": "gloo (CPU transport: a rehearsal of the code path, not of xGMI)"}.get(
-                               m["comm"]["backend"], m["comm"]["backend"]) + (", SKIPPED in the timed region" if m["comm"]["skipped_in_timed_region"] else ""),
-                           "3 pieces overlapped with the backward: [FCN + heads] beside the PointNet backward, the wide scales beside the narrow ones" if overlap else
-                           "one call after the backward")) if world > 1 else ""),
+        "config": {"workload": workload_name(a.cfg, a.batch, npoint, Ls, not a.no_optim, comm_note),
                    "global_batch": a.batch * world, "parallelism": "dp%d" % world,
-                   "launch": ((("hipGraph replay x%d per step (Adam at the head of the first), %d workspace sets" % (3 if graphs[0][2] is not None else 2, len(graphs))) if overlap else
-                               ("hipGraph replay x%d" % len(graphs)) + (", %d steps per replay" % m["steps_per_graph"] if m["steps_per_graph"] > 1 else ""))
-                              if graphs is not None else "eager") +
-                             (", next batch's grouping front prefetched beside the backward (double-buffered workspaces)" if m["prefetch"] else "") +
-                             (", the [ConvFeatNet + heads] bucket's Adam step on the next forward's weight-packing branch" if m.get("late_adam") else "")},
+                   "launch": launch_note},
         "gpu_event_ms_per_step": round(gpu_event_ms, 4),
         "final_loss": round(final_loss, 5),
     }
@@ -816,7 +972,8 @@ def main():
                                    "frac": round(tbps / PEAK_HBM_TBPS, 4)}
         else:
             out["hbm_roofline"] = {"traffic": None, "note": why}
-    if world == 1 and not a.no_configs and a.cfg == "car" and prec == "split" and not a.eager:
+    rehearsal = m["rehearse"]
+    if world == 1 and not a.no_configs and a.cfg == "car" and prec == "split" and not a.eager and not rehearsal:
         # the other BASELINE.json configurations, driver-visible in the same line: free the headline model first
         del model, state, data, graphs, m
         torch.cuda.synchronize()
@@ -842,6 +999,15 @@ def main():
         except Exception as e:  # noqa
             out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
     print(json.dumps(out), flush=True)
+    _shutdown_group()
+
+
+def _shutdown_group():
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        try:
+            torch.distributed.destroy_process_group()
+        except Exception:  # noqa
+            pass
 
 
 if __name__ == "__main__":

@@ -73,7 +73,7 @@ class InpRefineDesc(ctypes.Structure):
 
 EXPORTS = ("fcn_arch", "fcn_build_hash", "fcn_stat_replicas", "fcn_query_depth_point_f32", "fcn_query_depth_point_multi_f32", "fcn_pn_wgrad_rows", "fcn_pn_compact", "fcn_pn_group_compact", "fcn_pn_group_compact2",
            "fcn_pn_pack_weights", "fcn_pn_pack_weights_all", "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_backward3", "fcn_pn_backward_dense", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_det_loss_tail_rows2", "fcn_det_iou_metrics",
-           "fcn_det_loss_tail_scratch_floats", "fcn_adam_step_f32", "fcn_sgd_step_f32", "fcn_adam_step_slots", "fcn_prepare_inputs", "fcn_prepare_inputs_refine", "fcn_prepare_inputs_sunrgbd", "fcn_stamp",
+           "fcn_det_loss_tail_scratch_floats", "fcn_adam_step_f32", "fcn_sgd_step_f32", "fcn_adam_step_slots", "fcn_prepare_inputs", "fcn_prepare_inputs_refine", "fcn_prepare_inputs_sunrgbd", "fcn_stamp", "fcn_stream_capture_id",
            "fcn_convnet_sizes", "fcn_convnet_logits_ld", "fcn_convnet_pack", "fcn_convnet_forward", "fcn_convnet_forward2",
            "fcn_convnet_backward", "fcn_box3d_iou_pair_f32", "fcn_decode_detections", "fcn_rotate_nms_3d")
 
@@ -163,6 +163,8 @@ def lib():
     L.fcn_prepare_inputs_refine.argtypes = [ctypes.POINTER(InpRefineDesc)] + [c_fp] * 12 + [c_fp * 4] + [c_fp] * 8
     L.fcn_stamp.restype = ctypes.c_int
     L.fcn_stamp.argtypes = [c_fp, c_fp]
+    L.fcn_stream_capture_id.restype = ctypes.c_int
+    L.fcn_stream_capture_id.argtypes = [c_fp, ctypes.POINTER(ctypes.c_uint64)]
     L.fcn_adam_step_slots.restype = ctypes.c_int64
     L.fcn_adam_step_slots.argtypes = [ctypes.c_int64]
     L.fcn_det_loss_tail_rows.restype = ctypes.c_int
@@ -214,23 +216,21 @@ def current_stream(device=None):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-_hip = None
+_unknown_capture = [0]
 
 
 def capture_id(device=None):
-    """Id of the hipGraph capture the current stream of `device` is part of, 0 when it is not capturing (hipStreamGetCaptureInfo
-    on the HIP runtime torch loaded).  Used to keep state created during one capture from leaking into eager code or another
-    capture (PointNetFeat.prefetch)."""
-    global _hip
+    """Id of the hipGraph capture the current stream of `device` is part of, 0 when it is not capturing (fcn_stream_capture_id:
+    hipStreamGetCaptureInfo asked through libfcn_hip.so, i.e. of the HIP runtime the kernels are launched on -- never of a second
+    runtime dlopen'ed by name).  Used to keep state created during one capture from leaking into eager code or another capture
+    (PointNetFeat.prefetch).  When the id cannot be determined the answer is a fresh NEGATIVE number every time: two unknown
+    ids never compare equal, so state tagged with one is always treated as foreign (dropped, never consumed)."""
     import torch
     if not torch.cuda.is_available() or not torch.cuda.is_current_stream_capturing():
         return 0
-    if _hip is None:
-        _hip = ctypes.CDLL("libamdhip64.so")
-        _hip.hipStreamGetCaptureInfo.restype = ctypes.c_int
-        _hip.hipStreamGetCaptureInfo.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_ulonglong)]
-    status, cid = ctypes.c_int(0), ctypes.c_ulonglong(0)
-    rc = _hip.hipStreamGetCaptureInfo(current_stream(device), ctypes.byref(status), ctypes.byref(cid))
-    if rc != 0 or status.value != 1:          # (hipStreamCaptureStatusActive == 1)
-        return -1                             # capturing, id unknown: never equal to a recorded id of another state
-    return int(cid.value) + 1
+    cid = ctypes.c_uint64(0)
+    rc = lib().fcn_stream_capture_id(current_stream(device), ctypes.byref(cid))
+    if rc != 0 or cid.value == 0:             # capturing (torch says so), id unknown
+        _unknown_capture[0] -= 1
+        return _unknown_capture[0]
+    return int(cid.value)

@@ -134,3 +134,17 @@ extern "C" int fcn_stamp(uint64_t *slot, void *stream)
     FCN_CHECK_LAUNCH();
     return 0;
 }
+
+// Which hipGraph capture `stream` is part of: *id = 0 when it is not capturing, else the runtime's capture id + 1.  Asked through
+// THIS library so that the answer comes from the HIP runtime the kernels are launched on (a second libamdhip64 dlopen'ed by name
+// would not know the stream): the Python layer ties state created during a capture -- a prefetched front -- to that capture.
+extern "C" int fcn_stream_capture_id(void *stream, uint64_t *id)
+{
+    if (!id) return FCN_E_BADARG;
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    unsigned long long cid = 0;
+    hipError_t e = hipStreamGetCaptureInfo((hipStream_t)stream, &status, &cid);
+    if (e != hipSuccess) return (int)e;
+    *id = status == hipStreamCaptureStatusActive ? (uint64_t)cid + 1u : 0u;
+    return status == hipStreamCaptureStatusInvalidated ? FCN_E_BADARG : 0;
+}

@@ -772,7 +772,8 @@ __global__ __launch_bounds__(GT) void pool_nlc_kernel(
 __global__ __launch_bounds__(GT) void pool_keys_kernel(unsigned long long *__restrict__ pkey, PoolBn q,
                                                        const int32_t *__restrict__ cnt, float *__restrict__ feat,
                                                        int32_t *__restrict__ amax, float *__restrict__ ywin, int L, int C3, int WPB,
-                                                       double *__restrict__ zero_ptr, int zero_n)
+                                                       double *__restrict__ zero_ptr, int zero_n,
+                                                       const void *__restrict__ y3, int cap, int s16)
 {
     if (zero_ptr && blockIdx.y == 0)
         for (int i = blockIdx.x * GT + threadIdx.x; i < zero_n; i += gridDim.x * GT) zero_ptr[i] = 0.0;
@@ -838,6 +839,12 @@ __global__ __launch_bounds__(GT) void pool_keys_kernel(unsigned long long *__res
             fo[e] = pos ? u : 0.f;
             ao[e] = pos ? row : -1;
             yo[e] = y;
+            // gamma == 0: the key carries no value (fcn_pool_orient stores 0 so that the EARLIEST row wins the tie, as torch.max
+            // does on relu(beta)); the backward's sum(dz * xhat) of this channel needs the winner's real y3 -- one gather, only here
+            if (ywin && y3 && g[e] == 0.f && pos) {
+                const int64_t yi = ((int64_t)b * cap + row) * C3 + c + e;
+                yo[e] = s16 ? __uint_as_float((unsigned)((const unsigned short *)y3)[yi] << 16) : ((const float *)y3)[yi];
+            }
         }
         *(v2f *)(feat + o) = v2f{fo[0], fo[1]};
         if (amax) { amax[o] = ao[0]; amax[o + 1] = ao[1]; }
@@ -897,6 +904,8 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
     const int cap = L * K;
     const double M = (double)B * (double)L * (double)K;
     const int tr = d->training ? 1 : 0;
+    // a key-pooled training forward hands the winners' pre-BN values to its backward through ws->gmax (fcn_hip.h)
+    if (tr && ws->amax && !ws->gmax && fcn_pn_key_pool(d, ws, C3)) return FCN_E_BADARG;
     float *bn1 = ws->bn + fcn_bn_off(0, C1, C2);
     float *bn2 = ws->bn + fcn_bn_off(1, C1, C2);
     float *bn3 = ws->bn + fcn_bn_off(2, C1, C2);
@@ -949,7 +958,8 @@ extern "C" int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, cons
         int wpb = nsub;
         while ((int64_t)B * ((L + wpb - 1) / wpb) > 1024 && wpb < 8 * nsub) wpb += nsub;       // ~ two workgroups per CU at least
         hipLaunchKernelGGL(pool_keys_kernel, dim3((L + wpb - 1) / wpb, B), dim3(GT), 0, st, (unsigned long long *)ws->pkey, pb, cnt,
-                           feat, tr ? ws->amax : nullptr, tr ? ws->gmax : nullptr, L, C3, wpb, tr ? ws->bstat : nullptr, nz);
+                           feat, tr ? ws->amax : nullptr, tr ? ws->gmax : nullptr, L, C3, wpb, tr ? ws->bstat : nullptr, nz,
+                           (const void *)ws->y3, cap, s16 ? 1 : 0);
     } else if (nlc_pool) {
         PoolBn pb;
         pb.stat = tr ? st3 : nullptr; pb.rep_stride = 2 * C2 + 2 * C3; pb.gamma = p->gamma[2]; pb.beta = p->beta[2];

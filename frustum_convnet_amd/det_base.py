@@ -117,7 +117,14 @@ class PointNetModule(nn.Module):
         if pc.requires_grad and torch.is_grad_enabled():
             raise RuntimeError("PointNetModule.forward: no gradient w.r.t. the point cloud (the reference never asks for one either: "
                                "its inputs do not require grad)")
-        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            if not self.training:
+                # (the reference returns a differentiable tensor here too -- fine-tuning under frozen BatchNorm; the HIP backward
+                # chain differentiates batch-statistics BatchNorm only, so this raises instead of handing back a tensor without a graph)
+                raise NotImplementedError(
+                    "PointNetModule.forward in eval mode with gradients enabled and trainable parameters: the backward of "
+                    "running-statistics BatchNorm is not implemented; wrap the call in torch.no_grad() (inference) or call "
+                    ".train() (training)")
             return dense_pointnet(self._pool, self.dist, self.nsample, True, bn.eps, bn_momentum(bn),
                                   pc.contiguous(), new_pc.contiguous(), bufs, params)
         with torch.no_grad():

@@ -15,17 +15,32 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  Returns (rank, world, local)."""
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def init_from_env(backend=None, single_rank_group=False):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  Returns (rank, world, local).
+    A world of one creates no process group -- unless single_rank_group: then a ONE-rank group of `backend` is formed (rendezvous
+    on 127.0.0.1 when the launcher set none): a 1-rank "nccl" group is a real RCCL communicator on a one-GPU box, which is how
+    the N > 1 step (communication stream, captured collectives) is exercised without a second GPU."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" IS RCCL on ROCm
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if world == 1 and "MASTER_ADDR" not in os.environ:
+            dist.init_process_group(backend=backend, rank=0, world_size=1, init_method="tcp://127.0.0.1:%d" % _free_port())
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 

@@ -52,7 +52,7 @@ STEP_SPAN = 2048        # elements per workgroup of adam_kernel (ADAM_T * ADAM_V
 
 class FlatTrainState:
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, world=1, group=None,
-                 optimizer="adam", momentum=0.9):
+                 optimizer="adam", momentum=0.9, force_comm=False):
         if optimizer not in ("adam", "sgd"):
             raise ValueError("optimizer must be 'adam' or 'sgd' (cfg.TRAIN.OPTIMIZER, train/train_net_det.py:321-329)")
         self.optimizer = optimizer
@@ -98,6 +98,10 @@ class FlatTrainState:
                 p.grad = gv
                 p._fcn_grad = gv            # the HIP backward writes here and hands autograd no gradient
         self.world, self.group = int(world), group
+        # force_comm: issue the collectives even in a world of ONE rank (a 1-rank RCCL communicator on a one-GPU box exercises
+        # communicator set-up, the communication stream and hipGraph capture of the calls: tests/test_gpu_dist.py, bench.py's
+        # FCN_BENCH_COMM=rccl1 rehearsal); otherwise a world of one never touches torch.distributed
+        self.comm = self.world > 1 or bool(force_comm)
         # buckets in the order the backward completes them: everything after the PointNet scales (named feat_net.*,
         # first in the buffer), then the PointNet scales
         cut = cut_at or 0
@@ -111,7 +115,7 @@ class FlatTrainState:
                 k = int(n[len("feat_net.pointnet"):].split(".")[0]) - 1
                 lo, hi = self.scale_ranges.get(k, (o, o))
                 self.scale_ranges[k] = (min(lo, o), max(hi, (o + p.numel() + 3) // 4 * 4))
-        self._pending = []
+        self._pending = {}          # name -> the torch.distributed work of an all-reduce started and not yet waited for
         if optimizer == "sgd":          # lr, momentum, weight_decay, grad_scale; the momentum buffer lives in exp_avg
             self.hyper = torch.tensor([lr, momentum, weight_decay, 1.0 / self.world, 0.0, 1.0 / self.world], device=dev,
                                       dtype=torch.float32)
@@ -136,16 +140,23 @@ class FlatTrainState:
 
     def allreduce(self):
         """Sum of the flat gradient over ranks (the mean's 1/world lives in hyper[5]).  world 1: no-op."""
-        if self.world > 1:
+        if self.comm:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _start(self, name, lo, hi):
+        if name in self._pending:
+            raise RuntimeError("FlatTrainState: the all-reduce of '%s' was started twice without a wait_allreduce() in between" % name)
+        self._pending[name] = dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def allreduce_bucket_async(self, i):
         """Starts the summing all-reduce of bucket i on the communication stream (it waits for the work enqueued on the
         current stream so far, nothing later): call it right after the backward phase that completes the bucket, keep
-        launching the next phase, and call wait_allreduce() before the optimiser step.  world 1: no-op."""
-        if self.world > 1:
-            _, lo, hi = self.buckets[i]
-            self._pending.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        launching the next phase, and call wait_allreduce() before the optimiser step.  Inside a hipGraph capture the call
+        becomes a forked branch of the graph (RCCL's stream joins the capture) and wait_allreduce() its join -- every started
+        piece must be waited for before the capture ends.  world 1: no-op."""
+        if self.comm:
+            name, lo, hi = self.buckets[i]
+            self._start(name, lo, hi)
 
     def allreduce_scales_async(self, scales):
         """Starts the summing all-reduce of the gradients of the PointNet scales `scales` (0-based, a contiguous run of scales: one
@@ -154,15 +165,21 @@ class FlatTrainState:
         ks = sorted(scales)
         assert ks == list(range(ks[0], ks[-1] + 1)) and all(k in self.scale_ranges for k in ks), ks
         lo, hi = self.scale_ranges[ks[0]][0], self.scale_ranges[ks[-1]][1]
-        if self.world > 1:
-            self._pending.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.comm:
+            self._start("scales %d-%d" % (ks[0], ks[-1]), lo, hi)
         return lo, hi
 
-    def wait_allreduce(self):
-        """The current stream waits for every bucket started with allreduce_bucket_async (no host block on CUDA/HIP)."""
-        for w in self._pending:
+    def wait_allreduce(self, name=None):
+        """The current stream waits for every piece started with allreduce_*_async -- or, with `name` (a bucket's name), for that
+        piece alone (no host block on CUDA/HIP; a piece that was never started, or was waited for already, is skipped)."""
+        if name is not None:
+            w = self._pending.pop(name, None)
+            if w is not None:
+                w.wait()
+            return
+        for w in self._pending.values():
             w.wait()
-        self._pending = []
+        self._pending = {}
 
     def adam_step_bucket(self, i):
         """The optimiser step of bucket i alone (its gradients must be final -- and reduced for world > 1 -- on the current

@@ -30,6 +30,7 @@
  *   fcn_decode_detections       the numpy decode loop of train/test_net_det.py:254-293 + from_prediction_to_label_format
  *   fcn_rotate_nms_3d           rotate_nms_3d_cc, ops/pybind11/rbbox_iou.py:294-311 + nms_cpu.h:148-240
  *   fcn_stamp                   (measurement aid, no reference counterpart)
+ *   fcn_stream_capture_id       (graph-capture bookkeeping of the Python layer, no reference counterpart)
  *
  * Buffers are caller-owned.  "ws" buffers are scratch the caller provides (sizes documented per call).
  */
@@ -129,8 +130,14 @@ typedef struct fcn_pn_ws {
     double  *stat;               /* 16 + fcn_stat_replicas() * (2*C2 + 2*C3) doubles: input moments, then the
                                     replicated sum / sumsq blocks of conv2 and conv3                        */
     float   *bn;                 /* 4*(C1+C2+C3) floats: per layer scale, shift, mean, rstd  */
-    /* backward only */
-    float   *gmax;               /* (B, L, C3)  dfeat routed to the max rows                 */
+    /* backward -- and, for gmax, the hand-over from a key-pooled TRAINING forward to its backward */
+    float   *gmax;               /* (B, L, C3)  dfeat routed to the max rows (written by fcn_pn_backward*).  When the forward
+                                    pooled through keys (training = 1, nlc = 1, pkey and ewin set) fcn_pn_forward ALSO writes
+                                    it: the winners' pre-BN values, position-major, which the first backward kernel reads and
+                                    then overwrites with the routed gradient.  Between such a forward and its backward the
+                                    buffer is therefore LIVE: do not clear it, do not share it between scales or workspace
+                                    sets in flight, and pass the same pointer to both calls.  A training key-pool forward
+                                    with amax set and gmax NULL returns FCN_E_BADARG                                         */
     float   *dy3;                /* (B, cap, C3), or NULL: dy3 is not materialised -- conv3's weight-gradient GEMM rebuilds
                                     it from y3, ewin, amax, gmax and the BN3-backward sums while staging (bit-identical dW3;
                                     measured 0.7 % slower over the step, saves B*cap*C3 floats) */
@@ -205,11 +212,14 @@ int fcn_pn_pack_weights_all(int nscale, const fcn_pn_desc *const *d, const fcn_p
                             const fcn_pn_ws *const *ws, void *stream);
 
 /* Whole forward of one scale after fcn_pn_compact: feat (B, C3+nvec, L), one_hot (B,nvec) or NULL.  In training mode its
- * last kernel also zeroes ws.bstat (when non-NULL) for the fcn_pn_backward that follows. */
+ * last kernel also zeroes ws.bstat (when non-NULL) for the fcn_pn_backward that follows -- and, when the max-pool is taken
+ * from keys (nlc = 1, ws.pkey and ws.ewin set), writes the winners' pre-BN values into ws.gmax, which the following
+ * fcn_pn_backward* reads before overwriting it (see fcn_pn_ws.gmax; FCN_E_BADARG when ws.amax is set and ws.gmax is NULL). */
 int fcn_pn_forward(const fcn_pn_desc *d, const fcn_pn_params *p, const int32_t *cnt,
                    const float *one_hot, const fcn_pn_ws *ws, float *feat, void *stream);
 
-/* Backward: dfeat (B, C3+nvec, L) -> dW[3], dgamma[3], dbeta[3] (overwritten, not accumulated).  dW[1] and dW[2] must be
+/* Backward: dfeat (B, C3+nvec, L) -> dW[3], dgamma[3], dbeta[3] (overwritten, not accumulated).  After a key-pooled training
+ * forward (fcn_pn_forward above) it expects ws.gmax exactly as that forward left it.  dW[1] and dW[2] must be
  * 16-byte aligned (FCN_E_BADARG otherwise): the fixed-order sum of the split partials writes 16-byte vectors.  Size limits
  * (FCN_E_LIMIT): B * cap * max(C2, C3) < 2^31 elements (32-bit offsets) and B * cap < 2^24 entry rows (24-bit row multiplies). */
 int fcn_pn_backward(const fcn_pn_desc *d, const fcn_pn_params *p, const float *dfeat,
@@ -408,6 +418,11 @@ int fcn_rotate_nms_3d(const float *dets, const int32_t *valid, const int32_t *un
 
 /* Measurement aid: stores the device's constant-rate wall clock (100 MHz ticks) into *slot, in stream order. */
 int fcn_stamp(uint64_t *slot, void *stream);
+
+/* Which hipGraph capture `stream` is part of, asked of the HIP runtime this library launches on: *id = 0 when the stream is not
+ * capturing, the runtime's capture id + 1 otherwise.  Non-zero return: the query failed (hipError_t) or the capture was
+ * invalidated (FCN_E_BADARG) -- treat the id as unknown.  No reference counterpart (the reference captures no graphs). */
+int fcn_stream_capture_id(void *stream, uint64_t *id);
 
 /* 16 hex characters: sha256 over the kernel sources, headers and compile flags this library was built from
  * (frustum_convnet_amd/build.py source_hash()).  The library travels prebuilt; __graft_entry__.smoke() and bench.py compare

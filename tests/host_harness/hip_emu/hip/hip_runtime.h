@@ -60,6 +60,11 @@ typedef void *hipStream_t;
 typedef void *hipEvent_t;
 enum hipError_t { hipSuccess = 0, hipErrorInvalidValue = 1 };
 inline hipError_t hipGetLastError() { return hipSuccess; }
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1, hipStreamCaptureStatusInvalidated = 2 };
+inline hipError_t hipStreamGetCaptureInfo(hipStream_t, hipStreamCaptureStatus *st, unsigned long long *id)
+{
+    *st = hipStreamCaptureStatusNone; *id = 0; return hipSuccess;          // (the emulation runs every launch at once: no captures)
+}
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }

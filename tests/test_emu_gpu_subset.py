@@ -72,6 +72,8 @@ CASES = [
     ("test_gpu_pointnet", "test_key_pool_matches_row_pool", ((4, 512, 2.0, 128, (256, 256, 512), 2.0), True)),
     ("test_gpu_pointnet", "test_key_pool_matches_row_pool", ((4, 512, 1.0, 64, (128, 128, 256), 1.0), False)),
     ("test_gpu_pointnet", "test_key_pool_matches_row_pool", ((2, 128, 0.25, 16, (64, 64, 128), 0.3), True)),
+    ("test_gpu_pointnet", "test_key_pool_backward_with_zero_and_negative_gamma", ((3, 200, 2.5, 32, (64, 64, 128), 0.7),)),
+    ("test_gpu_pointnet", "test_key_pool_backward_with_zero_and_negative_gamma", ((4, 512, 2.0, 128, (256, 256, 512), 2.0),)),
     ("test_gpu_pointnet", "test_rebuilt_dy3_gives_bit_identical_gradients", ((3, 200, 2.5, 32, (64, 64, 128), 0.7),)),
     ("test_gpu_pointnet", "test_rebuilt_dy3_gives_bit_identical_gradients", ((4, 512, 2.0, 128, (256, 256, 512), 2.0),)),
     ("test_gpu_pointnet", "test_merged_mid_launch_gives_bit_identical_gradients", ((3, 200, 2.5, 32, (64, 64, 128), 0.7),)),

@@ -139,6 +139,18 @@ def test_prefetch_made_inside_a_capture_is_never_consumed_outside_it(monkeypatch
         assert not fn._prefetch_is_foreign()
         assert run() == base and fn._prefetched is None
         cap[0] = 0
+        # 3b. capturing, but the id cannot be determined: _native.capture_id hands out a FRESH negative number each time,
+        # so a prefetch tagged with one never equals a later answer -- always foreign, dropped, never consumed
+        unknown = [0]
+
+        def unknown_id(device=None):
+            unknown[0] -= 1
+            return unknown[0]
+        monkeypatch.setattr(_native, "capture_id", unknown_id)
+        fresh(); model.prefetch(data)
+        assert fn._prefetched["cap"] < 0 and fn._prefetch_is_foreign()
+        assert run() == base and fn._prefetched is None
+        monkeypatch.setattr(_native, "capture_id", lambda device=None: cap[0])
         # 4. a precision change between prefetch and forward: the handles froze the old code -> dropped, not consumed
         fresh(); model.prefetch(data)
         key = fn._prefetched["key"]

@@ -215,6 +215,127 @@ def test_two_rank_two_graph_step_on_one_gpu_over_gloo():
     assert all(g[1] and g[2] and g[3] == 3 for g in got), got
 
 
+def _worker_one_rank_rccl(rank, world, port, q):
+    """ONE rank, backend "nccl" (= RCCL on ROCm) on cuda:0: a real communicator on a one-GPU box.  (1) eager steps whose all-reduces
+    go through RCCL on the communication stream, bucket by bucket behind the split backward; (2) bench.py's default N > 1 step:
+    ONE hipGraph of two whole steps (even / odd workspace set) with the all-reduce calls captured INSIDE it -- [fcn+heads] forked
+    behind phase 1 of the backward, [pointnet] behind phase 2, Adam of each bucket at the head of the next step, the late form with
+    the [fcn+heads] update on the weight-packing branch.  Both must leave the parameters of the plain loop [forward, backward,
+    Adam] bit for bit (a sum over one rank is the identity)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    import torch.distributed as dist
+    from frustum_convnet_amd import _native, dist as fdist, synth
+    from frustum_convnet_amd.train_state import FlatTrainState
+    from frustum_convnet_amd.loss_fused import unit_grad
+    from helpers import load_golden, golden_inputs
+    from test_gpu_model import _model
+    torch.cuda.set_device(0)
+    r, w, _ = fdist.init_from_env(backend="nccl", single_rank_group=True)
+    assert (r, w) == (0, 1) and dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    g = load_golden("car_b4_n512")
+    data = synth.to_torch(golden_inputs(g), "cuda")
+    NSTEP = 4
+
+    def make(force):
+        m = _model(g)
+        m.train()
+        fdist.broadcast_state(m, 0)                      # (first collective: the communicator is created here)
+        return m, FlatTrainState(m, lr=1e-4, weight_decay=1e-4, world=1, force_comm=force)
+
+    # reference: the plain loop, no collectives
+    m0, st0 = make(False)
+    assert not st0.comm
+    for it in range(NSTEP + 1):
+        lo, _ = m0(data)
+        m0.backward(lo["total_loss"])
+        if it < NSTEP:
+            st0.adam_step()
+    torch.cuda.synchronize()
+    want, want_grad = st0.flat.clone(), st0.grad.clone()
+    res = {"rccl_loaded": "librccl" in open("/proc/self/maps").read()}
+    # (1) eager, over RCCL
+    m1, st1 = make(True)
+    assert st1.comm
+    m1.split_backward = True
+    for it in range(NSTEP + 1):
+        lo, _ = m1(data)
+        m1.backward_split(lo["total_loss"], between=lambda: st1.allreduce_bucket_async(0))
+        st1.allreduce_bucket_async(1)
+        st1.wait_allreduce()
+        if it < NSTEP:
+            st1.adam_step()
+    torch.cuda.synchronize()
+    res["eager"] = bool(torch.equal(st1.flat, want)) and bool(torch.equal(st1.grad, want_grad))
+    ones = torch.ones(4, device="cuda")
+    dist.all_reduce(ones)
+    res["ranks"] = int(ones[0].item())
+    # (2) the captured step, plain and late form
+    for late in (False, True):
+        m, st = make(True)
+        m.split_backward = True
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                  # prime: one backward + exchange, no optimiser step
+            m.next_batch = data
+            lo, _ = m(data)
+            m.backward(lo["total_loss"])
+            st.allreduce()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+
+        def late_bucket0():
+            st.wait_allreduce(st.buckets[0][0])
+            st.adam_step_bucket(0)
+        if late:
+            m._cn_pool.before_pack = late_bucket0
+        gph = torch.cuda.CUDAGraph()
+        ids = []
+        with torch.cuda.graph(gph, capture_error_mode="thread_local"):
+            ids.append(_native.capture_id())
+            m.feat_net.adopt_prefetch()
+            for k in range(2):
+                if late:
+                    st.wait_allreduce(st.buckets[1][0])
+                    st.adam_step_bucket(1)
+                else:
+                    st.wait_allreduce()
+                    st.adam_step()
+                m.next_batch = data
+                lo, _ = m(data)
+                pending = m.take_split()
+                lo["total_loss"].backward(gradient=unit_grad(lo["total_loss"].device))
+                st.allreduce_bucket_async(0)
+                pending.backward()
+                st.allreduce_bucket_async(1)
+            st.wait_allreduce()
+            ids.append(_native.capture_id())
+        m._cn_pool.before_pack = None
+        for it in range(NSTEP // 2):
+            gph.replay()
+        torch.cuda.synchronize()
+        key = "captured_late" if late else "captured"
+        res[key] = bool(torch.equal(st.flat, want)) and bool(torch.equal(st.grad, want_grad))
+        res[key + "_maxdiff"] = float((st.flat - want).abs().max())
+        res[key + "_capture_ids"] = (ids[0] > 0 and ids[0] == ids[1], _native.capture_id() == 0)
+    q.put(res)
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_group_eager_and_captured_step():
+    """RCCL under test on a ONE-GPU box: communicator set-up, the bucketed all-reduces on the communication
+    stream, and the collectives captured INTO the step's hipGraph -- parameters bit-identical to the step without communication."""
+    got = _run(_worker_one_rank_rccl, world=1)[0]
+    assert got["rccl_loaded"], got
+    assert got["ranks"] == 1
+    assert got["eager"], got
+    assert got["captured"] and got["captured_late"], got
+    assert all(got["captured_capture_ids"]) and all(got["captured_late_capture_ids"]), got
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -239,6 +239,17 @@ def test_dense_module_api_matches_oracle():
             (out * dout.cuda()).sum().backward()
         with pytest.raises(RuntimeError, match="point cloud"):
             net2(pc.clone().requires_grad_(True), None, ref)
+        # eval mode + gradients enabled + trainable parameters: the reference returns a differentiable tensor; this module
+        # refuses instead of silently returning one without a graph
+        net2.eval()
+        with pytest.raises(NotImplementedError, match="eval mode"):
+            net2(pc, None, ref)
+        with torch.no_grad():
+            assert net2(pc, None, ref).grad_fn is None
+        for p in net2.parameters():
+            p.requires_grad_(False)
+        assert net2(pc, None, ref).grad_fn is None          # frozen parameters: nothing to differentiate
+        net2.train()
 
 
 def test_cpu_input_fails_loudly():

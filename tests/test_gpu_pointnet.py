@@ -80,6 +80,67 @@ def test_key_pool_matches_row_pool(case, training):
     assert len(diff) <= max(4, ak.numel() // 10000), len(diff)
 
 
+@pytest.mark.parametrize("case", [(3, 200, 2.5, 32, (64, 64, 128), 0.7), (4, 512, 2.0, 128, (256, 256, 512), 2.0)],
+                         ids=lambda c: "B%d_C%d-K%d" % (c[0], c[4][2], c[3]))
+def test_key_pool_backward_with_zero_and_negative_gamma(case):
+    """Backward behind a key-pooled training forward against the one behind the row pooling, with one channel of BN3 at gamma = 0 and
+    beta > 0 (its pooled feature is relu(beta) > 0, every row of a window ties, the FIRST row wins and d gamma = sum dz * xhat of
+    THAT row -- the key of such a channel carries no value, so pool_keys_kernel fetches the winner's y3 itself: ADVICE r5) and one at
+    gamma < 0.  Every gradient of the scale agrees to 1e-5 of its maximum (arg-max rounding ties aside, the two are the same sums)."""
+    import ctypes
+    import os
+    import numpy as np
+    from frustum_convnet_amd import _native, pointnet_fused as pf, synth
+
+    B, N, stride, K, mlp, dist = case
+    dev = torch.device("cuda:0")
+    pc, ref, sd, one_hot = gsc.make_case(B, N, stride, K, mlp, dist)
+    sd["m.conv3.1.weight"][1] = -0.7
+    sd["m.conv3.1.weight"][2] = 0.0
+    sd["m.conv3.1.bias"][2] = 0.5
+    L = ref.shape[2]
+    dfeat = torch.from_numpy(synth.normalish(3, 1, (B, L, mlp[2])).astype(np.float32)).to(dev).contiguous()       # position-major
+    out = {}
+    old = os.environ.get("FCN_POOL_KEYS")
+    try:
+        for keys in ("1", "0"):
+            os.environ["FCN_POOL_KEYS"] = keys
+            sdg = {k: v.clone().to(dev) for k, v in sd.items()}
+            plist = []
+            for j in (1, 2, 3):
+                plist += [sdg["m.conv%d.0.weight" % j], sdg["m.conv%d.1.weight" % j], sdg["m.conv%d.1.bias" % j]]
+            bufs = ([sdg["m.conv%d.1.running_mean" % j] for j in (1, 2, 3)], [sdg["m.conv%d.1.running_var" % j] for j in (1, 2, 3)],
+                    [sdg["m.conv%d.1.num_batches_tracked" % j] for j in (1, 2, 3)])
+            pool = pf.WorkspacePool()
+            cfgt = (float(dist), int(K), True, 1e-5, 0.1, True, True)          # (.., need_grad, nlc)
+            feat, idx, cnt, ws, desc, keep = pf._forward_impl(pool, cfgt, pc.to(dev), ref.to(dev), None, bufs, plist, True)
+            assert (ws.pkey is not None) == (keys == "1")
+            assert float(feat[:, :, 2].max()) > 0          # the gamma = 0 channel pools to relu(beta) on every live window
+            Wc, gs, bs = keep[0], keep[1], keep[2]
+            dW = [torch.empty_like(w) for w in Wc]
+            dg = [torch.empty_like(g) for g in gs]
+            db = [torch.empty_like(b) for b in bs]
+            params = pf._params_struct(Wc, gs, bs, [None] * 3, [None] * 3, [None] * 3)
+            arr = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
+            rc = _native.lib().fcn_pn_backward(ctypes.byref(desc), ctypes.byref(params), dfeat.data_ptr(), ctypes.byref(ws.c),
+                                               arr(dW), arr(dg), arr(db), _native.current_stream(dev))
+            assert rc == 0, rc
+            torch.cuda.synchronize()
+            out[keys] = [t.detach().cpu() for t in dW + dg + db]
+    finally:
+        if old is None:
+            os.environ.pop("FCN_POOL_KEYS", None)
+        else:
+            os.environ["FCN_POOL_KEYS"] = old
+    names = ["dW1", "dW2", "dW3", "dg1", "dg2", "dg3", "db1", "db2", "db3"]
+    for n, a, b in zip(names, out["1"], out["0"]):
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9, (n, float((a - b).abs().max()), float(b.abs().max()))
+    dg3k, dg3r = out["1"][5], out["0"][5]
+    assert abs(float(dg3r[2])) > 0                       # the channel really has a d gamma
+    assert abs(float(dg3k[2] - dg3r[2])) <= 1e-5 * abs(float(dg3r[2])) + 1e-7, (float(dg3k[2]), float(dg3r[2]))
+
+
 @pytest.mark.parametrize("case", [gsc.CASES[1], gsc.CASES[4], gsc.CASES[5]], ids=lambda c: "B%d_N%d_s%s_K%d_C%d" % (c[0], c[1], c[2], c[3], c[4][2]))
 def test_rebuilt_dy3_gives_bit_identical_gradients(case):
     """FCN_STORE_DY3=0: dy3 is never materialised -- conv3's weight-gradient GEMM rebuilds it while staging from what the

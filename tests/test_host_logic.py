@@ -351,3 +351,20 @@ def test_refine_builder_refuses_the_non_rtc_geometry():
     config.reset_cfg()
     inputs.RefineInputBuilder(512, strides=(0.1, 0.2, 0.4, 0.8))      # the default (RTC True) constructs
 
+
+
+def test_bench_gpus_n_never_prints_a_line_for_fewer_ranks(tmp_path):
+    """`python bench.py --gpus 8` without a launcher used to measure ONE GPU and print n_gpus 1.  Now --gpus N with
+    WORLD_SIZE unset launches N ranks itself and refuses -- non-zero exit, no JSON line -- on a box with fewer than N GPUs (here:
+    none); with a launcher's WORLD_SIZE that disagrees with --gpus it refuses as well, for N = 1 too."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FCN_BENCH_ONE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert '"metric"' not in r.stdout and "refusing" in r.stderr
+    for gpus, world in (("1", "2"), ("2", "1"), ("4", "2")):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", gpus, "--steps", "1", "--warmup", "0"],
+                           env=dict(env, WORLD_SIZE=world, RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and '"metric"' not in r.stdout, (gpus, world, r.stdout[-300:], r.stderr[-300:])
