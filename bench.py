@@ -998,8 +998,14 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_batch, npoint, a.cfg)
         except Exception as e:  # noqa
             out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    print(json.dumps(out), flush=True)
     _shutdown_group()
+    # RCCL prints its version banner through C stdio (buffered when stdout is a pipe or a file: it would land BEHIND the line at
+    # exit): drain that buffer first, so that the JSON line is the last line of stdout
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa
+        pass
+    print(json.dumps(out), flush=True)
 
 
 def _shutdown_group():

@@ -152,22 +152,18 @@ class PointNetFeat(nn.Module):
         self.fused_front = os.environ.get("FCN_FUSED_FRONT", "1") != "0"
         self._stream_cache = {}
         self._prefetched = None     # prefetch(): the next batch's front, phase 1 (key, prepared handles, event, capture id)
-        # the widest scale is the long pole of the backward: its weight-gradient GEMMs run on a second stream beside
-        # its data-gradient chain (bit k of FCN_PN_SIDE = scale k+1; default scale 4 only)
-        # Stream topology switches (FCN_TOPO bit mask, default 0 = what measured fastest on ROCm 7.2 / MI355X):
-        #   1: scale 4 on its own forked stream too (else on the caller's stream, with a side stream for its wgrads)
-        #   2: no join after the scales; the FCN waits for each pooled map right before its first use (fcn_convnet_forward2)
-        #   4: the FCN backward continues on a second stream once the scale-4 gradient is final (fcn_fused.py)
-        # Every bit ADDS overlap on paper -- the FCN's first nine layers beside scale 4's PointNet, scale 4's backward
-        # beside the rest of the FCN backward -- and every bit measured SLOWER (16.1k -> 14.0-15.3k frustums/s, also with the
-        # streams folded into the 4 hardware queues ROCm uses by default, and with a high-priority capture stream -- graph replay
-        # ignores stream priorities): the
-        # captured branches already keep the CUs busy, and stretching the two latency-bound FCN chains costs more than
-        # the overlap returns.  Kept as tested options of the C-ABI, off by default.
-        self.topo = int(os.environ.get("FCN_TOPO", "0"))
-        mask = int(os.environ.get("FCN_PN_SIDE", "0" if self.topo & 1 else str(1 << (self.num_scales - 1))))
+        # the widest scale is the long pole of the backward: its weight-gradient GEMMs run on a second stream beside its
+        # data-gradient chain (set_wgrad_streams changes the choice).  Other stream topologies -- every scale forked, no join in
+        # front of the FCN, the FCN backward continuing on a second stream, other capture orders -- measured slower on ROCm 7.2 /
+        # MI355X in rounds 3-5 (EXPERIMENTS.md) and are not options of this layer any more.
+        self.set_wgrad_streams((self.num_scales - 1,))
+
+    def set_wgrad_streams(self, scales, three=False):
+        """Which scales (0-based) run their weight-gradient GEMMs on a second stream (fcn_pn_backward2; `three`: conv2's on a third,
+        fcn_pn_backward3).  Bit-identical gradients in every setting (tests/test_gpu_model.py)."""
         for k, net in enumerate(self.nets):
-            net._pool.side_wgrad = bool(mask >> k & 1)
+            net._pool.side_wgrad = k in tuple(scales)
+            net._pool.side_three = bool(three) and k in tuple(scales)
 
     @property
     def nets(self):
@@ -247,11 +243,9 @@ class PointNetFeat(nn.Module):
             net._pool.release(h["ws"])
         self._prefetched = None
 
-    def forward(self, point_cloud, sample_pc, feat=None, one_hot_vec=None, nlc=False, join=True, after_front=None):
+    def forward(self, point_cloud, sample_pc, feat=None, one_hot_vec=None, nlc=False, join=True):
         """join=False (fused FCN path): the caller's stream is NOT made to wait for the scales; self.done_events holds one
-        event per scale for the consumer to wait on (fcn_convnet_forward2 does, map by map).  after_front: called on the
-        caller's stream right behind the front's launches, before the scales fork (PointNetDet starts the FCN's weight packing
-        there: forked in front of the front, its 1650 workgroups delayed the front's light launches)."""
+        event per scale for the consumer to wait on (fcn_convnet_forward2 does, map by map)."""
         if one_hot_vec is not None:
             assert self.num_vec == one_hot_vec.shape[1]
         nets = self.nets
@@ -259,14 +253,12 @@ class PointNetFeat(nn.Module):
         self.done_events = None
         if not (self.concurrent_scales and point_cloud.is_cuda) or os.environ.get("FCN_SERIAL", "0") == "1":
             self.drop_prefetch()
-            if after_front is not None:
-                after_front()
             return tuple(net.forward_pooled(point_cloud, ref, one_hot_vec, nlc) for net, ref in zip(nets, sample_pc))
         # The scales are independent until the FCN: all but the last run on HIP streams forked from the current one and
         # the widest (the last scale, the long pole) on the current stream itself, captured as parallel branches of the step's
         # hipGraph, so one scale's tail (a few workgroups left on 256 CUs) overlaps the others' work.
-        #  * Forks are flat: ROCm 7.2 stream capture crashes on a fork from an already-forked stream, and scale 4's backward
-        #    forks a second stream for its weight-gradient GEMMs -- hence scale 4 stays on the current stream.
+        #  * Forks are flat: ROCm 7.2 stream capture crashes on a fork from an already-forked stream, and the widest scale's
+        #    backward forks a second stream for its weight-gradient GEMMs -- hence it stays on the current stream.
         #  * Launch order is heaviest first (4, 3, 1, 2); node creation order is 1, 2, 3, 4: autograd replays each scale's
         #    backward on the stream its node was created under, in REVERSE creation order -- widest first again.
         #    launch_pooled() / attach_pooled() separate the two orders.
@@ -274,8 +266,8 @@ class PointNetFeat(nn.Module):
         cur = torch.cuda.current_stream(dev)
         streams = self._streams(dev)
         fork = self._fork_event(dev)
-        # fused front: grouping + compaction + BN1 of all four scales in ONE launch on the caller's stream, in front of the
-        # fork (fcn_pn_group_compact); fused_front = False keeps the API-form grouping per scale (int64 idx, 5 nodes each)
+        # fused front: grouping + compaction + BN1 of all scales in ONE launch on the caller's stream, in front of the fork
+        # (fcn_pn_group_compact2); fused_front = False keeps the API-form grouping per scale (int64 idx, 5 nodes each)
         prepared = None
         if self._prefetched is not None and (self._prefetch_is_foreign() or
                                              self._prefetched["key"] != self._front_key(point_cloud, sample_pc, one_hot_vec, nlc,
@@ -292,45 +284,28 @@ class PointNetFeat(nn.Module):
             else:
                 prepared = [nets[s].prepare_pooled(point_cloud, sample_pc[s], one_hot_vec, nlc) for s in range(ns)]
                 group_compact(prepared, point_cloud)
-        if after_front is not None:
-            after_front()
         fork.record(cur)
+        sts = [streams[i] for i in range(ns - 1)] + [cur]
         handles = [None] * ns
-        s4_forked = bool(self.topo & 1)
-        # FCN_SCALE_STREAMS="0,0,2" (tuning): which forked stream each of the first ns-1 scales runs on (default: one each)
-        smap = [int(v) for v in os.environ.get("FCN_SCALE_STREAMS", "").split(",") if v != ""]
-        smap = smap if len(smap) == ns - 1 else list(range(ns - 1))
-        sts = [streams[smap[i]] for i in range(ns - 1)] + [streams[ns - 1] if s4_forked else cur]
-        heavy_first = (ns - 1,) + tuple(range(ns - 2, 1, -1)) + (0, 1)          # 4 scales: (3, 2, 0, 1)
-        waited = set()
-        for s in (((ns - 1,) + tuple(range(ns - 1))) if s4_forked else heavy_first):
-            st = sts[s]
-            if st is not cur and id(st) not in waited:
-                waited.add(id(st))
-                st.wait_event(fork)
-            with torch.cuda.stream(st):
+        for s in (ns - 1,) + tuple(range(ns - 2, 1, -1)) + (0, 1):           # heaviest first; 4 scales: (3, 2, 0, 1)
+            if sts[s] is not cur:
+                sts[s].wait_event(fork)
+            with torch.cuda.stream(sts[s]):
                 if prepared is not None:
                     handles[s] = launch_prepared(prepared[s])
                 else:
                     handles[s] = nets[s].launch_pooled(point_cloud, sample_pc[s], one_hot_vec, nlc)
         outs = [None] * ns
         done = self._done_events(dev)
-        # (FCN_ATTACH_ORDER="1,0,2,3", tuning: the order the autograd nodes are created in -- the backward runs them in reverse,
-        # and ROCm's graph executor assigns its four internal streams to branches in capture order)
-        aord = [int(v) for v in os.environ.get("FCN_ATTACH_ORDER", "").split(",") if v != ""]
-        aord = aord if sorted(aord) == list(range(ns)) else list(range(ns))
-        for s in aord:
+        for s in range(ns):
             with torch.cuda.stream(sts[s]):
                 outs[s] = nets[s].attach_pooled(handles[s])
                 done[s].record(sts[s])
-        if not (self.topo & 2):
-            join = True
-        if join:
-            for s in range(ns):
-                cur.wait_event(done[s])
-                outs[s].record_stream(cur)
-        else:
-            self.done_events = done
+        # (the join is always made: consuming the maps one by one without it -- the FCN's first layers beside the widest scale --
+        # measured slower; fcn_convnet_forward2 still accepts per-map events)
+        for s in range(ns):
+            cur.wait_event(done[s])
+            outs[s].record_stream(cur)
         return tuple(outs)
 
     def _done_events(self, device):
@@ -656,27 +631,12 @@ class PointNetDet(nn.Module):
                                       "model.fused_fcn = False explicitly to run the nn.Conv1d modules instead")
         if self.fused_fcn:
             from .fcn_fused import convnet_fused, convnet_prepack
-            # the FCN's weight re-packing depends on the weights only: it runs on a side stream beside the PointNet scales.
-            # FCN_PACK_ORDER: "first" (default) forks it in front of the grouping front; "behind" behind the front's launches;
-            # "beside" forks it in front of them but captures its launch behind theirs
-            pre_box = []
-            order = os.environ.get("FCN_PACK_ORDER", "first")
+            # the FCN's weight re-packing depends on the weights only: it runs on a side stream beside the PointNet scales, forked
+            # in FRONT of the grouping front (behind it, or captured behind its launches, measured slower)
             dev = point_cloud.device
-            ev0 = None
-            if order == "beside":
-                ev0 = self._zero_cache.get("pack_ev" + str(dev))
-                if ev0 is None:
-                    ev0 = self._zero_cache["pack_ev" + str(dev)] = torch.cuda.Event(enable_timing=False)
-                ev0.record(torch.cuda.current_stream(dev))
-            start_pack = lambda: pre_box.append(convnet_prepack(self._cn_pool, self.conv_net, self.cls_out, self.reg_out,
-                                                                batch_size, [r.shape[2] for r in refs], one_hot_vec, dev,
-                                                                after=ev0))
-            if order == "first":
-                start_pack()
-            # no join after the scales: the FCN waits for each pooled map right before the first layer that reads it
-            feats = self.feat_net(xyz, refs, None, one_hot_vec, nlc=True, join=False,
-                                  after_front=None if order == "first" else start_pack)
-            pre = pre_box[0]
+            pre = convnet_prepack(self._cn_pool, self.conv_net, self.cls_out, self.reg_out, batch_size,
+                                  [r.shape[2] for r in refs], one_hot_vec, dev)
+            feats = self.feat_net(xyz, refs, None, one_hot_vec, nlc=True, join=False)
             if self.split_backward and self.training and torch.is_grad_enabled():
                 # two-phase backward (backward_split): the FCN sees detached leaves, so loss.backward() stops at the pooled
                 # feature maps and the PointNet scales are differentiated by a second call

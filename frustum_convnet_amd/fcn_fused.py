@@ -53,23 +53,10 @@ class CnWorkspace:
                       p(self.partial), p(self.oh64), p(self.flags))
 
 
-# gradient tensor (data_ptr) -> event its consumer must wait for: set by _ConvNetFused.backward for the feature-map
-# gradients that become final on the continuation stream, consumed by pointnet_fused._PointNetPooled.backward
-PENDING_GRADS = {}
-
-
-def wait_pending_grad(t):
-    ev = PENDING_GRADS.pop(t.data_ptr(), None)
-    if ev is not None:
-        torch.cuda.current_stream(t.device).wait_event(ev)
-
-
 class CnPool:
     def __init__(self):
         self.free = {}
         self.side = {}
-        self.cont = {}
-        self.last_done = None
         self._flags = {}
 
     def flags(self, device):
@@ -78,19 +65,6 @@ class CnPool:
         if key not in self._flags:
             self._flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
         return self._flags[key]
-
-    def cont_stream(self, device):
-        """Continuation stream of the backward + its events (caller-owned, handed to fcn_convnet_backward)."""
-        key = str(device)
-        if key not in self.cont:
-            with torch.cuda.device(device):
-                st = torch.cuda.Stream(device=device)
-                evs = [torch.cuda.Event(enable_timing=False) for _ in range(CN_MAXLEV)]
-                for ev in evs:
-                    ev.record()                     # materialise the hipEvent_t handles
-                arr = (ctypes.c_void_p * CN_MAXLEV)(*[ev.cuda_event for ev in evs])
-            self.cont[key] = (st, evs, arr)
-        return self.cont[key]
 
     def pack_stream(self, device):
         """Side stream + event for the early weight packing (one per device)."""
@@ -218,31 +192,14 @@ class _ConvNetFused(torch.autograd.Function):
         params = CnParams(_arr(Ws + [Wh]), _arr(gs), _arr(bs), _arr([]), _arr([]), _arr([]), bh.data_ptr())
         fp = _arr(feats, CN_MAXLEV)
         dfp = _arr(dfeats, CN_MAXLEV)
-        # continuation stream: after the third launch the widest map's gradient is final and the rest of the chain moves to a second
-        # stream, so the scale-4 PointNet backward (the long pole, next on THIS stream) overlaps it.  The gradients of the
-        # other maps become final on that stream: their consumers find the event to wait for in PENDING_GRADS.
-        use_cont = bool(int(os.environ.get("FCN_TOPO", "0")) & 4)    # see det_base.PointNetFeat: measured slower, off
-        cont, evs, evarr = ctx.pool.cont_stream(dev)
-        if use_cont:
-            for t in dfeats[:nlev - 1]:
-                t.record_stream(cont)
+        # (the C-ABI can continue the chain on a second stream once the widest map's gradient is final -- stream2 / events of
+        # fcn_convnet_backward; measured slower over the step on MI355X in two rounds, EXPERIMENTS.md, so this layer passes none)
         with torch.cuda.device(dev):
             _native.check(L.fcn_convnet_backward(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(ws.c), fp,
                                                  None if oh is None else oh.data_ptr(), dlogits.data_ptr(), dfp,
                                                  _arr(dW), _arr(dg), _arr(db), dbh.data_ptr(),
-                                                 _native.current_stream(dev),
-                                                 ctypes.c_void_p(cont.cuda_stream) if use_cont else None,
-                                                 evarr if use_cont else None),
+                                                 _native.current_stream(dev), None, None),
                           "fcn_convnet_backward")
-        if not use_cont:
-            evs = [None] * CN_MAXLEV
-        else:
-            for k in range(1, nlev):                 # events[k]: dfeats[nlev-1-k] final
-                PENDING_GRADS[dfeats[nlev - 1 - k].data_ptr()] = evs[k]
-        # the parameter gradients are final at evs[3] as well: whoever consumes dfeats[0] joins the continuation stream,
-        # and this stream joins it here when nobody will (no PointNet consumer, e.g. features without grad)
-        ev_done = evs[nlev - 1]
-        ctx.pool.last_done = ev_done
         ctx.pool.release(ws)
         ctx.ws, ctx.live = None, False
         ncls = 2
@@ -256,10 +213,6 @@ class _ConvNetFused(torch.autograd.Function):
                 if gd[h0 + j] is not None:           # flat views that are not adjacent: copy in, hand autograd nothing
                     gd[h0 + j].copy_(hz[j])
                     hz[j] = None
-        if ev_done is not None and (any(o is not None for o in outs) or any(h is not None for h in hz)):
-            # ordinary autograd gradients are consumed on THIS stream as soon as we return: they are final on the
-            # continuation stream only (FlatTrainState's in-place gradients need no such wait)
-            torch.cuda.current_stream(dev).wait_event(ev_done)
         return (None,) * 8 + tuple(dfeats) + tuple(outs) + tuple(hz)
 
 

@@ -49,7 +49,13 @@ class InputBuilder:
     def build(self, records, draws=None, with_seg=True):
         """records: list of dicts with RECORD_KEYS (points (n,>=3) float32 in rect camera coordinates, seg (n,), box2d (4,),
         P (3,4), box3d (8,3) corners, heading, size (l,w,h), frustum_angle, type).  draws: (choice (B,N) int32, coin (B),
-        normal (B)) or None to draw like the reference.  Returns the batch dict on the device."""
+        normal (B)) or None to draw like the reference.  Returns the batch dict on the device.
+        = upload() (host -> device copies of the raw records and the draws) + launch() (the kernel)."""
+        return self.launch(self.upload(records, draws, with_seg))
+
+    def upload(self, records, draws=None, with_seg=True):
+        """The raw records of a batch and their random draws as device tensors (ONE packed point buffer): what a loader hands
+        the GPU.  The returned dict feeds launch() any number of times (a resident raw batch re-built every step: bench.py)."""
         if self.device.type != "cuda":
             raise RuntimeError("frustum_convnet_amd: input construction is a HIP kernel (MI355X only); no CPU fallback")
         B, N = len(records), self.npoints
@@ -67,9 +73,19 @@ class InputBuilder:
              "fangle": up(f64("frustum_angle", ())), "box2d": up(f64("box2d", (4,))), "P": up(f64("P", (12,))),
              "corners": up(f64("box3d", (24,))), "heading": up(f64("heading", ())), "size": up(f64("size", (3,))),
              "coin": up(np.asarray(coin, dtype=np.float64)), "normal": up(np.asarray(normal, dtype=np.float64))}
-        seg_raw = None
-        if with_seg:
-            seg_raw = up(np.concatenate([np.asarray(r["seg"]).astype(np.int64) for r in records], 0))
+        t["seg"] = up(np.concatenate([np.asarray(r["seg"]).astype(np.int64) for r in records], 0)) if with_seg else None
+        size_class = [self.classes.index(r["type"]) for r in records]
+        t["size_class"] = torch.tensor(size_class, dtype=torch.int64).view(B, 1).to(dev, non_blocking=True)
+        if self.one_hot:
+            oh = np.zeros((B, len(self.classes)), dtype=np.float32)
+            oh[np.arange(B), size_class] = 1.0
+            t["one_hot"] = up(oh)
+        t["B"], t["pt_stride"] = B, stride
+        return t
+
+    def alloc(self, B, with_seg=True):
+        """Output tensors of launch() for a batch of B frustums (pass as `out` to write the same buffers every step)."""
+        dev, N = self.device, self.npoints
         f32 = dict(dtype=torch.float32, device=dev)
         out = {"point_cloud": torch.empty((B, 3, N), **f32), "rot_angle": torch.empty((B, 1), **f32),
                "cls_label": torch.empty((B, self.L[1]), dtype=torch.int64, device=dev),
@@ -79,27 +95,42 @@ class InputBuilder:
             out["center_ref%d" % (s + 1)] = torch.empty((B, 3, self.L[s]), **f32)
         if with_seg:
             out["seg_label"] = torch.empty((B, N), dtype=torch.int64, device=dev)
-        desc = InpDesc(B, N, stride, (ctypes.c_int32 * 4)(*self.L), (ctypes.c_double * 4)(*self.strides), self.max_depth,
+        return out
+
+    def launch(self, t, out=None):
+        """ONE kernel launch on the current stream: uploaded records `t` -> the batch dict (into `out` when given: capturable
+        into a hipGraph, no allocation, no host work besides the call).  size_class / one_hot are the uploaded tensors."""
+        B, N = t["B"], self.npoints
+        dev = self.device
+        if out is None:
+            out = self.alloc(B, with_seg=t["seg"] is not None)
+        desc = InpDesc(B, N, t["pt_stride"], (ctypes.c_int32 * 4)(*self.L), (ctypes.c_double * 4)(*self.strides), self.max_depth,
                        1 if self.random_flip else 0, 1 if self.random_shift else 0)
         refs = (ctypes.c_void_p * 4)(*[out["center_ref%d" % (s + 1)].data_ptr() for s in range(4)])
         p = lambda x: None if x is None else x.data_ptr()
         L = _native.lib()
         with torch.cuda.device(dev):
-            _native.check(L.fcn_prepare_inputs(ctypes.byref(desc), p(t["raw"]), p(t["off"]), p(seg_raw), p(t["choice"]),
+            _native.check(L.fcn_prepare_inputs(ctypes.byref(desc), p(t["raw"]), p(t["off"]), p(t["seg"]), p(t["choice"]),
                                                p(t["fangle"]), p(t["box2d"]), p(t["P"]), p(t["corners"]), p(t["heading"]),
                                                p(t["size"]), p(t["coin"]), p(t["normal"]), p(out["point_cloud"]), refs,
                                                p(out["cls_label"]), p(out["box3d_center"]), p(out["box3d_heading"]),
-                                               p(out["box3d_size"]), p(out["rot_angle"]), p(out.get("seg_label")),
+                                               p(out["box3d_size"]), p(out["rot_angle"]),
+                                               p(out.get("seg_label")) if t["seg"] is not None else None,
                                                _native.current_stream(dev)), "fcn_prepare_inputs")
         for v in t.values():                       # the uploads are read by the kernel just enqueued
-            v.record_stream(torch.cuda.current_stream(dev))
-        size_class = [self.classes.index(r["type"]) for r in records]
-        out["size_class"] = torch.tensor(size_class, dtype=torch.int64).view(B, 1).to(dev, non_blocking=True)
-        if self.one_hot:
-            oh = np.zeros((B, len(self.classes)), dtype=np.float32)
-            oh[np.arange(B), size_class] = 1.0
-            out["one_hot"] = up(oh)
+            if isinstance(v, torch.Tensor):
+                v.record_stream(torch.cuda.current_stream(dev))
+        out["size_class"] = t["size_class"]
+        if "one_hot" in t:
+            out["one_hot"] = t["one_hot"]
         return out
+
+    def algorithmic_bytes(self, B, with_seg=True, pt_stride=4):
+        """HBM bytes one launch has to move (the roofline's numerator): per frustum N gathered raw points + their draw indices
+        (+ seg labels) in, point cloud + window centres + labels (+ seg) out; the per-frustum scalars (~400 B) ignored."""
+        N = self.npoints
+        per = N * (4 * pt_stride + 4) + 12 * N + 12 * sum(self.L) + 8 * self.L[1] + (16 * N if with_seg else 0)
+        return B * per
 
 
 def draw_sunrgbd(counts, npoints, random_flip=True, random_shift=True, rng=np.random):

@@ -253,8 +253,6 @@ class _PointNetPooled(torch.autograd.Function):
         Wc, gs, bs, cnt, idx, oh = ctx.keep
         dev = dfeat.device
         C1, C2, C3 = desc.C1, desc.C2, desc.C3
-        from .fcn_fused import wait_pending_grad
-        wait_pending_grad(dfeat)                  # final on the FCN backward's continuation stream (if it came from there)
         dfeat.record_stream(torch.cuda.current_stream(dev))
         dfeat = dfeat.contiguous().float()
         # gradient destinations: the parameter's flat-buffer view when the caller trains through FlatTrainState
@@ -270,11 +268,10 @@ class _PointNetPooled(torch.autograd.Function):
         if ctx.pool.side_wgrad:
             side, _evs, evarr, side3 = ctx.pool.side_stream(dev)
             s2 = ctypes.c_void_p(side.cuda_stream)
-            # three-way split (conv2's weight gradient on a stream of its own, fcn_pn_backward3; its capture order puts the two
-            # extra branches on the narrow scales' executor streams): the widest scale's chain 335 -> 269 us, but both narrow scales
-            # then wait for those branches and run alone at the tail -- step +4 % slower on MI355X (EXPERIMENTS.md round 4).
-            # FCN_PN_SIDE3=1 turns it on for experiments
-            three = os.environ.get("FCN_PN_SIDE3", "0") == "1" and hasattr(L, "fcn_pn_backward3")
+            # three-way split (conv2's weight gradient on a stream of its own, fcn_pn_backward3): the widest scale's chain 335 -> 269 us,
+            # but both narrow scales then wait for those branches and run alone at the tail -- step +4 % slower on MI355X (EXPERIMENTS.md
+            # round 4).  pool.side_three turns it on (tests: bit-identical gradients)
+            three = bool(getattr(ctx.pool, "side_three", False)) and hasattr(L, "fcn_pn_backward3")
         else:
             s2, evarr = None, None
         with torch.cuda.device(dev):

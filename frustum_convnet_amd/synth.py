@@ -130,6 +130,60 @@ def make_batch(batch, npoint, strides=(0.25, 0.5, 1.0, 2.0), max_depth=70.0, see
     return out
 
 
+KITTI_P2 = ((721.5377, 0.0, 609.5593, 44.85728), (0.0, 721.5377, 172.854, 0.2163791), (0.0, 0.0, 1.0, 0.002745884))
+
+
+def make_records(batch, seed=1234, n_raw=(1200, 2400), max_depth=70.0):
+    """Synthetic RAW frustum records -- what the reference's loader reads from its pickles before __getitem__ builds a sample
+    (datasets/provider_sample.py:137-262; keys = frustum_convnet_amd.inputs.RECORD_KEYS): per frustum a KITTI-car-shaped point
+    set in RECT CAMERA coordinates (n, 4) float32 (n ~ U(n_raw): the loader resamples it to NUM_SAMPLES), its segmentation mask,
+    the 2-D box and KITTI projection matrix whose centre ray carries the sliding-frustum centres, the 3-D box (corners, heading,
+    size) of a car on that ray, and the frustum angle (-atan2(z, x) of the box-centre ray).  Same point statistics as make_batch
+    (60 % foreground around the object, 40 % background along the ray), laid out in the frustum's own frame and rotated back."""
+    P = np.asarray(KITTI_P2, dtype=np.float64)
+    fu, fv, cu, cv = P[0, 0], P[1, 1], P[0, 2], P[1, 2]
+    bx, by = P[0, 3] / (-fu), P[1, 3] / (-fv)
+    u = lambda name, shape, lane=0: uniform01(seed, stream_id(name), shape, lane)
+    z_obj = 5.0 + u("rec_z_obj", (batch,)) * 55.0
+    px = 200.0 + u("rec_px", (batch,)) * 840.0               # 2-D box centre (pixels)
+    py = 150.0 + u("rec_py", (batch,)) * 60.0
+    nraw = (n_raw[0] + u("rec_n", (batch,)) * (n_raw[1] - n_raw[0])).astype(np.int64)
+    heading = (u("rec_heading", (batch,)) * 2.0 - 1.0) * np.pi
+    size = np.array(CAR_MEAN_SIZE)[None, :] * (0.9 + 0.2 * u("rec_size", (batch, 3)))
+    recs = []
+    for b in range(batch):
+        ray = lambda z: np.stack([(px[b] - cu) * z / fu + bx, (py[b] - cv) * z / fv + by, z], -1)      # (data_utils.py:73-93)
+        c = ray(np.array([20.0]))[0]                       # (the reference takes the angle of the ray's point at depth 20)
+        fangle = -np.arctan2(c[2], c[0])
+        rot = np.pi / 2.0 + fangle
+        cs, sn = np.cos(rot), np.sin(rot)
+        ctr0 = ray(np.array([z_obj[b]]))[0]
+        d_obj = ctr0[0] * sn + ctr0[2] * cs                # the object's depth in the frustum's own (rotated) frame
+        n = int(nraw[b])
+        lane = 1000 * (b + 1)
+        is_fg = u("rec_fg", (n,), lane) < 0.6
+        zf = d_obj + 0.8 * normalish(seed + b, stream_id("rec_zfg"), (n,))
+        zb = u("rec_zbg", (n,), lane) * max_depth
+        d = np.clip(np.where(is_fg, zf, zb), 0.05, max_depth - 0.05)
+        # frustum frame (x lateral, y vertical, d depth along the centre ray) -> rect camera frame: the inverse of rotate_pc_along_y
+        xl = (u("rec_x", (n,), lane) * 4.0 - 2.0) * (d / 20.0 + 0.2)
+        yl = u("rec_y", (n,), lane) * 2.5 - 1.5
+        xc = xl * cs + d * sn
+        zc = -xl * sn + d * cs
+        pts = np.stack([xc, (py[b] - cv) * zc / fv + by + yl, zc, u("rec_i", (n,), lane)], 1).astype(np.float32)
+        ctr = ray(np.array([z_obj[b]]))[0]
+        l, w, h = size[b]
+        ch, sh = np.cos(heading[b]), np.sin(heading[b])
+        xs = np.array([l, l, -l, -l, l, l, -l, -l]) / 2.0
+        ys = np.array([h, h, h, h, -h, -h, -h, -h]) / 2.0
+        zs = np.array([w, -w, -w, w, w, -w, -w, w]) / 2.0
+        corners = np.stack([ch * xs + sh * zs + ctr[0], ys + ctr[1], -sh * xs + ch * zs + ctr[2]], 1)   # (data_utils.py:44-70)
+        recs.append({"points": pts, "seg": is_fg.astype(np.int64), "box2d": np.array([px[b] - 40, py[b] - 25, px[b] + 40, py[b] + 25]),
+                     "P": P.copy(), "box3d": corners, "heading": float(heading[b]), "size": size[b].copy(),
+                     "frustum_angle": float(fangle), "type": "Car"})
+    return recs
+
+
 def fill_state_dict(state_dict, seed=7):
     """Overwrite every entry of a torch state_dict in place from the counter hash.
 

@@ -222,6 +222,8 @@ def _worker_one_rank_rccl(rank, world, port, q):
     behind phase 1 of the backward, [pointnet] behind phase 2, Adam of each bucket at the head of the next step, the late form with
     the [fcn+heads] update on the weight-packing branch.  Both must leave the parameters of the plain loop [forward, backward,
     Adam] bit for bit (a sum over one rank is the identity)."""
+    import faulthandler
+    faulthandler.enable()
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
@@ -322,7 +324,17 @@ def _worker_one_rank_rccl(rank, world, port, q):
         res[key + "_maxdiff"] = float((st.flat - want).abs().max())
         res[key + "_capture_ids"] = (ids[0] > 0 and ids[0] == ids[1], _native.capture_id() == 0)
     q.put(res)
+    # orderly teardown, then a hard exit: graphs that hold captured RCCL launches, the communicator and the HIP runtime are
+    # otherwise destroyed in interpreter-shutdown order (the first run of this test on the pool ended in SIGSEGV after its results
+    # were in; 7 later runs did not -- the results travel through the queue either way)
+    del gph, m, st, m0, st0, m1, st1
+    torch.cuda.synchronize()
     dist.destroy_process_group()
+    q.close()
+    q.join_thread()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
 
 
 def test_one_rank_rccl_group_eager_and_captured_step():

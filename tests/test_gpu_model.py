@@ -318,26 +318,27 @@ def test_backward_launch_structures_give_bit_identical_gradients(case):
     g = load_golden(case)
     data = synth.to_torch(golden_inputs(g), "cuda")
     grads = {}
-    settings = {"default": {}, "one stream, 8 launches": {"FCN_PN_SIDE": "0", "FCN_PN_MID": "0"},
-                "one stream, merged mid": {"FCN_PN_SIDE": "0", "FCN_PN_MID": "1"}, "three streams": {"FCN_PN_SIDE3": "1"}}
-    keys = ("FCN_PN_SIDE", "FCN_PN_MID", "FCN_PN_SIDE3")
-    saved = {k: os.environ.get(k) for k in keys}
+    # name -> (FCN_PN_MID, scales whose weight-gradient GEMMs run on a second stream (None: the default, the widest), a third one too)
+    settings = {"default": (None, None, False), "one stream, 8 launches": ("0", (), False),
+                "one stream, merged mid": ("1", (), False), "three streams": (None, None, True)}
+    saved = os.environ.get("FCN_PN_MID")
     try:
-        for name, env in settings.items():
-            for k in keys:
-                os.environ.pop(k, None)
-            os.environ.update(env)
-            m = _model(g)              # (the switches are read when the model / its workspaces are built)
+        for name, (mid, side, three) in settings.items():
+            os.environ.pop("FCN_PN_MID", None)
+            if mid is not None:
+                os.environ["FCN_PN_MID"] = mid
+            m = _model(g)              # (FCN_PN_MID is read when the workspaces are built)
             m.train()
+            fn = m.feat_net
+            fn.set_wgrad_streams((fn.num_scales - 1,) if side is None else side, three=three)
             losses, _ = m(data)
             losses["total_loss"].backward()
             torch.cuda.synchronize()
             grads[name] = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters() if p.grad is not None}
     finally:
-        for k, v in saved.items():
-            os.environ.pop(k, None)
-            if v is not None:
-                os.environ[k] = v
+        os.environ.pop("FCN_PN_MID", None)
+        if saved is not None:
+            os.environ["FCN_PN_MID"] = saved
     ref = grads["default"]
     assert len(ref) > 70
     for name, gr in grads.items():
