@@ -111,23 +111,45 @@ TIMED = ("fcn_pn_group_compact2", "fcn_pn_forward", "fcn_convnet_pack", "fcn_con
          "fcn_det_iou_metrics", "fcn_convnet_backward", "fcn_pn_backward2", "fcn_adam_step_f32")
 
 
+def _entry_key(name, a):
+    if name in ("fcn_pn_forward", "fcn_pn_backward2"):
+        d = a[0]._obj                      # the PnDesc behind ctypes.byref()
+        return "%s[L=%d,K=%d,C=%d-%d-%d]" % (name, d.L, d.K, d.C1, d.C2, d.C3)
+    return name
+
+
 class CallTimer:
-    def __init__(self, lib):
-        self.lib, self.orig, self.rec = lib, {}, []
+    """Brackets every C-ABI call of TIMED on the stream it is launched on: with HIP events (eager launches), or -- slots given --
+    with fcn_stamp launches (device wall clock, 100 MHz) that are CAPTURED with the step and fire inside every replay."""
+
+    def __init__(self, lib, slots=None, dev=None):
+        self.lib, self.orig, self.rec, self.slots, self.dev = lib, {}, [], slots, dev
 
     def __enter__(self):
+        from frustum_convnet_amd import _native
         for name in TIMED:
             fn = getattr(self.lib, name)
             self.orig[name] = fn
 
             def wrap(*a, _fn=fn, _name=name):
+                if self.slots is not None:
+                    k = len(self.rec)
+                    if 2 * k + 2 > self.slots.numel():
+                        return _fn(*a)
+                    stamp = self.orig_stamp
+                    _native.check(stamp(self.slots.data_ptr() + 16 * k, _native.current_stream(self.dev)), "fcn_stamp")
+                    rc = _fn(*a)
+                    _native.check(stamp(self.slots.data_ptr() + 16 * k + 8, _native.current_stream(self.dev)), "fcn_stamp")
+                    self.rec.append((_entry_key(_name, a), None, None, None))
+                    return rc
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = _fn(*a)
                 e1.record()
-                self.rec.append((_name, e0, e1, a))
+                self.rec.append((_entry_key(_name, a), e0, e1, None))
                 return rc
             setattr(self.lib, name, wrap)
+        self.orig_stamp = self.lib.fcn_stamp
         return self
 
     def __exit__(self, *exc):
@@ -146,7 +168,7 @@ def fcn_flops(B, Ls, nvec=3, c1=128, nout=41):
     return 2.0 * macs * B
 
 
-def kernel_table(model, state, data, optim, prec, reps=5):
+def kernel_table(model, state, data, optim, prec, reps=10, graph=True):
     """Per C-ABI entry point: launches per step, live GPU time, executed FLOPs / algorithmic bytes, fraction of its roof."""
     from frustum_convnet_amd import _native
     lib = _native.lib()
@@ -154,23 +176,62 @@ def kernel_table(model, state, data, optim, prec, reps=5):
     Ls = [data["center_ref%d" % i].shape[2] for i in range(1, 6) if ("center_ref%d" % i) in data]
     agg = {}
     model.feat_net.drop_prefetch()                       # (a front the last replayed step prefetched: this table times the whole front)
-    for rep in range(reps + 1):
-        with CallTimer(lib) as ct:
-            losses, _ = model(data)
-            model.backward(losses["total_loss"])
-            if optim:
-                state.adam_step()
+    dev = data["point_cloud"].device
+
+    def one_step():
+        losses, _ = model(data)
+        model.backward(losses["total_loss"])
+        if optim:
+            state.adam_step()
+
+    how = None
+    if graph:
+        # the step captured ONCE with a device-clock stamp in front of and behind every entry point's launches, on the stream they
+        # are launched on: the intervals are taken inside the REPLAYED graph, the form the headline times
+        try:
+            slots = torch.zeros(512, dtype=torch.int64, device=dev)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                one_step()
+            torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-        if rep == 0:
-            continue                                     # first pass: allocator / event warm-up
-        for name, e0, e1, a in ct.rec:
-            key = name
-            if name in ("fcn_pn_forward", "fcn_pn_backward2"):
-                d = a[0]._obj                      # the PnDesc behind ctypes.byref()
-                key = "%s[L=%d,K=%d,C=%d-%d-%d]" % (name, d.L, d.K, d.C1, d.C2, d.C3)
-            r = agg.setdefault(key, {"ms": 0.0, "calls": 0})
-            r["ms"] += e0.elapsed_time(e1)
-            r["calls"] += 1
+            g = torch.cuda.CUDAGraph()
+            with CallTimer(lib, slots=slots, dev=dev) as ct:
+                with torch.cuda.graph(g):
+                    one_step()
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+            for rep in range(reps):
+                g.replay()
+                torch.cuda.synchronize()
+                sl = slots.cpu().numpy().astype(np.float64) * 1e-5          # 100 MHz ticks -> ms
+                for k, (key, _, _, _) in enumerate(ct.rec):
+                    r = agg.setdefault(key, {"ms": 0.0, "calls": 0})
+                    r["ms"] += sl[2 * k + 1] - sl[2 * k]
+                    r["calls"] += 1
+            how = ("device-clock stamps (fcn_stamp) captured in front of and behind the entry point's launches, on their launch "
+                   "stream, read after each of %d REPLAYS of the captured step (one step per graph, whole front in the step); the "
+                   "2 x %d stamp launches stretch a replay by a few percent" % (reps, len(ct.rec)))
+            del g
+        except Exception as e:  # noqa
+            print("[bench] stamped capture failed (%s: %s); timing eager launches instead" % (type(e).__name__, e), file=sys.stderr)
+            agg = {}
+            model.feat_net.drop_prefetch()
+            torch.cuda.synchronize()
+    if not agg:
+        for rep in range(reps + 1):
+            with CallTimer(lib) as ct:
+                one_step()
+                torch.cuda.synchronize()
+            if rep == 0:
+                continue                                     # first pass: allocator / event warm-up
+            for key, e0, e1, _ in ct.rec:
+                r = agg.setdefault(key, {"ms": 0.0, "calls": 0})
+                r["ms"] += e0.elapsed_time(e1)
+                r["calls"] += 1
+        how = "HIP events on the launch stream around the call, eager launches, mean of %d steps" % reps
     # executed rows per scale (live entries) from the workspaces of the last forward
     nets = model.feat_net.nets
     E = {}
@@ -217,7 +278,7 @@ def kernel_table(model, state, data, optim, prec, reps=5):
             row.update(bound="hbm", bytes_algorithmic=nbytes, achieved_tbps=round(tb, 4), frac=round(tb / PEAK_HBM_TBPS, 4))
         rows.append(row)
     rows.sort(key=lambda r: -r["ms_per_step"])
-    return rows, peak_mm
+    return rows, peak_mm, how
 
 
 def source_hash():
@@ -278,10 +339,11 @@ def grouping_op_row(data, cfg_name, reps=20):
             "note": "standalone operator (the model itself uses the fused front, fcn_pn_group_compact2, which never writes idx)"}
 
 
-def pmc_traffic(kind, entry=None):
+def pmc_traffic(kind, entry=None, cfg_name="car"):
     """HBM bytes from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, written by tools/pmc_summarize.py from
-    tools/gpu_traffic.sh) -- only when they were measured on THESE kernel sources.  kind "step": the whole-step record;
-    kind "entry": {"launches_per_step", "bytes_per_step", "bytes_per_launch"} of one C-ABI entry point."""
+    tools/gpu_traffic.sh, keyed by configuration) -- only when they were measured on THESE kernel sources and for THIS
+    configuration.  kind "step": the whole-step record; kind "entry": {"launches_per_step", "bytes_per_step", "bytes_per_launch"}
+    of one C-ABI entry point.  -> (record | None, reason | None)."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         d = json.load(open(p))
@@ -290,10 +352,14 @@ def pmc_traffic(kind, entry=None):
     if d.get("source_hash") != source_hash():
         return None, "profiles/pmc_traffic.json was measured on other kernel sources (hash %s, now %s)" % (
             d.get("source_hash"), source_hash())
+    c = d.get("configs", {}).get(cfg_name)
+    if c is None:
+        return None, "profiles/pmc_traffic.json holds no PMC passes of the '%s' configuration (has: %s)" % (
+            cfg_name, ", ".join(sorted(d.get("configs", {}))) or "none")
     if kind == "entry":
-        e = d.get("entries", {}).get(entry)
+        e = c.get("entries", {}).get(entry)
         return (e, None) if e else (None, "no PMC record for %s" % entry)
-    return d.get(kind), None
+    return c.get(kind), None
 
 
 def cpu_baseline(batch, npoint, cfg_name):
@@ -350,7 +416,8 @@ def cpu_baseline(batch, npoint, cfg_name):
             "variants": variants, "host_cpus": ncpu, "seconds_spent": round(spent(), 1)}
 
 
-def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=None, npoint=None, force_optim=None):
+def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=None, npoint=None, force_optim=None,
+            build_inputs=False):
     """Builds the model + flat train state for one configuration, captures the step into hipGraph(s), warms up and times
     rounds * steps replays inside ONE barrier + synchronize bracket.  Returns a dict with the timing and the live objects
     (model / state / data) the roofline table needs."""
@@ -372,6 +439,22 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
     state = FlatTrainState(model, lr=1e-3, weight_decay=1e-4, world=world, force_comm=one_rank_comm)
     optim = (not a.no_optim) if force_optim is None else bool(force_optim)
     data = make_data(cfg_name, batch, npoint, 1234 + rank, dev)
+    # build_inputs: every step's batch dict is BUILT on the device from resident RAW frustum records (fcn_prepare_inputs: resample,
+    # rotate to the frustum's centre ray, sliding-frustum centres, labels -- datasets/provider_sample.py:137-262) on the prefetch
+    # branch of the step before, into the OTHER of two batch buffers: raw points -> step, no resident batch
+    sets = None
+    if build_inputs:
+        if cfg_name != "car":
+            raise SystemExit("build_inputs: the car configuration only")
+        from frustum_convnet_amd import inputs as finp, synth
+        builder = finp.InputBuilder(npoint, CFGS[cfg_name][1], 70.0, random_flip=True, random_shift=True, device=dev)
+        recs = synth.make_records(batch, seed=1234 + rank)
+        draws = finp.draw([len(r["points"]) for r in recs], npoint, True, True, np.random.RandomState(1234 + rank))
+        t_raw = builder.upload(recs, draws, with_seg=False)
+        sets = [builder.launch(t_raw, out=builder.alloc(batch, with_seg=False)) for _ in range(2)]
+        data = sets[0]
+        torch.cuda.synchronize()
+    kstep = [0]
     # FCN_BENCH_SPLIT_STEP=1: the N > 1 form of the step with ONE rank and no process group (the all-reduce calls are no-ops): what
     # a rank's step costs on this box without its collectives, beside the N = 1 line
     rehearse = one_rank_comm or os.environ.get("FCN_BENCH_SPLIT_STEP", "0") == "1"
@@ -411,17 +494,25 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
             state.adam_step()
 
     pf_point = os.environ.get("FCN_PF_POINT", "fcn_fwd")
+    resident = data
     spg = max(2, 2 * (int(os.environ.get("FCN_STEPS_PER_GRAPH", "2")) // 2))      # whole steps per captured graph (even)
 
     def fwd_bwd():
+        data = sets[kstep[0] % 2] if sets else resident          # this step's batch, and the next one's (the other buffer)
+        nxt = sets[(kstep[0] + 1) % 2] if sets else resident
+        kstep[0] += 1
+        if sets and not prefetch:
+            builder.launch(t_raw, out=data)                      # (no prefetch branch: built in front of the forward)
         if prefetch and pf_point == "fcn_fwd":
-            model.next_batch = data                   # forward() starts the prefetch beside the ConvFeatNet forward
+            model.next_batch = nxt                    # forward() starts the prefetch beside the ConvFeatNet forward
+            if sets:
+                model.next_batch_build = lambda: builder.launch(t_raw, out=nxt)
         losses, _ = model(data)
         if prefetch and pf_point != "fcn_fwd":
             # the next step's batch (the same resident synthetic batch): its batch-only front -- grouping, entry rows, tile lists,
             # input moments -- runs on a side branch beside this step's backward, as a loader prefetches; the work stays INSIDE the
             # timed step, only off its critical path.  Double-buffered workspaces: captured steps alternate between two graphs.
-            model.prefetch(data)
+            model.prefetch(nxt, before=(lambda: builder.launch(t_raw, out=nxt)) if sets else None)
         model.backward(losses["total_loss"])          # == loss.backward(), seeded with a cached unit gradient
         return losses["total_loss"]
 
@@ -799,6 +890,99 @@ def measure_inference(cfg_name, batch, dev, min_time=0.35, prec="split"):
             "timed_steps": n, "timed_seconds": round(wall, 4)}
 
 
+def _replay_time(fn, dev, inner=10, min_time=0.2):
+    """ms per call of `fn` (launches on the current stream, no host syncs) replayed from a hipGraph holding `inner` calls."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(inner):
+            fn()
+    for _ in range(5):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        g.replay()
+    torch.cuda.synchronize()
+    n = max(20, int(np.ceil(min_time / ((time.perf_counter() - t0) / 20))))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (n * inner), n * inner
+
+
+def inputs_row(dev, batch, npoint=1024):
+    """fcn_prepare_inputs -- the reference's ProviderDataset.__getitem__ + collate (datasets/provider_sample.py:
+    137-262,291-327,396-397) as ONE launch over resident raw frustum records -> the batch dict; frustums/s and the fraction of the
+    HBM roof its algorithmic bytes reach (raw points gathered through the resample indices in, batch tensors out)."""
+    from frustum_convnet_amd import inputs as finp, synth
+    from frustum_convnet_amd.config import reset_cfg, merge_cfg_from_file
+    reset_cfg()
+    merge_cfg_from_file(os.path.join(ROOT, CFGS["car"][0]))
+    b = finp.InputBuilder(npoint, CFGS["car"][1], 70.0, random_flip=True, random_shift=True, device=dev)
+    recs = synth.make_records(batch, seed=1234)
+    draws = finp.draw([len(r["points"]) for r in recs], npoint, True, True, np.random.RandomState(1234))
+    t = b.upload(recs, draws, with_seg=True)
+    out = b.alloc(batch, with_seg=True)
+    ms, n = _replay_time(lambda: b.launch(t, out=out), dev)
+    nbytes = float(b.algorithmic_bytes(batch, with_seg=True, pt_stride=t["pt_stride"]))
+    tb = nbytes / (ms * 1e-3) / 1e12
+    return {"cfg": "car", "mode": "input construction (fcn_prepare_inputs: raw frustum records -> batch dict, one launch)",
+            "workload": "cfgs/det_sample.yaml KITTI-car, batch=%d, %d..%d raw points per frustum resampled to Npoint=%d, rotate-to-centre, "
+                        "random flip + shift, L=(%s) window centres, cls / seg labels" % (
+                            batch, min(len(r["points"]) for r in recs), max(len(r["points"]) for r in recs), npoint,
+                            ",".join(str(v) for v in b.L)),
+            "value": round(batch / (ms * 1e-3), 1), "unit": "frustums/s", "ms_per_step": round(ms, 5), "timed_steps": n,
+            "roofline": {"bound": "hbm", "bytes_algorithmic": nbytes, "bytes_per_frustum": round(nbytes / batch),
+                         "achieved": round(tb, 4), "peak": PEAK_HBM_TBPS, "unit": "TB/s", "frac": round(tb / PEAK_HBM_TBPS, 5),
+                         "note": "one launch of %d workgroups' worth of work: latency-bound, not bandwidth-bound" % batch}}
+
+
+def detect_row(dev, batch, frames=8, prec="split"):
+    """PointNetDet.detect() -- eval forward, decode into label-format boxes, rotated 3-D NMS per (frame, class) group
+    (train/test_net_det.py:126-152,193-293) -- on a batch of `batch` frustums that belong to `frames` frames: frames/s."""
+    from frustum_convnet_amd import precision as fprec
+    fprec.set_precision(prec)
+    model = build_model(dev, "car").eval()
+    data = make_data("car", batch, CFGS["car"][3], 1234, dev)
+    data = {k: v for k, v in data.items() if k in ("point_cloud", "one_hot") or k.startswith("center_ref")}
+    data["rot_angle"] = torch.zeros(batch, 1, device=dev)
+    group = (torch.arange(batch, device=dev, dtype=torch.int32) * frames // batch).to(torch.int32).contiguous()
+
+    def run():
+        model.detect(data, unit_group=group, num_groups=frames, method="nms")
+    how = "hipGraph replay"
+    try:
+        ms, n = _replay_time(run, dev, inner=2)
+    except Exception as e:  # noqa  (a host synchronisation inside detect(): timed eagerly)
+        how = "eager (%s)" % type(e).__name__
+        torch.cuda.synchronize()
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 50
+        for _ in range(n):
+            run()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / n
+    return {"cfg": "car", "mode": "detect(): eval forward + decode + rotated 3-D NMS", "precision": prec,
+            "workload": "cfgs/det_sample.yaml KITTI-car, %d frustums of %d frames (%d per frame, one class), Npoint=%d, "
+                        "TEST.METHOD nms: every foreground window a candidate, greedy rotated-IoU suppression per frame" % (
+                            batch, frames, batch // frames, CFGS["car"][3]),
+            "value": round(frames / (ms * 1e-3), 1), "unit": "frames/s", "frustums_per_s": round(batch / (ms * 1e-3), 1),
+            "ms_per_step": round(ms, 4), "timed_steps": n, "launch": how}
+
+
 def other_configs(a, dev, min_time=0.3, car_flops=None):
     out = []
     for cfg_name, prec, npt in OTHER_CONFIGS:
@@ -827,6 +1011,30 @@ def other_configs(a, dev, min_time=0.3, car_flops=None):
         out.append(measure_inference("car", a.batch, dev, min_time))
     except Exception as e:  # noqa
         out.append({"cfg": "car", "mode": "inference", "error": "%s: %s" % (type(e).__name__, e)})
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    # SURVEY 8f rows 1 and 2 (the callers either side of the path), and the training step fed by the on-device builder
+    for name, fn in (("input construction", lambda: inputs_row(dev, a.batch)), ("detect", lambda: detect_row(dev, a.batch))):
+        try:
+            out.append(fn())
+        except Exception as e:  # noqa
+            out.append({"cfg": "car", "mode": name, "error": "%s: %s" % (type(e).__name__, e)})
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    try:
+        from frustum_convnet_amd import precision as fprec
+        fprec.set_precision("split")
+        m = measure(a, "car", "split", 20, 10, min_time, dev, 0, 1, build_inputs=True)
+        out.append({"cfg": "car", "precision": "split", "dtype": DTYPE_LABEL["split"],
+                    "mode": "train, batch BUILT on the device every step (raw frustum records -> fcn_prepare_inputs on the prefetch "
+                            "branch -> step); the headline's batch is resident",
+                    "workload": workload_name("car", m["batch"], m["npoint"], m["Ls"], m["optim"]),
+                    "value": round(m["batch"] / (m["ms_per_step"] / 1e3), 2), "unit": "frustums/s",
+                    "ms_per_step": round(m["ms_per_step"], 4), "timed_steps": m["nstep"],
+                    "timed_seconds": round(m["wall"], 4), "final_loss": round(m["final_loss"], 5)})
+        del m
+    except Exception as e:  # noqa
+        out.append({"cfg": "car", "mode": "train, batch built on the device", "error": "%s: %s" % (type(e).__name__, e)})
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     return out
@@ -928,7 +1136,7 @@ def main():
     if world == 1 and not a.no_roofline:
         try:
             model.split_backward = False
-            rows, peak_mm = kernel_table(model, state, data, optim, prec)
+            rows, peak_mm, how = kernel_table(model, state, data, optim, prec, graph=not a.eager)
             top = next(r for r in rows if "frac" in r)
             rl = {"kernel": top["entry"], "calls_per_step": top["calls_per_step"], "bound": top["bound"],
                   "avg_launch_group_ms": top["ms_per_step"] / max(top["calls_per_step"], 1), "frac": top["frac"]}
@@ -940,7 +1148,7 @@ def main():
                           else ("dense bf16 MFMA peak" if prec.startswith("bf16") else "fp32 MFMA peak"))
             else:
                 rl.update(achieved=top["achieved_tbps"], peak=PEAK_HBM_TBPS, unit="TB/s")
-            tr, why = pmc_traffic("entry", top["entry"].split("[")[0])
+            tr, why = pmc_traffic("entry", top["entry"].split("[")[0], a.cfg)
             rl["traffic"] = tr["bytes_per_launch"] if tr else None
             if tr:
                 rl["traffic_note"] = ("HBM bytes per launch of this entry point's kernels (%d launches, %.1f MB per step): "
@@ -949,8 +1157,7 @@ def main():
                                                                                      tr["bytes_per_step"] / 1e6))
             if why:
                 rl["traffic_note"] = why
-            rl["how"] = ("top-time C-ABI entry point of one step: HIP events on its launch stream around the call, eager "
-                         "launches, mean of 5 steps; FLOPs = executed (entry-space rows, real channels)")
+            rl["how"] = "top-time C-ABI entry point of one step: %s; FLOPs = executed (entry-space rows, real channels)" % how
             try:
                 rows.append(grouping_op_row(data, a.cfg))
             except Exception as e:  # noqa
@@ -963,7 +1170,7 @@ def main():
     if world == 1:
         # whole-step HBM roofline (BASELINE.json's "HBM roofline %"): fabric bytes of one step from the committed rocprofv3
         # --pmc passes over THIS command and THIS kernel source, divided by the step time measured now.
-        st, why = pmc_traffic("step")
+        st, why = pmc_traffic("step", cfg_name=a.cfg)
         if st:
             sb = st["bytes_per_step"]
             tbps = sb / (ms_per_step * 1e-3) / 1e12

@@ -176,14 +176,15 @@ class PointNetFeat(nn.Module):
         return (tuple((t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version) for t in ts), bool(nlc), bool(training),
                 torch.is_grad_enabled(), tuple(net.front_signature(nlc) for net in self.nets))
 
-    def prefetch(self, point_cloud, sample_pc, one_hot_vec=None, nlc=False):
+    def prefetch(self, point_cloud, sample_pc, one_hot_vec=None, nlc=False, before=None):
         """Phase 1 of the fused front (grouping, entry rows, tile lists, input moments: functions of the batch alone) for the
         batch the NEXT forward() will see, on a side stream forked from the current one -- as a data loader prefetches
         (datasets/provider_sample.py:291-327 run by DataLoader workers ahead of train/train_net_det.py:114).  The next forward
         then starts with the light weight-dependent launch (phase 2) instead of the whole front.  The tensors must be passed
         to that forward unmodified (same storage, no in-place write in between); anything else discards the prefetch.
         join_prefetch() makes the current stream wait for the branch (PointNetDet.backward does: inside a captured step
-        the branch has to end in the same capture)."""
+        the branch has to end in the same capture).  before: called on the branch's stream in FRONT of the front's launches --
+        the place of a launch that PRODUCES the batch on the device (inputs.InputBuilder.launch into these very tensors)."""
         if not (self.fused_front and self.concurrent_scales and point_cloud.is_cuda):
             return False
         self.drop_prefetch()
@@ -200,6 +201,8 @@ class PointNetFeat(nn.Module):
         ev_in.record(cur)
         side.wait_event(ev_in)
         with torch.cuda.stream(side):
+            if before is not None:
+                before()
             group_compact(prepared, point_cloud, phase=1)
             ev_out.record(side)
         for t in [point_cloud] + list(sample_pc):
@@ -522,20 +525,26 @@ class PointNetDet(nn.Module):
                                      "split precision, |x| >= 65504, or a genuine overflow); rerun with precision 'f32' or 'bf16'")
         return f
 
-    def prefetch(self, data_dicts):
+    def prefetch(self, data_dicts, before=None):
         """Starts the batch-only part of the NEXT forward's front (sliding-frustum grouping, entry rows, tile lists, input
         moments of all scales) on a side stream, beside whatever the current stream does next -- call it between
         `model(data)` and `model.backward(loss)` with the batch the next `model(...)` call will get (the same tensors,
         unmodified), as a DataLoader worker prepares the next batch while the step runs (train/train_net_det.py:114).
         backward() / backward_split() join the branch; the next forward then begins with one light launch (weight images +
-        BN1 fold) instead of the front.  Returns False when the prefetch does not apply (CPU tensors, module path)."""
+        BN1 fold) instead of the front.  Returns False when the prefetch does not apply (CPU tensors, module path).
+        before: a callable run on the branch in front of the front -- e.g. the launch that BUILDS that batch on the device from
+        resident raw records (inputs.InputBuilder.launch(t, out=data_dicts)); `model.next_batch_build` hands one to the prefetch
+        that forward() starts for `model.next_batch`."""
         pc = data_dicts.get('point_cloud')
         if pc is None or not pc.is_cuda or not self.fused_fcn or data_dicts.get('one_hot') is None:
             return False
         refs = [data_dicts.get('center_ref%d' % i) for i in range(1, self.num_scales + 1)]
         xyz = pc[:, :3, :].contiguous()
+        if before is not None and xyz.data_ptr() != pc.data_ptr():
+            raise RuntimeError("prefetch(before=...): the batch is produced on the prefetch branch, so its point cloud must be the "
+                               "(B, 3, N) tensor the front reads (a copy of the coordinate rows would be taken before it exists)")
         self._pf_xyz = ((pc.data_ptr(), tuple(pc.shape), pc._version), xyz)
-        return self.feat_net.prefetch(xyz, refs, data_dicts.get('one_hot'), nlc=True)
+        return self.feat_net.prefetch(xyz, refs, data_dicts.get('one_hot'), nlc=True, before=before)
 
     def _join_side(self):
         self._iou_metrics.join()
@@ -649,7 +658,8 @@ class PointNetDet(nn.Module):
                 # branch beside the latency-bound ConvFeatNet forward whose launches leave most CUs idle (instead of a
                 # model.prefetch() call between forward and backward, which lands beside the first backward launches)
                 self.next_batch = None
-                self.prefetch(nxt)
+                build, self.next_batch_build = getattr(self, "next_batch_build", None), None
+                self.prefetch(nxt, before=build)
             logits64 = convnet_fused(self._cn_pool, self.conv_net, self.cls_out, self.reg_out, feats, one_hot_vec, pre,
                                      self.feat_net.done_events)
             lv = logits64.view(batch_size, refs[1].shape[2], logits64.shape[1])

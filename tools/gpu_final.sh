@@ -4,7 +4,7 @@
 # precisions, rocprofv3 kernel stats of the same command, phase stamps.  TAG names the files (default r02_final).
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; T=${TAG:-r02_final}
-bash tools/gpu_traffic.sh > $O/${T}_traffic.log 2>&1; tail -3 $O/${T}_traffic.log | cut -c1-300
+CFGS="${TRAFFIC_CFGS:-car people refine sunrgbd}" bash tools/gpu_traffic.sh > $O/${T}_traffic.log 2>&1; tail -3 $O/${T}_traffic.log | cut -c1-300
 cp $O/pmc_traffic.json $R/profiles/pmc_traffic.json     # (on the box only: lets the bench below print traffic; merged back via gpurun_out)
 cp $O/pmc_traffic.json $O/${T}_pmc_traffic.json; cp $O/pmc_sq_summary.txt $O/${T}_pmc_sq_summary.txt
 cd $R

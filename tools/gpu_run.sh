@@ -23,7 +23,7 @@ QUICK="--no-cpu-baseline --no-roofline --no-configs --min-time 1.5"
 line() { python - "$1" <<'EOF'
 import json, sys
 try:
-    d = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])
+    d = json.loads([l for l in open(sys.argv[1]).read().strip().split("\n") if l.startswith("{")][-1])
     print(d["value"], d["ms_per_step"], d.get("n_gpus"), d.get("rccl_ranks", ""))
 except Exception as e:
     print("no line (%s)" % e)

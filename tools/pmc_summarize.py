@@ -6,7 +6,10 @@ passes, both are in KB, and on gfx950 FETCH_SIZE reports half of the bytes of wi
 WRITE_SIZE is taken as reported.  One step = the kernels between two consecutive loss-tail launches of the replayed graph
 (the last complete window of the run, i.e. a timed step, not the warm-up).
 
-usage: python tools/pmc_summarize.py gpurun_out/pmcs_FETCH_SIZE.csv gpurun_out/pmcs_WRITE_SIZE.csv out.json
+The record is keyed by CONFIGURATION (car | people | refine | sunrgbd): each call adds / replaces one configuration's entry of
+out.json (entries measured on other kernel sources are dropped), so bench.py --cfg X reports X's own traffic or null.
+
+usage: python tools/pmc_summarize.py gpurun_out/pmcs_FETCH_SIZE.csv gpurun_out/pmcs_WRITE_SIZE.csv out.json [cfg = car]
 """
 import collections
 import csv
@@ -48,6 +51,7 @@ def step_window(path, counter):
 
 def main():
     fpath, wpath, out = sys.argv[1:4]
+    cfg_name = sys.argv[4] if len(sys.argv) > 4 else "car"
     from bench import source_hash
     kern = collections.OrderedDict()
     for path, counter, corr in ((fpath, "FETCH_SIZE", 2.0), (wpath, "WRITE_SIZE", 1.0)):
@@ -67,22 +71,28 @@ def main():
         e["bytes_per_step"] += d["bytes_per_step"]
     for e in entries.values():
         e["bytes_per_launch"] = int(e["bytes_per_step"] / max(e["launches_per_step"], 1))
-    res = {
-        "source_hash": source_hash(),
-        "command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE> -- python bench.py --steps 4 --warmup 2 "
-                   "--no-cpu-baseline --no-roofline   (two separate passes, tools/gpu_traffic.sh)",
-        "note": "bytes = 1024 * (2 * FETCH_SIZE + WRITE_SIZE): both counters are KB; FETCH_SIZE doubled per "
-                "MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads), WRITE_SIZE as reported; one step = the "
-                "kernels between the last two loss-tail launches of the replayed hipGraph (B = 32 frustums); Infinity-Cache "
-                "hits are counted by these counters",
+    res = {"source_hash": source_hash(), "configs": {}}
+    try:
+        old = json.load(open(out))
+        if old.get("source_hash") == res["source_hash"] and isinstance(old.get("configs"), dict):
+            res["configs"] = old["configs"]
+    except Exception:  # noqa
+        pass
+    res["command"] = ("rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE> -- python bench.py --cfg <cfg> --steps 4 --warmup 2 "
+                      "--no-cpu-baseline --no-roofline   (two separate passes per configuration, tools/gpu_traffic.sh)")
+    res["note"] = ("bytes = 1024 * (2 * FETCH_SIZE + WRITE_SIZE): both counters are KB; FETCH_SIZE doubled per "
+                   "MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads), WRITE_SIZE as reported; one step = the "
+                   "kernels between the last two loss-tail launches of the replayed hipGraph (B = 32 frustums); Infinity-Cache "
+                   "hits are counted by these counters")
+    res["configs"][cfg_name] = {
         "step": {"bytes_per_step": int(tot), "fetch_size_kb_raw": round(sum(d["FETCH_SIZE_kb_raw"] for d in kern.values()), 1),
                  "write_size_kb_raw": round(sum(d["WRITE_SIZE_kb_raw"] for d in kern.values()), 1)},
         "entries": entries,
         "kernels": kern,
     }
     json.dump(res, open(out, "w"), indent=1)
-    print("step bytes %.1f MB over %d kernels; by entry: %s" % (
-        tot / 1e6, sum(d["launches"] for d in kern.values()),
+    print("%s: step bytes %.1f MB over %d kernels; by entry: %s" % (
+        cfg_name, tot / 1e6, sum(d["launches"] for d in kern.values()),
         ", ".join("%s %.1f MB" % (k, v["bytes_per_step"] / 1e6) for k, v in entries.items())))
 
 
