@@ -46,6 +46,15 @@ __device__ __forceinline__ double cg_rep_sum(const double *p, int stride)
 #define FCN_FT_NTW 1           // 32-column blocks per wave (a layer whose width is no multiple of the tile falls back to 1)
 #endif
 #define FCN_FT_THREADS (FCN_FT_G * 64 * FCN_FT_MW * FCN_FT_WNC)
+// FCN_FWD_DIRECT (round 6): the one-wave K-groups of the 32 x 32 forward tile take their MFMA operands STRAIGHT FROM GLOBAL MEMORY in
+// fragment shape -- a lane (row l & 31, half l >> 5) loads the 8 reduction-adjacent values of ITS row that the 32x32x16 instruction
+// wants from it (two 16-byte loads), applies the producer's BatchNorm + ReLU + split in registers and issues the MFMAs; the weight
+// image is pre-encoded in fragment order, so its fragments are plain 16-byte loads as well.  No wave shares an operand with another
+// (every K-group reduces its own chunks), so the LDS images of the staged form were a pure transposer: 8 ds_write + 8 ds_read_b128
+// + two LDS round trips per 6 MFMAs on the critical path of a wave that has ~2 siblings per SIMD to hide them behind.
+#ifndef FCN_FWD_DIRECT
+#define FCN_FWD_DIRECT 0
+#endif
 #define LDN 68                 // row-major LDS leading dim of a 64-wide tile (float4 aligned)
 #define OH_PAD 64              // channels of the virtual one-hot segment
 #define CG_SPLIT_ROWS 512      // rows per wgrad split
@@ -273,6 +282,10 @@ __device__ __forceinline__ void cg_fill_bn(LP Lp, float *sS, float *tS, int tid,
     }
 }
 
+// the bits of ONE ELEMENT of a packed operand vector as a float.  Through a by-value parameter on purpose: __builtin_bit_cast applied
+// to a vector-element expression (v[q]) reads the bytes at the START of the vector -- element 0 for every q (clang of ROCm 7.2, host
+// and device alike; found by the host emulation of the fp32 operand mode)
+__device__ __forceinline__ float cg_u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ float cg_act(float s, float x, float t, bool ok) { return ok ? fmaxf(fmaf(s, x, t), 0.f) : 0.f; }
 // the same with the row's mask as fcn_keep(ok): one v_fma_f32 + one v_med3_f32 per element
 __device__ __forceinline__ float cg_actk(float s, float x, float t, float keep) { return fcn_relu_keep(fmaf(s, x, t), keep); }
@@ -293,7 +306,8 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     constexpr int NB = TNC * 8 / TG;          // u32x4 of the encoded weight per thread per chunk
     static_assert(G * GU4 * 4 >= G * TMB * TNC, "the cross-group sum fits the operand images");
     static_assert(2 * TNC <= NTHR && (TMB * 8) % TG == 0 && (TNC * 8) % TG == 0, "epilogue / staging lane mapping");
-    __shared__ u32x4 lds4[G * GU4];           // per K-group: kb-major images of its A and W chunk (gemm_tile.h)
+    constexpr bool DIRECT = FCN_FWD_DIRECT && TG == 64 && NTW == 1;       // (operands straight into fragments: FCN_FWD_DIRECT above)
+    __shared__ u32x4 lds4[DIRECT ? G * TMB * TNC / 4 : G * GU4];   // per K-group: kb-major images of its A and W chunk (gemm_tile.h); DIRECT: only the cross-group sum
     __shared__ __attribute__((aligned(16))) float sS[CG_KMAX], tS[CG_KMAX];
     __shared__ int cSeg[CG_KMAX / KC], cTap[CG_KMAX / KC], cK0[CG_KMAX / KC];   // chunk -> (segment, tap, channel)
     float *lds = (float *)lds4;
@@ -327,6 +341,110 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     if (H0 + H1 + H2 + H3 + C0 + Q0 + T0 == -12345) return;
     PROBE_STAMP();
 #endif
+    f32x16 acc[1][NTW];
+    acc_zero<1, NTW>(acc);
+    if constexpr (DIRECT) {
+        // ---- operands in fragment shape: this lane's row of the tile, its 8-deep half of every 16-deep MFMA step
+        const int gr = row0 + l31;
+        const bool rv1 = gr < R;
+        int bb1 = 0, ll1 = 0;
+        cg_divmod(rv1 ? gr : 0, LLout, cg_inv(LLout), bb1, ll1);             // (R < 2^23: cn_make_plan)
+        constexpr bool X3 = !mm_x1<MM>;
+        constexpr int NW = X3 || MM == MM_F32 ? 4 : 2;                       // weight fragments per chunk: (step, plane)
+        // fragment (s, plane) of the weight image of a chunk: u32x4 ((plane * 4 + 2 s + lh) * Cout + n0 + l31)
+        unsigned wofd[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wofd[q] = (unsigned)((((q & 1) * 4 + 2 * (q >> 1) + lh) * LCout + l31)) * 16u;
+        const char *wsrc = (const char *)(LWenc + n0);
+        v4f da0[4], da1[4];                   // [2 * step + piece]: k = 16 step + 8 lh + 4 piece .. + 3 of the chunk
+        u32x4 dw0[4], dw1[4];                 // [2 * step + plane]
+        bool dk0 = false, dk1 = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { da0[i] = zero4(); da1[i] = zero4(); dw0[i] = u32x4{0u, 0u, 0u, 0u}; dw1[i] = u32x4{0u, 0u, 0u, 0u}; }
+#define CGD_FWD_LOAD_AT(cc, SG, TAP, K0, RA, RW, OK)                                                                  \
+    {                                                                                                                 \
+        const int c_ = (cc);                                                                                          \
+        const int sgi = (SG), tap = (TAP), k0 = (K0);                                                                 \
+        const float *x = SEL4(sgi, x0, x1, x2, x3);                                                                   \
+        const int C = SEL4(sgi, C0, C1, C2, C3), ty = SEL4(sgi, T0, T1, T2, T3), Ls = SEL4(sgi, Q0, Q1, Q2, Q3);      \
+        const int h16 = SEL4(sgi, H0, H1, H2, H3);                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+            RA[i] = cg_load_raw<MM>(geo, x, C, Ls, ty ? 0 : 1, tap, k0 + 16 * (i >> 1) + 8 * lh + 4 * (i & 1), bb1,   \
+                                    ll1, rv1, OK, h16);                                                               \
+        const char *wc_ = wsrc + (size_t)(unsigned)(c_ * 8 * LCout) * 16u;                                            \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                                 \
+            if (NW == 4 || !(q & 1)) RW[q] = *(gu4p)(wc_ + wofd[q]);                                                  \
+    }
+#define CGD_FWD_LOAD(cc, RA, RW, OK)                                                                                  \
+    {                                                                                                                 \
+        const int c__ = __builtin_amdgcn_readfirstlane(cc);                                                           \
+        CGD_FWD_LOAD_AT(c__, __builtin_amdgcn_readfirstlane(cSeg[c__]), __builtin_amdgcn_readfirstlane(cTap[c__]),    \
+                        __builtin_amdgcn_readfirstlane(cK0[c__]), RA, RW, OK);                                        \
+    }
+        // the transform of the staged form, on the 8 values of a step: BatchNorm scale / shift of column k (LDS tables, the 32
+        // lanes of a half read the same 16 bytes: a broadcast), ReLU + row mask as one v_med3, split-encode, MFMAs
+#define CGD_FWD_ITER(it_, RA, RW, OK)                                                                                 \
+    {                                                                                                                 \
+        const int c = __builtin_amdgcn_readfirstlane((it_) * G + g);                                                  \
+        if (c < nchunk) {                                                                                             \
+            const float kp = fcn_keep(OK);                                                                            \
+            _Pragma("unroll") for (int st_ = 0; st_ < 2; ++st_) {                                                     \
+                const float *sp_ = sS + c * KC + 16 * st_ + 8 * lh, *tp_ = tS + c * KC + 16 * st_ + 8 * lh;           \
+                const v4f s0 = *(const v4f *)sp_, s1 = *(const v4f *)(sp_ + 4), t0 = *(const v4f *)tp_,               \
+                          t1 = *(const v4f *)(tp_ + 4);                                                               \
+                const v4f a0 = RA[2 * st_], a1 = RA[2 * st_ + 1];                                                     \
+                const float xv[8] = {cg_actk(s0.x, a0.x, t0.x, kp), cg_actk(s0.y, a0.y, t0.y, kp),                    \
+                                     cg_actk(s0.z, a0.z, t0.z, kp), cg_actk(s0.w, a0.w, t0.w, kp),                    \
+                                     cg_actk(s1.x, a1.x, t1.x, kp), cg_actk(s1.y, a1.y, t1.y, kp),                    \
+                                     cg_actk(s1.z, a1.z, t1.z, kp), cg_actk(s1.w, a1.w, t1.w, kp)};                   \
+                u32x4 ah, al;                                                                                         \
+                enc8<MM_ENC_A>(xv, ah, al);                                                                           \
+                const u32x4 bh = RW[2 * st_], bl = RW[2 * st_ + 1];                                                   \
+                if constexpr (MM == MM_F32) {                                                                         \
+                    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                     \
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cg_u2f(ah[q]), cg_u2f(bh[q]), acc[0][0], 0, 0, 0); \
+                    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                     \
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cg_u2f(al[q]), cg_u2f(bl[q]), acc[0][0], 0, 0, 0); \
+                } else if constexpr (X3) {                                                                            \
+                    acc[0][0] = mfma16<MM>(ah, bl, acc[0][0]);                                                        \
+                    acc[0][0] = mfma16<MM>(al, bh, acc[0][0]);                                                        \
+                    acc[0][0] = mfma16<MM>(ah, bh, acc[0][0]);                                                        \
+                } else {                                                                                              \
+                    acc[0][0] = mfma16<MM>(ah, bh, acc[0][0]);                                                        \
+                }                                                                                                     \
+            }                                                                                                         \
+        }                                                                                                             \
+        if (c + 2 * G < nchunk) CGD_FWD_LOAD(c + 2 * G, RA, RW, OK);                                                  \
+    }
+        {
+            int sg_, tap_, k0_, so_;
+            const int ca = min(g, nchunk - 1), cb = min(g + G, nchunk - 1);
+            cg_locate_s(geo, C0, C1, C2, C3, ca * KC, sg_, tap_, k0_, so_);
+            CGD_FWD_LOAD_AT(__builtin_amdgcn_readfirstlane(ca), __builtin_amdgcn_readfirstlane(sg_), __builtin_amdgcn_readfirstlane(tap_),
+                            __builtin_amdgcn_readfirstlane(k0_), da0, dw0, dk0);
+            cg_locate_s(geo, C0, C1, C2, C3, cb * KC, sg_, tap_, k0_, so_);
+            CGD_FWD_LOAD_AT(__builtin_amdgcn_readfirstlane(cb), __builtin_amdgcn_readfirstlane(sg_), __builtin_amdgcn_readfirstlane(tap_),
+                            __builtin_amdgcn_readfirstlane(k0_), da1, dw1, dk1);
+        }
+        PROBE_STAMP();                                      // 1: first loads issued
+        if (tid < nchunk) {
+            int sg, tap, k0, so;
+            cg_locate_s(geo, C0, C1, C2, C3, tid * KC, sg, tap, k0, so);
+            cSeg[tid] = sg; cTap[tid] = tap; cK0[tid] = k0;
+        }
+        const cg_klayer_p Lk = cg_kernarg_layer(koff);
+        cg_fill_bn(Lk, sS, tS, tid, NTHR, bx == 0 && by == 0);
+        __syncthreads();                            // sS / tS and the chunk table ready
+        PROBE_STAMP();                                      // 2: prologue done
+        for (int it = 0; it < nit; it += 2) {
+            CGD_FWD_ITER(it, da0, dw0, dk0);
+            if (it + 1 < nit) CGD_FWD_ITER(it + 1, da1, dw1, dk1);
+        }
+        PROBE_STAMP();                                      // 3: K loop done (wave 0)
+#undef CGD_FWD_ITER
+#undef CGD_FWD_LOAD
+#undef CGD_FWD_LOAD_AT
+    } else {
     int bb[NA], ll[NA];
     bool rv[NA];
 #pragma unroll
@@ -342,8 +460,6 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     if (bb[0] + ll[0] == -12345) return;
     PROBE_STAMP();
 #endif
-    f32x16 acc[1][NTW];
-    acc_zero<1, NTW>(acc);
     // TWO register sets: the chunk staged in iteration `it` was requested two iterations earlier, so a load has two
     // MFMA phases (not one) to come back from L2 / MALL / HBM before the LDS store needs it
     v4f ra0[NA], ra1[NA];
@@ -450,6 +566,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     }
     PROBE_STAMP();                                      // 3: K loop done (wave 0)
     if (FCN_XF & 16) { if (acc[0][0][0] == 123.456f) Lk->y[0] = 0.f; return; }
+    }       // (staged form)
     const cg_klayer_p Le = cg_kernarg_layer(koff);      // the epilogue's fields: fetched now, not in the entry block
     // ---- sum the G group accumulators through LDS, then one epilogue pass over the tile
     if constexpr (TG == 64) __syncthreads();            // every group is done with its operand buffers (reused below)
