@@ -53,6 +53,8 @@ CASES = [
     ("test_gpu_inputs", "test_ragged_and_odd_sizes_against_oracle", (1, 100, True)),
     ("test_gpu_inputs", "test_ragged_and_odd_sizes_against_oracle", (3, 257, False)),
     ("test_gpu_inputs", "test_ragged_and_odd_sizes_against_oracle", (6, 1024, True)),
+    ("test_gpu_inputs", "test_synthetic_records_against_oracle_and_launch_into_given_buffers", ()),
+    ("test_gpu_inputs", "test_batch_built_on_the_prefetch_branch_feeds_the_same_step", ()),
     ("test_gpu_inputs", "test_refine_builder_matches_reference_batch", ()),
     ("test_gpu_inputs", "test_sunrgbd_builder_matches_reference_batch", ()),
     ("test_gpu_group_compact", "test_group_compact_matches_oracle_and_unfused", (4, 512, (0.25, 0.5, 1.0, 2.0), "car")),

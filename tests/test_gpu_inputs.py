@@ -90,6 +90,93 @@ def test_built_batch_feeds_the_model():
     assert torch.isfinite(losses["total_loss"]) and float(losses["total_loss"]) > 0
 
 
+def test_synthetic_records_against_oracle_and_launch_into_given_buffers():
+    """synth.make_records (bench.py's raw frustum records) through upload() + launch(out=...) -- the capturable, allocation-free form
+    -- against oracle/inputs_ref.py on the same records and draws; a second launch into the same buffers reproduces them bit for bit,
+    and build() (= upload + launch) equals the split form."""
+    from oracle import inputs_ref
+    from frustum_convnet_amd import synth
+    from frustum_convnet_amd.config import reset_cfg
+    from frustum_convnet_amd.inputs import InputBuilder, draw
+    reset_cfg()
+    B, N, strides = 5, 512, (0.25, 0.5, 1.0, 2.0)
+    recs = synth.make_records(B, seed=77)
+    counts = [len(r["points"]) for r in recs]
+    draws = draw(counts, N, True, True, np.random.RandomState(5))
+    rec = {"raw_points": np.concatenate([r["points"] for r in recs]), "raw_seg": np.concatenate([r["seg"] for r in recs]),
+           "raw_counts": np.asarray(counts), "box2d": np.stack([r["box2d"] for r in recs]), "P": np.stack([r["P"] for r in recs]),
+           "box3d_corners": np.stack([r["box3d"] for r in recs]), "heading": np.asarray([r["heading"] for r in recs]),
+           "size": np.stack([r["size"] for r in recs]), "frustum_angle": np.asarray([r["frustum_angle"] for r in recs]),
+           "draw_choice": draws[0], "draw_coin": draws[1], "draw_normal": draws[2]}
+    want = inputs_ref.prepare_batch(rec, strides, 70.0)
+    assert ((want["cls_label"] == 1).sum(1) >= 1).all()
+    b = InputBuilder(N, strides, 70.0, random_flip=True, random_shift=True)
+    t = b.upload(recs, draws, with_seg=True)
+    out = b.alloc(B, with_seg=True)
+    ptrs = {k: v.data_ptr() for k, v in out.items()}
+    written = list(out)                                   # (launch() adds the uploaded size_class / one_hot tensors to the dict)
+    got = b.launch(t, out=out)
+    assert all(got[k].data_ptr() == p for k, p in ptrs.items())
+    _check(got, want)
+    first = {k: v.clone() for k, v in got.items()}
+    for k in written:
+        out[k].zero_()
+    got = b.launch(t, out=out)
+    for k, v in first.items():
+        assert torch.equal(got[k], v), k
+    whole = b.build(recs, draws)
+    for k, v in first.items():
+        assert torch.equal(whole[k], v), k
+    assert b.algorithmic_bytes(B, with_seg=True, pt_stride=4) > 0
+
+
+def test_batch_built_on_the_prefetch_branch_feeds_the_same_step():
+    """PointNetDet.prefetch(data, before=launch): the NEXT batch is produced on the prefetch branch, in front of its grouping front, into
+    the tensors the next forward reads (bench.py's build_inputs line).  The losses of that forward equal the losses on a batch built
+    ahead of time, bit for bit; a point cloud that would have to be copied first is refused."""
+    from frustum_convnet_amd import det_base, synth
+    from frustum_convnet_amd.config import reset_cfg
+    from frustum_convnet_amd.inputs import InputBuilder, draw
+    reset_cfg()
+    B, N, strides = 4, 512, (0.25, 0.5, 1.0, 2.0)
+    recs = synth.make_records(B, seed=9)
+    draws = draw([len(r["points"]) for r in recs], N, True, True, np.random.RandomState(2))
+    b = InputBuilder(N, strides, 70.0, random_flip=True, random_shift=True)
+    t = b.upload(recs, draws, with_seg=False)
+
+    def model():
+        m = det_base.PointNetDet(3, num_vec=3, num_classes=2)
+        synth.fill_state_dict(m.state_dict(), seed=7)
+        return m.cuda().train()
+
+    ready = b.launch(t)                                   # built ahead of time
+    m0 = model()
+    l0, _ = m0(ready)
+    want = {k: float(v) for k, v in l0.items()}
+    m1 = model()
+    cur = b.launch(t)                                     # this step's batch
+    nxt = b.alloc(B, with_seg=False)                      # the next one: NOT built yet
+    for v in nxt.values():
+        v.zero_()
+    nxt["size_class"], nxt["one_hot"] = t["size_class"], t["one_hot"]        # (what launch() will hand back as well)
+    m1.next_batch = nxt
+    m1.next_batch_build = lambda: b.launch(t, out=nxt)
+    l1, _ = m1(cur)
+    m1.backward(l1["total_loss"])                         # (joins the prefetch branch)
+    assert m1.feat_net._prefetched is not None
+    torch.cuda.synchronize()
+    assert float(nxt["point_cloud"].abs().max()) > 0      # the branch built it
+    # a second model with the same weights consumes batch `nxt` without any prefetch: same losses as on `ready`
+    l2, _ = m0.__class__.forward(model(), nxt)
+    assert {k: float(v) for k, v in l2.items()} == want
+    # and m1 itself consumes its prefetched front (running statistics moved by its first step, so only finiteness is checked here)
+    l3, _ = m1(nxt)
+    assert m1.feat_net._prefetched is None and all(torch.isfinite(v) for v in l3.values())
+    with pytest.raises(RuntimeError, match="prefetch branch"):
+        four = torch.cat([nxt["point_cloud"], nxt["point_cloud"][:, :1]], 1).contiguous()
+        m1.prefetch(dict(nxt, point_cloud=four), before=lambda: None)
+
+
 def test_cpu_builder_fails_loudly():
     g = _golden()
     from frustum_convnet_amd.inputs import records_from_fixture

@@ -368,3 +368,24 @@ def test_bench_gpus_n_never_prints_a_line_for_fewer_ranks(tmp_path):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", gpus, "--steps", "1", "--warmup", "0"],
                            env=dict(env, WORLD_SIZE=world, RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and '"metric"' not in r.stdout, (gpus, world, r.stdout[-300:], r.stderr[-300:])
+
+
+def test_pmc_traffic_is_keyed_by_configuration(tmp_path, monkeypatch):
+    """every non-car bench line printed the CAR configuration's HBM counters.  The record is now keyed by
+    configuration and tied to the kernel sources: another configuration, or other sources, give None + the reason (-> `traffic: null`)."""
+    import json
+    import bench
+    os.makedirs(tmp_path / "profiles")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "source_hash", lambda: "abc")
+    rec = {"source_hash": "abc", "configs": {"car": {"step": {"bytes_per_step": 10}, "entries": {"fcn_pn_forward": {"bytes_per_launch": 3}}}}}
+    json.dump(rec, open(tmp_path / "profiles" / "pmc_traffic.json", "w"))
+    assert bench.pmc_traffic("step", cfg_name="car") == ({"bytes_per_step": 10}, None)
+    assert bench.pmc_traffic("entry", "fcn_pn_forward", "car")[0] == {"bytes_per_launch": 3}
+    got, why = bench.pmc_traffic("step", cfg_name="refine")
+    assert got is None and "refine" in why and "car" in why
+    got, why = bench.pmc_traffic("entry", "fcn_convnet_backward", "car")
+    assert got is None and "fcn_convnet_backward" in why
+    monkeypatch.setattr(bench, "source_hash", lambda: "other")
+    got, why = bench.pmc_traffic("step", cfg_name="car")
+    assert got is None and "other kernel sources" in why
