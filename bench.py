@@ -339,7 +339,7 @@ def grouping_op_row(data, cfg_name, reps=20):
             "note": "standalone operator (the model itself uses the fused front, fcn_pn_group_compact2, which never writes idx)"}
 
 
-def pmc_traffic(kind, entry=None, cfg_name="car"):
+def pmc_traffic(kind, entry=None, cfg_name="car", prec="split"):
     """HBM bytes from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, written by tools/pmc_summarize.py from
     tools/gpu_traffic.sh, keyed by configuration) -- only when they were measured on THESE kernel sources and for THIS
     configuration.  kind "step": the whole-step record; kind "entry": {"launches_per_step", "bytes_per_step", "bytes_per_launch"}
@@ -356,6 +356,9 @@ def pmc_traffic(kind, entry=None, cfg_name="car"):
     if c is None:
         return None, "profiles/pmc_traffic.json holds no PMC passes of the '%s' configuration (has: %s)" % (
             cfg_name, ", ".join(sorted(d.get("configs", {}))) or "none")
+    if c.get("precision", "split") != prec:
+        return None, "the PMC passes of the '%s' configuration were taken in the '%s' operand mode, this run is '%s'" % (
+            cfg_name, c.get("precision", "split"), prec)
     if kind == "entry":
         e = c.get("entries", {}).get(entry)
         return (e, None) if e else (None, "no PMC record for %s" % entry)
@@ -465,6 +468,8 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
     comm_form = os.environ.get("FCN_BENCH_COMM_FORM", "captured")
     if comm_form not in ("captured", "host"):
         raise SystemExit("FCN_BENCH_COMM_FORM must be 'captured' or 'host'")
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_backend() != "nccl":
+        comm_form = "host"          # (a CPU transport -- the gloo rehearsal -- blocks the host inside its collectives: not capturable)
     captured_comm = overlap and comm_form == "captured"
     model.split_backward = overlap
 
@@ -1148,7 +1153,7 @@ def main():
                           else ("dense bf16 MFMA peak" if prec.startswith("bf16") else "fp32 MFMA peak"))
             else:
                 rl.update(achieved=top["achieved_tbps"], peak=PEAK_HBM_TBPS, unit="TB/s")
-            tr, why = pmc_traffic("entry", top["entry"].split("[")[0], a.cfg)
+            tr, why = pmc_traffic("entry", top["entry"].split("[")[0], a.cfg, prec)
             rl["traffic"] = tr["bytes_per_launch"] if tr else None
             if tr:
                 rl["traffic_note"] = ("HBM bytes per launch of this entry point's kernels (%d launches, %.1f MB per step): "
@@ -1170,7 +1175,7 @@ def main():
     if world == 1:
         # whole-step HBM roofline (BASELINE.json's "HBM roofline %"): fabric bytes of one step from the committed rocprofv3
         # --pmc passes over THIS command and THIS kernel source, divided by the step time measured now.
-        st, why = pmc_traffic("step", cfg_name=a.cfg)
+        st, why = pmc_traffic("step", cfg_name=a.cfg, prec=prec)
         if st:
             sb = st["bytes_per_step"]
             tbps = sb / (ms_per_step * 1e-3) / 1e12

@@ -386,6 +386,8 @@ def test_pmc_traffic_is_keyed_by_configuration(tmp_path, monkeypatch):
     assert got is None and "refine" in why and "car" in why
     got, why = bench.pmc_traffic("entry", "fcn_convnet_backward", "car")
     assert got is None and "fcn_convnet_backward" in why
+    got, why = bench.pmc_traffic("step", cfg_name="car", prec="bf16")
+    assert got is None and "operand mode" in why
     monkeypatch.setattr(bench, "source_hash", lambda: "other")
     got, why = bench.pmc_traffic("step", cfg_name="car")
     assert got is None and "other kernel sources" in why

@@ -85,6 +85,7 @@ def main():
                    "kernels between the last two loss-tail launches of the replayed hipGraph (B = 32 frustums); Infinity-Cache "
                    "hits are counted by these counters")
     res["configs"][cfg_name] = {
+        "precision": os.environ.get("FCN_PRECISION", "split"),
         "step": {"bytes_per_step": int(tot), "fetch_size_kb_raw": round(sum(d["FETCH_SIZE_kb_raw"] for d in kern.values()), 1),
                  "write_size_kb_raw": round(sum(d["WRITE_SIZE_kb_raw"] for d in kern.values()), 1)},
         "entries": entries,
