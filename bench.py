@@ -1004,9 +1004,10 @@ def other_configs(a, dev, min_time=0.3, car_flops=None):
                 tf = car_flops / (m["ms_per_step"] * 1e-3) / 1e12
                 out[-1]["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s",
                                        "frac": round(tf / PEAK_16BIT_MFMA_TFLOPS, 4), "flops_executed_per_step": car_flops,
-                                       "note": ("bf16 operands, fp32 storage: BASELINE config 2's bf16 line" if prec == "bf16ops" else
-                                                "bf16 operands AND bf16 storage of the big intermediates: slower than fp32 storage on MI355X "
-                                                "(8-byte loads, 2-byte stores; DESIGN.md section 6) -- kept as the literal reading of config 2")}
+                                       "note": ("bf16 operands, fp32 storage everywhere" if prec == "bf16ops" else
+                                                "BASELINE config 2's bf16 line: bf16 operands, bf16 STORAGE of the PointNet's per-entry tensors "
+                                                "(y2 / y3 / dy3 / dz2: the streams that reach HBM), fp32 arenas in the L2-resident FCN "
+                                                "(round 6: bf16 arenas there made every FCN launch 22-49 % slower)")}
             del m
         except Exception as e:  # noqa
             out.append({"cfg": cfg_name, "precision": prec, "error": "%s: %s" % (type(e).__name__, e)})
@@ -1124,7 +1125,7 @@ def main():
         "vs_baseline": None, "dtype": DTYPE_LABEL[prec],
         "mfma_operands": {"split": "fp16x3 (forward) / bf16x3 (backward) split of fp32 operands, fp32 accumulate: fp32-class",
                           "f32": "fp32 (v_mfma_f32_32x32x2_f32)",
-                          "bf16": "bf16 single term, fp32 accumulate; y2/y3/dy3/dz2 and the FCN y/dz arenas stored as bf16",
+                          "bf16": "bf16 single term, fp32 accumulate; the PointNet's y2/y3/dy3/dz2 stored as bf16 (the FCN's L2-resident arenas stay fp32)",
                           "bf16ops": "bf16 single term, fp32 accumulate, fp32 storage"}[prec],
         "data": "synthetic",
         "config": {"workload": workload_name(a.cfg, a.batch, npoint, Ls, not a.no_optim, comm_note),

@@ -1663,6 +1663,15 @@ __global__ __launch_bounds__(64 * G, 4) void cg_bwd_pair_kernel(CgBwdPair p)
 //   4n-3: heads.
 // n = 4:  0 b1c1  1 b2c1  2 b2c2  3 b2m  4 b3c1  5 b3c2  6 b3m  7 b4c1  8 b4c2  9 b4m  10 b2d  11 b3d  12 b4d  13 heads
 // ================================================================================================
+// Operand mode of the FCN kernels for a precision of the descriptor.  FCN_PREC_BF16 ("bf16 operands AND bf16 storage of the big
+// intermediates") keeps its bf16 STORAGE for the PointNet's per-entry tensors only: the FCN's activations are 1-9 k rows per layer
+// and live in L2, so halving their bytes buys no memory time while every element pays a conversion on the way in and out --
+// per launch (rocprofv3, round 6, profiles/r06_m_bf16_storage_by_kernel.txt) cgk_fwd 16.2 -> 19.8 us, cg_bwd_step 17.3 -> 25.8 us,
+// cg_bwd_pair 28.5 -> 39.4 us with bf16 arenas, 164 us per step against the 70 us the PointNet kernels GAIN from theirs.  Here the
+// mode therefore means bf16 operands over fp32 arenas (MM_BF16X1), exactly FCN_PREC_BF16_OPS; the y16 / st16 / out16 flags of the
+// descriptors are inert without a half-width St<MM>.
+#define CN_MM_OF(prec, fwd) ((prec) == FCN_PREC_BF16 ? MM_BF16X1 : FCN_MM_OF(prec, fwd))
+
 struct CnPlan {
     int nlev, nl, heads;        // levels, layers in use (4*nlev - 2), id of the heads
     int KT[CN_NLAYER], stride[CN_NLAYER], pad[CN_NLAYER], Lin[CN_NLAYER], Lout[CN_NLAYER];
@@ -1866,9 +1875,9 @@ static int cn_pack(const fcn_cn_desc *d, const fcn_cn_params *p, const CnPlan &P
     t.oh = one_hot; t.oh64 = ws->oh64; t.B = d->B; t.nvec = d->nvec;
     t.z0 = d->training ? ws->stat : nullptr; t.z1 = d->training ? ws->bstat : nullptr; t.nz = FCN_CG_REP * O.st[P.nl];
     t.enc = ws->wp + O.wp[P.nl];            // second third of the weight arena (fcn_convnet_sizes)
-    t.mmf = FCN_MM_OF(d->precision, true);
+    t.mmf = CN_MM_OF(d->precision, true);
     t.grd = d->training ? ws->wp + 2 * O.wp[P.nl] : nullptr;      // third third: only a backward reads it
-    t.mmb = FCN_MM_OF(d->precision, false);
+    t.mmb = CN_MM_OF(d->precision, false);
     hipLaunchKernelGGL(cg_pack_kernel,
                        dim3((unsigned)(((t.grd ? 2 : 1) * (t.pre[CN_NLAYER] / 8) + (int64_t)d->B * OH_PAD + t.nz + 255) / 256)),
                        dim3(256), 0, st, t);
@@ -1921,7 +1930,7 @@ extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p
     cn_offsets(d, P, O);
     const int tr = d->training ? 1 : 0;
     if (d->precision < 0 || d->precision > FCN_PREC_BF16_OPS) return FCN_E_BADARG;
-    const int mmf = FCN_MM_OF(d->precision, true);
+    const int mmf = CN_MM_OF(d->precision, true);
     if (!d->prepacked) FCN_TRY(cn_pack(d, p, P, O, ws, one_hot, st));      // (also zeroes ws->stat / ws->bstat)
     // launches in dependency order; block{j}_conv1 and block{j-1}_deconv (j >= 3) are pairs of independent layers reading
     // the same merge output and share a launch (n = 4: {4, 10} and {7, 11})
@@ -2037,7 +2046,7 @@ extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p
     const bool cont = stream2 != nullptr && events != nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (d->precision < 0 || d->precision > FCN_PREC_BF16_OPS) return FCN_E_BADARG;
-    const int mmb = FCN_MM_OF(d->precision, false);
+    const int mmb = CN_MM_OF(d->precision, false);
     CnPlan P;
     FCN_TRY(cn_make_plan(d, P));
     CnOffsets O;

@@ -54,12 +54,13 @@ extern "C" {
  *                   operands (activations after BN+ReLU, weights) must stay below 65504 in magnitude.
  *   FCN_PREC_F32    exact fp32 MFMA (v_mfma_f32_32x32x2_f32): the reference mode for A/B comparisons.
  *   FCN_PREC_BF16   throughput mode of BASELINE config 2 (bf16 activations + GEMM inputs): single bf16 MFMA per product, fp32
- *                   accumulate, and the big intermediate tensors (PointNet y2 / y3 / dy3 / dz2, the FCN's y / dz arenas) STORED as
- *                   bf16 in the first half of their (fp32-sized) buffers; BatchNorm sums, pooled features, logits and all
- *                   parameter gradients stay fp32 (logits within a few 1e-2 relative of the fp32 reference; grouping indices
- *                   unaffected).
- *   FCN_PREC_BF16_OPS  the same operands with fp32 storage (rounds 1-2's bf16 mode): on MI355X the step is latency-, not
- *                   HBM-bound, and the narrower accesses of bf16 storage make it SLOWER than this variant. */
+ *                   accumulate, and the BIG intermediate tensors -- the PointNet's per-entry y2 / y3 / dy3 / dz2, the streams that
+ *                   reach HBM -- STORED as bf16 in the first half of their (fp32-sized) buffers; BatchNorm sums, pooled features,
+ *                   logits and all parameter gradients stay fp32 (logits within a few 1e-2 relative of the fp32 reference;
+ *                   grouping indices unaffected).  The FCN's y / dz arenas (a few thousand rows per layer, L2-resident) stay
+ *                   fp32 in this mode since round 6: bf16 arenas made every fcn_convnet_* launch 22-49 % slower and saved no
+ *                   memory time (fcn_net.hip, CN_MM_OF).
+ *   FCN_PREC_BF16_OPS  the same operands with fp32 storage everywhere (rounds 1-2's bf16 mode). */
 #define FCN_PREC_SPLIT 0
 #define FCN_PREC_F32   1
 #define FCN_PREC_BF16  2
