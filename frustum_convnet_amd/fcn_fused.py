@@ -240,20 +240,16 @@ def _gather(conv_net, cls_out, reg_out):
     return pt, bufs, bn0
 
 
-def convnet_prepack(pool, conv_net, cls_out, reg_out, B, Ls, one_hot, device, after=None):
+def convnet_prepack(pool, conv_net, cls_out, reg_out, B, Ls, one_hot, device):
     """Starts the weight re-packing of the coming convnet_fused() call on the pool's side stream (forked from the current
-    stream, or behind the event `after` recorded on it earlier) and returns the handle to pass as `pre`: 25 us that overlap
-    the PointNet scales instead of heading the FCN."""
+    stream) and returns the handle to pass as `pre`: 25 us that overlap the PointNet scales instead of heading the FCN."""
     pt, bufs, bn0 = _gather(conv_net, cls_out, reg_out)
     training = conv_net.training
     need_grad = bool(training) and torch.is_grad_enabled() and any(t.requires_grad for t in pt)
     cfgt = (bool(training), float(bn0.eps), bn_momentum(bn0), need_grad)
     cur = torch.cuda.current_stream(device)
     side, ev = pool.pack_stream(device)
-    if after is not None:
-        side.wait_event(after)
-    else:
-        side.wait_stream(cur)
+    side.wait_stream(cur)
     with torch.cuda.stream(side):
         # a step loop may hang work in FRONT of the packing, on its stream (bench.py FCN_ADAM_LATE: the optimiser step of the
         # [ConvFeatNet + heads] bucket, whose result nothing reads before this packing)
