@@ -50,19 +50,21 @@ def _stage_sources():
     return dst
 
 
-def build(force=False, extra=()):
+def build(force=False, extra=(), out=None):
+    """out: another output path (a tuning build of the emulation: extra = its -D flags; always rebuilt when the sources changed)."""
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "hip_emu", "hip", "hip_runtime.h"), __file__,
                                                                 os.path.join(ROOT, "include", "fcn_hip.h")]
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
-        return OUT
+    out = out or OUT
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
     src = _stage_sources()
     # -DFCN_BWD_G4_ROWS=1: the FCN backward's FOUR-wave workgroups (csrc/fcn_net.hip cn_bwd_groups) for every shape -- on the GPU the
     # small test shapes run the eight-wave kernels and only the full-size fixtures the four-wave ones; here it is the other way round,
     # so both instantiations see small, ragged shapes somewhere
     cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-g0", "-mf16c", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-w",
-           "-DFCN_BWD_G4_ROWS=1", "-I", os.path.join(HERE, "hip_emu")] + list(extra) + [os.path.join(src, s) for s in SOURCES] + ["-o", OUT]
+           "-DFCN_BWD_G4_ROWS=1", "-I", os.path.join(HERE, "hip_emu")] + list(extra) + [os.path.join(src, s) for s in SOURCES] + ["-o", out]
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
