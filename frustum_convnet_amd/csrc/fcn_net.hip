@@ -310,6 +310,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     __shared__ u32x4 lds4[DIRECT ? G * TMB * TNC / 4 : G * GU4];   // per K-group: kb-major images of its A and W chunk (gemm_tile.h); DIRECT: only the cross-group sum
     __shared__ __attribute__((aligned(16))) float sS[CG_KMAX], tS[CG_KMAX];
     __shared__ int cSeg[CG_KMAX / KC], cTap[CG_KMAX / KC], cK0[CG_KMAX / KC];   // chunk -> (segment, tap, channel)
+    __shared__ __attribute__((aligned(16))) int cDesc[DIRECT ? 8 * (CG_KMAX / KC) : 4];      // DIRECT: chunk descriptors
     float *lds = (float *)lds4;
     if (FCN_XF & 128) return;                           // (timing builds: the bare launch -- dispatch + kernel boundary)
     const int tid = threadIdx.x, g = tid / TG, gt = tid % TG;
@@ -349,6 +350,8 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         const bool rv1 = gr < R;
         int bb1 = 0, ll1 = 0;
         cg_divmod(rv1 ? gr : 0, LLout, cg_inv(LLout), bb1, ll1);             // (R < 2^23: cn_make_plan)
+        const int lin0 = rv1 ? (int)fcn_mad24((unsigned)ll1, (unsigned)geo.stride, (unsigned)(-geo.pad)) : -(1 << 30);
+        const unsigned laneoff = 32u * (unsigned)lh;                          // bytes: this lane's 8-deep half of a 16-deep step
         constexpr bool X3 = !mm_x1<MM>;
         constexpr int NW = X3 || MM == MM_F32 ? 4 : 2;                       // weight fragments per chunk: (step, plane)
         // fragment (s, plane) of the weight image of a chunk: u32x4 ((plane * 4 + 2 s + lh) * Cout + n0 + l31)
@@ -361,25 +364,49 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         bool dk0 = false, dk1 = false;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { da0[i] = zero4(); da1[i] = zero4(); dw0[i] = u32x4{0u, 0u, 0u, 0u}; dw1[i] = u32x4{0u, 0u, 0u, 0u}; }
-#define CGD_FWD_LOAD_AT(cc, SG, TAP, K0, RA, RW, OK)                                                                  \
+        // a chunk's scalars: source base, 4 * channels, rows per frustum, tap, 4 * first channel, position clamp, bf16 flag -- from the
+        // descriptor table the prologue builds in LDS (two 16-byte broadcast reads + readfirstlane) instead of five 4-way scalar
+        // select chains per chunk
+#define CGD_FWD_LOAD_CORE(cc, X, C4, LS, TAP, K04, LHI, H16, RA, RW, OK)                                              \
     {                                                                                                                 \
         const int c_ = (cc);                                                                                          \
-        const int sgi = (SG), tap = (TAP), k0 = (K0);                                                                 \
-        const float *x = SEL4(sgi, x0, x1, x2, x3);                                                                   \
-        const int C = SEL4(sgi, C0, C1, C2, C3), ty = SEL4(sgi, T0, T1, T2, T3), Ls = SEL4(sgi, Q0, Q1, Q2, Q3);      \
-        const int h16 = SEL4(sgi, H0, H1, H2, H3);                                                                    \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
-            RA[i] = cg_load_raw<MM>(geo, x, C, Ls, ty ? 0 : 1, tap, k0 + 16 * (i >> 1) + 8 * lh + 4 * (i & 1), bb1,   \
-                                    ll1, rv1, OK, h16);                                                               \
+        if constexpr (St<MM>::half) {                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
+                RA[i] = cg_load_raw<MM>(geo, (X), (C4) >> 2, (LS), (LHI) ? 1 : (geo.Lin == 1 ? 1 : 0), (TAP),         \
+                                        ((K04) >> 2) + 16 * (i >> 1) + 8 * lh + 4 * (i & 1), bb1, ll1, rv1, OK, (H16)); \
+        } else {                                                                                                      \
+            /* ONE address per chunk: the row of tap TAP (lin0 = position of tap 0, hoisted; an invalid row sits at */  \
+            /* -2^30, outside every range), clamped; the four 16-byte pieces of the lane's two 8-deep halves are */     \
+            /* constant byte offsets (0, 16, 64, 80) off it */                                                        \
+            const int lin = lin0 + (TAP);                                                                             \
+            OK = (unsigned)lin < (unsigned)geo.Lin;                                                                   \
+            const int lc = min(max(lin, 0), fcn_opaque_sgpr(LHI));                                                    \
+            const unsigned eb = fcn_mad24(fcn_mad24((unsigned)bb1, (unsigned)(LS), (unsigned)lc), (unsigned)(C4),     \
+                                          laneoff + (unsigned)(K04));                                                 \
+            const char *xb_ = (const char *)(X) + eb;                                                                 \
+            RA[0] = *(gv4fp)(xb_); RA[1] = *(gv4fp)(xb_ + 16); RA[2] = *(gv4fp)(xb_ + 64); RA[3] = *(gv4fp)(xb_ + 80); \
+        }                                                                                                             \
         const char *wc_ = wsrc + (size_t)(unsigned)(c_ * 8 * LCout) * 16u;                                            \
         _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                                 \
             if (NW == 4 || !(q & 1)) RW[q] = *(gu4p)(wc_ + wofd[q]);                                                  \
     }
+#define CGD_FWD_LOAD_AT(cc, SG, TAP, K0, RA, RW, OK)                                                                  \
+    {                                                                                                                 \
+        const int sgi = (SG);                                                                                         \
+        const float *x = SEL4(sgi, x0, x1, x2, x3);                                                                   \
+        const int C = SEL4(sgi, C0, C1, C2, C3), ty = SEL4(sgi, T0, T1, T2, T3), Ls = SEL4(sgi, Q0, Q1, Q2, Q3);      \
+        const int h16 = SEL4(sgi, H0, H1, H2, H3);                                                                    \
+        CGD_FWD_LOAD_CORE(cc, x, 4 * C, Ls, (TAP), 4 * (K0), (geo.Lin - 1) * (ty ? 0 : 1), h16, RA, RW, OK);          \
+    }
 #define CGD_FWD_LOAD(cc, RA, RW, OK)                                                                                  \
     {                                                                                                                 \
         const int c__ = __builtin_amdgcn_readfirstlane(cc);                                                           \
-        CGD_FWD_LOAD_AT(c__, __builtin_amdgcn_readfirstlane(cSeg[c__]), __builtin_amdgcn_readfirstlane(cTap[c__]),    \
-                        __builtin_amdgcn_readfirstlane(cK0[c__]), RA, RW, OK);                                        \
+        const v4i q0_ = *(const v4i *)(cDesc + 8 * c__), q1_ = *(const v4i *)(cDesc + 8 * c__ + 4);                   \
+        const unsigned xlo_ = (unsigned)__builtin_amdgcn_readfirstlane(q0_.x), xhi_ = (unsigned)__builtin_amdgcn_readfirstlane(q0_.y); \
+        const float *x_ = (const float *)(((unsigned long long)xhi_ << 32) | (unsigned long long)xlo_);               \
+        CGD_FWD_LOAD_CORE(c__, x_, __builtin_amdgcn_readfirstlane(q0_.z), __builtin_amdgcn_readfirstlane(q0_.w),      \
+                          __builtin_amdgcn_readfirstlane(q1_.x), __builtin_amdgcn_readfirstlane(q1_.y),               \
+                          __builtin_amdgcn_readfirstlane(q1_.z), __builtin_amdgcn_readfirstlane(q1_.w), RA, RW, OK);  \
     }
         // the transform of the staged form, on the 8 values of a step: BatchNorm scale / shift of column k (LDS tables, the 32
         // lanes of a half read the same 16 bytes: a broadcast), ReLU + row mask as one v_med3, split-encode, MFMAs
@@ -427,10 +454,16 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
                             __builtin_amdgcn_readfirstlane(k0_), da1, dw1, dk1);
         }
         PROBE_STAMP();                                      // 1: first loads issued
-        if (tid < nchunk) {
+        if (tid < nchunk) {                                 // the chunk descriptors: 8 dwords each
             int sg, tap, k0, so;
             cg_locate_s(geo, C0, C1, C2, C3, tid * KC, sg, tap, k0, so);
-            cSeg[tid] = sg; cTap[tid] = tap; cK0[tid] = k0;
+            const float *x = SEL4(sg, x0, x1, x2, x3);
+            const int C = SEL4(sg, C0, C1, C2, C3), ty = SEL4(sg, T0, T1, T2, T3), Ls = SEL4(sg, Q0, Q1, Q2, Q3);
+            const unsigned long long xa = (unsigned long long)x;
+            const v4i d0 = {(int)(unsigned)xa, (int)(unsigned)(xa >> 32), 4 * C, Ls};
+            const v4i d1 = {tap, 4 * k0, (geo.Lin - 1) * (ty ? 0 : 1), SEL4(sg, H0, H1, H2, H3)};
+            *(v4i *)(cDesc + 8 * tid) = d0;
+            *(v4i *)(cDesc + 8 * tid + 4) = d1;
         }
         const cg_klayer_p Lk = cg_kernarg_layer(koff);
         cg_fill_bn(Lk, sS, tS, tid, NTHR, bx == 0 && by == 0);
@@ -444,6 +477,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
 #undef CGD_FWD_ITER
 #undef CGD_FWD_LOAD
 #undef CGD_FWD_LOAD_AT
+#undef CGD_FWD_LOAD_CORE
     } else {
     int bb[NA], ll[NA];
     bool rv[NA];
