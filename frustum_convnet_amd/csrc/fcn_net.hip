@@ -55,6 +55,9 @@ __device__ __forceinline__ double cg_rep_sum(const double *p, int stride)
 #ifndef FCN_FWD_DIRECT
 #define FCN_FWD_DIRECT 0
 #endif
+#ifndef FCN_FWD_DEPTH
+#define FCN_FWD_DEPTH 2        // chunks in flight per K-group of the direct form (2 or 3 register sets)
+#endif
 #define LDN 68                 // row-major LDS leading dim of a 64-wide tile (float4 aligned)
 #define OH_PAD 64              // channels of the virtual one-hot segment
 #define CG_SPLIT_ROWS 512      // rows per wgrad split
@@ -359,11 +362,16 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
 #pragma unroll
         for (int q = 0; q < 4; ++q) wofd[q] = (unsigned)((((q & 1) * 4 + 2 * (q >> 1) + lh) * LCout + l31)) * 16u;
         const char *wsrc = (const char *)(LWenc + n0);
-        v4f da0[4], da1[4];                   // [2 * step + piece]: k = 16 step + 8 lh + 4 piece .. + 3 of the chunk
-        u32x4 dw0[4], dw1[4];                 // [2 * step + plane]
-        bool dk0 = false, dk1 = false;
+        constexpr int DEPTH = FCN_FWD_DEPTH;
+        static_assert(DEPTH == 2 || DEPTH == 3, "two or three chunks in flight");
+        v4f da0[4], da1[4], da2[4];           // [2 * step + piece]: k = 16 step + 8 lh + 4 piece .. + 3 of the chunk
+        u32x4 dw0[4], dw1[4], dw2[4];         // [2 * step + plane]
+        bool dk0 = false, dk1 = false, dk2 = false;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { da0[i] = zero4(); da1[i] = zero4(); dw0[i] = u32x4{0u, 0u, 0u, 0u}; dw1[i] = u32x4{0u, 0u, 0u, 0u}; }
+        for (int i = 0; i < 4; ++i) {
+            da0[i] = zero4(); da1[i] = zero4(); da2[i] = zero4();
+            dw0[i] = u32x4{0u, 0u, 0u, 0u}; dw1[i] = u32x4{0u, 0u, 0u, 0u}; dw2[i] = u32x4{0u, 0u, 0u, 0u};
+        }
         // a chunk's scalars: source base, 4 * channels, rows per frustum, tap, 4 * first channel, position clamp, bf16 flag -- from the
         // descriptor table the prologue builds in LDS (two 16-byte broadcast reads + readfirstlane) instead of five 4-way scalar
         // select chains per chunk
@@ -441,7 +449,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
                 }                                                                                                     \
             }                                                                                                         \
         }                                                                                                             \
-        if (c + 2 * G < nchunk) CGD_FWD_LOAD(c + 2 * G, RA, RW, OK);                                                  \
+        if (c + DEPTH * G < nchunk) CGD_FWD_LOAD(c + DEPTH * G, RA, RW, OK);                                          \
     }
         {
             int sg_, tap_, k0_, so_;
@@ -452,6 +460,12 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
             cg_locate_s(geo, C0, C1, C2, C3, cb * KC, sg_, tap_, k0_, so_);
             CGD_FWD_LOAD_AT(__builtin_amdgcn_readfirstlane(cb), __builtin_amdgcn_readfirstlane(sg_), __builtin_amdgcn_readfirstlane(tap_),
                             __builtin_amdgcn_readfirstlane(k0_), da1, dw1, dk1);
+            if constexpr (DEPTH == 3) {
+                const int cc = min(g + 2 * G, nchunk - 1);
+                cg_locate_s(geo, C0, C1, C2, C3, cc * KC, sg_, tap_, k0_, so_);
+                CGD_FWD_LOAD_AT(__builtin_amdgcn_readfirstlane(cc), __builtin_amdgcn_readfirstlane(sg_), __builtin_amdgcn_readfirstlane(tap_),
+                                __builtin_amdgcn_readfirstlane(k0_), da2, dw2, dk2);
+            }
         }
         PROBE_STAMP();                                      // 1: first loads issued
         if (tid < nchunk) {                                 // the chunk descriptors: 8 dwords each
@@ -469,9 +483,12 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
         cg_fill_bn(Lk, sS, tS, tid, NTHR, bx == 0 && by == 0);
         __syncthreads();                            // sS / tS and the chunk table ready
         PROBE_STAMP();                                      // 2: prologue done
-        for (int it = 0; it < nit; it += 2) {
+        for (int it = 0; it < nit; it += DEPTH) {
             CGD_FWD_ITER(it, da0, dw0, dk0);
             if (it + 1 < nit) CGD_FWD_ITER(it + 1, da1, dw1, dk1);
+            if constexpr (DEPTH == 3) {
+                if (it + 2 < nit) CGD_FWD_ITER(it + 2, da2, dw2, dk2);
+            }
         }
         PROBE_STAMP();                                      // 3: K loop done (wave 0)
 #undef CGD_FWD_ITER
