@@ -55,6 +55,16 @@ __device__ __forceinline__ double cg_rep_sum(const double *p, int stride)
 #ifndef FCN_FWD_DIRECT
 #define FCN_FWD_DIRECT 0
 #endif
+// FCN_FWD_EARLY_BN: the batch sums of the layer's FIRST input segment (its main producer) are requested at kernel entry -- two
+// channels per thread, all replicas -- and consumed by cg_fill_bn, so that their round trip runs beside the row divisions, the
+// chunk table and the first operand loads instead of behind them (the ablation of EXPERIMENTS 6.2: the consumer-side BatchNorm
+// finalisation is 2.7 us of every forward launch).  One channel per thread: a second slot (C = 512) or a second segment costs 36 more
+// live VGPRs in front of the K loop -- 158 + scratch, two waves per SIMD, 512 slots for 560 tiles.  Same sums in the same replica
+// order: bit-identical outputs.  Measured (session u, four alternating pairs on one box): 1.1057 against 1.1123 ms per step (-0.6 %),
+// cgk_fwd_kernel 18.0 against 18.3 us, the probe's prologue phase -0.3 ... -0.6 us on every layer with a BatchNorm in front.
+#ifndef FCN_FWD_EARLY_BN
+#define FCN_FWD_EARLY_BN 1
+#endif
 #ifndef FCN_FWD_DEPTH
 #define FCN_FWD_DEPTH 2        // chunks in flight per K-group of the direct form (2 or 3 register sets)
 #endif
@@ -240,8 +250,14 @@ __device__ __forceinline__ cg_klayer_p cg_kernarg_layer(int koff)
     return p;
 }
 
+// first-slot sums of segment 0 requested at kernel entry (FCN_FWD_EARLY_BN): channel tid, every replica
+struct CgBnEarly {
+    double s1[1][FCN_CG_REP], s2[1][FCN_CG_REP];
+    float g[1], b[1];
+    bool on;                   // (wave-uniform) the values above are segment 0's batch sums / gamma / beta
+};
 template <class LP>            // LP: const CgLayer * (by-value parameter) or cg_klayer_p
-__device__ __forceinline__ void cg_fill_bn(LP Lp, float *sS, float *tS, int tid, int nthr, bool pub)
+__device__ __forceinline__ void cg_fill_bn(LP Lp, float *sS, float *tS, int tid, int nthr, bool pub, const CgBnEarly *early = nullptr)
 {
     const auto &L = *Lp;
     int off = 0;
@@ -254,19 +270,33 @@ __device__ __forceinline__ void cg_fill_bn(LP Lp, float *sS, float *tS, int tid,
                 const bool batch = S.stat != nullptr;
                 const bool wr = pub && S.writer;
                 const double invM = 1.0 / S.M;
+                const bool pre = s == 0 && early && early->on && batch;
                 for (int k = tid; k < C; k += nthr) {
                     double mean, var;
-                    if (batch) {
-                        mean = cg_rep_sum(S.stat + k, L.rep_stride) * invM;
-                        var = cg_rep_sum(S.stat + C + k, L.rep_stride) * invM - mean * mean;
+                    float gk, bk;
+                    const int slot = (k - tid) / nthr;                 // (0, 1, ...: which of this thread's channels)
+                    if (pre && slot < 1) {
+                        double a1 = early->s1[0][0], a2 = early->s2[0][0];
+#pragma unroll
+                        for (int r = 1; r < FCN_CG_REP; ++r) { a1 += early->s1[0][r]; a2 += early->s2[0][r]; }
+                        mean = a1 * invM;
+                        var = a2 * invM - mean * mean;
                         if (var < 0.0) var = 0.0;
+                        gk = early->g[0]; bk = early->b[0];
                     } else {
-                        mean = S.rmean[k];
-                        var = S.rvar[k];
+                        if (batch) {
+                            mean = cg_rep_sum(S.stat + k, L.rep_stride) * invM;
+                            var = cg_rep_sum(S.stat + C + k, L.rep_stride) * invM - mean * mean;
+                            if (var < 0.0) var = 0.0;
+                        } else {
+                            mean = S.rmean[k];
+                            var = S.rvar[k];
+                        }
+                        gk = S.gamma[k]; bk = S.beta[k];
                     }
                     const double rstd = cg_rsqrt64(var + (double)L.eps);
-                    const double sc = (double)S.gamma[k] * rstd;
-                    const float fs = (float)sc, ft = (float)((double)S.beta[k] - mean * sc);
+                    const double sc = (double)gk * rstd;
+                    const float fs = (float)sc, ft = (float)((double)bk - mean * sc);
                     for (int t = 0; t < L.KT; ++t) { sS[off + t * C + k] = fs; tS[off + t * C + k] = ft; }
                     if (wr) {
                         S.bn[k] = fs; S.bn[C + k] = ft; S.bn[2 * C + k] = (float)mean; S.bn[3 * C + k] = (float)rstd;
@@ -330,6 +360,27 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     geo.nseg = opaque_s(L.nseg); geo.KT = opaque_s(L.KT); geo.stride = opaque_s(L.stride); geo.pad = opaque_s(L.pad);
     geo.Lin = opaque_s(L.Lin);
     const u32x4 *LWenc = opaque_s(L.Wenc);
+    CgBnEarly early;
+    early.on = false;
+    if constexpr (FCN_FWD_EARLY_BN != 0) {
+        const double *st0 = opaque_s(L.seg[0].stat);
+        const float *gm0 = opaque_s(L.seg[0].gamma), *bt0 = opaque_s(L.seg[0].beta);
+        const int rs0 = opaque_s(L.rep_stride), Ce = opaque_s(L.seg[0].C);
+        early.on = st0 != nullptr && gm0 != nullptr;
+        if (early.on) {
+#pragma unroll
+            for (int i = 0; i < 1; ++i) {
+                const int k = min(tid + i * NTHR, Ce - 1);              // (clamped: unconditional loads)
+#pragma unroll
+                for (int r = 0; r < FCN_CG_REP; ++r) {
+                    early.s1[i][r] = st0[(int64_t)r * rs0 + k];
+                    early.s2[i][r] = st0[(int64_t)r * rs0 + Ce + k];
+                }
+                early.g[i] = gm0[k];
+                early.b[i] = bt0[k];
+            }
+        }
+    }
     const int R = LB * LLout;
     const int row0 = bx * TMB, n0 = by * TNC;
     const int kq = gt & 7, rb = gt >> 3;      // rb: 0..31 (MW=2) or 0..15 (MW=1)
@@ -480,7 +531,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
             *(v4i *)(cDesc + 8 * tid + 4) = d1;
         }
         const cg_klayer_p Lk = cg_kernarg_layer(koff);
-        cg_fill_bn(Lk, sS, tS, tid, NTHR, bx == 0 && by == 0);
+        cg_fill_bn(Lk, sS, tS, tid, NTHR, bx == 0 && by == 0, &early);
         __syncthreads();                            // sS / tS and the chunk table ready
         PROBE_STAMP();                                      // 2: prologue done
         for (int it = 0; it < nit; it += DEPTH) {
@@ -607,7 +658,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     // (from here on the descriptor is read through the kernarg pointer: see cg_kernarg_layer)
     const cg_klayer_p Lk = cg_kernarg_layer(koff);
     if (FCN_XF & 32) { for (int i = tid; i < LKtot; i += NTHR) { sS[i] = 1.f; tS[i] = 0.f; } }
-    else cg_fill_bn(Lk, sS, tS, tid, NTHR, bx == 0 && by == 0);
+    else cg_fill_bn(Lk, sS, tS, tid, NTHR, bx == 0 && by == 0, &early);
     __syncthreads();                            // sS / tS and the chunk table ready
     if (FCN_XF & 256) { if (sS[0] == 123.456f) Lk->y[0] = 0.f; return; }      // (timing builds: launch + prologue only)
     PROBE_STAMP();                                      // 2: prologue done
