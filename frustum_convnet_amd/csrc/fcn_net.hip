@@ -799,6 +799,29 @@ __device__ __forceinline__ void cg_bnbwd_coef(const QT &q, int Cs, int c, float 
     if (pub && q.dgamma) { q.dgamma[c] = (float)dg; q.dbeta[c] = (float)db; }
 }
 
+// the same from sums / table entries that are already in registers (FCN_BWD_EARLY_BN: requested at kernel entry)
+template <class QT>
+__device__ __forceinline__ void cg_bnbwd_coef_pre(const QT &q, int Cs, int c, const double (&sb)[FCN_CG_REP], const double (&sg)[FCN_CG_REP],
+                                                  float rstd, float mean, float gam, float (&cf)[5], bool pub)
+{
+    double db = sb[0], dg = sg[0];
+#pragma unroll
+    for (int r = 1; r < FCN_CG_REP; ++r) { db += sb[r]; dg += sg[r]; }
+    cf[0] = gam * rstd;
+    cf[1] = mean;
+    const double invM = 1.0 / q.M;
+    const double c0 = (double)cf[0];
+    cf[2] = (float)(c0 * (double)rstd * (dg * invM));
+    cf[3] = (float)(c0 * (db * invM));
+    cf[4] = 0.f;
+    if (pub && q.dgamma) { q.dgamma[c] = (float)dg; q.dbeta[c] = (float)db; }
+}
+// FCN_BWD_EARLY_BN: the data-gradient role requests the BatchNorm-backward sums of channel `tid` (all replicas) and its mean / rstd /
+// gamma at entry, beside the kernel-argument batch, as FCN_FWD_EARLY_BN does in the forward
+#ifndef FCN_BWD_EARLY_BN
+#define FCN_BWD_EARLY_BN 0
+#endif
+
 #define CG_CMAX 512            // largest BN width (Cs) whose backward coefficients are staged in LDS
 
 // dy of a BN layer from raw (dz, y) and the LDS-staged coefficients: kk*(dz - dbeta/M - xhat*dgamma/M)
@@ -1172,6 +1195,21 @@ __device__ __forceinline__ void cg_dgrad_body(const LT &L, const CT &cb, const f
     CG_PIN(13, SC, SLsrc, LB, LLin, LLout, LCout, LKT, LCs, Lpad, Lstride, LKtot, LWgrd, cbstat);
     const int tid = threadIdx.x, g = tid >> 6;
     const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+    double esb[FCN_CG_REP], esg[FCN_CG_REP];
+    float erstd = 0.f, emean = 0.f, egam = 0.f;
+    if constexpr (FCN_BWD_EARLY_BN != 0) {
+        if (cbstat != nullptr) {
+            const int ce = min(tid, LCs - 1);                               // (clamped: unconditional loads)
+            const int rs_ = cb.rep_stride;
+            const float *bnp = cb.bn, *gmp = cb.gamma;
+#pragma unroll
+            for (int r = 0; r < FCN_CG_REP; ++r) {
+                esb[r] = cbstat[(int64_t)r * rs_ + ce];
+                esg[r] = cbstat[(int64_t)r * rs_ + LCs + ce];
+            }
+            erstd = bnp[3 * LCs + ce]; emean = bnp[2 * LCs + ce]; egam = gmp[ce];
+        }
+    }
     u32x4 *Ai = (u32x4 *)(lds + g * CGB_WSZ), *Bi = (u32x4 *)(lds + g * CGB_WSZ + ASZ);
     const int C = SC, Rs = LB * SLsrc, Cs = LCs;
     bool wave_live = true;
@@ -1258,7 +1296,8 @@ __device__ __forceinline__ void cg_dgrad_body(const LT &L, const CT &cb, const f
     if (hasbn) {
         for (int c = tid; c < Cs; c += NTHR) {
             float cf[5];
-            cg_bnbwd_coef(cb, Cs, c, cf, pub);
+            if (FCN_BWD_EARLY_BN != 0 && c == tid) cg_bnbwd_coef_pre(cb, Cs, c, esb, esg, erstd, emean, egam, cf, pub);
+            else cg_bnbwd_coef(cb, Cs, c, cf, pub);
 #pragma unroll
             for (int q = 0; q < 5; ++q) coefS[q * Cs + c] = cf[q];
         }
