@@ -330,7 +330,7 @@ __device__ __forceinline__ float cg_actk(float s, float x, float t, float keep) 
 // gives 4-16 resident waves per tile to hide the gather / staging latency, and nothing but the result goes back to HBM.
 // In use: <1,4,1> (32 x 32 tile, 4 waves) -- 560 workgroups per layer; <1,4> (32 x 64) and <2,4> (64 x 64) measured
 // 5 % slower over the forward (280 tiles for 256 CUs at every level of the pyramid).
-template <int MM, int MW, int G, int WNC = 2, int NTW = 1>      // WNC waves across N per K-group, NTW 32-column blocks per wave:
+template <int MM, int MW, int G, int WNC = 2, int NTW = 1, int EB = FCN_FWD_EARLY_BN>      // WNC waves across N per K-group, NTW 32-column blocks per wave; EB: early batch sums (training launches)
 __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, const int by, const int koff)      // tile (32*MW) x (32*WNC*NTW); koff: offset of L in the kernarg segment
 {
     constexpr int TG = 64 * MW * WNC, TMB = 32 * MW, TNC = 32 * WNC * NTW, NTHR = G * TG;
@@ -362,7 +362,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     const u32x4 *LWenc = opaque_s(L.Wenc);
     CgBnEarly early;
     early.on = false;
-    if constexpr (FCN_FWD_EARLY_BN != 0) {
+    if constexpr (EB != 0) {
         const double *st0 = opaque_s(L.seg[0].stat);
         const float *gm0 = opaque_s(L.seg[0].gamma), *bt0 = opaque_s(L.seg[0].beta);
         const int rs0 = opaque_s(L.rep_stride), Ce = opaque_s(L.seg[0].C);
@@ -739,7 +739,7 @@ __device__ __forceinline__ void cgk_fwd_body(const CgLayer &L, const int bx, con
     PROBE_FLUSH(((unsigned long long)Le->Ktot << 32) | ((unsigned long long)Le->Cout << 16) | (unsigned long long)(Le->Lout & 0xffff));
 }
 
-template <int MM, int MW, int G, int WNC = 2, int NTW = 1>
+template <int MM, int MW, int G, int WNC = 2, int NTW = 1, int EB = FCN_FWD_EARLY_BN>
 __global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_kernel(CgLayer L)
 {
     const int nby = L.Cout / (32 * WNC * NTW), nbx = (L.B * L.Lout + 32 * MW - 1) / (32 * MW);
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_kernel(CgLayer L)
     if (t < 0) return;
     int bx, by;
     cg_divmod(t, nby, cg_inv(nby), bx, by);                    // (t < 2^23: a grid is at most a few thousand workgroups)
-    cgk_fwd_body<MM, MW, G, WNC, NTW>(L, bx, by, 0);
+    cgk_fwd_body<MM, MW, G, WNC, NTW, EB>(L, bx, by, 0);
 }
 
 // Two INDEPENDENT layers in one launch (a deconvolution next to the stride-2 conv that reads the same merge output):
@@ -758,7 +758,7 @@ struct CgLayerPair {
     int na;                    // workgroups of A (a multiple of 8); the rest belong to B
 };
 
-template <int MM, int MW, int G, int WNC, int NTW = 1>
+template <int MM, int MW, int G, int WNC, int NTW = 1, int EB = FCN_FWD_EARLY_BN>
 __global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_pair_kernel(CgLayerPair p)
 {
     const int bid = blockIdx.x;
@@ -769,8 +769,8 @@ __global__ __launch_bounds__(G * 64 * MW * WNC) void cgk_fwd_pair_kernel(CgLayer
     if (t < 0) return;
     int bx, by;
     cg_divmod(t, nby, cg_inv(nby), bx, by);
-    if (isA) cgk_fwd_body<MM, MW, G, WNC, NTW>(p.A, bx, by, (int)offsetof(CgLayerPair, A));
-    else cgk_fwd_body<MM, MW, G, WNC, NTW>(p.B, bx, by, (int)offsetof(CgLayerPair, B));
+    if (isA) cgk_fwd_body<MM, MW, G, WNC, NTW, EB>(p.A, bx, by, (int)offsetof(CgLayerPair, A));
+    else cgk_fwd_body<MM, MW, G, WNC, NTW, EB>(p.B, bx, by, (int)offsetof(CgLayerPair, B));
 }
 
 // BN-backward coefficients of one channel from the batch sums (sum dz, sum dz*xhat): gamma*rstd, mean, rstd, dbeta/M,
@@ -2105,6 +2105,11 @@ extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p
         else if (tr) L.stat = ws->stat + O.st[l];
         return 0;
     };
+    // (the early batch sums only in TRAINING launches: an eval forward reads running statistics and would only pay for the bigger
+    // entry batch -- 57.5 -> 56.6 k frustums/s of inference with them, session x)
+#define CN_FWD_LAUNCH(KERNEL, NTW_, GRID, BLOCK, ARG)                                                                 \
+    if (tr) { FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((KERNEL<MM, FCN_FT_MW, FCN_FT_G, FCN_FT_WNC, NTW_, FCN_FWD_EARLY_BN>), GRID, BLOCK, 0, st, ARG)); } \
+    else { FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((KERNEL<MM, FCN_FT_MW, FCN_FT_G, FCN_FT_WNC, NTW_, 0>), GRID, BLOCK, 0, st, ARG)); }
     // 32 x 32 tiles: 560 workgroups of 4 waves (2-3 resident per CU) instead of 280 of 8 (every level of the pyramid has
     // B*L*N/2048 = 280 tiles of 32 x 64 for 256 CUs); measured 369 -> 352 us over the forward
     for (int q = 0; q < norder; ++q) {
@@ -2121,14 +2126,12 @@ extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p
             if (FCN_FT_NTW > 1 && P.N[l] % TCW == 0 && P.N[l2] % TCW == 0) {
                 pp.na = cg_pad8(((R + TR - 1) / TR) * (P.N[l] / TCW));
                 const int nb = cg_pad8(((R2 + TR - 1) / TR) * (P.N[l2] / TCW));
-                FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_pair_kernel<MM, FCN_FT_MW, FCN_FT_G, FCN_FT_WNC, FCN_FT_NTW>), dim3(pp.na + nb),
-                                                      dim3(FCN_FT_THREADS), 0, st, pp));
+                CN_FWD_LAUNCH(cgk_fwd_pair_kernel, FCN_FT_NTW, dim3(pp.na + nb), dim3(FCN_FT_THREADS), pp);
             } else {
                 constexpr int TC = 32 * FCN_FT_WNC;
                 pp.na = cg_pad8(((R + TR - 1) / TR) * (P.N[l] / TC));
                 const int nb = cg_pad8(((R2 + TR - 1) / TR) * (P.N[l2] / TC));
-                FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_pair_kernel<MM, FCN_FT_MW, FCN_FT_G, FCN_FT_WNC, 1>), dim3(pp.na + nb),
-                                                      dim3(FCN_FT_THREADS), 0, st, pp));
+                CN_FWD_LAUNCH(cgk_fwd_pair_kernel, 1, dim3(pp.na + nb), dim3(FCN_FT_THREADS), pp);
             }
             FCN_CHECK_LAUNCH();
             ++q;
@@ -2137,12 +2140,10 @@ extern "C" int fcn_convnet_forward2(const fcn_cn_desc *d, const fcn_cn_params *p
             FCN_TRY(prep(l, L));
             constexpr int TR = 32 * FCN_FT_MW, TCW = 32 * FCN_FT_WNC * FCN_FT_NTW;
             if (FCN_FT_NTW > 1 && P.N[l] % TCW == 0) {
-                FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_kernel<MM, FCN_FT_MW, FCN_FT_G, FCN_FT_WNC, FCN_FT_NTW>),
-                                                      dim3(cg_pad8(((R + TR - 1) / TR) * (P.N[l] / TCW))), dim3(FCN_FT_THREADS), 0, st, L));
+                CN_FWD_LAUNCH(cgk_fwd_kernel, FCN_FT_NTW, dim3(cg_pad8(((R + TR - 1) / TR) * (P.N[l] / TCW))), dim3(FCN_FT_THREADS), L);
             } else {
                 constexpr int TC = 32 * FCN_FT_WNC;
-                FCN_MM_SWITCH(mmf, hipLaunchKernelGGL((cgk_fwd_kernel<MM, FCN_FT_MW, FCN_FT_G, FCN_FT_WNC, 1>),
-                                                      dim3(cg_pad8(((R + TR - 1) / TR) * (P.N[l] / TC))), dim3(FCN_FT_THREADS), 0, st, L));
+                CN_FWD_LAUNCH(cgk_fwd_kernel, 1, dim3(cg_pad8(((R + TR - 1) / TR) * (P.N[l] / TC))), dim3(FCN_FT_THREADS), L);
             }
             FCN_CHECK_LAUNCH();
         }
