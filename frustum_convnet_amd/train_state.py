@@ -73,11 +73,16 @@ class FlatTrainState:
         # ... and the first tensor after the PointNet scales starts on a multiple of the optimiser kernel's workgroup span
         # (STEP_SPAN elements): the [pointnet] bucket's workgroups and the [fcn+heads] bucket's then tile the buffer exactly like
         # the workgroups of ONE launch over the whole buffer, so both forms share their per-workgroup step counters
+        # ... and so does every PointNet scale (feat_net.pointnet<k>.*): adam_step_scale(k) steps ONE scale with the workgroups --
+        # and the step-counter slots -- the whole-buffer launch would use for it (the padding holds zeros and stays zero)
+        scale_of = lambda n: n.split(".")[1] if n.startswith("feat_net.pointnet") else None
         offs, off, cut_at = [], 0, None
         for k, (n, p) in enumerate(named):
             if k > 0 and named[k - 1][0].startswith("feat_net.") and not n.startswith("feat_net."):
                 off = (off + STEP_SPAN - 1) // STEP_SPAN * STEP_SPAN
                 cut_at = off
+            elif k > 0 and scale_of(n) is not None and scale_of(n) != scale_of(named[k - 1][0]):
+                off = (off + STEP_SPAN - 1) // STEP_SPAN * STEP_SPAN
             offs.append(off)
             off += p.numel()
             if not (n in ("cls_out.weight", "cls_out.bias")):
@@ -221,6 +226,17 @@ class FlatTrainState:
                                               self._step_slots.data_ptr() + 8 * slot0,
                                               _native.current_stream(self.device)),
                           "fcn_adam_step_f32")
+
+    def adam_step_scale(self, k):
+        """The optimiser step of PointNet scale k (0-based) alone, on the current stream: the slice feat_net.pointnet<k+1>.* of the
+        [pointnet] bucket.  A step loop that runs it right behind that scale's backward -- on the stream the scale's backward ran on --
+        lets the scale's NEXT forward follow without waiting for the other scales (bench.py's scale chains).  Every scale must then be
+        stepped exactly once per training step and the [pointnet] bucket not at all; world 1 only (the gradients are not reduced)."""
+        if self.comm:
+            raise RuntimeError("FlatTrainState.adam_step_scale: per-scale steps are for a world of one rank (no all-reduce in between)")
+        lo, hi = self.scale_ranges[k]
+        assert lo % STEP_SPAN == 0
+        self._step_range(lo, hi, lo // STEP_SPAN, "scale %d" % k)
 
     def adam_step(self):
         """The optimiser step of every bucket on the current stream: ONE launch over the whole buffer (the buckets exist for
