@@ -483,36 +483,13 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
     late = (os.environ.get("FCN_ADAM_LATE", "1") == "1" and optim and len(state.buckets) == 2 and
             ((world == 1 and not rehearse) or captured_comm))
 
-    # FCN_SCALE_CHAINS=1 (N = 1, captured step): every PointNet scale is stepped by itself right behind ITS backward, on the scale's stream
-    # (FlatTrainState.adam_step_scale from WorkspacePool.after_backward), and inside the graph the scale's next forward -- weight fold,
-    # conv1-3, pooling -- follows on that stream without waiting for the other scales' backward (PointNetFeat._forward_chained): the
-    # narrow scales' forward runs beside the widest scale's backward tail instead of abreast with its forward.  Same launches on the
-    # same data: the parameters after K steps are bit-identical (tests/test_gpu_train_state.py).
-    chains = (os.environ.get("FCN_SCALE_CHAINS", "1") == "1" and world == 1 and not rehearse and optim and not a.eager and prefetch
-              and not state.comm and len(state.scale_ranges) == model.feat_net.num_scales and len(state.buckets) == 2)
-
-    def set_chains(on):
-        model.feat_net.scale_chains = bool(on)
-        for k, net in enumerate(model.feat_net.nets):
-            net._pool.after_backward = (lambda k=k: state.adam_step_scale(k)) if on else None
-
-    set_chains(chains)
-    for pair in [x for x in os.environ.get("FCN_BWD_SHARE", "").split("+") if x]:       # "0:1": scale 0's backward on scale 1's stream
-        sc, host = (int(v) for v in pair.split(":"))
-        model.feat_net.share_backward_stream(sc, host, dev)
-
     def late_bucket0():
         # (on the packing branch's stream) N > 1: the bucket's all-reduce -- started behind the previous step's FCN backward -- first
         state.wait_allreduce(state.buckets[0][0])
         state.adam_step_bucket(0)
 
     def opt_step():
-        if chains:                    # (the scales were stepped inside the backward)
-            if late:
-                model._cn_pool.before_pack = late_bucket0
-            else:
-                state.adam_step_bucket(0)
-        elif late:
+        if late:
             state.adam_step_bucket(1)
             # armed only now, BEHIND a backward: a forward that runs before any gradient exists must not step the bucket (ADVICE r5:
             # armed from the start, the first warm-up forward applied an Adam step of zero gradients -- weight decay, counter + 1 --
@@ -688,8 +665,6 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
             overlap = False
             captured_comm = False
             late = False
-            chains = False
-            set_chains(False)
             model._cn_pool.before_pack = None
             state._pending = {}
             steps_per_graph = 1
@@ -780,7 +755,6 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
         state.adam_step_bucket(0)
         torch.cuda.synchronize()
     model._cn_pool.before_pack = None
-    set_chains(False)                                 # (the roofline / configs helpers drive the plain model)
     Ls = [data["center_ref%d" % i].shape[2] for i in range(1, 6) if ("center_ref%d" % i) in data]
     comm = None
     if world > 1 or one_rank_comm:
@@ -815,7 +789,7 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
     return {"captured_comm": captured_comm, "rehearse": rehearse, "model": model, "state": state, "data": data, "graphs": graphs, "overlap": overlap, "optim": optim, "comm": comm,
             "rounds": rounds, "nstep": nstep, "wall": wall, "ms_per_step": wall * 1e3 / nstep,
             "gpu_event_ms_per_step": e0.elapsed_time(e1) / nstep, "final_loss": float(loss.item()),
-            "steps_per_graph": steps_per_graph, "prefetch": prefetch, "late_adam": bool(late), "scale_chains": bool(chains and graphs is not None),
+            "steps_per_graph": steps_per_graph, "prefetch": prefetch, "late_adam": bool(late),
             "batch": batch, "npoint": npoint, "Ls": Ls}
 
 
@@ -1140,9 +1114,7 @@ def main():
             ", %d steps per replay" % m["steps_per_graph"] if m["steps_per_graph"] > 1 else "") + (
             ", the gradient all-reduces captured inside it (Adam of each bucket at the head of the next step)" if captured_comm else "")
     launch_note += (", next batch's grouping front prefetched beside the backward (double-buffered workspaces)" if m["prefetch"] else "") + (
-        ", the [ConvFeatNet + heads] bucket's Adam step on the next forward's weight-packing branch" if m.get("late_adam") else "") + (
-        ", every PointNet scale's Adam step behind its own backward and its next forward chained behind that on the scale's stream"
-        if m.get("scale_chains") else "")
+        ", the [ConvFeatNet + heads] bucket's Adam step on the next forward's weight-packing branch" if m.get("late_adam") else "")
     out = {
         "metric": "frustums/sec (train fwd+bwd) %s B=%d N=%d" % (
             {"car": "KITTI-car", "people": "KITTI-people", "refine": "KITTI-refine", "sunrgbd": "SUN-RGBD"}[a.cfg], a.batch, npoint),

@@ -157,9 +157,6 @@ class PointNetFeat(nn.Module):
         # front of the FCN, the FCN backward continuing on a second stream, other capture orders -- measured slower on ROCm 7.2 /
         # MI355X in rounds 3-5 (EXPERIMENTS.md) and are not options of this layer any more.
         self.set_wgrad_streams((self.num_scales - 1,))
-        # scale chains (a step loop's option, bench.py): inside ONE hipGraph capture a scale's forward follows its own previous
-        # backward + optimiser step (WorkspacePool.after_backward) on the scale's stream, without waiting for the other scales
-        self.scale_chains = False
 
     def set_wgrad_streams(self, scales, three=False):
         """Which scales (0-based) run their weight-gradient GEMMs on a second stream (fcn_pn_backward2; `three`: conv2's on a third,
@@ -167,14 +164,6 @@ class PointNetFeat(nn.Module):
         for k, net in enumerate(self.nets):
             net._pool.side_wgrad = k in tuple(scales)
             net._pool.side_three = bool(three) and k in tuple(scales)
-
-    def share_backward_stream(self, scale, host, device):
-        """The backward of `scale` (0-based, not the widest) is enqueued on the stream of scale `host` (not the widest either), behind
-        that scale's chain, instead of on its own: one parallel branch less in a captured step's backward (the graph executor of ROCm
-        7.2 deals its branches onto four internal streams).  host = None restores the scale's own stream.  Bit-identical gradients."""
-        ns = self.num_scales
-        assert 0 <= scale < ns - 1 and (host is None or (0 <= host < ns - 1 and host != scale))
-        self.nets[scale]._pool.bwd_stream = None if host is None else self._streams(torch.device(device))[host]
 
     @property
     def nets(self):
@@ -220,7 +209,7 @@ class PointNetFeat(nn.Module):
             t.record_stream(side)
         # cap: the hipGraph capture these launches belong to (0: none -- they really ran)
         self._prefetched = {"key": self._front_key(point_cloud, sample_pc, one_hot_vec, nlc, self.training), "handles": prepared,
-                            "event": ev_out, "chain_event": ev_out, "dev": dev, "cap": _native.capture_id(dev)}
+                            "event": ev_out, "dev": dev, "cap": _native.capture_id(dev)}
         return True
 
     def _prefetch_is_foreign(self):
@@ -238,7 +227,7 @@ class PointNetFeat(nn.Module):
         pf = self._prefetched
         if pf is not None:
             pf["cap"] = _native.capture_id(pf["dev"])
-            pf["event"] = pf["chain_event"] = None
+            pf["event"] = None
 
     def join_prefetch(self):
         """The current stream waits for the prefetch branch (no-op without one, or when the branch belongs to another capture)."""
@@ -293,11 +282,7 @@ class PointNetFeat(nn.Module):
                 # the batch-only part ran ahead (prefetch): only the weight-dependent launch is left on the chain
                 self.join_prefetch()
                 prepared = self._prefetched["handles"]
-                chain_event = self._prefetched.get("chain_event")
                 self._prefetched = None
-                cap = _native.capture_id(dev)
-                if self.scale_chains and self.training and cap != 0:
-                    return self._forward_chained(prepared, point_cloud, cur, cap, chain_event)
                 group_compact(prepared, point_cloud, phase=2)
             else:
                 prepared = [nets[s].prepare_pooled(point_cloud, sample_pc[s], one_hot_vec, nlc) for s in range(ns)]
@@ -321,40 +306,6 @@ class PointNetFeat(nn.Module):
                 done[s].record(sts[s])
         # (the join is always made: consuming the maps one by one without it -- the FCN's first layers beside the widest scale --
         # measured slower; fcn_convnet_forward2 still accepts per-map events)
-        for s in range(ns):
-            cur.wait_event(done[s])
-            outs[s].record_stream(cur)
-        return tuple(outs)
-
-    def _forward_chained(self, prepared, point_cloud, cur, cap, chain_event):
-        """The scales of a prefetched front as CHAINS inside a hipGraph capture: each scale's weight fold (phase 2 of the front, its own
-        launch) and forward run on the scale's stream, and a side stream that already belongs to this capture -- it carried the scale's
-        previous backward and optimiser step (WorkspacePool.after_backward) -- is NOT made to wait for the caller's stream, i.e. for the
-        other scales' backward: it waits for the prefetch branch that prepared this batch and for nothing else.  The first step of a
-        capture forks the streams as the plain form does.  Same launches on the same data as the plain form: bit-identical steps."""
-        from .pointnet_fused import group_compact, launch_prepared
-        nets, ns = self.nets, self.num_scales
-        dev = point_cloud.device
-        streams = self._streams(dev)
-        fork = self._fork_event(dev)
-        fork.record(cur)
-        sts = [streams[i] for i in range(ns - 1)] + [cur]
-        handles = [None] * ns
-        for s in (ns - 1,) + tuple(range(ns - 2, 1, -1)) + (0, 1):           # heaviest first, as forward()
-            with torch.cuda.stream(sts[s]):
-                if sts[s] is not cur:
-                    if _native.capture_id(dev) != cap or chain_event is None:
-                        sts[s].wait_event(fork)                  # not part of this capture yet (its first step): an ordinary fork
-                    else:
-                        sts[s].wait_event(chain_event)           # the batch-only front of this batch (the prefetch branch)
-                group_compact([prepared[s]], point_cloud, phase=2)
-                handles[s] = launch_prepared(prepared[s])
-        outs = [None] * ns
-        done = self._done_events(dev)
-        for s in range(ns):
-            with torch.cuda.stream(sts[s]):
-                outs[s] = nets[s].attach_pooled(handles[s])
-                done[s].record(sts[s])
         for s in range(ns):
             cur.wait_event(done[s])
             outs[s].record_stream(cur)

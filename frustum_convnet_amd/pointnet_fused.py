@@ -124,12 +124,6 @@ class WorkspacePool:
             self.side[key] = (st, evs, arr, st3)
         return self.side[key]
 
-    def bwd_events(self, device):
-        key = "bwdev" + str(device)
-        if key not in self.side:
-            self.side[key] = (torch.cuda.Event(enable_timing=False), torch.cuda.Event(enable_timing=False))
-        return self.side[key]
-
     def acquire(self, *key, device, need_grad):
         k = tuple(key) + (bool(need_grad), str(device))
         lst = self.free.setdefault(k, [])
@@ -280,21 +274,7 @@ class _PointNetPooled(torch.autograd.Function):
             three = bool(getattr(ctx.pool, "side_three", False)) and hasattr(L, "fcn_pn_backward3")
         else:
             s2, evarr = None, None
-        # bwd_stream: this scale's backward is enqueued on ANOTHER scale's stream, behind that scale's chain (PointNetFeat.
-        # share_backward_stream: one branch less in the captured step's backward)
-        alt = getattr(ctx.pool, "bwd_stream", None)
-        home = torch.cuda.current_stream(dev)
-        if alt is not None and alt != home:
-            ev_in, ev_out = ctx.pool.bwd_events(dev)
-            capturing = torch.cuda.is_current_stream_capturing()
-            if not capturing:          # (ROCm 7.2 stream capture crashes when a forked stream waits for another forked stream)
-                ev_in.record(home)
-                alt.wait_event(ev_in)
-            dfeat.record_stream(alt)
-        else:
-            alt = None
-        run_on = alt if alt is not None else home
-        with torch.cuda.device(dev), torch.cuda.stream(run_on):
+        with torch.cuda.device(dev):
             if three:
                 _native.check(L.fcn_pn_backward3(ctypes.byref(desc), ctypes.byref(params), dfeat.data_ptr(),
                                                  ctypes.byref(ws.c), arr(dW), arr(dg), arr(db),
@@ -305,18 +285,9 @@ class _PointNetPooled(torch.autograd.Function):
                                                  ctypes.byref(ws.c), arr(dW), arr(dg), arr(db),
                                                  _native.current_stream(dev), s2, evarr),
                               "fcn_pn_backward2")
-            if alt is not None and not capturing:
-                ev_out.record(alt)
-        if alt is not None and not capturing:
-            home.wait_event(ev_out)
         ctx.pool.release(ws)
         ctx.ws = None
         ctx.live = False
-        # a step loop may continue THIS scale's chain right here, on the stream its backward ran on (bench.py's scale chains: the
-        # scale's optimiser step, so that its next forward need not wait for the other scales' backward)
-        cb = getattr(ctx.pool, "after_backward", None)
-        if cb is not None:
-            cb()
         s1, s2, s3 = ctx.shapes
         outs = [dW[0].view(s1), dg[0], db[0], dW[1].view(s2), dg[1], db[1], dW[2].view(s3), dg[2], db[2]]
         outs = [None if gd[j] is not None else t for j, t in enumerate(outs)]

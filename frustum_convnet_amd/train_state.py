@@ -230,8 +230,9 @@ class FlatTrainState:
     def adam_step_scale(self, k):
         """The optimiser step of PointNet scale k (0-based) alone, on the current stream: the slice feat_net.pointnet<k+1>.* of the
         [pointnet] bucket.  A step loop that runs it right behind that scale's backward -- on the stream the scale's backward ran on --
-        lets the scale's NEXT forward follow without waiting for the other scales (bench.py's scale chains).  Every scale must then be
-        stepped exactly once per training step and the [pointnet] bucket not at all; world 1 only (the gradients are not reduced)."""
+        lets the scale's NEXT forward follow without waiting for the other scales (round 6 built that step: bit-identical, 2.5 % slower
+        on MI355X, EXPERIMENTS 6.8 -- not in bench.py).  Every scale must then be stepped exactly once per training step and the
+        [pointnet] bucket not at all; world 1 only (the gradients are not reduced)."""
         if self.comm:
             raise RuntimeError("FlatTrainState.adam_step_scale: per-scale steps are for a world of one rank (no all-reduce in between)")
         lo, hi = self.scale_ranges[k]
