@@ -40,17 +40,26 @@ struct LossArgs {
     float *total;              // optional copy of out[0] in its own buffer (the differentiable scalar of the binding)
 };
 
-template <int NT>
-__device__ __forceinline__ float block_sum(float v, float *sh)
+// N sums at once through ONE barrier pair: v[i] <- the sum over the workgroup, as block_sum computes it (wave sum, then the waves
+// in order).  sh: NT / 64 * N floats.
+template <int NT, int N>
+__device__ __forceinline__ void block_sums(float (&v)[N], float *sh)
 {
-    v = wave_sum_f32(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = wave_sum_f32(v[i]);
     __syncthreads();
-    if (lane == 0) sh[wave] = v;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) sh[wave * N + i] = v[i];
+    }
     __syncthreads();
-    float t = 0.f;
-    for (int w = 0; w < NT / 64; ++w) t += sh[w];
-    return t;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float t = 0.f;
+        for (int w = 0; w < NT / 64; ++w) t += sh[w * N + i];
+        v[i] = t;
+    }
 }
 
 __device__ __forceinline__ float pymod(float a, float b) { return a - b * floorf(a / b); }
@@ -75,7 +84,7 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
 {
     constexpr int NB = LT_NB, NC = 3 + 2 * NB + 4 * NS;
     constexpr int SW = (NC + 2) | 1;       // LDS row stride: the row's 2 + NC logits, odd
-    __shared__ float sh[LT_THREADS / 64];
+    __shared__ float shN[LT_THREADS / 64 * 11];
     __shared__ int last_s;
     // row-major variant: the workgroup's LT_THREADS gradient rows are staged here (odd stride: a thread writes its own
     // row without bank conflicts) and go out as coalesced 256-byte rows instead of 64 strided dwords per thread
@@ -124,11 +133,19 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
         typedef long long lt_v2l __attribute__((ext_vector_type(2)));
         typedef const lt_v2l __attribute__((address_space(1))) *lt_gv2lp;
         const int R2 = R >> 1;
-#pragma unroll 8
-        for (int r = tid; r < R2; r += LT_THREADS) {
-            const lt_v2l lab = *(lt_gv2lp)(a.cls_label + 2 * r);
-            cfg_ += ((lab[0] == 1) ? 1.f : 0.f) + ((lab[1] == 1) ? 1.f : 0.f);
-            ckeep += ((lab[0] != -1) ? 1.f : 0.f) + ((lab[1] != -1) ? 1.f : 0.f);
+        // LT_CNT loads per thread requested at once (clamped index, masked sum): B*L2 = 4 480 labels are ONE batch of 128 threads
+        // x 18 (three batches of 8 before: three dependent round trips on the critical path of every workgroup)
+        constexpr int LT_CNT = 18;
+        for (int base = 0; base < R2; base += LT_CNT * LT_THREADS) {
+            lt_v2l lab[LT_CNT];
+#pragma unroll
+            for (int k = 0; k < LT_CNT; ++k) lab[k] = *(lt_gv2lp)(a.cls_label + 2 * min(base + tid + k * LT_THREADS, R2 - 1));
+#pragma unroll
+            for (int k = 0; k < LT_CNT; ++k) {
+                const bool in = base + tid + k * LT_THREADS < R2;
+                cfg_ += in ? ((lab[k][0] == 1) ? 1.f : 0.f) + ((lab[k][1] == 1) ? 1.f : 0.f) : 0.f;
+                ckeep += in ? ((lab[k][0] != -1) ? 1.f : 0.f) + ((lab[k][1] != -1) ? 1.f : 0.f) : 0.f;
+            }
         }
         if ((R & 1) && tid == 0) {
             const int64_t lab = a.cls_label[R - 1];
@@ -136,8 +153,9 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
             ckeep += (lab != -1) ? 1.f : 0.f;
         }
     }
-    const float nfg = block_sum<LT_THREADS>(cfg_, sh);
-    const float nkeep = block_sum<LT_THREADS>(ckeep, sh);
+    float cnt2[2] = {cfg_, ckeep};
+    block_sums<LT_THREADS, 2>(cnt2, shN);          // (sums of 0 / 1: exact in any order)
+    const float nfg = cnt2[0], nkeep = cnt2[1];
     const float inv_cls = 1.f / (nfg + 1e-14f);
     // a batch without a foreground row (the reference asserts on it, det_base.py:416): the foreground means report 0
     // instead of 0 * inf = NaN, and out[11] = nfg lets the caller see it without a host sync on the hot path
@@ -342,9 +360,11 @@ __global__ __launch_bounds__(LT_THREADS) void loss_tail_kernel(LossArgs a)
     }
     // ---- combine the workgroups: out[1..10] accumulate, out[15] (as int) is the arrival ticket; both were zeroed by the
     // hipMemsetAsync in front of the launch.  Accumulators are written and read with device-scope atomics only.
+    // (one barrier pair for the ten sums, each still wave sum first, then the waves in order: the values of ten block_sum calls)
     float tot[11];
 #pragma unroll
-    for (int i = 1; i < 11; ++i) tot[i] = block_sum<LT_THREADS>(acc[i], sh);
+    for (int i = 0; i < 11; ++i) tot[i] = acc[i];
+    block_sums<LT_THREADS, 11>(tot, shN);
     if (tid == 0) {
         int ticket;
         if (a.scratch) {
