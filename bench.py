@@ -483,8 +483,6 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
     late = (os.environ.get("FCN_ADAM_LATE", "1") == "1" and optim and len(state.buckets) == 2 and
             ((world == 1 and not rehearse) or captured_comm))
 
-    model._cn_pool.wgrad_side = int(os.environ.get("FCN_CN_WGRAD_SIDE", "0"))
-
     def late_bucket0():
         # (on the packing branch's stream) N > 1: the bucket's all-reduce -- started behind the previous step's FCN backward -- first
         state.wait_allreduce(state.buckets[0][0])

@@ -75,7 +75,7 @@ EXPORTS = ("fcn_arch", "fcn_build_hash", "fcn_stat_replicas", "fcn_query_depth_p
            "fcn_pn_pack_weights", "fcn_pn_pack_weights_all", "fcn_pn_forward", "fcn_pn_backward", "fcn_pn_backward2", "fcn_pn_backward3", "fcn_pn_backward_dense", "fcn_pn_conv_fwd", "fcn_det_loss_tail", "fcn_det_loss_tail_rows", "fcn_det_loss_tail_rows2", "fcn_det_iou_metrics",
            "fcn_det_loss_tail_scratch_floats", "fcn_adam_step_f32", "fcn_sgd_step_f32", "fcn_adam_step_slots", "fcn_prepare_inputs", "fcn_prepare_inputs_refine", "fcn_prepare_inputs_sunrgbd", "fcn_stamp", "fcn_stream_capture_id",
            "fcn_convnet_sizes", "fcn_convnet_logits_ld", "fcn_convnet_pack", "fcn_convnet_forward", "fcn_convnet_forward2",
-           "fcn_convnet_backward", "fcn_convnet_backward_side", "fcn_box3d_iou_pair_f32", "fcn_decode_detections", "fcn_rotate_nms_3d")
+           "fcn_convnet_backward", "fcn_box3d_iou_pair_f32", "fcn_decode_detections", "fcn_rotate_nms_3d")
 
 _lib = None
 
@@ -191,9 +191,6 @@ def lib():
     L.fcn_convnet_backward.argtypes = [ctypes.POINTER(CnDesc), ctypes.POINTER(CnParams), ctypes.POINTER(CnWs),
                                        c_fp * CN_MAXLEV, c_fp, c_fp, c_fp * CN_MAXLEV, c_fp * CN_MAXLAYER, c_fp * CN_MAXLAYER,
                                        c_fp * CN_MAXLAYER, c_fp, c_fp, c_fp, ctypes.POINTER(c_fp)]
-    if hasattr(L, "fcn_convnet_backward_side"):                   # (A/B builds of older kernel sources lack it)
-        L.fcn_convnet_backward_side.restype = ctypes.c_int
-        L.fcn_convnet_backward_side.argtypes = list(L.fcn_convnet_backward.argtypes) + [ctypes.c_int]
     L.fcn_box3d_iou_pair_f32.restype = ctypes.c_int
     L.fcn_box3d_iou_pair_f32.argtypes = [c_fp, c_fp, ctypes.c_int, c_fp, c_fp]
     L.fcn_decode_detections.restype = ctypes.c_int

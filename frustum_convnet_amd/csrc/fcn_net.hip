@@ -1058,7 +1058,6 @@ struct CgBwdStep {
     float *partial;            // wgrad partials of this layer
     int rows, w_ns, w_ny;      // rows per split (multiple of KC), splits, 64-row tiles of Wp
     int w_blk0, r_blk0;
-    int bid0;                  // added to the workgroup index: a launch that holds only the roles from w_blk0 on (fcn_convnet_backward_side)
     CgReduce red;
 };
 
@@ -1731,9 +1730,8 @@ __device__ __forceinline__ void cg_reduce_body(const QT &q, int rid, float *smem
 }
 
 template <int MM, int G>
-__device__ __forceinline__ void cg_bwd_step_body(const CgBwdStep &a, const int bid_in, float *smem, const int koff)
+__device__ __forceinline__ void cg_bwd_step_body(const CgBwdStep &a, const int bid, float *smem, const int koff)
 {
-    const int bid = bid_in + opaque_s(a.bid0);
     // The role of this workgroup from ONE batch of scalar loads of the by-value parameter; everything else is read through the kernarg
     // POINTER inside the role that needs it (cg_kernarg_layer explains: fields read through the by-value parameter are all fetched in
     // the entry block -- here the union of what three roles read, a dozen serialized s_load / s_waitcnt / v_writelane batches in front
@@ -2173,42 +2171,11 @@ static int64_t cn_partial_elems(const fcn_cn_desc *d, const CnPlan &P)
     return pmax;
 }
 
-static int cn_backward_impl(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
-                            const float *const feats[FCN_CN_MAXLEV], const float *one_hot, const float *dlogits,
-                            float *const dfeats[FCN_CN_MAXLEV], float *const dW[CN_NLAYER],
-                            float *const dgamma[CN_NLAYER], float *const dbeta[CN_NLAYER], float *dbias,
-                            void *stream, void *stream2, void *const *events, int side_mode);
-
 extern "C" int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
                                     const float *const feats[FCN_CN_MAXLEV], const float *one_hot, const float *dlogits,
                                     float *const dfeats[FCN_CN_MAXLEV], float *const dW[CN_NLAYER],
                                     float *const dgamma[CN_NLAYER], float *const dbeta[CN_NLAYER], float *dbias,
                                     void *stream, void *stream2, void *const *events)
-{
-    return cn_backward_impl(d, p, ws, feats, one_hot, dlogits, dfeats, dW, dgamma, dbeta, dbias, stream, stream2, events, 0);
-}
-
-// The same backward with the weight-gradient and reduce roles of every launch as launches of their own on stream2: the chain on `stream`
-// carries the data-gradient tiles only (a launch ends when ITS tiles end, not when the weight-gradient splits riding with them do), the
-// weight gradients follow on stream2, each launch behind the chain launch that completed its inputs.  events2: two caller-owned
-// hipEvent_t.  join != 0: `stream` waits for stream2 before the call returns work (everything final on `stream`, as
-// fcn_convnet_backward); join == 0: dfeats are final on `stream`, dW / dbias are final at events2[1] (recorded on stream2) -- the caller
-// makes their first reader wait for it.  Same kernels, same partials, same fixed-order sums: bit-identical gradients.
-extern "C" int fcn_convnet_backward_side(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
-                                         const float *const feats[FCN_CN_MAXLEV], const float *one_hot, const float *dlogits,
-                                         float *const dfeats[FCN_CN_MAXLEV], float *const dW[CN_NLAYER],
-                                         float *const dgamma[CN_NLAYER], float *const dbeta[CN_NLAYER], float *dbias,
-                                         void *stream, void *stream2, void *const *events2, int join)
-{
-    if (!stream2 || !events2 || !events2[0] || !events2[1] || stream2 == stream) return FCN_E_BADARG;
-    return cn_backward_impl(d, p, ws, feats, one_hot, dlogits, dfeats, dW, dgamma, dbeta, dbias, stream, stream2, events2, join ? 1 : 2);
-}
-
-static int cn_backward_impl(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
-                            const float *const feats[FCN_CN_MAXLEV], const float *one_hot, const float *dlogits,
-                            float *const dfeats[FCN_CN_MAXLEV], float *const dW[CN_NLAYER],
-                            float *const dgamma[CN_NLAYER], float *const dbeta[CN_NLAYER], float *dbias,
-                            void *stream, void *stream2, void *const *events, int side_mode)
 {
     if (!d || !p || !ws || !feats || !dlogits || !dfeats || !dW || !dgamma || !dbeta || !dbias) return FCN_E_BADARG;
     if (!d->training) return FCN_E_BADARG;
@@ -2218,8 +2185,7 @@ static int cn_backward_impl(const fcn_cn_desc *d, const fcn_cn_params *p, const 
     // on stream2 so that `stream` is free again: the caller's widest PointNet backward -- the long pole -- starts beside
     // the rest of the FCN backward instead of after it.  events[0]: fork; events[k]: dfeats[nlev-1-k] final (after
     // block{nlev-k}_merge), k = 1..nlev-2; events[nlev-1]: everything final (dfeats[0], all dW).
-    const bool cont = side_mode == 0 && stream2 != nullptr && events != nullptr;
-    const bool side = side_mode != 0;
+    const bool cont = stream2 != nullptr && events != nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (d->precision < 0 || d->precision > FCN_PREC_BF16_OPS) return FCN_E_BADARG;
     const int mmb = CN_MM_OF(d->precision, false);
@@ -2245,7 +2211,7 @@ static int cn_backward_impl(const fcn_cn_desc *d, const fcn_cn_params *p, const 
     const int BG = cn_bwd_groups(d);           // waves per backward workgroup (4 or 8): one choice for the whole chain
     // data-gradient + weight-gradient roles of layer l (l < 0: none); returns the workgroups in front of the reduce role
     auto make_step = [&](int l, float *pbuf, CgBwdStep &a, CgReduce &own, int &own_blocks) -> int {
-        a.ndg = 0; a.w_ns = 0; a.w_ny = 1; a.rows = 2 * KC; a.partial = nullptr; a.dz = nullptr; a.dz16 = 0; a.bid0 = 0;
+        a.ndg = 0; a.w_ns = 0; a.w_ny = 1; a.rows = 2 * KC; a.partial = nullptr; a.dz = nullptr; a.dz16 = 0;
         a.cb.bstat = nullptr; a.cb.rep_stride = O.st[P.nl]; a.cb.gamma = nullptr; a.cb.bn = nullptr; a.cb.M = 1.0; a.cb.dgamma = nullptr; a.cb.dbeta = nullptr;
         CgDgSeg *dgs[CG_NSEG] = {&a.dg[0], &a.dg[1], &a.dg[2], &a.dg[3]};
         for (int s = 0; s < CG_NSEG; ++s) {
@@ -2355,46 +2321,7 @@ static int cn_backward_impl(const fcn_cn_desc *d, const fcn_cn_params *p, const 
             if (pendB_blocks > 0) { pp.B.red = pendB; nB += pendB_blocks; } else blank_reduce(pp.B.red);
         }
         pp.na = nA;
-        if (!needB) { pp.B.bid0 = 0; pp.B.w_blk0 = pp.B.r_blk0 = 0; }
-        if (side) {
-            // the roles from w_blk0 on (weight-gradient splits of this layer, reduce of the previous one) as a launch on stream2, behind
-            // the chain launch that completed their inputs (k = 0: behind whatever `stream` held at entry); the chain launch itself
-            // holds the data-gradient tiles only.  ONE event is enough: every wait is enqueued before the event is recorded again.
-            auto launch_roles = [&](const CgBwdPair &q, int gA, int gB, hipStream_t s_) -> int {
-                if (gA + gB <= 0) return 0;
-                if (BG == 4) {
-                    if (gB > 0) { FCN_MM_SWITCH(mmb, hipLaunchKernelGGL((cg_bwd_pair_kernel<MM, 4>), dim3(gA + gB), dim3(256), 0, s_, q)); }
-                    else { FCN_MM_SWITCH(mmb, hipLaunchKernelGGL((cg_bwd_step_kernel<MM, 4>), dim3(gA), dim3(256), 0, s_, q.A)); }
-                } else {
-                    if (gB > 0) { FCN_MM_SWITCH(mmb, hipLaunchKernelGGL((cg_bwd_pair_kernel<MM, 8>), dim3(gA + gB), dim3(512), 0, s_, q)); }
-                    else { FCN_MM_SWITCH(mmb, hipLaunchKernelGGL((cg_bwd_step_kernel<MM, 8>), dim3(gA), dim3(512), 0, s_, q.A)); }
-                }
-                FCN_CHECK_LAUNCH();
-                return 0;
-            };
-            if (k == 0) {
-                e = hipEventRecord((hipEvent_t)events[0], st);
-                if (e != hipSuccess) return (int)e;
-            }
-            CgBwdPair ps = pp;
-            ps.A.bid0 = pp.A.w_blk0;
-            ps.B.bid0 = needB ? pp.B.w_blk0 : 0;
-            const int sA = nA - pp.A.w_blk0, sB = needB ? nB - pp.B.w_blk0 : 0;
-            ps.na = sA;
-            if (sA + sB > 0) {
-                e = hipStreamWaitEvent((hipStream_t)stream2, (hipEvent_t)events[0], 0);
-                if (e != hipSuccess) return (int)e;
-                FCN_TRY(launch_roles(ps, sA, sB, (hipStream_t)stream2));
-            }
-            CgBwdPair pm = pp;
-            const int mA = pp.A.w_blk0, mB = needB ? pp.B.w_blk0 : 0;
-            pm.na = mA;
-            FCN_TRY(launch_roles(pm, mA, mB, st));
-            if (mA + mB > 0 && k + 1 < nchain) {
-                e = hipEventRecord((hipEvent_t)events[0], st);
-                if (e != hipSuccess) return (int)e;
-            }
-        } else if (nA + nB > 0) {
+        if (nA + nB > 0) {
             if (BG == 4) {
                 if (nB > 0) { FCN_MM_SWITCH(mmb, hipLaunchKernelGGL((cg_bwd_pair_kernel<MM, 4>), dim3(nA + nB), dim3(256), 0, st, pp)); }
                 else { FCN_MM_SWITCH(mmb, hipLaunchKernelGGL((cg_bwd_step_kernel<MM, 4>), dim3(nA), dim3(256), 0, st, pp.A)); }
@@ -2420,14 +2347,6 @@ static int cn_backward_impl(const fcn_cn_desc *d, const fcn_cn_params *p, const 
                 if (e != hipSuccess) return (int)e;
                 st = (hipStream_t)stream2;
             }
-        }
-    }
-    if (side) {
-        e = hipEventRecord((hipEvent_t)events[1], (hipStream_t)stream2);
-        if (e != hipSuccess) return (int)e;
-        if (side_mode == 1) {
-            e = hipStreamWaitEvent(st, (hipEvent_t)events[1], 0);
-            if (e != hipSuccess) return (int)e;
         }
     }
     return 0;

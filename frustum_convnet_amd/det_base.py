@@ -549,10 +549,6 @@ class PointNetDet(nn.Module):
     def _join_side(self):
         self._iou_metrics.join()
         self.feat_net.join_prefetch()
-        pend = getattr(self._cn_pool, "wgrad_pending", None)      # (ConvFeatNet weight gradients still in flight on their side stream)
-        if pend is not None:
-            torch.cuda.current_stream().wait_event(pend)
-            self._cn_pool.wgrad_pending = None
 
     def backward(self, loss):
         """loss.backward() seeded with a cached unit gradient (loss_fused.unit_grad): two tiny kernels (ones fill, multiply by

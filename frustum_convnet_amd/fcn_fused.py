@@ -66,26 +66,6 @@ class CnPool:
             self._flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
         return self._flags[key]
 
-    def wgrad_stream(self, device):
-        """Second stream + 2 events (caller-owned, handed to fcn_convnet_backward_side) per device."""
-        key = "wg" + str(device)
-        if key not in self.side:
-            with torch.cuda.device(device):
-                st = torch.cuda.Stream(device=device)
-                evs = [torch.cuda.Event(enable_timing=False) for _ in range(2)]
-                for ev in evs:
-                    ev.record()                     # materialise the hipEvent_t handles
-                arr = (ctypes.c_void_p * 2)(*[ev.cuda_event for ev in evs])
-            self.side[key] = (st, evs, arr)
-        return self.side[key]
-
-    def join_wgrad(self, device):
-        """The current stream waits for the weight gradients of a backward that ran with wgrad_side = 2 (no-op otherwise)."""
-        ev = getattr(self, "wgrad_pending", None)
-        if ev is not None:
-            torch.cuda.current_stream(device).wait_event(ev)
-            self.wgrad_pending = None
-
     def pack_stream(self, device):
         """Side stream + event for the early weight packing (one per device)."""
         key = str(device)
@@ -214,31 +194,12 @@ class _ConvNetFused(torch.autograd.Function):
         dfp = _arr(dfeats, CN_MAXLEV)
         # (the C-ABI can continue the chain on a second stream once the widest map's gradient is final -- stream2 / events of
         # fcn_convnet_backward; measured slower over the step on MI355X in two rounds, EXPERIMENTS.md, so this layer passes none)
-        side = getattr(ctx.pool, "wgrad_side", 0)         # 0: one stream; 1 / 2: fcn_convnet_backward_side, joined inside / by the caller
         with torch.cuda.device(dev):
-            if side:
-                # the weight-gradient + reduce roles as launches of their own on the pool's second stream, the chain carries the
-                # data-gradient tiles only
-                st2, evs, evarr = ctx.pool.wgrad_stream(dev)
-                cur = torch.cuda.current_stream(dev)
-                for t in dW + [dbh]:
-                    t.record_stream(st2)
-                _native.check(L.fcn_convnet_backward_side(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(ws.c), fp,
-                                                          None if oh is None else oh.data_ptr(), dlogits.data_ptr(), dfp,
-                                                          _arr(dW), _arr(dg), _arr(db), dbh.data_ptr(),
-                                                          _native.current_stream(dev), ctypes.c_void_p(st2.cuda_stream), evarr,
-                                                          1 if side == 1 else 0),
-                              "fcn_convnet_backward_side")
-                if side != 1:
-                    ctx.pool.wgrad_pending = evs[1]      # dW / dbias final there: join_wgrad() before their first reader
-                    if not heads_direct or any(g is None for g in gd[:3 * nb]):
-                        ctx.pool.join_wgrad(dev)         # (gradients handed back to autograd are consumed on this stream at once)
-            else:
-                _native.check(L.fcn_convnet_backward(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(ws.c), fp,
-                                                     None if oh is None else oh.data_ptr(), dlogits.data_ptr(), dfp,
-                                                     _arr(dW), _arr(dg), _arr(db), dbh.data_ptr(),
-                                                     _native.current_stream(dev), None, None),
-                              "fcn_convnet_backward")
+            _native.check(L.fcn_convnet_backward(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(ws.c), fp,
+                                                 None if oh is None else oh.data_ptr(), dlogits.data_ptr(), dfp,
+                                                 _arr(dW), _arr(dg), _arr(db), dbh.data_ptr(),
+                                                 _native.current_stream(dev), None, None),
+                          "fcn_convnet_backward")
         ctx.pool.release(ws)
         ctx.ws, ctx.live = None, False
         ncls = 2

@@ -323,18 +323,6 @@ int fcn_convnet_backward(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn
                          float *const dfeats[FCN_CN_MAXLEV], float *const dW[FCN_CN_MAXLAYER],
                          float *const dgamma[FCN_CN_MAXLAYER], float *const dbeta[FCN_CN_MAXLAYER], float *dbias,
                          void *stream, void *stream2, void *const *events);
-/* The same backward with the weight-gradient and reduce roles of every launch as launches of their OWN on stream2: the chain on
- * `stream` carries the data-gradient tiles only (a chain launch ends when its tiles end, not when the weight-gradient splits that
- * used to ride with them do), the weight gradients follow on stream2, each behind the chain launch that completed its inputs.
- * events2: two caller-owned hipEvent_t.  join != 0: `stream` waits for stream2 before returning work (everything final on `stream`);
- * join == 0: dfeats, dgamma, dbeta are final on `stream`, dW and dbias at events2[1] (recorded on stream2) -- their first reader must
- * wait for it.  Same kernels, partials and fixed-order sums as fcn_convnet_backward: bit-identical gradients.  (autograd of
- * models/det_base.py:196-224,367-368) */
-int fcn_convnet_backward_side(const fcn_cn_desc *d, const fcn_cn_params *p, const fcn_cn_ws *ws,
-                              const float *const feats[FCN_CN_MAXLEV], const float *one_hot, const float *dlogits,
-                              float *const dfeats[FCN_CN_MAXLEV], float *const dW[FCN_CN_MAXLAYER],
-                              float *const dgamma[FCN_CN_MAXLAYER], float *const dbeta[FCN_CN_MAXLAYER], float *dbias,
-                              void *stream, void *stream2, void *const *events2, int join);
 /* One launch per chain layer (the off-chain deconvolution steps ride along): its data-gradient tiles, its weight-gradient
  * row splits and the reduce of the previous layer's splits are workgroup roles of the same kernel.  stream2 / events: NULL,
  * or a second stream + nlev caller-owned events -- after the launch that completes dfeats[nlev-1] the chain continues on

@@ -390,36 +390,3 @@ def test_scales_stepped_one_by_one_equal_the_bucket_step():
     torch.cuda.synchronize()
     assert int(states[1]._step_slots.min()) == int(states[1]._step_slots.max()) == 3
     assert torch.equal(states[0].flat, states[1].flat) and torch.equal(states[0].exp_avg_sq, states[1].exp_avg_sq)
-
-
-def test_convnet_weight_gradients_on_a_side_stream_are_bit_identical():
-    """fcn_convnet_backward_side: the weight-gradient + reduce roles of every ConvFeatNet backward launch as launches of their own on a
-    second stream (joined inside the call, or by PointNetDet.backward's join), the chain carrying the data-gradient tiles only.  Same
-    kernels, same partials, same fixed-order sums: every gradient of the model bit for bit, eager and inside a captured step."""
-    from frustum_convnet_amd.train_state import FlatTrainState
-    g = load_golden("car_b4_n512")
-    data = synth.to_torch(golden_inputs(g), "cuda")
-    grads, flats = [], []
-    for side in (0, 1, 2):
-        m = _model(g)
-        m.train()
-        s = FlatTrainState(m, lr=1e-4, weight_decay=1e-4)
-        m._cn_pool.wgrad_side = side
-        lo, _ = m(data)
-        m.backward(lo["total_loss"])
-        torch.cuda.synchronize()
-        grads.append(s.grad.clone())
-        s.adam_step()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            for _ in range(2):
-                lo, _ = m(data)
-                m.backward(lo["total_loss"])
-                s.adam_step()
-        for _ in range(3):
-            graph.replay()
-        torch.cuda.synchronize()
-        flats.append(s.flat.clone())
-    assert float(grads[0].abs().max()) > 0
-    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
-    assert torch.equal(flats[0], flats[1]) and torch.equal(flats[0], flats[2])
