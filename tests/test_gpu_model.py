@@ -151,6 +151,15 @@ def test_train_eval_parity(case):
             assert np.abs(got - ref).max() < TOL, nm
 
 
+# exact-fp32 mode, elementwise distance from the fp64 oracle as a fraction of the tensor's max (measured on MI355X, rounds 5-6); the
+# tight bar these three miss is 1.16e-3 / 1.24e-3 / 8.2e-4 (three times the reference's own fp32 error there)
+F32_MODE_KNOWN_LAYER1 = {
+    ("people_b32_n1024", "feat_net.pointnet1.conv1.0.weight"): 4.43e-3,
+    ("people_b32_n1024", "feat_net.pointnet1.conv1.1.weight"): 5.30e-3,
+    ("people_b32_n1024", "feat_net.pointnet1.conv1.1.bias"): 7.07e-3,
+}
+
+
 @pytest.mark.parametrize("case", ["people_b32_n1024", "refine_b32_n512", "sunrgbd_b32_n2048"])
 def test_full_size_gradients_in_the_exact_fp32_mode(case):
     """FCN_PREC_F32 (v_mfma_f32_32x32x2_f32 in every GEMM) at the full batch size: every sampled gradient tensor within 1e-4 of
@@ -188,8 +197,15 @@ def test_full_size_gradients_in_the_exact_fp32_mode(case):
         # this mode 7.3e-4, the split mode 1e-4) -- plain fp32 evaluations of these cancellation-heavy BatchNorm-backward sums scatter
         # at the 1e-3 level, one realisation of the reference's error is not a bound for another fp32 evaluation, and the split mode
         # (fp16 x 3 forward, sixteen exact products per accumulate) is the more accurate path on every one of these tensors.  The
-        # mode is the A/B reference, not the product; its layer-1 tensors are held to 1e-2 here.)
-        bar = 1e-2 if ".conv1." in k else max(1e-4, 3.0 * e32)
+        # mode is the A/B reference, not the product.  VERDICT r5: no blanket bar for the layer-1 tensors -- exactly THREE sampled tensors
+        # of the three full-size fixtures miss max(1e-4, 3 x the reference's fp32 error), all on people's scale 1; they are named here
+        # with their measured distance (identical in every run of rounds 5-6: profiles/r06_final_pytest.txt) and held to 1.25 x it;
+        # every other tensor, every other `.conv1.` included, is held to the tight bar.)
+        bar = max(1e-4, 3.0 * e32)
+        known = F32_MODE_KNOWN_LAYER1.get((case, k[8:]))
+        if known is not None:
+            assert e64 > bar, ("a named exception that now meets the tight bar: drop it from F32_MODE_KNOWN_LAYER1", k, e64, bar)
+            bar = 1.25 * known
         assert e64 <= bar, (k, e64, e32)
     print(case, "exact-fp32 mode, worst sampled gradient vs fp64: %.2f of its bar (%s)" % worst)
 
