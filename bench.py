@@ -483,6 +483,12 @@ def measure(a, cfg_name, prec, steps, warmup, min_time, dev, rank, world, batch=
     late = (os.environ.get("FCN_ADAM_LATE", "1") == "1" and optim and len(state.buckets) == 2 and
             ((world == 1 and not rehearse) or captured_comm))
 
+    if "FCN_BWD_SHARE" in os.environ:           # A/B: "none", or "0:2+1:3" = scale 0's backward on scale 2's stream, scale 1's on scale 3's
+        model.feat_net.bwd_share.clear()
+        for pair in [x for x in os.environ["FCN_BWD_SHARE"].split("+") if x and x != "none"]:
+            sc, host = (int(v) for v in pair.split(":"))
+            model.feat_net.share_backward_stream(sc, host)
+
     def late_bucket0():
         # (on the packing branch's stream) N > 1: the bucket's all-reduce -- started behind the previous step's FCN backward -- first
         state.wait_allreduce(state.buckets[0][0])

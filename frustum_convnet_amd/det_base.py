@@ -157,6 +157,12 @@ class PointNetFeat(nn.Module):
         # front of the FCN, the FCN backward continuing on a second stream, other capture orders -- measured slower on ROCm 7.2 /
         # MI355X in rounds 3-5 (EXPERIMENTS.md) and are not options of this layer any more.
         self.set_wgrad_streams((self.num_scales - 1,))
+        # guest scale -> host scale: the guest's backward is enqueued on the host's stream, behind the host's chain (one parallel
+        # branch less in a captured step's backward: share_backward_stream).  Applied only while `share_active` is set -- by
+        # PointNetDet.forward on its fused-FCN path, where ONE launch sequence produces every scale's gradient.
+        self.bwd_share = dict(self.BWD_SHARE.get(self.num_scales, ()))
+        self.share_active = False
+        self._step_id = 0
 
     def set_wgrad_streams(self, scales, three=False):
         """Which scales (0-based) run their weight-gradient GEMMs on a second stream (fcn_pn_backward2; `three`: conv2's on a third,
@@ -164,6 +170,30 @@ class PointNetFeat(nn.Module):
         for k, net in enumerate(self.nets):
             net._pool.side_wgrad = k in tuple(scales)
             net._pool.side_three = bool(three) and k in tuple(scales)
+
+    # measured on MI355X / ROCm 7.2 (EXPERIMENTS 6.12): 4 scales: 1 -> 2 (car -1.5 %, people -1.0 %, refine -3.3 %, bf16 mode -2.3 %);
+    # 5 scales (SUN-RGBD): 0 -> 2 and 1 -> 3 (-1.9 %)
+    BWD_SHARE = {4: ((1, 2),), 5: ((0, 2), (1, 3))}
+
+    def share_backward_stream(self, scale, host):
+        """The backward of `scale` (0-based) is enqueued on the stream of scale `host`, BEHIND that scale's backward chain, instead of
+        on its own stream: one parallel branch less in a captured step's backward -- ROCm 7.2's graph executor deals the branches onto
+        four internal streams, and the PointNet backward of a 4-scale model has five (the scales + the widest scale's weight-gradient
+        stream): the one left over starts ~200 us late (EXPERIMENTS 4.2 / 6.12).  host = None restores the scale's own stream.
+        Requires scale < host < num_scales - 1: autograd runs the scales' nodes in reverse creation order (forward() creates them
+        0 .. n-1), so the host's node has ALREADY run when the guest's kernels are enqueued on its stream.  Eager launches get event
+        edges both ways (correct for any graph).  Under hipGraph capture ROCm 7.2 cannot take an edge between two forked streams, so
+        stream order is the only edge: valid when every scale's incoming gradient is final before ANY scale's node runs -- the fused
+        ConvFeatNet backward (one call produces them all); PointNetDet sets `share_active` on that path only, and a guest whose host
+        has not been differentiated for the same forward, or is not part of the same capture, stays on its own stream
+        (pointnet_fused._PointNetPooled.backward).  Same kernels on the same data: bit-identical gradients."""
+        ns = self.num_scales
+        if host is None:
+            self.bwd_share.pop(scale, None)
+            return
+        if not (0 <= scale < host < ns - 1):
+            raise ValueError("share_backward_stream: need 0 <= scale < host < %d (got scale %d, host %d)" % (ns - 1, scale, host))
+        self.bwd_share[scale] = host
 
     @property
     def nets(self):
@@ -256,6 +286,8 @@ class PointNetFeat(nn.Module):
         self.done_events = None
         if not (self.concurrent_scales and point_cloud.is_cuda) or os.environ.get("FCN_SERIAL", "0") == "1":
             self.drop_prefetch()
+            for net in nets:
+                net._pool.bwd_stream = net._pool.bwd_host_pool = None
             return tuple(net.forward_pooled(point_cloud, ref, one_hot_vec, nlc) for net, ref in zip(nets, sample_pc))
         # The scales are independent until the FCN: all but the last run on HIP streams forked from the current one and
         # the widest (the last scale, the long pole) on the current stream itself, captured as parallel branches of the step's
@@ -289,6 +321,13 @@ class PointNetFeat(nn.Module):
                 group_compact(prepared, point_cloud)
         fork.record(cur)
         sts = [streams[i] for i in range(ns - 1)] + [cur]
+        self._step_id += 1
+        for k in range(ns):                  # where each scale's backward will be enqueued (read by its autograd node)
+            host = self.bwd_share.get(k) if (self.share_active and self.training) else None
+            pool = nets[k]._pool
+            pool.fwd_step = self._step_id
+            pool.bwd_stream = None if host is None else streams[host]
+            pool.bwd_host_pool = None if host is None else nets[host]._pool
         handles = [None] * ns
         for s in (ns - 1,) + tuple(range(ns - 2, 1, -1)) + (0, 1):           # heaviest first; 4 scales: (3, 2, 0, 1)
             if sts[s] is not cur:
@@ -645,6 +684,7 @@ class PointNetDet(nn.Module):
             dev = point_cloud.device
             pre = convnet_prepack(self._cn_pool, self.conv_net, self.cls_out, self.reg_out, batch_size,
                                   [r.shape[2] for r in refs], one_hot_vec, dev)
+            self.feat_net.share_active = True          # (every scale's gradient comes out of ONE fcn_convnet_backward call)
             feats = self.feat_net(xyz, refs, None, one_hot_vec, nlc=True, join=False)
             if self.split_backward and self.training and torch.is_grad_enabled():
                 # two-phase backward (backward_split): the FCN sees detached leaves, so loss.backward() stops at the pooled
@@ -667,6 +707,7 @@ class PointNetDet(nn.Module):
             cls_raw = lv[:, :, 0:2].permute(0, 2, 1)
             reg_raw = lv[:, :, 2:2 + nreg].permute(0, 2, 1)
         else:
+            self.feat_net.share_active = False
             x = self.conv_net(*self.feat_net(xyz, refs, None, one_hot_vec))
             cls_raw = self.cls_out(x)
             reg_raw = self.reg_out(x)

@@ -124,6 +124,12 @@ class WorkspacePool:
             self.side[key] = (st, evs, arr, st3)
         return self.side[key]
 
+    def bwd_events(self, device):
+        key = "bwdev" + str(device)
+        if key not in self.side:
+            self.side[key] = (torch.cuda.Event(enable_timing=False), torch.cuda.Event(enable_timing=False))
+        return self.side[key]
+
     def acquire(self, *key, device, need_grad):
         k = tuple(key) + (bool(need_grad), str(device))
         lst = self.free.setdefault(k, [])
@@ -232,6 +238,7 @@ class _PointNetPooled(torch.autograd.Function):
         else:
             feat, idx, cnt, ws, desc, keep = _forward_impl(pool, cfgt, pc, ref, one_hot, bufs, plist, need_grad)
         ctx.pool = pool
+        ctx.step = getattr(pool, "fwd_step", None)        # which forward of the step loop this node belongs to (PointNetFeat.forward)
         ctx.live = need_grad
         if need_grad:
             ctx.ws, ctx.desc, ctx.keep = ws, desc, keep
@@ -274,7 +281,36 @@ class _PointNetPooled(torch.autograd.Function):
             three = bool(getattr(ctx.pool, "side_three", False)) and hasattr(L, "fcn_pn_backward3")
         else:
             s2, evarr = None, None
-        with torch.cuda.device(dev):
+        # bwd_stream (PointNetFeat.share_backward_stream): this scale's backward is enqueued on ANOTHER scale's stream, behind that
+        # scale's chain -- one parallel branch less in the captured step's backward.  Eager: the host stream waits for this node's
+        # stream (the gradient's producer) and this node's stream for the host's afterwards -- correct for any graph.  Under hipGraph
+        # capture ROCm 7.2 cannot take an edge between two FORKED streams (the capture dumps core), so none is made: the host stream
+        # must already be ordered behind the producer of `dfeat` -- PointNetFeat guarantees it (see share_backward_stream) -- and the
+        # work is joined with the host scale's own (autograd joins every leaf stream into the caller's at the end of backward()).
+        alt = getattr(ctx.pool, "bwd_stream", None)
+        home = torch.cuda.current_stream(dev)
+        capturing = False
+        hostp = getattr(ctx.pool, "bwd_host_pool", None)
+        if alt is not None and (hostp is None or getattr(hostp, "bwd_step", None) != ctx.step):
+            alt = None                 # the host scale has not been differentiated for this forward (yet): own stream
+        if alt is not None and alt != home:
+            ev_in, ev_out = ctx.pool.bwd_events(dev)
+            # (a real stream has a non-null handle; the host emulation of tests/ runs with inert stream objects and no device)
+            capturing = bool(getattr(alt, "cuda_stream", 0)) and torch.cuda.is_current_stream_capturing()
+            if capturing:
+                cap = _native.capture_id(dev)
+                with torch.cuda.stream(alt):
+                    same = _native.capture_id(dev) == cap
+                if not same:           # the host stream carries no work of THIS capture (its scale was differentiated in another
+                    alt = None         # graph, or not at all): this scale stays on its own stream
+            else:
+                ev_in.record(home)
+                alt.wait_event(ev_in)
+            if alt is not None:
+                dfeat.record_stream(alt)
+        else:
+            alt = None
+        with torch.cuda.device(dev), torch.cuda.stream(alt if alt is not None else home):
             if three:
                 _native.check(L.fcn_pn_backward3(ctypes.byref(desc), ctypes.byref(params), dfeat.data_ptr(),
                                                  ctypes.byref(ws.c), arr(dW), arr(dg), arr(db),
@@ -285,6 +321,11 @@ class _PointNetPooled(torch.autograd.Function):
                                                  ctypes.byref(ws.c), arr(dW), arr(dg), arr(db),
                                                  _native.current_stream(dev), s2, evarr),
                               "fcn_pn_backward2")
+            if alt is not None and not capturing:
+                ev_out.record(alt)
+        if alt is not None and not capturing:
+            home.wait_event(ev_out)
+        ctx.pool.bwd_step = ctx.step       # (this scale's backward of that forward is enqueued: it may host another scale's now)
         ctx.pool.release(ws)
         ctx.ws = None
         ctx.live = False

@@ -390,3 +390,44 @@ def test_scales_stepped_one_by_one_equal_the_bucket_step():
     torch.cuda.synchronize()
     assert int(states[1]._step_slots.min()) == int(states[1]._step_slots.max()) == 3
     assert torch.equal(states[0].flat, states[1].flat) and torch.equal(states[0].exp_avg_sq, states[1].exp_avg_sq)
+
+
+def test_shared_backward_stream_gives_bit_identical_steps():
+    """PointNetFeat.share_backward_stream(scale, host): a narrow scale's backward enqueued on another scale's stream, behind that scale's
+    chain (one parallel branch less for the graph executor's four streams).  Eager (event edges both ways) and inside a captured
+    two-step graph (stream order only): gradients after one backward and parameters after several replayed steps equal the plain
+    model's bit for bit; a host that is not ahead of the guest in autograd's order is refused."""
+    from frustum_convnet_amd.train_state import FlatTrainState
+    g = load_golden("car_b4_n512")
+    data = synth.to_torch(golden_inputs(g), "cuda")
+    grads, flats = [], []
+    for share in (None, (0, 2), (1, 2)):
+        m = _model(g)
+        m.train()
+        s = FlatTrainState(m, lr=1e-4, weight_decay=1e-4)
+        assert m.feat_net.bwd_share == {1: 2}                     # the 4-scale default
+        m.feat_net.bwd_share.clear()
+        if share is not None:
+            m.feat_net.share_backward_stream(share[0], share[1])
+        lo, _ = m(data)
+        m.backward(lo["total_loss"])
+        torch.cuda.synchronize()
+        grads.append(s.grad.clone())
+        s.adam_step()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(2):
+                lo, _ = m(data)
+                m.backward(lo["total_loss"])
+                s.adam_step()
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        flats.append(s.flat.clone())
+    assert float(grads[0].abs().max()) > 0
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+    assert torch.equal(flats[0], flats[1]) and torch.equal(flats[0], flats[2])
+    with pytest.raises(ValueError):
+        m.feat_net.share_backward_stream(2, 1)          # the host's node would run AFTER the guest's
+    with pytest.raises(ValueError):
+        m.feat_net.share_backward_stream(0, 3)          # the widest scale runs on the caller's stream
